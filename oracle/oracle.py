@@ -1,0 +1,262 @@
+"""ctypes front-end of the CPU oracle — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module (see ``oracle/ss_oracle.h``).  It restates
+``/root/reference/src/solvers/homotopy-cpu.cpp:186-275`` on the CPU and is the
+checker the HIP path is compared against; it is never the thing shipped or
+measured as the product.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libss_oracle.so")
+
+SPARSE_NOTRANS = 1
+STRICT_SIGN = 2
+
+
+class _Report(ctypes.Structure):
+    _fields_ = [("iter", ctypes.c_uint32), ("solution_error", ctypes.c_double)]
+
+
+class _Trace(ctypes.Structure):
+    _fields_ = [
+        ("capacity", ctypes.c_uint32),
+        ("count", ctypes.c_uint32),
+        ("idx", ctypes.POINTER(ctypes.c_uint32)),
+        ("added", ctypes.POINTER(ctypes.c_uint8)),
+        ("gamma", ctypes.POINTER(ctypes.c_double)),
+        ("c_inf", ctypes.POINTER(ctypes.c_double)),
+    ]
+
+
+def build(force=False):
+    """Compile libss_oracle.so with the committed Makefile (gcc, a few seconds)."""
+    srcs = [os.path.join(_HERE, f) for f in ("ss_oracle.c", "ss_oracle_impl.inc", "ss_oracle.h")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "libss_oracle.so"], check=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, sz, pd = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_ssize_t
+        for suf, ct in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
+            f = getattr(L, "ss_oracle_homotopy_" + suf)
+            f.restype = ctypes.c_int
+            f.argtypes = [vp, sz, sz, pd, pd, vp, pd, ct, ctypes.c_uint32, vp, pd,
+                          ctypes.POINTER(_Report), ctypes.POINTER(_Trace), ctypes.c_uint]
+            for name in ("ss_oracle_gemv_t_", "ss_oracle_gemv_n_"):
+                g = getattr(L, name + suf)
+                g.restype = None
+                g.argtypes = [vp, sz, sz, pd, pd, vp, vp]
+            g = getattr(L, "ss_oracle_square_permute_" + suf)
+            g.restype = None
+            g.argtypes = [vp, sz, sz, sz]
+        L.ss_oracle_erase_last_rowcol_f32.restype = None
+        L.ss_oracle_erase_last_rowcol_f32.argtypes = [vp, sz, sz]
+        L.ss_oracle_insert_last_rowcol_f32.restype = None
+        L.ss_oracle_insert_last_rowcol_f32.argtypes = [vp, sz, sz, ctypes.c_float]
+        L.ss_oracle_inverse_create.restype = vp
+        L.ss_oracle_inverse_create.argtypes = [sz, ctypes.c_int]
+        L.ss_oracle_inverse_destroy.argtypes = [vp]
+        L.ss_oracle_inverse_insert.argtypes = [vp, sz, vp]
+        L.ss_oracle_inverse_remove.argtypes = [vp, sz]
+        L.ss_oracle_inverse_size.restype = sz
+        L.ss_oracle_inverse_size.argtypes = [vp]
+        L.ss_oracle_inverse_get.argtypes = [vp, vp]
+        L.ss_oracle_rank_index_create.restype = vp
+        L.ss_oracle_rank_index_destroy.argtypes = [vp]
+        L.ss_oracle_rank_index_insert.argtypes = [vp, ctypes.c_uint32]
+        L.ss_oracle_rank_index_erase.argtypes = [vp, ctypes.c_uint32]
+        L.ss_oracle_rank_index_rank_of.argtypes = [vp, ctypes.c_uint32]
+        L.ss_oracle_rank_index_rank_at.restype = ctypes.c_uint32
+        L.ss_oracle_rank_index_rank_at.argtypes = [vp, sz]
+        L.ss_oracle_rank_index_size.restype = sz
+        L.ss_oracle_rank_index_size.argtypes = [vp]
+        L.ss_oracle_num_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _suffix(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "f32"
+    if dtype == np.float64:
+        return "f64"
+    raise TypeError("oracle supports float32/float64, got %s" % dtype)
+
+
+def num_threads():
+    return lib().ss_oracle_num_threads()
+
+
+def homotopy(A, y, tolerance, max_iterations, flags=SPARSE_NOTRANS, trace=False):
+    """run_solver<T> (homotopy-cpu.cpp:186-275) on the CPU.
+
+    A may have any 2-D strides (row-major, padded row-major, column-major views).
+    Returns (x, iter, solution_error[, trace dict]).
+    """
+    A = np.asarray(A)
+    suf = _suffix(A.dtype)
+    y = np.asarray(y)
+    if y.dtype != A.dtype:
+        raise TypeError("dtype of y must match A")
+    if A.ndim != 2 or y.ndim != 1:
+        raise ValueError("A must be 2-D and y 1-D")
+    m, n = A.shape
+    if y.shape[0] != m:
+        raise ValueError("len(y) != rows of A")
+    item = A.dtype.itemsize
+    x = np.zeros(n, dtype=A.dtype)
+    rep = _Report()
+    tr = _Trace()
+    keep = None
+    if trace:
+        cap = int(max_iterations) + 1
+        keep = (np.zeros(cap, np.uint32), np.zeros(cap, np.uint8),
+                np.zeros(cap, np.float64), np.zeros(cap, np.float64))
+        tr.capacity = cap
+        tr.idx = keep[0].ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        tr.added = keep[1].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+        tr.gamma = keep[2].ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        tr.c_inf = keep[3].ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    fn = getattr(lib(), "ss_oracle_homotopy_" + suf)
+    rc = fn(A.ctypes.data, m, n, A.strides[0] // item, A.strides[1] // item,
+            y.ctypes.data, y.strides[0] // item, tolerance, int(max_iterations),
+            x.ctypes.data, 1, ctypes.byref(rep), ctypes.byref(tr) if trace else None,
+            int(flags))
+    if rc != 0:
+        raise RuntimeError("oracle homotopy failed with code %d" % rc)
+    if trace:
+        k = tr.count
+        return x, rep.iter, rep.solution_error, {
+            "idx": keep[0][:k].copy(), "added": keep[1][:k].copy(),
+            "gamma": keep[2][:k].copy(), "c_inf": keep[3][:k].copy()}
+    return x, rep.iter, rep.solution_error
+
+
+def gemv_t(A, v):
+    """c = A^T v with the oracle's summation order."""
+    A = np.asarray(A)
+    suf = _suffix(A.dtype)
+    v = np.ascontiguousarray(v, dtype=A.dtype)
+    m, n = A.shape
+    item = A.dtype.itemsize
+    c = np.zeros(n, dtype=A.dtype)
+    getattr(lib(), "ss_oracle_gemv_t_" + suf)(
+        A.ctypes.data, m, n, A.strides[0] // item, A.strides[1] // item, v.ctypes.data, c.ctypes.data)
+    return c
+
+
+def gemv_n(A, x):
+    """y = A x with the oracle's summation order (reconstruct_signal, lib.cpp:78-104)."""
+    A = np.asarray(A)
+    suf = _suffix(A.dtype)
+    x = np.ascontiguousarray(x, dtype=A.dtype)
+    m, n = A.shape
+    item = A.dtype.itemsize
+    y = np.zeros(m, dtype=A.dtype)
+    getattr(lib(), "ss_oracle_gemv_n_" + suf)(
+        A.ctypes.data, m, n, A.strides[0] // item, A.strides[1] // item, x.ctypes.data, y.ctypes.data)
+    return y
+
+
+def square_permute(A, src, dest):
+    A = np.ascontiguousarray(A)
+    suf = _suffix(A.dtype)
+    out = A.copy()
+    getattr(lib(), "ss_oracle_square_permute_" + suf)(out.ctypes.data, A.shape[0], src, dest)
+    return out
+
+
+def erase_last_rowcol(A):
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    M, N = A.shape
+    buf = A.copy().ravel()
+    lib().ss_oracle_erase_last_rowcol_f32(buf.ctypes.data, M, N)
+    return buf[:(M - 1) * (N - 1)].reshape(M - 1, N - 1).copy()
+
+
+def insert_last_rowcol(A, val=0.0):
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    M, N = A.shape
+    buf = np.empty((M + 1) * (N + 1), dtype=np.float32)
+    buf[:M * N] = A.ravel()
+    lib().ss_oracle_insert_last_rowcol_f32(buf.ctypes.data, M, N, val)
+    return buf.reshape(M + 1, N + 1)
+
+
+class OnlineColumnInverse:
+    """online_column_inverse<T> (online_inverse.h:35-63)."""
+
+    def __init__(self, m, dtype=np.float32):
+        self.dtype = np.dtype(dtype)
+        self.m = m
+        self._h = lib().ss_oracle_inverse_create(m, 1 if self.dtype == np.float64 else 0)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ss_oracle_inverse_destroy(self._h)
+            self._h = None
+
+    def insert(self, rank, col):
+        col = np.ascontiguousarray(col, dtype=self.dtype)
+        assert col.shape == (self.m,)
+        if lib().ss_oracle_inverse_insert(self._h, rank, col.ctypes.data) != 0:
+            raise RuntimeError("insert failed")
+
+    def remove(self, rank):
+        if lib().ss_oracle_inverse_remove(self._h, rank) != 0:
+            raise RuntimeError("remove failed")
+
+    def N(self):
+        return lib().ss_oracle_inverse_size(self._h)
+
+    def inverse(self):
+        k = self.N()
+        out = np.zeros((k, k), dtype=self.dtype)
+        if k:
+            lib().ss_oracle_inverse_get(self._h, out.ctypes.data)
+        return out
+
+
+class RankIndex:
+    """rank_index<uint32_t> (rank_index.h:26-98)."""
+
+    def __init__(self):
+        self._h = lib().ss_oracle_rank_index_create()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ss_oracle_rank_index_destroy(self._h)
+            self._h = None
+
+    def insert(self, item):
+        return lib().ss_oracle_rank_index_insert(self._h, item)
+
+    def erase(self, item):
+        return bool(lib().ss_oracle_rank_index_erase(self._h, item))
+
+    def rank_of(self, item):
+        return lib().ss_oracle_rank_index_rank_of(self._h, item)
+
+    def rank_at(self, rank):
+        return lib().ss_oracle_rank_index_rank_at(self._h, rank)
+
+    def size(self):
+        return lib().ss_oracle_rank_index_size(self._h)

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "sparse-solvers_amd", "python")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    path = os.path.join(ROOT, "tests", "golden", "homotopy_golden.npz")
+    g = np.load(path)
+    cases = {}
+    for key in g.files:
+        name, field = key.split("/")
+        cases.setdefault(name, {})[field] = g[key]
+    return cases
+
+
+def make_gaussian_problem(seed, m, n, k, dtype, scale=None):
+    """SURVEY §8d recipe: A ~ N(0,1)/sqrt(m), k positive coefficients 1+|N(0,1)|,
+    y = A x0 computed in float64 then cast."""
+    rng = np.random.default_rng(seed)
+    A = (rng.standard_normal((m, n), dtype=np.float32 if np.dtype(dtype) == np.float32 else np.float64)
+         / np.sqrt(m)).astype(dtype)
+    x0 = np.zeros(n)
+    sup = np.sort(rng.choice(n, size=k, replace=False))
+    x0[sup] = 1.0 + np.abs(rng.standard_normal(k))
+    y = (A.astype(np.float64) @ x0).astype(dtype)
+    return A, y, x0, sup
