@@ -1,0 +1,157 @@
+/*
+ * ss_hip.h — C-ABI of the MI355X (gfx950) Homotopy l1 hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types,
+ * no exceptions.  Every entry point returns 0 on success or a non-zero
+ * ss_hip_status and writes a NUL-terminated message into `err` (if non-NULL).
+ * The C++14 host layer (include/ss/*.h) and the pybind11 module call nothing
+ * else; a maintainer of the reference would bind exactly these symbols from a
+ * new `op<compute_mode::HIP, T>` specialisation.
+ *
+ * Citations are file:line under /root/reference.
+ *
+ * Data pointers (A, y, x, Y, X, r, c) may be HOST or DEVICE pointers; the library
+ * asks the HIP runtime which.  The sensing matrix is copied to the device (and
+ * re-laid-out column-contiguous) once, at create time — the natural upload point
+ * because ss::solver captures A at construction (include/ss/ss.h:98-105).  Later
+ * mutation of the caller's A is not observed.
+ */
+#ifndef SS_HIP_H
+#define SS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_HIP_ABI_VERSION 1
+
+typedef struct ss_hip_ctx ss_hip_ctx;
+
+typedef enum ss_hip_status {
+    SS_HIP_OK            = 0,
+    SS_HIP_EINVAL        = 1,  /* precondition violated (homotopy-cpu.cpp:193-199 asserts) */
+    SS_HIP_ENODEVICE     = 2,  /* no usable HIP device                                     */
+    SS_HIP_ERUNTIME      = 3,  /* a HIP runtime call failed (message carries hipGetErrorString) */
+    SS_HIP_ENOMEM        = 4,
+    SS_HIP_ECAPACITY     = 5,  /* active set outgrew the workspace capacity                */
+    SS_HIP_ETYPE         = 6   /* f32 entry point called on an f64 context or vice versa   */
+} ss_hip_status;
+
+/* Number of HIP devices visible to this process (0 if none / runtime unusable). */
+int ss_hip_device_count(void);
+
+/* "major.minor.patch" of this library; ABI version above. */
+const char* ss_hip_version(void);
+
+/*
+ * Replaces the state construction of ss::solver<T, homotopy_policy>
+ * (include/ss/ss.h:98-105, include/ss/policies.h:42): captures the m x n sensing
+ * matrix, element (i,j) at A[i*stride_row + j*stride_col] (strides in ELEMENTS;
+ * row-major, padded row-major and column-major views all accepted, the layout
+ * rules of src/linalg/blas_wrapper.h:63-94 generalised).
+ * Returns NULL on failure (message in err).
+ */
+ss_hip_ctx* ss_hip_homotopy_create_f32(const float* A, size_t m, size_t n,
+                                       ptrdiff_t stride_row, ptrdiff_t stride_col,
+                                       int device, char* err, size_t errlen);
+ss_hip_ctx* ss_hip_homotopy_create_f64(const double* A, size_t m, size_t n,
+                                       ptrdiff_t stride_row, ptrdiff_t stride_col,
+                                       int device, char* err, size_t errlen);
+
+void ss_hip_homotopy_destroy(ss_hip_ctx* ctx);
+
+/*
+ * Replaces solve_homotopy::op<compute_mode, T> (src/solvers/homotopy.h:27-38,
+ * run_solver src/solvers/homotopy-cpu.cpp:186-275):
+ *   min ||x||_1  s.t.  A x = y
+ *   y   : m elements, increment incy (elements)
+ *   x   : n elements, increment incx; fully overwritten
+ *   tol : eps(T) <= tol < 1;   max_iter > 0
+ *   iter_out / err_out : ss::homotopy_report{iter, solution_error} (policies.h:25-32)
+ */
+int ss_hip_homotopy_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_t incy,
+                              float tol, uint32_t max_iter,
+                              float* x, ptrdiff_t incx,
+                              uint32_t* iter_out, double* err_out,
+                              char* err, size_t errlen);
+int ss_hip_homotopy_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy,
+                              double tol, uint32_t max_iter,
+                              double* x, ptrdiff_t incx,
+                              uint32_t* iter_out, double* err_out,
+                              char* err, size_t errlen);
+
+/*
+ * Batch of B signals sharing the context's sensing matrix: signal b is
+ * Y[b*y_stride + i*incy], its solution X[b*x_stride + j*incx].
+ * iter_out[B], err_out[B] receive the per-signal reports.
+ */
+int ss_hip_homotopy_solve_batch_f32(ss_hip_ctx* ctx, const float* Y, size_t B,
+                                    ptrdiff_t y_stride, ptrdiff_t incy,
+                                    float tol, uint32_t max_iter,
+                                    float* X, ptrdiff_t x_stride, ptrdiff_t incx,
+                                    uint32_t* iter_out, double* err_out,
+                                    char* err, size_t errlen);
+int ss_hip_homotopy_solve_batch_f64(ss_hip_ctx* ctx, const double* Y, size_t B,
+                                    ptrdiff_t y_stride, ptrdiff_t incy,
+                                    double tol, uint32_t max_iter,
+                                    double* X, ptrdiff_t x_stride, ptrdiff_t incx,
+                                    uint32_t* iter_out, double* err_out,
+                                    char* err, size_t errlen);
+
+/*
+ * The correlation sweep on its own, c = A^T r — the blas::xgemv(CblasTrans, ...)
+ * of residual_vector (homotopy-cpu.cpp:97).  Runs `repeats` launches (>= 1) and
+ * reports the mean kernel time in milliseconds measured with HIP events on the
+ * context's stream (ms_out may be NULL).  r: m elements, c: n elements.
+ */
+int ss_hip_gemv_t_f32(ss_hip_ctx* ctx, const float* r, float* c, int repeats, float* ms_out,
+                      char* err, size_t errlen);
+int ss_hip_gemv_t_f64(ss_hip_ctx* ctx, const double* r, double* c, int repeats, float* ms_out,
+                      char* err, size_t errlen);
+
+/*
+ * y = A x on the device copy — ss::reconstruct_signal (src/lib.cpp:78-104).
+ * x: n elements, y: m elements.
+ */
+int ss_hip_reconstruct_f32(ss_hip_ctx* ctx, const float* x, float* y, char* err, size_t errlen);
+int ss_hip_reconstruct_f64(ss_hip_ctx* ctx, const double* x, double* y, char* err, size_t errlen);
+
+/* ---- measurement ---------------------------------------------------------- */
+
+typedef struct ss_hip_stats {
+    uint64_t solves;               /* solve calls since the last reset                         */
+    uint64_t iterations;           /* homotopy iterations over those solves                    */
+    uint64_t sweep_launches;       /* fused 2-RHS sweep launches [c,q] = A^T [r,p] (timed ones) */
+    double   sweep_ms;             /* sum of their HIP-event durations (profiling on)          */
+    uint64_t sweep_bytes;          /* algorithmic bytes of ONE fused sweep: m*n*s + 2*m*s + 2*n*s */
+    uint64_t sweep1_launches;      /* 1-RHS sweep launches (initial c = A^T y)                 */
+    double   sweep1_ms;
+    uint64_t sweep1_bytes;         /* m*n*s + m*s + n*s                                         */
+    double   solve_ms;             /* HIP-event time of whole solves (upload of y .. x ready)  */
+} ss_hip_stats;
+
+/* profiling != 0: bracket every sweep launch with HIP events on the context's stream. */
+int ss_hip_set_profiling(ss_hip_ctx* ctx, int profiling);
+int ss_hip_get_stats(ss_hip_ctx* ctx, ss_hip_stats* out);
+int ss_hip_reset_stats(ss_hip_ctx* ctx);
+
+/*
+ * Tuning knobs (integers), for benchmarks only; unknown keys return SS_HIP_EINVAL.
+ *   "sweep_variant"  kernel variant of the sweep (see csrc/sweep.hip)
+ *   "lookahead"      iterations the host enqueues ahead of the device's done flag
+ *   "strict_sign"    1 = seed the first direction with sign(c[idx]) instead of the
+ *                    reference's sign(|c[idx]|) (homotopy-cpu.cpp:223-227); default 0
+ */
+int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value);
+int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value);
+
+/* Shape / placement queries. */
+int ss_hip_ctx_info(const ss_hip_ctx* ctx, size_t* m, size_t* n, int* is_f64, int* device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SS_HIP_H */

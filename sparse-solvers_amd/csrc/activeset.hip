@@ -1,0 +1,610 @@
+// activeset.hip — everything of a Homotopy iteration that is not the sweep:
+// the step-length scan, the support toggle, the online (A_S^T A_S)^-1 update, the new
+// direction and the two m-vectors r = y - A x, p = A d that feed the next sweep.
+//
+// Reference (paths under /root/reference):
+//   find_max_gamma scan        src/solvers/homotopy-cpu.cpp:122-163   -> k_scan + k_select
+//   inverse_add_or_remove      src/solvers/homotopy-cpu.cpp:166-183   -> k_select (rank_index part)
+//   online_column_inverse      src/linalg/online_inverse.h:183-293    -> k_gram + k_update
+//   direction update           src/solvers/homotopy-cpu.cpp:257-267   -> k_update
+//   x += gamma * d             src/solvers/homotopy-cpu.cpp:252       -> k_select
+//   residual_vector (A x part) src/solvers/homotopy-cpu.cpp:94-96     -> k_rp
+//   p = A d                    src/solvers/homotopy-cpu.cpp:114-116   -> k_rp
+//   loop control / inf_norm    src/solvers/homotopy-cpu.cpp:32-37,235-274 -> k_select
+//
+// All of it is O(n + K*m + K^2) per iteration against the sweep's O(m*n); these kernels
+// are latency-, not bandwidth-bound, and are kept simple.  The (A_S^T A_S)^-1 matrix is
+// kept as an explicit inverse updated by bordering/deflation exactly like the reference
+// (NOT a Cholesky factor): every entry of the new inverse is an independent expression
+// of the old one, which is what a 1024-thread workgroup wants, whereas a Cholesky
+// append/downdate is a chain of K dependent steps.  The inverse is rebuilt out of place
+// (ping-pong buffers) directly in sorted-support order, so the reference's rotate /
+// memmove churn (square_permute, insert_last_rowcol) disappears.
+//
+// This file is compiled with -ffp-contract=off: products and sums round separately,
+// like the reference's scalar code.
+#include "ss_hip_internal.h"
+
+#include <cfloat>
+
+namespace sship {
+
+template <typename T> struct Lim;
+template <> struct Lim<float>  { static constexpr float  max() { return FLT_MAX; } };
+template <> struct Lim<double> { static constexpr double max() { return DBL_MAX; } };
+
+typedef float  v4f __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int kSmallThreads = 256;
+constexpr int kUpdThreads = 1024;
+
+// ---- block reductions --------------------------------------------------------------
+
+// "better" for the arg-max of |c| (ixamax): larger value, ties -> smaller index
+template <typename T>
+__device__ __forceinline__ bool better_max(T v, uint32_t i, T bv, uint32_t bi)
+{
+    return v > bv || (v == bv && i < bi);
+}
+// "better" for the step length: smaller value, ties -> smaller (left-most) index
+template <typename T>
+__device__ __forceinline__ bool better_min(T v, uint32_t i, T bv, uint32_t bi)
+{
+    return v < bv || (v == bv && i < bi);
+}
+
+template <typename T, bool MAX>
+__device__ __forceinline__ void wave_reduce_pair(T& v, uint32_t& i)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const T ov = __shfl_xor(v, off, 64);
+        const uint32_t oi = __shfl_xor(i, off, 64);
+        const bool take = MAX ? better_max(ov, oi, v, i) : better_min(ov, oi, v, i);
+        if (take) { v = ov; i = oi; }
+    }
+}
+
+// all threads of the block receive the reduced pair; sv/si: LDS scratch of >= 16 entries
+template <typename T, bool MAX>
+__device__ __forceinline__ void block_reduce_pair(T& v, uint32_t& i, T* sv, uint32_t* si)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    wave_reduce_pair<T, MAX>(v, i);
+    __syncthreads();
+    if (lane == 0) { sv[wave] = v; si[wave] = i; }
+    __syncthreads();
+    T bv = sv[0];
+    uint32_t bi = si[0];
+    for (int w = 1; w < nw; ++w) {
+        const T ov = sv[w];
+        const uint32_t oi = si[w];
+        const bool take = MAX ? better_max(ov, oi, bv, bi) : better_min(ov, oi, bv, bi);
+        if (take) { bv = ov; bi = oi; }
+    }
+    v = bv;
+    i = bi;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* sv)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sv[wave] = v;
+    __syncthreads();
+    T s = sv[0];
+    for (int w = 1; w < nw; ++w) s += sv[w];
+    return s;
+}
+
+// max |c| and its first index from the per-workgroup partials of the sweep
+template <typename T>
+__device__ __forceinline__ void reduce_sweep_partials(const T* pv, const uint32_t* pi, uint32_t nb,
+                                                      T& val, uint32_t& idx, T* sv, uint32_t* si)
+{
+    T v = T(-1);
+    uint32_t ix = 0xffffffffu;
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+        const T ov = pv[b];
+        const uint32_t oi = pi[b];
+        if (better_max(ov, oi, v, ix)) { v = ov; ix = oi; }
+    }
+    block_reduce_pair<T, true>(v, ix, sv, si);
+    if (ix == 0xffffffffu) ix = 0;   // all-NaN correlations: keep every later index in range
+    val = v;
+    idx = ix;
+}
+
+template <typename T>
+__device__ __forceinline__ T sign_tol(T v, T tol)   // homotopy-cpu.cpp:59-67
+{
+    if (v > tol) return T(1);
+    if (v < -tol) return T(-1);
+    return T(0);
+}
+
+// dot product of two contiguous device rows of length len (multiple of 256) by one block
+template <typename T>
+__device__ __forceinline__ T block_dot(const T* a, const T* b, uint32_t len, T* sv)
+{
+    T acc = T(0);
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) acc += a[i] * b[i];
+    return block_sum(acc, sv);
+}
+
+// ---- k_init: first pick, homotopy-cpu.cpp:217-229 ------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kUpdThreads)
+void k_init(const T* __restrict__ At, uint32_t ldm, const T* __restrict__ c,
+            const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
+            T* __restrict__ d, uint8_t* __restrict__ insup, uint32_t* __restrict__ gam,
+            uint32_t* __restrict__ touched, T* __restrict__ inv0, T tol, int strict_sign,
+            DevState* st)
+{
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    T c_inf;
+    uint32_t idx;
+    reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, idx, sv, si);
+    const T* col = At + (size_t)idx * ldm;
+    const T dot = block_dot(col, col, ldm, sv);
+    if (threadIdx.x == 0) {
+        // online_inverse.h:193-201: inv = [1 / ||col||^2] through xnrm2
+        const T nrm = sqrt(dot);
+        const T inv00 = T(1) / (nrm * nrm);
+        // first-step quirk: the sign is taken of c_inf = |c[idx]| >= 0
+        const T seed = strict_sign ? c[idx] : c_inf;
+        d[idx] = sign_tol(seed, tol) * inv00;
+        insup[idx] = 1;
+        gam[0] = idx;
+        touched[0] = idx;
+        inv0[0] = inv00;
+        st->done = 0;
+        st->status = 0;
+        st->iter = 0;
+        st->K = 1;
+        st->ntouched = 1;
+        st->idx = idx;
+        st->rank = 0;
+        st->added = 1;
+        st->cur = 0;
+        st->done_round = 0;
+        st->c_inf = (double)c_inf;
+        st->gamma = 0.0;
+        st->dot = (double)dot;
+    }
+}
+
+// ---- k_rp: r = y - A x ; p = A d over the touched columns -----------------------------
+template <typename T>
+__global__ __launch_bounds__(128)
+void k_rp(const T* __restrict__ At, uint32_t ldm, const T* __restrict__ y,
+          const T* __restrict__ x, const T* __restrict__ d,
+          const uint32_t* __restrict__ touched2 /* [2][kcap] */, uint32_t kcap,
+          T* __restrict__ rhs, const DevState* st)
+{
+    if (st->done) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ldm) return;
+    const uint32_t nt = st->ntouched;
+    const uint32_t* touched = touched2 + (size_t)st->cur * kcap;
+    T accr = T(0), accp = T(0);
+    uint32_t j = 0;
+    for (; j + 4 <= nt; j += 4) {
+        const uint32_t c0 = touched[j], c1 = touched[j + 1], c2 = touched[j + 2], c3 = touched[j + 3];
+        const T a0 = At[(size_t)c0 * ldm + i], a1 = At[(size_t)c1 * ldm + i];
+        const T a2 = At[(size_t)c2 * ldm + i], a3 = At[(size_t)c3 * ldm + i];
+        accr += x[c0] * a0; accp += d[c0] * a0;
+        accr += x[c1] * a1; accp += d[c1] * a1;
+        accr += x[c2] * a2; accp += d[c2] * a2;
+        accr += x[c3] * a3; accp += d[c3] * a3;
+    }
+    for (; j < nt; ++j) {
+        const uint32_t c0 = touched[j];
+        const T a0 = At[(size_t)c0 * ldm + i];
+        accr += x[c0] * a0;
+        accp += d[c0] * a0;
+    }
+    rhs[i] = y[i] - accr;
+    rhs[(size_t)ldm + i] = accp;
+}
+
+// ---- k_scan: candidates of find_max_gamma, homotopy-cpu.cpp:122-163 -------------------
+constexpr int kScanPerThread = 4;
+
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_scan(const T* __restrict__ c, const T* __restrict__ q, const T* __restrict__ x,
+            const T* __restrict__ d, const uint8_t* __restrict__ insup, uint32_t n,
+            const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
+            T* __restrict__ pmin_val, uint32_t* __restrict__ pmin_idx, const DevState* st)
+{
+    if (st->done) return;
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    T c_inf;
+    uint32_t dummy;
+    reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, dummy, sv, si);
+
+    T best = Lim<T>::max();
+    uint32_t best_i = 0xffffffffu;
+    for (uint32_t base = blockIdx.x * (kSmallThreads * kScanPerThread); base < n;
+         base += gridDim.x * (kSmallThreads * kScanPerThread))
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const uint32_t i = base + k * kSmallThreads + threadIdx.x;
+        if (i < n) {
+            T m = Lim<T>::max();
+            if (insup[i]) {
+                const T t = -x[i] / d[i];
+                if (t > T(0) && t < m) m = t;
+            } else {
+                const T qi = q[i], ci = c[i];
+                const T dl = T(1) - qi, dr = T(1) + qi;
+                if (dl != T(0)) {
+                    const T t = (c_inf - ci) / dl;
+                    if (t > T(0) && t < m) m = t;
+                }
+                if (dr != T(0)) {
+                    const T t = (c_inf + ci) / dr;
+                    if (t > T(0) && t < m) m = t;
+                }
+            }
+            if (better_min(m, i, best, best_i)) { best = m; best_i = i; }
+        }
+    }
+    block_reduce_pair<T, false>(best, best_i, sv, si);
+    if (threadIdx.x == 0) {
+        pmin_val[blockIdx.x] = best;
+        pmin_idx[blockIdx.x] = best_i;
+    }
+}
+
+// ---- k_select: loop control, pick, support toggle, x update ---------------------------
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_select(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
+              const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
+              const T* __restrict__ pmin_val, const uint32_t* __restrict__ pmin_idx, uint32_t ns,
+              T* __restrict__ x, const T* __restrict__ d, uint8_t* __restrict__ insup,
+              uint32_t* __restrict__ gam2, uint32_t* __restrict__ touched2, uint32_t kcap,
+              DevState* st)
+{
+    if (st->done) return;
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_cnt[2];
+
+    // inf_norm of the correlations the sweep just produced (homotopy-cpu.cpp:270 / :219)
+    T c_inf;
+    uint32_t imax;
+    reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, imax, sv, si);
+
+    // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
+    // round t starts iteration t, so the while-test of iteration t-1 is evaluated here.
+    if ((round > 1 && !(c_inf > tol)) || round > max_iter) {
+        if (threadIdx.x == 0) {
+            st->c_inf = (double)c_inf;
+            st->iter = round - 1;
+            st->done_round = round;
+            st->done = 1;
+        }
+        return;
+    }
+
+    // final (gamma, idx) of find_max_gamma: smallest positive candidate, left-most index;
+    // (T_MAX, 0) when there is no candidate (homotopy-cpu.cpp:123-124)
+    T g = Lim<T>::max();
+    uint32_t idx = 0xffffffffu;
+    for (uint32_t b = threadIdx.x; b < ns; b += blockDim.x) {
+        const T ov = pmin_val[b];
+        const uint32_t oi = pmin_idx[b];
+        if (better_min(ov, oi, g, idx)) { g = ov; idx = oi; }
+    }
+    block_reduce_pair<T, false>(g, idx, sv, si);
+    if (!(g < Lim<T>::max())) idx = 0;
+
+    const uint32_t cur = st->cur;
+    const uint32_t K = st->K;
+    const uint32_t nt = st->ntouched;
+    const uint32_t* gam = gam2 + (size_t)cur * kcap;
+    uint32_t* gam_new = gam2 + (size_t)(cur ^ 1u) * kcap;
+    const uint32_t* tch = touched2 + (size_t)cur * kcap;
+    uint32_t* tch_new = touched2 + (size_t)(cur ^ 1u) * kcap;
+    const bool added = insup[idx] == 0;
+
+    // rank of idx in the sorted support / touched list (rank_index.h:65-83)
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t lr = 0, lt = 0;
+    for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) lr += (gam[j] < idx) ? 1u : 0u;
+    for (uint32_t j = threadIdx.x; j < nt; j += blockDim.x) lt += (tch[j] < idx) ? 1u : 0u;
+    if (lr) atomicAdd(&s_cnt[0], lr);
+    if (lt) atomicAdd(&s_cnt[1], lt);
+    __syncthreads();
+    const uint32_t rank = s_cnt[0];
+    const uint32_t trank = s_cnt[1];
+    const uint32_t K_new = added ? K + 1 : K - 1;
+
+    if (K_new == 0) {
+        // homotopy-cpu.cpp:248-249: support became empty -> break before x is updated;
+        // the report carries the c_inf of the previous iteration's end (== this c_inf)
+        if (threadIdx.x == 0) {
+            insup[idx] = 0;
+            st->K = 0;
+            st->idx = idx;
+            st->rank = rank;
+            st->added = 0;
+            st->gamma = (double)g;
+            st->c_inf = (double)c_inf;
+            st->iter = round;
+            st->done_round = round;
+            st->done = 1;
+        }
+        return;
+    }
+    if (K_new > kcap) {
+        if (threadIdx.x == 0) {
+            st->status = SS_HIP_ECAPACITY;
+            st->c_inf = (double)c_inf;
+            st->iter = round - 1;
+            st->done_round = round;
+            st->done = 1;
+        }
+        return;
+    }
+
+    // x += gamma * direction over the OLD support (homotopy-cpu.cpp:252; d is zero elsewhere)
+    for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) {
+        const uint32_t col = gam[j];
+        x[col] = x[col] + g * d[col];
+    }
+
+    // new sorted support, written out of place
+    if (added) {
+        for (uint32_t j = threadIdx.x; j < K_new; j += blockDim.x)
+            gam_new[j] = (j < rank) ? gam[j] : (j == rank ? idx : gam[j - 1]);
+    } else {
+        for (uint32_t j = threadIdx.x; j < K_new; j += blockDim.x)
+            gam_new[j] = gam[j + (j >= rank ? 1u : 0u)];
+    }
+    // touched list: sorted union of every support so far
+    const bool seen = (trank < nt) && (tch[trank] == idx);
+    const uint32_t nt_new = (added && !seen) ? nt + 1 : nt;
+    if (added && !seen) {
+        for (uint32_t j = threadIdx.x; j < nt_new; j += blockDim.x)
+            tch_new[j] = (j < trank) ? tch[j] : (j == trank ? idx : tch[j - 1]);
+    } else {
+        for (uint32_t j = threadIdx.x; j < nt_new; j += blockDim.x) tch_new[j] = tch[j];
+    }
+
+    if (threadIdx.x == 0) {
+        insup[idx] = added ? 1 : 0;
+        st->K = K_new;
+        st->ntouched = nt_new;
+        st->idx = idx;
+        st->rank = rank;
+        st->added = added ? 1u : 0u;
+        st->gamma = (double)g;
+        st->c_inf = (double)c_inf;
+        st->iter = round;
+    }
+}
+
+// ---- k_gram: u1 = A_S^T a_idx and a_idx . a_idx (online_inverse.h:209-218) -------------
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_gram(const T* __restrict__ At, uint32_t ldm, const uint32_t* __restrict__ gam2, uint32_t kcap,
+            T* __restrict__ u1, DevState* st)
+{
+    if (st->done || !st->added) return;
+    const uint32_t b = blockIdx.x;
+    const uint32_t K_new = st->K;
+    if (b >= K_new) return;
+    __shared__ T sv[16];
+    const uint32_t rank = st->rank;
+    const uint32_t* gam_new = gam2 + (size_t)(st->cur ^ 1u) * kcap;
+    const T* col = At + (size_t)gam_new[b] * ldm;
+    const T* cnew = At + (size_t)st->idx * ldm;
+    const T v = block_dot(col, cnew, ldm, sv);
+    if (threadIdx.x == 0) {
+        if (b == rank) st->dot = (double)v;
+        else u1[b - (b > rank ? 1u : 0u)] = v;
+    }
+}
+
+// ---- k_update: bordering / deflation of (A_S^T A_S)^-1 + new direction ----------------
+template <typename T>
+__global__ __launch_bounds__(kUpdThreads)
+void k_update(T* __restrict__ inv0, T* __restrict__ inv1, uint32_t kcap,
+              const T* __restrict__ u1, T* __restrict__ u2, T* __restrict__ sgn,
+              const uint32_t* __restrict__ gam2, const T* __restrict__ c, const T* __restrict__ q,
+              T* __restrict__ d, T tol, DevState* st)
+{
+    if (st->done) return;
+    __shared__ T sv[16];
+    __shared__ T s_d;
+    const uint32_t cur = st->cur;
+    const T* Iold = cur ? inv1 : inv0;
+    T* Inew = cur ? inv0 : inv1;
+    const uint32_t K_new = st->K;
+    const uint32_t rank = st->rank;
+    const bool added = st->added != 0;
+    const uint32_t K_old = added ? K_new - 1 : K_new + 1;
+    const uint32_t* gam_old = gam2 + (size_t)cur * kcap;
+    const uint32_t* gam_new = gam2 + (size_t)(cur ^ 1u) * kcap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = kUpdThreads / 64;
+    const size_t P = kcap;
+
+    if (added) {
+        const uint32_t n = K_old;
+        // u2 = inv * u1 (online_inverse.h:224-225), one wave per row
+        for (uint32_t i = wave; i < n; i += NW) {
+            T acc = T(0);
+            for (uint32_t j = lane; j < n; j += 64) acc += Iold[i * P + j] * u1[j];
+            acc = wave_sum(acc);
+            if (lane == 0) u2[i] = acc;
+        }
+        __syncthreads();
+        // d = 1 / (dot - u1.u2) (online_inverse.h:228)
+        T part = T(0);
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) part += u1[j] * u2[j];
+        const T s = block_sum(part, sv);
+        if (threadIdx.x == 0) s_d = T(1) / ((T)st->dot - s);
+        __syncthreads();
+        const T dv = s_d;
+        // new inverse in sorted order: [inv + d u2 u2^T, -d u2; -d u2^T, d] with the new
+        // row/column at position `rank` (online_inverse.h:229-248)
+        const uint32_t tot = K_new * K_new;
+        for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
+            const uint32_t a = e / K_new, b = e - a * K_new;
+            T v;
+            if (a == rank && b == rank) {
+                v = dv;
+            } else if (a == rank) {
+                v = -dv * u2[b - (b > rank ? 1u : 0u)];
+            } else if (b == rank) {
+                v = -dv * u2[a - (a > rank ? 1u : 0u)];
+            } else {
+                const uint32_t oa = a - (a > rank ? 1u : 0u), ob = b - (b > rank ? 1u : 0u);
+                v = Iold[oa * P + ob] + (dv * u2[oa]) * u2[ob];
+            }
+            Inew[a * P + b] = v;
+        }
+    } else {
+        // remove row/column `rank` (online_inverse.h:275-290)
+        const uint32_t n = K_old;
+        const T dd = Iold[rank * P + rank];
+        const T sc = -(T(1) / dd);
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) u2[i] = Iold[i * P + rank] * sc;
+        __syncthreads();
+        const uint32_t tot = K_new * K_new;
+        for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
+            const uint32_t a = e / K_new, b = e - a * K_new;
+            const uint32_t oa = a + (a >= rank ? 1u : 0u), ob = b + (b >= rank ? 1u : 0u);
+            Inew[a * P + b] = Iold[oa * P + ob] + (-dd * u2[oa]) * u2[ob];
+        }
+    }
+
+    // sign(c[Gamma]) with dead zone tol (homotopy-cpu.cpp:259-260).  The correlations after
+    // the step are c - gamma*q (c_new = A^T(y - A(x + gamma d)) = c - gamma A^T A d); only
+    // their sign is used here, the next sweep recomputes c itself from r.
+    const T g = (T)st->gamma;
+    for (uint32_t a = threadIdx.x; a < K_new; a += blockDim.x) {
+        const uint32_t col = gam_new[a];
+        const T cn = c[col] - g * q[col];
+        sgn[a] = sign_tol(cn, tol);
+    }
+    // clear the old direction
+    for (uint32_t j = threadIdx.x; j < K_old; j += blockDim.x) d[gam_old[j]] = T(0);
+    __syncthreads();
+    // direction = inv * sign (homotopy-cpu.cpp:263), scattered to its columns (:266)
+    for (uint32_t a = wave; a < K_new; a += NW) {
+        T acc = T(0);
+        for (uint32_t b = lane; b < K_new; b += 64) acc += Inew[a * P + b] * sgn[b];
+        acc = wave_sum(acc);
+        if (lane == 0) d[gam_new[a]] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st->cur = cur ^ 1u;
+}
+
+// ---- y = A x (reconstruct_signal, lib.cpp:78-104) -------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_gemv_n(const T* __restrict__ At, uint32_t ldm, uint32_t m, uint32_t n,
+              const T* __restrict__ x, T* __restrict__ y)
+{
+    // one thread per row; columns with x[j] == 0 are skipped (exact: they add 0)
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    T acc = T(0);
+    for (uint32_t j = 0; j < n; ++j) {
+        const T xj = x[j];
+        if (xj != T(0)) acc += At[(size_t)j * ldm + i] * xj;
+    }
+    y[i] = acc;
+}
+
+// ---- launchers ------------------------------------------------------------------------
+
+template <typename T>
+hipError_t launch_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsweep_blocks, T tol)
+{
+    hipLaunchKernelGGL((k_init<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ctx->ldm, ws.c, ws.pmax_val, ws.pmax_idx,
+                       nsweep_blocks, ws.d, ws.insup, ws.gam, ws.touched, ws.inv[0], tol,
+                       ctx->strict_sign, ws.st);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_rp(const ss_hip_ctx* ctx, Workspace<T>& ws)
+{
+    const uint32_t blocks = (ctx->ldm + 127) / 128;
+    hipLaunchKernelGGL((k_rp<T>), dim3(blocks), dim3(128), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ctx->ldm, ws.y, ws.x, ws.d, ws.touched,
+                       ws.kcap, ws.rhs, ws.st);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round,
+                                 uint32_t nsweep_blocks, T tol, uint32_t max_iter)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    const uint32_t per_block = kSmallThreads * kScanPerThread;
+    uint32_t ns = (n + per_block - 1) / per_block;
+    if (ns > kMaxScanBlocks) ns = kMaxScanBlocks;   // k_scan grid-strides
+    hipLaunchKernelGGL((k_scan<T>), dim3(ns), dim3(kSmallThreads), 0, ctx->stream, ws.c, ws.q, ws.x,
+                       ws.d, ws.insup, n, ws.pmax_val, ws.pmax_idx, nsweep_blocks, ws.pmin_val,
+                       ws.pmin_idx, ws.st);
+    hipLaunchKernelGGL((k_select<T>), dim3(1), dim3(kSmallThreads), 0, ctx->stream, round, tol,
+                       max_iter, n, ws.pmax_val, ws.pmax_idx, nsweep_blocks, ws.pmin_val,
+                       ws.pmin_idx, ns, ws.x, ws.d, ws.insup, ws.gam, ws.touched, ws.kcap, ws.st);
+    uint32_t gb = round + 1;
+    if (gb > ws.kcap) gb = ws.kcap;
+    hipLaunchKernelGGL((k_gram<T>), dim3(gb), dim3(kSmallThreads), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ctx->ldm, ws.gam, ws.kcap, ws.u1, ws.st);
+    hipLaunchKernelGGL((k_update<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, ws.inv[0],
+                       ws.inv[1], ws.kcap, ws.u1, ws.u2, ws.sgn, ws.gam, ws.c, ws.q, ws.d, tol,
+                       ws.st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_rp(ctx, ws);
+}
+
+template <typename T>
+hipError_t launch_gemv_n(const ss_hip_ctx* ctx, const T* x_dev, T* y_dev)
+{
+    const uint32_t m = (uint32_t)ctx->m;
+    hipLaunchKernelGGL((k_gemv_n<T>), dim3((m + kSmallThreads - 1) / kSmallThreads),
+                       dim3(kSmallThreads), 0, ctx->stream, static_cast<const T*>(ctx->At), ctx->ldm,
+                       m, (uint32_t)ctx->n, x_dev, y_dev);
+    return hipGetLastError();
+}
+
+template hipError_t launch_init<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
+template hipError_t launch_init<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double);
+template hipError_t launch_rp<float>(const ss_hip_ctx*, Workspace<float>&);
+template hipError_t launch_rp<double>(const ss_hip_ctx*, Workspace<double>&);
+template hipError_t launch_iteration_tail<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t,
+                                                 uint32_t, float, uint32_t);
+template hipError_t launch_iteration_tail<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t,
+                                                  uint32_t, double, uint32_t);
+template hipError_t launch_gemv_n<float>(const ss_hip_ctx*, const float*, float*);
+template hipError_t launch_gemv_n<double>(const ss_hip_ctx*, const double*, double*);
+
+}  // namespace sship

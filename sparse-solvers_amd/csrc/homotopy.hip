@@ -1,0 +1,654 @@
+// homotopy.hip — the C-ABI of libss_hip.so (include/ss_hip.h): context creation (upload +
+// re-layout of the sensing matrix), the host side of the device-resident Homotopy loop,
+// the standalone sweep entry and the measurement hooks.
+//
+// Reference being replaced (paths under /root/reference):
+//   ss::solver<T,P>::solver / homotopy_policy state   include/ss/ss.h:98-105, policies.h:42
+//   solve_homotopy::op<mode,T> / run_solver<T>         src/solvers/homotopy.h:27-38,
+//                                                      src/solvers/homotopy-cpu.cpp:186-275
+//
+// Execution model: one HIP stream per context.  A solve enqueues, per homotopy
+// iteration ("round"), one fused sweep kernel and five small kernels; termination is
+// decided ON THE DEVICE (k_select raises DevState::done, after which every kernel is a
+// no-op), the host only polls a copy of that flag `lookahead` rounds behind the queue
+// head, so the GPU never waits for the host between iterations.
+#include "ss_hip_internal.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+
+using namespace sship;
+
+namespace sship {
+
+void set_err(char* err, size_t errlen, const std::string& msg)
+{
+    if (!err || errlen == 0) return;
+    const size_t k = std::min(errlen - 1, msg.size());
+    std::memcpy(err, msg.data(), k);
+    err[k] = '\0';
+}
+
+}  // namespace sship
+
+namespace {
+
+struct HipFail {
+    hipError_t code;
+    const char* what;
+};
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) throw HipFail{ e_, #expr };                                     \
+    } while (0)
+
+std::string hip_msg(const HipFail& f)
+{
+    return std::string("HIP error: ") + hipGetErrorString(f.code) + " in " + f.what;
+}
+
+template <typename T>
+Workspace<T>* ws_of(ss_hip_ctx* ctx) { return static_cast<Workspace<T>*>(ctx->ws); }
+
+bool is_device_pointer(const void* p)
+{
+    hipPointerAttribute_t attr;
+    std::memset(&attr, 0, sizeof(attr));
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // unregistered host memory: clear the sticky error
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged ||
+           attr.type == hipMemoryTypeUnified;
+}
+
+// ---- re-layout: At[j][i] = src[i*rs + j*cs] for rows [r0, r0+R) --------------------
+template <typename T>
+__global__ __launch_bounds__(1024)
+void k_relayout(const T* __restrict__ src, long long rs, long long cs, uint32_t R, uint32_t n,
+                uint32_t r0, T* __restrict__ At, uint32_t ldm)
+{
+    __shared__ T tile[32][33];
+    const uint32_t j0 = blockIdx.x * 32;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (uint32_t i0 = blockIdx.y * 32; i0 < R; i0 += gridDim.y * 32) {   // uniform per block
+        {
+            const uint32_t i = i0 + ty, j = j0 + tx;
+            tile[ty][tx] = (i < R && j < n) ? src[(long long)i * rs + (long long)j * cs] : T(0);
+        }
+        __syncthreads();
+        {
+            const uint32_t j = j0 + ty, i = i0 + tx;
+            if (j < n && i < R) At[(size_t)j * ldm + r0 + i] = tile[tx][ty];
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+void upload_matrix(ss_hip_ctx* ctx, const T* A, ptrdiff_t rs, ptrdiff_t cs)
+{
+    const size_t m = ctx->m, n = ctx->n, s = sizeof(T);
+    T* At = static_cast<T*>(ctx->At);
+    const uint32_t ldm = ctx->ldm;
+    const bool on_device = is_device_pointer(A);
+
+    if (on_device) {
+        // one generic strided transpose straight from the caller's device buffer
+        const dim3 grid((unsigned)((n + 31) / 32), (unsigned)std::min<size_t>((m + 31) / 32, 32768));
+        hipLaunchKernelGGL((k_relayout<T>), grid, dim3(1024), 0, ctx->stream, A, (long long)rs,
+                           (long long)cs, (uint32_t)m, (uint32_t)n, 0u, At, ldm);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return;
+    }
+
+    if ((rs == 1 || m == 1) && (cs >= (ptrdiff_t)m || n == 1) && cs > 0) {
+        // column-major host view: columns are already contiguous
+        HIPCHK(hipMemcpy2D(At, (size_t)ldm * s, A, (size_t)cs * s, m * s, n, hipMemcpyHostToDevice));
+        return;
+    }
+
+    // row panels through a staging buffer, transposed on the device
+    const size_t panel_bytes = (size_t)256 << 20;
+    size_t R = std::max<size_t>(1, std::min(m, panel_bytes / std::max<size_t>(1, n * s)));
+    T* stage = nullptr;
+    HIPCHK(hipMalloc(&stage, R * n * s));
+    std::vector<T> gather;
+    const bool rowmajor = (cs == 1 || n == 1) && rs >= (ptrdiff_t)n && rs > 0;
+    try {
+        for (size_t r0 = 0; r0 < m; r0 += R) {
+            const size_t rows = std::min(R, m - r0);
+            if (rowmajor) {
+                HIPCHK(hipMemcpy2D(stage, n * s, A + (ptrdiff_t)r0 * rs, (size_t)rs * s, n * s, rows,
+                                   hipMemcpyHostToDevice));
+            } else {
+                // arbitrary (e.g. negative or doubly strided) host view: gather on the host
+                gather.resize(rows * n);
+                for (size_t i = 0; i < rows; ++i)
+                    for (size_t j = 0; j < n; ++j)
+                        gather[i * n + j] = A[(ptrdiff_t)(r0 + i) * rs + (ptrdiff_t)j * cs];
+                HIPCHK(hipMemcpy(stage, gather.data(), rows * n * s, hipMemcpyHostToDevice));
+            }
+            const dim3 grid((unsigned)((n + 31) / 32), (unsigned)std::min<size_t>((rows + 31) / 32, 32768));
+            hipLaunchKernelGGL((k_relayout<T>), grid, dim3(1024), 0, ctx->stream, stage, (long long)n,
+                               1LL, (uint32_t)rows, (uint32_t)n, (uint32_t)r0, At, ldm);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+    } catch (...) {
+        (void)hipFree(stage);
+        throw;
+    }
+    HIPCHK(hipFree(stage));
+}
+
+template <typename T>
+void free_ws(Workspace<T>* w)
+{
+    if (!w) return;
+    void* ptrs[] = { w->y, w->rhs, w->c, w->q, w->x, w->d, w->insup, w->pmax_val, w->pmax_idx,
+                     w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->inv[1], w->u1,
+                     w->u2, w->sgn, w->st };
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete w;
+}
+
+template <typename T>
+void alloc_ws_fixed(ss_hip_ctx* ctx)
+{
+    auto* w = new Workspace<T>();
+    ctx->ws = w;
+    const size_t ldm = ctx->ldm, np = ctx->n_pad, s = sizeof(T);
+    HIPCHK(hipMalloc(&w->y, ldm * s));
+    HIPCHK(hipMalloc(&w->rhs, 2 * ldm * s));
+    HIPCHK(hipMalloc(&w->c, np * s));
+    HIPCHK(hipMalloc(&w->q, np * s));
+    HIPCHK(hipMalloc(&w->x, np * s));
+    HIPCHK(hipMalloc(&w->d, np * s));
+    HIPCHK(hipMalloc(&w->insup, np));
+    HIPCHK(hipMalloc(&w->pmax_val, kMaxSweepBlocks * s));
+    HIPCHK(hipMalloc(&w->pmax_idx, kMaxSweepBlocks * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&w->pmin_val, kMaxScanBlocks * s));
+    HIPCHK(hipMalloc(&w->pmin_idx, kMaxScanBlocks * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&w->st, sizeof(DevState)));
+    HIPCHK(hipMemset(w->y, 0, ldm * s));
+    HIPCHK(hipMemset(w->rhs, 0, 2 * ldm * s));
+    HIPCHK(hipMemset(w->c, 0, np * s));
+    HIPCHK(hipMemset(w->q, 0, np * s));
+    HIPCHK(hipMemset(w->st, 0, sizeof(DevState)));
+}
+
+template <typename T>
+void ensure_kcap(ss_hip_ctx* ctx, uint32_t kcap)
+{
+    Workspace<T>* w = ws_of<T>(ctx);
+    if (kcap <= w->kcap) return;
+    // grow geometrically so repeated solves with slightly larger max_iter do not realloc
+    uint32_t want = std::max<uint32_t>(kcap, std::min<uint32_t>(kKcapLimit, std::max<uint32_t>(64, w->kcap * 2)));
+    void* olds[] = { w->gam, w->touched, w->inv[0], w->inv[1], w->u1, w->u2, w->sgn };
+    for (void* p : olds)
+        if (p) HIPCHK(hipFree(p));
+    w->gam = w->touched = nullptr;
+    w->inv[0] = w->inv[1] = w->u1 = w->u2 = w->sgn = nullptr;
+    w->kcap = 0;
+    const size_t s = sizeof(T);
+    HIPCHK(hipMalloc(&w->gam, 2 * (size_t)want * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&w->touched, 2 * (size_t)want * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&w->inv[0], (size_t)want * want * s));
+    HIPCHK(hipMalloc(&w->inv[1], (size_t)want * want * s));
+    HIPCHK(hipMalloc(&w->u1, (size_t)want * s));
+    HIPCHK(hipMalloc(&w->u2, (size_t)want * s));
+    HIPCHK(hipMalloc(&w->sgn, (size_t)want * s));
+    w->kcap = want;
+}
+
+template <typename T>
+ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, int device,
+                        char* err, size_t errlen)
+{
+    if (!A || m == 0 || n == 0) {
+        set_err(err, errlen, "ss_hip_homotopy_create: A must be a non-empty m x n matrix");
+        return nullptr;
+    }
+    if (m > (size_t)1 << 28 || n > (size_t)1 << 30) {
+        set_err(err, errlen, "ss_hip_homotopy_create: matrix dimensions too large");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        set_err(err, errlen, "ss_hip_homotopy_create: no HIP device available");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        set_err(err, errlen, "ss_hip_homotopy_create: device index out of range");
+        return nullptr;
+    }
+    ss_hip_ctx* ctx = new (std::nothrow) ss_hip_ctx();
+    if (!ctx) {
+        set_err(err, errlen, "ss_hip_homotopy_create: out of host memory");
+        return nullptr;
+    }
+    try {
+        HIPCHK(hipSetDevice(device));
+        ctx->device = device;
+        ctx->is_f64 = sizeof(T) == 8;
+        ctx->m = m;
+        ctx->n = n;
+        ctx->ldm = (uint32_t)((m + kRowPad - 1) / kRowPad * kRowPad);
+        ctx->n_pad = (uint32_t)((n + kColPad - 1) / kColPad * kColPad);
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        const size_t bytes = (size_t)ctx->n_pad * ctx->ldm * sizeof(T);
+        HIPCHK(hipMalloc(&ctx->At, bytes));
+        HIPCHK(hipMemsetAsync(ctx->At, 0, bytes, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        upload_matrix<T>(ctx, A, rs, cs);
+        alloc_ws_fixed<T>(ctx);
+        HIPCHK(hipHostMalloc(&ctx->host_flags, 64 * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(hipEventCreate(&ctx->ev_solve0));
+        HIPCHK(hipEventCreate(&ctx->ev_solve1));
+        const uint64_t s = sizeof(T);
+        ctx->stats.sweep_bytes = (uint64_t)m * n * s + 2 * (uint64_t)m * s + 2 * (uint64_t)n * s;
+        ctx->stats.sweep1_bytes = (uint64_t)m * n * s + (uint64_t)m * s + (uint64_t)n * s;
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        ss_hip_homotopy_destroy(ctx);
+        return nullptr;
+    } catch (const std::bad_alloc&) {
+        set_err(err, errlen, "ss_hip_homotopy_create: out of host memory");
+        ss_hip_homotopy_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+// copies a strided vector (host or device) into a contiguous device buffer
+template <typename T>
+void copy_in(ss_hip_ctx* ctx, T* dst_dev, const T* src, ptrdiff_t inc, size_t len)
+{
+    if (inc == 1) {
+        HIPCHK(hipMemcpyAsync(dst_dev, src, len * sizeof(T), hipMemcpyDefault, ctx->stream));
+    } else {
+        HIPCHK(hipMemcpy2DAsync(dst_dev, sizeof(T), src, (size_t)inc * sizeof(T), sizeof(T), len,
+                                hipMemcpyDefault, ctx->stream));
+    }
+}
+
+template <typename T>
+void copy_out(ss_hip_ctx* ctx, T* dst, ptrdiff_t inc, const T* src_dev, size_t len)
+{
+    if (inc == 1) {
+        HIPCHK(hipMemcpyAsync(dst, src_dev, len * sizeof(T), hipMemcpyDefault, ctx->stream));
+    } else {
+        HIPCHK(hipMemcpy2DAsync(dst, (size_t)inc * sizeof(T), src_dev, sizeof(T), sizeof(T), len,
+                                hipMemcpyDefault, ctx->stream));
+    }
+}
+
+hipEvent_t prof_event(ss_hip_ctx* ctx, size_t i)
+{
+    while (ctx->prof_events.size() <= i) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        ctx->prof_events.push_back(e);
+    }
+    return ctx->prof_events[i];
+}
+
+template <typename T>
+int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
+               ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen)
+{
+    if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
+    if (ctx->is_f64 != (sizeof(T) == 8)) {
+        set_err(err, errlen, "solve: element type of the call does not match the context");
+        return SS_HIP_ETYPE;
+    }
+    if (!y || !x) { set_err(err, errlen, "solve: y and x must not be null"); return SS_HIP_EINVAL; }
+    // preconditions the reference asserts (homotopy-cpu.cpp:193-199)
+    if (max_iter == 0) { set_err(err, errlen, "solve: max_iterations must be > 0"); return SS_HIP_EINVAL; }
+    if (!(tol >= std::numeric_limits<T>::epsilon() && tol < T(1))) {
+        set_err(err, errlen, "solve: tolerance must satisfy eps <= tolerance < 1");
+        return SS_HIP_EINVAL;
+    }
+    if (incy <= 0 || incx <= 0) {
+        set_err(err, errlen, "solve: vector increments must be positive");
+        return SS_HIP_EINVAL;
+    }
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        const size_t m = ctx->m, n = ctx->n;
+        const uint32_t kcap = (uint32_t)std::min<uint64_t>(
+            std::min<uint64_t>(n, (uint64_t)max_iter + 1), kKcapLimit);
+        ensure_kcap<T>(ctx, kcap);
+        Workspace<T>& ws = *ws_of<T>(ctx);
+        hipStream_t st = ctx->stream;
+        const bool prof = ctx->profiling != 0;
+        size_t nprof = 0;
+        ctx->prof_kind.clear();
+
+        if (prof) HIPCHK(hipEventRecord(ctx->ev_solve0, st));
+        copy_in<T>(ctx, ws.y, y, incy, m);
+        HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)ctx->n_pad * sizeof(T), st));
+        HIPCHK(hipMemsetAsync(ws.d, 0, (size_t)ctx->n_pad * sizeof(T), st));
+        HIPCHK(hipMemsetAsync(ws.insup, 0, (size_t)ctx->n_pad, st));
+        HIPCHK(hipMemsetAsync(ws.st, 0, sizeof(DevState), st));
+        HIPCHK(hipMemcpyAsync(ws.rhs, ws.y, (size_t)ctx->ldm * sizeof(T), hipMemcpyDeviceToDevice, st));
+
+        // c = A^T y  (residual_vector with x = 0, homotopy-cpu.cpp:215)
+        uint32_t nb1 = 0;
+        if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+        HIPCHK(launch_sweep<T>(ctx, ws.rhs, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+        if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+        HIPCHK(launch_init<T>(ctx, ws, nb1, tol));
+        HIPCHK(launch_rp<T>(ctx, ws));
+
+        const int L = std::max(1, std::min(ctx->lookahead, 32));
+        const int RING = L + 2;
+        while ((int)ctx->flag_events.size() < RING) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->flag_events.push_back(e);
+        }
+        for (int i = 0; i < RING; ++i) ctx->host_flags[i] = 0;
+
+        const uint64_t last_round = (uint64_t)max_iter + 1;
+        for (uint64_t round = 1; round <= last_round; ++round) {
+            if (round > (uint64_t)L) {
+                const uint64_t chk = round - L;
+                HIPCHK(hipEventSynchronize(ctx->flag_events[chk % RING]));
+                if (ctx->host_flags[chk % RING] != 0) break;
+            }
+            uint32_t nb = 0;
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, 2, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, &nb, ws.st));
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(2); ++nprof; }
+            HIPCHK(launch_iteration_tail<T>(ctx, ws, (uint32_t)round, nb, tol, max_iter));
+            HIPCHK(hipMemcpyAsync(&ctx->host_flags[round % RING], &ws.st->done, sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, st));
+            HIPCHK(hipEventRecord(ctx->flag_events[round % RING], st));
+        }
+
+        DevState hs;
+        HIPCHK(hipMemcpyAsync(&hs, ws.st, sizeof(DevState), hipMemcpyDeviceToHost, st));
+        copy_out<T>(ctx, x, incx, ws.x, n);
+        if (prof) HIPCHK(hipEventRecord(ctx->ev_solve1, st));
+        HIPCHK(hipStreamSynchronize(st));
+
+        if (!hs.done) {
+            set_err(err, errlen, "solve: internal error, device loop did not terminate");
+            return SS_HIP_ERUNTIME;
+        }
+        if (hs.status != 0) {
+            set_err(err, errlen, "solve: active set outgrew the workspace capacity (4096 columns)");
+            return (int)hs.status;
+        }
+        if (iter_out) *iter_out = hs.iter;
+        if (err_out) *err_out = hs.c_inf;
+
+        ctx->stats.solves += 1;
+        ctx->stats.iterations += hs.iter;
+        if (prof) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
+            ctx->stats.solve_ms += ms;
+            // only sweeps that did real work: the initial one and rounds 1..done_round
+            size_t fused_seen = 0;
+            for (size_t i = 0; i < nprof; ++i) {
+                HIPCHK(hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
+                if (ctx->prof_kind[i] == 1) {
+                    ctx->stats.sweep1_launches += 1;
+                    ctx->stats.sweep1_ms += ms;
+                } else {
+                    ++fused_seen;
+                    if (fused_seen <= hs.done_round) {
+                        ctx->stats.sweep_launches += 1;
+                        ctx->stats.sweep_ms += ms;
+                    }
+                }
+            }
+        }
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        return SS_HIP_ERUNTIME;
+    } catch (const std::bad_alloc&) {
+        set_err(err, errlen, "solve: out of host memory");
+        return SS_HIP_ENOMEM;
+    }
+    return SS_HIP_OK;
+}
+
+template <typename T>
+int solve_batch_impl(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, T tol,
+                     uint32_t max_iter, T* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
+                     double* err_out, char* err, size_t errlen)
+{
+    if (!Y || !X) { set_err(err, errlen, "solve_batch: Y and X must not be null"); return SS_HIP_EINVAL; }
+    for (size_t b = 0; b < B; ++b) {
+        uint32_t it = 0;
+        double e = 0.0;
+        const int rc = solve_impl<T>(ctx, Y + (ptrdiff_t)b * y_stride, incy, tol, max_iter,
+                                     X + (ptrdiff_t)b * x_stride, incx, &it, &e, err, errlen);
+        if (rc != SS_HIP_OK) return rc;
+        if (iter_out) iter_out[b] = it;
+        if (err_out) err_out[b] = e;
+    }
+    return SS_HIP_OK;
+}
+
+template <typename T>
+int gemv_t_impl(ss_hip_ctx* ctx, const T* r, T* c, int repeats, float* ms_out, char* err, size_t errlen)
+{
+    if (!ctx || !r || !c) { set_err(err, errlen, "gemv_t: null argument"); return SS_HIP_EINVAL; }
+    if (ctx->is_f64 != (sizeof(T) == 8)) { set_err(err, errlen, "gemv_t: type mismatch"); return SS_HIP_ETYPE; }
+    if (repeats < 1) repeats = 1;
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        Workspace<T>& ws = *ws_of<T>(ctx);
+        hipStream_t st = ctx->stream;
+        copy_in<T>(ctx, ws.rhs, r, 1, ctx->m);
+        uint32_t nb = 0;
+        HIPCHK(hipEventRecord(ctx->ev_solve0, st));
+        for (int i = 0; i < repeats; ++i)
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
+        HIPCHK(hipEventRecord(ctx->ev_solve1, st));
+        copy_out<T>(ctx, c, 1, ws.c, ctx->n);
+        HIPCHK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
+        if (ms_out) *ms_out = ms / (float)repeats;
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        return SS_HIP_ERUNTIME;
+    }
+    return SS_HIP_OK;
+}
+
+template <typename T>
+int reconstruct_impl(ss_hip_ctx* ctx, const T* x, T* y, char* err, size_t errlen)
+{
+    if (!ctx || !x || !y) { set_err(err, errlen, "reconstruct: null argument"); return SS_HIP_EINVAL; }
+    if (ctx->is_f64 != (sizeof(T) == 8)) { set_err(err, errlen, "reconstruct: type mismatch"); return SS_HIP_ETYPE; }
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        Workspace<T>& ws = *ws_of<T>(ctx);
+        copy_in<T>(ctx, ws.q, x, 1, ctx->n);
+        HIPCHK(launch_gemv_n<T>(ctx, ws.q, ws.rhs));
+        copy_out<T>(ctx, y, 1, ws.rhs, ctx->m);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        // rhs padding must stay zero for the sweeps: rows >= m were not written
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        return SS_HIP_ERUNTIME;
+    }
+    return SS_HIP_OK;
+}
+
+}  // namespace
+
+// ---- C-ABI ----------------------------------------------------------------------------
+
+extern "C" {
+
+int ss_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char* ss_hip_version(void) { return "0.1.0"; }
+
+ss_hip_ctx* ss_hip_homotopy_create_f32(const float* A, size_t m, size_t n, ptrdiff_t stride_row,
+                                       ptrdiff_t stride_col, int device, char* err, size_t errlen)
+{
+    return create_impl<float>(A, m, n, stride_row, stride_col, device, err, errlen);
+}
+
+ss_hip_ctx* ss_hip_homotopy_create_f64(const double* A, size_t m, size_t n, ptrdiff_t stride_row,
+                                       ptrdiff_t stride_col, int device, char* err, size_t errlen)
+{
+    return create_impl<double>(A, m, n, stride_row, stride_col, device, err, errlen);
+}
+
+void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) {
+        if (ctx->is_f64) free_ws(static_cast<Workspace<double>*>(ctx->ws));
+        else free_ws(static_cast<Workspace<float>*>(ctx->ws));
+    }
+    if (ctx->At) (void)hipFree(ctx->At);
+    if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
+    for (hipEvent_t e : ctx->flag_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    if (ctx->ev_solve0) (void)hipEventDestroy(ctx->ev_solve0);
+    if (ctx->ev_solve1) (void)hipEventDestroy(ctx->ev_solve1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int ss_hip_homotopy_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_t incy, float tol,
+                              uint32_t max_iter, float* x, ptrdiff_t incx, uint32_t* iter_out,
+                              double* err_out, char* err, size_t errlen)
+{
+    return solve_impl<float>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen);
+}
+
+int ss_hip_homotopy_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy, double tol,
+                              uint32_t max_iter, double* x, ptrdiff_t incx, uint32_t* iter_out,
+                              double* err_out, char* err, size_t errlen)
+{
+    return solve_impl<double>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen);
+}
+
+int ss_hip_homotopy_solve_batch_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride,
+                                    ptrdiff_t incy, float tol, uint32_t max_iter, float* X,
+                                    ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
+                                    double* err_out, char* err, size_t errlen)
+{
+    return solve_batch_impl<float>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx,
+                                   iter_out, err_out, err, errlen);
+}
+
+int ss_hip_homotopy_solve_batch_f64(ss_hip_ctx* ctx, const double* Y, size_t B, ptrdiff_t y_stride,
+                                    ptrdiff_t incy, double tol, uint32_t max_iter, double* X,
+                                    ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
+                                    double* err_out, char* err, size_t errlen)
+{
+    return solve_batch_impl<double>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx,
+                                    iter_out, err_out, err, errlen);
+}
+
+int ss_hip_gemv_t_f32(ss_hip_ctx* ctx, const float* r, float* c, int repeats, float* ms_out,
+                      char* err, size_t errlen)
+{
+    return gemv_t_impl<float>(ctx, r, c, repeats, ms_out, err, errlen);
+}
+
+int ss_hip_gemv_t_f64(ss_hip_ctx* ctx, const double* r, double* c, int repeats, float* ms_out,
+                      char* err, size_t errlen)
+{
+    return gemv_t_impl<double>(ctx, r, c, repeats, ms_out, err, errlen);
+}
+
+int ss_hip_reconstruct_f32(ss_hip_ctx* ctx, const float* x, float* y, char* err, size_t errlen)
+{
+    return reconstruct_impl<float>(ctx, x, y, err, errlen);
+}
+
+int ss_hip_reconstruct_f64(ss_hip_ctx* ctx, const double* x, double* y, char* err, size_t errlen)
+{
+    return reconstruct_impl<double>(ctx, x, y, err, errlen);
+}
+
+int ss_hip_set_profiling(ss_hip_ctx* ctx, int profiling)
+{
+    if (!ctx) return SS_HIP_EINVAL;
+    ctx->profiling = profiling ? 1 : 0;
+    return SS_HIP_OK;
+}
+
+int ss_hip_get_stats(ss_hip_ctx* ctx, ss_hip_stats* out)
+{
+    if (!ctx || !out) return SS_HIP_EINVAL;
+    *out = ctx->stats;
+    return SS_HIP_OK;
+}
+
+int ss_hip_reset_stats(ss_hip_ctx* ctx)
+{
+    if (!ctx) return SS_HIP_EINVAL;
+    const uint64_t b2 = ctx->stats.sweep_bytes, b1 = ctx->stats.sweep1_bytes;
+    ctx->stats = ss_hip_stats{};
+    ctx->stats.sweep_bytes = b2;
+    ctx->stats.sweep1_bytes = b1;
+    return SS_HIP_OK;
+}
+
+int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
+{
+    if (!ctx || !key) return SS_HIP_EINVAL;
+    if (!std::strcmp(key, "sweep_variant")) { ctx->sweep_variant = (int)value; return SS_HIP_OK; }
+    if (!std::strcmp(key, "lookahead"))     { ctx->lookahead = (int)value; return SS_HIP_OK; }
+    if (!std::strcmp(key, "strict_sign"))   { ctx->strict_sign = value ? 1 : 0; return SS_HIP_OK; }
+    return SS_HIP_EINVAL;
+}
+
+int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
+{
+    if (!ctx || !key || !value) return SS_HIP_EINVAL;
+    if (!std::strcmp(key, "sweep_variant")) { *value = ctx->sweep_variant; return SS_HIP_OK; }
+    if (!std::strcmp(key, "lookahead"))     { *value = ctx->lookahead; return SS_HIP_OK; }
+    if (!std::strcmp(key, "strict_sign"))   { *value = ctx->strict_sign; return SS_HIP_OK; }
+    return SS_HIP_EINVAL;
+}
+
+int ss_hip_ctx_info(const ss_hip_ctx* ctx, size_t* m, size_t* n, int* is_f64, int* device)
+{
+    if (!ctx) return SS_HIP_EINVAL;
+    if (m) *m = ctx->m;
+    if (n) *n = ctx->n;
+    if (is_f64) *is_f64 = ctx->is_f64;
+    if (device) *device = ctx->device;
+    return SS_HIP_OK;
+}
+
+}  // extern "C"

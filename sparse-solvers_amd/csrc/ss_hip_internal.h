@@ -1,0 +1,131 @@
+// Internal declarations shared by the HIP translation units of libss_hip.so.
+// Not part of the C-ABI (include/ss_hip.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "ss_hip.h"
+
+namespace sship {
+
+// Column pitch of the device copy is a multiple of this many ELEMENTS so that every
+// wave-instruction of the sweep (64 lanes x 16 B) stays inside one column and the
+// zero padding contributes exact zeros to the dot products.
+constexpr uint32_t kRowPad = 256;
+// Columns are padded (zero-filled) to a multiple of this so the sweep needs no tail code.
+constexpr uint32_t kColPad = 64;
+// Hard cap of the active-set capacity (workspace is 2 * Kcap^2 elements).
+constexpr uint32_t kKcapLimit = 4096;
+// Upper bound of workgroups any sweep variant launches (size of the partial-max arrays).
+constexpr uint32_t kMaxSweepBlocks = 4096;
+// Upper bound of workgroups of the gamma scan.
+constexpr uint32_t kMaxScanBlocks = 2048;
+
+// Device-resident solver state, one per in-flight signal.  Written by single-workgroup
+// kernels, read by everything else; lives in global memory (L2-resident).
+struct DevState {
+    uint32_t done;        // 1 once the solve has terminated; every kernel becomes a no-op
+    uint32_t status;      // ss_hip_status raised on the device (capacity overflow)
+    uint32_t iter;        // homotopy iterations performed (ss::homotopy_report::iter)
+    uint32_t K;           // current support size |Gamma|
+    uint32_t ntouched;    // columns that were ever in the support (x may be non-zero there)
+    uint32_t idx;         // column toggled by the current iteration
+    uint32_t rank;        // its rank in the sorted support
+    uint32_t added;       // 1 insert, 0 remove
+    uint32_t cur;         // which of the two inverse / support buffers is current
+    uint32_t done_round;  // round (1-based) in which `done` was raised
+    double   c_inf;       // lambda = ||c||_inf (ss::homotopy_report::solution_error)
+    double   gamma;       // step length of the current iteration
+    double   dot;         // a_idx . a_idx of the column being inserted
+};
+
+template <typename T>
+struct Workspace {
+    // per-solve vectors
+    T* y = nullptr;        // [ldm]      signal, zero padded
+    T* rhs = nullptr;      // [2][ldm]   r = y - A x  and  p = A d   (zero padded)
+    T* c = nullptr;        // [n_pad]    correlations A^T r
+    T* q = nullptr;        // [n_pad]    A^T A d
+    T* x = nullptr;        // [n_pad]    dense solution
+    T* d = nullptr;        // [n_pad]    dense direction (non-zero on Gamma only)
+    uint8_t* insup = nullptr;   // [n_pad] membership flags of Gamma
+    // sweep / scan partial reductions
+    T* pmax_val = nullptr;       uint32_t* pmax_idx = nullptr;   // [kMaxSweepBlocks]
+    T* pmin_val = nullptr;       uint32_t* pmin_idx = nullptr;   // [kMaxScanBlocks]
+    // active set
+    uint32_t kcap = 0;
+    uint32_t* gam = nullptr;      // [2][kcap] sorted support (lambda_indices), ping-pong with inv
+    uint32_t* touched = nullptr;  // [2][kcap] sorted, every column ever inserted
+    T* inv[2] = { nullptr, nullptr };  // [kcap][kcap] ping-pong (A_S^T A_S)^-1
+    T* u1 = nullptr;              // [kcap]
+    T* u2 = nullptr;              // [kcap]
+    T* sgn = nullptr;             // [kcap]
+    DevState* st = nullptr;
+};
+
+struct SweepConfig {
+    int variant = 0;
+};
+
+}  // namespace sship
+
+struct ss_hip_ctx {
+    int device = 0;
+    int is_f64 = 0;
+    size_t m = 0, n = 0;
+    uint32_t ldm = 0;        // column pitch in elements (multiple of kRowPad)
+    uint32_t n_pad = 0;      // padded column count (multiple of kColPad)
+    void* At = nullptr;      // [n_pad][ldm] column-contiguous device copy of A
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    size_t lds_per_block = 65536;
+
+    // options
+    int sweep_variant = 0;
+    int lookahead = 4;
+    int strict_sign = 0;
+    int profiling = 0;
+
+    // workspace (type-erased; Workspace<float> or Workspace<double>)
+    void* ws = nullptr;
+    uint32_t* host_flags = nullptr;   // pinned: done flags polled by the host loop
+    std::vector<hipEvent_t> flag_events;
+    std::vector<hipEvent_t> prof_events;   // pairs (start, stop) for sweeps of the current solve
+    std::vector<int> prof_kind;            // 2 = fused sweep, 1 = single-RHS sweep
+    hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;
+
+    ss_hip_stats stats{};
+};
+
+namespace sship {
+
+// ---- launchers implemented in sweep.hip ----------------------------------------
+// [out0, out1] = A^T [rhs0, rhs1]; out1 == nullptr selects the single-RHS kernel.
+// pmax_* receive one (max |out0|, first index) pair per workgroup; *nblocks_out is the
+// number of pairs written.  st may be nullptr (standalone sweep).
+template <typename T>
+hipError_t launch_sweep(const ss_hip_ctx* ctx, const T* rhs, int nrhs, T* out0, T* out1,
+                        T* pmax_val, uint32_t* pmax_idx, uint32_t* nblocks_out,
+                        const DevState* st);
+size_t sweep_max_lds_bytes();
+
+// ---- launchers implemented in activeset.hip ------------------------------------
+template <typename T>
+hipError_t launch_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsweep_blocks, T tol);
+template <typename T>
+hipError_t launch_rp(const ss_hip_ctx* ctx, Workspace<T>& ws);
+template <typename T>
+hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round,
+                                 uint32_t nsweep_blocks, T tol, uint32_t max_iter);
+template <typename T>
+hipError_t launch_gemv_n(const ss_hip_ctx* ctx, const T* x_dev, T* y_dev);
+
+// ---- helpers implemented in homotopy.hip ---------------------------------------
+void set_err(char* err, size_t errlen, const std::string& msg);
+
+}  // namespace sship

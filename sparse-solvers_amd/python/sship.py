@@ -1,0 +1,249 @@
+"""ctypes binding of the C-ABI in include/ss_hip.h (libss_hip.so).
+
+Used by bench.py and the GPU parity tests so that they exercise exactly the symbols a
+maintainer of the reference would bind.  There is no CPU fallback
+here: if the library or a GPU is missing the calls raise.
+
+Arrays may be numpy arrays (host) or anything exposing ``data_ptr()`` / ``__cuda_array_interface__``
+(device memory, e.g. torch tensors on ``cuda``) — the library asks the HIP runtime where
+a pointer lives.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libss_hip.so")
+
+# every symbol include/ss_hip.h declares
+SYMBOLS = [
+    "ss_hip_device_count", "ss_hip_version",
+    "ss_hip_homotopy_create_f32", "ss_hip_homotopy_create_f64", "ss_hip_homotopy_destroy",
+    "ss_hip_homotopy_solve_f32", "ss_hip_homotopy_solve_f64",
+    "ss_hip_homotopy_solve_batch_f32", "ss_hip_homotopy_solve_batch_f64",
+    "ss_hip_gemv_t_f32", "ss_hip_gemv_t_f64",
+    "ss_hip_reconstruct_f32", "ss_hip_reconstruct_f64",
+    "ss_hip_set_profiling", "ss_hip_get_stats", "ss_hip_reset_stats",
+    "ss_hip_set_option", "ss_hip_get_option", "ss_hip_ctx_info",
+]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("solves", ctypes.c_uint64),
+        ("iterations", ctypes.c_uint64),
+        ("sweep_launches", ctypes.c_uint64),
+        ("sweep_ms", ctypes.c_double),
+        ("sweep_bytes", ctypes.c_uint64),
+        ("sweep1_launches", ctypes.c_uint64),
+        ("sweep1_ms", ctypes.c_double),
+        ("sweep1_bytes", ctypes.c_uint64),
+        ("solve_ms", ctypes.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libss_hip.so (raises OSError if it was not built — no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libss_hip.so not built: run `python sparse-solvers_amd/build.py` "
+                      "(expected at %s)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, pd, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_ssize_t, ctypes.c_uint32
+    cp = ctypes.c_char_p
+    L.ss_hip_device_count.restype = ctypes.c_int
+    L.ss_hip_version.restype = ctypes.c_char_p
+    for suf, ct in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
+        f = getattr(L, "ss_hip_homotopy_create_" + suf)
+        f.restype = vp
+        f.argtypes = [vp, sz, sz, pd, pd, ctypes.c_int, cp, sz]
+        f = getattr(L, "ss_hip_homotopy_solve_" + suf)
+        f.restype = ctypes.c_int
+        f.argtypes = [vp, vp, pd, ct, u32, vp, pd, ctypes.POINTER(u32),
+                      ctypes.POINTER(ctypes.c_double), cp, sz]
+        f = getattr(L, "ss_hip_homotopy_solve_batch_" + suf)
+        f.restype = ctypes.c_int
+        f.argtypes = [vp, vp, sz, pd, pd, ct, u32, vp, pd, pd, vp, vp, cp, sz]
+        f = getattr(L, "ss_hip_gemv_t_" + suf)
+        f.restype = ctypes.c_int
+        f.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), cp, sz]
+        f = getattr(L, "ss_hip_reconstruct_" + suf)
+        f.restype = ctypes.c_int
+        f.argtypes = [vp, vp, vp, cp, sz]
+    L.ss_hip_homotopy_destroy.restype = None
+    L.ss_hip_homotopy_destroy.argtypes = [vp]
+    L.ss_hip_set_profiling.argtypes = [vp, ctypes.c_int]
+    L.ss_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.ss_hip_reset_stats.argtypes = [vp]
+    L.ss_hip_set_option.argtypes = [vp, cp, ctypes.c_long]
+    L.ss_hip_get_option.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_long)]
+    L.ss_hip_ctx_info.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(sz),
+                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    _lib = L
+    return L
+
+
+def device_count():
+    return lib().ss_hip_device_count()
+
+
+def version():
+    return lib().ss_hip_version().decode()
+
+
+class SsHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ss_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _describe(a):
+    """-> (pointer, shape, strides_in_elements, np.dtype, keepalive)"""
+    if isinstance(a, np.ndarray):
+        item = a.dtype.itemsize
+        return a.ctypes.data, a.shape, tuple(s // item for s in a.strides), a.dtype, a
+    if hasattr(a, "data_ptr"):      # torch tensor (host or device)
+        import torch
+        dt = {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64)}[a.dtype]
+        return a.data_ptr(), tuple(a.shape), tuple(a.stride()), dt, a
+    raise TypeError("expected a numpy array or a torch tensor")
+
+
+def _suffix(dt):
+    if dt == np.float32:
+        return "f32", ctypes.c_float
+    if dt == np.float64:
+        return "f64", ctypes.c_double
+    raise TypeError("only float32 / float64 are supported, got %s" % dt)
+
+
+class Homotopy:
+    """A device-resident copy of the sensing matrix + the solver loop (one HIP stream)."""
+
+    def __init__(self, A, device=0):
+        ptr, shape, strides, dt, keep = _describe(A)
+        if len(shape) != 2:
+            raise ValueError("A must be 2-D")
+        self.suffix, self.ctype = _suffix(dt)
+        self.dtype = dt
+        self.m, self.n = int(shape[0]), int(shape[1])
+        err = ctypes.create_string_buffer(512)
+        fn = getattr(lib(), "ss_hip_homotopy_create_" + self.suffix)
+        self._h = fn(ptr, self.m, self.n, strides[0], strides[1], device, err, len(err))
+        if not self._h:
+            raise SsHipError(-1, err.value.decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ss_hip_homotopy_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, err):
+        if rc != 0:
+            raise SsHipError(rc, err.value.decode())
+
+    def solve(self, y, tolerance=None, max_iterations=100, out=None):
+        """-> (x, iter, solution_error); defaults mirror the reference binding
+        (tolerance = eps(T)*10, max_iterations = 100: binding.cpp:94-95)."""
+        yp, yshape, ystr, ydt, keep = _describe(y)
+        if ydt != self.dtype:
+            raise TypeError("dtype of y (%s) does not match the matrix (%s)" % (ydt, self.dtype))
+        if len(yshape) != 1 or yshape[0] != self.m:
+            raise ValueError("y must have length m = %d" % self.m)
+        if tolerance is None:
+            tolerance = float(np.finfo(self.dtype).eps) * 10
+        if out is None:
+            out = np.empty(self.n, dtype=self.dtype)
+        xp, xshape, xstr, xdt, keepx = _describe(out)
+        if xdt != self.dtype or len(xshape) != 1 or xshape[0] != self.n:
+            raise ValueError("out must be a length-n vector of the matrix dtype")
+        it = ctypes.c_uint32(0)
+        e = ctypes.c_double(0.0)
+        err = ctypes.create_string_buffer(512)
+        fn = getattr(lib(), "ss_hip_homotopy_solve_" + self.suffix)
+        rc = fn(self._h, yp, ystr[0], self.ctype(tolerance), int(max_iterations), xp, xstr[0],
+                ctypes.byref(it), ctypes.byref(e), err, len(err))
+        self._check(rc, err)
+        return out, int(it.value), float(e.value)
+
+    def solve_batch(self, Y, tolerance=None, max_iterations=100):
+        """Y: (B, m) -> X (B, n), iters (B,), errors (B,)"""
+        Yp, shape, strides, dt, keep = _describe(Y)
+        if dt != self.dtype or len(shape) != 2 or shape[1] != self.m:
+            raise ValueError("Y must be (B, m) of the matrix dtype")
+        B = int(shape[0])
+        if tolerance is None:
+            tolerance = float(np.finfo(self.dtype).eps) * 10
+        X = np.empty((B, self.n), dtype=self.dtype)
+        iters = np.zeros(B, dtype=np.uint32)
+        errs = np.zeros(B, dtype=np.float64)
+        err = ctypes.create_string_buffer(512)
+        fn = getattr(lib(), "ss_hip_homotopy_solve_batch_" + self.suffix)
+        rc = fn(self._h, Yp, B, strides[0], strides[1], self.ctype(tolerance), int(max_iterations),
+                X.ctypes.data, self.n, 1, iters.ctypes.data, errs.ctypes.data, err, len(err))
+        self._check(rc, err)
+        return X, iters, errs
+
+    def gemv_t(self, r, repeats=1):
+        """c = A^T r on the device copy -> (c, mean kernel ms)"""
+        rp, shape, strides, dt, keep = _describe(r)
+        if dt != self.dtype or len(shape) != 1 or shape[0] != self.m or strides[0] != 1:
+            raise ValueError("r must be a contiguous length-m vector of the matrix dtype")
+        c = np.empty(self.n, dtype=self.dtype)
+        ms = ctypes.c_float(0.0)
+        err = ctypes.create_string_buffer(512)
+        fn = getattr(lib(), "ss_hip_gemv_t_" + self.suffix)
+        self._check(fn(self._h, rp, c.ctypes.data, int(repeats), ctypes.byref(ms), err, len(err)), err)
+        return c, float(ms.value)
+
+    def reconstruct(self, x):
+        """y = A x on the device copy (ss::reconstruct_signal)."""
+        xp, shape, strides, dt, keep = _describe(x)
+        if dt != self.dtype or len(shape) != 1 or shape[0] != self.n or strides[0] != 1:
+            raise ValueError("x must be a contiguous length-n vector of the matrix dtype")
+        y = np.empty(self.m, dtype=self.dtype)
+        err = ctypes.create_string_buffer(512)
+        fn = getattr(lib(), "ss_hip_reconstruct_" + self.suffix)
+        self._check(fn(self._h, xp, y.ctypes.data, err, len(err)), err)
+        return y
+
+    def set_profiling(self, on):
+        lib().ss_hip_set_profiling(self._h, 1 if on else 0)
+
+    def reset_stats(self):
+        lib().ss_hip_reset_stats(self._h)
+
+    def stats(self):
+        s = Stats()
+        lib().ss_hip_get_stats(self._h, ctypes.byref(s))
+        return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def set_option(self, key, value):
+        rc = lib().ss_hip_set_option(self._h, key.encode(), int(value))
+        if rc != 0:
+            raise SsHipError(rc, "unknown option %r" % key)
+
+    def get_option(self, key):
+        v = ctypes.c_long(0)
+        rc = lib().ss_hip_get_option(self._h, key.encode(), ctypes.byref(v))
+        if rc != 0:
+            raise SsHipError(rc, "unknown option %r" % key)
+        return int(v.value)

@@ -1,0 +1,309 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): the HIP path, called through the
+C-ABI (include/ss_hip.h via sparse-solvers_amd/python/sship.py), against
+  - the CPU oracle on identical seeded inputs (support bit-exact, coefficients within
+    1e-5 (fp32) / 1e-10 (fp64) relative to max|x|, equal iteration count),
+  - the committed golden vectors of the reference's numpy solver,
+  - the reference's own test cases (tests/ref_cases.py),
+  - size-independent properties at BASELINE.json's full size.
+Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import ref_cases
+from conftest import make_gaussian_problem
+
+pytestmark = pytest.mark.gpu
+
+F32_EPS = float(np.finfo(np.float32).eps)
+F64_EPS = float(np.finfo(np.float64).eps)
+RTOL = {np.dtype(np.float32): 1e-5, np.dtype(np.float64): 1e-10}
+
+
+@pytest.fixture(scope="module")
+def sship():
+    import sship as mod
+    assert mod.device_count() >= 1, "no HIP device visible"
+    return mod
+
+
+def hip_solve_factory(sship):
+    def solve(A, y, tol, max_iter):
+        with sship.Homotopy(A) as h:
+            return h.solve(np.asarray(y, dtype=A.dtype), tol, max_iter)
+    return solve
+
+
+def hip_solve_default_factory(sship):
+    def solve(A, y):
+        with sship.Homotopy(A) as h:
+            return h.solve(np.asarray(y, dtype=A.dtype))
+    return solve
+
+
+def assert_parity(xg, itg, eg, xo, ito, eo, dtype, rtol=None):
+    rtol = RTOL[np.dtype(dtype)] if rtol is None else rtol
+    assert itg == ito, "iteration count differs: hip %d vs oracle %d" % (itg, ito)
+    assert np.array_equal(np.nonzero(xg)[0], np.nonzero(xo)[0]), "support differs"
+    scale = np.abs(xo).max()
+    assert np.abs(xg.astype(np.float64) - xo.astype(np.float64)).max() <= rtol * scale
+    assert abs(eg - eo) <= max(rtol * max(abs(eo), 1.0), 10 * rtol * scale)
+
+
+# ---------------------------------------------------------------- oracle parity
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(64, 256, 6), (128, 1000, 10), (300, 1500, 20), (512, 4096, 24)])
+def test_gaussian_vs_oracle(sship, shape, dtype):
+    m, n, k = shape
+    A, y, x0, sup = make_gaussian_problem(100 + m, m, n, k, dtype)
+    tol = 1e-3 if dtype == np.float32 else 1e-9
+    xo, ito, eo = oracle.homotopy(A, y, tol, 4 * k)
+    with sship.Homotopy(A) as h:
+        xg, itg, eg = h.solve(y, tol, 4 * k)
+    assert_parity(xg, itg, eg, xo, ito, eo, dtype)
+    assert np.array_equal(np.nonzero(xg)[0], sup)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_layouts_vs_oracle(sship, dtype):
+    """row-major, padded row-major (lda > n), column-major and a device-resident matrix."""
+    A, y, _, _ = make_gaussian_problem(7, 96, 700, 9, dtype)
+    tol = 1e-3 if dtype == np.float32 else 1e-9
+    xo, ito, eo = oracle.homotopy(A, y, tol, 60)
+    padded = np.zeros((96, 760), dtype=dtype)
+    padded[:, 30:730] = A
+    views = [A, padded[:, 30:730], np.asfortranarray(A), np.ascontiguousarray(A[:, ::-1])[:, ::-1]]
+    for v in views:
+        with sship.Homotopy(v) as h:
+            xg, itg, eg = h.solve(y, tol, 60)
+        assert_parity(xg, itg, eg, xo, ito, eo, dtype)
+    import torch
+    At = torch.from_numpy(np.ascontiguousarray(A)).to("cuda:0")
+    yt = torch.from_numpy(y).to("cuda:0")
+    xt = torch.empty(A.shape[1], dtype=At.dtype, device="cuda:0")
+    with sship.Homotopy(At) as h:
+        _, itg, eg = h.solve(yt, tol, 60, out=xt)
+    torch.cuda.synchronize()
+    assert_parity(xt.cpu().numpy(), itg, eg, xo, ito, eo, dtype)
+
+
+def test_strided_vectors(sship):
+    A, y, _, _ = make_gaussian_problem(8, 64, 300, 5, np.float64)
+    xo, ito, eo = oracle.homotopy(A, y, 1e-9, 40)
+    ybuf = np.zeros(2 * 64)
+    ybuf[::2] = y
+    xbuf = np.full(3 * 300, -7.0)
+    with sship.Homotopy(A) as h:
+        _, itg, eg = h.solve(ybuf[::2], 1e-9, 40, out=xbuf[::3])
+    assert_parity(xbuf[::3], itg, eg, xo, ito, eo, np.float64)
+    assert np.all(xbuf.reshape(-1, 3)[:, 1:] == -7.0)
+
+
+@pytest.mark.parametrize("name", ["gauss_f64_40x120_k4", "gauss_f32_64x256_k6", "gauss_f64_96x384_k8",
+                                  "gauss_f32_128x512_k10", "removal_f64_24x64_seed1000",
+                                  "removal_f32_24x64_seed1000", "readme_toy_f64_10x10", "main_py_5x5_f32"])
+def test_golden(sship, golden, name):
+    """committed outputs of the reference's numpy solver (tests/golden/make_golden.py)"""
+    g = golden[name]
+    A, y, tol, xr = g["A"], g["y"], float(g["tol"]), g["x"]
+    with sship.Homotopy(A) as h:
+        xg, itg, eg = h.solve(y, tol, 4000)
+    assert itg == int(g["iters"])
+    assert eg <= tol
+    assert np.array_equal(np.nonzero(xg)[0], np.nonzero(xr)[0])
+    rtol = {"removal_f32_24x64_seed1000": 5e-4}.get(name, RTOL[A.dtype])
+    assert np.abs(xg - xr).max() / np.abs(xr).max() <= rtol
+    # and against the oracle on the same input
+    xo, ito, eo = oracle.homotopy(A, y, tol, 4000)
+    assert_parity(xg, itg, eg, xo, ito, eo, A.dtype, rtol=rtol)
+
+
+def test_removal_path_vs_oracle(sship):
+    """paths with removals: small m relative to k"""
+    found = 0
+    for seed in range(1000, 1012):
+        rng = np.random.default_rng(seed)
+        m, n, k = 24, 64, 10
+        A = rng.standard_normal((m, n)) / np.sqrt(m)
+        x0 = np.zeros(n)
+        x0[rng.choice(n, k, replace=False)] = 1 + np.abs(rng.standard_normal(k))
+        y = A @ x0
+        xo, ito, eo, tr = oracle.homotopy(A, y, 1e-6, 200, trace=True)
+        if not (tr["added"] == 0).any() or ito >= 200:
+            continue
+        found += 1
+        with sship.Homotopy(A) as h:
+            xg, itg, eg = h.solve(y, 1e-6, 200)
+        assert_parity(xg, itg, eg, xo, ito, eo, np.float64, rtol=1e-8)
+    assert found >= 2
+
+
+def test_max_iter_and_errors(sship):
+    A, y, _, _ = make_gaussian_problem(9, 64, 256, 8, np.float32)
+    with sship.Homotopy(A) as h:
+        for mi in (1, 2, 5):
+            xo, ito, eo = oracle.homotopy(A, y, 1e-3, mi)
+            xg, itg, eg = h.solve(y, 1e-3, mi)
+            assert ito == mi
+            assert_parity(xg, itg, eg, xo, ito, eo, np.float32)
+        with pytest.raises(sship.SsHipError):
+            h.solve(y, 1e-3, 0)
+        with pytest.raises(sship.SsHipError):
+            h.solve(y, 1.0, 5)
+        with pytest.raises(sship.SsHipError):
+            h.solve(y, F32_EPS / 2, 5)
+        with pytest.raises(TypeError):
+            h.solve(y.astype(np.float64), 1e-3, 5)
+
+
+def test_first_step_sign_quirk(sship):
+    """bug-for-bug default vs strict_sign option (homotopy-cpu.cpp:223-227)"""
+    A, y, x0, sup = make_gaussian_problem(7, 64, 256, 5, np.float64)
+    with sship.Homotopy(A) as h:
+        xo, ito, eo = oracle.homotopy(A, -y, 1e-8, 50)
+        xg, itg, eg = h.solve(-y, 1e-8, 50)
+        assert itg == ito
+        assert np.allclose(xg, xo, rtol=0, atol=1e-6 * max(1.0, np.abs(xo).max()))
+        h.set_option("strict_sign", 1)
+        xs, its, es = h.solve(-y, 1e-8, 50)
+        assert np.allclose(xs, -x0, atol=1e-8)
+
+
+def test_repeated_solves_are_deterministic(sship):
+    A, y, _, _ = make_gaussian_problem(10, 128, 2048, 12, np.float32)
+    with sship.Homotopy(A) as h:
+        a = h.solve(y, 1e-3, 64)
+        b = h.solve(y, 1e-3, 64)
+        for v in range(0, 12):
+            h.set_option("sweep_variant", v)
+            c = h.solve(y, 1e-3, 64)
+            assert c[1] == a[1] and np.array_equal(c[0], a[0]), "variant %d changes the result" % v
+    assert a[1] == b[1] and a[2] == b[2] and np.array_equal(a[0], b[0])
+
+
+def test_batch_entry(sship):
+    A, _, _, _ = make_gaussian_problem(11, 96, 512, 6, np.float32)
+    Y = []
+    for s in range(5):
+        rng = np.random.default_rng(500 + s)
+        x0 = np.zeros(512)
+        x0[rng.choice(512, 6, replace=False)] = 1 + np.abs(rng.standard_normal(6))
+        Y.append((A.astype(np.float64) @ x0).astype(np.float32))
+    Y = np.stack(Y)
+    with sship.Homotopy(A) as h:
+        X, iters, errs = h.solve_batch(Y, 1e-3, 40)
+    for b in range(5):
+        xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 40)
+        assert_parity(X[b], int(iters[b]), float(errs[b]), xo, ito, eo, np.float32)
+
+
+# ---------------------------------------------------------------- sweep kernel
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(5, 5), (100, 25), (257, 1000), (1024, 777), (8192, 300), (20000, 130)])
+def test_sweep_vs_oracle(sship, shape, dtype):
+    m, n = shape
+    rng = np.random.default_rng(m * 7 + n)
+    A = rng.standard_normal((m, n)).astype(dtype)
+    r = rng.standard_normal(m).astype(dtype)
+    want = A.astype(np.float64).T @ r.astype(np.float64)
+    co = oracle.gemv_t(A, r)
+    tol = (3e-6 if dtype == np.float32 else 1e-14) * np.sqrt(m) * np.abs(want).max()
+    with sship.Homotopy(A) as h:
+        for v in range(0, 12):
+            h.set_option("sweep_variant", v)
+            cg, ms = h.gemv_t(r)
+            assert np.abs(cg - want).max() <= tol, "variant %d" % v
+            assert np.abs(cg.astype(np.float64) - co).max() <= 2 * tol
+        xs = np.zeros(n, dtype=dtype)
+        xs[rng.choice(n, min(n, 7), replace=False)] = rng.standard_normal(min(n, 7)).astype(dtype)
+        yg = h.reconstruct(xs)
+        assert np.allclose(yg, A.astype(np.float64) @ xs, rtol=1e-5 if dtype == np.float32 else 1e-12,
+                           atol=1e-5 if dtype == np.float32 else 1e-12)
+
+
+def test_sweep_linearity_full_size(sship):
+    """BASELINE.json configs[1] shape (8192 x 65536 fp32): linearity + a sampled exact check."""
+    import torch
+    m, n = 8192, 65536
+    g = torch.Generator(device="cuda:0").manual_seed(1234)
+    A = (torch.randn((m, n), generator=g, device="cuda:0", dtype=torch.float32) / np.sqrt(m))
+    rng = np.random.default_rng(0)
+    r1 = rng.standard_normal(m).astype(np.float32)
+    r2 = rng.standard_normal(m).astype(np.float32)
+    with sship.Homotopy(A) as h:
+        c1, _ = h.gemv_t(r1)
+        c2, _ = h.gemv_t(r2)
+        c12, ms = h.gemv_t((r1 + r2).astype(np.float32))
+        e, _ = h.gemv_t(np.eye(1, m, 17, dtype=np.float32)[0])
+    assert np.abs(c12 - (c1 + c2)).max() <= 2e-5 * np.abs(c12).max()
+    # A^T e_17 is row 17 of A, exactly
+    assert np.array_equal(e, A[17].cpu().numpy())
+    cols = rng.choice(n, 64, replace=False)
+    want = A[:, torch.from_numpy(cols).to("cuda:0")].double().T @ torch.from_numpy(r1).double().to("cuda:0")
+    assert np.abs(c1[cols] - want.cpu().numpy()).max() <= 1e-5 * np.abs(c1).max()
+
+
+def test_full_size_recovery(sship):
+    """configs[1]: single signal, A 8192 x 65536 fp32 Gaussian, k = 64.  The oracle would
+    need minutes here, so check the domain's own invariants: exact support recovery,
+    coefficients, iteration count == k (no removals since m >> k ln(n/k)), residual."""
+    import torch
+    m, n, k = 8192, 65536, 64
+    g = torch.Generator(device="cuda:0").manual_seed(1234)
+    A = (torch.randn((m, n), generator=g, device="cuda:0", dtype=torch.float32) / np.sqrt(m))
+    rng = np.random.default_rng(1235)
+    sup = np.sort(rng.choice(n, k, replace=False))
+    coef = 1.0 + np.abs(rng.standard_normal(k))
+    As = A[:, torch.from_numpy(sup).to("cuda:0")].double()
+    y = (As @ torch.from_numpy(coef).to("cuda:0")).float().contiguous()
+    with sship.Homotopy(A) as h:
+        x, it, err = h.solve(y, 1e-3, 256)
+        assert it == k
+        assert err <= 1e-3
+        assert np.array_equal(np.nonzero(x)[0], sup)
+        assert np.abs(x[sup] - coef).max() <= 1e-4 * coef.max()
+        recon = h.reconstruct(x)
+    assert np.abs(recon - y.cpu().numpy()).max() <= 1e-4
+
+
+# ---------------------------------------------------------------- the reference's tests
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ref_smoke(sship, dtype):
+    ref_cases.smoke(hip_solve_factory(sship), dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ref_smoke_column_subset(sship, dtype):
+    ref_cases.smoke_column_subset(hip_solve_factory(sship), dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ref_noisy_signal(sship, dtype):
+    ref_cases.noisy_signal(hip_solve_factory(sship), dtype)
+
+
+@pytest.mark.parametrize("shape", [(100, 25), (25, 100)])
+def test_ref_noisy_patterns(sship, shape):
+    ref_cases.noisy_patterns(hip_solve_factory(sship), shape[0], shape[1])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cfg", [(10, 10, .1, .1, 10), (25, 10, .1, .1, 50), (10, 25, .05, .05, 50)])
+def test_ref_permutations(sship, cfg, dtype):
+    M, N, sn, an, skip = cfg
+    ref_cases.permutations(hip_solve_factory(sship), M, N, dtype, sn, an, skip)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ref_binding_smoke(sship, dtype):
+    ref_cases.binding_smoke(hip_solve_default_factory(sship), dtype)
+
+
+def test_ref_binding_layouts(sship):
+    ref_cases.binding_row_subset(hip_solve_default_factory(sship))
+    ref_cases.binding_col_subset(hip_solve_default_factory(sship))
+    ref_cases.binding_transpose(hip_solve_default_factory(sship))
