@@ -48,6 +48,28 @@ def build(force=False):
 _lib = None
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask and cgroup quota, capped at 16
+    (the GPU box advertises 128 logical CPUs but grants a share of 16 per GPU; running
+    128 OpenMP threads there oversubscribes ~8x).  SS_ORACLE_THREADS overrides."""
+    if os.environ.get("SS_ORACLE_THREADS"):
+        return max(1, int(os.environ["SS_ORACLE_THREADS"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 16))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -88,6 +110,8 @@ def lib():
         L.ss_oracle_rank_index_size.restype = sz
         L.ss_oracle_rank_index_size.argtypes = [vp]
         L.ss_oracle_num_threads.restype = ctypes.c_int
+        L.ss_oracle_set_num_threads.argtypes = [ctypes.c_int]
+        L.ss_oracle_set_num_threads(usable_cpus())
         _lib = L
     return _lib
 

@@ -44,6 +44,15 @@ int ss_oracle_num_threads(void)
 #endif
 }
 
+void ss_oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 void ss_oracle_erase_last_rowcol_f32(float* A, size_t M, size_t N)
 {
     erase_last_rowcol_f32(A, M, N);

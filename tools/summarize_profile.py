@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Summarises a gpurun_out/prof_<tag>/ directory produced by tools/profile_bench.sh into
+profiles/<tag>_* (tracked): per-kernel durations from the rocprofv3 kernel trace and the
+HBM traffic of the fused sweep from the PMC passes.
+
+gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE is reported in KiB and counts
+exactly half of the bytes of a wide coalesced streaming read, so
+    read bytes = FETCH_SIZE * 1024 * 2;     write bytes = WRITE_SIZE * 1024.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0]
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    out = {"tag": tag}
+    lines = ["# rocprofv3 summary `%s`" % tag, "",
+             "command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`", ""]
+
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+    trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+    if trace:
+        rows = list(csv.DictReader(open(trace[0])))
+        per = {}
+        for r in rows:
+            n = short(r["Kernel_Name"])
+            if "sship" not in n and "k_relayout" not in n:
+                continue
+            per.setdefault(n, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        lines += ["| kernel | launches | mean us (all) | launches doing work | mean us (working) |", "|---|---|---|---|---|"]
+        kern = {}
+        for n, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            # launches enqueued after the device raised `done` return at once (a few us)
+            work = [x for x in v if x > 20000] if "k_sweep" in n else v
+            kern[n] = {"launches": len(v), "mean_us_all": sum(v) / len(v) / 1e3,
+                       "working": len(work), "mean_us_working": sum(work) / max(1, len(work)) / 1e3}
+            lines.append("| `%s` | %d | %.2f | %d | %.2f |" % (n, len(v), kern[n]["mean_us_all"],
+                                                            len(work), kern[n]["mean_us_working"]))
+        out["kernels"] = kern
+        lines.append("")
+
+    traffic = {}
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = glob.glob(os.path.join(src, "pmc_" + kind, "*", "*_counter_collection.csv"))
+        if not f:
+            continue
+        rows = list(csv.DictReader(open(f[0])))
+        vals = [float(r["Counter_Value"]) for r in rows
+                if "k_sweep<float, 2" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        # drop the no-op launches (solve already finished): they move (almost) nothing
+        thresh = 0.5 * max(vals) if vals else 0
+        vals = [v for v in vals if v >= thresh]
+        if vals:
+            traffic[counter] = {"launches": len(vals), "mean_raw_KiB": statistics.mean(vals)}
+    if traffic:
+        rd = traffic.get("FETCH_SIZE", {}).get("mean_raw_KiB", 0.0) * 1024 * 2
+        wr = traffic.get("WRITE_SIZE", {}).get("mean_raw_KiB", 0.0) * 1024
+        out["sweep2_hbm_read_bytes_per_launch"] = rd
+        out["sweep2_hbm_write_bytes_per_launch"] = wr
+        out["sweep2_hbm_bytes_per_launch"] = rd + wr
+        out["pmc_raw"] = traffic
+        alg = 8192 * 65536 * 4 + 2 * 8192 * 4 + 2 * 65536 * 4
+        lines += ["## HBM traffic of the fused sweep (PMC, separate passes)", "",
+                  "- FETCH_SIZE mean %.1f KiB x 1024 x 2 (gfx950 correction) = %.0f B read" % (
+                      traffic.get("FETCH_SIZE", {}).get("mean_raw_KiB", 0.0), rd),
+                  "- WRITE_SIZE mean %.1f KiB x 1024 = %.0f B written" % (
+                      traffic.get("WRITE_SIZE", {}).get("mean_raw_KiB", 0.0), wr),
+                  "- algorithmic bytes per launch: %d; traffic / algorithmic = %.4f" % (alg, (rd + wr) / alg), ""]
+        json.dump({"sweep2_hbm_bytes_per_launch": rd + wr, "source": "profiles/%s_summary.md" % tag,
+                   "read": rd, "write": wr}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    log = os.path.join(src, "bench_trace.log")
+    if os.path.exists(log):
+        for ln in open(log):
+            if ln.startswith("{"):
+                lines += ["## bench line of the traced run", "", "```", ln.strip(), "```", ""]
+    open(os.path.join(dst, tag + "_summary.md"), "w").write("\n".join(lines))
+    json.dump(out, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
