@@ -1,0 +1,72 @@
+/*
+ * ss/policies.h — solver policies (reference: include/ss/policies.h:21-54).
+ *
+ * homotopy_policy keeps the reference's interface (report_type, state_type<T>, run x
+ * {float,double}); its state is no longer the bare view of A but an owning object that
+ * holds the MI355X-resident copy of the sensing matrix (the policy design allows a
+ * non-trivial state: the reference's own irls_state, policies.h:77-85).  The copy is made
+ * when the solver is constructed; later mutation of the caller's A is not observed.
+ */
+#pragma once
+
+#include "ss/ndspan.h"
+#include <kernelpp/types.h>
+
+#include <cstdint>
+#include <string>
+
+struct ss_hip_ctx;   /* include/ss_hip.h */
+
+namespace ss
+{
+    /* Homotopy ------------------------------------------------------------ */
+
+    struct homotopy_report
+    {
+        /* The number of iterations performed. */
+        uint32_t iter;
+
+        /* The solution error */
+        double solution_error;
+    };
+
+    inline bool operator== (const homotopy_report&, const homotopy_report&) { return false; }
+
+    /* Device-side state of one homotopy solver: the context of include/ss_hip.h */
+    template <typename T>
+    class homotopy_state
+    {
+      public:
+        /* uploads (and re-lays-out) the m x n view A to HIP device `device` */
+        explicit homotopy_state(const ndspan<T, 2> A, int device = 0);
+        ~homotopy_state();
+
+        homotopy_state(const homotopy_state&) = delete;
+        homotopy_state& operator=(const homotopy_state&) = delete;
+
+        ss_hip_ctx* ctx() const { return _ctx; }
+        size_t rows() const { return _m; }
+        size_t cols() const { return _n; }
+        /* non-empty when construction failed (no device, out of memory, ...) */
+        const std::string& error() const { return _error; }
+
+      private:
+        ss_hip_ctx* _ctx;
+        size_t      _m, _n;
+        std::string _error;
+    };
+
+    /* A solver policy which implements the homotopy method on an MI355X */
+    struct homotopy_policy
+    {
+        using report_type = homotopy_report;
+
+        template <typename T> using state_type = homotopy_state<T>;
+
+        static kernelpp::maybe<homotopy_report> run(
+            state_type<float>&, const ndspan<float>, float, uint32_t, ndspan<float>);
+
+        static kernelpp::maybe<homotopy_report> run(
+            state_type<double>&, const ndspan<double>, double, uint32_t, ndspan<double>);
+    };
+}

@@ -1,0 +1,125 @@
+/*
+ * binding.cpp — pybind11 module `sparsesolvers.binding`, the Python surface of the
+ * reference (bindings/python/sparsesolvers/binding.cpp:114-148) for the Homotopy path:
+ *   version() -> [major, minor, patch]
+ *   HomotopyReport{iter, solution_error}
+ *   Homotopy(A: ndarray[f32|f64, 2-D, any strides])
+ *   Homotopy.solve(b, tolerance=eps(T)*10, max_iterations=100) -> (x, HomotopyReport)
+ * Errors surface as RuntimeError.  The sensing matrix is copied to the MI355X when the
+ * solver is constructed (so, unlike the reference, no dangling view of A is kept); the GIL
+ * is released while the device solves.
+ */
+#include <pybind11/pybind11.h>
+#include <pybind11/numpy.h>
+#include <pybind11/stl.h>
+
+#include <ss/ss.h>
+
+#include <array>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace py = pybind11;
+
+namespace
+{
+    /* API level of the reference this module mirrors (sparse-solvers v0.8.8) */
+    const int VERSION[3] = { 0, 8, 8 };
+
+    template <size_t N, typename T>
+    ss::ndspan<T, N> as_span(py::array_t<T>& arr)
+    {
+        if (arr.ndim() != (py::ssize_t)N) throw std::runtime_error(
+            "Unexpected number of dimensions. Expected " + std::to_string(N) + " but got "
+            + std::to_string(arr.ndim()));
+
+        std::array<size_t, N> shape;
+        std::array<size_t, N> strides;
+        for (size_t d = 0; d < N; d++) {
+            if (arr.strides(d) < 0) throw std::runtime_error(
+                "Negative strides are not supported; pass numpy.ascontiguousarray(a)");
+            shape[d] = (size_t)arr.shape(d);
+            strides[d] = (size_t)(arr.strides(d) / (py::ssize_t)sizeof(T));
+        }
+        return ss::as_span<N, T>(arr.mutable_data(), shape, strides);
+    }
+
+    template <typename R>
+    void try_throw(const kernelpp::maybe<R>& r)
+    {
+        if (r.template is<kernelpp::error>())
+            throw std::runtime_error(r.template get<kernelpp::error>().data());
+    }
+
+    struct py_homotopy
+    {
+        std::array<size_t, 2> shape;
+        std::unique_ptr<ss::homotopy<float>>  f32;
+        std::unique_ptr<ss::homotopy<double>> f64;
+    };
+
+    template <typename T> std::unique_ptr<ss::homotopy<T>>& slot(py_homotopy& s);
+    template <> std::unique_ptr<ss::homotopy<float>>&  slot<float>(py_homotopy& s)  { return s.f32; }
+    template <> std::unique_ptr<ss::homotopy<double>>& slot<double>(py_homotopy& s) { return s.f64; }
+
+    template <typename T>
+    void def_init(py::class_<py_homotopy>& cls)
+    {
+        cls.def(py::init([](py::array_t<T> A_) {
+            auto A = as_span<2>(A_);
+            auto* self = new py_homotopy{ A.shape(), nullptr, nullptr };
+            slot<T>(*self).reset(new ss::homotopy<T>(A));
+            return self;
+        }), py::arg("A"));
+    }
+
+    template <typename T>
+    void def_solve(py::class_<py_homotopy>& cls)
+    {
+        cls.def("solve",
+            [](py_homotopy& self, py::array_t<T> b, T tol, uint32_t maxiter)
+            {
+                auto& s = slot<T>(self);
+                if (!s) throw std::runtime_error(
+                    "dtype of b does not match the dtype of the sensing matrix");
+                py::array_t<T> x((py::ssize_t)self.shape[1]);
+                auto bs = as_span<1>(b);
+                auto xs = as_span<1>(x);
+                kernelpp::maybe<ss::homotopy_report> result = ss::homotopy_report{ 0u, 0.0 };
+                {
+                    py::gil_scoped_release release;
+                    result = s->solve(bs, tol, maxiter, xs);
+                }
+                try_throw(result);
+                return std::make_tuple(x, result.template get<ss::homotopy_report>());
+            },
+            "Execute the solver on the given inputs.",
+            py::arg("b").noconvert(),
+            py::arg("tolerance") = std::numeric_limits<T>::epsilon() * 10,
+            py::arg("max_iterations") = 100);
+    }
+}
+
+PYBIND11_MODULE(binding, m)
+{
+    m.doc() = "MI355X-native sparse-solvers (Homotopy l1) binding";
+    m.def("version", []() { return std::vector<int>(VERSION, VERSION + 3); },
+          "API version of sparsesolvers this module mirrors");
+
+    /* homotopy report */
+    py::class_<ss::homotopy_report>(m, "HomotopyReport")
+        .def(py::init([]() { return ss::homotopy_report{ 0u, 0.0 }; }))
+        .def_readwrite("iter", &ss::homotopy_report::iter)
+        .def_readwrite("solution_error", &ss::homotopy_report::solution_error);
+
+    /* homotopy solver */
+    auto homotopy = py::class_<py_homotopy>(m, "Homotopy");
+    def_init<float>(homotopy);
+    def_init<double>(homotopy);
+    def_solve<float>(homotopy);
+    def_solve<double>(homotopy);
+}

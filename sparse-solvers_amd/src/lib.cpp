@@ -1,0 +1,132 @@
+/*
+ * lib.cpp — C++14 host library behind include/ss/*.h.  The counterpart of the reference's
+ * src/lib.cpp:28-46 (policy -> kernel glue): homotopy_policy::run forwards to the HIP
+ * implementation through the C-ABI of include/ss_hip.h.  There is no CPU path here: if no
+ * MI355X is usable the result is the error alternative, never a silent fallback.
+ */
+#include <ss/ss.h>
+
+#include "ss_hip.h"
+
+#include <cmath>
+#include <cstddef>
+#include <vector>
+
+namespace ss
+{
+    namespace
+    {
+        inline ss_hip_ctx* create(const float* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs,
+                                  int dev, char* err, size_t len)
+        { return ss_hip_homotopy_create_f32(A, m, n, rs, cs, dev, err, len); }
+
+        inline ss_hip_ctx* create(const double* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs,
+                                  int dev, char* err, size_t len)
+        { return ss_hip_homotopy_create_f64(A, m, n, rs, cs, dev, err, len); }
+
+        inline int solve(ss_hip_ctx* c, const float* y, ptrdiff_t incy, float tol, uint32_t it,
+                         float* x, ptrdiff_t incx, uint32_t* io, double* eo, char* err, size_t len)
+        { return ss_hip_homotopy_solve_f32(c, y, incy, tol, it, x, incx, io, eo, err, len); }
+
+        inline int solve(ss_hip_ctx* c, const double* y, ptrdiff_t incy, double tol, uint32_t it,
+                         double* x, ptrdiff_t incx, uint32_t* io, double* eo, char* err, size_t len)
+        { return ss_hip_homotopy_solve_f64(c, y, incy, tol, it, x, incx, io, eo, err, len); }
+
+        template <typename T>
+        kernelpp::maybe<homotopy_report> run_hip(
+            homotopy_state<T>& st, const ndspan<T> y, T tol, uint32_t maxiter, ndspan<T> x)
+        {
+            if (!st.ctx())
+                return kernelpp::error(st.error().empty() ? "homotopy: no device context" : st.error());
+            if (y.size() != st.rows())
+                return kernelpp::error("homotopy: length of y does not match the rows of A",
+                                       kernelpp::error_code::INVALID_ARGUMENT);
+            if (x.size() != st.cols())
+                return kernelpp::error("homotopy: length of x does not match the columns of A",
+                                       kernelpp::error_code::INVALID_ARGUMENT);
+            char msg[512] = { 0 };
+            homotopy_report rep{ 0u, 0.0 };
+            const int rc = solve(st.ctx(), y.data(), (ptrdiff_t)y.strides()[0], tol, maxiter,
+                                 x.data(), (ptrdiff_t)x.strides()[0], &rep.iter, &rep.solution_error,
+                                 msg, sizeof(msg));
+            if (rc != SS_HIP_OK)
+                return kernelpp::error(msg, rc == SS_HIP_EINVAL ? kernelpp::error_code::INVALID_ARGUMENT
+                                                                : kernelpp::error_code::KERNEL_FAILED);
+            return rep;
+        }
+    }
+
+    /* Homotopy solver ----------------------------------------------------- */
+
+    template <typename T>
+    homotopy_state<T>::homotopy_state(const ndspan<T, 2> A, int device)
+        : _ctx(nullptr), _m(A.shape()[0]), _n(A.shape()[1])
+    {
+        char msg[512] = { 0 };
+        _ctx = create(A.data(), _m, _n, (ptrdiff_t)A.strides()[0], (ptrdiff_t)A.strides()[1],
+                      device, msg, sizeof(msg));
+        if (!_ctx) _error = msg;
+    }
+
+    template <typename T>
+    homotopy_state<T>::~homotopy_state()
+    {
+        if (_ctx) ss_hip_homotopy_destroy(_ctx);
+    }
+
+    template class homotopy_state<float>;
+    template class homotopy_state<double>;
+
+    kernelpp::maybe<homotopy_report> homotopy_policy::run(
+        homotopy_state<float>& st, const ndspan<float> y, float tol, uint32_t maxiter, ndspan<float> x)
+    {
+        return run_hip<float>(st, y, tol, maxiter, x);
+    }
+
+    kernelpp::maybe<homotopy_report> homotopy_policy::run(
+        homotopy_state<double>& st, const ndspan<double> y, double tol, uint32_t maxiter, ndspan<double> x)
+    {
+        return run_hip<double>(st, y, tol, maxiter, x);
+    }
+
+    /* Utils --------------------------------------------------------------- */
+
+    namespace detail
+    {
+        /* y = A x on the host: x is sparse in every use of the reference
+           (test_util.h:167,187), so only its non-zero columns are visited */
+        template <typename T>
+        void reconstruct_signal(const ndspan<T, 2> A, const ndspan<T> x, ndspan<T> y)
+        {
+            const size_t m = A.shape()[0], n = A.shape()[1];
+            for (size_t i = 0; i < m; i++) y[i] = T(0);
+            for (size_t j = 0; j < n; j++) {
+                const T xj = x[j];
+                if (xj == T(0)) continue;
+                for (size_t i = 0; i < m; i++) y[i] += A(i, j) * xj;
+            }
+        }
+
+        template <typename T>
+        void norm_l1(ndspan<T, 2> A)
+        {
+            const size_t m = A.shape()[0], n = A.shape()[1];
+            std::vector<T> sums(n, T(0));
+            for (size_t i = 0; i < m; i++)
+                for (size_t j = 0; j < n; j++) sums[j] += std::abs(A(i, j));
+            for (size_t i = 0; i < m; i++)
+                for (size_t j = 0; j < n; j++) A(i, j) /= sums[j];
+        }
+    }
+
+    void reconstruct_signal(const ndspan<float, 2> A, const ndspan<float> x, ndspan<float> y) {
+        detail::reconstruct_signal(A, x, y);
+    }
+
+    void reconstruct_signal(const ndspan<double, 2> A, const ndspan<double> x, ndspan<double> y) {
+        detail::reconstruct_signal(A, x, y);
+    }
+
+    void norm_l1(ndspan<float, 2> A)  { detail::norm_l1(A); }
+    void norm_l1(ndspan<double, 2> A) { detail::norm_l1(A); }
+}

@@ -1,0 +1,126 @@
+// C++14 user of the drop-in API (include/ss/ss.h), restating the reference's
+// src/solvers/homotopy_test.cpp:8-40 + src/solvers/test_util.h:27-92 against ss::homotopy<T>.
+//   test_ss_api                 -> needs an MI355X; exit code 0 when every check passes
+//   test_ss_api --no-device     -> checks the error convention when no GPU is usable
+#include <ss/ss.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static int failures = 0;
+#define CHECK(cond)                                                                    \
+    do {                                                                               \
+        if (!(cond)) { std::printf("CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); ++failures; } \
+    } while (0)
+
+template <typename Report>
+void check_report(kernelpp::maybe<Report>& result, float tolerance, uint32_t max_iterations)
+{
+    CHECK(result.template is<Report>());
+    if (!result.template is<Report>()) {
+        std::printf("  error: %s\n", result.template get<kernelpp::error>().data());
+        return;
+    }
+    auto r = result.template get<Report>();
+    CHECK(r.iter >= 1);
+    CHECK(r.iter <= max_iterations);
+    if (r.iter < max_iterations) CHECK(r.solution_error <= tolerance);
+}
+
+template <typename T>
+void smoke_test()
+{
+    const uint32_t N = 5;
+    std::vector<T> identity(N * N, T(0)), signal(N), x(N);
+    for (uint32_t i = 0; i < N; i++) identity[i * N + i] = T(1);
+
+    ss::homotopy<T> solver(ss::as_span<2>(identity.data(), { N, N }));
+    for (uint32_t n = 0; n < N; n++) {
+        ss::view(ss::as_span(signal)) = T(0);
+        signal[n] = T(1);
+        ss::view(ss::as_span(x)) = T(0);
+        auto result = solver.solve(ss::as_span(signal), T(.001), N, ss::as_span(x));
+        check_report(result, .001f, N);
+        CHECK(x == signal);
+    }
+}
+
+template <typename T>
+void smoke_test_column_subset()
+{
+    const size_t N = 10, M = 5;
+    std::vector<T> data(M * N, T(0));
+    for (size_t i = 0; i < M; i++) {
+        for (size_t j = 0; j + 1 < M; j++) data[i * N + j] = T(0.01) * T((i * 7 + j * 3) % 10);
+        data[i * N + M + i] = T(1);
+    }
+    // columns 5..9 of the 5 x 10 buffer: row stride 10
+    auto identity = ss::as_span<2>(data.data() + M, { M, M }, { N, size_t(1) });
+    ss::homotopy<T> solver(identity);
+    std::vector<T> signal(M), x(M);
+    for (size_t n = 0; n < M; n++) {
+        for (size_t i = 0; i < M; i++) signal[i] = identity(i, n);
+        ss::view(ss::as_span(x)) = T(0);
+        auto result = solver.solve(ss::as_span(signal), T(.001), uint32_t(N), ss::as_span(x));
+        CHECK(result.template is<ss::homotopy_report>());
+        CHECK(x == signal);
+    }
+}
+
+void error_convention()
+{
+    std::vector<float> A(16, 0.f), y(4, 1.f), x(4, 0.f);
+    for (int i = 0; i < 4; i++) A[i * 4 + i] = 1.f;
+    ss::homotopy<float> s(ss::as_span<2>(A.data(), { size_t(4), size_t(4) }));
+    ss::homotopy<float> moved(std::move(s));                      // move-only, like the reference
+    auto bad = moved.solve(ss::as_span(y), 0.5f, 0, ss::as_span(x));   // max_iterations == 0
+    CHECK(bad.is<kernelpp::error>());
+    CHECK(!bad.is<ss::homotopy_report>());
+    CHECK(std::strlen(bad.get<kernelpp::error>().data()) > 0);
+    auto bad2 = moved.solve(ss::as_span(y), 1.5f, 4, ss::as_span(x));  // tol >= 1
+    CHECK(bad2.is<kernelpp::error>());
+    std::vector<float> yshort(3, 1.f);
+    auto bad3 = moved.solve(ss::as_span(yshort), 0.5f, 4, ss::as_span(x));
+    CHECK(bad3.is<kernelpp::error>());
+    auto ok = moved.solve(ss::as_span(y), 0.001f, 8, ss::as_span(x));
+    CHECK(ok.is<ss::homotopy_report>());
+    CHECK(ok.get_unchecked<ss::homotopy_report>().iter >= 1);
+}
+
+void utilities()
+{
+    // norm_l1 literal (reference: src/linalg/norms_test.cpp) and reconstruct_signal
+    std::vector<double> A = { 1, 2, 3, 6 };   // 2 x 2
+    ss::norm_l1(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }));
+    CHECK(A[0] == 0.25 && A[1] == 0.25 && A[2] == 0.75 && A[3] == 0.75);
+    std::vector<double> x = { 2, 0 }, y(2, -1);
+    ss::reconstruct_signal(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }), ss::as_span(x), ss::as_span(y));
+    CHECK(y[0] == 0.5 && y[1] == 1.5);
+}
+
+int no_device()
+{
+    std::vector<float> A = { 1, 0, 0, 1 }, y = { 1, 0 }, x(2);
+    ss::homotopy<float> s(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }));
+    auto r = s.solve(ss::as_span(y), 0.001f, 2, ss::as_span(x));
+    CHECK(r.is<kernelpp::error>());
+    if (r.is<kernelpp::error>()) std::printf("error (expected): %s\n", r.get<kernelpp::error>().data());
+    utilities();
+    return failures;
+}
+
+int main(int argc, char** argv)
+{
+    static_assert(ss::detail::is_solver<ss::homotopy_policy, float>::value, "f32");
+    static_assert(ss::detail::is_solver<ss::homotopy_policy, double>::value, "f64");
+    if (argc > 1 && !std::strcmp(argv[1], "--no-device")) return no_device() ? 1 : 0;
+    smoke_test<float>();
+    smoke_test<double>();
+    smoke_test_column_subset<float>();
+    smoke_test_column_subset<double>();
+    error_convention();
+    utilities();
+    std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
+    return failures ? 1 : 0;
+}

@@ -325,3 +325,53 @@ def test_ref_binding_layouts(sship):
     ref_cases.binding_row_subset(hip_solve_default_factory(sship))
     ref_cases.binding_col_subset(hip_solve_default_factory(sship))
     ref_cases.binding_transpose(hip_solve_default_factory(sship))
+
+
+# ---------------------------------------------------------------- drop-in surfaces
+
+def test_cpp_api_on_device(sship, tmp_path):
+    """C++14 user program against include/ss/ss.h (tests/cpp/test_ss_api.cpp)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "sparse-solvers_amd", "lib")
+    exe = str(tmp_path / "test_ss_api")
+    cmd = ["g++", "-std=c++14", "-O1", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "cpp", "test_ss_api.cpp"), "-o", exe,
+           "-L", lib, "-lsparsesolvers", "-lss_hip", "-Wl,-rpath," + lib]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    assert "ok (0 failures)" in r.stdout
+
+
+def test_python_module_binding_tests(sship):
+    """bindings/python/tests/test_binding.py:9-68 against the drop-in `sparsesolvers` module"""
+    import sparsesolvers as ss
+
+    def solve_default(A, y):
+        x, info = ss.Homotopy(A).solve(np.asarray(y, dtype=A.dtype))
+        assert isinstance(info, ss.HomotopyReport)
+        return x, info.iter, info.solution_error
+
+    for dtype in (np.float32, np.float64):
+        ref_cases.binding_smoke(solve_default, dtype)
+    ref_cases.binding_row_subset(solve_default)
+    ref_cases.binding_col_subset(solve_default)
+    ref_cases.binding_transpose(solve_default)
+
+    # README toy (README.md:18-30) with explicit keyword arguments
+    rng = np.random.default_rng(0)
+    N = 10
+    A = rng.normal(loc=0.025, scale=0.025, size=(N, N)) + np.identity(N)
+    signal = np.zeros(N)
+    signal[2] = 1
+    x, info = ss.Homotopy(A).solve(signal, tolerance=0.1)
+    assert np.argmax(x) == 2 and 1 - np.count_nonzero(x) / N == 0.9
+    xo, ito, eo = oracle.homotopy(A, signal, 0.1, 100)
+    assert info.iter == ito and np.allclose(x, xo, rtol=0, atol=1e-12)
+    with pytest.raises(RuntimeError):
+        ss.Homotopy(A).solve(signal, tolerance=2.0)
+    with pytest.raises(RuntimeError):
+        ss.Homotopy(A).solve(signal.astype(np.float32))
