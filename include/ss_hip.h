@@ -144,9 +144,22 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "lookahead"      iterations the host enqueues ahead of the device's done flag
  *   "strict_sign"    1 = seed the first direction with sign(c[idx]) instead of the
  *                    reference's sign(|c[idx]|) (homotopy-cpu.cpp:223-227); default 0
+ *   "trace"          1 = record the homotopy path of each solve (ss_hip_get_trace)
+ *   "zero_on_removal" 1 (default) = a coefficient whose column leaves the support is set
+ *                    to exactly 0; 0 = keep the reference's x + gamma*d rounding residue
+ *                    (homotopy-cpu.cpp:246-252), which can make a re-inserted column bounce
  */
 int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value);
 int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value);
+
+/*
+ * The homotopy path of the LAST solve when option "trace" is on: entry 0 is the initial
+ * pick, entry t the column toggled by iteration t (added = 1 insert / 0 remove), the step
+ * length gamma taken and lambda = ||c||_inf at the start of that iteration.  Writes up to
+ * `capacity` entries into each non-NULL array; *count receives the number available.
+ */
+int ss_hip_get_trace(ss_hip_ctx* ctx, uint32_t capacity, uint32_t* idx, uint8_t* added,
+                     double* gamma, double* c_inf, uint32_t* count);
 
 /* Shape / placement queries. */
 int ss_hip_ctx_info(const ss_hip_ctx* ctx, size_t* m, size_t* n, int* is_f64, int* device);

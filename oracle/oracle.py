@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libss_oracle.so")
 
 SPARSE_NOTRANS = 1
 STRICT_SIGN = 2
+ZERO_ON_REMOVAL = 4
 
 
 class _Report(ctypes.Structure):

@@ -3,14 +3,14 @@
 // direction and the two m-vectors r = y - A x, p = A d that feed the next sweep.
 //
 // Reference (paths under /root/reference):
-//   find_max_gamma scan        src/solvers/homotopy-cpu.cpp:122-163   -> k_scan + k_select
-//   inverse_add_or_remove      src/solvers/homotopy-cpu.cpp:166-183   -> k_select (rank_index part)
-//   online_column_inverse      src/linalg/online_inverse.h:183-293    -> k_gram + k_update
-//   direction update           src/solvers/homotopy-cpu.cpp:257-267   -> k_update
-//   x += gamma * d             src/solvers/homotopy-cpu.cpp:252       -> k_select
+//   find_max_gamma scan        src/solvers/homotopy-cpu.cpp:122-163   -> k_scansel
+//   inverse_add_or_remove      src/solvers/homotopy-cpu.cpp:166-183   -> k_scansel (rank_index part)
+//   online_column_inverse      src/linalg/online_inverse.h:183-293    -> k_gramupd
+//   direction update           src/solvers/homotopy-cpu.cpp:257-267   -> k_gramupd
+//   x += gamma * d             src/solvers/homotopy-cpu.cpp:252       -> k_scansel
 //   residual_vector (A x part) src/solvers/homotopy-cpu.cpp:94-96     -> k_rp
 //   p = A d                    src/solvers/homotopy-cpu.cpp:114-116   -> k_rp
-//   loop control / inf_norm    src/solvers/homotopy-cpu.cpp:32-37,235-274 -> k_select
+//   loop control / inf_norm    src/solvers/homotopy-cpu.cpp:32-37,235-274 -> k_scansel
 //
 // All of it is O(n + K*m + K^2) per iteration against the sweep's O(m*n); these kernels
 // are latency-, not bandwidth-bound, and are kept simple.  The (A_S^T A_S)^-1 matrix is
@@ -150,7 +150,7 @@ void k_init(const T* __restrict__ At, uint32_t ldm, const T* __restrict__ c,
             const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
             T* __restrict__ d, uint8_t* __restrict__ insup, uint32_t* __restrict__ gam,
             uint32_t* __restrict__ touched, T* __restrict__ inv0, T tol, int strict_sign,
-            DevState* st)
+            DevState* st, TraceEntry* trace)
 {
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
@@ -183,59 +183,150 @@ void k_init(const T* __restrict__ At, uint32_t ldm, const T* __restrict__ c,
         st->c_inf = (double)c_inf;
         st->gamma = 0.0;
         st->dot = (double)dot;
+        if (trace != nullptr) {
+            trace[0].idx = idx;
+            trace[0].added = 1;
+            trace[0].gamma = 0.0;
+            trace[0].c_inf = (double)c_inf;
+        }
     }
 }
 
+// ---- in-launch hand-off: "last workgroup to arrive finishes the job" --------------------
+// Placement-independent release/acquire at agent scope (cdna_hip_programming.md §6
+// Guideline 16, counter form): every wave drains its stores, the workgroup's leader
+// releases and takes a ticket; the workgroup that draws the last ticket acquires and may
+// then read, with VECTOR loads, what the others stored.  Returns true in that workgroup.
+// The counter is reset by the last arriver (every other workgroup has already arrived).
+__device__ __forceinline__ bool arrive_last(uint32_t* counter, uint32_t total, uint32_t* s_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t last = (t == total - 1u) ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *s_flag = last;
+    }
+    __syncthreads();
+    return *s_flag != 0u;
+}
+
+// a scalar another workgroup stored in this launch: read it on the vector path, L1 bypassed
+__device__ __forceinline__ double load_handoff(const double* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- k_rp: r = y - A x ; p = A d over the touched columns -----------------------------
+// 256 threads = 4 waves; a workgroup owns kRpRows rows, wave w takes the columns
+// touched[w], touched[w+4], ... (independent 8/16-byte loads, unrolled), the four partial
+// sums are combined in wave order through LDS.
+constexpr int kRpThreads = 256;
+constexpr int kRpRowsPerLane = 2;
+constexpr int kRpRows = 64 * kRpRowsPerLane;
+
 template <typename T>
-__global__ __launch_bounds__(128)
+__global__ __launch_bounds__(kRpThreads)
 void k_rp(const T* __restrict__ At, uint32_t ldm, const T* __restrict__ y,
           const T* __restrict__ x, const T* __restrict__ d,
           const uint32_t* __restrict__ touched2 /* [2][kcap] */, uint32_t kcap,
           T* __restrict__ rhs, const DevState* st)
 {
     if (st->done) return;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ldm) return;
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    __shared__ T s_r[4][kRpRows];
+    __shared__ T s_p[4][kRpRows];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t row = blockIdx.x * kRpRows + lane * kRpRowsPerLane;     // ldm % 256 == 0
     const uint32_t nt = st->ntouched;
     const uint32_t* touched = touched2 + (size_t)st->cur * kcap;
-    T accr = T(0), accp = T(0);
-    uint32_t j = 0;
-    for (; j + 4 <= nt; j += 4) {
-        const uint32_t c0 = touched[j], c1 = touched[j + 1], c2 = touched[j + 2], c3 = touched[j + 3];
-        const T a0 = At[(size_t)c0 * ldm + i], a1 = At[(size_t)c1 * ldm + i];
-        const T a2 = At[(size_t)c2 * ldm + i], a3 = At[(size_t)c3 * ldm + i];
-        accr += x[c0] * a0; accp += d[c0] * a0;
-        accr += x[c1] * a1; accp += d[c1] * a1;
-        accr += x[c2] * a2; accp += d[c2] * a2;
-        accr += x[c3] * a3; accp += d[c3] * a3;
+    T ar0 = T(0), ar1 = T(0), ap0 = T(0), ap1 = T(0);
+    uint32_t j = wave;
+    for (; j + 12 < nt; j += 16) {
+        uint32_t cj[4];
+        V2 a[4];
+        T xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            cj[u] = touched[j + 4 * u];
+            a[u] = *reinterpret_cast<const V2*>(At + (size_t)cj[u] * ldm + row);
+            xv[u] = x[cj[u]];
+            dv[u] = d[cj[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ar0 += xv[u] * a[u][0]; ar1 += xv[u] * a[u][1];
+            ap0 += dv[u] * a[u][0]; ap1 += dv[u] * a[u][1];
+        }
     }
-    for (; j < nt; ++j) {
+    for (; j < nt; j += 4) {
         const uint32_t c0 = touched[j];
-        const T a0 = At[(size_t)c0 * ldm + i];
-        accr += x[c0] * a0;
-        accp += d[c0] * a0;
+        const V2 a0 = *reinterpret_cast<const V2*>(At + (size_t)c0 * ldm + row);
+        const T xv = x[c0], dv = d[c0];
+        ar0 += xv * a0[0]; ar1 += xv * a0[1];
+        ap0 += dv * a0[0]; ap1 += dv * a0[1];
     }
-    rhs[i] = y[i] - accr;
-    rhs[(size_t)ldm + i] = accp;
+    s_r[wave][lane * 2] = ar0; s_r[wave][lane * 2 + 1] = ar1;
+    s_p[wave][lane * 2] = ap0; s_p[wave][lane * 2 + 1] = ap1;
+    __syncthreads();
+    if (threadIdx.x < kRpRows) {
+        const uint32_t t = threadIdx.x, i = blockIdx.x * kRpRows + t;
+        const T sr = ((s_r[0][t] + s_r[1][t]) + s_r[2][t]) + s_r[3][t];
+        const T sp = ((s_p[0][t] + s_p[1][t]) + s_p[2][t]) + s_p[3][t];
+        rhs[i] = y[i] - sr;
+        rhs[(size_t)ldm + i] = sp;
+    }
 }
 
-// ---- k_scan: candidates of find_max_gamma, homotopy-cpu.cpp:122-163 -------------------
+// ---- k_scansel: find_max_gamma's scan (homotopy-cpu.cpp:122-163) in every workgroup,
+// ---- then loop control, pick, support toggle and x update in the last one to arrive ----
 constexpr int kScanPerThread = 4;
 
 template <typename T>
 __global__ __launch_bounds__(kSmallThreads)
-void k_scan(const T* __restrict__ c, const T* __restrict__ q, const T* __restrict__ x,
-            const T* __restrict__ d, const uint8_t* __restrict__ insup, uint32_t n,
-            const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
-            T* __restrict__ pmin_val, uint32_t* __restrict__ pmin_idx, const DevState* st)
+void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
+               const T* __restrict__ c, const T* __restrict__ q, T* __restrict__ x,
+               const T* __restrict__ d, uint8_t* __restrict__ insup,
+               const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
+               T* pmin_val, uint32_t* pmin_idx,
+               uint32_t* __restrict__ gam2, uint32_t* __restrict__ touched2, uint32_t kcap,
+               DevState* st, uint32_t* hflags, TraceEntry* trace, uint32_t trace_cap,
+               int zero_on_removal)
 {
     if (st->done) return;
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
+    __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_flag;
+
+    // inf_norm of the correlations the sweep just produced (homotopy-cpu.cpp:270 / :219)
     T c_inf;
-    uint32_t dummy;
-    reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, dummy, sv, si);
+    uint32_t imax;
+    reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, imax, sv, si);
+
+    // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
+    // round t starts iteration t, so the while-test of iteration t-1 is evaluated here;
+    // every workgroup takes the same branch (same inputs, exact max).
+    if ((round > 1 && !(c_inf > tol)) || round > max_iter) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->c_inf = (double)c_inf;
+            st->iter = round - 1;
+            st->done_round = round;
+            st->done = 1;
+            if (hflags) {
+                __hip_atomic_store(&hflags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
 
     T best = Lim<T>::max();
     uint32_t best_i = 0xffffffffu;
@@ -269,42 +360,11 @@ void k_scan(const T* __restrict__ c, const T* __restrict__ q, const T* __restric
         pmin_val[blockIdx.x] = best;
         pmin_idx[blockIdx.x] = best_i;
     }
-}
+    if (!arrive_last(&st->ticket_scan, gridDim.x, &s_flag)) return;
 
-// ---- k_select: loop control, pick, support toggle, x update ---------------------------
-template <typename T>
-__global__ __launch_bounds__(kSmallThreads)
-void k_select(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
-              const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
-              const T* __restrict__ pmin_val, const uint32_t* __restrict__ pmin_idx, uint32_t ns,
-              T* __restrict__ x, const T* __restrict__ d, uint8_t* __restrict__ insup,
-              uint32_t* __restrict__ gam2, uint32_t* __restrict__ touched2, uint32_t kcap,
-              DevState* st)
-{
-    if (st->done) return;
-    __shared__ T sv[16];
-    __shared__ uint32_t si[16];
-    __shared__ uint32_t s_cnt[2];
-
-    // inf_norm of the correlations the sweep just produced (homotopy-cpu.cpp:270 / :219)
-    T c_inf;
-    uint32_t imax;
-    reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, imax, sv, si);
-
-    // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
-    // round t starts iteration t, so the while-test of iteration t-1 is evaluated here.
-    if ((round > 1 && !(c_inf > tol)) || round > max_iter) {
-        if (threadIdx.x == 0) {
-            st->c_inf = (double)c_inf;
-            st->iter = round - 1;
-            st->done_round = round;
-            st->done = 1;
-        }
-        return;
-    }
-
-    // final (gamma, idx) of find_max_gamma: smallest positive candidate, left-most index;
-    // (T_MAX, 0) when there is no candidate (homotopy-cpu.cpp:123-124)
+    // ---- last workgroup: final (gamma, idx) of find_max_gamma: smallest positive
+    // candidate, left-most index; (T_MAX, 0) when there is none (homotopy-cpu.cpp:123-124)
+    const uint32_t ns = gridDim.x;
     T g = Lim<T>::max();
     uint32_t idx = 0xffffffffu;
     for (uint32_t b = threadIdx.x; b < ns; b += blockDim.x) {
@@ -337,38 +397,50 @@ void k_select(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
     const uint32_t trank = s_cnt[1];
     const uint32_t K_new = added ? K + 1 : K - 1;
 
-    if (K_new == 0) {
-        // homotopy-cpu.cpp:248-249: support became empty -> break before x is updated;
-        // the report carries the c_inf of the previous iteration's end (== this c_inf)
-        if (threadIdx.x == 0) {
-            insup[idx] = 0;
-            st->K = 0;
-            st->idx = idx;
-            st->rank = rank;
-            st->added = 0;
-            st->gamma = (double)g;
-            st->c_inf = (double)c_inf;
-            st->iter = round;
-            st->done_round = round;
-            st->done = 1;
-        }
-        return;
+    if (trace != nullptr && threadIdx.x == 0 && round < trace_cap) {
+        trace[round].idx = idx;
+        trace[round].added = added ? 1u : 0u;
+        trace[round].gamma = (double)g;
+        trace[round].c_inf = (double)c_inf;
     }
-    if (K_new > kcap) {
+
+    if (K_new == 0 || K_new > kcap) {
+        // K_new == 0: homotopy-cpu.cpp:248-249, the support became empty -> break before x
+        // is updated; the report carries the c_inf of the previous iteration's end.
+        // K_new > kcap: workspace exhausted.
         if (threadIdx.x == 0) {
-            st->status = SS_HIP_ECAPACITY;
+            if (K_new == 0) {
+                insup[idx] = 0;
+                st->K = 0;
+                st->idx = idx;
+                st->rank = rank;
+                st->added = 0;
+                st->gamma = (double)g;
+                st->iter = round;
+            } else {
+                st->status = SS_HIP_ECAPACITY;
+                st->iter = round - 1;
+            }
             st->c_inf = (double)c_inf;
-            st->iter = round - 1;
             st->done_round = round;
             st->done = 1;
+            if (hflags) {
+                __hip_atomic_store(&hflags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         return;
     }
 
-    // x += gamma * direction over the OLD support (homotopy-cpu.cpp:252; d is zero elsewhere)
+    // x += gamma * direction over the OLD support (homotopy-cpu.cpp:252; d is zero elsewhere).
+    // The column that leaves the support lands on x + (-x/d)*d, i.e. 0 up to an ulp; the
+    // reference keeps that residue, and a residue of the wrong sign makes a later re-insertion
+    // of the column bounce straight out again (gamma ~ 1e-18 steps).  By default the entry is
+    // set to exactly 0 (option "zero_on_removal" = 0 restores the reference's residue).
     for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) {
         const uint32_t col = gam[j];
-        x[col] = x[col] + g * d[col];
+        const T xn = x[col] + g * d[col];
+        x[col] = (!added && zero_on_removal && col == idx) ? T(0) : xn;
     }
 
     // new sorted support, written out of place
@@ -399,70 +471,78 @@ void k_select(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
         st->gamma = (double)g;
         st->c_inf = (double)c_inf;
         st->iter = round;
+        if (hflags) __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-// ---- k_gram: u1 = A_S^T a_idx and a_idx . a_idx (online_inverse.h:209-218) -------------
+// ---- k_gramupd: u1 = A_S^T a_idx and a_idx . a_idx (online_inverse.h:209-218), one
+// ---- workgroup per active column; the last to arrive borders / deflates
+// ---- (A_S^T A_S)^-1 (online_inverse.h:224-248, 275-290) and forms the new direction
+// ---- (homotopy-cpu.cpp:257-267) ---------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kSmallThreads)
-void k_gram(const T* __restrict__ At, uint32_t ldm, const uint32_t* __restrict__ gam2, uint32_t kcap,
-            T* __restrict__ u1, DevState* st)
-{
-    if (st->done || !st->added) return;
-    const uint32_t b = blockIdx.x;
-    const uint32_t K_new = st->K;
-    if (b >= K_new) return;
-    __shared__ T sv[16];
-    const uint32_t rank = st->rank;
-    const uint32_t* gam_new = gam2 + (size_t)(st->cur ^ 1u) * kcap;
-    const T* col = At + (size_t)gam_new[b] * ldm;
-    const T* cnew = At + (size_t)st->idx * ldm;
-    const T v = block_dot(col, cnew, ldm, sv);
-    if (threadIdx.x == 0) {
-        if (b == rank) st->dot = (double)v;
-        else u1[b - (b > rank ? 1u : 0u)] = v;
-    }
-}
-
-// ---- k_update: bordering / deflation of (A_S^T A_S)^-1 + new direction ----------------
-template <typename T>
-__global__ __launch_bounds__(kUpdThreads)
-void k_update(T* __restrict__ inv0, T* __restrict__ inv1, uint32_t kcap,
-              const T* __restrict__ u1, T* __restrict__ u2, T* __restrict__ sgn,
-              const uint32_t* __restrict__ gam2, const T* __restrict__ c, const T* __restrict__ q,
-              T* __restrict__ d, T tol, DevState* st)
+void k_gramupd(const T* __restrict__ At, uint32_t ldm, const uint32_t* __restrict__ gam2, uint32_t kcap,
+               T* inv0, T* inv1, T* u1, T* u2, T* sgn,
+               const T* __restrict__ c, const T* __restrict__ q, T* __restrict__ d, T tol,
+               DevState* st)
 {
     if (st->done) return;
+    typedef T V4 __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr int VN = 16 / sizeof(T);
     __shared__ T sv[16];
     __shared__ T s_d;
+    __shared__ uint32_t s_flag;
+
     const uint32_t cur = st->cur;
-    const T* Iold = cur ? inv1 : inv0;
-    T* Inew = cur ? inv0 : inv1;
     const uint32_t K_new = st->K;
     const uint32_t rank = st->rank;
     const bool added = st->added != 0;
-    const uint32_t K_old = added ? K_new - 1 : K_new + 1;
     const uint32_t* gam_old = gam2 + (size_t)cur * kcap;
     const uint32_t* gam_new = gam2 + (size_t)(cur ^ 1u) * kcap;
+
+    if (added && blockIdx.x < K_new) {
+        const uint32_t b = blockIdx.x;
+        const V4* col = reinterpret_cast<const V4*>(At + (size_t)gam_new[b] * ldm);
+        const V4* cnew = reinterpret_cast<const V4*>(At + (size_t)st->idx * ldm);
+        const uint32_t nv = ldm / VN;                       // multiple of 64
+        T acc = T(0);
+#pragma unroll 4
+        for (uint32_t i = threadIdx.x; i < nv; i += kSmallThreads) {
+            const V4 a = col[i], bnew = cnew[i];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc += a[e] * bnew[e];
+        }
+        const T v = block_sum(acc, sv);
+        if (threadIdx.x == 0) {
+            if (b == rank) st->dot = (double)v;
+            else u1[b - (b > rank ? 1u : 0u)] = v;
+        }
+    }
+    if (!arrive_last(&st->ticket_gram, gridDim.x, &s_flag)) return;
+
+    // ---- last workgroup --------------------------------------------------------------
+    const T* Iold = cur ? inv1 : inv0;
+    T* Inew = cur ? inv0 : inv1;
+    const uint32_t K_old = added ? K_new - 1 : K_new + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = kUpdThreads / 64;
+    constexpr int NW = kSmallThreads / 64;
     const size_t P = kcap;
 
     if (added) {
-        const uint32_t n = K_old;
+        const uint32_t nn = K_old;
         // u2 = inv * u1 (online_inverse.h:224-225), one wave per row
-        for (uint32_t i = wave; i < n; i += NW) {
+        for (uint32_t i = wave; i < nn; i += NW) {
             T acc = T(0);
-            for (uint32_t j = lane; j < n; j += 64) acc += Iold[i * P + j] * u1[j];
+            for (uint32_t j = lane; j < nn; j += 64) acc += Iold[i * P + j] * u1[j];
             acc = wave_sum(acc);
             if (lane == 0) u2[i] = acc;
         }
         __syncthreads();
         // d = 1 / (dot - u1.u2) (online_inverse.h:228)
         T part = T(0);
-        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) part += u1[j] * u2[j];
+        for (uint32_t j = threadIdx.x; j < nn; j += blockDim.x) part += u1[j] * u2[j];
         const T s = block_sum(part, sv);
-        if (threadIdx.x == 0) s_d = T(1) / ((T)st->dot - s);
+        if (threadIdx.x == 0) s_d = T(1) / ((T)load_handoff(&st->dot) - s);
         __syncthreads();
         const T dv = s_d;
         // new inverse in sorted order: [inv + d u2 u2^T, -d u2; -d u2^T, d] with the new
@@ -485,10 +565,10 @@ void k_update(T* __restrict__ inv0, T* __restrict__ inv1, uint32_t kcap,
         }
     } else {
         // remove row/column `rank` (online_inverse.h:275-290)
-        const uint32_t n = K_old;
+        const uint32_t nn = K_old;
         const T dd = Iold[rank * P + rank];
         const T sc = -(T(1) / dd);
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) u2[i] = Iold[i * P + rank] * sc;
+        for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) u2[i] = Iold[i * P + rank] * sc;
         __syncthreads();
         const uint32_t tot = K_new * K_new;
         for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
@@ -546,15 +626,15 @@ hipError_t launch_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsweep_
     hipLaunchKernelGGL((k_init<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream,
                        static_cast<const T*>(ctx->At), ctx->ldm, ws.c, ws.pmax_val, ws.pmax_idx,
                        nsweep_blocks, ws.d, ws.insup, ws.gam, ws.touched, ws.inv[0], tol,
-                       ctx->strict_sign, ws.st);
+                       ctx->strict_sign, ws.st, ws.trace);
     return hipGetLastError();
 }
 
 template <typename T>
 hipError_t launch_rp(const ss_hip_ctx* ctx, Workspace<T>& ws)
 {
-    const uint32_t blocks = (ctx->ldm + 127) / 128;
-    hipLaunchKernelGGL((k_rp<T>), dim3(blocks), dim3(128), 0, ctx->stream,
+    const uint32_t blocks = ctx->ldm / kRpRows;
+    hipLaunchKernelGGL((k_rp<T>), dim3(blocks), dim3(kRpThreads), 0, ctx->stream,
                        static_cast<const T*>(ctx->At), ctx->ldm, ws.y, ws.x, ws.d, ws.touched,
                        ws.kcap, ws.rhs, ws.st);
     return hipGetLastError();
@@ -567,20 +647,16 @@ hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32
     const uint32_t n = (uint32_t)ctx->n;
     const uint32_t per_block = kSmallThreads * kScanPerThread;
     uint32_t ns = (n + per_block - 1) / per_block;
-    if (ns > kMaxScanBlocks) ns = kMaxScanBlocks;   // k_scan grid-strides
-    hipLaunchKernelGGL((k_scan<T>), dim3(ns), dim3(kSmallThreads), 0, ctx->stream, ws.c, ws.q, ws.x,
-                       ws.d, ws.insup, n, ws.pmax_val, ws.pmax_idx, nsweep_blocks, ws.pmin_val,
-                       ws.pmin_idx, ws.st);
-    hipLaunchKernelGGL((k_select<T>), dim3(1), dim3(kSmallThreads), 0, ctx->stream, round, tol,
-                       max_iter, n, ws.pmax_val, ws.pmax_idx, nsweep_blocks, ws.pmin_val,
-                       ws.pmin_idx, ns, ws.x, ws.d, ws.insup, ws.gam, ws.touched, ws.kcap, ws.st);
+    if (ns > kMaxScanBlocks) ns = kMaxScanBlocks;   // k_scansel grid-strides
+    hipLaunchKernelGGL((k_scansel<T>), dim3(ns), dim3(kSmallThreads), 0, ctx->stream, round, tol,
+                       max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
+                       nsweep_blocks, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.kcap, ws.st,
+                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal);
     uint32_t gb = round + 1;
     if (gb > ws.kcap) gb = ws.kcap;
-    hipLaunchKernelGGL((k_gram<T>), dim3(gb), dim3(kSmallThreads), 0, ctx->stream,
-                       static_cast<const T*>(ctx->At), ctx->ldm, ws.gam, ws.kcap, ws.u1, ws.st);
-    hipLaunchKernelGGL((k_update<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, ws.inv[0],
-                       ws.inv[1], ws.kcap, ws.u1, ws.u2, ws.sgn, ws.gam, ws.c, ws.q, ws.d, tol,
-                       ws.st);
+    hipLaunchKernelGGL((k_gramupd<T>), dim3(gb), dim3(kSmallThreads), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ctx->ldm, ws.gam, ws.kcap, ws.inv[0], ws.inv[1],
+                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_rp(ctx, ws);

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <thread>
 
 using namespace sship;
 
@@ -156,7 +157,7 @@ void free_ws(Workspace<T>* w)
     if (!w) return;
     void* ptrs[] = { w->y, w->rhs, w->c, w->q, w->x, w->d, w->insup, w->pmax_val, w->pmax_idx,
                      w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->inv[1], w->u1,
-                     w->u2, w->sgn, w->st };
+                     w->u2, w->sgn, w->st, w->trace };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete w;
@@ -256,7 +257,9 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
         HIPCHK(hipStreamSynchronize(ctx->stream));
         upload_matrix<T>(ctx, A, rs, cs);
         alloc_ws_fixed<T>(ctx);
-        HIPCHK(hipHostMalloc(&ctx->host_flags, 64 * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&ctx->host_flags, 64 * sizeof(uint32_t), hipHostMallocMapped));
+        std::memset(ctx->host_flags, 0, 64 * sizeof(uint32_t));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->dev_flags), ctx->host_flags, 0));
         HIPCHK(hipEventCreate(&ctx->ev_solve0));
         HIPCHK(hipEventCreate(&ctx->ev_solve1));
         const uint64_t s = sizeof(T);
@@ -335,10 +338,23 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         ensure_kcap<T>(ctx, kcap);
         Workspace<T>& ws = *ws_of<T>(ctx);
         hipStream_t st = ctx->stream;
+        const uint32_t want_trace = ctx->tracing ? (uint32_t)std::min<uint64_t>((uint64_t)max_iter + 2, 1u << 20) : 0u;
+        if (want_trace > ws.trace_cap) {
+            if (ws.trace) HIPCHK(hipFree(ws.trace));
+            ws.trace = nullptr;
+            ws.trace_cap = 0;
+            HIPCHK(hipMalloc(&ws.trace, (size_t)want_trace * sizeof(TraceEntry)));
+            ws.trace_cap = want_trace;
+        }
+        TraceEntry* const trace_keep = ws.trace;
+        if (!ctx->tracing) ws.trace = nullptr;          // kernels skip the stores
+        struct Restore { Workspace<T>& w; TraceEntry* p; ~Restore() { w.trace = p; } } restore{ ws, trace_keep };
         const bool prof = ctx->profiling != 0;
         size_t nprof = 0;
         ctx->prof_kind.clear();
 
+        ctx->host_flags[0] = 0;     // the stream is idle here: the previous solve synchronised
+        ctx->host_flags[1] = 0;
         if (prof) HIPCHK(hipEventRecord(ctx->ev_solve0, st));
         copy_in<T>(ctx, ws.y, y, incy, m);
         HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)ctx->n_pad * sizeof(T), st));
@@ -355,30 +371,32 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         HIPCHK(launch_init<T>(ctx, ws, nb1, tol));
         HIPCHK(launch_rp<T>(ctx, ws));
 
-        const int L = std::max(1, std::min(ctx->lookahead, 32));
-        const int RING = L + 2;
-        while ((int)ctx->flag_events.size() < RING) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->flag_events.push_back(e);
-        }
-        for (int i = 0; i < RING; ++i) ctx->host_flags[i] = 0;
-
+        // The device decides termination (k_scansel raises DevState::done and mirrors it,
+        // with the round it has reached, into pinned host memory).  The host keeps at most
+        // `lookahead` rounds queued beyond the device's position and stops enqueueing as
+        // soon as it sees `done`; rounds already queued behind it are no-ops.
+        const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
+        volatile uint32_t* hf = ctx->host_flags;
         const uint64_t last_round = (uint64_t)max_iter + 1;
         for (uint64_t round = 1; round <= last_round; ++round) {
-            if (round > (uint64_t)L) {
-                const uint64_t chk = round - L;
-                HIPCHK(hipEventSynchronize(ctx->flag_events[chk % RING]));
-                if (ctx->host_flags[chk % RING] != 0) break;
+            if (round > L) {
+                const uint32_t need = (uint32_t)(round - L);
+                uint32_t spins = 0;
+                while (hf[1] == 0 && hf[0] < need) {
+                    if ((++spins & 0x3ffu) == 0) {
+                        const hipError_t q = hipStreamQuery(st);
+                        if (q == hipSuccess) break;               // queue drained
+                        if (q != hipErrorNotReady) throw HipFail{ q, "hipStreamQuery(solve loop)" };
+                    }
+                    std::this_thread::yield();
+                }
+                if (hf[1] != 0) break;
             }
             uint32_t nb = 0;
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, 2, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, &nb, ws.st));
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(2); ++nprof; }
             HIPCHK(launch_iteration_tail<T>(ctx, ws, (uint32_t)round, nb, tol, max_iter));
-            HIPCHK(hipMemcpyAsync(&ctx->host_flags[round % RING], &ws.st->done, sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, st));
-            HIPCHK(hipEventRecord(ctx->flag_events[round % RING], st));
         }
 
         DevState hs;
@@ -397,6 +415,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         }
         if (iter_out) *iter_out = hs.iter;
         if (err_out) *err_out = hs.c_inf;
+        ctx->last_trace.clear();
+        if (ctx->tracing && ws.trace) {
+            // entry 0 = the initial pick, entry t = the toggle of iteration t
+            const size_t cnt = std::min<size_t>((size_t)hs.iter + 1, ws.trace_cap);
+            ctx->last_trace.resize(cnt);
+            HIPCHK(hipMemcpy(ctx->last_trace.data(), ws.trace, cnt * sizeof(TraceEntry), hipMemcpyDeviceToHost));
+        }
 
         ctx->stats.solves += 1;
         ctx->stats.iterations += hs.iter;
@@ -537,7 +562,6 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     }
     if (ctx->At) (void)hipFree(ctx->At);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
-    for (hipEvent_t e : ctx->flag_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_solve0) (void)hipEventDestroy(ctx->ev_solve0);
     if (ctx->ev_solve1) (void)hipEventDestroy(ctx->ev_solve1);
@@ -629,7 +653,24 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "sweep_variant")) { ctx->sweep_variant = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "lookahead"))     { ctx->lookahead = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "strict_sign"))   { ctx->strict_sign = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "trace"))         { ctx->tracing = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "zero_on_removal")) { ctx->zero_on_removal = value ? 1 : 0; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
+}
+
+int ss_hip_get_trace(ss_hip_ctx* ctx, uint32_t capacity, uint32_t* idx, uint8_t* added, double* gamma,
+                     double* c_inf, uint32_t* count)
+{
+    if (!ctx || !count) return SS_HIP_EINVAL;
+    const uint32_t n = (uint32_t)std::min<size_t>(capacity, ctx->last_trace.size());
+    for (uint32_t i = 0; i < n; ++i) {
+        if (idx) idx[i] = ctx->last_trace[i].idx;
+        if (added) added[i] = (uint8_t)ctx->last_trace[i].added;
+        if (gamma) gamma[i] = ctx->last_trace[i].gamma;
+        if (c_inf) c_inf[i] = ctx->last_trace[i].c_inf;
+    }
+    *count = (uint32_t)ctx->last_trace.size();
+    return SS_HIP_OK;
 }
 
 int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
@@ -638,6 +679,8 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "sweep_variant")) { *value = ctx->sweep_variant; return SS_HIP_OK; }
     if (!std::strcmp(key, "lookahead"))     { *value = ctx->lookahead; return SS_HIP_OK; }
     if (!std::strcmp(key, "strict_sign"))   { *value = ctx->strict_sign; return SS_HIP_OK; }
+    if (!std::strcmp(key, "trace"))         { *value = ctx->tracing; return SS_HIP_OK; }
+    if (!std::strcmp(key, "zero_on_removal")) { *value = ctx->zero_on_removal; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 

@@ -29,6 +29,7 @@ constexpr uint32_t kMaxScanBlocks = 2048;
 // Device-resident solver state, one per in-flight signal.  Written by single-workgroup
 // kernels, read by everything else; lives in global memory (L2-resident).
 struct DevState {
+    // ---- line 0: written only by single-workgroup code, read by every kernel ----------
     uint32_t done;        // 1 once the solve has terminated; every kernel becomes a no-op
     uint32_t status;      // ss_hip_status raised on the device (capacity overflow)
     uint32_t iter;        // homotopy iterations performed (ss::homotopy_report::iter)
@@ -41,7 +42,23 @@ struct DevState {
     uint32_t done_round;  // round (1-based) in which `done` was raised
     double   c_inf;       // lambda = ||c||_inf (ss::homotopy_report::solution_error)
     double   gamma;       // step length of the current iteration
-    double   dot;         // a_idx . a_idx of the column being inserted
+    uint32_t pad0_[18];
+    // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
+    uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
+    uint32_t pad1_[31];
+    uint32_t ticket_gram; // arrival counter of k_gramupd
+    uint32_t pad2_[31];
+    double   dot;         // a_idx . a_idx of the column being inserted (k_gramupd hand-off)
+    uint32_t pad3_[30];
+};
+static_assert(sizeof(DevState) == 512, "DevState layout");
+
+// optional per-iteration record of the homotopy path (ss_hip_get_trace)
+struct TraceEntry {
+    uint32_t idx;
+    uint32_t added;
+    double   gamma;
+    double   c_inf;   // lambda at the START of the iteration (the one the scan used)
 };
 
 template <typename T>
@@ -66,6 +83,8 @@ struct Workspace {
     T* u2 = nullptr;              // [kcap]
     T* sgn = nullptr;             // [kcap]
     DevState* st = nullptr;
+    TraceEntry* trace = nullptr;  // [trace_cap] when tracing is on
+    uint32_t trace_cap = 0;
 };
 
 struct SweepConfig {
@@ -89,12 +108,17 @@ struct ss_hip_ctx {
     int sweep_variant = 0;
     int lookahead = 4;
     int strict_sign = 0;
+    int zero_on_removal = 1;
     int profiling = 0;
+    int tracing = 0;
+    std::vector<sship::TraceEntry> last_trace;   // host copy of the last solve's path
 
     // workspace (type-erased; Workspace<float> or Workspace<double>)
     void* ws = nullptr;
-    uint32_t* host_flags = nullptr;   // pinned: done flags polled by the host loop
-    std::vector<hipEvent_t> flag_events;
+    // pinned, device-mapped: [0] = last round the device started, [1] = done.  Written by
+    // k_scansel with system-scope stores, polled by the host loop (no copies in the stream).
+    uint32_t* host_flags = nullptr;
+    uint32_t* dev_flags = nullptr;    // device address of host_flags
     std::vector<hipEvent_t> prof_events;   // pairs (start, stop) for sweeps of the current solve
     std::vector<int> prof_kind;            // 2 = fused sweep, 1 = single-RHS sweep
     hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;

@@ -27,7 +27,7 @@ SYMBOLS = [
     "ss_hip_gemv_t_f32", "ss_hip_gemv_t_f64",
     "ss_hip_reconstruct_f32", "ss_hip_reconstruct_f64",
     "ss_hip_set_profiling", "ss_hip_get_stats", "ss_hip_reset_stats",
-    "ss_hip_set_option", "ss_hip_get_option", "ss_hip_ctx_info",
+    "ss_hip_set_option", "ss_hip_get_option", "ss_hip_get_trace", "ss_hip_ctx_info",
 ]
 
 
@@ -86,6 +86,7 @@ def lib():
     L.ss_hip_reset_stats.argtypes = [vp]
     L.ss_hip_set_option.argtypes = [vp, cp, ctypes.c_long]
     L.ss_hip_get_option.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_long)]
+    L.ss_hip_get_trace.argtypes = [vp, u32, vp, vp, vp, vp, ctypes.POINTER(u32)]
     L.ss_hip_ctx_info.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(sz),
                                   ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     _lib = L
@@ -238,6 +239,20 @@ class Homotopy:
         s = Stats()
         lib().ss_hip_get_stats(self._h, ctypes.byref(s))
         return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def trace(self):
+        """path of the last solve (option "trace" must be on): dict of arrays"""
+        cnt = ctypes.c_uint32(0)
+        lib().ss_hip_get_trace(self._h, 0, None, None, None, None, ctypes.byref(cnt))
+        k = int(cnt.value)
+        idx = np.zeros(k, np.uint32)
+        added = np.zeros(k, np.uint8)
+        gamma = np.zeros(k, np.float64)
+        c_inf = np.zeros(k, np.float64)
+        if k:
+            lib().ss_hip_get_trace(self._h, k, idx.ctypes.data, added.ctypes.data, gamma.ctypes.data,
+                                   c_inf.ctypes.data, ctypes.byref(cnt))
+        return {"idx": idx, "added": added, "gamma": gamma, "c_inf": c_inf}
 
     def set_option(self, key, value):
         rc = lib().ss_hip_set_option(self._h, key.encode(), int(value))
