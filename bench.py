@@ -105,6 +105,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    import sharding
     import sship
 
     torch.cuda.set_device(local_rank)
@@ -142,13 +143,8 @@ def main():
         iters[s] = it
         errs[s] = e
     # fixed-size support records {idx[KMAX], val[KMAX]} per signal; one gather over xGMI
-    vals, idx = torch.topk(X.abs(), KMAX_RECORD, dim=1)
-    rec = torch.cat([idx.to(torch.float32), torch.gather(X, 1, idx)], dim=1).contiguous()
-    if world > 1:
-        allrec = torch.empty((world,) + tuple(rec.shape), device=dev, dtype=rec.dtype)
-        dist.all_gather_into_tensor(allrec, rec)
-    else:
-        allrec = rec.unsqueeze(0)
+    rec = sharding.pack_records(X, KMAX_RECORD)
+    allrec = sharding.gather_records(rec, world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -174,6 +170,9 @@ def main():
     if world > 1:
         dist.all_reduce(rc)
     recovered_total = int(rc.item())
+    # the gathered records of this rank's own block decode back to its solutions
+    mine = sharding.unpack_records(allrec[rank].cpu().numpy(), KMAX_RECORD, N)
+    gather_ok = all(np.array_equal(ix, np.nonzero(Xh[s])[0]) for s, (ix, _) in enumerate(mine))
 
     st = h.stats()
     out = None
@@ -222,7 +221,7 @@ def main():
             "iterations_mean": float(iters.mean()),
             "sweeps_per_iteration": {"this": 1, "reference": 4},
             "recovered": {"signals": world * args.steps, "support_exact": recovered_total,
-                          "max_rel_coef_err_rank0": coef_err},
+                          "max_rel_coef_err_rank0": coef_err, "gathered_records_ok": bool(gather_ok)},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, parity = cpu_baseline(A, sigs[args.warmup][0], h, int(round(iters.mean())),
