@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--variant", type=int, default=None, help="sweep kernel variant (tuning)")
+    ap.add_argument("--profile-every", type=int, default=8,
+                    help="time every k-th fused sweep of the timed solves with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     args = ap.parse_args()
@@ -132,6 +134,7 @@ def main():
         h.solve(sigs[s][0], TOL, MAX_ITER, out=xw)
 
     h.set_profiling(True)
+    h.set_option("profile_every", args.profile_every)
     h.reset_stats()
     torch.cuda.synchronize()
     if world > 1:

@@ -145,6 +145,7 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "strict_sign"    1 = seed the first direction with sign(c[idx]) instead of the
  *                    reference's sign(|c[idx]|) (homotopy-cpu.cpp:223-227); default 0
  *   "trace"          1 = record the homotopy path of each solve (ss_hip_get_trace)
+ *   "profile_every"  with profiling on, bracket only every k-th fused sweep with events
  *   "zero_on_removal" 1 (default) = a coefficient whose column leaves the support is set
  *                    to exactly 0; 0 = keep the reference's x + gamma*d rounding residue
  *                    (homotopy-cpu.cpp:246-252), which can make a re-inserted column bounce

@@ -480,7 +480,7 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
 // ---- (A_S^T A_S)^-1 (online_inverse.h:224-248, 275-290) and forms the new direction
 // ---- (homotopy-cpu.cpp:257-267) ---------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(kSmallThreads)
+__global__ __launch_bounds__(kUpdThreads)
 void k_gramupd(const T* __restrict__ At, uint32_t ldm, const uint32_t* __restrict__ gam2, uint32_t kcap,
                T* inv0, T* inv1, T* u1, T* u2, T* sgn,
                const T* __restrict__ c, const T* __restrict__ q, T* __restrict__ d, T tol,
@@ -507,7 +507,7 @@ void k_gramupd(const T* __restrict__ At, uint32_t ldm, const uint32_t* __restric
         const uint32_t nv = ldm / VN;                       // multiple of 64
         T acc = T(0);
 #pragma unroll 4
-        for (uint32_t i = threadIdx.x; i < nv; i += kSmallThreads) {
+        for (uint32_t i = threadIdx.x; i < nv; i += kUpdThreads) {
             const V4 a = col[i], bnew = cnew[i];
 #pragma unroll
             for (int e = 0; e < VN; ++e) acc += a[e] * bnew[e];
@@ -525,7 +525,7 @@ void k_gramupd(const T* __restrict__ At, uint32_t ldm, const uint32_t* __restric
     T* Inew = cur ? inv0 : inv1;
     const uint32_t K_old = added ? K_new - 1 : K_new + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = kSmallThreads / 64;
+    constexpr int NW = kUpdThreads / 64;
     const size_t P = kcap;
 
     if (added) {
@@ -654,7 +654,7 @@ hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32
                        ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal);
     uint32_t gb = round + 1;
     if (gb > ws.kcap) gb = ws.kcap;
-    hipLaunchKernelGGL((k_gramupd<T>), dim3(gb), dim3(kSmallThreads), 0, ctx->stream,
+    hipLaunchKernelGGL((k_gramupd<T>), dim3(gb), dim3(kUpdThreads), 0, ctx->stream,
                        static_cast<const T*>(ctx->At), ctx->ldm, ws.gam, ws.kcap, ws.inv[0], ws.inv[1],
                        ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st);
     hipError_t e = hipGetLastError();

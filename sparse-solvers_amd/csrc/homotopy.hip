@@ -393,9 +393,16 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 if (hf[1] != 0) break;
             }
             uint32_t nb = 0;
-            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+            // HIP events cost tens of microseconds of stream time each: time every
+            // `profile_every`-th fused sweep only (option), still inside the solve
+            const bool timed = prof && (round % (uint64_t)std::max(1, ctx->profile_every) == 0);
+            if (timed) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, 2, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, &nb, ws.st));
-            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(2); ++nprof; }
+            if (timed) {
+                HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st));
+                ctx->prof_kind.push_back((int)round + 16);     // >= 16: fused sweep of round (kind-16)
+                ++nprof;
+            }
             HIPCHK(launch_iteration_tail<T>(ctx, ws, (uint32_t)round, nb, tol, max_iter));
         }
 
@@ -430,18 +437,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
             ctx->stats.solve_ms += ms;
             // only sweeps that did real work: the initial one and rounds 1..done_round
-            size_t fused_seen = 0;
             for (size_t i = 0; i < nprof; ++i) {
                 HIPCHK(hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
                 if (ctx->prof_kind[i] == 1) {
                     ctx->stats.sweep1_launches += 1;
                     ctx->stats.sweep1_ms += ms;
-                } else {
-                    ++fused_seen;
-                    if (fused_seen <= hs.done_round) {
-                        ctx->stats.sweep_launches += 1;
-                        ctx->stats.sweep_ms += ms;
-                    }
+                } else if ((uint32_t)(ctx->prof_kind[i] - 16) <= hs.done_round) {
+                    ctx->stats.sweep_launches += 1;
+                    ctx->stats.sweep_ms += ms;
                 }
             }
         }
@@ -655,6 +658,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "strict_sign"))   { ctx->strict_sign = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "trace"))         { ctx->tracing = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { ctx->zero_on_removal = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 
@@ -681,6 +685,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "strict_sign"))   { *value = ctx->strict_sign; return SS_HIP_OK; }
     if (!std::strcmp(key, "trace"))         { *value = ctx->tracing; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { *value = ctx->zero_on_removal; return SS_HIP_OK; }
+    if (!std::strcmp(key, "profile_every")) { *value = ctx->profile_every; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 

@@ -105,11 +105,12 @@ struct ss_hip_ctx {
     size_t lds_per_block = 65536;
 
     // options
-    int sweep_variant = 0;
+    int sweep_variant = 5;   // 16 waves x 4 columns, 2-stage ring, 1 workgroup per CU: fastest on MI355X (profiles/)
     int lookahead = 4;
     int strict_sign = 0;
     int zero_on_removal = 1;
     int profiling = 0;
+    int profile_every = 1;   // with profiling on, time every k-th fused sweep
     int tracing = 0;
     std::vector<sship::TraceEntry> last_trace;   // host copy of the last solve's path
 
