@@ -87,6 +87,9 @@ int ss_hip_homotopy_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy,
  * Batch of B signals sharing the context's sensing matrix: signal b is
  * Y[b*y_stride + i*incy], its solution X[b*x_stride + j*incx].
  * iter_out[B], err_out[B] receive the per-signal reports.
+ * fp32 batches of >= "batch_min" (default 4) signals advance in lock-step: the 2B
+ * correlation GEMVs of a round become MFMA GEMMs over the shared matrix.  Smaller batches
+ * and fp64 run one signal at a time on the memory-bound sweep path.
  */
 int ss_hip_homotopy_solve_batch_f32(ss_hip_ctx* ctx, const float* Y, size_t B,
                                     ptrdiff_t y_stride, ptrdiff_t incy,
@@ -113,6 +116,15 @@ int ss_hip_gemv_t_f64(ss_hip_ctx* ctx, const double* r, double* c, int repeats, 
                       char* err, size_t errlen);
 
 /*
+ * Batched correlations C[b][:] = A^T R[b][:] for B right-hand sides sharing the context's
+ * matrix — the MFMA (fp32 matrix-core) form the batched solver uses once B signals run in
+ * lock-step.  R: B rows of m elements (row stride ldR), C: B rows of n elements (ldC).
+ * fp32 contexts only.  ms_out: mean GEMM time over `repeats` launches (HIP events).
+ */
+int ss_hip_gemm_t_f32(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, float* C, ptrdiff_t ldC,
+                      int repeats, float* ms_out, char* err, size_t errlen);
+
+/*
  * y = A x on the device copy — ss::reconstruct_signal (src/lib.cpp:78-104).
  * x: n elements, y: m elements.
  */
@@ -131,6 +143,7 @@ typedef struct ss_hip_stats {
     double   sweep1_ms;
     uint64_t sweep1_bytes;         /* m*n*s + m*s + n*s                                         */
     double   solve_ms;             /* HIP-event time of whole solves (upload of y .. x ready)  */
+    uint64_t batch_rounds;         /* lock-step rounds run by the batched (MFMA) path          */
 } ss_hip_stats;
 
 /* profiling != 0: bracket every sweep launch with HIP events on the context's stream. */
@@ -145,6 +158,8 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "strict_sign"    1 = seed the first direction with sign(c[idx]) instead of the
  *                    reference's sign(|c[idx]|) (homotopy-cpu.cpp:223-227); default 0
  *   "trace"          1 = record the homotopy path of each solve (ss_hip_get_trace)
+ *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 4)
+ *   "batch_chunk"    signals processed together by the batched path (default 4096)
  *   "profile_every"  with profiling on, bracket only every k-th fused sweep with events
  *   "zero_on_removal" 1 (default) = a coefficient whose column leaves the support is set
  *                    to exactly 0; 0 = keep the reference's x + gamma*d rounding residue

@@ -146,12 +146,22 @@ __device__ __forceinline__ T block_dot(const T* a, const T* b, uint32_t len, T* 
 // ---- k_init: first pick, homotopy-cpu.cpp:217-229 ------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kUpdThreads)
-void k_init(const T* __restrict__ At, uint32_t ldm, const T* __restrict__ c,
+void k_init(const T* __restrict__ At, SlotDims L, const T* __restrict__ c,
             const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
             T* __restrict__ d, uint8_t* __restrict__ insup, uint32_t* __restrict__ gam,
             uint32_t* __restrict__ touched, T* __restrict__ inv0, T tol, int strict_sign,
             DevState* st, TraceEntry* trace)
 {
+    {   // slot = blockIdx.y
+        const size_t s = blockIdx.y;
+        c += s * L.n_pad; d += s * L.n_pad; insup += s * L.n_pad;
+        pmax_val += s * L.pmax_stride; pmax_idx += s * L.pmax_stride;
+        gam += s * 2 * L.kcap; touched += s * 2 * L.kcap;
+        inv0 += s * 2 * (size_t)L.kcap * L.kcap;
+        st += s;
+        if (s != 0) trace = nullptr;
+    }
+    const uint32_t ldm = L.ldm;
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
     T c_inf;
@@ -234,11 +244,21 @@ constexpr int kRpRows = 64 * kRpRowsPerLane;
 
 template <typename T>
 __global__ __launch_bounds__(kRpThreads)
-void k_rp(const T* __restrict__ At, uint32_t ldm, const T* __restrict__ y,
+void k_rp(const T* __restrict__ At, SlotDims L, const T* __restrict__ y,
           const T* __restrict__ x, const T* __restrict__ d,
-          const uint32_t* __restrict__ touched2 /* [2][kcap] */, uint32_t kcap,
+          const uint32_t* __restrict__ touched2 /* [2][kcap] */,
           T* __restrict__ rhs, const DevState* st)
 {
+    const uint32_t ldm = L.ldm, kcap = L.kcap;
+    T* rhs_p;
+    {   // slot = blockIdx.y
+        const size_t s = blockIdx.y;
+        y += s * ldm; x += s * L.n_pad; d += s * L.n_pad;
+        touched2 += s * 2 * kcap;
+        rhs_p = rhs + ((size_t)L.b_pad + s) * ldm;
+        rhs += s * ldm;
+        st += s;
+    }
     if (st->done) return;
     typedef T V2 __attribute__((ext_vector_type(2)));
     __shared__ T s_r[4][kRpRows];
@@ -281,7 +301,18 @@ void k_rp(const T* __restrict__ At, uint32_t ldm, const T* __restrict__ y,
         const T sr = ((s_r[0][t] + s_r[1][t]) + s_r[2][t]) + s_r[3][t];
         const T sp = ((s_p[0][t] + s_p[1][t]) + s_p[2][t]) + s_p[3][t];
         rhs[i] = y[i] - sr;
-        rhs[(size_t)ldm + i] = sp;
+        rhs_p[i] = sp;
+    }
+}
+
+// a slot finished: count it; the solve is over when every slot has (host sees hflags[1])
+__device__ __forceinline__ void signal_done(uint32_t* hflags, uint32_t* ndone, uint32_t nslots, uint32_t round)
+{
+    uint32_t prev = nslots - 1u;
+    if (ndone != nullptr) prev = __hip_atomic_fetch_add(ndone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (hflags != nullptr) {
+        if (prev + 1u >= nslots) __hip_atomic_store(&hflags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -296,10 +327,20 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
                const T* __restrict__ d, uint8_t* __restrict__ insup,
                const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
                T* pmin_val, uint32_t* pmin_idx,
-               uint32_t* __restrict__ gam2, uint32_t* __restrict__ touched2, uint32_t kcap,
+               uint32_t* __restrict__ gam2, uint32_t* __restrict__ touched2, SlotDims L,
                DevState* st, uint32_t* hflags, TraceEntry* trace, uint32_t trace_cap,
-               int zero_on_removal)
+               int zero_on_removal, uint32_t* ndone, uint32_t nslots)
 {
+    const uint32_t kcap = L.kcap;
+    {   // slot = blockIdx.y
+        const size_t s = blockIdx.y;
+        c += s * L.n_pad; q += s * L.n_pad; x += s * L.n_pad; d += s * L.n_pad; insup += s * L.n_pad;
+        pmax_val += s * L.pmax_stride; pmax_idx += s * L.pmax_stride;
+        pmin_val += s * L.pmin_stride; pmin_idx += s * L.pmin_stride;
+        gam2 += s * 2 * kcap; touched2 += s * 2 * kcap;
+        st += s;
+        if (s != 0) trace = nullptr;
+    }
     if (st->done) return;
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
@@ -320,10 +361,7 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
             st->iter = round - 1;
             st->done_round = round;
             st->done = 1;
-            if (hflags) {
-                __hip_atomic_store(&hflags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            signal_done(hflags, ndone, nslots, round);
         }
         return;
     }
@@ -424,10 +462,7 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
             st->c_inf = (double)c_inf;
             st->done_round = round;
             st->done = 1;
-            if (hflags) {
-                __hip_atomic_store(&hflags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            signal_done(hflags, ndone, nslots, round);
         }
         return;
     }
@@ -481,11 +516,20 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
 // ---- (homotopy-cpu.cpp:257-267) ---------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kUpdThreads)
-void k_gramupd(const T* __restrict__ At, uint32_t ldm, const uint32_t* __restrict__ gam2, uint32_t kcap,
+void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict__ gam2,
                T* inv0, T* inv1, T* u1, T* u2, T* sgn,
                const T* __restrict__ c, const T* __restrict__ q, T* __restrict__ d, T tol,
                DevState* st)
 {
+    const uint32_t ldm = L.ldm, kcap = L.kcap;
+    {   // slot = blockIdx.y
+        const size_t s = blockIdx.y;
+        gam2 += s * 2 * kcap;
+        inv0 += s * 2 * (size_t)kcap * kcap; inv1 += s * 2 * (size_t)kcap * kcap;
+        u1 += s * kcap; u2 += s * kcap; sgn += s * kcap;
+        c += s * L.n_pad; q += s * L.n_pad; d += s * L.n_pad;
+        st += s;
+    }
     if (st->done) return;
     typedef T V4 __attribute__((ext_vector_type(16 / sizeof(T))));
     constexpr int VN = 16 / sizeof(T);
@@ -618,48 +662,91 @@ void k_gemv_n(const T* __restrict__ At, uint32_t ldm, uint32_t m, uint32_t n,
     y[i] = acc;
 }
 
+// ---- k_absmax: per-slot partial (max |c|, first index) of the GEMM's correlation rows -------
+constexpr uint32_t kAbsmaxChunk = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_absmax(const T* __restrict__ c, uint32_t n, SlotDims L, T* __restrict__ pmax_val,
+              uint32_t* __restrict__ pmax_idx, const DevState* st)
+{
+    const size_t s = blockIdx.y;
+    if (st[s].done) return;
+    c += s * L.n_pad;
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    T v = T(-1);
+    uint32_t ix = 0xffffffffu;
+    const uint32_t base = blockIdx.x * kAbsmaxChunk;
+#pragma unroll
+    for (uint32_t k = 0; k < kAbsmaxChunk / kSmallThreads; ++k) {
+        const uint32_t i = base + k * kSmallThreads + threadIdx.x;
+        if (i < n) {
+            const T a = c[i] < T(0) ? -c[i] : c[i];
+            if (better_max(a, i, v, ix)) { v = a; ix = i; }
+        }
+    }
+    block_reduce_pair<T, true>(v, ix, sv, si);
+    if (threadIdx.x == 0) {
+        pmax_val[s * L.pmax_stride + blockIdx.x] = v;
+        pmax_idx[s * L.pmax_stride + blockIdx.x] = ix;
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------
 
 template <typename T>
-hipError_t launch_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsweep_blocks, T tol)
+hipError_t launch_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t nparts, T tol)
 {
-    hipLaunchKernelGGL((k_init<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream,
-                       static_cast<const T*>(ctx->At), ctx->ldm, ws.c, ws.pmax_val, ws.pmax_idx,
-                       nsweep_blocks, ws.d, ws.insup, ws.gam, ws.touched, ws.inv[0], tol,
+    hipLaunchKernelGGL((k_init<T>), dim3(1, nslots), dim3(kUpdThreads), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ws.dims, ws.c, ws.pmax_val, ws.pmax_idx,
+                       nparts, ws.d, ws.insup, ws.gam, ws.touched, ws.inv[0], tol,
                        ctx->strict_sign, ws.st, ws.trace);
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_rp(const ss_hip_ctx* ctx, Workspace<T>& ws)
+hipError_t launch_rp(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots)
 {
     const uint32_t blocks = ctx->ldm / kRpRows;
-    hipLaunchKernelGGL((k_rp<T>), dim3(blocks), dim3(kRpThreads), 0, ctx->stream,
-                       static_cast<const T*>(ctx->At), ctx->ldm, ws.y, ws.x, ws.d, ws.touched,
-                       ws.kcap, ws.rhs, ws.st);
+    hipLaunchKernelGGL((k_rp<T>), dim3(blocks, nslots), dim3(kRpThreads), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ws.dims, ws.y, ws.x, ws.d, ws.touched,
+                       ws.rhs, ws.st);
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round,
-                                 uint32_t nsweep_blocks, T tol, uint32_t max_iter)
+hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round,
+                                 uint32_t nparts, T tol, uint32_t max_iter)
 {
     const uint32_t n = (uint32_t)ctx->n;
     const uint32_t per_block = kSmallThreads * kScanPerThread;
     uint32_t ns = (n + per_block - 1) / per_block;
-    if (ns > kMaxScanBlocks) ns = kMaxScanBlocks;   // k_scansel grid-strides
-    hipLaunchKernelGGL((k_scansel<T>), dim3(ns), dim3(kSmallThreads), 0, ctx->stream, round, tol,
+    if (ns > ws.dims.pmin_stride) ns = ws.dims.pmin_stride;   // k_scansel grid-strides
+    hipLaunchKernelGGL((k_scansel<T>), dim3(ns, nslots), dim3(kSmallThreads), 0, ctx->stream, round, tol,
                        max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
-                       nsweep_blocks, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.kcap, ws.st,
-                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal);
+                       nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
+                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ws.ndone, nslots);
     uint32_t gb = round + 1;
     if (gb > ws.kcap) gb = ws.kcap;
-    hipLaunchKernelGGL((k_gramupd<T>), dim3(gb), dim3(kUpdThreads), 0, ctx->stream,
-                       static_cast<const T*>(ctx->At), ctx->ldm, ws.gam, ws.kcap, ws.inv[0], ws.inv[1],
+    hipLaunchKernelGGL((k_gramupd<T>), dim3(gb, nslots), dim3(kUpdThreads), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ws.dims, ws.gam, ws.inv[0], ws.inv[1],
                        ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_rp(ctx, ws);
+    return launch_rp(ctx, ws, nslots);
+}
+
+template <typename T>
+hipError_t launch_absmax(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t* nparts_out)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    const uint32_t nb = (n + kAbsmaxChunk - 1) / kAbsmaxChunk;
+    if (nb > ws.dims.pmax_stride) return hipErrorInvalidValue;
+    if (nparts_out) *nparts_out = nb;
+    hipLaunchKernelGGL((k_absmax<T>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, ws.c, n,
+                       ws.dims, ws.pmax_val, ws.pmax_idx, ws.st);
+    return hipGetLastError();
 }
 
 template <typename T>
@@ -672,14 +759,16 @@ hipError_t launch_gemv_n(const ss_hip_ctx* ctx, const T* x_dev, T* y_dev)
     return hipGetLastError();
 }
 
-template hipError_t launch_init<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
-template hipError_t launch_init<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double);
-template hipError_t launch_rp<float>(const ss_hip_ctx*, Workspace<float>&);
-template hipError_t launch_rp<double>(const ss_hip_ctx*, Workspace<double>&);
-template hipError_t launch_iteration_tail<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t,
+template hipError_t launch_init<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, float);
+template hipError_t launch_init<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t, double);
+template hipError_t launch_rp<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t);
+template hipError_t launch_rp<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t);
+template hipError_t launch_iteration_tail<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t,
                                                  uint32_t, float, uint32_t);
-template hipError_t launch_iteration_tail<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t,
+template hipError_t launch_iteration_tail<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t,
                                                   uint32_t, double, uint32_t);
+template hipError_t launch_absmax<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t*);
+template hipError_t launch_absmax<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t*);
 template hipError_t launch_gemv_n<float>(const ss_hip_ctx*, const float*, float*);
 template hipError_t launch_gemv_n<double>(const ss_hip_ctx*, const double*, double*);
 

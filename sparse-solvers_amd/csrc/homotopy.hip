@@ -152,64 +152,82 @@ void upload_matrix(ss_hip_ctx* ctx, const T* A, ptrdiff_t rs, ptrdiff_t cs)
 }
 
 template <typename T>
+void release_arrays(Workspace<T>* w)
+{
+    void* ptrs[] = { w->y, w->rhs, w->cq, w->x, w->d, w->insup, w->pmax_val, w->pmax_idx,
+                     w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->u1,
+                     w->u2, w->sgn, w->st, w->ndone };
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    TraceEntry* tr = w->trace;
+    const uint32_t tc = w->trace_cap;
+    *w = Workspace<T>();
+    w->trace = tr;
+    w->trace_cap = tc;
+}
+
+template <typename T>
 void free_ws(Workspace<T>* w)
 {
     if (!w) return;
-    void* ptrs[] = { w->y, w->rhs, w->c, w->q, w->x, w->d, w->insup, w->pmax_val, w->pmax_idx,
-                     w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->inv[1], w->u1,
-                     w->u2, w->sgn, w->st, w->trace };
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    release_arrays(w);
+    if (w->trace) (void)hipFree(w->trace);
     delete w;
 }
 
+// Makes sure the workspace holds `nslots` signals and an active set of `kcap` columns each.
+// Everything is (re)allocated together; sizes only grow.
 template <typename T>
-void alloc_ws_fixed(ss_hip_ctx* ctx)
+void ensure_workspace(ss_hip_ctx* ctx, uint32_t nslots, uint32_t kcap)
 {
-    auto* w = new Workspace<T>();
-    ctx->ws = w;
-    const size_t ldm = ctx->ldm, np = ctx->n_pad, s = sizeof(T);
-    HIPCHK(hipMalloc(&w->y, ldm * s));
-    HIPCHK(hipMalloc(&w->rhs, 2 * ldm * s));
-    HIPCHK(hipMalloc(&w->c, np * s));
-    HIPCHK(hipMalloc(&w->q, np * s));
-    HIPCHK(hipMalloc(&w->x, np * s));
-    HIPCHK(hipMalloc(&w->d, np * s));
-    HIPCHK(hipMalloc(&w->insup, np));
-    HIPCHK(hipMalloc(&w->pmax_val, kMaxSweepBlocks * s));
-    HIPCHK(hipMalloc(&w->pmax_idx, kMaxSweepBlocks * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&w->pmin_val, kMaxScanBlocks * s));
-    HIPCHK(hipMalloc(&w->pmin_idx, kMaxScanBlocks * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&w->st, sizeof(DevState)));
-    HIPCHK(hipMemset(w->y, 0, ldm * s));
-    HIPCHK(hipMemset(w->rhs, 0, 2 * ldm * s));
-    HIPCHK(hipMemset(w->c, 0, np * s));
-    HIPCHK(hipMemset(w->q, 0, np * s));
-    HIPCHK(hipMemset(w->st, 0, sizeof(DevState)));
-}
-
-template <typename T>
-void ensure_kcap(ss_hip_ctx* ctx, uint32_t kcap)
-{
+    if (!ctx->ws) ctx->ws = new Workspace<T>();
     Workspace<T>* w = ws_of<T>(ctx);
-    if (kcap <= w->kcap) return;
-    // grow geometrically so repeated solves with slightly larger max_iter do not realloc
-    uint32_t want = std::max<uint32_t>(kcap, std::min<uint32_t>(kKcapLimit, std::max<uint32_t>(64, w->kcap * 2)));
-    void* olds[] = { w->gam, w->touched, w->inv[0], w->inv[1], w->u1, w->u2, w->sgn };
-    for (void* p : olds)
-        if (p) HIPCHK(hipFree(p));
-    w->gam = w->touched = nullptr;
-    w->inv[0] = w->inv[1] = w->u1 = w->u2 = w->sgn = nullptr;
-    w->kcap = 0;
-    const size_t s = sizeof(T);
-    HIPCHK(hipMalloc(&w->gam, 2 * (size_t)want * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&w->touched, 2 * (size_t)want * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&w->inv[0], (size_t)want * want * s));
-    HIPCHK(hipMalloc(&w->inv[1], (size_t)want * want * s));
-    HIPCHK(hipMalloc(&w->u1, (size_t)want * s));
-    HIPCHK(hipMalloc(&w->u2, (size_t)want * s));
-    HIPCHK(hipMalloc(&w->sgn, (size_t)want * s));
-    w->kcap = want;
+    if (nslots <= w->b_cap && kcap <= w->kcap) return;
+    uint32_t want_k = std::max<uint32_t>(kcap, w->kcap);
+    if (kcap > w->kcap)   // grow geometrically so slightly larger max_iter does not realloc
+        want_k = std::max<uint32_t>(kcap, std::min<uint32_t>(kKcapLimit, std::max<uint32_t>(64, w->kcap * 2)));
+    const uint32_t want_b = std::max<uint32_t>(nslots, w->b_cap);
+    // one slot keeps the classic [2][ldm] / [2][n_pad] layout; batches are padded to whole
+    // 128-row GEMM tiles
+    const uint32_t b_pad = want_b == 1 ? 1u : (want_b + 127u) / 128u * 128u;
+    release_arrays(w);
+    const size_t ldm = ctx->ldm, np = ctx->n_pad, s = sizeof(T), B = want_b, K = want_k;
+    SlotDims L{};
+    L.n_pad = ctx->n_pad;
+    L.ldm = ctx->ldm;
+    L.kcap = want_k;
+    L.b_pad = b_pad;
+    L.pmax_stride = kMaxSweepBlocks;
+    L.pmin_stride = kMaxScanBlocks;
+    HIPCHK(hipMalloc(&w->y, B * ldm * s));
+    HIPCHK(hipMalloc(&w->rhs, 2 * (size_t)b_pad * ldm * s));
+    HIPCHK(hipMalloc(&w->cq, 2 * (size_t)b_pad * np * s));
+    HIPCHK(hipMalloc(&w->x, B * np * s));
+    HIPCHK(hipMalloc(&w->d, B * np * s));
+    HIPCHK(hipMalloc(&w->insup, B * np));
+    HIPCHK(hipMalloc(&w->pmax_val, B * L.pmax_stride * s));
+    HIPCHK(hipMalloc(&w->pmax_idx, B * L.pmax_stride * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&w->pmin_val, B * L.pmin_stride * s));
+    HIPCHK(hipMalloc(&w->pmin_idx, B * L.pmin_stride * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&w->gam, B * 2 * K * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&w->touched, B * 2 * K * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&w->inv[0], B * 2 * K * K * s));
+    HIPCHK(hipMalloc(&w->u1, B * K * s));
+    HIPCHK(hipMalloc(&w->u2, B * K * s));
+    HIPCHK(hipMalloc(&w->sgn, B * K * s));
+    HIPCHK(hipMalloc(&w->st, B * sizeof(DevState)));
+    HIPCHK(hipMalloc(&w->ndone, 64));
+    w->inv[1] = w->inv[0] + K * K;
+    w->c = w->cq;
+    w->q = w->cq + (size_t)b_pad * np;
+    w->b_cap = want_b;
+    w->kcap = want_k;
+    w->dims = L;
+    HIPCHK(hipMemset(w->y, 0, B * ldm * s));
+    HIPCHK(hipMemset(w->rhs, 0, 2 * (size_t)b_pad * ldm * s));
+    HIPCHK(hipMemset(w->cq, 0, 2 * (size_t)b_pad * np * s));
+    HIPCHK(hipMemset(w->st, 0, B * sizeof(DevState)));
+    HIPCHK(hipMemset(w->ndone, 0, 64));
 }
 
 template <typename T>
@@ -256,7 +274,7 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
         HIPCHK(hipMemsetAsync(ctx->At, 0, bytes, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         upload_matrix<T>(ctx, A, rs, cs);
-        alloc_ws_fixed<T>(ctx);
+        ensure_workspace<T>(ctx, 1, 64);
         HIPCHK(hipHostMalloc(&ctx->host_flags, 64 * sizeof(uint32_t), hipHostMallocMapped));
         std::memset(ctx->host_flags, 0, 64 * sizeof(uint32_t));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->dev_flags), ctx->host_flags, 0));
@@ -335,7 +353,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const size_t m = ctx->m, n = ctx->n;
         const uint32_t kcap = (uint32_t)std::min<uint64_t>(
             std::min<uint64_t>(n, (uint64_t)max_iter + 1), kKcapLimit);
-        ensure_kcap<T>(ctx, kcap);
+        ensure_workspace<T>(ctx, 1, kcap);
         Workspace<T>& ws = *ws_of<T>(ctx);
         hipStream_t st = ctx->stream;
         const uint32_t want_trace = ctx->tracing ? (uint32_t)std::min<uint64_t>((uint64_t)max_iter + 2, 1u << 20) : 0u;
@@ -361,15 +379,17 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         HIPCHK(hipMemsetAsync(ws.d, 0, (size_t)ctx->n_pad * sizeof(T), st));
         HIPCHK(hipMemsetAsync(ws.insup, 0, (size_t)ctx->n_pad, st));
         HIPCHK(hipMemsetAsync(ws.st, 0, sizeof(DevState), st));
+        HIPCHK(hipMemsetAsync(ws.ndone, 0, sizeof(uint32_t), st));
         HIPCHK(hipMemcpyAsync(ws.rhs, ws.y, (size_t)ctx->ldm * sizeof(T), hipMemcpyDeviceToDevice, st));
+        const size_t rhs_stride = (size_t)ws.dims.b_pad * ctx->ldm;   // r-block -> p-block
 
         // c = A^T y  (residual_vector with x = 0, homotopy-cpu.cpp:215)
         uint32_t nb1 = 0;
         if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
-        HIPCHK(launch_sweep<T>(ctx, ws.rhs, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+        HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
         if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
-        HIPCHK(launch_init<T>(ctx, ws, nb1, tol));
-        HIPCHK(launch_rp<T>(ctx, ws));
+        HIPCHK(launch_init<T>(ctx, ws, 1, nb1, tol));
+        HIPCHK(launch_rp<T>(ctx, ws, 1));
 
         // The device decides termination (k_scansel raises DevState::done and mirrors it,
         // with the round it has reached, into pinned host memory).  The host keeps at most
@@ -397,13 +417,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             // `profile_every`-th fused sweep only (option), still inside the solve
             const bool timed = prof && (round % (uint64_t)std::max(1, ctx->profile_every) == 0);
             if (timed) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
-            HIPCHK(launch_sweep<T>(ctx, ws.rhs, 2, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, &nb, ws.st));
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 2, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, &nb, ws.st));
             if (timed) {
                 HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st));
                 ctx->prof_kind.push_back((int)round + 16);     // >= 16: fused sweep of round (kind-16)
                 ++nprof;
             }
-            HIPCHK(launch_iteration_tail<T>(ctx, ws, (uint32_t)round, nb, tol, max_iter));
+            HIPCHK(launch_iteration_tail<T>(ctx, ws, 1, (uint32_t)round, nb, tol, max_iter));
         }
 
         DevState hs;
@@ -458,12 +478,120 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
     return SS_HIP_OK;
 }
 
-template <typename T>
-int solve_batch_impl(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, T tol,
-                     uint32_t max_iter, T* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
-                     double* err_out, char* err, size_t errlen)
+// ---- batched solve: B signals share the sensing matrix and advance in lock-step ---------
+// Per round the 2*B correlation GEMVs are two MFMA GEMMs ([c] = R·Atᵀ, [q] = P·Atᵀ, gemm.hip);
+// the active-set tail runs for all signals at once (grid.y = slot).  A signal that has
+// terminated turns its kernels into no-ops; the solve ends when every slot is done.
+int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy,
+                         float tol, uint32_t max_iter, float* X, ptrdiff_t x_stride, ptrdiff_t incx,
+                         uint32_t* iter_out, double* err_out, char* err, size_t errlen)
 {
-    if (!Y || !X) { set_err(err, errlen, "solve_batch: Y and X must not be null"); return SS_HIP_EINVAL; }
+    using T = float;
+    if (max_iter == 0) { set_err(err, errlen, "solve_batch: max_iterations must be > 0"); return SS_HIP_EINVAL; }
+    if (!(tol >= std::numeric_limits<T>::epsilon() && tol < T(1))) {
+        set_err(err, errlen, "solve_batch: tolerance must satisfy eps <= tolerance < 1");
+        return SS_HIP_EINVAL;
+    }
+    if (incy <= 0 || incx <= 0) { set_err(err, errlen, "solve_batch: increments must be positive"); return SS_HIP_EINVAL; }
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        const size_t m = ctx->m, n = ctx->n, ldm = ctx->ldm, np = ctx->n_pad;
+        const uint32_t kcap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n, (uint64_t)max_iter + 1), kKcapLimit);
+        const size_t chunk = (size_t)std::max(4, ctx->batch_chunk);
+        hipStream_t st = ctx->stream;
+        std::vector<DevState> hs;
+        for (size_t b0 = 0; b0 < B; b0 += chunk) {
+            const uint32_t Bc = (uint32_t)std::min(chunk, B - b0);
+            ensure_workspace<T>(ctx, Bc, kcap);
+            Workspace<T>& ws = *ws_of<T>(ctx);
+            const uint32_t rows = (Bc + 127u) / 128u * 128u;          // GEMM rows of each block
+            const size_t bp = ws.dims.b_pad;
+            T* const Rblk = ws.rhs;
+            T* const Pblk = ws.rhs + bp * ldm;
+
+            ctx->host_flags[0] = 0;
+            ctx->host_flags[1] = 0;
+            const T* Yc = Y + (ptrdiff_t)b0 * y_stride;
+            if (incy == 1) {
+                HIPCHK(hipMemcpy2DAsync(ws.y, ldm * sizeof(T), Yc, (size_t)y_stride * sizeof(T), m * sizeof(T), Bc,
+                                        hipMemcpyDefault, st));
+            } else {
+                for (uint32_t b = 0; b < Bc; ++b) copy_in<T>(ctx, ws.y + (size_t)b * ldm, Yc + (ptrdiff_t)b * y_stride, incy, m);
+            }
+            HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)Bc * np * sizeof(T), st));
+            HIPCHK(hipMemsetAsync(ws.d, 0, (size_t)Bc * np * sizeof(T), st));
+            HIPCHK(hipMemsetAsync(ws.insup, 0, (size_t)Bc * np, st));
+            HIPCHK(hipMemsetAsync(ws.st, 0, (size_t)Bc * sizeof(DevState), st));
+            HIPCHK(hipMemsetAsync(ws.ndone, 0, sizeof(uint32_t), st));
+            HIPCHK(hipMemsetAsync(ws.rhs, 0, 2 * bp * ldm * sizeof(T), st));
+            HIPCHK(hipMemcpyAsync(Rblk, ws.y, (size_t)Bc * ldm * sizeof(T), hipMemcpyDeviceToDevice, st));
+
+            // c_b = A^T y_b for every signal (residual_vector with x = 0, homotopy-cpu.cpp:215)
+            uint32_t nparts = 0;
+            HIPCHK(launch_gemm_tn_f32(ctx, Rblk, rows, (uint32_t)ldm, ws.c, (uint32_t)np, nullptr));
+            HIPCHK(launch_absmax<T>(ctx, ws, Bc, &nparts));
+            HIPCHK(launch_init<T>(ctx, ws, Bc, nparts, tol));
+            HIPCHK(launch_rp<T>(ctx, ws, Bc));
+
+            const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
+            volatile uint32_t* hf = ctx->host_flags;
+            const uint64_t last_round = (uint64_t)max_iter + 1;
+            uint64_t rounds_run = 0;
+            for (uint64_t round = 1; round <= last_round; ++round) {
+                if (round > L) {
+                    const uint32_t need = (uint32_t)(round - L);
+                    uint32_t spins = 0;
+                    while (hf[1] == 0 && hf[0] < need) {
+                        if ((++spins & 0x3ffu) == 0) {
+                            const hipError_t q = hipStreamQuery(st);
+                            if (q == hipSuccess) break;
+                            if (q != hipErrorNotReady) throw HipFail{ q, "hipStreamQuery(batch loop)" };
+                        }
+                        std::this_thread::yield();
+                    }
+                    if (hf[1] != 0) break;
+                }
+                HIPCHK(launch_gemm_tn_f32(ctx, Rblk, rows, (uint32_t)ldm, ws.c, (uint32_t)np, nullptr));
+                HIPCHK(launch_gemm_tn_f32(ctx, Pblk, rows, (uint32_t)ldm, ws.q, (uint32_t)np, nullptr));
+                HIPCHK(launch_absmax<T>(ctx, ws, Bc, &nparts));
+                HIPCHK(launch_iteration_tail<T>(ctx, ws, Bc, (uint32_t)round, nparts, tol, max_iter));
+                ++rounds_run;
+            }
+            hs.resize(Bc);
+            HIPCHK(hipMemcpyAsync(hs.data(), ws.st, (size_t)Bc * sizeof(DevState), hipMemcpyDeviceToHost, st));
+            float* Xc = X + (ptrdiff_t)b0 * x_stride;
+            if (incx == 1) {
+                HIPCHK(hipMemcpy2DAsync(Xc, (size_t)x_stride * sizeof(T), ws.x, np * sizeof(T), n * sizeof(T), Bc,
+                                        hipMemcpyDefault, st));
+            } else {
+                for (uint32_t b = 0; b < Bc; ++b) copy_out<T>(ctx, Xc + (ptrdiff_t)b * x_stride, incx, ws.x + (size_t)b * np, n);
+            }
+            HIPCHK(hipStreamSynchronize(st));
+            for (uint32_t b = 0; b < Bc; ++b) {
+                if (!hs[b].done) { set_err(err, errlen, "solve_batch: internal error, a signal did not terminate"); return SS_HIP_ERUNTIME; }
+                if (hs[b].status != 0) { set_err(err, errlen, "solve_batch: active set outgrew the workspace capacity"); return (int)hs[b].status; }
+                if (iter_out) iter_out[b0 + b] = hs[b].iter;
+                if (err_out) err_out[b0 + b] = hs[b].c_inf;
+                ctx->stats.iterations += hs[b].iter;
+            }
+            ctx->stats.solves += Bc;
+            ctx->stats.batch_rounds += rounds_run;
+        }
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        return SS_HIP_ERUNTIME;
+    } catch (const std::bad_alloc&) {
+        set_err(err, errlen, "solve_batch: out of host memory");
+        return SS_HIP_ENOMEM;
+    }
+    return SS_HIP_OK;
+}
+
+template <typename T>
+int solve_batch_seq(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, T tol,
+                    uint32_t max_iter, T* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
+                    double* err_out, char* err, size_t errlen)
+{
     for (size_t b = 0; b < B; ++b) {
         uint32_t it = 0;
         double e = 0.0;
@@ -474,6 +602,36 @@ int solve_batch_impl(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, 
         if (err_out) err_out[b] = e;
     }
     return SS_HIP_OK;
+}
+
+int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, float tol,
+                         uint32_t max_iter, float* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
+                         double* err_out, char* err, size_t errlen)
+{
+    // lock-step MFMA path once enough signals share the matrix (batch_min option, default 4)
+    if (B >= (size_t)std::max(2, ctx->batch_min))
+        return solve_batch_gemm_f32(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen);
+    return solve_batch_seq<float>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen);
+}
+
+int solve_batch_dispatch(ss_hip_ctx* ctx, const double* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, double tol,
+                         uint32_t max_iter, double* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
+                         double* err_out, char* err, size_t errlen)
+{
+    // fp64: one signal at a time (memory-bound sweep path)
+    return solve_batch_seq<double>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen);
+}
+
+template <typename T>
+int solve_batch_impl(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, T tol,
+                     uint32_t max_iter, T* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
+                     double* err_out, char* err, size_t errlen)
+{
+    if (!ctx) { set_err(err, errlen, "solve_batch: null context"); return SS_HIP_EINVAL; }
+    if (ctx->is_f64 != (sizeof(T) == 8)) { set_err(err, errlen, "solve_batch: element type mismatch"); return SS_HIP_ETYPE; }
+    if (!Y || !X) { set_err(err, errlen, "solve_batch: Y and X must not be null"); return SS_HIP_EINVAL; }
+    if (B == 0) return SS_HIP_OK;
+    return solve_batch_dispatch(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen);
 }
 
 template <typename T>
@@ -490,7 +648,7 @@ int gemv_t_impl(ss_hip_ctx* ctx, const T* r, T* c, int repeats, float* ms_out, c
         uint32_t nb = 0;
         HIPCHK(hipEventRecord(ctx->ev_solve0, st));
         for (int i = 0; i < repeats; ++i)
-            HIPCHK(launch_sweep<T>(ctx, ws.rhs, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, 0, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
         HIPCHK(hipEventRecord(ctx->ev_solve1, st));
         copy_out<T>(ctx, c, 1, ws.c, ctx->n);
         HIPCHK(hipStreamSynchronize(st));
@@ -502,6 +660,44 @@ int gemv_t_impl(ss_hip_ctx* ctx, const T* r, T* c, int repeats, float* ms_out, c
         return SS_HIP_ERUNTIME;
     }
     return SS_HIP_OK;
+}
+
+// C[b][:] = A^T R[b][:] for B right-hand sides through the MFMA GEMM (fp32 contexts)
+int gemm_t_impl(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, float* C, ptrdiff_t ldC,
+                int repeats, float* ms_out, char* err, size_t errlen)
+{
+    if (!ctx || !R || !C || B == 0) { set_err(err, errlen, "gemm_t: null/empty argument"); return SS_HIP_EINVAL; }
+    if (ctx->is_f64) { set_err(err, errlen, "gemm_t: fp32 contexts only"); return SS_HIP_ETYPE; }
+    if (repeats < 1) repeats = 1;
+    float* Rd = nullptr;
+    float* Dd = nullptr;
+    int rc = SS_HIP_OK;
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        const size_t Bp = (B + 127) / 128 * 128;
+        const size_t ldm = ctx->ldm, np = ctx->n_pad;
+        HIPCHK(hipMalloc(&Rd, Bp * ldm * sizeof(float)));
+        HIPCHK(hipMalloc(&Dd, Bp * np * sizeof(float)));
+        HIPCHK(hipMemsetAsync(Rd, 0, Bp * ldm * sizeof(float), ctx->stream));
+        HIPCHK(hipMemcpy2DAsync(Rd, ldm * sizeof(float), R, (size_t)ldR * sizeof(float),
+                                ctx->m * sizeof(float), B, hipMemcpyDefault, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev_solve0, ctx->stream));
+        for (int i = 0; i < repeats; ++i)
+            HIPCHK(launch_gemm_tn_f32(ctx, Rd, (uint32_t)Bp, (uint32_t)ldm, Dd, (uint32_t)np, nullptr));
+        HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
+        HIPCHK(hipMemcpy2DAsync(C, (size_t)ldC * sizeof(float), Dd, np * sizeof(float),
+                                ctx->n * sizeof(float), B, hipMemcpyDefault, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
+        if (ms_out) *ms_out = ms / (float)repeats;
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        rc = SS_HIP_ERUNTIME;
+    }
+    if (Rd) (void)hipFree(Rd);
+    if (Dd) (void)hipFree(Dd);
+    return rc;
 }
 
 template <typename T>
@@ -616,6 +812,12 @@ int ss_hip_gemv_t_f64(ss_hip_ctx* ctx, const double* r, double* c, int repeats, 
     return gemv_t_impl<double>(ctx, r, c, repeats, ms_out, err, errlen);
 }
 
+int ss_hip_gemm_t_f32(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, float* C, ptrdiff_t ldC,
+                      int repeats, float* ms_out, char* err, size_t errlen)
+{
+    return gemm_t_impl(ctx, R, B, ldR, C, ldC, repeats, ms_out, err, errlen);
+}
+
 int ss_hip_reconstruct_f32(ss_hip_ctx* ctx, const float* x, float* y, char* err, size_t errlen)
 {
     return reconstruct_impl<float>(ctx, x, y, err, errlen);
@@ -659,6 +861,8 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "trace"))         { ctx->tracing = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { ctx->zero_on_removal = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_chunk"))   { ctx->batch_chunk = (int)std::max<long>(4, value); return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 
@@ -686,6 +890,8 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "trace"))         { *value = ctx->tracing; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { *value = ctx->zero_on_removal; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { *value = ctx->profile_every; return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_chunk"))   { *value = ctx->batch_chunk; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 

@@ -17,14 +17,15 @@ namespace sship {
 // wave-instruction of the sweep (64 lanes x 16 B) stays inside one column and the
 // zero padding contributes exact zeros to the dot products.
 constexpr uint32_t kRowPad = 256;
-// Columns are padded (zero-filled) to a multiple of this so the sweep needs no tail code.
-constexpr uint32_t kColPad = 64;
+// Columns are padded (zero-filled) to a multiple of this so the sweep needs no tail code
+// and the MFMA GEMM of the batched path sees whole 128-column tiles.
+constexpr uint32_t kColPad = 128;
 // Hard cap of the active-set capacity (workspace is 2 * Kcap^2 elements).
 constexpr uint32_t kKcapLimit = 4096;
 // Upper bound of workgroups any sweep variant launches (size of the partial-max arrays).
-constexpr uint32_t kMaxSweepBlocks = 4096;
+constexpr uint32_t kMaxSweepBlocks = 1024;
 // Upper bound of workgroups of the gamma scan.
-constexpr uint32_t kMaxScanBlocks = 2048;
+constexpr uint32_t kMaxScanBlocks = 256;
 
 // Device-resident solver state, one per in-flight signal.  Written by single-workgroup
 // kernels, read by everything else; lives in global memory (L2-resident).
@@ -61,28 +62,44 @@ struct TraceEntry {
     double   c_inf;   // lambda at the START of the iteration (the one the scan used)
 };
 
+// Per-signal ("slot") strides of the workspace arrays.  Every kernel of the active-set tail
+// takes blockIdx.y as the slot and offsets its pointers by these; a single solve is slot 0
+// of a one-slot batch.
+struct SlotDims {
+    uint32_t n_pad;        // c, q, x, d, insup: one row of n_pad per slot
+    uint32_t ldm;          // y, r, p: one row of ldm per slot
+    uint32_t kcap;         // gam/touched: 2*kcap per slot; inv: 2*kcap*kcap; u1/u2/sgn: kcap
+    uint32_t b_pad;        // rows of the r-block (the p-block / q-block start b_pad rows later)
+    uint32_t pmax_stride;  // partial (max |c|, index) pairs per slot
+    uint32_t pmin_stride;  // partial (min gamma, index) pairs per slot
+};
+
 template <typename T>
 struct Workspace {
-    // per-solve vectors
-    T* y = nullptr;        // [ldm]      signal, zero padded
-    T* rhs = nullptr;      // [2][ldm]   r = y - A x  and  p = A d   (zero padded)
-    T* c = nullptr;        // [n_pad]    correlations A^T r
-    T* q = nullptr;        // [n_pad]    A^T A d
-    T* x = nullptr;        // [n_pad]    dense solution
-    T* d = nullptr;        // [n_pad]    dense direction (non-zero on Gamma only)
-    uint8_t* insup = nullptr;   // [n_pad] membership flags of Gamma
+    uint32_t b_cap = 0;    // slots allocated
+    SlotDims dims{};
+    // per-slot vectors
+    T* y = nullptr;        // [b_cap][ldm]       signals, zero padded
+    T* rhs = nullptr;      // [2][b_pad][ldm]    r = y - A x (block 0) and p = A d (block 1)
+    T* cq = nullptr;       // [2][b_pad][n_pad]  correlations A^T r (block 0) and A^T A d (block 1)
+    T* c = nullptr;        // = cq
+    T* q = nullptr;        // = cq + b_pad*n_pad
+    T* x = nullptr;        // [b_cap][n_pad]     dense solutions
+    T* d = nullptr;        // [b_cap][n_pad]     dense directions (non-zero on Gamma only)
+    uint8_t* insup = nullptr;   // [b_cap][n_pad] membership flags of Gamma
     // sweep / scan partial reductions
-    T* pmax_val = nullptr;       uint32_t* pmax_idx = nullptr;   // [kMaxSweepBlocks]
-    T* pmin_val = nullptr;       uint32_t* pmin_idx = nullptr;   // [kMaxScanBlocks]
+    T* pmax_val = nullptr;       uint32_t* pmax_idx = nullptr;   // [b_cap][pmax_stride]
+    T* pmin_val = nullptr;       uint32_t* pmin_idx = nullptr;   // [b_cap][pmin_stride]
     // active set
     uint32_t kcap = 0;
-    uint32_t* gam = nullptr;      // [2][kcap] sorted support (lambda_indices), ping-pong with inv
-    uint32_t* touched = nullptr;  // [2][kcap] sorted, every column ever inserted
-    T* inv[2] = { nullptr, nullptr };  // [kcap][kcap] ping-pong (A_S^T A_S)^-1
-    T* u1 = nullptr;              // [kcap]
-    T* u2 = nullptr;              // [kcap]
-    T* sgn = nullptr;             // [kcap]
-    DevState* st = nullptr;
+    uint32_t* gam = nullptr;      // [b_cap][2][kcap] sorted support (lambda_indices), ping-pong with inv
+    uint32_t* touched = nullptr;  // [b_cap][2][kcap] sorted, every column ever inserted
+    T* inv[2] = { nullptr, nullptr };  // [b_cap][2][kcap][kcap] ping-pong (A_S^T A_S)^-1; inv[1] = inv[0] + kcap^2
+    T* u1 = nullptr;              // [b_cap][kcap]
+    T* u2 = nullptr;              // [b_cap][kcap]
+    T* sgn = nullptr;             // [b_cap][kcap]
+    DevState* st = nullptr;       // [b_cap]
+    uint32_t* ndone = nullptr;    // number of slots that raised `done` in the current (batch) solve
     TraceEntry* trace = nullptr;  // [trace_cap] when tracing is on
     uint32_t trace_cap = 0;
 };
@@ -111,6 +128,8 @@ struct ss_hip_ctx {
     int zero_on_removal = 1;
     int profiling = 0;
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
+    int batch_min = 4;       // batches of at least this many fp32 signals run in lock-step on the MFMA GEMM
+    int batch_chunk = 4096;  // signals processed together by the batched path
     int tracing = 0;
     std::vector<sship::TraceEntry> last_trace;   // host copy of the last solve's path
 
@@ -134,21 +153,30 @@ namespace sship {
 // pmax_* receive one (max |out0|, first index) pair per workgroup; *nblocks_out is the
 // number of pairs written.  st may be nullptr (standalone sweep).
 template <typename T>
-hipError_t launch_sweep(const ss_hip_ctx* ctx, const T* rhs, int nrhs, T* out0, T* out1,
+hipError_t launch_sweep(const ss_hip_ctx* ctx, const T* rhs, size_t rhs_stride, int nrhs, T* out0, T* out1,
                         T* pmax_val, uint32_t* pmax_idx, uint32_t* nblocks_out,
                         const DevState* st);
 size_t sweep_max_lds_bytes();
 
 // ---- launchers implemented in activeset.hip ------------------------------------
+// nslots = signals in flight (grid.y); nparts = partial maxima per slot in pmax_*
 template <typename T>
-hipError_t launch_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsweep_blocks, T tol);
+hipError_t launch_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t nparts, T tol);
 template <typename T>
-hipError_t launch_rp(const ss_hip_ctx* ctx, Workspace<T>& ws);
+hipError_t launch_rp(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots);
 template <typename T>
-hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round,
-                                 uint32_t nsweep_blocks, T tol, uint32_t max_iter);
+hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round,
+                                 uint32_t nparts, T tol, uint32_t max_iter);
+// per-slot partial (max |c|, first index) over chunks of the correlation rows (batched path)
+template <typename T>
+hipError_t launch_absmax(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t* nparts_out);
 template <typename T>
 hipError_t launch_gemv_n(const ss_hip_ctx* ctx, const T* x_dev, T* y_dev);
+
+// ---- launcher implemented in gemm.hip --------------------------------------------
+// D[Mg][ldd] = R[Mg][ldr] * At^T on the MFMA units (fp32).  Mg % 128 == 0.
+hipError_t launch_gemm_tn_f32(const ss_hip_ctx* ctx, const float* R, uint32_t Mg, uint32_t ldr,
+                              float* D, uint32_t ldd, const uint32_t* row_tile_skip);
 
 // ---- helpers implemented in homotopy.hip ---------------------------------------
 void set_err(char* err, size_t errlen, const std::string& msg);

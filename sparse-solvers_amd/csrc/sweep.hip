@@ -46,7 +46,7 @@ __device__ __forceinline__ T wave_sum(T v)
 template <typename T, int NRHS, int CPW, int WAVES, bool NT, int DEPTH, int BPC>
 __global__ __launch_bounds__(WAVES * 64, (BPC * WAVES) / 4)
 void k_sweep(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngroups, uint32_t mc,
-             const T* __restrict__ rhs, T* __restrict__ out0, T* __restrict__ out1,
+             const T* __restrict__ rhs, size_t rhs_stride, T* __restrict__ out0, T* __restrict__ out1,
              T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx, const DevState* st)
 {
     using V = typename VecOf<T>::type;
@@ -82,7 +82,7 @@ void k_sweep(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngroup
                 for (int k = 0; k < NRHS; ++k)
                     for (uint32_t i = threadIdx.x * VN; i < rows; i += WAVES * 64 * VN)
                         *reinterpret_cast<V*>(&lds[k * mc + i]) =
-                            *reinterpret_cast<const V*>(&rhs[(size_t)k * ldm + r0 + i]);
+                            *reinterpret_cast<const V*>(&rhs[(size_t)k * rhs_stride + r0 + i]);
                 __syncthreads();
                 lds_valid = true;
             }
@@ -208,7 +208,7 @@ constexpr size_t kLdsBudget = 65536;
 size_t sweep_max_lds_bytes() { return kLdsBudget; }
 
 template <typename T, int NRHS, int CPW, int WAVES, bool NT, int DEPTH, int BPC>
-static hipError_t launch_one(const ss_hip_ctx* ctx, const Variant& v, const T* rhs, T* out0, T* out1,
+static hipError_t launch_one(const ss_hip_ctx* ctx, const Variant& v, const T* rhs, size_t rhs_stride, T* out0, T* out1,
                              T* pmax_val, uint32_t* pmax_idx, uint32_t* nblocks_out,
                              const DevState* st)
 {
@@ -224,12 +224,12 @@ static hipError_t launch_one(const ss_hip_ctx* ctx, const Variant& v, const T* r
     if (nblocks_out) *nblocks_out = grid;
     hipLaunchKernelGGL((k_sweep<T, NRHS, CPW, WAVES, NT, DEPTH, BPC>), dim3(grid), dim3(WAVES * 64), lds_bytes,
                        ctx->stream, static_cast<const T*>(ctx->At), ldm, (uint32_t)ctx->n, ngroups, mc,
-                       rhs, out0, out1, pmax_val, pmax_idx, st);
+                       rhs, rhs_stride, out0, out1, pmax_val, pmax_idx, st);
     return hipGetLastError();
 }
 
 template <typename T, int NRHS>
-static hipError_t dispatch(const ss_hip_ctx* ctx, const T* rhs, T* out0, T* out1, T* pmax_val,
+static hipError_t dispatch(const ss_hip_ctx* ctx, const T* rhs, size_t rhs_stride, T* out0, T* out1, T* pmax_val,
                            uint32_t* pmax_idx, uint32_t* nblocks_out, const DevState* st)
 {
     int vi = ctx->sweep_variant;
@@ -237,7 +237,7 @@ static hipError_t dispatch(const ss_hip_ctx* ctx, const T* rhs, T* out0, T* out1
     const Variant& v = kVariants[vi];
 #define SS_CASE(W, C, N, D, B)                                                               \
     if (v.waves == W && v.cpw == C && v.nt == N && v.depth == D && v.blocks_per_cu == B)     \
-        return launch_one<T, NRHS, C, W, (N != 0), D, B>(ctx, v, rhs, out0, out1, pmax_val,  \
+        return launch_one<T, NRHS, C, W, (N != 0), D, B>(ctx, v, rhs, rhs_stride, out0, out1, pmax_val,  \
                                                          pmax_idx, nblocks_out, st);
     SS_CASE(8, 4, 1, 2, 2)
     SS_CASE(8, 4, 0, 2, 2)
@@ -256,16 +256,16 @@ static hipError_t dispatch(const ss_hip_ctx* ctx, const T* rhs, T* out0, T* out1
 }
 
 template <typename T>
-hipError_t launch_sweep(const ss_hip_ctx* ctx, const T* rhs, int nrhs, T* out0, T* out1,
+hipError_t launch_sweep(const ss_hip_ctx* ctx, const T* rhs, size_t rhs_stride, int nrhs, T* out0, T* out1,
                         T* pmax_val, uint32_t* pmax_idx, uint32_t* nblocks_out, const DevState* st)
 {
-    if (nrhs == 2) return dispatch<T, 2>(ctx, rhs, out0, out1, pmax_val, pmax_idx, nblocks_out, st);
-    return dispatch<T, 1>(ctx, rhs, out0, nullptr, pmax_val, pmax_idx, nblocks_out, st);
+    if (nrhs == 2) return dispatch<T, 2>(ctx, rhs, rhs_stride, out0, out1, pmax_val, pmax_idx, nblocks_out, st);
+    return dispatch<T, 1>(ctx, rhs, rhs_stride, out0, nullptr, pmax_val, pmax_idx, nblocks_out, st);
 }
 
-template hipError_t launch_sweep<float>(const ss_hip_ctx*, const float*, int, float*, float*, float*,
+template hipError_t launch_sweep<float>(const ss_hip_ctx*, const float*, size_t, int, float*, float*, float*,
                                         uint32_t*, uint32_t*, const DevState*);
-template hipError_t launch_sweep<double>(const ss_hip_ctx*, const double*, int, double*, double*,
+template hipError_t launch_sweep<double>(const ss_hip_ctx*, const double*, size_t, int, double*, double*,
                                          double*, uint32_t*, uint32_t*, const DevState*);
 
 }  // namespace sship

@@ -24,7 +24,7 @@ SYMBOLS = [
     "ss_hip_homotopy_create_f32", "ss_hip_homotopy_create_f64", "ss_hip_homotopy_destroy",
     "ss_hip_homotopy_solve_f32", "ss_hip_homotopy_solve_f64",
     "ss_hip_homotopy_solve_batch_f32", "ss_hip_homotopy_solve_batch_f64",
-    "ss_hip_gemv_t_f32", "ss_hip_gemv_t_f64",
+    "ss_hip_gemv_t_f32", "ss_hip_gemv_t_f64", "ss_hip_gemm_t_f32",
     "ss_hip_reconstruct_f32", "ss_hip_reconstruct_f64",
     "ss_hip_set_profiling", "ss_hip_get_stats", "ss_hip_reset_stats",
     "ss_hip_set_option", "ss_hip_get_option", "ss_hip_get_trace", "ss_hip_ctx_info",
@@ -42,6 +42,7 @@ class Stats(ctypes.Structure):
         ("sweep1_ms", ctypes.c_double),
         ("sweep1_bytes", ctypes.c_uint64),
         ("solve_ms", ctypes.c_double),
+        ("batch_rounds", ctypes.c_uint64),
     ]
 
 
@@ -79,6 +80,8 @@ def lib():
         f = getattr(L, "ss_hip_reconstruct_" + suf)
         f.restype = ctypes.c_int
         f.argtypes = [vp, vp, vp, cp, sz]
+    L.ss_hip_gemm_t_f32.restype = ctypes.c_int
+    L.ss_hip_gemm_t_f32.argtypes = [vp, vp, sz, pd, vp, pd, ctypes.c_int, ctypes.POINTER(ctypes.c_float), cp, sz]
     L.ss_hip_homotopy_destroy.restype = None
     L.ss_hip_homotopy_destroy.argtypes = [vp]
     L.ss_hip_set_profiling.argtypes = [vp, ctypes.c_int]
@@ -188,21 +191,24 @@ class Homotopy:
         self._check(rc, err)
         return out, int(it.value), float(e.value)
 
-    def solve_batch(self, Y, tolerance=None, max_iterations=100):
-        """Y: (B, m) -> X (B, n), iters (B,), errors (B,)"""
+    def solve_batch(self, Y, tolerance=None, max_iterations=100, out=None):
+        """Y: (B, m) -> X (B, n), iters (B,), errors (B,); Y / out may live on the device"""
         Yp, shape, strides, dt, keep = _describe(Y)
         if dt != self.dtype or len(shape) != 2 or shape[1] != self.m:
             raise ValueError("Y must be (B, m) of the matrix dtype")
         B = int(shape[0])
         if tolerance is None:
             tolerance = float(np.finfo(self.dtype).eps) * 10
-        X = np.empty((B, self.n), dtype=self.dtype)
+        X = np.empty((B, self.n), dtype=self.dtype) if out is None else out
+        Xp, xshape, xstr, xdt, keepx = _describe(X)
+        if xdt != self.dtype or tuple(xshape) != (B, self.n):
+            raise ValueError("out must be (B, n) of the matrix dtype")
         iters = np.zeros(B, dtype=np.uint32)
         errs = np.zeros(B, dtype=np.float64)
         err = ctypes.create_string_buffer(512)
         fn = getattr(lib(), "ss_hip_homotopy_solve_batch_" + self.suffix)
         rc = fn(self._h, Yp, B, strides[0], strides[1], self.ctype(tolerance), int(max_iterations),
-                X.ctypes.data, self.n, 1, iters.ctypes.data, errs.ctypes.data, err, len(err))
+                Xp, xstr[0], xstr[1], iters.ctypes.data, errs.ctypes.data, err, len(err))
         self._check(rc, err)
         return X, iters, errs
 
@@ -217,6 +223,23 @@ class Homotopy:
         fn = getattr(lib(), "ss_hip_gemv_t_" + self.suffix)
         self._check(fn(self._h, rp, c.ctypes.data, int(repeats), ctypes.byref(ms), err, len(err)), err)
         return c, float(ms.value)
+
+    def gemm_t(self, R, repeats=1, out=None):
+        """C[b] = A^T R[b] for the rows of R (B, m) on the MFMA units -> (C (B, n), mean ms)"""
+        Rp, shape, strides, dt, keep = _describe(R)
+        if dt != np.float32 or self.dtype != np.float32 or len(shape) != 2 or shape[1] != self.m or strides[1] != 1:
+            raise ValueError("R must be a (B, m) float32 array with contiguous rows")
+        B = int(shape[0])
+        if out is None:
+            out = np.empty((B, self.n), dtype=np.float32)
+        Cp, cshape, cstr, cdt, keepc = _describe(out)
+        if cdt != np.float32 or tuple(cshape) != (B, self.n) or cstr[1] != 1:
+            raise ValueError("out must be (B, n) float32 with contiguous rows")
+        ms = ctypes.c_float(0.0)
+        err = ctypes.create_string_buffer(512)
+        self._check(lib().ss_hip_gemm_t_f32(self._h, Rp, B, strides[0], Cp, cstr[0], int(repeats),
+                                            ctypes.byref(ms), err, len(err)), err)
+        return out, float(ms.value)
 
     def reconstruct(self, x):
         """y = A x on the device copy (ss::reconstruct_signal)."""

@@ -241,20 +241,79 @@ def test_repeated_solves_are_deterministic(sship):
     assert a[1] == b[1] and a[2] == b[2] and np.array_equal(a[0], b[0])
 
 
-def test_batch_entry(sship):
-    A, _, _, _ = make_gaussian_problem(11, 96, 512, 6, np.float32)
-    Y = []
-    for s in range(5):
-        rng = np.random.default_rng(500 + s)
-        x0 = np.zeros(512)
-        x0[rng.choice(512, 6, replace=False)] = 1 + np.abs(rng.standard_normal(6))
-        Y.append((A.astype(np.float64) @ x0).astype(np.float32))
-    Y = np.stack(Y)
+def _batch_problem(seed, m, n, B, kmin, kmax, dtype):
+    rng = np.random.default_rng(seed)
+    A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(dtype)
+    Y, sups = [], []
+    for b in range(B):
+        k = int(rng.integers(kmin, kmax + 1))
+        x0 = np.zeros(n)
+        sup = np.sort(rng.choice(n, k, replace=False))
+        x0[sup] = 1 + np.abs(rng.standard_normal(k))
+        Y.append((A.astype(np.float64) @ x0).astype(dtype))
+        sups.append(sup)
+    return A, np.stack(Y), sups
+
+
+@pytest.mark.parametrize("B", [1, 3, 9, 130])
+def test_batch_vs_oracle(sship, B):
+    """ss_hip_homotopy_solve_batch_*: B < 4 runs signal by signal on the sweep path, B >= 4 in
+    lock-step on the MFMA GEMM (signals of different sparsity finish in different rounds)."""
+    A, Y, sups = _batch_problem(500 + B, 256, 640, B, 3, 9, np.float32)   # m >> k log(n/k): well-posed recovery
     with sship.Homotopy(A) as h:
         X, iters, errs = h.solve_batch(Y, 1e-3, 40)
+        if B >= 4:
+            assert h.stats()["batch_rounds"] > 0
+        for b in range(B):
+            xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 40)
+            assert_parity(X[b], int(iters[b]), float(errs[b]), xo, ito, eo, np.float32)
+            assert np.array_equal(significant_support(X[b], 1e-3), sups[b])
+        # the lock-step path and the one-signal path agree to rounding
+        x1, it1, e1 = h.solve(Y[B // 2], 1e-3, 40)
+        assert it1 == iters[B // 2]
+        assert np.abs(x1 - X[B // 2]).max() <= 1e-5 * np.abs(x1).max()
+
+
+def test_batch_device_io_and_strides(sship):
+    import torch
+    A, Y, sups = _batch_problem(77, 256, 1024, 6, 4, 8, np.float32)
+    with sship.Homotopy(A) as h:
+        Xh, ih, eh = h.solve_batch(Y, 1e-3, 40)
+        Yd = torch.from_numpy(Y).to("cuda:0")
+        Xd = torch.zeros((6, 1024), device="cuda:0", dtype=torch.float32)
+        _, idv, edv = h.solve_batch(Yd, 1e-3, 40, out=Xd)
+        torch.cuda.synchronize()
+        assert np.array_equal(Xd.cpu().numpy(), Xh) and np.array_equal(idv, ih)
+        # strided signals (every other row of a larger buffer) and a chunked batch
+        Ybig = np.zeros((12, 256), dtype=np.float32)
+        Ybig[::2] = Y
+        Xs, isv, esv = h.solve_batch(Ybig[::2], 1e-3, 40)
+        assert np.array_equal(Xs, Xh)
+        h.set_option("batch_chunk", 4)
+        Xc, icv, ecv = h.solve_batch(Y, 1e-3, 40)
+        assert np.array_equal(Xc, Xh) and np.array_equal(icv, ih)
+
+
+def test_batch_f64_runs_sequentially(sship):
+    A, Y, sups = _batch_problem(78, 128, 300, 5, 3, 6, np.float64)
+    with sship.Homotopy(A) as h:
+        X, iters, errs = h.solve_batch(Y, 1e-9, 40)
+        assert h.stats()["batch_rounds"] == 0
     for b in range(5):
-        xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 40)
-        assert_parity(X[b], int(iters[b]), float(errs[b]), xo, ito, eo, np.float32)
+        xo, ito, eo = oracle.homotopy(A, Y[b], 1e-9, 40)
+        assert_parity(X[b], int(iters[b]), float(errs[b]), xo, ito, eo, np.float64)
+
+
+def test_gemm_t_vs_numpy(sship):
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((300, 1000)).astype(np.float32)
+    R = rng.standard_normal((7, 300)).astype(np.float32)
+    with sship.Homotopy(A) as h:
+        C, ms = h.gemm_t(R)
+        want = R.astype(np.float64) @ A.astype(np.float64)
+        assert np.abs(C - want).max() <= 2e-5 * np.abs(want).max()
+        c0, _ = h.gemv_t(R[3])
+        assert np.abs(C[3] - c0).max() <= 2e-5 * np.abs(c0).max()
 
 
 # ---------------------------------------------------------------- sweep kernel
