@@ -693,6 +693,32 @@ void k_absmax(const T* __restrict__ c, uint32_t n, SlotDims L, T* __restrict__ p
     }
 }
 
+// ---- k_tile_list: compact list of the 128-row GEMM tiles that still hold a running signal --
+// list[0..count) = active tile indices, list[mtiles] = count.  The GEMM maps its leading
+// count*ntiles workgroups onto these tiles, so the live work is contiguous in blockIdx and
+// spreads over all XCDs / CUs (a strided subset of blockIdx lands on a few CUs only).
+__global__ __launch_bounds__(128)
+void k_tile_list(const DevState* __restrict__ st, uint32_t nslots, uint32_t mtiles, uint32_t* __restrict__ list)
+{
+    __shared__ uint32_t s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    for (uint32_t t = 0; t < mtiles; ++t) {
+        const uint32_t slot = t * 128u + threadIdx.x;
+        const int running = (slot < nslots) && (st[slot].done == 0);
+        const int any = __syncthreads_or(running);
+        if (threadIdx.x == 0 && any) list[s_count++] = t;
+    }
+    if (threadIdx.x == 0) list[mtiles] = s_count;
+}
+
+hipError_t launch_tile_list(const ss_hip_ctx* ctx, const DevState* st, uint32_t nslots, uint32_t rows,
+                            uint32_t* list)
+{
+    hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(128), 0, ctx->stream, st, nslots, rows / 128u, list);
+    return hipGetLastError();
+}
+
 // ---- launchers ------------------------------------------------------------------------
 
 template <typename T>

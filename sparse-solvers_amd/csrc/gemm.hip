@@ -38,9 +38,18 @@ void k_gemm_tn_f32(const float* __restrict__ R, const float* __restrict__ Q, flo
     __shared__ __attribute__((aligned(16))) float sR[2][GM][GLD];
     __shared__ __attribute__((aligned(16))) float sQ[2][GN][GLD];
 
-    const uint32_t bm = blockIdx.x % mtiles;       // row tiles fastest: concurrently resident
-    const uint32_t bn = blockIdx.x / mtiles;       // workgroups share the same panel of At
-    if (row_tile_skip != nullptr && row_tile_skip[bm] != 0) return;   // every signal of the tile is done
+    // row tiles fastest: concurrently resident workgroups share the same panel of At.  With a
+    // tile list only its `nact` tiles are computed, by the leading nact*ntiles workgroups.
+    uint32_t bm, bn;
+    if (row_tile_skip != nullptr) {
+        const uint32_t nact = row_tile_skip[mtiles];
+        if (nact == 0 || blockIdx.x / nact >= gridDim.x / mtiles) return;
+        bm = row_tile_skip[blockIdx.x % nact];
+        bn = blockIdx.x / nact;
+    } else {
+        bm = blockIdx.x % mtiles;
+        bn = blockIdx.x / mtiles;
+    }
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;

@@ -156,7 +156,7 @@ void release_arrays(Workspace<T>* w)
 {
     void* ptrs[] = { w->y, w->rhs, w->cq, w->x, w->d, w->insup, w->pmax_val, w->pmax_idx,
                      w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->u1,
-                     w->u2, w->sgn, w->st, w->ndone };
+                     w->u2, w->sgn, w->st, w->ndone, w->tile_skip };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     TraceEntry* tr = w->trace;
@@ -217,6 +217,8 @@ void ensure_workspace(ss_hip_ctx* ctx, uint32_t nslots, uint32_t kcap)
     HIPCHK(hipMalloc(&w->sgn, B * K * s));
     HIPCHK(hipMalloc(&w->st, B * sizeof(DevState)));
     HIPCHK(hipMalloc(&w->ndone, 64));
+    HIPCHK(hipMalloc(&w->tile_skip, ((size_t)b_pad / 128 + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMemset(w->tile_skip, 0, ((size_t)b_pad / 128 + 1) * sizeof(uint32_t)));
     w->inv[1] = w->inv[0] + K * K;
     w->c = w->cq;
     w->q = w->cq + (size_t)b_pad * np;
@@ -551,8 +553,9 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                     }
                     if (hf[1] != 0) break;
                 }
-                HIPCHK(launch_gemm_tn_f32(ctx, Rblk, rows, (uint32_t)ldm, ws.c, (uint32_t)np, nullptr));
-                HIPCHK(launch_gemm_tn_f32(ctx, Pblk, rows, (uint32_t)ldm, ws.q, (uint32_t)np, nullptr));
+                HIPCHK(launch_tile_list(ctx, ws.st, Bc, rows, ws.tile_skip));
+                HIPCHK(launch_gemm_tn_f32(ctx, Rblk, rows, (uint32_t)ldm, ws.c, (uint32_t)np, ws.tile_skip));
+                HIPCHK(launch_gemm_tn_f32(ctx, Pblk, rows, (uint32_t)ldm, ws.q, (uint32_t)np, ws.tile_skip));
                 HIPCHK(launch_absmax<T>(ctx, ws, Bc, &nparts));
                 HIPCHK(launch_iteration_tail<T>(ctx, ws, Bc, (uint32_t)round, nparts, tol, max_iter));
                 ++rounds_run;
@@ -890,6 +893,20 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "trace"))         { *value = ctx->tracing; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { *value = ctx->zero_on_removal; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { *value = ctx->profile_every; return SS_HIP_OK; }
+    if (!std::strcmp(key, "dbg_ndone") || !std::strcmp(key, "dbg_skip_sum")) {
+        // debugging aids: device-side counters of the last batched solve (fp32 contexts)
+        if (ctx->is_f64 || !ctx->ws) return SS_HIP_EINVAL;
+        Workspace<float>* w = static_cast<Workspace<float>*>(ctx->ws);
+        if (hipSetDevice(ctx->device) != hipSuccess) return SS_HIP_ERUNTIME;
+        if (!std::strcmp(key, "dbg_ndone")) {
+            uint32_t v = 0;
+            if (hipMemcpy(&v, w->ndone, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return SS_HIP_ERUNTIME;
+            *value = (long)v;
+        } else {
+            *value = -1;   // (the tile list is rebuilt every round; nothing meaningful to report)
+        }
+        return SS_HIP_OK;
+    }
     if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { *value = ctx->batch_chunk; return SS_HIP_OK; }
     return SS_HIP_EINVAL;

@@ -100,6 +100,7 @@ struct Workspace {
     T* sgn = nullptr;             // [b_cap][kcap]
     DevState* st = nullptr;       // [b_cap]
     uint32_t* ndone = nullptr;    // number of slots that raised `done` in the current (batch) solve
+    uint32_t* tile_skip = nullptr; // [b_pad/128 + 1] compact list of GEMM row tiles with a running signal + count
     TraceEntry* trace = nullptr;  // [trace_cap] when tracing is on
     uint32_t trace_cap = 0;
 };
@@ -167,6 +168,9 @@ hipError_t launch_rp(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots);
 template <typename T>
 hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round,
                                  uint32_t nparts, T tol, uint32_t max_iter);
+// list[0..count) = 128-row tiles that still hold a running signal, list[rows/128] = count
+hipError_t launch_tile_list(const ss_hip_ctx* ctx, const DevState* st, uint32_t nslots, uint32_t rows,
+                            uint32_t* list);
 // per-slot partial (max |c|, first index) over chunks of the correlation rows (batched path)
 template <typename T>
 hipError_t launch_absmax(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t* nparts_out);
@@ -174,9 +178,10 @@ template <typename T>
 hipError_t launch_gemv_n(const ss_hip_ctx* ctx, const T* x_dev, T* y_dev);
 
 // ---- launcher implemented in gemm.hip --------------------------------------------
-// D[Mg][ldd] = R[Mg][ldr] * At^T on the MFMA units (fp32).  Mg % 128 == 0.
+// D[Mg][ldd] = R[Mg][ldr] * At^T on the MFMA units (fp32).  Mg % 128 == 0.  tile_list (may be
+// null = all tiles): compact list of the row tiles to compute, count at tile_list[Mg/128].
 hipError_t launch_gemm_tn_f32(const ss_hip_ctx* ctx, const float* R, uint32_t Mg, uint32_t ldr,
-                              float* D, uint32_t ldd, const uint32_t* row_tile_skip);
+                              float* D, uint32_t ldd, const uint32_t* tile_list);
 
 // ---- helpers implemented in homotopy.hip ---------------------------------------
 void set_err(char* err, size_t errlen, const std::string& msg);
