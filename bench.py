@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="sweep kernel variant (tuning)")
     ap.add_argument("--profile-every", type=int, default=8,
                     help="time every k-th fused sweep of the timed solves with HIP events")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="signals of the extra configs[2]-style lock-step batch run reported under "
+                         "'batched' (outside the timed region; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     args = ap.parse_args()
@@ -132,6 +135,8 @@ def main():
 
     for s in range(args.warmup):
         h.solve(sigs[s][0], TOL, MAX_ITER, out=xw)
+    # warm up the record packing / gather too (first use of a torch kernel loads its code object)
+    sharding.gather_records(sharding.pack_records(xw.unsqueeze(0).expand(args.steps, N).contiguous(), KMAX_RECORD), world)
 
     h.set_profiling(True)
     h.set_option("profile_every", args.profile_every)
@@ -178,6 +183,39 @@ def main():
     gather_ok = all(np.array_equal(ix, np.nonzero(Xh[s])[0]) for s, (ix, _) in enumerate(mine))
 
     st = h.stats()
+
+    # configs[2]-style extra (NOT part of `value`): a batch of signals sharing A, solved in
+    # lock-step with the correlations on the MFMA units
+    batched = None
+    if args.batch > 0:
+        Bx = args.batch
+        rngb = np.random.default_rng(4242 + rank)
+        supb = np.stack([np.sort(rngb.choice(N, K_SPARSE, replace=False)) for _ in range(Bx)])
+        coefb = 1.0 + np.abs(rngb.standard_normal((Bx, K_SPARSE)))
+        Yb = torch.empty((Bx, M), device=dev, dtype=torch.float32)
+        for b0 in range(0, Bx, 128):
+            b1 = min(Bx, b0 + 128)
+            cols = A.t()[torch.from_numpy(supb[b0:b1]).to(dev).reshape(-1)].reshape(b1 - b0, K_SPARSE, M).double()
+            Yb[b0:b1] = torch.einsum("bkm,bk->bm", cols, torch.from_numpy(coefb[b0:b1]).to(dev)).float()
+        Xb = torch.zeros((Bx, N), device=dev, dtype=torch.float32)
+        h.solve_batch(Yb[:8].contiguous(), TOL, MAX_ITER, out=Xb[:8])          # warm-up / allocation
+        torch.cuda.synchronize()
+        h.reset_stats()
+        tb = time.perf_counter()
+        _, itb, _ = h.solve_batch(Yb, TOL, MAX_ITER, out=Xb)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - tb
+        rounds = h.stats()["batch_rounds"]
+        Xbh = Xb.cpu().numpy()
+        okb = sum(int(np.array_equal(np.nonzero(Xbh[b])[0], supb[b])) for b in range(Bx))
+        rows = (Bx + 127) // 128 * 128
+        batched = {"workload": "configs[2]-style: %d signals sharing A, lock-step, MFMA fp32 GEMM correlations" % Bx,
+                   "signals": Bx, "signals_per_s": Bx / dtb, "seconds": dtb, "rounds": int(rounds),
+                   "support_exact": okb, "iterations_max": int(itb.max()),
+                   "gemm_tflops_incl_tail": (2 * rounds + 1) * 2.0 * rows * N * M / dtb / 1e12,
+                   "mfma_f32_peak_tflops": 157.3}
+        del Xb, Yb
+
     out = None
     if rank == 0:
         avg_ms = st["sweep_ms"] / max(1, st["sweep_launches"])
@@ -221,6 +259,7 @@ def main():
                 "avg_launch_ms": avg_ms,
                 "launches_timed": st["sweep_launches"],
             },
+            "batched": batched,
             "iterations_mean": float(iters.mean()),
             "sweeps_per_iteration": {"this": 1, "reference": 4},
             "recovered": {"signals": world * args.steps, "support_exact": recovered_total,
