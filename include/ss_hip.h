@@ -161,6 +161,10 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 4)
  *   "batch_chunk"    signals processed together by the batched path (default 4096)
  *   "profile_every"  with profiling on, bracket only every k-th fused sweep with events
+ *   "tie_guard"      1 (default) = an off-support column that attains max|c| exactly (it
+ *                    tied with an inserted column within an ulp) enters by a zero-length step
+ *                    instead of being skipped for good by the reference's strict `t > 0`
+ *                    (homotopy-cpu.cpp:143-153); 0 = reference behaviour
  *   "zero_on_removal" 1 (default) = a coefficient whose column leaves the support is set
  *                    to exactly 0; 0 = keep the reference's x + gamma*d rounding residue
  *                    (homotopy-cpu.cpp:246-252), which can make a re-inserted column bounce

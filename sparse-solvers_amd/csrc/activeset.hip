@@ -30,8 +30,8 @@
 namespace sship {
 
 template <typename T> struct Lim;
-template <> struct Lim<float>  { static constexpr float  max() { return FLT_MAX; } };
-template <> struct Lim<double> { static constexpr double max() { return DBL_MAX; } };
+template <> struct Lim<float>  { static constexpr float  max() { return FLT_MAX; } static constexpr float  tiny() { return FLT_MIN; } };
+template <> struct Lim<double> { static constexpr double max() { return DBL_MAX; } static constexpr double tiny() { return DBL_MIN; } };
 
 typedef float  v4f __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -329,7 +329,7 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
                T* pmin_val, uint32_t* pmin_idx,
                uint32_t* __restrict__ gam2, uint32_t* __restrict__ touched2, SlotDims L,
                DevState* st, uint32_t* hflags, TraceEntry* trace, uint32_t trace_cap,
-               int zero_on_removal, uint32_t* ndone, uint32_t nslots)
+               int zero_on_removal, int tie_guard, uint32_t* ndone, uint32_t nslots)
 {
     const uint32_t kcap = L.kcap;
     {   // slot = blockIdx.y
@@ -381,12 +381,19 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
             } else {
                 const T qi = q[i], ci = c[i];
                 const T dl = T(1) - qi, dr = T(1) + qi;
+                // tie guard: an off-support column that ATTAINS the maximum (|c_i| == c_inf, so
+                // t == 0) has overtaken the support by rounding — two columns reached the
+                // boundary within an ulp and the other one was inserted first.  The reference's
+                // strict `t > 0` then skips it for good and the path never reaches the solution;
+                // with the guard it is inserted by a zero-length step (option "tie_guard").
                 if (dl != T(0)) {
-                    const T t = (c_inf - ci) / dl;
+                    T t = (c_inf - ci) / dl;
+                    if (tie_guard && t == T(0) && dl > T(0)) t = Lim<T>::tiny();
                     if (t > T(0) && t < m) m = t;
                 }
                 if (dr != T(0)) {
-                    const T t = (c_inf + ci) / dr;
+                    T t = (c_inf + ci) / dr;
+                    if (tie_guard && t == T(0) && dr > T(0)) t = Lim<T>::tiny();
                     if (t > T(0) && t < m) m = t;
                 }
             }
@@ -752,7 +759,7 @@ hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32
     hipLaunchKernelGGL((k_scansel<T>), dim3(ns, nslots), dim3(kSmallThreads), 0, ctx->stream, round, tol,
                        max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
                        nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
-                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ws.ndone, nslots);
+                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots);
     uint32_t gb = round + 1;
     if (gb > ws.kcap) gb = ws.kcap;
     hipLaunchKernelGGL((k_gramupd<T>), dim3(gb, nslots), dim3(kUpdThreads), 0, ctx->stream,

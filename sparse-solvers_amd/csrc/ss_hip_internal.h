@@ -127,6 +127,7 @@ struct ss_hip_ctx {
     int lookahead = 4;
     int strict_sign = 0;
     int zero_on_removal = 1;
+    int tie_guard = 1;
     int profiling = 0;
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
     int batch_min = 4;       // batches of at least this many fp32 signals run in lock-step on the MFMA GEMM
