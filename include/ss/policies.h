@@ -56,6 +56,32 @@ namespace ss
         std::string _error;
     };
 
+    /* Orthogonal matching pursuit ------------------------------------------ */
+
+    /* Not part of the reference (which ships homotopy and irls only, ss.h:60-64); same
+       report shape as homotopy_report: iterations and ||A^T r||_inf at exit. */
+    struct omp_report
+    {
+        uint32_t iter;
+        double solution_error;
+    };
+
+    inline bool operator== (const omp_report&, const omp_report&) { return false; }
+
+    /* greedy l0 pursuit on the same device-resident matrix copy as homotopy_policy */
+    struct omp_policy
+    {
+        using report_type = omp_report;
+
+        template <typename T> using state_type = homotopy_state<T>;
+
+        static kernelpp::maybe<omp_report> run(
+            state_type<float>&, const ndspan<float>, float, uint32_t, ndspan<float>);
+
+        static kernelpp::maybe<omp_report> run(
+            state_type<double>&, const ndspan<double>, double, uint32_t, ndspan<double>);
+    };
+
     /* A solver policy which implements the homotopy method on an MI355X */
     struct homotopy_policy
     {

@@ -54,6 +54,10 @@ namespace ss
     template <typename T>
     using homotopy = solver<T, homotopy_policy>;
 
+    /* orthogonal matching pursuit (an addition: the reference has no OMP) */
+    template <typename T>
+    using omp = solver<T, omp_policy>;
+
 
     /* Utilities ----------------------------------------------------------- */
 

@@ -84,6 +84,22 @@ int ss_hip_homotopy_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy,
                               char* err, size_t errlen);
 
 /*
+ * Orthogonal matching pursuit on the same context (NOT in the reference, which ships only
+ * homotopy and irls: include/ss/ss.h:60-64; BASELINE.json names an `ss::omp` solver).  Greedy:
+ *   r = y;  while (iter < max_iter && ||A^T r||_inf > tol) {
+ *       idx = argmax |A^T r|;  S += idx;  x_S = argmin ||y - A_S x_S||_2;  r = y - A_S x_S;  }
+ * Reuses the correlation sweep (one right-hand side), the arg-max epilogue and the bordered
+ * (A_S^T A_S)^-1 of the Homotopy path.  Same argument meaning as ss_hip_homotopy_solve_*;
+ * the report is {iterations, ||A^T r||_inf at exit}.
+ */
+int ss_hip_omp_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_t incy,
+                         float tol, uint32_t max_iter, float* x, ptrdiff_t incx,
+                         uint32_t* iter_out, double* err_out, char* err, size_t errlen);
+int ss_hip_omp_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy,
+                         double tol, uint32_t max_iter, double* x, ptrdiff_t incx,
+                         uint32_t* iter_out, double* err_out, char* err, size_t errlen);
+
+/*
  * Batch of B signals sharing the context's sensing matrix: signal b is
  * Y[b*y_stride + i*incy], its solution X[b*x_stride + j*incx].
  * iter_out[B], err_out[B] receive the per-signal reports.

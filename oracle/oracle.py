@@ -82,6 +82,10 @@ def lib():
             f.restype = ctypes.c_int
             f.argtypes = [vp, sz, sz, pd, pd, vp, pd, ct, ctypes.c_uint32, vp, pd,
                           ctypes.POINTER(_Report), ctypes.POINTER(_Trace), ctypes.c_uint]
+            f = getattr(L, "ss_oracle_omp_" + suf)
+            f.restype = ctypes.c_int
+            f.argtypes = [vp, sz, sz, pd, pd, vp, pd, ct, ctypes.c_uint32, vp, pd,
+                          ctypes.POINTER(_Report), ctypes.POINTER(_Trace)]
             for name in ("ss_oracle_gemv_t_", "ss_oracle_gemv_n_"):
                 g = getattr(L, name + suf)
                 g.restype = None
@@ -173,6 +177,32 @@ def homotopy(A, y, tolerance, max_iterations, flags=SPARSE_NOTRANS, trace=False)
             "idx": keep[0][:k].copy(), "added": keep[1][:k].copy(),
             "gamma": keep[2][:k].copy(), "c_inf": keep[3][:k].copy()}
     return x, rep.iter, rep.solution_error
+
+
+def omp(A, y, tolerance, max_iterations):
+    """Orthogonal matching pursuit (no reference implementation exists: unpinned).
+    Returns (x, iter, ||A^T r||_inf, selected columns in pick order)."""
+    A = np.asarray(A)
+    suf = _suffix(A.dtype)
+    y = np.asarray(y)
+    if y.dtype != A.dtype:
+        raise TypeError("dtype of y must match A")
+    m, n = A.shape
+    item = A.dtype.itemsize
+    x = np.zeros(n, dtype=A.dtype)
+    rep = _Report()
+    cap = int(max_iterations) + 1
+    idx = np.zeros(cap, np.uint32)
+    tr = _Trace()
+    tr.capacity = cap
+    tr.idx = idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    rc = getattr(lib(), "ss_oracle_omp_" + suf)(
+        A.ctypes.data, m, n, A.strides[0] // item, A.strides[1] // item, y.ctypes.data,
+        y.strides[0] // item, tolerance, int(max_iterations), x.ctypes.data, 1,
+        ctypes.byref(rep), ctypes.byref(tr))
+    if rc != 0:
+        raise RuntimeError("oracle omp failed with code %d" % rc)
+    return x, rep.iter, rep.solution_error, idx[:tr.count].copy()
 
 
 def gemv_t(A, v):

@@ -517,6 +517,87 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
     }
 }
 
+// ---- k_omp_select: orthogonal matching pursuit's pick (one workgroup per slot) -------------
+// c = A^T r has just been swept: idx = argmax |c| (first index), loop control
+//   while (iter < max_iter && c_inf > tol) { insert idx; x_S = lstsq; r = y - A_S x_S; }
+// There is no OMP in the reference; the report mirrors homotopy_report {iter, ||A^T r||_inf}.
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_omp_select(uint32_t round, T tol, uint32_t max_iter,
+                  const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
+                  uint8_t* __restrict__ insup, uint32_t* __restrict__ gam2, uint32_t* __restrict__ touched2,
+                  SlotDims L, DevState* st, uint32_t* hflags, TraceEntry* trace, uint32_t trace_cap,
+                  uint32_t* ndone, uint32_t nslots)
+{
+    const uint32_t kcap = L.kcap;
+    {
+        const size_t s = blockIdx.y;
+        pmax_val += s * L.pmax_stride; pmax_idx += s * L.pmax_stride;
+        insup += s * L.n_pad;
+        gam2 += s * 2 * kcap; touched2 += s * 2 * kcap;
+        st += s;
+        if (s != 0) trace = nullptr;
+    }
+    if (st->done) return;
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_cnt;
+    T c_inf;
+    uint32_t idx;
+    reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, idx, sv, si);
+
+    const uint32_t cur = st->cur;
+    const uint32_t K = st->K;
+    // stop: tolerance reached, iteration budget spent, the support is full, or the best
+    // column is already active (its correlation should be ~0: numerical stall)
+    const bool stall = insup[idx] != 0;
+    if (!(c_inf > tol) || round > max_iter || K >= kcap || stall) {
+        if (threadIdx.x == 0) {
+            st->c_inf = (double)c_inf;
+            st->iter = round - 1;
+            st->done_round = round;
+            if (K >= kcap && c_inf > tol && round <= max_iter && !stall) st->status = SS_HIP_ECAPACITY;
+            st->done = 1;
+            signal_done(hflags, ndone, nslots, round);
+        }
+        return;
+    }
+    const uint32_t* gam = gam2 + (size_t)cur * kcap;
+    uint32_t* gam_new = gam2 + (size_t)(cur ^ 1u) * kcap;
+    uint32_t* tch_new = touched2 + (size_t)(cur ^ 1u) * kcap;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t lr = 0;
+    for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) lr += (gam[j] < idx) ? 1u : 0u;
+    if (lr) atomicAdd(&s_cnt, lr);
+    __syncthreads();
+    const uint32_t rank = s_cnt;
+    const uint32_t K_new = K + 1;
+    for (uint32_t j = threadIdx.x; j < K_new; j += blockDim.x) {
+        const uint32_t v = (j < rank) ? gam[j] : (j == rank ? idx : gam[j - 1]);
+        gam_new[j] = v;
+        tch_new[j] = v;          // the residual kernel walks the `touched` list == support
+    }
+    if (threadIdx.x == 0) {
+        insup[idx] = 1;
+        st->K = K_new;
+        st->ntouched = K_new;
+        st->idx = idx;
+        st->rank = rank;
+        st->added = 1;
+        st->gamma = 0.0;
+        st->c_inf = (double)c_inf;
+        st->iter = round;
+        if (trace != nullptr && round < trace_cap) {
+            trace[round].idx = idx;
+            trace[round].added = 1;
+            trace[round].gamma = 0.0;
+            trace[round].c_inf = (double)c_inf;
+        }
+        if (hflags) __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- k_gramupd: u1 = A_S^T a_idx and a_idx . a_idx (online_inverse.h:209-218), one
 // ---- workgroup per active column; the last to arrive borders / deflates
 // ---- (A_S^T A_S)^-1 (online_inverse.h:224-248, 275-290) and forms the new direction
@@ -526,11 +607,12 @@ __global__ __launch_bounds__(kUpdThreads)
 void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict__ gam2,
                T* inv0, T* inv1, T* u1, T* u2, T* sgn,
                const T* __restrict__ c, const T* __restrict__ q, T* __restrict__ d, T tol,
-               DevState* st)
+               DevState* st, int omp, const T* __restrict__ y, T* __restrict__ x)
 {
     const uint32_t ldm = L.ldm, kcap = L.kcap;
     {   // slot = blockIdx.y
         const size_t s = blockIdx.y;
+        if (omp) { y += s * ldm; x += s * L.n_pad; }
         gam2 += s * 2 * kcap;
         inv0 += s * 2 * (size_t)kcap * kcap; inv1 += s * 2 * (size_t)kcap * kcap;
         u1 += s * kcap; u2 += s * kcap; sgn += s * kcap;
@@ -556,17 +638,31 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
         const V4* col = reinterpret_cast<const V4*>(At + (size_t)gam_new[b] * ldm);
         const V4* cnew = reinterpret_cast<const V4*>(At + (size_t)st->idx * ldm);
         const uint32_t nv = ldm / VN;                       // multiple of 64
-        T acc = T(0);
+        T acc = T(0), accy = T(0);
+        if (omp) {
+            // OMP also needs b_S = A_S^T y for the least-squares solve x_S = inv * b_S
+            const V4* yv = reinterpret_cast<const V4*>(y);
 #pragma unroll 4
-        for (uint32_t i = threadIdx.x; i < nv; i += kUpdThreads) {
-            const V4 a = col[i], bnew = cnew[i];
+            for (uint32_t i = threadIdx.x; i < nv; i += kUpdThreads) {
+                const V4 a = col[i], bnew = cnew[i], yy = yv[i];
 #pragma unroll
-            for (int e = 0; e < VN; ++e) acc += a[e] * bnew[e];
+                for (int e = 0; e < VN; ++e) { acc += a[e] * bnew[e]; accy += a[e] * yy[e]; }
+            }
+        } else {
+#pragma unroll 4
+            for (uint32_t i = threadIdx.x; i < nv; i += kUpdThreads) {
+                const V4 a = col[i], bnew = cnew[i];
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc += a[e] * bnew[e];
+            }
         }
         const T v = block_sum(acc, sv);
+        T vy = T(0);
+        if (omp) vy = block_sum(accy, sv);
         if (threadIdx.x == 0) {
             if (b == rank) st->dot = (double)v;
             else u1[b - (b > rank ? 1u : 0u)] = v;
+            if (omp) sgn[b] = vy;                      // b_S in the new sorted order
         }
     }
     if (!arrive_last(&st->ticket_gram, gridDim.x, &s_flag)) return;
@@ -627,6 +723,20 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
             const uint32_t oa = a + (a >= rank ? 1u : 0u), ob = b + (b >= rank ? 1u : 0u);
             Inew[a * P + b] = Iold[oa * P + ob] + (-dd * u2[oa]) * u2[ob];
         }
+    }
+
+    if (omp) {
+        // orthogonal matching pursuit: x_S = (A_S^T A_S)^-1 A_S^T y, written to its columns
+        __syncthreads();
+        for (uint32_t a = wave; a < K_new; a += NW) {
+            T acc = T(0);
+            for (uint32_t b = lane; b < K_new; b += 64) acc += Inew[a * P + b] * sgn[b];
+            acc = wave_sum(acc);
+            if (lane == 0) x[gam_new[a]] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) st->cur = cur ^ 1u;
+        return;
     }
 
     // sign(c[Gamma]) with dead zone tol (homotopy-cpu.cpp:259-260).  The correlations after
@@ -764,7 +874,25 @@ hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32
     if (gb > ws.kcap) gb = ws.kcap;
     hipLaunchKernelGGL((k_gramupd<T>), dim3(gb, nslots), dim3(kUpdThreads), 0, ctx->stream,
                        static_cast<const T*>(ctx->At), ws.dims, ws.gam, ws.inv[0], ws.inv[1],
-                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st);
+                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 0, (const T*)nullptr, (T*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_rp(ctx, ws, nslots);
+}
+
+// one OMP round after the sweep c = A^T r: pick, bordered inverse + least squares, residual
+template <typename T>
+hipError_t launch_omp_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round,
+                           uint32_t nparts, T tol, uint32_t max_iter)
+{
+    hipLaunchKernelGGL((k_omp_select<T>), dim3(1, nslots), dim3(kSmallThreads), 0, ctx->stream, round, tol,
+                       max_iter, ws.pmax_val, ws.pmax_idx, nparts, ws.insup, ws.gam, ws.touched, ws.dims,
+                       ws.st, ctx->dev_flags, ws.trace, ws.trace_cap, ws.ndone, nslots);
+    uint32_t gb = round;                 // support size after this round's insert is <= round
+    if (gb > ws.kcap) gb = ws.kcap;
+    hipLaunchKernelGGL((k_gramupd<T>), dim3(gb, nslots), dim3(kUpdThreads), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ws.dims, ws.gam, ws.inv[0], ws.inv[1],
+                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 1, (const T*)ws.y, ws.x);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_rp(ctx, ws, nslots);
@@ -800,6 +928,10 @@ template hipError_t launch_iteration_tail<float>(const ss_hip_ctx*, Workspace<fl
                                                  uint32_t, float, uint32_t);
 template hipError_t launch_iteration_tail<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t,
                                                   uint32_t, double, uint32_t);
+template hipError_t launch_omp_tail<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t,
+                                           uint32_t, float, uint32_t);
+template hipError_t launch_omp_tail<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t,
+                                            uint32_t, double, uint32_t);
 template hipError_t launch_absmax<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t*);
 template hipError_t launch_absmax<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t*);
 template hipError_t launch_gemv_n<float>(const ss_hip_ctx*, const float*, float*);

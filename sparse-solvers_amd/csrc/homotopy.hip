@@ -332,7 +332,8 @@ hipEvent_t prof_event(ss_hip_ctx* ctx, size_t i)
 
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
-               ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen)
+               ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
+               bool omp = false)
 {
     if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
     if (ctx->is_f64 != (sizeof(T) == 8)) {
@@ -385,13 +386,15 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         HIPCHK(hipMemcpyAsync(ws.rhs, ws.y, (size_t)ctx->ldm * sizeof(T), hipMemcpyDeviceToDevice, st));
         const size_t rhs_stride = (size_t)ws.dims.b_pad * ctx->ldm;   // r-block -> p-block
 
-        // c = A^T y  (residual_vector with x = 0, homotopy-cpu.cpp:215)
-        uint32_t nb1 = 0;
-        if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
-        HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
-        if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
-        HIPCHK(launch_init<T>(ctx, ws, 1, nb1, tol));
-        HIPCHK(launch_rp<T>(ctx, ws, 1));
+        if (!omp) {
+            // c = A^T y  (residual_vector with x = 0, homotopy-cpu.cpp:215)
+            uint32_t nb1 = 0;
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+            HIPCHK(launch_init<T>(ctx, ws, 1, nb1, tol));
+            HIPCHK(launch_rp<T>(ctx, ws, 1));
+        }
 
         // The device decides termination (k_scansel raises DevState::done and mirrors it,
         // with the round it has reached, into pinned host memory).  The host keeps at most
@@ -413,6 +416,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     std::this_thread::yield();
                 }
                 if (hf[1] != 0) break;
+            }
+            if (omp) {
+                // orthogonal matching pursuit round: c = A^T r (one right-hand side), pick,
+                // bordered inverse + least squares on the support, new residual
+                uint32_t nbo = 0;
+                HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nbo, ws.st));
+                HIPCHK(launch_omp_tail<T>(ctx, ws, 1, (uint32_t)round, nbo, tol, max_iter));
+                continue;
             }
             uint32_t nb = 0;
             // HIP events cost tens of microseconds of stream time each: time every
@@ -783,6 +794,18 @@ int ss_hip_homotopy_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy, 
                               double* err_out, char* err, size_t errlen)
 {
     return solve_impl<double>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen);
+}
+
+int ss_hip_omp_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_t incy, float tol, uint32_t max_iter,
+                         float* x, ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen)
+{
+    return solve_impl<float>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, true);
+}
+
+int ss_hip_omp_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy, double tol, uint32_t max_iter,
+                         double* x, ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen)
+{
+    return solve_impl<double>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, true);
 }
 
 int ss_hip_homotopy_solve_batch_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride,

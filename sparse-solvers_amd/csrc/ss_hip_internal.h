@@ -172,6 +172,9 @@ hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32
 // list[0..count) = 128-row tiles that still hold a running signal, list[rows/128] = count
 hipError_t launch_tile_list(const ss_hip_ctx* ctx, const DevState* st, uint32_t nslots, uint32_t rows,
                             uint32_t* list);
+template <typename T>
+hipError_t launch_omp_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round,
+                           uint32_t nparts, T tol, uint32_t max_iter);
 // per-slot partial (max |c|, first index) over chunks of the correlation rows (batched path)
 template <typename T>
 hipError_t launch_absmax(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t* nparts_out);

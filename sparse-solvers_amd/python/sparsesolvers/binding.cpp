@@ -55,47 +55,52 @@ namespace
             throw std::runtime_error(r.template get<kernelpp::error>().data());
     }
 
-    struct py_homotopy
+    /* one Python class per policy, holding a float OR a double solver (binding.cpp:64-72) */
+    template <typename Policy>
+    struct py_solver
     {
         std::array<size_t, 2> shape;
-        std::unique_ptr<ss::homotopy<float>>  f32;
-        std::unique_ptr<ss::homotopy<double>> f64;
+        std::unique_ptr<ss::solver<float, Policy>>  f32;
+        std::unique_ptr<ss::solver<double, Policy>> f64;
     };
+    using py_homotopy = py_solver<ss::homotopy_policy>;
+    using py_omp = py_solver<ss::omp_policy>;
 
-    template <typename T> std::unique_ptr<ss::homotopy<T>>& slot(py_homotopy& s);
-    template <> std::unique_ptr<ss::homotopy<float>>&  slot<float>(py_homotopy& s)  { return s.f32; }
-    template <> std::unique_ptr<ss::homotopy<double>>& slot<double>(py_homotopy& s) { return s.f64; }
+    template <typename T, typename P> struct slot_of;
+    template <typename P> struct slot_of<float, P>  { static std::unique_ptr<ss::solver<float, P>>&  get(py_solver<P>& s) { return s.f32; } };
+    template <typename P> struct slot_of<double, P> { static std::unique_ptr<ss::solver<double, P>>& get(py_solver<P>& s) { return s.f64; } };
 
-    template <typename T>
-    void def_init(py::class_<py_homotopy>& cls)
+    template <typename T, typename P>
+    void def_init(py::class_<py_solver<P>>& cls)
     {
         cls.def(py::init([](py::array_t<T> A_) {
             auto A = as_span<2>(A_);
-            auto* self = new py_homotopy{ A.shape(), nullptr, nullptr };
-            slot<T>(*self).reset(new ss::homotopy<T>(A));
+            auto* self = new py_solver<P>{ A.shape(), nullptr, nullptr };
+            slot_of<T, P>::get(*self).reset(new ss::solver<T, P>(A));
             return self;
         }), py::arg("A"));
     }
 
-    template <typename T>
-    void def_solve(py::class_<py_homotopy>& cls)
+    template <typename T, typename P>
+    void def_solve(py::class_<py_solver<P>>& cls)
     {
+        using report_type = typename P::report_type;
         cls.def("solve",
-            [](py_homotopy& self, py::array_t<T> b, T tol, uint32_t maxiter)
+            [](py_solver<P>& self, py::array_t<T> b, T tol, uint32_t maxiter)
             {
-                auto& s = slot<T>(self);
+                auto& s = slot_of<T, P>::get(self);
                 if (!s) throw std::runtime_error(
                     "dtype of b does not match the dtype of the sensing matrix");
                 py::array_t<T> x((py::ssize_t)self.shape[1]);
                 auto bs = as_span<1>(b);
                 auto xs = as_span<1>(x);
-                kernelpp::maybe<ss::homotopy_report> result = ss::homotopy_report{ 0u, 0.0 };
+                kernelpp::maybe<report_type> result = report_type{ 0u, 0.0 };
                 {
                     py::gil_scoped_release release;
                     result = s->solve(bs, tol, maxiter, xs);
                 }
                 try_throw(result);
-                return std::make_tuple(x, result.template get<ss::homotopy_report>());
+                return std::make_tuple(x, result.template get<report_type>());
             },
             "Execute the solver on the given inputs.",
             py::arg("b").noconvert(),
@@ -118,8 +123,19 @@ PYBIND11_MODULE(binding, m)
 
     /* homotopy solver */
     auto homotopy = py::class_<py_homotopy>(m, "Homotopy");
-    def_init<float>(homotopy);
-    def_init<double>(homotopy);
-    def_solve<float>(homotopy);
-    def_solve<double>(homotopy);
+    def_init<float, ss::homotopy_policy>(homotopy);
+    def_init<double, ss::homotopy_policy>(homotopy);
+    def_solve<float, ss::homotopy_policy>(homotopy);
+    def_solve<double, ss::homotopy_policy>(homotopy);
+
+    /* orthogonal matching pursuit (an addition; the reference exposes Homotopy and Irls) */
+    py::class_<ss::omp_report>(m, "OmpReport")
+        .def(py::init([]() { return ss::omp_report{ 0u, 0.0 }; }))
+        .def_readwrite("iter", &ss::omp_report::iter)
+        .def_readwrite("solution_error", &ss::omp_report::solution_error);
+    auto omp = py::class_<py_omp>(m, "Omp");
+    def_init<float, ss::omp_policy>(omp);
+    def_init<double, ss::omp_policy>(omp);
+    def_solve<float, ss::omp_policy>(omp);
+    def_solve<double, ss::omp_policy>(omp);
 }

@@ -23,6 +23,7 @@ SYMBOLS = [
     "ss_hip_device_count", "ss_hip_version",
     "ss_hip_homotopy_create_f32", "ss_hip_homotopy_create_f64", "ss_hip_homotopy_destroy",
     "ss_hip_homotopy_solve_f32", "ss_hip_homotopy_solve_f64",
+    "ss_hip_omp_solve_f32", "ss_hip_omp_solve_f64",
     "ss_hip_homotopy_solve_batch_f32", "ss_hip_homotopy_solve_batch_f64",
     "ss_hip_gemv_t_f32", "ss_hip_gemv_t_f64", "ss_hip_gemm_t_f32",
     "ss_hip_reconstruct_f32", "ss_hip_reconstruct_f64",
@@ -68,6 +69,10 @@ def lib():
         f.restype = vp
         f.argtypes = [vp, sz, sz, pd, pd, ctypes.c_int, cp, sz]
         f = getattr(L, "ss_hip_homotopy_solve_" + suf)
+        f.restype = ctypes.c_int
+        f.argtypes = [vp, vp, pd, ct, u32, vp, pd, ctypes.POINTER(u32),
+                      ctypes.POINTER(ctypes.c_double), cp, sz]
+        f = getattr(L, "ss_hip_omp_solve_" + suf)
         f.restype = ctypes.c_int
         f.argtypes = [vp, vp, pd, ct, u32, vp, pd, ctypes.POINTER(u32),
                       ctypes.POINTER(ctypes.c_double), cp, sz]
@@ -167,7 +172,11 @@ class Homotopy:
         if rc != 0:
             raise SsHipError(rc, err.value.decode())
 
-    def solve(self, y, tolerance=None, max_iterations=100, out=None):
+    def solve_omp(self, y, tolerance=None, max_iterations=100, out=None):
+        """orthogonal matching pursuit on the same device copy -> (x, iter, ||A^T r||_inf)"""
+        return self.solve(y, tolerance, max_iterations, out, _entry="ss_hip_omp_solve_")
+
+    def solve(self, y, tolerance=None, max_iterations=100, out=None, _entry="ss_hip_homotopy_solve_"):
         """-> (x, iter, solution_error); defaults mirror the reference binding
         (tolerance = eps(T)*10, max_iterations = 100: binding.cpp:94-95)."""
         yp, yshape, ystr, ydt, keep = _describe(y)
@@ -185,7 +194,7 @@ class Homotopy:
         it = ctypes.c_uint32(0)
         e = ctypes.c_double(0.0)
         err = ctypes.create_string_buffer(512)
-        fn = getattr(lib(), "ss_hip_homotopy_solve_" + self.suffix)
+        fn = getattr(lib(), _entry + self.suffix)
         rc = fn(self._h, yp, ystr[0], self.ctype(tolerance), int(max_iterations), xp, xstr[0],
                 ctypes.byref(it), ctypes.byref(e), err, len(err))
         self._check(rc, err)

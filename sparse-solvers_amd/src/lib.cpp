@@ -32,6 +32,34 @@ namespace ss
                          double* x, ptrdiff_t incx, uint32_t* io, double* eo, char* err, size_t len)
         { return ss_hip_homotopy_solve_f64(c, y, incy, tol, it, x, incx, io, eo, err, len); }
 
+        inline int solve_omp(ss_hip_ctx* c, const float* y, ptrdiff_t incy, float tol, uint32_t it,
+                             float* x, ptrdiff_t incx, uint32_t* io, double* eo, char* err, size_t len)
+        { return ss_hip_omp_solve_f32(c, y, incy, tol, it, x, incx, io, eo, err, len); }
+
+        inline int solve_omp(ss_hip_ctx* c, const double* y, ptrdiff_t incy, double tol, uint32_t it,
+                             double* x, ptrdiff_t incx, uint32_t* io, double* eo, char* err, size_t len)
+        { return ss_hip_omp_solve_f64(c, y, incy, tol, it, x, incx, io, eo, err, len); }
+
+        template <typename T>
+        kernelpp::maybe<omp_report> run_hip_omp(
+            homotopy_state<T>& st, const ndspan<T> y, T tol, uint32_t maxiter, ndspan<T> x)
+        {
+            if (!st.ctx())
+                return kernelpp::error(st.error().empty() ? "omp: no device context" : st.error());
+            if (y.size() != st.rows() || x.size() != st.cols())
+                return kernelpp::error("omp: vector lengths do not match the shape of A",
+                                       kernelpp::error_code::INVALID_ARGUMENT);
+            char msg[512] = { 0 };
+            omp_report rep{ 0u, 0.0 };
+            const int rc = solve_omp(st.ctx(), y.data(), (ptrdiff_t)y.strides()[0], tol, maxiter,
+                                     x.data(), (ptrdiff_t)x.strides()[0], &rep.iter, &rep.solution_error,
+                                     msg, sizeof(msg));
+            if (rc != SS_HIP_OK)
+                return kernelpp::error(msg, rc == SS_HIP_EINVAL ? kernelpp::error_code::INVALID_ARGUMENT
+                                                                : kernelpp::error_code::KERNEL_FAILED);
+            return rep;
+        }
+
         template <typename T>
         kernelpp::maybe<homotopy_report> run_hip(
             homotopy_state<T>& st, const ndspan<T> y, T tol, uint32_t maxiter, ndspan<T> x)
@@ -87,6 +115,18 @@ namespace ss
         homotopy_state<double>& st, const ndspan<double> y, double tol, uint32_t maxiter, ndspan<double> x)
     {
         return run_hip<double>(st, y, tol, maxiter, x);
+    }
+
+    kernelpp::maybe<omp_report> omp_policy::run(
+        homotopy_state<float>& st, const ndspan<float> y, float tol, uint32_t maxiter, ndspan<float> x)
+    {
+        return run_hip_omp<float>(st, y, tol, maxiter, x);
+    }
+
+    kernelpp::maybe<omp_report> omp_policy::run(
+        homotopy_state<double>& st, const ndspan<double> y, double tol, uint32_t maxiter, ndspan<double> x)
+    {
+        return run_hip_omp<double>(st, y, tol, maxiter, x);
     }
 
     /* Utils --------------------------------------------------------------- */

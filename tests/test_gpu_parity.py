@@ -477,3 +477,69 @@ def test_python_module_binding_tests(sship):
         ss.Homotopy(A).solve(signal, tolerance=2.0)
     with pytest.raises(RuntimeError):
         ss.Homotopy(A).solve(signal.astype(np.float32))
+
+
+# ---------------------------------------------------------------- OMP and the fp64 config
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_omp_vs_oracle(sship, dtype):
+    """ss_hip_omp_solve_*: same greedy picks, same least-squares coefficients as the CPU
+    statement of the algorithm (no OMP exists in the reference: unpinned there)."""
+    A, y, x0, sup = make_gaussian_problem(31, 256, 2000, 14, dtype)
+    tol = 1e-4 if dtype == np.float32 else 1e-9
+    xo, ito, eo, picks = oracle.omp(A, y, tol, 60)
+    with sship.Homotopy(A) as h:
+        h.set_option("trace", 1)
+        xg, itg, eg = h.solve_omp(y, tol, 60)
+        tr = h.trace()
+        assert itg == ito == 14
+        assert np.array_equal(tr["idx"][1:itg + 1], picks)          # entry t = pick of iteration t
+        assert np.array_equal(np.nonzero(xg)[0], sup)
+        assert np.abs(xg - xo).max() <= RTOL[np.dtype(dtype)] * np.abs(xo).max()
+        assert eg <= tol
+        for mi in (1, 5):
+            xo2, ito2, eo2, p2 = oracle.omp(A, y, tol, mi)
+            xg2, itg2, eg2 = h.solve_omp(y, tol, mi)
+            assert itg2 == ito2 == mi and np.array_equal(np.nonzero(xg2)[0], np.nonzero(xo2)[0])
+            assert np.abs(xg2 - xo2).max() <= 10 * RTOL[np.dtype(dtype)] * np.abs(xo2).max()
+            assert abs(eg2 - eo2) <= 1e-4 * abs(eo2)
+        # the homotopy entry still works on the same context afterwards
+        xh, ith, eh = h.solve(y, 1e-3 if dtype == np.float32 else 1e-9, 60)
+        assert np.array_equal(significant_support(xh, 1e-4), sup)
+
+
+def test_python_module_omp(sship):
+    import sparsesolvers as ss
+    A, y, x0, sup = make_gaussian_problem(32, 128, 512, 6, np.float64)
+    x, info = ss.Omp(A).solve(y, tolerance=1e-9, max_iterations=30)
+    assert isinstance(info, ss.OmpReport) and info.iter == 6 and info.solution_error <= 1e-9
+    assert np.array_equal(np.nonzero(x)[0], sup) and np.allclose(x, x0, atol=1e-10)
+
+
+def test_fp64_config_full_size(sship):
+    """BASELINE.json configs[4] shape: A 16384 x 131072 fp64 (16 GiB), k = 128, tol 1e-9.
+    Homotopy and OMP on one MI355X; the oracle would take minutes here, so check exact
+    support recovery, coefficients to 1e-10 and the iteration count."""
+    import torch
+    m, n, k = 16384, 131072, 128
+    g = torch.Generator(device="cuda:0").manual_seed(4321)
+    A = torch.randn((m, n), generator=g, device="cuda:0", dtype=torch.float64)
+    A /= np.sqrt(m)
+    rng = np.random.default_rng(4322)
+    sup = np.sort(rng.choice(n, k, replace=False))
+    coef = 1.0 + np.abs(rng.standard_normal(k))
+    y = (A[:, torch.from_numpy(sup).to("cuda:0")] @ torch.from_numpy(coef).to("cuda:0")).contiguous()
+    with sship.Homotopy(A) as h:
+        del A
+        torch.cuda.empty_cache()
+        x, it, err = h.solve(y, 1e-9, 512)
+        assert it == k and err <= 1e-9
+        assert np.array_equal(np.nonzero(x)[0], sup)
+        assert np.abs(x[sup] - coef).max() <= 1e-10 * coef.max()
+        xo, ito, eo = h.solve_omp(y, 1e-9, 512)
+        assert ito == k and eo <= 1e-9
+        assert np.array_equal(np.nonzero(xo)[0], sup)
+        assert np.abs(xo[sup] - coef).max() <= 1e-10 * coef.max()
+        r = rng.standard_normal(m)
+        c, ms = h.gemv_t(r, 3)
+        print("fp64 sweep: %.3f ms = %.0f GB/s" % (ms, (m * n * 8 + m * 8 + n * 8) / ms / 1e6))

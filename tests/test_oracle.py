@@ -309,3 +309,23 @@ def test_gemv_matches_numpy(dtype):
         assert np.allclose(yv, A.astype(np.float64) @ x, rtol=tol, atol=tol * 30)
     assert np.array_equal(oracle.gemv_t(A, v), oracle.gemv_t(np.asfortranarray(A), v))
     assert np.array_equal(oracle.gemv_n(A, x), oracle.gemv_n(np.asfortranarray(A), x))
+
+
+# ------------------------------------------------------------- OMP (unpinned by the reference)
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_omp_oracle_vs_sklearn(dtype):
+    """There is no OMP in the reference (include/ss/ss.h:60-64), so the oracle's OMP is
+    cross-checked against scikit-learn's orthogonal_mp instead of reference fixtures."""
+    from sklearn.linear_model import orthogonal_mp
+    A, y, x0, sup = make_gaussian_problem(21, 128, 600, 9, dtype)
+    tol = 1e-4 if dtype == np.float32 else 1e-9
+    x, it, err, picks = oracle.omp(A, y, tol, 50)
+    assert it == 9 and err <= tol
+    assert np.array_equal(np.sort(picks), sup)
+    xs = orthogonal_mp(A.astype(np.float64), y.astype(np.float64), n_nonzero_coefs=it)
+    assert np.array_equal(np.nonzero(x)[0], np.nonzero(xs)[0])
+    assert np.abs(x - xs).max() <= (1e-5 if dtype == np.float32 else 1e-12) * np.abs(xs).max()
+    # budget-limited run: first k picks of the same greedy sequence
+    x3, it3, err3, picks3 = oracle.omp(A, y, tol, 3)
+    assert it3 == 3 and np.array_equal(picks3, picks[:3]) and err3 > tol
