@@ -88,6 +88,23 @@ void error_convention()
     CHECK(ok.get_unchecked<ss::homotopy_report>().iter >= 1);
 }
 
+void omp_api()
+{
+    // ss::omp<T>: greedy pursuit on the same solver<T, Policy> template
+    const size_t M = 6, N = 6;
+    std::vector<double> A(M * N, 0.0), y(M, 0.0), x(N, 0.0);
+    for (size_t i = 0; i < M; i++) A[i * N + i] = 1.0;
+    y[1] = 2.0; y[4] = -3.0;
+    ss::omp<double> solver(ss::as_span<2>(A.data(), { M, N }));
+    auto r = solver.solve(ss::as_span(y), 1e-9, 6, ss::as_span(x));
+    CHECK(r.is<ss::omp_report>());
+    if (r.is<ss::omp_report>()) {
+        CHECK(r.get<ss::omp_report>().iter == 2);
+        CHECK(r.get<ss::omp_report>().solution_error <= 1e-9);
+    }
+    CHECK(x == y);
+}
+
 void utilities()
 {
     // norm_l1 literal (reference: src/linalg/norms_test.cpp) and reconstruct_signal
@@ -114,12 +131,14 @@ int main(int argc, char** argv)
 {
     static_assert(ss::detail::is_solver<ss::homotopy_policy, float>::value, "f32");
     static_assert(ss::detail::is_solver<ss::homotopy_policy, double>::value, "f64");
+    static_assert(ss::detail::is_solver<ss::omp_policy, float>::value, "omp f32");
     if (argc > 1 && !std::strcmp(argv[1], "--no-device")) return no_device() ? 1 : 0;
     smoke_test<float>();
     smoke_test<double>();
     smoke_test_column_subset<float>();
     smoke_test_column_subset<double>();
     error_convention();
+    omp_api();
     utilities();
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;
