@@ -1,33 +1,41 @@
 /*
- * ss/fwd.h — is_solver trait (reference: include/ss/fwd.h:19-38): well formed when the
- * policy P can solve problems parameterised by T, i.e. provides
- *     P::run(P::state_type<T>&, ndspan<T>, T, size_t, ndspan<T>).
+ * ss/fwd.h — compile-time check that a policy type can drive ss::solver<T, Policy>.
+ *
+ * A policy qualifies for element type T when the expression
+ *     Policy::run(state, y, tolerance, max_iterations, x)
+ * is valid for a `Policy::state_type<T>& state` and 1-d views y, x of T.  This is the role
+ * of the reference's detail::is_solver (include/ss/fwd.h:19-38), written here as an
+ * overload-resolution probe instead of a void_t partial specialisation.
  */
 #pragma once
 
 #include "ss/ndspan.h"
 
+#include <cstddef>
 #include <type_traits>
 #include <utility>
 
-namespace ss {
-    namespace detail
+namespace ss { namespace detail {
+
+    struct solver_probe
     {
-        using std::declval;
+        /* preferred overload: participates only when Policy::run(...) is well formed */
+        template <typename Policy, typename Elem,
+                  typename State = typename Policy::template state_type<Elem>,
+                  typename = decltype(Policy::run(std::declval<State&>(),
+                                                  std::declval<ndspan<Elem>>(),
+                                                  Elem(),
+                                                  std::size_t(),
+                                                  std::declval<ndspan<Elem>>()))>
+        static std::true_type test(int);
 
-        template <typename...> struct make_void { using type = void; };
-        template <typename... Ts> using void_t = typename make_void<Ts...>::type;
+        /* fallback */
+        template <typename Policy, typename Elem>
+        static std::false_type test(...);
+    };
 
-        template <typename P, typename T>
-        using solvable = decltype(
-            P::run(declval<typename P::template state_type<T>&>(),
-                   declval<ndspan<T>>(), T{0}, std::size_t{0},
-                   declval<ndspan<T>>()));
+    /* is_solver<Policy, T>::value — true when Policy can solve problems over T */
+    template <typename Policy, typename Elem>
+    struct is_solver : decltype(solver_probe::test<Policy, Elem>(0)) {};
 
-        template <typename P, typename T, typename = void>
-        struct is_solver : std::false_type {};
-
-        template <typename P, typename T>
-        struct is_solver <P, T, void_t<solvable<P, T>>> : std::true_type {};
-    }
-}
+}}

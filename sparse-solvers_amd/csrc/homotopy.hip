@@ -883,6 +883,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!ctx || !key) return SS_HIP_EINVAL;
     if (!std::strcmp(key, "sweep_variant")) { ctx->sweep_variant = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "lookahead"))     { ctx->lookahead = (int)value; return SS_HIP_OK; }
+    if (!std::strcmp(key, "temporal_cols")) { ctx->temporal_cols = std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "strict_sign"))   { ctx->strict_sign = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "trace"))         { ctx->tracing = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { ctx->zero_on_removal = value ? 1 : 0; return SS_HIP_OK; }
@@ -913,6 +914,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!ctx || !key || !value) return SS_HIP_EINVAL;
     if (!std::strcmp(key, "sweep_variant")) { *value = ctx->sweep_variant; return SS_HIP_OK; }
     if (!std::strcmp(key, "lookahead"))     { *value = ctx->lookahead; return SS_HIP_OK; }
+    if (!std::strcmp(key, "temporal_cols")) { *value = ctx->temporal_cols; return SS_HIP_OK; }
     if (!std::strcmp(key, "strict_sign"))   { *value = ctx->strict_sign; return SS_HIP_OK; }
     if (!std::strcmp(key, "trace"))         { *value = ctx->tracing; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { *value = ctx->zero_on_removal; return SS_HIP_OK; }

@@ -124,6 +124,7 @@ struct ss_hip_ctx {
 
     // options
     int sweep_variant = 5;   // 16 waves x 4 columns, 2-stage ring, 1 workgroup per CU: fastest on MI355X (profiles/)
+    long temporal_cols = 0;  // leading dictionary columns swept with cache-allocating loads (rest: nt)
     int lookahead = 4;
     int strict_sign = 0;
     int zero_on_removal = 1;

@@ -43,11 +43,67 @@ __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
+// Streams one chunk of CPW columns against the right-hand sides in LDS.
+// DEPTH-stage register ring: the loads of step t+DEPTH-1 are issued before the FMAs of step
+// t, so each wave keeps (DEPTH-1)*CPW .. DEPTH*CPW 16-byte loads (1 KiB each per wave) in
+// flight.  The step counter is wave-uniform (rows is a multiple of 64*VN), so guards are
+// scalar branches and the steady-state loop has none.
+template <typename T, int NRHS, int CPW, int DEPTH, bool NTL>
+__device__ __forceinline__ void stream_columns(const char* const (&cb)[CPW], const char* lds_b, uint32_t mc,
+                                               uint32_t nsteps, uint32_t lane_b, T (&acc)[CPW][NRHS])
+{
+    using V = typename VecOf<T>::type;
+    constexpr int VN = VecOf<T>::N;
+    constexpr uint32_t step_b = 64 * 16;                 // bytes per wave-step per column
+    V a[DEPTH][CPW];
+
+#define SS_LOAD(STAGE, TSTEP)                                                                 \
+    _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                                         \
+        const V* p_ = reinterpret_cast<const V*>(cb[c] + (lane_b + (TSTEP) * step_b));        \
+        a[STAGE][c] = NTL ? __builtin_nontemporal_load(p_) : *p_;                             \
+    }
+#define SS_COMPUTE(STAGE, TSTEP)                                                              \
+    {                                                                                         \
+        V rv_[NRHS];                                                                          \
+        _Pragma("unroll") for (int k = 0; k < NRHS; ++k) rv_[k] = *reinterpret_cast<const V*>( \
+            lds_b + ((uint32_t)k * mc * (uint32_t)sizeof(T) + lane_b + (TSTEP) * step_b));    \
+        _Pragma("unroll") for (int c = 0; c < CPW; ++c)                                       \
+        _Pragma("unroll") for (int k = 0; k < NRHS; ++k)                                      \
+        _Pragma("unroll") for (int e = 0; e < VN; ++e)                                        \
+            acc[c][k] = fma_t(a[STAGE][c][e], rv_[k][e], acc[c][k]);                          \
+    }
+
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s)
+        if ((uint32_t)s < nsteps) { SS_LOAD(s, (uint32_t)s) }
+
+    uint32_t t = 0;
+    for (; t + (2 * DEPTH - 1) <= nsteps; t += DEPTH) {      // steady state: no guards
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            SS_LOAD((s + DEPTH - 1) % DEPTH, t + (uint32_t)(s + DEPTH - 1))
+            SS_COMPUTE(s, t + (uint32_t)s)
+        }
+    }
+    for (; t < nsteps; t += DEPTH) {                          // drain
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            if (t + (uint32_t)(s + DEPTH - 1) < nsteps) {
+                SS_LOAD((s + DEPTH - 1) % DEPTH, t + (uint32_t)(s + DEPTH - 1))
+            }
+            if (t + (uint32_t)s < nsteps) { SS_COMPUTE(s, t + (uint32_t)s) }
+        }
+    }
+#undef SS_LOAD
+#undef SS_COMPUTE
+}
+
 template <typename T, int NRHS, int CPW, int WAVES, bool NT, int DEPTH, int BPC>
 __global__ __launch_bounds__(WAVES * 64, (BPC * WAVES) / 4)
 void k_sweep(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngroups, uint32_t mc,
              const T* __restrict__ rhs, size_t rhs_stride, T* __restrict__ out0, T* __restrict__ out1,
-             T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx, const DevState* st)
+             T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx, const DevState* st,
+             uint32_t temporal_groups)
 {
     using V = typename VecOf<T>::type;
     constexpr int VN = VecOf<T>::N;
@@ -95,55 +151,14 @@ void k_sweep(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngroup
                 cb[c] = reinterpret_cast<const char*>(At + (size_t)(col0 + c) * ldm + r0);
             const char* lds_b = reinterpret_cast<const char*>(lds);
 
-            // DEPTH-stage register ring: the loads of step t+DEPTH-1 are issued before the
-            // FMAs of step t, so each wave keeps (DEPTH-1)*CPW .. DEPTH*CPW 16-byte loads
-            // (1 KiB each per wave) in flight.  The step counter is wave-uniform (rows is
-            // a multiple of 64*VN), so guards are scalar branches and the steady-state
-            // loop has none.
-            constexpr uint32_t step_b = 64 * 16;                 // bytes per wave-step per column
             const uint32_t nsteps = rows / (64 * VN);
             const uint32_t lane_b = lane * 16;
-            V a[DEPTH][CPW];
-
-#define SS_LOAD(STAGE, TSTEP)                                                                 \
-    _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                                         \
-        const V* p_ = reinterpret_cast<const V*>(cb[c] + (lane_b + (TSTEP) * step_b));        \
-        a[STAGE][c] = NT ? __builtin_nontemporal_load(p_) : *p_;                              \
-    }
-#define SS_COMPUTE(STAGE, TSTEP)                                                              \
-    {                                                                                         \
-        V rv_[NRHS];                                                                          \
-        _Pragma("unroll") for (int k = 0; k < NRHS; ++k) rv_[k] = *reinterpret_cast<const V*>( \
-            lds_b + ((uint32_t)k * mc * (uint32_t)sizeof(T) + lane_b + (TSTEP) * step_b));    \
-        _Pragma("unroll") for (int c = 0; c < CPW; ++c)                                       \
-        _Pragma("unroll") for (int k = 0; k < NRHS; ++k)                                      \
-        _Pragma("unroll") for (int e = 0; e < VN; ++e)                                        \
-            acc[c][k] = fma_t(a[STAGE][c][e], rv_[k][e], acc[c][k]);                          \
-    }
-
-#pragma unroll
-            for (int s = 0; s < DEPTH - 1; ++s)
-                if ((uint32_t)s < nsteps) { SS_LOAD(s, (uint32_t)s) }
-
-            uint32_t t = 0;
-            for (; t + (2 * DEPTH - 1) <= nsteps; t += DEPTH) {      // steady state: no guards
-#pragma unroll
-                for (int s = 0; s < DEPTH; ++s) {
-                    SS_LOAD((s + DEPTH - 1) % DEPTH, t + (uint32_t)(s + DEPTH - 1))
-                    SS_COMPUTE(s, t + (uint32_t)s)
-                }
-            }
-            for (; t < nsteps; t += DEPTH) {                          // drain
-#pragma unroll
-                for (int s = 0; s < DEPTH; ++s) {
-                    if (t + (uint32_t)(s + DEPTH - 1) < nsteps) {
-                        SS_LOAD((s + DEPTH - 1) % DEPTH, t + (uint32_t)(s + DEPTH - 1))
-                    }
-                    if (t + (uint32_t)s < nsteps) { SS_COMPUTE(s, t + (uint32_t)s) }
-                }
-            }
-#undef SS_LOAD
-#undef SS_COMPUTE
+            // leading `temporal_groups` column groups are read with ordinary (cache-allocating)
+            // loads, the rest with the non-temporal hint (wave-uniform choice)
+            if (NT && g >= temporal_groups)
+                stream_columns<T, NRHS, CPW, DEPTH, true>(cb, lds_b, mc, nsteps, lane_b, acc);
+            else
+                stream_columns<T, NRHS, CPW, DEPTH, false>(cb, lds_b, mc, nsteps, lane_b, acc);
         }
 
 #pragma unroll
@@ -224,7 +239,8 @@ static hipError_t launch_one(const ss_hip_ctx* ctx, const Variant& v, const T* r
     if (nblocks_out) *nblocks_out = grid;
     hipLaunchKernelGGL((k_sweep<T, NRHS, CPW, WAVES, NT, DEPTH, BPC>), dim3(grid), dim3(WAVES * 64), lds_bytes,
                        ctx->stream, static_cast<const T*>(ctx->At), ldm, (uint32_t)ctx->n, ngroups, mc,
-                       rhs, rhs_stride, out0, out1, pmax_val, pmax_idx, st);
+                       rhs, rhs_stride, out0, out1, pmax_val, pmax_idx, st,
+                       (uint32_t)(ctx->temporal_cols / (WAVES * CPW)));
     return hipGetLastError();
 }
 

@@ -30,29 +30,34 @@ namespace
     /* API level of the reference this module mirrors (sparse-solvers v0.8.8) */
     const int VERSION[3] = { 0, 8, 8 };
 
-    template <size_t N, typename T>
-    ss::ndspan<T, N> as_span(py::array_t<T>& arr)
+    /* numpy array -> strided view (element strides); the dimension-count message is the
+       reference's (binding.cpp:24-25) because user code may match on it */
+    template <size_t Rank, typename T>
+    ss::ndspan<T, Rank> view_of(py::array_t<T>& array)
     {
-        if (arr.ndim() != (py::ssize_t)N) throw std::runtime_error(
-            "Unexpected number of dimensions. Expected " + std::to_string(N) + " but got "
-            + std::to_string(arr.ndim()));
-
-        std::array<size_t, N> shape;
-        std::array<size_t, N> strides;
-        for (size_t d = 0; d < N; d++) {
-            if (arr.strides(d) < 0) throw std::runtime_error(
-                "Negative strides are not supported; pass numpy.ascontiguousarray(a)");
-            shape[d] = (size_t)arr.shape(d);
-            strides[d] = (size_t)(arr.strides(d) / (py::ssize_t)sizeof(T));
+        const py::ssize_t have = array.ndim();
+        if (have != (py::ssize_t)Rank) {
+            throw std::runtime_error("Unexpected number of dimensions. Expected "
+                                     + std::to_string(Rank) + " but got " + std::to_string(have));
         }
-        return ss::as_span<N, T>(arr.mutable_data(), shape, strides);
+        std::array<size_t, Rank> extent, step;
+        for (size_t axis = 0; axis < Rank; ++axis) {
+            const py::ssize_t bytes = array.strides((py::ssize_t)axis);
+            if (bytes < 0) {
+                throw std::runtime_error("Negative strides are not supported; pass numpy.ascontiguousarray(a)");
+            }
+            extent[axis] = (size_t)array.shape((py::ssize_t)axis);
+            step[axis] = (size_t)bytes / sizeof(T);
+        }
+        return ss::ndspan<T, Rank>(array.mutable_data(), extent, step);
     }
 
-    template <typename R>
-    void try_throw(const kernelpp::maybe<R>& r)
+    /* library errors are values; Python gets them as RuntimeError */
+    template <typename Report>
+    void raise_if_error(const kernelpp::maybe<Report>& outcome)
     {
-        if (r.template is<kernelpp::error>())
-            throw std::runtime_error(r.template get<kernelpp::error>().data());
+        if (!outcome.template is<Report>())
+            throw std::runtime_error(outcome.template get<kernelpp::error>().data());
     }
 
     /* one Python class per policy, holding a float OR a double solver (binding.cpp:64-72) */
@@ -74,7 +79,7 @@ namespace
     void def_init(py::class_<py_solver<P>>& cls)
     {
         cls.def(py::init([](py::array_t<T> A_) {
-            auto A = as_span<2>(A_);
+            auto A = view_of<2>(A_);
             auto* self = new py_solver<P>{ A.shape(), nullptr, nullptr };
             slot_of<T, P>::get(*self).reset(new ss::solver<T, P>(A));
             return self;
@@ -92,14 +97,14 @@ namespace
                 if (!s) throw std::runtime_error(
                     "dtype of b does not match the dtype of the sensing matrix");
                 py::array_t<T> x((py::ssize_t)self.shape[1]);
-                auto bs = as_span<1>(b);
-                auto xs = as_span<1>(x);
+                auto bs = view_of<1>(b);
+                auto xs = view_of<1>(x);
                 kernelpp::maybe<report_type> result = report_type{ 0u, 0.0 };
                 {
                     py::gil_scoped_release release;
                     result = s->solve(bs, tol, maxiter, xs);
                 }
-                try_throw(result);
+                raise_if_error(result);
                 return std::make_tuple(x, result.template get<report_type>());
             },
             "Execute the solver on the given inputs.",
