@@ -300,8 +300,9 @@ void k_rp(const T* __restrict__ At, SlotDims L, const T* __restrict__ y,
         const uint32_t t = threadIdx.x, i = blockIdx.x * kRpRows + t;
         const T sr = ((s_r[0][t] + s_r[1][t]) + s_r[2][t]) + s_r[3][t];
         const T sp = ((s_p[0][t] + s_p[1][t]) + s_p[2][t]) + s_p[3][t];
-        rhs[i] = y[i] - sr;
-        rhs_p[i] = sp;
+        // padding rows stay exactly zero even if x or d went non-finite (0 * inf = NaN)
+        rhs[i] = (i < L.m) ? (y[i] - sr) : T(0);
+        rhs_p[i] = (i < L.m) ? sp : T(0);
     }
 }
 

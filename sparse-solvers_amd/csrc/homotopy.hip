@@ -113,7 +113,9 @@ void upload_matrix(ss_hip_ctx* ctx, const T* A, ptrdiff_t rs, ptrdiff_t cs)
 
     if ((rs == 1 || m == 1) && (cs >= (ptrdiff_t)m || n == 1) && cs > 0) {
         // column-major host view: columns are already contiguous
-        HIPCHK(hipMemcpy2D(At, (size_t)ldm * s, A, (size_t)cs * s, m * s, n, hipMemcpyHostToDevice));
+        // (a single column has no meaningful column stride: any pitch >= the width will do)
+        const size_t spitch = (n == 1) ? m * s : (size_t)cs * s;
+        HIPCHK(hipMemcpy2D(At, (size_t)ldm * s, A, spitch, m * s, n, hipMemcpyHostToDevice));
         return;
     }
 
@@ -123,12 +125,13 @@ void upload_matrix(ss_hip_ctx* ctx, const T* A, ptrdiff_t rs, ptrdiff_t cs)
     T* stage = nullptr;
     HIPCHK(hipMalloc(&stage, R * n * s));
     std::vector<T> gather;
-    const bool rowmajor = (cs == 1 || n == 1) && rs >= (ptrdiff_t)n && rs > 0;
+    const bool rowmajor = (cs == 1 || n == 1) && (rs >= (ptrdiff_t)n || m == 1) && rs > 0;
     try {
         for (size_t r0 = 0; r0 < m; r0 += R) {
             const size_t rows = std::min(R, m - r0);
             if (rowmajor) {
-                HIPCHK(hipMemcpy2D(stage, n * s, A + (ptrdiff_t)r0 * rs, (size_t)rs * s, n * s, rows,
+                const size_t spitch = (m == 1) ? n * s : (size_t)rs * s;
+                HIPCHK(hipMemcpy2D(stage, n * s, A + (ptrdiff_t)r0 * rs, spitch, n * s, rows,
                                    hipMemcpyHostToDevice));
             } else {
                 // arbitrary (e.g. negative or doubly strided) host view: gather on the host
@@ -195,6 +198,7 @@ void ensure_workspace(ss_hip_ctx* ctx, uint32_t nslots, uint32_t kcap)
     SlotDims L{};
     L.n_pad = ctx->n_pad;
     L.ldm = ctx->ldm;
+    L.m = (uint32_t)ctx->m;
     L.kcap = want_k;
     L.b_pad = b_pad;
     L.pmax_stride = kMaxSweepBlocks;
@@ -659,6 +663,8 @@ int gemv_t_impl(ss_hip_ctx* ctx, const T* r, T* c, int repeats, float* ms_out, c
         Workspace<T>& ws = *ws_of<T>(ctx);
         hipStream_t st = ctx->stream;
         copy_in<T>(ctx, ws.rhs, r, 1, ctx->m);
+        if (ctx->ldm > ctx->m)
+            HIPCHK(hipMemsetAsync(ws.rhs + ctx->m, 0, (ctx->ldm - ctx->m) * sizeof(T), st));
         uint32_t nb = 0;
         HIPCHK(hipEventRecord(ctx->ev_solve0, st));
         for (int i = 0; i < repeats; ++i)

@@ -68,6 +68,7 @@ struct TraceEntry {
 struct SlotDims {
     uint32_t n_pad;        // c, q, x, d, insup: one row of n_pad per slot
     uint32_t ldm;          // y, r, p: one row of ldm per slot
+    uint32_t m;            // rows of A (entries m..ldm-1 of y, r, p are zero padding)
     uint32_t kcap;         // gam/touched: 2*kcap per slot; inv: 2*kcap*kcap; u1/u2/sgn: kcap
     uint32_t b_pad;        // rows of the r-block (the p-block / q-block start b_pad rows later)
     uint32_t pmax_stride;  // partial (max |c|, index) pairs per slot

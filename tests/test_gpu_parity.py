@@ -543,3 +543,38 @@ def test_fp64_config_full_size(sship):
         r = rng.standard_normal(m)
         c, ms = h.gemv_t(r, 3)
         print("fp64 sweep: %.3f ms = %.0f GB/s" % (ms, (m * n * 8 + m * 8 + n * 8) / ms / 1e6))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 5), (5, 1), (3, 200), (200, 3), (255, 127), (256, 128),
+                                   (257, 129), (40, 1000)])
+def test_ragged_shapes_vs_oracle(sship, shape, dtype):
+    """shapes around the padding boundaries (column pitch 256 rows, 128-column tiles) and
+    degenerate ones (single row / column; more columns than rows); bounded iteration budgets
+    so that ill-posed shapes compare the first segments of the path only."""
+    m, n = shape
+    rng = np.random.default_rng(m * 1009 + n)
+    A = rng.standard_normal((m, n)).astype(dtype)
+    A /= np.maximum(np.linalg.norm(A, axis=0, keepdims=True), 1e-3)
+    x0 = np.zeros(n)
+    k = max(1, min(n, m // 4, 6))
+    x0[rng.choice(n, k, replace=False)] = 1 + np.abs(rng.standard_normal(k))
+    y = (A.astype(np.float64) @ x0).astype(dtype)
+    tol = 1e-3 if dtype == np.float32 else 1e-9
+    with sship.Homotopy(A) as h:
+        for max_iter in (1, 2, min(4, 2 * k)):
+            xo, ito, eo = oracle.homotopy(A, y, tol, max_iter, flags=oracle.SPARSE_NOTRANS | oracle.ZERO_ON_REMOVAL)
+            xg, itg, eg = h.solve(y, tol, max_iter)
+            assert itg == ito
+            scale = max(np.abs(xo).max(), 1e-30)
+            if np.isfinite(xo).all():
+                assert np.abs(xg - xo).max() <= 50 * RTOL[np.dtype(dtype)] * scale
+                assert abs(eg - eo) <= 50 * RTOL[np.dtype(dtype)] * max(1.0, abs(eo))
+            else:
+                assert not np.isfinite(xg).all()
+        c, _ = h.gemv_t(y)
+        assert np.allclose(c, A.astype(np.float64).T @ y, rtol=1e-4 if dtype == np.float32 else 1e-11,
+                           atol=1e-5 if dtype == np.float32 else 1e-12)
+        xo, ito, eo, picks = oracle.omp(A, y, tol, k)
+        xg, itg, eg = h.solve_omp(y, tol, k)
+        assert itg == ito and np.abs(xg - xo).max() <= 50 * RTOL[np.dtype(dtype)] * max(np.abs(xo).max(), 1e-30)
