@@ -141,6 +141,16 @@ int ss_hip_gemm_t_f32(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, 
                       int repeats, float* ms_out, char* err, size_t errlen);
 
 /*
+ * Gram columns G[s][:] = A^T a_{cols[s]} for up to 32 dictionary columns (host index list) in
+ * ONE pass over the matrix: the "lookahead sweep" of the single-signal solver, which fetches
+ * the correlations of the 32 most likely next entrants at once so that most Homotopy
+ * iterations need no sweep at all.  32 right-hand sides are 16 flop per byte of A — still
+ * HBM-bound on MI355X — computed on the fp32 MFMA units.  G: S rows of n elements (ldG).
+ */
+int ss_hip_gram_cols_f32(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, float* G, ptrdiff_t ldG,
+                         int repeats, float* ms_out, char* err, size_t errlen);
+
+/*
  * y = A x on the device copy — ss::reconstruct_signal (src/lib.cpp:78-104).
  * x: n elements, y: m elements.
  */
@@ -160,6 +170,7 @@ typedef struct ss_hip_stats {
     uint64_t sweep1_bytes;         /* m*n*s + m*s + n*s                                         */
     double   solve_ms;             /* HIP-event time of whole solves (upload of y .. x ready)  */
     uint64_t batch_rounds;         /* lock-step rounds run by the batched (MFMA) path          */
+    uint64_t lookahead_sweeps;     /* 32-RHS lookahead sweeps run by the fp32 single-signal engine */
 } ss_hip_stats;
 
 /* profiling != 0: bracket every sweep launch with HIP events on the context's stream. */
@@ -174,6 +185,11 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "strict_sign"    1 = seed the first direction with sign(c[idx]) instead of the
  *                    reference's sign(|c[idx]|) (homotopy-cpu.cpp:223-227); default 0
  *   "trace"          1 = record the homotopy path of each solve (ss_hip_get_trace)
+ *   "engine"         fp32 single-signal Homotopy: 1 (default) = lookahead engine — Gram
+ *                    columns A^T a_j of active columns are cached and A is swept (32 right-hand
+ *                    sides per pass) only when an uncached column enters; 0 = one fused 2-RHS
+ *                    sweep per iteration.  fp64 always uses 0.
+ *   "cache_mib"      memory budget of the lookahead engine's Gram-column cache (default 2048)
  *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 4)
  *   "batch_chunk"    signals processed together by the batched path (default 4096)
  *   "profile_every"  with profiling on, bracket only every k-th fused sweep with events

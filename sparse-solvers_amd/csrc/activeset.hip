@@ -330,7 +330,8 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
                T* pmin_val, uint32_t* pmin_idx,
                uint32_t* __restrict__ gam2, uint32_t* __restrict__ touched2, SlotDims L,
                DevState* st, uint32_t* hflags, TraceEntry* trace, uint32_t trace_cap,
-               int zero_on_removal, int tie_guard, uint32_t* ndone, uint32_t nslots)
+               int zero_on_removal, int tie_guard, uint32_t* ndone, uint32_t nslots,
+               T* __restrict__ tcand, const int32_t* __restrict__ slot_of)
 {
     const uint32_t kcap = L.kcap;
     {   // slot = blockIdx.y
@@ -361,6 +362,7 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
             st->c_inf = (double)c_inf;
             st->iter = round - 1;
             st->done_round = round;
+            st->need_sweep = 0;
             st->done = 1;
             signal_done(hflags, ndone, nslots, round);
         }
@@ -398,6 +400,8 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
                     if (t > T(0) && t < m) m = t;
                 }
             }
+            // lookahead ranking: only columns that are neither active nor cached compete
+            if (tcand != nullptr) tcand[i] = (insup[i] || slot_of[i] >= 0) ? Lim<T>::max() : m;
             if (better_min(m, i, best, best_i)) { best = m; best_i = i; }
         }
     }
@@ -469,6 +473,7 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
             }
             st->c_inf = (double)c_inf;
             st->done_round = round;
+            st->need_sweep = 0;
             st->done = 1;
             signal_done(hflags, ndone, nslots, round);
         }
@@ -514,8 +519,180 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
         st->gamma = (double)g;
         st->c_inf = (double)c_inf;
         st->iter = round;
+        // lookahead engine: the inserted column needs its Gram column; sweep only if not cached
+        st->need_sweep = (slot_of != nullptr && added && slot_of[idx] < 0) ? 1u : 0u;
         if (hflags) __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// =========================================================================================
+// Lookahead engine (fp32 single signal).  Instead of sweeping A every iteration, the Gram
+// columns g_j = A^T a_j of the active columns are cached: with them
+//     c = A^T y - sum_j x_j g_j ,   q = sum_j d_j g_j ,   u1 = g_idx[Gamma] ,  a_idx.a_idx = g_idx[idx]
+// are O(K n) gathers, and A is only swept when a column enters whose g is not cached — and that
+// sweep fetches, in the same pass over A, the g of the 31 columns most likely to enter next
+// (smallest step-length candidates of find_max_gamma), so most iterations need no sweep at all.
+// Same algorithm, same decisions; only the order of floating-point operations in c and q
+// changes (Gram form instead of residual form).
+// =========================================================================================
+
+// first pick after c0 = A^T y: idx = argmax |c0| (homotopy-cpu.cpp:217-221)
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_la_init_pick(const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
+                    uint8_t* __restrict__ insup, uint32_t* __restrict__ gam, uint32_t* __restrict__ touched,
+                    DevState* st, TraceEntry* trace)
+{
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    T c_inf;
+    uint32_t idx;
+    reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, idx, sv, si);
+    if (threadIdx.x == 0) {
+        insup[idx] = 1;
+        gam[0] = idx;
+        touched[0] = idx;
+        st->done = 0; st->status = 0; st->iter = 0;
+        st->K = 1; st->ntouched = 1; st->idx = idx; st->rank = 0; st->added = 1;
+        st->cur = 1;    // the update kernel reads the new lists from buffer cur^1 = 0 and flips
+        st->done_round = 0;
+        st->c_inf = (double)c_inf;
+        st->gamma = 0.0;
+        st->need_sweep = 1; st->cache_used = 0; st->nsweeps = 0;
+        if (trace != nullptr) { trace[0].idx = idx; trace[0].added = 1; trace[0].gamma = 0.0; trace[0].c_inf = (double)c_inf; }
+    }
+}
+
+// choose the columns of the next lookahead sweep: the entering column first, then not-yet-
+// cached columns with small step-length candidates (init: large |c0|).  The ranking is a
+// prefetch heuristic, not part of the algorithm's decisions, so it is approximate on purpose:
+// every thread offers the best of its n/1024 strided columns and the 32 best offers win.
+constexpr int kTopS = 32;
+
+template <typename T>
+__global__ __launch_bounds__(kUpdThreads)
+void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, int init_mode,
+              const uint8_t* __restrict__ insup, int32_t* __restrict__ slot_of, uint32_t gcap,
+              uint32_t* __restrict__ sw_list, DevState* st, uint32_t* hflags)
+{
+    if (st->done || !st->need_sweep) return;
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    const uint32_t idx = st->idx;
+    const uint32_t tid = threadIdx.x;
+
+    // this thread's two best offers among its columns (MAX = nothing to offer).  In the scan
+    // mode tcand already carries MAX for active and cached columns; in init mode nothing is
+    // cached yet and only idx is active.
+    T v1 = Lim<T>::max(), v2 = Lim<T>::max();
+    uint32_t i1 = 0xffffffffu, i2 = 0xffffffffu;
+    for (uint32_t i = tid; i < n; i += kUpdThreads) {
+        T v;
+        if (init_mode) { const T a = c[i] < T(0) ? -c[i] : c[i]; v = -a; }
+        else v = tcand[i];
+        if (i == idx) v = -Lim<T>::max();                       // the entering column always wins
+        if (better_min(v, i, v1, i1)) { v2 = v1; i2 = i1; v1 = v; i1 = i; }
+        else if (better_min(v, i, v2, i2)) { v2 = v; i2 = i; }
+    }
+    uint32_t used = st->cache_used;
+    uint32_t count = 0;
+    for (int sidx = 0; sidx < kTopS; ++sidx) {
+        T bv = v1;
+        uint32_t bi = i1;
+        block_reduce_pair<T, false>(bv, bi, sv, si);
+        if (!(bv < Lim<T>::max()) || bi == 0xffffffffu || used >= gcap) break;   // uniform
+        if (bi == i1) { v1 = v2; i1 = i2; v2 = Lim<T>::max(); i2 = 0xffffffffu; }   // offer taken
+        if (tid == 0) {
+            sw_list[count] = bi;               // rcols: right-hand side = column bi of A
+            sw_list[kTopS + count] = used;     // drows: output row = cache slot
+            slot_of[bi] = (int32_t)used;
+        }
+        ++used;
+        ++count;
+    }
+    if (tid == 0) {
+        for (uint32_t s2 = count; s2 < (uint32_t)kTopS; ++s2) { sw_list[s2] = 0xffffffffu; sw_list[kTopS + s2] = 0xffffffffu; }
+        st->cache_used = used;
+        st->nsweeps += 1;
+        if (slot_of[idx] < 0) {                 // cache exhausted: the column cannot be inserted
+            st->status = SS_HIP_ECAPACITY;
+            st->need_sweep = 0;
+            st->done = 1;
+            signal_done(hflags, nullptr, 1u, st->iter);
+        }
+    }
+}
+
+// c = c0 - sum_j x_j g_j ; q = sum_j d_j g_j over the touched columns; partial max |c|
+constexpr uint32_t kCqChunk = 1024;
+constexpr uint32_t kCqTile = 256;        // touched columns staged in LDS per pass
+
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, const T* __restrict__ c0,
+             const T* __restrict__ x, const T* __restrict__ d, const uint32_t* __restrict__ touched2,
+             uint32_t n, uint32_t gpitch, SlotDims L, T* __restrict__ c, T* __restrict__ q,
+             T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx, const DevState* st)
+{
+    if (st->done) return;
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_slot[kCqTile];
+    __shared__ T s_x[kCqTile];
+    __shared__ T s_d[kCqTile];
+    const uint32_t nt = st->ntouched;
+    const uint32_t* touched = touched2 + (size_t)st->cur * L.kcap;
+    const uint32_t base = blockIdx.x * kCqChunk;
+    const T* gbase = gcache + base + threadIdx.x;               // gpitch % 1024 == 0: rows never run out
+    T ax[4] = { T(0), T(0), T(0), T(0) }, ad[4] = { T(0), T(0), T(0), T(0) };
+    for (uint32_t j0 = 0; j0 < nt; j0 += kCqTile) {
+        const uint32_t cnt = (nt - j0 < kCqTile) ? (nt - j0) : kCqTile;
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const uint32_t col = touched[j0 + threadIdx.x];
+            s_slot[threadIdx.x] = (uint32_t)slot_of[col];
+            s_x[threadIdx.x] = x[col];
+            s_d[threadIdx.x] = d[col];
+        }
+        __syncthreads();
+        uint32_t j = 0;
+        for (; j + 4 <= cnt; j += 4) {
+            T gv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T* g = gbase + (size_t)s_slot[j + u] * gpitch;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gv[u][k] = g[k * kSmallThreads];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T xj = s_x[j + u], dj = s_d[j + u];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ax[k] += xj * gv[u][k]; ad[k] += dj * gv[u][k]; }
+            }
+        }
+        for (; j < cnt; ++j) {
+            const T* g = gbase + (size_t)s_slot[j] * gpitch;
+            const T xj = s_x[j], dj = s_d[j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const T gvv = g[k * kSmallThreads]; ax[k] += xj * gvv; ad[k] += dj * gvv; }
+        }
+    }
+    T bv = T(-1);
+    uint32_t bi = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = base + k * kSmallThreads + threadIdx.x;
+        if (i < n) {
+            const T cv = c0[i] - ax[k];
+            c[i] = cv;
+            q[i] = ad[k];
+            const T a = cv < T(0) ? -cv : cv;
+            if (better_max(a, i, bv, bi)) { bv = a; bi = i; }
+        }
+    }
+    block_reduce_pair<T, true>(bv, bi, sv, si);
+    if (threadIdx.x == 0) { pmax_val[blockIdx.x] = bv; pmax_idx[blockIdx.x] = bi; }
 }
 
 // ---- k_omp_select: orthogonal matching pursuit's pick (one workgroup per slot) -------------
@@ -608,7 +785,9 @@ __global__ __launch_bounds__(kUpdThreads)
 void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict__ gam2,
                T* inv0, T* inv1, T* u1, T* u2, T* sgn,
                const T* __restrict__ c, const T* __restrict__ q, T* __restrict__ d, T tol,
-               DevState* st, int omp, const T* __restrict__ y, T* __restrict__ x)
+               DevState* st, int omp, const T* __restrict__ y, T* __restrict__ x,
+               const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, uint32_t gpitch,
+               int first, int strict_sign)
 {
     const uint32_t ldm = L.ldm, kcap = L.kcap;
     {   // slot = blockIdx.y
@@ -634,7 +813,20 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
     const uint32_t* gam_old = gam2 + (size_t)cur * kcap;
     const uint32_t* gam_new = gam2 + (size_t)(cur ^ 1u) * kcap;
 
-    if (added && blockIdx.x < K_new) {
+    if (gcache != nullptr) {
+        // lookahead engine: one workgroup; u1 and a_idx.a_idx are gathered from the cached
+        // Gram column of the entering column
+        if (st->status != 0) return;
+        if (added) {
+            const T* gi = gcache + (size_t)slot_of[st->idx] * gpitch;
+            for (uint32_t b = threadIdx.x; b < K_new; b += blockDim.x) {
+                const T v = gi[gam_new[b]];
+                if (b == rank) st->dot = (double)v;
+                else u1[b - (b > rank ? 1u : 0u)] = v;
+            }
+        }
+        __syncthreads();
+    } else if (added && blockIdx.x < K_new) {
         const uint32_t b = blockIdx.x;
         const V4* col = reinterpret_cast<const V4*>(At + (size_t)gam_new[b] * ldm);
         const V4* cnew = reinterpret_cast<const V4*>(At + (size_t)st->idx * ldm);
@@ -666,7 +858,7 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
             if (omp) sgn[b] = vy;                      // b_S in the new sorted order
         }
     }
-    if (!arrive_last(&st->ticket_gram, gridDim.x, &s_flag)) return;
+    if (gcache == nullptr && !arrive_last(&st->ticket_gram, gridDim.x, &s_flag)) return;
 
     // ---- last workgroup --------------------------------------------------------------
     const T* Iold = cur ? inv1 : inv0;
@@ -690,7 +882,16 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
         T part = T(0);
         for (uint32_t j = threadIdx.x; j < nn; j += blockDim.x) part += u1[j] * u2[j];
         const T s = block_sum(part, sv);
-        if (threadIdx.x == 0) s_d = T(1) / ((T)load_handoff(&st->dot) - s);
+        if (threadIdx.x == 0) {
+            const T dotv = (T)load_handoff(&st->dot);
+            if (nn == 0) {
+                // first column: inv = [1 / ||col||^2] through the norm (online_inverse.h:193-201)
+                const T nrm = sqrt(dotv);
+                s_d = T(1) / (nrm * nrm);
+            } else {
+                s_d = T(1) / (dotv - s);
+            }
+        }
         __syncthreads();
         const T dv = s_d;
         // new inverse in sorted order: [inv + d u2 u2^T, -d u2; -d u2^T, d] with the new
@@ -746,7 +947,9 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
     const T g = (T)st->gamma;
     for (uint32_t a = threadIdx.x; a < K_new; a += blockDim.x) {
         const uint32_t col = gam_new[a];
-        const T cn = c[col] - g * q[col];
+        T cn = c[col] - g * q[col];
+        // first-step quirk (homotopy-cpu.cpp:223-227): the seed is sign(|c[idx]|) = +1
+        if (first) cn = strict_sign ? c[col] : (c[col] < T(0) ? -c[col] : c[col]);
         sgn[a] = sign_tol(cn, tol);
     }
     // clear the old direction
@@ -870,12 +1073,14 @@ hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32
     hipLaunchKernelGGL((k_scansel<T>), dim3(ns, nslots), dim3(kSmallThreads), 0, ctx->stream, round, tol,
                        max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
                        nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
-                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots);
+                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,
+                       (T*)nullptr, (const int32_t*)nullptr);
     uint32_t gb = round + 1;
     if (gb > ws.kcap) gb = ws.kcap;
     hipLaunchKernelGGL((k_gramupd<T>), dim3(gb, nslots), dim3(kUpdThreads), 0, ctx->stream,
                        static_cast<const T*>(ctx->At), ws.dims, ws.gam, ws.inv[0], ws.inv[1],
-                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 0, (const T*)nullptr, (T*)nullptr);
+                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 0, (const T*)nullptr, (T*)nullptr,
+                       (const T*)nullptr, (const int32_t*)nullptr, 0u, 0, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_rp(ctx, ws, nslots);
@@ -893,10 +1098,66 @@ hipError_t launch_omp_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsl
     if (gb > ws.kcap) gb = ws.kcap;
     hipLaunchKernelGGL((k_gramupd<T>), dim3(gb, nslots), dim3(kUpdThreads), 0, ctx->stream,
                        static_cast<const T*>(ctx->At), ws.dims, ws.gam, ws.inv[0], ws.inv[1],
-                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 1, (const T*)ws.y, ws.x);
+                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 1, (const T*)ws.y, ws.x,
+                       (const T*)nullptr, (const int32_t*)nullptr, 0u, 0, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_rp(ctx, ws, nslots);
+}
+
+// ---- lookahead engine launchers -------------------------------------------------------------
+template <typename T>
+hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts)
+{
+    hipLaunchKernelGGL((k_la_init_pick<T>), dim3(1), dim3(kSmallThreads), 0, ctx->stream, ws.pmax_val,
+                       ws.pmax_idx, nparts, ws.insup, ws.gam, ws.touched, ws.st, ws.trace);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode)
+{
+    hipLaunchKernelGGL((k_la_top<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, ws.tcand, ws.c0,
+                       (uint32_t)ctx->n, init_mode, ws.insup, ws.slot_of, ws.gcap, ws.sw_list, ws.st, ctx->dev_flags);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_la_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol)
+{
+    hipLaunchKernelGGL((k_gramupd<T>), dim3(1, 1), dim3(kUpdThreads), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ws.dims, ws.gam, ws.inv[0], ws.inv[1],
+                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 0, (const T*)nullptr, (T*)nullptr,
+                       (const T*)ws.gcache, (const int32_t*)ws.slot_of, ws.gpitch, round == 0 ? 1 : 0, ctx->strict_sign);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_la_cq(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t* nparts_out)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    const uint32_t nb = (n + kCqChunk - 1) / kCqChunk;
+    if (nb > ws.dims.pmax_stride) return hipErrorInvalidValue;
+    if (nparts_out) *nparts_out = nb;
+    hipLaunchKernelGGL((k_la_cq<T>), dim3(nb), dim3(kSmallThreads), 0, ctx->stream, ws.gcache, ws.slot_of,
+                       ws.c0, ws.x, ws.d, ws.touched, n, ws.gpitch, ws.dims, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, ws.st);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol,
+                             uint32_t max_iter)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    const uint32_t per_block = kSmallThreads * kScanPerThread;
+    uint32_t ns = (n + per_block - 1) / per_block;
+    if (ns > ws.dims.pmin_stride) ns = ws.dims.pmin_stride;
+    hipLaunchKernelGGL((k_scansel<T>), dim3(ns, 1), dim3(kSmallThreads), 0, ctx->stream, round, tol,
+                       max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
+                       nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
+                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, 1u,
+                       ws.tcand, (const int32_t*)ws.slot_of);
+    return hipGetLastError();
 }
 
 template <typename T>
@@ -933,6 +1194,11 @@ template hipError_t launch_omp_tail<float>(const ss_hip_ctx*, Workspace<float>&,
                                            uint32_t, float, uint32_t);
 template hipError_t launch_omp_tail<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t,
                                             uint32_t, double, uint32_t);
+template hipError_t launch_la_init_pick<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t);
+template hipError_t launch_la_top<float>(const ss_hip_ctx*, Workspace<float>&, int);
+template hipError_t launch_la_update<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
+template hipError_t launch_la_cq<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t*);
+template hipError_t launch_la_scansel<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, float, uint32_t);
 template hipError_t launch_absmax<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t*);
 template hipError_t launch_absmax<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t*);
 template hipError_t launch_gemv_n<float>(const ss_hip_ctx*, const float*, float*);

@@ -136,6 +136,140 @@ void k_gemm_tn_f32(const float* __restrict__ R, const float* __restrict__ Q, flo
         }
 }
 
+// ---- 32-row variant: the "lookahead sweep" ---------------------------------------------------
+// D[s][:] = At · r_s for up to 32 right-hand sides in ONE pass over At.  With 32 rows the MFMA
+// work per byte of At is 16 flop/B — still left of the fp32 ridge (157 TFLOP/s / 6.6 TB/s =
+// 24 flop/B) — so this kernel is HBM-bound like the 2-RHS sweep and costs about the same time,
+// but yields 32 correlation vectors.  The single-signal solver uses it to fetch the Gram columns
+// A^T a_j of the 32 most likely next entrants at once (homotopy.hip, engine "lookahead").
+//
+// Right-hand sides are rows of At itself, named by rcols[s] (0xffffffff = unused row -> zeros);
+// output row s goes to D + drows[s]*ldd (scattered into the Gram-column cache).
+// Tile 32 x 256 x 32 per 256-thread workgroup: wave w owns dictionary columns [64w, 64w+64) as
+// two 32x32 MFMA tiles; same K-contiguous ds_read_b128 feeding as above.
+constexpr int HM = 32, HN = 256, HT = 512;
+
+// One workgroup per CU (83 KiB LDS), 8 waves, each wave one 32x32 accumulator (32 dictionary
+// columns).  To keep enough HBM requests in flight from a single workgroup the global loads
+// run THREE K-steps ahead through a ring of register sets (3 x 36 KiB per workgroup), LDS is
+// double buffered, one barrier per K-step.
+__global__ __launch_bounds__(HT, 1)
+void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
+                     const uint32_t* __restrict__ drows, float* __restrict__ D,
+                     uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
+                     const DevState* __restrict__ st)
+{
+    if (st != nullptr && (st->done != 0 || st->need_sweep == 0)) return;   // no sweep needed this round
+    __shared__ __attribute__((aligned(16))) float sR[2][HM][GLD];
+    __shared__ __attribute__((aligned(16))) float sQ[2][HN][GLD];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t h = lane >> 5, l31 = lane & 31u;
+    const uint32_t srow = tid >> 3, squad = tid & 7u;          // staging: rows srow + 64j, k-quad squad
+    const bool has_r = tid < 256;                               // R tile: 32 rows x 8 quads
+
+    const uint32_t rc = rcols[srow & 31u];
+    const bool rvalid = has_r && rc != 0xffffffffu;
+    const float* gR = At + (size_t)(rvalid ? rc : 0u) * ldq + squad * 4;
+    const v4f zero4 = { 0.f, 0.f, 0.f, 0.f };
+    const uint32_t nk = K / GK;
+
+    for (uint32_t bn = blockIdx.x; bn < ntiles; bn += gridDim.x) {
+        const float* gQ = At + (size_t)(bn * HN + srow) * ldq + squad * 4;
+        v16f acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+        v4f rR[3], rQ[3][4];
+#define G32_LOAD(SET, KT)                                                                      \
+    {                                                                                          \
+        const uint32_t koff_ = (KT) * GK;                                                      \
+        rR[SET] = rvalid ? *reinterpret_cast<const v4f*>(gR + koff_) : zero4;                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+            rQ[SET][j] = __builtin_nontemporal_load(                                           \
+                reinterpret_cast<const v4f*>(gQ + (size_t)(64 * j) * ldq + koff_));            \
+    }
+#define G32_STORE(SET, BUF)                                                                    \
+    {                                                                                          \
+        if (has_r) *reinterpret_cast<v4f*>(&sR[BUF][srow][squad * 4]) = rR[SET];               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+            *reinterpret_cast<v4f*>(&sQ[BUF][srow + 64 * j][squad * 4]) = rQ[SET][j];          \
+    }
+#define G32_COMPUTE(BUF)                                                                       \
+    _Pragma("unroll") for (int g = 0; g < GK / 8; ++g) {                                       \
+        const uint32_t kq_ = (2u * g + h) * 4u;                                                \
+        const v4f a_ = *reinterpret_cast<const v4f*>(&sR[BUF][l31][kq_]);                      \
+        const v4f b_ = *reinterpret_cast<const v4f*>(&sQ[BUF][wave * 32 + l31][kq_]);          \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                          \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], b_[t], acc, 0, 0, 0);            \
+    }
+
+        // prologue: tiles 0,1,2 in flight; tile 0 -> LDS[0]; tile 3 re-uses set 0
+        G32_LOAD(0, 0u)
+        if (nk > 1) G32_LOAD(1, 1u)
+        if (nk > 2) G32_LOAD(2, 2u)
+        __syncthreads();                                        // previous column tile fully consumed
+        G32_STORE(0, 0)
+        if (nk > 3) G32_LOAD(0, 3u)
+        __syncthreads();
+
+        // steady state, unrolled by 3 so that the register sets have fixed names:
+        // iteration kt computes tile kt from LDS[kt&1], stores tile kt+1 (set (kt+1)%3) into the
+        // other buffer and refills that set with tile kt+4
+        uint32_t kt = 0;
+        for (; kt + 3 <= nk; kt += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const uint32_t k = kt + (uint32_t)u;
+                const int buf = (int)(k & 1u);
+                if (buf == 0) { G32_COMPUTE(0) } else { G32_COMPUTE(1) }
+                if (k + 1 < nk) {
+                    const int set = (u + 1) % 3;
+                    if (buf == 0) { G32_STORE(set, 1) } else { G32_STORE(set, 0) }
+                    if (k + 4 < nk) G32_LOAD(set, k + 4)
+                }
+                __syncthreads();
+            }
+        }
+        for (; kt < nk; ++kt) {                                 // nk % 3 leftovers (not hit when K % 96 == 0)
+            const int buf = (int)(kt & 1u);
+            if (buf == 0) { G32_COMPUTE(0) } else { G32_COMPUTE(1) }
+            if (kt + 1 < nk) {
+                const uint32_t set = (kt + 1) % 3;
+                if (set == 0) { if (buf == 0) { G32_STORE(0, 1) } else { G32_STORE(0, 0) } if (kt + 4 < nk) G32_LOAD(0, kt + 4) }
+                else if (set == 1) { if (buf == 0) { G32_STORE(1, 1) } else { G32_STORE(1, 0) } if (kt + 4 < nk) G32_LOAD(1, kt + 4) }
+                else { if (buf == 0) { G32_STORE(2, 1) } else { G32_STORE(2, 0) } if (kt + 4 < nk) G32_LOAD(2, kt + 4) }
+            }
+            __syncthreads();
+        }
+#undef G32_LOAD
+#undef G32_STORE
+#undef G32_COMPUTE
+
+        const uint32_t col = bn * HN + wave * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const uint32_t dr = drows[row];
+            if (dr != 0xffffffffu) D[(size_t)dr * ldd + col] = acc[e];
+        }
+    }
+}
+
+// D[drows[s]][:] = At · At[rcols[s]][:] for s < 32 (entries 0xffffffff are skipped)
+hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
+                                float* D, uint32_t ldd, const DevState* st)
+{
+    if (ctx->n_pad % HN != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
+    const uint32_t ntiles = ctx->n_pad / HN;
+    const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
+    hipLaunchKernelGGL(k_gemm32_tn_f32, dim3(grid), dim3(HT), 0, ctx->stream,
+                       static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles,
+                       st);
+    return hipGetLastError();
+}
+
 // D[Mg][ldd] = R[Mg][ldr] * At^T ; Mg % 128 == 0, ctx->n_pad % 128 == 0, ldm % 32 == 0
 hipError_t launch_gemm_tn_f32(const ss_hip_ctx* ctx, const float* R, uint32_t Mg, uint32_t ldr,
                               float* D, uint32_t ldd, const uint32_t* row_tile_skip)

@@ -159,7 +159,8 @@ void release_arrays(Workspace<T>* w)
 {
     void* ptrs[] = { w->y, w->rhs, w->cq, w->x, w->d, w->insup, w->pmax_val, w->pmax_idx,
                      w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->u1,
-                     w->u2, w->sgn, w->st, w->ndone, w->tile_skip };
+                     w->u2, w->sgn, w->st, w->ndone, w->tile_skip, w->gcache, w->slot_of, w->c0,
+                     w->tcand, w->sw_list };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     TraceEntry* tr = w->trace;
@@ -301,6 +302,69 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
     return ctx;
 }
 
+// ---- lookahead engine (fp32): Gram-column cache management and round launches -------------
+template <typename T> struct Lookahead {
+    static constexpr bool supported = false;
+    static void ensure(ss_hip_ctx*, Workspace<T>&, uint32_t) {}
+    static void init(ss_hip_ctx*, Workspace<T>&, uint32_t, T) {}
+    static void round(ss_hip_ctx*, Workspace<T>&, uint32_t, T, uint32_t) {}
+};
+
+template <> struct Lookahead<float> {
+    using T = float;
+    static constexpr bool supported = true;
+
+    static void ensure(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t kcap)
+    {
+        const uint32_t gpitch = (ctx->n_pad + 1023u) / 1024u * 1024u;
+        // every sweep caches up to 32 columns; a solve needs at most one sweep per inserted column
+        uint64_t want = 32ull * ((uint64_t)kcap + 2);
+        const uint64_t budget = (uint64_t)ctx->cache_mib << 20;
+        const uint64_t fit = std::max<uint64_t>(64, budget / ((uint64_t)gpitch * sizeof(T)));
+        if (want > fit) want = fit;
+        if (ws.gcache && ws.gcap >= want && ws.gpitch == gpitch) return;
+        void* olds[] = { ws.gcache, ws.slot_of, ws.c0, ws.tcand, ws.sw_list };
+        for (void* p : olds) if (p) HIPCHK(hipFree(p));
+        ws.gcache = nullptr; ws.slot_of = nullptr; ws.c0 = nullptr; ws.tcand = nullptr; ws.sw_list = nullptr;
+        ws.gcap = 0;
+        HIPCHK(hipMalloc(&ws.gcache, (size_t)want * gpitch * sizeof(T)));
+        HIPCHK(hipMalloc(&ws.slot_of, (size_t)ctx->n_pad * sizeof(int32_t)));
+        HIPCHK(hipMalloc(&ws.c0, (size_t)ctx->n_pad * sizeof(T)));
+        HIPCHK(hipMalloc(&ws.tcand, (size_t)ctx->n_pad * sizeof(T)));
+        HIPCHK(hipMalloc(&ws.sw_list, 64 * sizeof(uint32_t)));
+        ws.gcap = (uint32_t)want;
+        ws.gpitch = gpitch;
+    }
+
+    // c0 = A^T y has been swept into ws.c0 (partials in pmax): first pick, first lookahead sweep
+    static void init(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol)
+    {
+        hipStream_t st = ctx->stream;
+        HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // -1
+        HIPCHK(hipMemcpyAsync(ws.c, ws.c0, (size_t)ctx->n_pad * sizeof(T), hipMemcpyDeviceToDevice, st));
+        HIPCHK(launch_la_init_pick<T>(ctx, ws, nparts));
+        HIPCHK(launch_la_top<T>(ctx, ws, 1));
+        HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_la_update<T>(ctx, ws, 0, tol));
+        uint32_t np2 = 0;
+        HIPCHK(launch_la_cq<T>(ctx, ws, &np2));
+        ws.la_nparts = np2;
+    }
+
+    // one homotopy iteration: scan + select, (sweep if the entering column is not cached),
+    // inverse update + direction from the cache, Gram-form c and q
+    static void round(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t rnd, T tol, uint32_t max_iter)
+    {
+        HIPCHK(launch_la_scansel<T>(ctx, ws, rnd, ws.la_nparts, tol, max_iter));
+        HIPCHK(launch_la_top<T>(ctx, ws, 0));
+        HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_la_update<T>(ctx, ws, rnd, tol));
+        uint32_t np2 = 0;
+        HIPCHK(launch_la_cq<T>(ctx, ws, &np2));
+        ws.la_nparts = np2;
+    }
+};
+
 // copies a strided vector (host or device) into a contiguous device buffer
 template <typename T>
 void copy_in(ss_hip_ctx* ctx, T* dst_dev, const T* src, ptrdiff_t inc, size_t len)
@@ -390,7 +454,15 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         HIPCHK(hipMemcpyAsync(ws.rhs, ws.y, (size_t)ctx->ldm * sizeof(T), hipMemcpyDeviceToDevice, st));
         const size_t rhs_stride = (size_t)ws.dims.b_pad * ctx->ldm;   // r-block -> p-block
 
-        if (!omp) {
+        const bool la = !omp && Lookahead<T>::supported && ctx->engine == 1;
+        if (la) {
+            Lookahead<T>::ensure(ctx, ws, kcap);
+            uint32_t nb1 = 0;
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+            Lookahead<T>::init(ctx, ws, nb1, tol);
+        } else if (!omp) {
             // c = A^T y  (residual_vector with x = 0, homotopy-cpu.cpp:215)
             uint32_t nb1 = 0;
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
@@ -420,6 +492,10 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     std::this_thread::yield();
                 }
                 if (hf[1] != 0) break;
+            }
+            if (la) {
+                Lookahead<T>::round(ctx, ws, (uint32_t)round, tol, max_iter);
+                continue;
             }
             if (omp) {
                 // orthogonal matching pursuit round: c = A^T r (one right-hand side), pick,
@@ -469,6 +545,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
 
         ctx->stats.solves += 1;
         ctx->stats.iterations += hs.iter;
+        if (la) ctx->stats.lookahead_sweeps += hs.nsweeps;
         if (prof) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
@@ -720,6 +797,48 @@ int gemm_t_impl(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, float*
     return rc;
 }
 
+// G[s][:] = A^T a_{cols[s]} for up to 32 columns in one HBM-bound pass (lookahead sweep kernel)
+int gram_cols_impl(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, float* G, ptrdiff_t ldG, int repeats,
+                   float* ms_out, char* err, size_t errlen)
+{
+    if (!ctx || !cols || !G || S == 0 || S > 32) { set_err(err, errlen, "gram_cols: need 1..32 columns"); return SS_HIP_EINVAL; }
+    if (ctx->is_f64) { set_err(err, errlen, "gram_cols: fp32 contexts only"); return SS_HIP_ETYPE; }
+    for (size_t s = 0; s < S; ++s)
+        if (cols[s] >= ctx->n) { set_err(err, errlen, "gram_cols: column index out of range"); return SS_HIP_EINVAL; }
+    if (repeats < 1) repeats = 1;
+    uint32_t* dlist = nullptr;
+    float* Dd = nullptr;
+    int rc = SS_HIP_OK;
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        uint32_t h[64];
+        for (int s = 0; s < 32; ++s) {
+            h[s] = (size_t)s < S ? cols[s] : 0xffffffffu;
+            h[32 + s] = (size_t)s < S ? (uint32_t)s : 0xffffffffu;
+        }
+        const size_t np = ctx->n_pad;
+        HIPCHK(hipMalloc(&dlist, sizeof(h)));
+        HIPCHK(hipMalloc(&Dd, 32 * np * sizeof(float)));
+        HIPCHK(hipMemcpyAsync(dlist, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev_solve0, ctx->stream));
+        for (int i = 0; i < repeats; ++i)
+            HIPCHK(launch_gemm32_tn_f32(ctx, dlist, dlist + 32, Dd, (uint32_t)np, nullptr));
+        HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
+        HIPCHK(hipMemcpy2DAsync(G, (size_t)ldG * sizeof(float), Dd, np * sizeof(float), ctx->n * sizeof(float), S,
+                                hipMemcpyDefault, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
+        if (ms_out) *ms_out = ms / (float)repeats;
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        rc = SS_HIP_ERUNTIME;
+    }
+    if (dlist) (void)hipFree(dlist);
+    if (Dd) (void)hipFree(Dd);
+    return rc;
+}
+
 template <typename T>
 int reconstruct_impl(ss_hip_ctx* ctx, const T* x, T* y, char* err, size_t errlen)
 {
@@ -850,6 +969,12 @@ int ss_hip_gemm_t_f32(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, 
     return gemm_t_impl(ctx, R, B, ldR, C, ldC, repeats, ms_out, err, errlen);
 }
 
+int ss_hip_gram_cols_f32(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, float* G, ptrdiff_t ldG, int repeats,
+                         float* ms_out, char* err, size_t errlen)
+{
+    return gram_cols_impl(ctx, cols, S, G, ldG, repeats, ms_out, err, errlen);
+}
+
 int ss_hip_reconstruct_f32(ss_hip_ctx* ctx, const float* x, float* y, char* err, size_t errlen)
 {
     return reconstruct_impl<float>(ctx, x, y, err, errlen);
@@ -895,6 +1020,8 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "zero_on_removal")) { ctx->zero_on_removal = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
+    if (!std::strcmp(key, "engine"))        { ctx->engine = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "cache_mib"))     { ctx->cache_mib = std::max<long>(16, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { ctx->batch_chunk = (int)std::max<long>(4, value); return SS_HIP_OK; }
     return SS_HIP_EINVAL;
@@ -940,6 +1067,8 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
         }
         return SS_HIP_OK;
     }
+    if (!std::strcmp(key, "engine"))        { *value = ctx->engine; return SS_HIP_OK; }
+    if (!std::strcmp(key, "cache_mib"))     { *value = ctx->cache_mib; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { *value = ctx->batch_chunk; return SS_HIP_OK; }
     return SS_HIP_EINVAL;

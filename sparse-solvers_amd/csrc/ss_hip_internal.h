@@ -19,7 +19,7 @@ namespace sship {
 constexpr uint32_t kRowPad = 256;
 // Columns are padded (zero-filled) to a multiple of this so the sweep needs no tail code
 // and the MFMA GEMM of the batched path sees whole 128-column tiles.
-constexpr uint32_t kColPad = 128;
+constexpr uint32_t kColPad = 256;
 // Hard cap of the active-set capacity (workspace is 2 * Kcap^2 elements).
 constexpr uint32_t kKcapLimit = 4096;
 // Upper bound of workgroups any sweep variant launches (size of the partial-max arrays).
@@ -43,7 +43,11 @@ struct DevState {
     uint32_t done_round;  // round (1-based) in which `done` was raised
     double   c_inf;       // lambda = ||c||_inf (ss::homotopy_report::solution_error)
     double   gamma;       // step length of the current iteration
-    uint32_t pad0_[18];
+    // lookahead engine: Gram-column cache
+    uint32_t need_sweep;  // 1 when the column being inserted has no cached Gram column yet
+    uint32_t cache_used;  // cache slots handed out so far
+    uint32_t nsweeps;     // lookahead sweeps that did work in this solve
+    uint32_t pad0_[15];
     // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
     uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
     uint32_t pad1_[31];
@@ -101,6 +105,15 @@ struct Workspace {
     T* sgn = nullptr;             // [b_cap][kcap]
     DevState* st = nullptr;       // [b_cap]
     uint32_t* ndone = nullptr;    // number of slots that raised `done` in the current (batch) solve
+    // lookahead engine (fp32 single-signal): cache of Gram columns g_j = A^T a_j
+    T* gcache = nullptr;          // [gcap][n_pad]
+    uint32_t gcap = 0;
+    uint32_t gpitch = 0;          // row pitch of gcache in elements (n_pad rounded up to 1024)
+    int32_t* slot_of = nullptr;   // [n_pad] cache slot of a column, -1 = not cached
+    T* c0 = nullptr;              // [n_pad] A^T y
+    T* tcand = nullptr;           // [n_pad] per-column step-length candidate of the last scan
+    uint32_t* sw_list = nullptr;  // [64] rcols[32] then drows[32] of the next lookahead sweep
+    uint32_t la_nparts = 0;       // partial maxima written by the last k_la_cq launch
     uint32_t* tile_skip = nullptr; // [b_pad/128 + 1] compact list of GEMM row tiles with a running signal + count
     TraceEntry* trace = nullptr;  // [trace_cap] when tracing is on
     uint32_t trace_cap = 0;
@@ -132,6 +145,8 @@ struct ss_hip_ctx {
     int tie_guard = 1;
     int profiling = 0;
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
+    long cache_mib = 2048;   // budget of the lookahead engine's Gram-column cache
+    int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns), 0 = one fused sweep per iteration
     int batch_min = 4;       // batches of at least this many fp32 signals run in lock-step on the MFMA GEMM
     int batch_chunk = 4096;  // signals processed together by the batched path
     int tracing = 0;
@@ -177,6 +192,18 @@ hipError_t launch_tile_list(const ss_hip_ctx* ctx, const DevState* st, uint32_t 
 template <typename T>
 hipError_t launch_omp_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round,
                            uint32_t nparts, T tol, uint32_t max_iter);
+// lookahead engine launchers (activeset.hip); see homotopy.hip for the round structure
+template <typename T>
+hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts);
+template <typename T>
+hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode);
+template <typename T>
+hipError_t launch_la_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol);
+template <typename T>
+hipError_t launch_la_cq(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t* nparts_out);
+template <typename T>
+hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol,
+                             uint32_t max_iter);
 // per-slot partial (max |c|, first index) over chunks of the correlation rows (batched path)
 template <typename T>
 hipError_t launch_absmax(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t* nparts_out);
@@ -188,6 +215,12 @@ hipError_t launch_gemv_n(const ss_hip_ctx* ctx, const T* x_dev, T* y_dev);
 // null = all tiles): compact list of the row tiles to compute, count at tile_list[Mg/128].
 hipError_t launch_gemm_tn_f32(const ss_hip_ctx* ctx, const float* R, uint32_t Mg, uint32_t ldr,
                               float* D, uint32_t ldd, const uint32_t* tile_list);
+
+// D[drows[s]][:] = At · At[rcols[s]][:] for s < 32: 32 right-hand sides in one HBM-bound pass
+// (rcols / drows live on the device; 0xffffffff entries are skipped; with st != null the launch
+// is a no-op unless st->need_sweep is set and the solve is still running)
+hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
+                                float* D, uint32_t ldd, const DevState* st);
 
 // ---- helpers implemented in homotopy.hip ---------------------------------------
 void set_err(char* err, size_t errlen, const std::string& msg);
