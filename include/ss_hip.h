@@ -171,6 +171,9 @@ typedef struct ss_hip_stats {
     double   solve_ms;             /* HIP-event time of whole solves (upload of y .. x ready)  */
     uint64_t batch_rounds;         /* lock-step rounds run by the batched (MFMA) path          */
     uint64_t lookahead_sweeps;     /* 32-RHS lookahead sweeps run by the fp32 single-signal engine */
+    uint64_t sweep32_launches;     /* ... of which timed with HIP events (profiling on)         */
+    double   sweep32_ms;           /* sum of their durations                                    */
+    uint64_t sweep32_bytes;        /* algorithmic bytes of ONE lookahead sweep: m*n*s + 32*m*s + 32*n*s */
 } ss_hip_stats;
 
 /* profiling != 0: bracket every sweep launch with HIP events on the context's stream. */

@@ -290,6 +290,7 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
         const uint64_t s = sizeof(T);
         ctx->stats.sweep_bytes = (uint64_t)m * n * s + 2 * (uint64_t)m * s + 2 * (uint64_t)n * s;
         ctx->stats.sweep1_bytes = (uint64_t)m * n * s + (uint64_t)m * s + (uint64_t)n * s;
+        ctx->stats.sweep32_bytes = (uint64_t)m * n * s + 32 * (uint64_t)m * s + 32 * (uint64_t)n * s;
     } catch (const HipFail& f) {
         set_err(err, errlen, hip_msg(f));
         ss_hip_homotopy_destroy(ctx);
@@ -307,7 +308,7 @@ template <typename T> struct Lookahead {
     static constexpr bool supported = false;
     static void ensure(ss_hip_ctx*, Workspace<T>&, uint32_t) {}
     static void init(ss_hip_ctx*, Workspace<T>&, uint32_t, T) {}
-    static void round(ss_hip_ctx*, Workspace<T>&, uint32_t, T, uint32_t) {}
+    static void round(ss_hip_ctx*, Workspace<T>&, uint32_t, T, uint32_t, hipEvent_t = nullptr, hipEvent_t = nullptr) {}
 };
 
 template <> struct Lookahead<float> {
@@ -353,11 +354,14 @@ template <> struct Lookahead<float> {
 
     // one homotopy iteration: scan + select, (sweep if the entering column is not cached),
     // inverse update + direction from the cache, Gram-form c and q
-    static void round(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t rnd, T tol, uint32_t max_iter)
+    static void round(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t rnd, T tol, uint32_t max_iter,
+                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
     {
         HIPCHK(launch_la_scansel<T>(ctx, ws, rnd, ws.la_nparts, tol, max_iter));
         HIPCHK(launch_la_top<T>(ctx, ws, 0));
+        if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
         HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
         HIPCHK(launch_la_update<T>(ctx, ws, rnd, tol));
         uint32_t np2 = 0;
         HIPCHK(launch_la_cq<T>(ctx, ws, &np2));
@@ -494,7 +498,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 if (hf[1] != 0) break;
             }
             if (la) {
-                Lookahead<T>::round(ctx, ws, (uint32_t)round, tol, max_iter);
+                // the launch is a no-op unless a column without cached Gram column enters: time
+                // every `profile_every`-th launch and keep the ones that did work (see below)
+                const bool timed_la = prof && (round % (uint64_t)std::max(1, ctx->profile_every) == 0);
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (timed_la) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
+                Lookahead<T>::round(ctx, ws, (uint32_t)round, tol, max_iter, e0, e1);
+                if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
                 continue;
             }
             if (omp) {
@@ -556,6 +566,12 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 if (ctx->prof_kind[i] == 1) {
                     ctx->stats.sweep1_launches += 1;
                     ctx->stats.sweep1_ms += ms;
+                } else if (ctx->prof_kind[i] == 3) {
+                    // lookahead sweep: a launch that found nothing to do returns in microseconds
+                    if ((double)ctx->stats.sweep32_bytes / (ms * 1e-3) < 50e12) {   // < 50 TB/s: it streamed A
+                        ctx->stats.sweep32_launches += 1;
+                        ctx->stats.sweep32_ms += ms;
+                    }
                 } else if ((uint32_t)(ctx->prof_kind[i] - 16) <= hs.done_round) {
                     ctx->stats.sweep_launches += 1;
                     ctx->stats.sweep_ms += ms;
@@ -1002,10 +1018,11 @@ int ss_hip_get_stats(ss_hip_ctx* ctx, ss_hip_stats* out)
 int ss_hip_reset_stats(ss_hip_ctx* ctx)
 {
     if (!ctx) return SS_HIP_EINVAL;
-    const uint64_t b2 = ctx->stats.sweep_bytes, b1 = ctx->stats.sweep1_bytes;
+    const uint64_t b2 = ctx->stats.sweep_bytes, b1 = ctx->stats.sweep1_bytes, b32 = ctx->stats.sweep32_bytes;
     ctx->stats = ss_hip_stats{};
     ctx->stats.sweep_bytes = b2;
     ctx->stats.sweep1_bytes = b1;
+    ctx->stats.sweep32_bytes = b32;
     return SS_HIP_OK;
 }
 

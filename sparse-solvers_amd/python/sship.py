@@ -45,6 +45,9 @@ class Stats(ctypes.Structure):
         ("solve_ms", ctypes.c_double),
         ("batch_rounds", ctypes.c_uint64),
         ("lookahead_sweeps", ctypes.c_uint64),
+        ("sweep32_launches", ctypes.c_uint64),
+        ("sweep32_ms", ctypes.c_double),
+        ("sweep32_bytes", ctypes.c_uint64),
     ]
 
 

@@ -23,8 +23,14 @@ def short(name):
     return name.split("(")[0]
 
 
+KERNEL_KEY = "k_gemm32_tn_f32"      # dominant kernel whose traffic is priced (argv[2] overrides)
+
+
 def main():
+    global KERNEL_KEY
     tag = sys.argv[1]
+    if len(sys.argv) > 2:
+        KERNEL_KEY = sys.argv[2]
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -48,7 +54,7 @@ def main():
         kern = {}
         for n, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
             # launches enqueued after the device raised `done` return at once (a few us)
-            work = [x for x in v if x > 20000] if "k_sweep" in n else v
+            work = [x for x in v if x > 20000] if ("k_sweep" in n or "k_gemm32" in n) else v
             kern[n] = {"launches": len(v), "mean_us_all": sum(v) / len(v) / 1e3,
                        "working": len(work), "mean_us_working": sum(work) / max(1, len(work)) / 1e3}
             lines.append("| `%s` | %d | %.2f | %d | %.2f |" % (n, len(v), kern[n]["mean_us_all"],
@@ -63,7 +69,7 @@ def main():
             continue
         rows = list(csv.DictReader(open(f[0])))
         vals = [float(r["Counter_Value"]) for r in rows
-                if "k_sweep<float, 2" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                if KERNEL_KEY in r["Kernel_Name"] and r["Counter_Name"] == counter]
         # drop the no-op launches (solve already finished): they move (almost) nothing
         thresh = 0.5 * max(vals) if vals else 0
         vals = [v for v in vals if v >= thresh]
@@ -72,19 +78,24 @@ def main():
     if traffic:
         rd = traffic.get("FETCH_SIZE", {}).get("mean_raw_KiB", 0.0) * 1024 * 2
         wr = traffic.get("WRITE_SIZE", {}).get("mean_raw_KiB", 0.0) * 1024
-        out["sweep2_hbm_read_bytes_per_launch"] = rd
-        out["sweep2_hbm_write_bytes_per_launch"] = wr
-        out["sweep2_hbm_bytes_per_launch"] = rd + wr
+        key = "gemm32" if "gemm32" in KERNEL_KEY else "sweep2"
+        out[key + "_hbm_read_bytes_per_launch"] = rd
+        out[key + "_hbm_write_bytes_per_launch"] = wr
+        out[key + "_hbm_bytes_per_launch"] = rd + wr
         out["pmc_raw"] = traffic
-        alg = 8192 * 65536 * 4 + 2 * 8192 * 4 + 2 * 65536 * 4
-        lines += ["## HBM traffic of the fused sweep (PMC, separate passes)", "",
+        nrhs = 32 if key == "gemm32" else 2
+        alg = 8192 * 65536 * 4 + nrhs * 8192 * 4 + nrhs * 65536 * 4
+        lines += ["## HBM traffic of `%s` (PMC, separate passes)" % KERNEL_KEY, "",
                   "- FETCH_SIZE mean %.1f KiB x 1024 x 2 (gfx950 correction) = %.0f B read" % (
                       traffic.get("FETCH_SIZE", {}).get("mean_raw_KiB", 0.0), rd),
                   "- WRITE_SIZE mean %.1f KiB x 1024 = %.0f B written" % (
                       traffic.get("WRITE_SIZE", {}).get("mean_raw_KiB", 0.0), wr),
                   "- algorithmic bytes per launch: %d; traffic / algorithmic = %.4f" % (alg, (rd + wr) / alg), ""]
-        json.dump({"sweep2_hbm_bytes_per_launch": rd + wr, "source": "profiles/%s_summary.md" % tag,
-                   "read": rd, "write": wr}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+        tpath = os.path.join(dst, "traffic.json")
+        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        tj[key + "_hbm_bytes_per_launch"] = rd + wr
+        tj[key + "_source"] = "profiles/%s_summary.md" % tag
+        json.dump(tj, open(tpath, "w"), indent=1)
     log = os.path.join(src, "bench_trace.log")
     if os.path.exists(log):
         for ln in open(log):
