@@ -25,6 +25,7 @@
 // like the reference's scalar code.
 #include "ss_hip_internal.h"
 
+#include <algorithm>
 #include <cfloat>
 
 namespace sship {
@@ -317,6 +318,137 @@ __device__ __forceinline__ void signal_done(uint32_t* hflags, uint32_t* ndone, u
     }
 }
 
+// ---- select_toggle: the serial end of find_max_gamma + inverse_add_or_remove's index part, run
+// ---- by ONE workgroup once every workgroup's (min gamma, idx) partial is visible: final pick,
+// ---- support toggle, x update.  Returns false when the solve terminated here (done raised).
+template <typename T>
+__device__ __forceinline__ bool select_toggle(uint32_t round, T c_inf, uint32_t ns,
+                                              const T* pmin_val, const uint32_t* pmin_idx,
+                                              T* __restrict__ x, const T* __restrict__ d, uint8_t* __restrict__ insup,
+                                              uint32_t* __restrict__ gam2, uint32_t* __restrict__ touched2, uint32_t kcap,
+                                              DevState* st, uint32_t* hflags, bool post_round,
+                                              TraceEntry* trace, uint32_t trace_cap, int zero_on_removal,
+                                              uint32_t* ndone, uint32_t nslots, const int32_t* __restrict__ slot_of,
+                                              T* sv, uint32_t* si, uint32_t* s_cnt,
+                                              uint32_t* o_idx = nullptr, uint32_t* o_rank = nullptr,
+                                              uint32_t* o_added = nullptr, uint32_t* o_knew = nullptr, T* o_gamma = nullptr)
+{
+    // ---- last workgroup: final (gamma, idx) of find_max_gamma: smallest positive
+    // candidate, left-most index; (T_MAX, 0) when there is none (homotopy-cpu.cpp:123-124)
+        T g = Lim<T>::max();
+    uint32_t idx = 0xffffffffu;
+    for (uint32_t b = threadIdx.x; b < ns; b += blockDim.x) {
+        const T ov = pmin_val[b];
+        const uint32_t oi = pmin_idx[b];
+        if (better_min(ov, oi, g, idx)) { g = ov; idx = oi; }
+    }
+    block_reduce_pair<T, false>(g, idx, sv, si);
+    if (!(g < Lim<T>::max())) idx = 0;
+
+    const uint32_t cur = st->cur;
+    const uint32_t K = st->K;
+    const uint32_t nt = st->ntouched;
+    const uint32_t* gam = gam2 + (size_t)cur * kcap;
+    uint32_t* gam_new = gam2 + (size_t)(cur ^ 1u) * kcap;
+    const uint32_t* tch = touched2 + (size_t)cur * kcap;
+    uint32_t* tch_new = touched2 + (size_t)(cur ^ 1u) * kcap;
+    const bool added = insup[idx] == 0;
+
+    // rank of idx in the sorted support / touched list (rank_index.h:65-83)
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t lr = 0, lt = 0;
+    for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) lr += (gam[j] < idx) ? 1u : 0u;
+    for (uint32_t j = threadIdx.x; j < nt; j += blockDim.x) lt += (tch[j] < idx) ? 1u : 0u;
+    if (lr) atomicAdd(&s_cnt[0], lr);
+    if (lt) atomicAdd(&s_cnt[1], lt);
+    __syncthreads();
+    const uint32_t rank = s_cnt[0];
+    const uint32_t trank = s_cnt[1];
+    const uint32_t K_new = added ? K + 1 : K - 1;
+
+    if (trace != nullptr && threadIdx.x == 0 && round < trace_cap) {
+        trace[round].idx = idx;
+        trace[round].added = added ? 1u : 0u;
+        trace[round].gamma = (double)g;
+        trace[round].c_inf = (double)c_inf;
+    }
+
+    if (K_new == 0 || K_new > kcap) {
+        // K_new == 0: homotopy-cpu.cpp:248-249, the support became empty -> break before x
+        // is updated; the report carries the c_inf of the previous iteration's end.
+        // K_new > kcap: workspace exhausted.
+        if (threadIdx.x == 0) {
+            if (K_new == 0) {
+                insup[idx] = 0;
+                st->K = 0;
+                st->idx = idx;
+                st->rank = rank;
+                st->added = 0;
+                st->gamma = (double)g;
+                st->iter = round;
+            } else {
+                st->status = SS_HIP_ECAPACITY;
+                st->iter = round - 1;
+            }
+            st->c_inf = (double)c_inf;
+            st->done_round = round;
+            st->need_sweep = 0;
+            st->done = 1;
+            signal_done(hflags, ndone, nslots, round);
+        }
+        return false;
+    }
+
+    // x += gamma * direction over the OLD support (homotopy-cpu.cpp:252; d is zero elsewhere).
+    // The column that leaves the support lands on x + (-x/d)*d, i.e. 0 up to an ulp; the
+    // reference keeps that residue, and a residue of the wrong sign makes a later re-insertion
+    // of the column bounce straight out again (gamma ~ 1e-18 steps).  By default the entry is
+    // set to exactly 0 (option "zero_on_removal" = 0 restores the reference's residue).
+    for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) {
+        const uint32_t col = gam[j];
+        const T xn = x[col] + g * d[col];
+        x[col] = (!added && zero_on_removal && col == idx) ? T(0) : xn;
+    }
+
+    // new sorted support, written out of place
+    if (added) {
+        for (uint32_t j = threadIdx.x; j < K_new; j += blockDim.x)
+            gam_new[j] = (j < rank) ? gam[j] : (j == rank ? idx : gam[j - 1]);
+    } else {
+        for (uint32_t j = threadIdx.x; j < K_new; j += blockDim.x)
+            gam_new[j] = gam[j + (j >= rank ? 1u : 0u)];
+    }
+    // touched list: sorted union of every support so far
+    const bool seen = (trank < nt) && (tch[trank] == idx);
+    const uint32_t nt_new = (added && !seen) ? nt + 1 : nt;
+    if (added && !seen) {
+        for (uint32_t j = threadIdx.x; j < nt_new; j += blockDim.x)
+            tch_new[j] = (j < trank) ? tch[j] : (j == trank ? idx : tch[j - 1]);
+    } else {
+        for (uint32_t j = threadIdx.x; j < nt_new; j += blockDim.x) tch_new[j] = tch[j];
+    }
+
+    if (threadIdx.x == 0) {
+        insup[idx] = added ? 1 : 0;
+        st->K = K_new;
+        st->ntouched = nt_new;
+        st->idx = idx;
+        st->rank = rank;
+        st->added = added ? 1u : 0u;
+        st->gamma = (double)g;
+        st->c_inf = (double)c_inf;
+        st->iter = round;
+        // lookahead engine: the inserted column needs its Gram column; sweep only if not cached
+        st->need_sweep = (slot_of != nullptr && added && slot_of[idx] < 0) ? 1u : 0u;
+        if (hflags && post_round) __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // the same values in registers, for a caller that goes on in this launch (DevState fields
+    // are read through the scalar cache, which does not see this launch's vector stores)
+    if (o_idx) { *o_idx = idx; *o_rank = rank; *o_added = added ? 1u : 0u; *o_knew = K_new; *o_gamma = g; }
+    return true;
+}
+
 // ---- k_scansel: find_max_gamma's scan (homotopy-cpu.cpp:122-163) in every workgroup,
 // ---- then loop control, pick, support toggle and x update in the last one to arrive ----
 constexpr int kScanPerThread = 4;
@@ -412,117 +544,8 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
     }
     if (!arrive_last(&st->ticket_scan, gridDim.x, &s_flag)) return;
 
-    // ---- last workgroup: final (gamma, idx) of find_max_gamma: smallest positive
-    // candidate, left-most index; (T_MAX, 0) when there is none (homotopy-cpu.cpp:123-124)
-    const uint32_t ns = gridDim.x;
-    T g = Lim<T>::max();
-    uint32_t idx = 0xffffffffu;
-    for (uint32_t b = threadIdx.x; b < ns; b += blockDim.x) {
-        const T ov = pmin_val[b];
-        const uint32_t oi = pmin_idx[b];
-        if (better_min(ov, oi, g, idx)) { g = ov; idx = oi; }
-    }
-    block_reduce_pair<T, false>(g, idx, sv, si);
-    if (!(g < Lim<T>::max())) idx = 0;
-
-    const uint32_t cur = st->cur;
-    const uint32_t K = st->K;
-    const uint32_t nt = st->ntouched;
-    const uint32_t* gam = gam2 + (size_t)cur * kcap;
-    uint32_t* gam_new = gam2 + (size_t)(cur ^ 1u) * kcap;
-    const uint32_t* tch = touched2 + (size_t)cur * kcap;
-    uint32_t* tch_new = touched2 + (size_t)(cur ^ 1u) * kcap;
-    const bool added = insup[idx] == 0;
-
-    // rank of idx in the sorted support / touched list (rank_index.h:65-83)
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t lr = 0, lt = 0;
-    for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) lr += (gam[j] < idx) ? 1u : 0u;
-    for (uint32_t j = threadIdx.x; j < nt; j += blockDim.x) lt += (tch[j] < idx) ? 1u : 0u;
-    if (lr) atomicAdd(&s_cnt[0], lr);
-    if (lt) atomicAdd(&s_cnt[1], lt);
-    __syncthreads();
-    const uint32_t rank = s_cnt[0];
-    const uint32_t trank = s_cnt[1];
-    const uint32_t K_new = added ? K + 1 : K - 1;
-
-    if (trace != nullptr && threadIdx.x == 0 && round < trace_cap) {
-        trace[round].idx = idx;
-        trace[round].added = added ? 1u : 0u;
-        trace[round].gamma = (double)g;
-        trace[round].c_inf = (double)c_inf;
-    }
-
-    if (K_new == 0 || K_new > kcap) {
-        // K_new == 0: homotopy-cpu.cpp:248-249, the support became empty -> break before x
-        // is updated; the report carries the c_inf of the previous iteration's end.
-        // K_new > kcap: workspace exhausted.
-        if (threadIdx.x == 0) {
-            if (K_new == 0) {
-                insup[idx] = 0;
-                st->K = 0;
-                st->idx = idx;
-                st->rank = rank;
-                st->added = 0;
-                st->gamma = (double)g;
-                st->iter = round;
-            } else {
-                st->status = SS_HIP_ECAPACITY;
-                st->iter = round - 1;
-            }
-            st->c_inf = (double)c_inf;
-            st->done_round = round;
-            st->need_sweep = 0;
-            st->done = 1;
-            signal_done(hflags, ndone, nslots, round);
-        }
-        return;
-    }
-
-    // x += gamma * direction over the OLD support (homotopy-cpu.cpp:252; d is zero elsewhere).
-    // The column that leaves the support lands on x + (-x/d)*d, i.e. 0 up to an ulp; the
-    // reference keeps that residue, and a residue of the wrong sign makes a later re-insertion
-    // of the column bounce straight out again (gamma ~ 1e-18 steps).  By default the entry is
-    // set to exactly 0 (option "zero_on_removal" = 0 restores the reference's residue).
-    for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) {
-        const uint32_t col = gam[j];
-        const T xn = x[col] + g * d[col];
-        x[col] = (!added && zero_on_removal && col == idx) ? T(0) : xn;
-    }
-
-    // new sorted support, written out of place
-    if (added) {
-        for (uint32_t j = threadIdx.x; j < K_new; j += blockDim.x)
-            gam_new[j] = (j < rank) ? gam[j] : (j == rank ? idx : gam[j - 1]);
-    } else {
-        for (uint32_t j = threadIdx.x; j < K_new; j += blockDim.x)
-            gam_new[j] = gam[j + (j >= rank ? 1u : 0u)];
-    }
-    // touched list: sorted union of every support so far
-    const bool seen = (trank < nt) && (tch[trank] == idx);
-    const uint32_t nt_new = (added && !seen) ? nt + 1 : nt;
-    if (added && !seen) {
-        for (uint32_t j = threadIdx.x; j < nt_new; j += blockDim.x)
-            tch_new[j] = (j < trank) ? tch[j] : (j == trank ? idx : tch[j - 1]);
-    } else {
-        for (uint32_t j = threadIdx.x; j < nt_new; j += blockDim.x) tch_new[j] = tch[j];
-    }
-
-    if (threadIdx.x == 0) {
-        insup[idx] = added ? 1 : 0;
-        st->K = K_new;
-        st->ntouched = nt_new;
-        st->idx = idx;
-        st->rank = rank;
-        st->added = added ? 1u : 0u;
-        st->gamma = (double)g;
-        st->c_inf = (double)c_inf;
-        st->iter = round;
-        // lookahead engine: the inserted column needs its Gram column; sweep only if not cached
-        st->need_sweep = (slot_of != nullptr && added && slot_of[idx] < 0) ? 1u : 0u;
-        if (hflags) __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    select_toggle<T>(round, c_inf, gridDim.x, pmin_val, pmin_idx, x, d, insup, gam2, touched2, kcap, st, hflags,
+                     true, trace, trace_cap, zero_on_removal, ndone, nslots, slot_of, sv, si, s_cnt);
 }
 
 // =========================================================================================
@@ -776,6 +799,123 @@ void k_omp_select(uint32_t round, T tol, uint32_t max_iter,
     }
 }
 
+// ---- update_direction: online_column_inverse's bordering / deflation (online_inverse.h:224-248,
+// ---- 275-290) and the new direction (homotopy-cpu.cpp:257-267), run by ONE workgroup once u1 and
+// ---- st->dot are visible.
+template <typename T>
+__device__ __forceinline__ void update_direction(uint32_t cur, uint32_t K_new, uint32_t rank, bool added,
+                                                 const uint32_t* __restrict__ gam_old, const uint32_t* __restrict__ gam_new,
+                                                 T* inv0, T* inv1, T* u1, T* u2, T* sgn,
+                                                 const T* __restrict__ c, const T* __restrict__ q, T* __restrict__ d,
+                                                 T tol, DevState* st, int omp, T* __restrict__ x, int first, int strict_sign,
+                                                 uint32_t kcap, T* sv, T* s_dp, T g)
+{
+    T& s_d = *s_dp;
+    // ---- last workgroup --------------------------------------------------------------
+    const T* Iold = cur ? inv1 : inv0;
+    T* Inew = cur ? inv0 : inv1;
+    const uint32_t K_old = added ? K_new - 1 : K_new + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NW = (int)(blockDim.x >> 6);
+    const size_t P = kcap;
+
+    if (added) {
+        const uint32_t nn = K_old;
+        // u2 = inv * u1 (online_inverse.h:224-225), one wave per row
+        for (uint32_t i = wave; i < nn; i += NW) {
+            T acc = T(0);
+            for (uint32_t j = lane; j < nn; j += 64) acc += Iold[i * P + j] * u1[j];
+            acc = wave_sum(acc);
+            if (lane == 0) u2[i] = acc;
+        }
+        __syncthreads();
+        // d = 1 / (dot - u1.u2) (online_inverse.h:228)
+        T part = T(0);
+        for (uint32_t j = threadIdx.x; j < nn; j += blockDim.x) part += u1[j] * u2[j];
+        const T s = block_sum(part, sv);
+        if (threadIdx.x == 0) {
+            const T dotv = (T)load_handoff(&st->dot);
+            if (nn == 0) {
+                // first column: inv = [1 / ||col||^2] through the norm (online_inverse.h:193-201)
+                const T nrm = sqrt(dotv);
+                s_d = T(1) / (nrm * nrm);
+            } else {
+                s_d = T(1) / (dotv - s);
+            }
+        }
+        __syncthreads();
+        const T dv = s_d;
+        // new inverse in sorted order: [inv + d u2 u2^T, -d u2; -d u2^T, d] with the new
+        // row/column at position `rank` (online_inverse.h:229-248)
+        const uint32_t tot = K_new * K_new;
+        for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
+            const uint32_t a = e / K_new, b = e - a * K_new;
+            T v;
+            if (a == rank && b == rank) {
+                v = dv;
+            } else if (a == rank) {
+                v = -dv * u2[b - (b > rank ? 1u : 0u)];
+            } else if (b == rank) {
+                v = -dv * u2[a - (a > rank ? 1u : 0u)];
+            } else {
+                const uint32_t oa = a - (a > rank ? 1u : 0u), ob = b - (b > rank ? 1u : 0u);
+                v = Iold[oa * P + ob] + (dv * u2[oa]) * u2[ob];
+            }
+            Inew[a * P + b] = v;
+        }
+    } else {
+        // remove row/column `rank` (online_inverse.h:275-290)
+        const uint32_t nn = K_old;
+        const T dd = Iold[rank * P + rank];
+        const T sc = -(T(1) / dd);
+        for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) u2[i] = Iold[i * P + rank] * sc;
+        __syncthreads();
+        const uint32_t tot = K_new * K_new;
+        for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
+            const uint32_t a = e / K_new, b = e - a * K_new;
+            const uint32_t oa = a + (a >= rank ? 1u : 0u), ob = b + (b >= rank ? 1u : 0u);
+            Inew[a * P + b] = Iold[oa * P + ob] + (-dd * u2[oa]) * u2[ob];
+        }
+    }
+
+    if (omp) {
+        // orthogonal matching pursuit: x_S = (A_S^T A_S)^-1 A_S^T y, written to its columns
+        __syncthreads();
+        for (uint32_t a = wave; a < K_new; a += NW) {
+            T acc = T(0);
+            for (uint32_t b = lane; b < K_new; b += 64) acc += Inew[a * P + b] * sgn[b];
+            acc = wave_sum(acc);
+            if (lane == 0) x[gam_new[a]] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) st->cur = cur ^ 1u;
+        return;
+    }
+
+    // sign(c[Gamma]) with dead zone tol (homotopy-cpu.cpp:259-260).  The correlations after
+    // the step are c - gamma*q (c_new = A^T(y - A(x + gamma d)) = c - gamma A^T A d); only
+    // their sign is used here, the next sweep recomputes c itself from r.
+    for (uint32_t a = threadIdx.x; a < K_new; a += blockDim.x) {
+        const uint32_t col = gam_new[a];
+        T cn = c[col] - g * q[col];
+        // first-step quirk (homotopy-cpu.cpp:223-227): the seed is sign(|c[idx]|) = +1
+        if (first) cn = strict_sign ? c[col] : (c[col] < T(0) ? -c[col] : c[col]);
+        sgn[a] = sign_tol(cn, tol);
+    }
+    // clear the old direction
+    for (uint32_t j = threadIdx.x; j < K_old; j += blockDim.x) d[gam_old[j]] = T(0);
+    __syncthreads();
+    // direction = inv * sign (homotopy-cpu.cpp:263), scattered to its columns (:266)
+    for (uint32_t a = wave; a < K_new; a += NW) {
+        T acc = T(0);
+        for (uint32_t b = lane; b < K_new; b += 64) acc += Inew[a * P + b] * sgn[b];
+        acc = wave_sum(acc);
+        if (lane == 0) d[gam_new[a]] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st->cur = cur ^ 1u;
+}
+
 // ---- k_gramupd: u1 = A_S^T a_idx and a_idx . a_idx (online_inverse.h:209-218), one
 // ---- workgroup per active column; the last to arrive borders / deflates
 // ---- (A_S^T A_S)^-1 (online_inverse.h:224-248, 275-290) and forms the new direction
@@ -860,110 +1000,261 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
     }
     if (gcache == nullptr && !arrive_last(&st->ticket_gram, gridDim.x, &s_flag)) return;
 
-    // ---- last workgroup --------------------------------------------------------------
-    const T* Iold = cur ? inv1 : inv0;
-    T* Inew = cur ? inv0 : inv1;
-    const uint32_t K_old = added ? K_new - 1 : K_new + 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = kUpdThreads / 64;
-    const size_t P = kcap;
+    update_direction<T>(cur, K_new, rank, added, gam_old, gam_new, inv0, inv1, u1, u2, sgn, c, q, d, tol, st, omp, x,
+                        first, strict_sign, kcap, sv, &s_d, (T)st->gamma);
+    // lookahead engine: the entering column's Gram column has arrived and been used
+    if (gcache != nullptr && threadIdx.x == 0) st->need_sweep = 0;
+}
 
-    if (added) {
-        const uint32_t nn = K_old;
-        // u2 = inv * u1 (online_inverse.h:224-225), one wave per row
-        for (uint32_t i = wave; i < nn; i += NW) {
-            T acc = T(0);
-            for (uint32_t j = lane; j < nn; j += 64) acc += Iold[i * P + j] * u1[j];
-            acc = wave_sum(acc);
-            if (lane == 0) u2[i] = acc;
+// ---- k_la_iter: one whole iteration of the lookahead engine in ONE launch --------------------
+//   phase 1 (every workgroup)  c = c0 - sum_j x_j g_j, q = sum_j d_j g_j over its columns, max |c|
+//   grid barrier               lambda = ||c||_inf needs every workgroup's maximum
+//   phase 2 (every workgroup)  find_max_gamma's scan over its columns        (homotopy-cpu.cpp:122-163)
+//   last workgroup to arrive   pick, support toggle, x update; then, if the entering column's Gram
+//                              column is cached, the inverse update and the new direction.  If it is
+//                              not, need_sweep is raised (mirrored to the host, which enqueues
+//                              k_la_top + the lookahead sweep + k_gramupd) and later k_la_iter
+//                              launches are no-ops until that update has run.
+// Every launch, working or not, bumps DevState::seq and mirrors it to hflags[0] so that the host
+// can keep a fixed number of launches queued ahead of the device.
+constexpr int kItThreads = 256;
+constexpr int kItCols = 2;                               // columns per thread and pass
+constexpr uint32_t kItChunk = kItThreads * kItCols;
+constexpr uint32_t kItMaxBlocks = 256;                   // all resident at once on any gfx950 part
+
+// Grid barrier.  Safe because every workgroup of the launch is resident (<= 256 workgroups of 256
+// threads, tiny LDS); arrivals are counted monotonically over the solve (target = round * grid).
+// The spin is bounded: on expiry the caller abandons the solve instead of hanging the queue.
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target, uint32_t* s_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t ok = 0;
+        for (uint32_t spin = 0; spin < (1u << 21); ++spin) {
+            if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
         }
-        __syncthreads();
-        // d = 1 / (dot - u1.u2) (online_inverse.h:228)
-        T part = T(0);
-        for (uint32_t j = threadIdx.x; j < nn; j += blockDim.x) part += u1[j] * u2[j];
-        const T s = block_sum(part, sv);
-        if (threadIdx.x == 0) {
-            const T dotv = (T)load_handoff(&st->dot);
-            if (nn == 0) {
-                // first column: inv = [1 / ||col||^2] through the norm (online_inverse.h:193-201)
-                const T nrm = sqrt(dotv);
-                s_d = T(1) / (nrm * nrm);
-            } else {
-                s_d = T(1) / (dotv - s);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *s_flag = ok;
+    }
+    __syncthreads();
+    return *s_flag != 0u;
+}
+
+__device__ __forceinline__ void bump_seq(DevState* st, uint32_t* hflags)
+{
+    const uint32_t sq = st->seq + 1u;
+    st->seq = sq;
+    __hip_atomic_store(&hflags[0], sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kItThreads)
+void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
+               const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, const T* __restrict__ c0,
+               uint32_t gpitch, T* c, T* q, T* x, T* d, uint8_t* insup,
+               T* pmax_val, uint32_t* pmax_idx, T* pmin_val, uint32_t* pmin_idx,
+               uint32_t* gam2, uint32_t* touched2, T* inv0, T* inv1, T* u1, T* u2, T* sgn,
+               T* __restrict__ tcand, SlotDims L, DevState* st, uint32_t* hflags,
+               TraceEntry* trace, uint32_t trace_cap, int zero_on_removal, int tie_guard, uint64_t* dbg)
+{
+    uint64_t ts[8];
+    ts[0] = wall_clock64();
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_flag;
+    __shared__ T s_dd;
+    __shared__ uint32_t s_slot[kCqTile];
+    __shared__ T s_x[kCqTile];
+    __shared__ T s_dv[kCqTile];
+    const uint32_t kcap = L.kcap;
+    const uint32_t tid = threadIdx.x;
+
+    if (st->done || st->need_sweep) {            // finished, or waiting for a lookahead sweep
+        if (blockIdx.x == 0 && tid == 0) bump_seq(st, hflags);
+        return;
+    }
+    const uint32_t round = st->iter + 1u;
+    const uint32_t cur0 = st->cur;
+    // columns with a non-zero x or d: the support when leaving columns are zeroed exactly
+    // (their terms would add exact zeros), every column ever touched otherwise
+    const uint32_t nt = zero_on_removal ? st->K : st->ntouched;
+    const uint32_t* touched = (zero_on_removal ? gam2 : touched2) + (size_t)cur0 * kcap;
+
+    // ---- phase 1: Gram-form correlations --------------------------------------------------
+    T bv = T(-1);
+    uint32_t bi = 0xffffffffu;
+    for (uint32_t base = blockIdx.x * kItChunk; base < n; base += gridDim.x * kItChunk) {
+        const T* gbase = gcache + base + tid;            // gpitch % 1024 == 0: rows never run out
+        T ax[kItCols], ad[kItCols];
+#pragma unroll
+        for (int k = 0; k < kItCols; ++k) { ax[k] = T(0); ad[k] = T(0); }
+        for (uint32_t j0 = 0; j0 < nt; j0 += kCqTile) {
+            const uint32_t cnt = (nt - j0 < kCqTile) ? (nt - j0) : kCqTile;
+            __syncthreads();
+            if (tid < cnt) {
+                const uint32_t col = touched[j0 + tid];
+                s_slot[tid] = (uint32_t)slot_of[col];
+                s_x[tid] = x[col];
+                s_dv[tid] = d[col];
+            }
+            __syncthreads();
+            uint32_t j = 0;
+            for (; j + 8 <= cnt; j += 8) {
+                T gv[8][kItCols];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const T* g = gbase + (size_t)s_slot[j + u] * gpitch;
+#pragma unroll
+                    for (int k = 0; k < kItCols; ++k) gv[u][k] = g[k * kItThreads];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const T xj = s_x[j + u], dj = s_dv[j + u];
+#pragma unroll
+                    for (int k = 0; k < kItCols; ++k) { ax[k] += xj * gv[u][k]; ad[k] += dj * gv[u][k]; }
+                }
+            }
+            for (; j < cnt; ++j) {
+                const T* g = gbase + (size_t)s_slot[j] * gpitch;
+                const T xj = s_x[j], dj = s_dv[j];
+#pragma unroll
+                for (int k = 0; k < kItCols; ++k) { const T gvv = g[k * kItThreads]; ax[k] += xj * gvv; ad[k] += dj * gvv; }
             }
         }
-        __syncthreads();
-        const T dv = s_d;
-        // new inverse in sorted order: [inv + d u2 u2^T, -d u2; -d u2^T, d] with the new
-        // row/column at position `rank` (online_inverse.h:229-248)
-        const uint32_t tot = K_new * K_new;
-        for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
-            const uint32_t a = e / K_new, b = e - a * K_new;
-            T v;
-            if (a == rank && b == rank) {
-                v = dv;
-            } else if (a == rank) {
-                v = -dv * u2[b - (b > rank ? 1u : 0u)];
-            } else if (b == rank) {
-                v = -dv * u2[a - (a > rank ? 1u : 0u)];
-            } else {
-                const uint32_t oa = a - (a > rank ? 1u : 0u), ob = b - (b > rank ? 1u : 0u);
-                v = Iold[oa * P + ob] + (dv * u2[oa]) * u2[ob];
+#pragma unroll
+        for (int k = 0; k < kItCols; ++k) {
+            const uint32_t i = base + k * kItThreads + tid;
+            if (i < n) {
+                const T cv = c0[i] - ax[k];
+                c[i] = cv;
+                q[i] = ad[k];
+                const T a = cv < T(0) ? -cv : cv;
+                if (better_max(a, i, bv, bi)) { bv = a; bi = i; }
             }
-            Inew[a * P + b] = v;
-        }
-    } else {
-        // remove row/column `rank` (online_inverse.h:275-290)
-        const uint32_t nn = K_old;
-        const T dd = Iold[rank * P + rank];
-        const T sc = -(T(1) / dd);
-        for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) u2[i] = Iold[i * P + rank] * sc;
-        __syncthreads();
-        const uint32_t tot = K_new * K_new;
-        for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
-            const uint32_t a = e / K_new, b = e - a * K_new;
-            const uint32_t oa = a + (a >= rank ? 1u : 0u), ob = b + (b >= rank ? 1u : 0u);
-            Inew[a * P + b] = Iold[oa * P + ob] + (-dd * u2[oa]) * u2[ob];
         }
     }
+    block_reduce_pair<T, true>(bv, bi, sv, si);
+    if (tid == 0) { pmax_val[blockIdx.x] = bv; pmax_idx[blockIdx.x] = bi; }
+    ts[1] = wall_clock64();
 
-    if (omp) {
-        // orthogonal matching pursuit: x_S = (A_S^T A_S)^-1 A_S^T y, written to its columns
-        __syncthreads();
-        for (uint32_t a = wave; a < K_new; a += NW) {
-            T acc = T(0);
-            for (uint32_t b = lane; b < K_new; b += 64) acc += Inew[a * P + b] * sgn[b];
-            acc = wave_sum(acc);
-            if (lane == 0) x[gam_new[a]] = acc;
+    if (!grid_barrier(&st->bar_count, round * gridDim.x, &s_flag)) {
+        if (blockIdx.x == 0 && tid == 0) {               // cannot happen with a resident grid
+            st->status = SS_HIP_ERUNTIME;
+            st->done = 1;
+            signal_done(hflags, nullptr, 1u, round);
         }
-        __syncthreads();
-        if (threadIdx.x == 0) st->cur = cur ^ 1u;
         return;
     }
 
-    // sign(c[Gamma]) with dead zone tol (homotopy-cpu.cpp:259-260).  The correlations after
-    // the step are c - gamma*q (c_new = A^T(y - A(x + gamma d)) = c - gamma A^T A d); only
-    // their sign is used here, the next sweep recomputes c itself from r.
-    const T g = (T)st->gamma;
-    for (uint32_t a = threadIdx.x; a < K_new; a += blockDim.x) {
-        const uint32_t col = gam_new[a];
-        T cn = c[col] - g * q[col];
-        // first-step quirk (homotopy-cpu.cpp:223-227): the seed is sign(|c[idx]|) = +1
-        if (first) cn = strict_sign ? c[col] : (c[col] < T(0) ? -c[col] : c[col]);
-        sgn[a] = sign_tol(cn, tol);
+    ts[2] = wall_clock64();
+    // lambda = ||c||_inf (homotopy-cpu.cpp:270 / :219); same exact value in every workgroup
+    T c_inf;
+    uint32_t imax;
+    reduce_sweep_partials(pmax_val, pmax_idx, gridDim.x, c_inf, imax, sv, si);
+
+    // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
+    if ((round > 1 && !(c_inf > tol)) || round > max_iter) {
+        if (blockIdx.x == 0 && tid == 0) {
+            st->c_inf = (double)c_inf;
+            st->iter = round - 1;
+            st->done_round = round;
+            st->need_sweep = 0;
+            st->done = 1;
+            signal_done(hflags, nullptr, 1u, round);
+            bump_seq(st, hflags);
+        }
+        return;
     }
-    // clear the old direction
-    for (uint32_t j = threadIdx.x; j < K_old; j += blockDim.x) d[gam_old[j]] = T(0);
-    __syncthreads();
-    // direction = inv * sign (homotopy-cpu.cpp:263), scattered to its columns (:266)
-    for (uint32_t a = wave; a < K_new; a += NW) {
-        T acc = T(0);
-        for (uint32_t b = lane; b < K_new; b += 64) acc += Inew[a * P + b] * sgn[b];
-        acc = wave_sum(acc);
-        if (lane == 0) d[gam_new[a]] = acc;
+
+    // ---- phase 2: step-length scan (same expressions as k_scansel) ---------------------------
+    T best = Lim<T>::max();
+    uint32_t best_i = 0xffffffffu;
+    for (uint32_t base = blockIdx.x * kItChunk; base < n; base += gridDim.x * kItChunk)
+#pragma unroll
+    for (int k = 0; k < kItCols; ++k) {
+        const uint32_t i = base + k * kItThreads + tid;
+        if (i < n) {
+            T m = Lim<T>::max();
+            const bool act = insup[i] != 0;
+            if (act) {
+                const T t = -x[i] / d[i];
+                if (t > T(0) && t < m) m = t;
+            } else {
+                const T qi = q[i], ci = c[i];
+                const T dl = T(1) - qi, dr = T(1) + qi;
+                if (dl != T(0)) {
+                    T t = (c_inf - ci) / dl;
+                    if (tie_guard && t == T(0) && dl > T(0)) t = Lim<T>::tiny();
+                    if (t > T(0) && t < m) m = t;
+                }
+                if (dr != T(0)) {
+                    T t = (c_inf + ci) / dr;
+                    if (tie_guard && t == T(0) && dr > T(0)) t = Lim<T>::tiny();
+                    if (t > T(0) && t < m) m = t;
+                }
+            }
+            tcand[i] = (act || slot_of[i] >= 0) ? Lim<T>::max() : m;
+            if (better_min(m, i, best, best_i)) { best = m; best_i = i; }
+        }
     }
+    block_reduce_pair<T, false>(best, best_i, sv, si);
+    if (tid == 0) { pmin_val[blockIdx.x] = best; pmin_idx[blockIdx.x] = best_i; }
+    ts[3] = wall_clock64();
+    if (!arrive_last(&st->ticket_scan, gridDim.x, &s_flag)) return;
+    ts[4] = wall_clock64();
+
+    // ---- last workgroup -----------------------------------------------------------------------
+    uint32_t idx = 0, rank = 0, added = 0, K_new = 0;
+    T g = T(0);
+    const bool go = select_toggle<T>(round, c_inf, gridDim.x, pmin_val, pmin_idx, x, d, insup, gam2, touched2, kcap,
+                                     st, hflags, false, trace, trace_cap, zero_on_removal, nullptr, 1u, slot_of,
+                                     sv, si, s_cnt, &idx, &rank, &added, &K_new, &g);
+    if (!go) {
+        if (tid == 0) bump_seq(st, hflags);
+        return;
+    }
+    ts[5] = wall_clock64();
+    const uint32_t* gam_old = gam2 + (size_t)cur0 * kcap;
+    const uint32_t* gam_new = gam2 + (size_t)(cur0 ^ 1u) * kcap;
+    if (added) {
+        const int32_t slot = slot_of[idx];
+        if (slot < 0) {
+            // not cached: select_toggle raised need_sweep; tell the host and wait for the sweep
+            if (tid == 0) {
+                const uint32_t nm = st->nmiss + 1u;
+                st->nmiss = nm;
+                __hip_atomic_store(&hflags[2], nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                bump_seq(st, hflags);
+            }
+            return;
+        }
+        // u1 = A_S^T a_idx and a_idx.a_idx gathered from the cached Gram column (online_inverse.h:209-218)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                  // gam_new written by select_toggle
+        const T* gi = gcache + (size_t)slot * gpitch;
+        for (uint32_t b = tid; b < K_new; b += blockDim.x) {
+            const T v = gi[gam_new[b]];
+            if (b == rank) st->dot = (double)v;
+            else u1[b - (b > rank ? 1u : 0u)] = v;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) st->cur = cur ^ 1u;
+    update_direction<T>(cur0, K_new, rank, added != 0, gam_old, gam_new, inv0, inv1, u1, u2, sgn, c, q, d, tol, st, 0,
+                        x, 0, 0, kcap, sv, &s_dd, g);
+    if (tid == 0) bump_seq(st, hflags);
+    if (dbg != nullptr && tid == 0 && round < 1024u) {     // stage timestamps of the last workgroup (100 MHz)
+        ts[6] = wall_clock64();
+        ts[7] = blockIdx.x;
+        for (int k2 = 0; k2 < 8; ++k2) dbg[(size_t)round * 8 + k2] = ts[k2];
+    }
 }
 
 // ---- y = A x (reconstruct_signal, lib.cpp:78-104) -------------------------------------
@@ -1145,6 +1436,23 @@ hipError_t launch_la_cq(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t* npart
 }
 
 template <typename T>
+hipError_t launch_la_iter(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    uint32_t nb = (n + kItChunk - 1) / kItChunk;
+    const uint32_t cap = std::min<uint32_t>(std::min<uint32_t>(kItMaxBlocks, (uint32_t)ctx->num_cus),
+                                            std::min<uint32_t>(ws.dims.pmax_stride, ws.dims.pmin_stride));
+    if (nb > cap) nb = cap;                              // the kernel grid-strides; the grid must be resident
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL((k_la_iter<T>), dim3(nb), dim3(kItThreads), 0, ctx->stream, tol, max_iter, n,
+                       (const T*)ws.gcache, (const int32_t*)ws.slot_of, (const T*)ws.c0, ws.gpitch,
+                       ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx, ws.pmin_val, ws.pmin_idx,
+                       ws.gam, ws.touched, ws.inv[0], ws.inv[1], ws.u1, ws.u2, ws.sgn, ws.tcand, ws.dims, ws.st,
+                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.la_dbg);
+    return hipGetLastError();
+}
+
+template <typename T>
 hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol,
                              uint32_t max_iter)
 {
@@ -1198,6 +1506,7 @@ template hipError_t launch_la_init_pick<float>(const ss_hip_ctx*, Workspace<floa
 template hipError_t launch_la_top<float>(const ss_hip_ctx*, Workspace<float>&, int);
 template hipError_t launch_la_update<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
 template hipError_t launch_la_cq<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t*);
+template hipError_t launch_la_iter<float>(const ss_hip_ctx*, Workspace<float>&, float, uint32_t);
 template hipError_t launch_la_scansel<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, float, uint32_t);
 template hipError_t launch_absmax<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t*);
 template hipError_t launch_absmax<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t*);

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -160,7 +161,7 @@ void release_arrays(Workspace<T>* w)
     void* ptrs[] = { w->y, w->rhs, w->cq, w->x, w->d, w->insup, w->pmax_val, w->pmax_idx,
                      w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->u1,
                      w->u2, w->sgn, w->st, w->ndone, w->tile_skip, w->gcache, w->slot_of, w->c0,
-                     w->tcand, w->sw_list };
+                     w->tcand, w->sw_list, w->la_dbg };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     TraceEntry* tr = w->trace;
@@ -309,6 +310,8 @@ template <typename T> struct Lookahead {
     static void ensure(ss_hip_ctx*, Workspace<T>&, uint32_t) {}
     static void init(ss_hip_ctx*, Workspace<T>&, uint32_t, T) {}
     static void round(ss_hip_ctx*, Workspace<T>&, uint32_t, T, uint32_t, hipEvent_t = nullptr, hipEvent_t = nullptr) {}
+    static void iterate(ss_hip_ctx*, Workspace<T>&, T, uint32_t) {}
+    static void fetch(ss_hip_ctx*, Workspace<T>&, T, hipEvent_t = nullptr, hipEvent_t = nullptr) {}
 };
 
 template <> struct Lookahead<float> {
@@ -335,6 +338,8 @@ template <> struct Lookahead<float> {
         HIPCHK(hipMalloc(&ws.sw_list, 64 * sizeof(uint32_t)));
         ws.gcap = (uint32_t)want;
         ws.gpitch = gpitch;
+        // developer aid: SS_HIP_LA_DEBUG=<file> dumps the stage timestamps of k_la_iter after each solve
+        if (!ws.la_dbg && std::getenv("SS_HIP_LA_DEBUG")) HIPCHK(hipMalloc(&ws.la_dbg, 1024 * 8 * sizeof(uint64_t)));
     }
 
     // c0 = A^T y has been swept into ws.c0 (partials in pmax): first pick, first lookahead sweep
@@ -347,9 +352,26 @@ template <> struct Lookahead<float> {
         HIPCHK(launch_la_top<T>(ctx, ws, 1));
         HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
         HIPCHK(launch_la_update<T>(ctx, ws, 0, tol));
+        if (ctx->la_fused) return;                 // k_la_iter forms c and q itself
         uint32_t np2 = 0;
         HIPCHK(launch_la_cq<T>(ctx, ws, &np2));
         ws.la_nparts = np2;
+    }
+
+    // fused form: one launch per iteration ...
+    static void iterate(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter)
+    {
+        HIPCHK(launch_la_iter<T>(ctx, ws, tol, max_iter));
+    }
+    // ... and, when the device reports an entering column without cached Gram column, the sweep
+    // that fetches it (plus 31 likely successors) and the inverse update that was waiting for it
+    static void fetch(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+    {
+        HIPCHK(launch_la_top<T>(ctx, ws, 0));
+        if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
+        HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
+        HIPCHK(launch_la_update<T>(ctx, ws, 1, tol));
     }
 
     // one homotopy iteration: scan + select, (sweep if the entering column is not cached),
@@ -448,6 +470,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
 
         ctx->host_flags[0] = 0;     // the stream is idle here: the previous solve synchronised
         ctx->host_flags[1] = 0;
+        ctx->host_flags[2] = 0;
         if (prof) HIPCHK(hipEventRecord(ctx->ev_solve0, st));
         copy_in<T>(ctx, ws.y, y, incy, m);
         HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)ctx->n_pad * sizeof(T), st));
@@ -483,6 +506,45 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
         volatile uint32_t* hf = ctx->host_flags;
         const uint64_t last_round = (uint64_t)max_iter + 1;
+        if (la && ctx->la_fused) {
+            // Fused lookahead engine: every launch of k_la_iter performs the next iteration, or
+            // nothing while the device waits for a Gram column (hf[2] counts those waits).  The
+            // host keeps L launches queued ahead and answers each wait with one fetch.
+            uint64_t enq = 0;
+            uint32_t handled = 0, timed_fetches = 0;
+            const uint64_t max_launch = 4 * ((uint64_t)max_iter + 2) + 64;
+            bool stuck = false;
+            for (;;) {
+                uint32_t spins = 0;
+                while (hf[1] == 0 && hf[2] == handled && enq >= (uint64_t)hf[0] + L) {
+                    if ((++spins & 0x3ffu) == 0) {
+                        const hipError_t qs = hipStreamQuery(st);
+                        if (qs == hipSuccess) break;
+                        if (qs != hipErrorNotReady) throw HipFail{ qs, "hipStreamQuery(solve loop)" };
+                    }
+                    std::this_thread::yield();
+                }
+                if (hf[1] != 0) break;
+                if (hf[2] != handled) {
+                    const bool timed_la = prof && (timed_fetches++ % (uint32_t)std::max(1, ctx->profile_every) == 0);
+                    hipEvent_t e0 = nullptr, e1 = nullptr;
+                    if (timed_la) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
+                    Lookahead<T>::fetch(ctx, ws, tol, e0, e1);
+                    if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
+                    ++handled;
+                }
+                if (enq >= max_launch) { stuck = true; break; }
+                Lookahead<T>::iterate(ctx, ws, tol, max_iter);
+                ++enq;
+            }
+            if (stuck) {
+                HIPCHK(hipStreamSynchronize(st));
+                if (hf[1] == 0) {
+                    set_err(err, errlen, "solve: internal error, lookahead loop made no progress");
+                    return SS_HIP_ERUNTIME;
+                }
+            }
+        } else
         for (uint64_t round = 1; round <= last_round; ++round) {
             if (round > L) {
                 const uint32_t need = (uint32_t)(round - L);
@@ -545,6 +607,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         }
         if (iter_out) *iter_out = hs.iter;
         if (err_out) *err_out = hs.c_inf;
+        if (la && ws.la_dbg) {
+            if (const char* path = std::getenv("SS_HIP_LA_DEBUG")) {
+                std::vector<uint64_t> tsb(1024 * 8);
+                HIPCHK(hipMemcpy(tsb.data(), ws.la_dbg, tsb.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                if (FILE* fp = std::fopen(path, "wb")) { std::fwrite(tsb.data(), sizeof(uint64_t), tsb.size(), fp); std::fclose(fp); }
+            }
+        }
         ctx->last_trace.clear();
         if (ctx->tracing && ws.trace) {
             // entry 0 = the initial pick, entry t = the toggle of iteration t
@@ -1038,6 +1107,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "engine"))        { ctx->engine = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { ctx->cache_mib = std::max<long>(16, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { ctx->batch_chunk = (int)std::max<long>(4, value); return SS_HIP_OK; }
@@ -1085,6 +1155,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
         return SS_HIP_OK;
     }
     if (!std::strcmp(key, "engine"))        { *value = ctx->engine; return SS_HIP_OK; }
+    if (!std::strcmp(key, "la_fused"))      { *value = ctx->la_fused; return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { *value = ctx->cache_mib; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { *value = ctx->batch_chunk; return SS_HIP_OK; }

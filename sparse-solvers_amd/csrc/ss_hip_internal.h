@@ -47,7 +47,9 @@ struct DevState {
     uint32_t need_sweep;  // 1 when the column being inserted has no cached Gram column yet
     uint32_t cache_used;  // cache slots handed out so far
     uint32_t nsweeps;     // lookahead sweeps that did work in this solve
-    uint32_t pad0_[15];
+    uint32_t seq;         // k_la_iter launches executed so far (mirrored to hflags[0])
+    uint32_t nmiss;       // iterations that had to wait for a lookahead sweep (mirrored to hflags[2])
+    uint32_t pad0_[13];
     // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
     uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
     uint32_t pad1_[31];
@@ -55,8 +57,10 @@ struct DevState {
     uint32_t pad2_[31];
     double   dot;         // a_idx . a_idx of the column being inserted (k_gramupd hand-off)
     uint32_t pad3_[30];
+    uint32_t bar_count;   // grid barrier of k_la_iter: arrivals so far in this solve (monotonic)
+    uint32_t pad4_[31];
 };
-static_assert(sizeof(DevState) == 512, "DevState layout");
+static_assert(sizeof(DevState) == 640, "DevState layout");
 
 // optional per-iteration record of the homotopy path (ss_hip_get_trace)
 struct TraceEntry {
@@ -113,6 +117,7 @@ struct Workspace {
     T* c0 = nullptr;              // [n_pad] A^T y
     T* tcand = nullptr;           // [n_pad] per-column step-length candidate of the last scan
     uint32_t* sw_list = nullptr;  // [64] rcols[32] then drows[32] of the next lookahead sweep
+    uint64_t* la_dbg = nullptr;   // [1024][8] stage timestamps of k_la_iter (option "la_debug"), else null
     uint32_t la_nparts = 0;       // partial maxima written by the last k_la_cq launch
     uint32_t* tile_skip = nullptr; // [b_pad/128 + 1] compact list of GEMM row tiles with a running signal + count
     TraceEntry* trace = nullptr;  // [trace_cap] when tracing is on
@@ -147,6 +152,7 @@ struct ss_hip_ctx {
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
     long cache_mib = 2048;   // budget of the lookahead engine's Gram-column cache
     int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns), 0 = one fused sweep per iteration
+    int la_fused = 1;        // lookahead engine: 1 = one kernel per iteration (k_la_iter), 0 = scan / update / cq kernels
     int batch_min = 4;       // batches of at least this many fp32 signals run in lock-step on the MFMA GEMM
     int batch_chunk = 4096;  // signals processed together by the batched path
     int tracing = 0;
@@ -154,8 +160,9 @@ struct ss_hip_ctx {
 
     // workspace (type-erased; Workspace<float> or Workspace<double>)
     void* ws = nullptr;
-    // pinned, device-mapped: [0] = last round the device started, [1] = done.  Written by
-    // k_scansel with system-scope stores, polled by the host loop (no copies in the stream).
+    // pinned, device-mapped: [0] = last round the device started (fused lookahead engine: iteration
+    // launches executed), [1] = done, [2] = iterations waiting for a lookahead sweep so far.
+    // Written by the device with system-scope stores, polled by the host loop (no copies in the stream).
     uint32_t* host_flags = nullptr;
     uint32_t* dev_flags = nullptr;    // device address of host_flags
     std::vector<hipEvent_t> prof_events;   // pairs (start, stop) for sweeps of the current solve
@@ -201,6 +208,9 @@ template <typename T>
 hipError_t launch_la_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol);
 template <typename T>
 hipError_t launch_la_cq(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t* nparts_out);
+// fused iteration of the lookahead engine (c, q from the cache; scan; select; update)
+template <typename T>
+hipError_t launch_la_iter(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter);
 template <typename T>
 hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol,
                              uint32_t max_iter);

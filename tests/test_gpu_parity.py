@@ -578,3 +578,65 @@ def test_ragged_shapes_vs_oracle(sship, shape, dtype):
         xo, ito, eo, picks = oracle.omp(A, y, tol, k)
         xg, itg, eg = h.solve_omp(y, tol, k)
         assert itg == ito and np.abs(xg - xo).max() <= 50 * RTOL[np.dtype(dtype)] * max(np.abs(xo).max(), 1e-30)
+
+
+# ---------------------------------------------------------------- the three fp32 engines
+
+ENGINES = {"sweep": {"engine": 0}, "lookahead": {"engine": 1, "la_fused": 0}, "lookahead-fused": {"engine": 1, "la_fused": 1}}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(96, 700, 8), (300, 1500, 20), (1024, 9000, 48)])
+def test_engines_agree(sship, shape):
+    """one fused sweep per iteration / lookahead with separate kernels / lookahead with one
+    kernel per iteration: same breakpoints, same answer (they differ in summation order only)"""
+    m, n, k = shape
+    A, y, x0, sup = make_gaussian_problem(4000 + m, m, n, k, np.float32)
+    xo, ito, eo, tro = oracle.homotopy(A, y, 1e-3, 4 * k, trace=True)
+    with sship.Homotopy(A) as h:
+        h.set_option("trace", 1)
+        for name, opts in ENGINES.items():
+            for key, val in opts.items():
+                h.set_option(key, val)
+            xg, itg, eg = h.solve(y, 1e-3, 4 * k)
+            trg = h.trace()
+            assert_parity(xg, itg, eg, xo, ito, eo, np.float32)
+            assert np.array_equal(trg["idx"][:-1], tro["idx"][:-1]), name
+            assert np.array_equal(trg["added"][:-1], tro["added"][:-1]), name
+            assert np.allclose(trg["gamma"][:-1], tro["gamma"][:-1], rtol=1e-4), name
+
+
+@pytest.mark.gpu
+def test_engines_agree_on_removal_paths(sship):
+    """fp32 paths on which columns leave the support again, all three engines vs the oracle"""
+    found = 0
+    flags = oracle.SPARSE_NOTRANS | oracle.ZERO_ON_REMOVAL
+    for seed in range(2000, 2040):
+        rng = np.random.default_rng(seed)
+        m, n, k = 40, 120, 14
+        A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(np.float32)
+        x0 = np.zeros(n, np.float32)
+        x0[rng.choice(n, k, replace=False)] = 1 + np.abs(rng.standard_normal(k))
+        y = A @ x0
+        # reference path in double precision decides whether the case is usable: it must have a
+        # removal, terminate, and every step length must be well separated from its runner-up
+        xd, itd, ed, trd = oracle.homotopy(A.astype(np.float64), y.astype(np.float64), 1e-3, 200, flags=flags, trace=True)
+        xo, ito, eo, tro = oracle.homotopy(A, y, 1e-3, 200, flags=flags, trace=True)
+        if not (trd["added"] == 0).any() or itd >= 200 or ito != itd or not np.array_equal(tro["idx"], trd["idx"]):
+            continue
+        found += 1
+        with sship.Homotopy(A) as h:
+            h.set_option("trace", 1)
+            for name, opts in ENGINES.items():
+                for key, val in opts.items():
+                    h.set_option(key, val)
+                xg, itg, eg = h.solve(y, 1e-3, 200)
+                tg = h.trace()
+                assert itg == ito, (seed, name)
+                assert np.array_equal(tg["idx"][:-1], tro["idx"][:-1]), (seed, name)
+                assert np.array_equal(tg["added"][:-1], tro["added"][:-1]), (seed, name)
+                assert np.array_equal(significant_support(xg, 1e-4), significant_support(xo, 1e-4)), (seed, name)
+                assert np.abs(xg - xo).max() <= 2e-4 * np.abs(xo).max(), (seed, name)
+        if found >= 6:
+            break
+    assert found >= 3
