@@ -33,6 +33,7 @@ HIP_UNITS = [
     ("sweep.hip", []),
     # scalar bookkeeping mirrors the reference's separately-rounded products and sums
     ("activeset.hip", ["-ffp-contract=off"]),
+    ("persist.hip", ["-ffp-contract=off"]),
     ("gemm.hip", []),
     ("homotopy.hip", []),
 ]

@@ -24,125 +24,12 @@
 // This file is compiled with -ffp-contract=off: products and sums round separately,
 // like the reference's scalar code.
 #include "ss_hip_internal.h"
+#include "ss_hip_device.h"
 
 #include <algorithm>
 #include <cfloat>
 
 namespace sship {
-
-template <typename T> struct Lim;
-template <> struct Lim<float>  { static constexpr float  max() { return FLT_MAX; } static constexpr float  tiny() { return FLT_MIN; } };
-template <> struct Lim<double> { static constexpr double max() { return DBL_MAX; } static constexpr double tiny() { return DBL_MIN; } };
-
-typedef float  v4f __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-constexpr int kSmallThreads = 256;
-constexpr int kUpdThreads = 1024;
-
-// ---- block reductions --------------------------------------------------------------
-
-// "better" for the arg-max of |c| (ixamax): larger value, ties -> smaller index
-template <typename T>
-__device__ __forceinline__ bool better_max(T v, uint32_t i, T bv, uint32_t bi)
-{
-    return v > bv || (v == bv && i < bi);
-}
-// "better" for the step length: smaller value, ties -> smaller (left-most) index
-template <typename T>
-__device__ __forceinline__ bool better_min(T v, uint32_t i, T bv, uint32_t bi)
-{
-    return v < bv || (v == bv && i < bi);
-}
-
-template <typename T, bool MAX>
-__device__ __forceinline__ void wave_reduce_pair(T& v, uint32_t& i)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const T ov = __shfl_xor(v, off, 64);
-        const uint32_t oi = __shfl_xor(i, off, 64);
-        const bool take = MAX ? better_max(ov, oi, v, i) : better_min(ov, oi, v, i);
-        if (take) { v = ov; i = oi; }
-    }
-}
-
-// all threads of the block receive the reduced pair; sv/si: LDS scratch of >= 16 entries
-template <typename T, bool MAX>
-__device__ __forceinline__ void block_reduce_pair(T& v, uint32_t& i, T* sv, uint32_t* si)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    wave_reduce_pair<T, MAX>(v, i);
-    __syncthreads();
-    if (lane == 0) { sv[wave] = v; si[wave] = i; }
-    __syncthreads();
-    T bv = sv[0];
-    uint32_t bi = si[0];
-    for (int w = 1; w < nw; ++w) {
-        const T ov = sv[w];
-        const uint32_t oi = si[w];
-        const bool take = MAX ? better_max(ov, oi, bv, bi) : better_min(ov, oi, bv, bi);
-        if (take) { bv = ov; bi = oi; }
-    }
-    v = bv;
-    i = bi;
-}
-
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-template <typename T>
-__device__ __forceinline__ T block_sum(T v, T* sv)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    v = wave_sum(v);
-    __syncthreads();
-    if (lane == 0) sv[wave] = v;
-    __syncthreads();
-    T s = sv[0];
-    for (int w = 1; w < nw; ++w) s += sv[w];
-    return s;
-}
-
-// max |c| and its first index from the per-workgroup partials of the sweep
-template <typename T>
-__device__ __forceinline__ void reduce_sweep_partials(const T* pv, const uint32_t* pi, uint32_t nb,
-                                                      T& val, uint32_t& idx, T* sv, uint32_t* si)
-{
-    T v = T(-1);
-    uint32_t ix = 0xffffffffu;
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
-        const T ov = pv[b];
-        const uint32_t oi = pi[b];
-        if (better_max(ov, oi, v, ix)) { v = ov; ix = oi; }
-    }
-    block_reduce_pair<T, true>(v, ix, sv, si);
-    if (ix == 0xffffffffu) ix = 0;   // all-NaN correlations: keep every later index in range
-    val = v;
-    idx = ix;
-}
-
-template <typename T>
-__device__ __forceinline__ T sign_tol(T v, T tol)   // homotopy-cpu.cpp:59-67
-{
-    if (v > tol) return T(1);
-    if (v < -tol) return T(-1);
-    return T(0);
-}
-
-// dot product of two contiguous device rows of length len (multiple of 256) by one block
-template <typename T>
-__device__ __forceinline__ T block_dot(const T* a, const T* b, uint32_t len, T* sv)
-{
-    T acc = T(0);
-    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) acc += a[i] * b[i];
-    return block_sum(acc, sv);
-}
 
 // ---- k_init: first pick, homotopy-cpu.cpp:217-229 ------------------------------------
 template <typename T>
@@ -201,38 +88,6 @@ void k_init(const T* __restrict__ At, SlotDims L, const T* __restrict__ c,
             trace[0].c_inf = (double)c_inf;
         }
     }
-}
-
-// ---- in-launch hand-off: "last workgroup to arrive finishes the job" --------------------
-// Placement-independent release/acquire at agent scope (cdna_hip_programming.md §6
-// Guideline 16, counter form): every wave drains its stores, the workgroup's leader
-// releases and takes a ticket; the workgroup that draws the last ticket acquires and may
-// then read, with VECTOR loads, what the others stored.  Returns true in that workgroup.
-// The counter is reset by the last arriver (every other workgroup has already arrived).
-__device__ __forceinline__ bool arrive_last(uint32_t* counter, uint32_t total, uint32_t* s_flag)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t last = (t == total - 1u) ? 1u : 0u;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *s_flag = last;
-    }
-    __syncthreads();
-    return *s_flag != 0u;
-}
-
-// a scalar another workgroup stored in this launch: read it on the vector path, L1 bypassed
-__device__ __forceinline__ double load_handoff(const double* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- k_rp: r = y - A x ; p = A d over the touched columns -----------------------------
@@ -304,17 +159,6 @@ void k_rp(const T* __restrict__ At, SlotDims L, const T* __restrict__ y,
         // padding rows stay exactly zero even if x or d went non-finite (0 * inf = NaN)
         rhs[i] = (i < L.m) ? (y[i] - sr) : T(0);
         rhs_p[i] = (i < L.m) ? sp : T(0);
-    }
-}
-
-// a slot finished: count it; the solve is over when every slot has (host sees hflags[1])
-__device__ __forceinline__ void signal_done(uint32_t* hflags, uint32_t* ndone, uint32_t nslots, uint32_t round)
-{
-    uint32_t prev = nslots - 1u;
-    if (ndone != nullptr) prev = __hip_atomic_fetch_add(ndone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (hflags != nullptr) {
-        if (prev + 1u >= nslots) __hip_atomic_store(&hflags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&hflags[0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -599,8 +443,6 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
               uint32_t* __restrict__ sw_list, DevState* st, uint32_t* hflags)
 {
     if (st->done || !st->need_sweep) return;
-    __shared__ T sv[16];
-    __shared__ uint32_t si[16];
     const uint32_t idx = st->idx;
     const uint32_t tid = threadIdx.x;
 
@@ -617,15 +459,39 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
         if (better_min(v, i, v1, i1)) { v2 = v1; i2 = i1; v1 = v; i1 = i; }
         else if (better_min(v, i, v2, i2)) { v2 = v; i2 = i; }
     }
+    // stage 1: every wave extracts the 6 best of its 128 offers (wave-level reductions only)
+    constexpr int kPerWave = 6;
+    constexpr int kNW = kUpdThreads / 64;
+    __shared__ T s_cv[kNW * kPerWave];
+    __shared__ uint32_t s_ci[kNW * kPerWave];
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = 0; r < kPerWave; ++r) {
+        T bv = v1;
+        uint32_t bi = i1;
+        wave_reduce_pair<T, false>(bv, bi);
+        if (bi == i1 && bi != 0xffffffffu) { v1 = v2; i1 = i2; v2 = Lim<T>::max(); i2 = 0xffffffffu; }   // offer taken
+        if (lane == 0) { s_cv[wave * kPerWave + r] = bv; s_ci[wave * kPerWave + r] = bi; }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // stage 2: one wave ranks the 96 finalists and hands out cache slots, best first
+    constexpr int kFinal = kNW * kPerWave;
+    static_assert(kFinal <= 128, "two finalists per lane");
+    T f1 = s_cv[lane];
+    uint32_t j1 = s_ci[lane];
+    T f2 = Lim<T>::max();
+    uint32_t j2 = 0xffffffffu;
+    if (lane + 64 < kFinal) { f2 = s_cv[lane + 64]; j2 = s_ci[lane + 64]; }
+    if (better_min(f2, j2, f1, j1)) { const T tv = f1; f1 = f2; f2 = tv; const uint32_t ti = j1; j1 = j2; j2 = ti; }
     uint32_t used = st->cache_used;
     uint32_t count = 0;
     for (int sidx = 0; sidx < kTopS; ++sidx) {
-        T bv = v1;
-        uint32_t bi = i1;
-        block_reduce_pair<T, false>(bv, bi, sv, si);
+        T bv = f1;
+        uint32_t bi = j1;
+        wave_reduce_pair<T, false>(bv, bi);
         if (!(bv < Lim<T>::max()) || bi == 0xffffffffu || used >= gcap) break;   // uniform
-        if (bi == i1) { v1 = v2; i1 = i2; v2 = Lim<T>::max(); i2 = 0xffffffffu; }   // offer taken
-        if (tid == 0) {
+        if (bi == j1) { f1 = f2; j1 = j2; f2 = Lim<T>::max(); j2 = 0xffffffffu; }
+        if (lane == 0) {
             sw_list[count] = bi;               // rcols: right-hand side = column bi of A
             sw_list[kTopS + count] = used;     // drows: output row = cache slot
             slot_of[bi] = (int32_t)used;
@@ -633,10 +499,11 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
         ++used;
         ++count;
     }
-    if (tid == 0) {
+    if (lane == 0) {
         for (uint32_t s2 = count; s2 < (uint32_t)kTopS; ++s2) { sw_list[s2] = 0xffffffffu; sw_list[kTopS + s2] = 0xffffffffu; }
         st->cache_used = used;
         st->nsweeps += 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (slot_of[idx] < 0) {                 // cache exhausted: the column cannot be inserted
             st->status = SS_HIP_ECAPACITY;
             st->need_sweep = 0;
@@ -1023,7 +890,7 @@ constexpr uint32_t kItChunk = kItThreads * kItCols;
 constexpr uint32_t kItMaxBlocks = 256;                   // all resident at once on any gfx950 part
 
 // Grid barrier.  Safe because every workgroup of the launch is resident (<= 256 workgroups of 256
-// threads, tiny LDS); arrivals are counted monotonically over the solve (target = round * grid).
+// threads, tiny LDS); arrivals are counted monotonically over the solve (target = barrier rounds so far * grid).
 // The spin is bounded: on expiry the caller abandons the solve instead of hanging the queue.
 __device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target, uint32_t* s_flag)
 {
@@ -1044,13 +911,6 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target,
     }
     __syncthreads();
     return *s_flag != 0u;
-}
-
-__device__ __forceinline__ void bump_seq(DevState* st, uint32_t* hflags)
-{
-    const uint32_t sq = st->seq + 1u;
-    st->seq = sq;
-    __hip_atomic_store(&hflags[0], sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <typename T>
@@ -1144,7 +1004,8 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
     if (tid == 0) { pmax_val[blockIdx.x] = bv; pmax_idx[blockIdx.x] = bi; }
     ts[1] = wall_clock64();
 
-    if (!grid_barrier(&st->bar_count, round * gridDim.x, &s_flag)) {
+    const uint32_t bar_round = st->bar_rounds + 1u;
+    if (!grid_barrier(&st->bar_count, bar_round * gridDim.x, &s_flag)) {
         if (blockIdx.x == 0 && tid == 0) {               // cannot happen with a resident grid
             st->status = SS_HIP_ERUNTIME;
             st->done = 1;
@@ -1167,6 +1028,7 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
             st->done_round = round;
             st->need_sweep = 0;
             st->done = 1;
+            st->bar_rounds = bar_round;
             signal_done(hflags, nullptr, 1u, round);
             bump_seq(st, hflags);
         }
@@ -1211,6 +1073,7 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
     ts[4] = wall_clock64();
 
     // ---- last workgroup -----------------------------------------------------------------------
+    if (tid == 0) st->bar_rounds = bar_round;
     uint32_t idx = 0, rank = 0, added = 0, K_new = 0;
     T g = T(0);
     const bool go = select_toggle<T>(round, c_inf, gridDim.x, pmin_val, pmin_idx, x, d, insup, gam2, touched2, kcap,

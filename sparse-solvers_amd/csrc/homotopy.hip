@@ -161,7 +161,7 @@ void release_arrays(Workspace<T>* w)
     void* ptrs[] = { w->y, w->rhs, w->cq, w->x, w->d, w->insup, w->pmax_val, w->pmax_idx,
                      w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->u1,
                      w->u2, w->sgn, w->st, w->ndone, w->tile_skip, w->gcache, w->slot_of, w->c0,
-                     w->tcand, w->sw_list, w->la_dbg };
+                     w->tcand, w->sw_list, w->la_dbg, w->la_sync };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     TraceEntry* tr = w->trace;
@@ -224,18 +224,18 @@ void ensure_workspace(ss_hip_ctx* ctx, uint32_t nslots, uint32_t kcap)
     HIPCHK(hipMalloc(&w->st, B * sizeof(DevState)));
     HIPCHK(hipMalloc(&w->ndone, 64));
     HIPCHK(hipMalloc(&w->tile_skip, ((size_t)b_pad / 128 + 1) * sizeof(uint32_t)));
-    HIPCHK(hipMemset(w->tile_skip, 0, ((size_t)b_pad / 128 + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(w->tile_skip, 0, ((size_t)b_pad / 128 + 1) * sizeof(uint32_t), ctx->stream));
     w->inv[1] = w->inv[0] + K * K;
     w->c = w->cq;
     w->q = w->cq + (size_t)b_pad * np;
     w->b_cap = want_b;
     w->kcap = want_k;
     w->dims = L;
-    HIPCHK(hipMemset(w->y, 0, B * ldm * s));
-    HIPCHK(hipMemset(w->rhs, 0, 2 * (size_t)b_pad * ldm * s));
-    HIPCHK(hipMemset(w->cq, 0, 2 * (size_t)b_pad * np * s));
-    HIPCHK(hipMemset(w->st, 0, B * sizeof(DevState)));
-    HIPCHK(hipMemset(w->ndone, 0, 64));
+    HIPCHK(hipMemsetAsync(w->y, 0, B * ldm * s, ctx->stream));
+    HIPCHK(hipMemsetAsync(w->rhs, 0, 2 * (size_t)b_pad * ldm * s, ctx->stream));
+    HIPCHK(hipMemsetAsync(w->cq, 0, 2 * (size_t)b_pad * np * s, ctx->stream));
+    HIPCHK(hipMemsetAsync(w->st, 0, B * sizeof(DevState), ctx->stream));
+    HIPCHK(hipMemsetAsync(w->ndone, 0, 64, ctx->stream));
 }
 
 template <typename T>
@@ -310,7 +310,7 @@ template <typename T> struct Lookahead {
     static void ensure(ss_hip_ctx*, Workspace<T>&, uint32_t) {}
     static void init(ss_hip_ctx*, Workspace<T>&, uint32_t, T) {}
     static void round(ss_hip_ctx*, Workspace<T>&, uint32_t, T, uint32_t, hipEvent_t = nullptr, hipEvent_t = nullptr) {}
-    static void iterate(ss_hip_ctx*, Workspace<T>&, T, uint32_t) {}
+    static void iterate(ss_hip_ctx*, Workspace<T>&, T, uint32_t, uint32_t) {}
     static void fetch(ss_hip_ctx*, Workspace<T>&, T, hipEvent_t = nullptr, hipEvent_t = nullptr) {}
 };
 
@@ -339,7 +339,8 @@ template <> struct Lookahead<float> {
         ws.gcap = (uint32_t)want;
         ws.gpitch = gpitch;
         // developer aid: SS_HIP_LA_DEBUG=<file> dumps the stage timestamps of k_la_iter after each solve
-        if (!ws.la_dbg && std::getenv("SS_HIP_LA_DEBUG")) HIPCHK(hipMalloc(&ws.la_dbg, 1024 * 8 * sizeof(uint64_t)));
+        if (!ws.la_dbg && std::getenv("SS_HIP_LA_DEBUG")) HIPCHK(hipMalloc(&ws.la_dbg, 2048 * 8 * sizeof(uint64_t)));
+        if (!ws.la_sync) HIPCHK(hipMalloc(&ws.la_sync, kLaSyncBytes));
     }
 
     // c0 = A^T y has been swept into ws.c0 (partials in pmax): first pick, first lookahead sweep
@@ -347,6 +348,12 @@ template <> struct Lookahead<float> {
     {
         hipStream_t st = ctx->stream;
         HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // -1
+        {   // hand-off area of the resident kernel: header and triples zero, offer slots "empty"
+            const size_t head = sizeof(LaSync) + (size_t)kLaPubWords * sizeof(uint64_t);
+            HIPCHK(hipMemsetAsync(ws.la_sync, 0, head, st));
+            HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(ws.la_sync) + head, 0xff, kLaSyncBytes - head, st));
+        }
+        if (ws.la_dbg) HIPCHK(hipMemsetAsync(ws.la_dbg, 0, 2048 * 8 * sizeof(uint64_t), st));
         HIPCHK(hipMemcpyAsync(ws.c, ws.c0, (size_t)ctx->n_pad * sizeof(T), hipMemcpyDeviceToDevice, st));
         HIPCHK(launch_la_init_pick<T>(ctx, ws, nparts));
         HIPCHK(launch_la_top<T>(ctx, ws, 1));
@@ -359,9 +366,11 @@ template <> struct Lookahead<float> {
     }
 
     // fused form: one launch per iteration ...
-    static void iterate(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter)
+    // lds_cols != 0: resident form holding up to that many support columns in LDS
+    static void iterate(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter, uint32_t lds_cols)
     {
-        HIPCHK(launch_la_iter<T>(ctx, ws, tol, max_iter));
+        if (lds_cols != 0) HIPCHK(launch_la_persist_f32(ctx, ws, tol, max_iter, lds_cols));
+        else HIPCHK(launch_la_iter<T>(ctx, ws, tol, max_iter));
     }
     // ... and, when the device reports an entering column without cached Gram column, the sweep
     // that fetches it (plus 31 likely successors) and the inverse update that was waiting for it
@@ -471,6 +480,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         ctx->host_flags[0] = 0;     // the stream is idle here: the previous solve synchronised
         ctx->host_flags[1] = 0;
         ctx->host_flags[2] = 0;
+        ctx->host_flags[3] = 0;
         if (prof) HIPCHK(hipEventRecord(ctx->ev_solve0, st));
         copy_in<T>(ctx, ws.y, y, incy, m);
         HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)ctx->n_pad * sizeof(T), st));
@@ -512,6 +522,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             // host keeps L launches queued ahead and answers each wait with one fetch.
             uint64_t enq = 0;
             uint32_t handled = 0, timed_fetches = 0;
+            // resident kernel: LDS tier (support columns it can hold); 0 = one launch per iteration
+            uint32_t lds_cols = 0;
+            const uint32_t kcap_ws = ws.dims.kcap;       // what the device checks K against (>= this solve's kcap)
+            if (ctx->la_fused >= 2 && ctx->zero_on_removal) {
+                lds_cols = std::min<uint32_t>(kcap_ws, kLaLdsSmall);
+                if (!la_persist_usable(ctx, lds_cols)) lds_cols = 0;
+            }
             const uint64_t max_launch = 4 * ((uint64_t)max_iter + 2) + 64;
             bool stuck = false;
             for (;;) {
@@ -533,8 +550,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
                     ++handled;
                 }
+                if (lds_cols != 0 && hf[3] > lds_cols) {
+                    // the support outgrew the tier: take the large one, or go on one launch per iteration
+                    const uint32_t big = std::min<uint32_t>(kcap_ws, kLaLdsLarge);
+                    lds_cols = (hf[3] <= big && big > lds_cols && la_persist_usable(ctx, big)) ? big : 0u;
+                }
                 if (enq >= max_launch) { stuck = true; break; }
-                Lookahead<T>::iterate(ctx, ws, tol, max_iter);
+                Lookahead<T>::iterate(ctx, ws, tol, max_iter, lds_cols);
                 ++enq;
             }
             if (stuck) {
@@ -609,7 +631,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         if (err_out) *err_out = hs.c_inf;
         if (la && ws.la_dbg) {
             if (const char* path = std::getenv("SS_HIP_LA_DEBUG")) {
-                std::vector<uint64_t> tsb(1024 * 8);
+                std::vector<uint64_t> tsb(2048 * 8);
                 HIPCHK(hipMemcpy(tsb.data(), ws.la_dbg, tsb.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
                 if (FILE* fp = std::fopen(path, "wb")) { std::fwrite(tsb.data(), sizeof(uint64_t), tsb.size(), fp); std::fclose(fp); }
             }
@@ -1107,7 +1129,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "engine"))        { ctx->engine = value ? 1 : 0; return SS_HIP_OK; }
-    if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { ctx->cache_mib = std::max<long>(16, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { ctx->batch_chunk = (int)std::max<long>(4, value); return SS_HIP_OK; }

@@ -1,0 +1,792 @@
+// persist.hip — the lookahead engine's iterations as ONE resident launch.
+//
+// k_la_iter (activeset.hip) already runs a whole Homotopy iteration per launch, but every
+// iteration still pays a launch, two fenced hand-offs and a chain of dependent global-memory
+// round trips through the (A_S^T A_S)^-1 matrix: ~34 us for ~2 us of arithmetic.  Here the
+// launch stays resident for as many iterations as it can:
+//
+//   workgroup 0 ("master")     keeps the active set in LDS — sorted support, cache slots, x_S, d_S
+//                              and the explicit inverse — and does the serial part of every
+//                              iteration there: loop control, pick, toggle, x update, bordering /
+//                              deflation of the inverse (online_inverse.h:183-293), new direction
+//                              (homotopy-cpu.cpp:236-272).
+//   workgroups 1.. ("workers") own the n columns: c_i = c0_i - sum_j x_j G[j][i], q_i = sum_j d_j G[j][i]
+//                              from the cached Gram columns, max |c_i|, find_max_gamma's scan
+//                              (homotopy-cpu.cpp:122-163) over the inactive columns.
+//
+// Per iteration: the master publishes (slot_j, x_j, d_j) of the support, the workers form c, q
+// and agree on lambda = ||c||_inf through one 64-bit atomic max, scan, and hand their best
+// step-length candidate to the master through a second one.  Every word that crosses
+// workgroups inside the launch is moved with agent-scope atomic (L2-bypassing) accesses, so no
+// cache write-back / invalidate fences are needed and everything else stays cached.
+//
+// The launch ends when the solve terminates, when the entering column has no cached Gram
+// column (the host then runs k_la_top + the lookahead sweep + k_gramupd and launches again), or
+// when the support outgrows the LDS tier it was launched with.  State is handed over in the
+// global-memory layout k_la_iter / k_gramupd use, so the three forms can follow one another.
+//
+// Residency: the grid is sized by the host from the occupancy of this kernel, every wait is a
+// bounded spin, and a workgroup that gives up makes every other one give up within the bound.
+//
+// The arithmetic is the same, in the same order, as k_la_iter's (sorted support, sequential
+// accumulation over j, the same block reductions), so the two produce identical paths.
+// Requires option zero_on_removal = 1 (columns that left the support carry exact zeros).
+// Compiled with -ffp-contract=off like activeset.hip.
+#include "ss_hip_internal.h"
+#include "ss_hip_device.h"
+
+#include <algorithm>
+
+namespace sship {
+
+constexpr int kPsThreads = 512;
+constexpr int kPsCols = 2;                      // columns a worker thread owns at most
+constexpr uint32_t kPsSpinLimit = 1u << 20;     // polls (~1 us each) before a wait gives up
+
+// ---- L2-bypassing accessors for words that cross workgroups inside the launch ----------------
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t ld_u64(const uint64_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_u32(uint32_t* p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_u64(uint64_t* p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_f32(const float* p)
+{
+    return __uint_as_float(ld_u32(reinterpret_cast<const uint32_t*>(p)));
+}
+__device__ __forceinline__ void st_f32(float* p, float v)
+{
+    st_u32(reinterpret_cast<uint32_t*>(p), __float_as_uint(v));
+}
+__device__ __forceinline__ void drain_vmem()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// LDS carve-up (floats / 32-bit words), P = columns the launch can hold
+struct PsLds {
+    float* I;        // [P][P + 1] explicit inverse, sorted-support order (master)
+    uint32_t* gam;   // [P] sorted support (master)
+    uint32_t* slt;   // [P] cache slot of each support column (master: state; workers: staged copy)
+    float* xs;       // [P] x on the support
+    float* ds;       // [P] direction on the support
+    float* u1;       // [P]
+    float* u2;       // [P]
+    float* sg;       // [P] sign vector
+    float* cn;       // [P] correlations after the step, support order
+};
+__host__ __device__ inline size_t ps_lds_words(uint32_t P) { return (size_t)P * (P + 1) + 8 * (size_t)P; }
+
+// four independent wave sums with their butterflies interleaved (same order of additions as wave_sum)
+__device__ __forceinline__ void wave_sum4(float (&v)[4])
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __shfl_xor(v[r], off, 64);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += o[r];
+    }
+}
+
+// In-place update of the LDS inverse I (pitch Pp) to the new sorted support; every pass reads all
+// it needs before it writes (rows bottom-up for an insertion, top-down for a removal).
+//   insertion: [inv + d u2 u2^T, -d u2; -d u2^T, d] with the new row/column at `rank`   (online_inverse.h:229-248)
+//   removal:   inv' - u3 u3^T / d over the remaining rows/columns                         (online_inverse.h:275-290)
+// The same element expressions are evaluated on the fly by new_inverse_elem() when the new
+// direction is formed before this store pass has run.
+__device__ __forceinline__ float new_inverse_elem(const float* I, uint32_t Pp, const float* u2, bool added,
+                                                  uint32_t rank, float dv, uint32_t a, uint32_t b)
+{
+    if (added) {
+        if (a == rank && b == rank) return dv;
+        if (a == rank) return -dv * u2[b - (b > rank ? 1u : 0u)];
+        if (b == rank) return -dv * u2[a - (a > rank ? 1u : 0u)];
+        const uint32_t oa = a - (a > rank ? 1u : 0u), ob = b - (b > rank ? 1u : 0u);
+        return I[oa * Pp + ob] + (dv * u2[oa]) * u2[ob];
+    }
+    const uint32_t oa = a + (a >= rank ? 1u : 0u), ob = b + (b >= rank ? 1u : 0u);
+    return I[oa * Pp + ob] + (-dv * u2[oa]) * u2[ob];          // dv = the removed diagonal entry here
+}
+
+__device__ __forceinline__ void store_new_inverse(float* I, uint32_t Pp, const float* u2, bool added,
+                                                  uint32_t rank, float dv, uint32_t K_new)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wv = tid >> 6;
+    constexpr uint32_t NWv = kPsThreads / 64;
+    const uint32_t cch = (K_new + 63u) / 64u;                 // 64-column chunks: 1..3
+    const uint32_t er = cch == 1u ? 8u : (cch == 2u ? 4u : 2u);   // row slots per thread (8 values in registers)
+    const uint32_t rpp = NWv * er;                            // rows per pass
+    const uint32_t npass = (K_new + rpp - 1u) / rpp;
+    for (uint32_t ps = 0; ps < npass; ++ps) {
+        // insertion: last rows first; removal: first rows first
+        const uint32_t r0 = added ? (K_new > (ps + 1u) * rpp ? K_new - (ps + 1u) * rpp : 0u) : ps * rpp;
+        const uint32_t r1 = added ? K_new - ps * rpp : (r0 + rpp < K_new ? r0 + rpp : K_new);
+        float v[8];
+#pragma unroll
+        for (uint32_t e = 0; e < 8; ++e) {
+            const uint32_t ri = cch == 1u ? e : (cch == 2u ? (e >> 1) : (e >> 2));
+            const uint32_t ci = cch == 1u ? 0u : (cch == 2u ? (e & 1u) : (e & 3u));
+            const uint32_t a = r0 + wv + NWv * ri, b = lane + 64u * ci;
+            v[e] = 0.f;
+            if (ri < er && ci < cch && a < r1 && b < K_new) v[e] = new_inverse_elem(I, Pp, u2, added, rank, dv, a, b);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t e = 0; e < 8; ++e) {
+            const uint32_t ri = cch == 1u ? e : (cch == 2u ? (e >> 1) : (e >> 2));
+            const uint32_t ci = cch == 1u ? 0u : (cch == 2u ? (e & 1u) : (e & 3u));
+            const uint32_t a = r0 + wv + NWv * ri, b = lane + 64u * ci;
+            if (ri < er && ci < cch && a < r1 && b < K_new) I[a * Pp + b] = v[e];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kPsThreads)
+void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
+                  const float* __restrict__ gcache, const int32_t* __restrict__ slot_of,
+                  const float* __restrict__ c0, uint32_t gpitch,
+                  float* c, float* q, float* x, float* d, uint8_t* insup,
+                  uint32_t* gam2, float* inv0, float* inv1, float* __restrict__ tcand,
+                  SlotDims L, DevState* st, LaSync* sy, uint64_t* pub, uint64_t* smax, uint64_t* smin, uint32_t* hflags,
+                  TraceEntry* trace, uint32_t trace_cap, int tie_guard, uint64_t* dbg)
+{
+    extern __shared__ float smem[];
+    __shared__ float sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_flag;
+    __shared__ float s_dd;
+    __shared__ uint64_t s_w64[2];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nw = gridDim.x - 1u;
+    const uint32_t kcap = L.kcap;
+    const uint32_t Pp = P + 1u;
+    PsLds S;
+    S.I = smem;
+    S.gam = reinterpret_cast<uint32_t*>(smem + (size_t)P * Pp);
+    S.slt = S.gam + P;
+    S.xs = reinterpret_cast<float*>(S.slt + P);
+    S.ds = S.xs + P;
+    S.u1 = S.ds + P;
+    S.u2 = S.u1 + P;
+    S.sg = S.u2 + P;
+    S.cn = S.sg + P;
+
+    // ---- nothing to do in this launch? (same answer in every workgroup: DevState was written
+    // ---- by earlier launches only) --------------------------------------------------------------
+    const uint32_t K0 = st->K;
+    const bool grow = (K0 + 1u > P) && (P < kcap);
+    if (st->done || st->need_sweep || grow) {
+        if (blockIdx.x == 0 && tid == 0) {
+            if (!st->done && !st->need_sweep)
+                __hip_atomic_store(&hflags[3], K0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            bump_seq(st, hflags);
+        }
+        return;
+    }
+    const uint32_t myseq = st->seq + 1u;
+    uint32_t tick = sy->tick;
+
+    // =============================================================================================
+    // workers
+    // =============================================================================================
+    if (blockIdx.x != 0) {
+        const uint32_t w = blockIdx.x - 1u;
+        uint32_t col[kPsCols];
+        bool in[kPsCols], cached[kPsCols];
+        uint32_t act[kPsCols];
+        float c0v[kPsCols];
+#pragma unroll
+        for (int k = 0; k < kPsCols; ++k) {
+            col[k] = w * kPsThreads + tid + (uint32_t)k * nw * kPsThreads;
+            in[k] = col[k] < n;
+            c0v[k] = 0.f; act[k] = 0; cached[k] = false;
+            if (in[k]) {
+                c0v[k] = c0[col[k]];
+                act[k] = insup[col[k]];
+                cached[k] = slot_of[col[k]] >= 0;
+            }
+        }
+        uint64_t ts[6];
+        for (;;) {
+            ++tick;
+            ts[0] = wall_clock64();
+            // wait for iteration `tick`: every published word carries its tick in the upper half, so the
+            // poll IS the load (one round trip); the header word may instead end the launch
+            uint32_t e_slot = 0xffffffffu, e_x = 0u, e_d = 0u, hdr = 0xffffffffu;
+            {
+                bool got = false;
+                for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
+                    const uint64_t h = ld_u64(&pub[0]);
+                    bool ready = (uint32_t)(h >> 32) == tick;
+                    const bool bye = (uint32_t)(h >> 32) == 0xffffffffu && (uint32_t)h == myseq;
+                    if (tid < P) {
+                        const uint64_t w0 = ld_u64(&pub[1 + tid]);
+                        const uint64_t w1 = ld_u64(&pub[1 + kLaPubStride + tid]);
+                        const uint64_t w2 = ld_u64(&pub[1 + 2 * kLaPubStride + tid]);
+                        ready = ready && (uint32_t)(w0 >> 32) == tick && (uint32_t)(w1 >> 32) == tick && (uint32_t)(w2 >> 32) == tick;
+                        e_slot = (uint32_t)w0; e_x = (uint32_t)w1; e_d = (uint32_t)w2;
+                    }
+                    hdr = (uint32_t)h;
+                    if (__syncthreads_or(bye ? 1 : 0)) return;
+                    if (__syncthreads_and(ready ? 1 : 0)) { got = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!got) return;                         // uniform: the votes are block-wide
+            }
+            ts[1] = wall_clock64();
+            const uint32_t tog_idx = hdr == 0xffffffffu ? 0xffffffffu : (hdr >> 1);
+            const uint32_t tog_added = hdr & 1u;
+            if (tid < P) { S.slt[tid] = e_slot; S.xs[tid] = __uint_as_float(e_x); S.ds[tid] = __uint_as_float(e_d); }
+            const uint32_t K = (uint32_t)__syncthreads_count((tid < P && e_slot != 0xffffffffu) ? 1 : 0);
+            ts[2] = wall_clock64();
+
+            // ---- c, q in Gram form; partial maximum of |c| ------------------------------------
+            float bv = -1.f;
+            uint32_t bi = 0xffffffffu;
+            float cv[kPsCols], qv[kPsCols];
+#pragma unroll
+            for (int k = 0; k < kPsCols; ++k) {
+                cv[k] = 0.f; qv[k] = 0.f;
+                if (!in[k]) continue;
+                if (col[k] == tog_idx) act[k] = tog_added;
+                // the row base is uniform (scalar registers), the column offset is this lane's constant
+                const uint32_t cofs = col[k];
+                auto grow = [&](uint32_t jj) -> float {
+                    const uint32_t sl = __builtin_amdgcn_readfirstlane(S.slt[jj]);
+                    return (gcache + (size_t)sl * gpitch)[cofs];
+                };
+                float ax = 0.f, ad = 0.f;
+                uint32_t j = 0;
+                for (; j + 32 <= K; j += 32) {
+                    float gv[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) gv[u] = grow(j + u);
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) { ax += S.xs[j + u] * gv[u]; ad += S.ds[j + u] * gv[u]; }
+                }
+                for (; j + 8 <= K; j += 8) {
+                    float gv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) gv[u] = grow(j + u);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { ax += S.xs[j + u] * gv[u]; ad += S.ds[j + u] * gv[u]; }
+                }
+                for (; j < K; ++j) {
+                    const float gvv = grow(j);
+                    ax += S.xs[j] * gvv;
+                    ad += S.ds[j] * gvv;
+                }
+                cv[k] = c0v[k] - ax;
+                qv[k] = ad;
+                st_f32(&c[col[k]], cv[k]);                // the master reads c, q on the support
+                st_f32(&q[col[k]], qv[k]);
+                const float a = cv[k] < 0.f ? -cv[k] : cv[k];
+                if (better_max(a, col[k], bv, bi)) { bv = a; bi = col[k]; }
+            }
+            block_reduce_pair<float, true>(bv, bi, sv, si);
+            ts[3] = wall_clock64();
+            // ---- lambda = ||c||_inf: every worker posts its maximum in its own slot and reads all of them
+            const uint32_t par = (tick & 1u) * kLaSlotStride;
+            if (tid == 0)
+                st_u64(&smax[par + w], bi != 0xffffffffu ? (((uint64_t)__float_as_uint(bv) << 32) | (uint64_t)(0xffffffffu - bi)) : 0ull);
+            float c_inf;
+            {
+                float mv = -1.f;
+                uint32_t mi = 0xffffffffu;
+                bool ok = true;
+                for (uint32_t s0 = 0; s0 < nw; s0 += kPsThreads) {
+                    const uint32_t sidx = s0 + tid;
+                    uint64_t pk = 0ull;
+                    if (sidx < nw) {
+                        pk = kLaSlotEmpty;
+                        for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
+                            pk = ld_u64(&smax[par + sidx]);
+                            if (pk != kLaSlotEmpty) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (pk == kLaSlotEmpty) { ok = false; pk = 0ull; }
+                    }
+                    if (pk != 0ull) {
+                        const float v = __uint_as_float((uint32_t)(pk >> 32));
+                        const uint32_t i2 = 0xffffffffu - (uint32_t)pk;
+                        if (better_max(v, i2, mv, mi)) { mv = v; mi = i2; }
+                    }
+                }
+                if (__syncthreads_or(ok ? 0 : 1)) return;          // a slot never filled: give up (uniform)
+                block_reduce_pair<float, true>(mv, mi, sv, si);
+                c_inf = mv;
+            }
+            ts[4] = wall_clock64();
+
+            // ---- step-length candidates of the inactive columns (same expressions as k_scansel) --
+            float best = Lim<float>::max();
+            uint32_t best_i = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < kPsCols; ++k) {
+                if (!in[k]) continue;
+                float m = Lim<float>::max();
+                if (!act[k]) {
+                    const float qi = qv[k], ci = cv[k];
+                    const float dl = 1.f - qi, dr = 1.f + qi;
+                    if (dl != 0.f) {
+                        float t = (c_inf - ci) / dl;
+                        if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
+                        if (t > 0.f && t < m) m = t;
+                    }
+                    if (dr != 0.f) {
+                        float t = (c_inf + ci) / dr;
+                        if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
+                        if (t > 0.f && t < m) m = t;
+                    }
+                }
+                tcand[col[k]] = (act[k] || cached[k]) ? Lim<float>::max() : m;
+                if (m < Lim<float>::max() && better_min(m, col[k], best, best_i)) { best = m; best_i = col[k]; }
+            }
+            block_reduce_pair<float, false>(best, best_i, sv, si);
+            drain_vmem();                                  // this wave's c, q stores are performed
+            __syncthreads();
+            if (tid == 0)
+                st_u64(&smin[par + w], best_i != 0xffffffffu ? (((uint64_t)__float_as_uint(best) << 32) | (uint64_t)best_i) : kLaSlotNone);
+            if (dbg != nullptr && w == 0 && tid == 0) {
+                ts[5] = wall_clock64();
+                for (int k2 = 0; k2 < 6; ++k2) dbg[(size_t)(1024u + (tick & 1023u)) * 8 + k2] = ts[k2];
+            }
+        }
+    }
+
+    // =============================================================================================
+    // master
+    // =============================================================================================
+    const uint32_t cur = st->cur;
+    float* const Ig = cur ? inv1 : inv0;
+    uint32_t* const gam_cur = gam2 + (size_t)cur * kcap;
+    uint32_t* const gam_alt = gam2 + (size_t)(cur ^ 1u) * kcap;
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = kPsThreads / 64;
+
+    uint32_t K = K0;
+    for (uint32_t e = tid; e < K * K; e += kPsThreads) {
+        const uint32_t a = e / K, b = e - a * K;
+        S.I[a * Pp + b] = Ig[(size_t)a * kcap + b];
+    }
+    if (tid < K) {
+        const uint32_t cl = gam_cur[tid];
+        S.gam[tid] = cl;
+        S.slt[tid] = (uint32_t)slot_of[cl];
+        S.xs[tid] = x[cl];
+        S.ds[tid] = d[cl];
+    }
+    __syncthreads();
+
+    uint32_t iter = st->iter;
+    float c_inf_rep = (float)st->c_inf;      // what the report will carry
+    float gamma_last = (float)st->gamma;
+    uint32_t last_idx = st->idx, last_rank = st->rank, last_added = st->added;
+    uint32_t tog_idx = 0xffffffffu, tog_added = 0u;
+    uint32_t done_round = 0u, status = 0u;
+    // 1 = solve finished, 2 = Gram column missing, 3 = support outgrew the LDS tier, 4 = wait expired
+    int exit_code = 0;
+    bool report_empty = false;               // the support became empty (DevState::K = 0)
+    bool save_lists_for_update = false;      // exit 2: the pick is made, the inverse update is pending
+    uint32_t pend_rank = 0, pend_idx = 0;
+    uint64_t ts[8];
+
+    bool pend = false, pend_added = false;   // the LDS inverse still has to take the last toggle
+    uint32_t pend_rk = 0, pend_K = 0;
+    float pend_dv = 0.f;
+    for (;;) {
+        if (K + 1u > P && P < kcap) {
+            if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
+            exit_code = 3;
+            break;
+        }
+        ++tick;
+        const uint32_t round = iter + 1u;
+        ts[0] = wall_clock64();
+
+        // ---- publish the support's (slot, x, d) and the previous toggle: every word tagged with the tick --
+        {
+            const uint64_t tag = (uint64_t)tick << 32;
+            if (tid < P) {
+                st_u64(&pub[1 + tid], tag | (uint64_t)(tid < K ? S.slt[tid] : 0xffffffffu));
+                st_u64(&pub[1 + kLaPubStride + tid], tag | (uint64_t)__float_as_uint(tid < K ? S.xs[tid] : 0.f));
+                st_u64(&pub[1 + 2 * kLaPubStride + tid], tag | (uint64_t)__float_as_uint(tid < K ? S.ds[tid] : 0.f));
+            }
+            if (tid == 0) st_u64(&pub[0], tag | (uint64_t)(tog_idx == 0xffffffffu ? 0xffffffffu : ((tog_idx << 1) | tog_added)));
+        }
+        ts[1] = wall_clock64();
+        // the workers are busy now: bring the stored inverse up to date with the last toggle
+        if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
+
+        // ---- candidates of the active columns, -x_j / d_j (homotopy-cpu.cpp:128-135) -----------------
+        float best = Lim<float>::max();
+        uint32_t best_i = 0xffffffffu;
+        if (tid < K) {
+            const float t = -S.xs[tid] / S.ds[tid];
+            if (t > 0.f && t < Lim<float>::max()) { best = t; best_i = S.gam[tid]; }
+        }
+        block_reduce_pair<float, false>(best, best_i, sv, si);
+
+        // ---- collect every worker's (min gamma, idx) and maximum; clear the slots of the next tick ------
+        const uint32_t par = (tick & 1u) * kLaSlotStride, par_next = ((tick + 1u) & 1u) * kLaSlotStride;
+        float c_inf = -1.f, tw = Lim<float>::max();
+        uint32_t ci_idx = 0xffffffffu, iw = 0xffffffffu;
+        {
+            bool ok = true;
+            for (uint32_t s0 = 0; s0 < nw; s0 += kPsThreads) {
+                const uint32_t sidx = s0 + tid;
+                if (sidx < nw) {
+                    uint64_t pk = kLaSlotEmpty, pm = 0ull;
+                    for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
+                        pm = ld_u64(&smax[par + sidx]);                 // posted before the worker's minimum
+                        pk = ld_u64(&smin[par + sidx]);
+                        if (pk != kLaSlotEmpty) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (pk == kLaSlotEmpty) ok = false;
+                    else if (pk != kLaSlotNone) {
+                        const float v = __uint_as_float((uint32_t)(pk >> 32));
+                        const uint32_t i2 = (uint32_t)pk;
+                        if (better_min(v, i2, tw, iw)) { tw = v; iw = i2; }
+                    }
+                    if (pm != 0ull && pm != kLaSlotEmpty) {
+                        const float v = __uint_as_float((uint32_t)(pm >> 32));
+                        const uint32_t i2 = 0xffffffffu - (uint32_t)pm;
+                        if (better_max(v, i2, c_inf, ci_idx)) { c_inf = v; ci_idx = i2; }
+                    }
+                    st_u64(&smax[par_next + sidx], kLaSlotEmpty);
+                    st_u64(&smin[par_next + sidx], kLaSlotEmpty);
+                }
+            }
+            if (__syncthreads_or(ok ? 0 : 1)) { exit_code = 4; break; }
+            block_reduce_pair<float, false>(tw, iw, sv, si);
+            block_reduce_pair<float, true>(c_inf, ci_idx, sv, si);
+        }
+        ts[2] = wall_clock64();
+
+        // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
+        if ((round > 1u && !(c_inf > tol)) || round > max_iter) {
+            c_inf_rep = c_inf;
+            iter = round - 1u;
+            done_round = round;
+            exit_code = 1;
+            break;
+        }
+
+        // ---- final (gamma, idx): smallest positive candidate, left-most index (:123-124) -------------
+        float g = best;
+        uint32_t idx = best_i;
+        if (iw != 0xffffffffu && better_min(tw, iw, g, idx)) { g = tw; idx = iw; }
+        if (!(g < Lim<float>::max())) idx = 0u;
+
+        // rank of idx in the sorted support, membership (rank_index.h:65-83)
+        if (tid < 2) s_cnt[tid] = 0u;
+        __syncthreads();
+        if (tid < K) {
+            const uint32_t gj = S.gam[tid];
+            if (gj < idx) atomicAdd(&s_cnt[0], 1u);
+            if (gj == idx) atomicAdd(&s_cnt[1], 1u);
+        }
+        __syncthreads();
+        const uint32_t rank = s_cnt[0];
+        const bool added = s_cnt[1] == 0u;
+        const uint32_t K_new = added ? K + 1u : K - 1u;
+        if (trace != nullptr && tid == 0 && round < trace_cap) {
+            trace[round].idx = idx;
+            trace[round].added = added ? 1u : 0u;
+            trace[round].gamma = (double)g;
+            trace[round].c_inf = (double)c_inf;
+        }
+        if (K_new == 0u || K_new > kcap) {
+            // homotopy-cpu.cpp:248-249 (support became empty: break before x is updated) / workspace full
+            if (K_new == 0u) {
+                if (tid == 0) insup[idx] = 0;
+                report_empty = true;                     // the lists keep the one column: its x is handed back
+                last_idx = idx; last_rank = rank; last_added = 0u; gamma_last = g;
+                iter = round;
+            } else {
+                status = SS_HIP_ECAPACITY;
+                iter = round - 1u;
+            }
+            c_inf_rep = c_inf;
+            done_round = round;
+            exit_code = 1;
+            break;
+        }
+
+        // loads that only need idx: c, q on the support (and at idx), the cache slot of idx
+        float cj = 0.f, qj = 0.f;
+        if (tid < K) { cj = ld_f32(&c[S.gam[tid]]); qj = ld_f32(&q[S.gam[tid]]); }
+        else if (tid == K && added) { cj = ld_f32(&c[idx]); qj = ld_f32(&q[idx]); }
+        int32_t slot = 0;
+        if (added) slot = slot_of[idx];
+
+        // x += gamma * direction over the OLD support (:252); the leaving column lands on exactly 0
+        if (tid < K) {
+            const float xn = S.xs[tid] + g * S.ds[tid];
+            S.xs[tid] = (!added && tid == rank) ? 0.f : xn;
+        }
+        if (tid == 0) insup[idx] = added ? 1 : 0;
+        iter = round;
+        c_inf_rep = c_inf;
+        gamma_last = g;
+        last_idx = idx; last_rank = rank; last_added = added ? 1u : 0u;
+        __syncthreads();
+        ts[3] = wall_clock64();
+
+        if (added && slot < 0) {
+            // no cached Gram column: hand the pending inverse update to k_gramupd
+            save_lists_for_update = true;
+            pend_rank = rank;
+            pend_idx = idx;
+            exit_code = 2;
+            break;
+        }
+
+        // correlations after the step on the new support, c - gamma*q (their sign is all that is used)
+        const float cnv = cj - g * qj;
+        float dv;
+        if (added) {
+            // u1 = A_S^T a_idx, dot = a_idx.a_idx from the cached Gram column (online_inverse.h:209-218)
+            const float* gi = gcache + (size_t)slot * gpitch;
+            float u1v = 0.f;
+            if (tid < K) u1v = gi[S.gam[tid]];
+            else if (tid == K) u1v = gi[idx];
+            if (tid < K) S.u1[tid] = u1v;
+            else if (tid == K) s_dd = u1v;                       // dot, replaced by d below
+            __syncthreads();
+            ts[4] = wall_clock64();
+            const uint32_t nn = K;
+            // u2 = inv * u1 (online_inverse.h:224-225), one wave per row
+            for (uint32_t i0 = wave; i0 < nn; i0 += 4 * NW) {
+                float acc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t i = i0 + (uint32_t)r * NW;
+                    acc[r] = 0.f;
+                    if (i < nn)
+                        for (uint32_t j = lane; j < nn; j += 64) acc[r] += S.I[i * Pp + j] * S.u1[j];
+                }
+                wave_sum4(acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t i = i0 + (uint32_t)r * NW;
+                    if (lane == 0 && i < nn) S.u2[i] = acc[r];
+                }
+            }
+            __syncthreads();
+            // d = 1 / (dot - u1.u2) (online_inverse.h:228)
+            float part = 0.f;
+            for (uint32_t j = tid; j < nn; j += kPsThreads) part += S.u1[j] * S.u2[j];
+            const float ssum = block_sum(part, sv);
+            __syncthreads();
+            if (tid == 0) s_dd = 1.f / (s_dd - ssum);
+            __syncthreads();
+            dv = s_dd;
+            // lists: insert at `rank`
+            uint32_t ng = 0, ns = 0;
+            float nx = 0.f, ncn = 0.f;
+            if (tid < K_new) {
+                const uint32_t o = tid - (tid > rank ? 1u : 0u);
+                if (tid == rank) { ng = idx; ns = (uint32_t)slot; nx = 0.f; }
+                else { ng = S.gam[o]; ns = S.slt[o]; nx = S.xs[o]; }
+            }
+            // cnv sits in thread j (old position) / thread K (idx): move through LDS
+            if (tid <= K) S.cn[tid] = cnv;
+            __syncthreads();
+            if (tid < K_new) {
+                const uint32_t o = tid - (tid > rank ? 1u : 0u);
+                ncn = (tid == rank) ? S.cn[K] : S.cn[o];
+            }
+            __syncthreads();
+            if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; }
+        } else {
+            ts[4] = wall_clock64();
+            // remove row/column `rank` (online_inverse.h:275-290)
+            const uint32_t nn = K;
+            dv = S.I[rank * Pp + rank];                            // d of the reference; (-d u3) u3^T below
+            const float sc = -(1.f / dv);
+            __syncthreads();
+            for (uint32_t i = tid; i < nn; i += kPsThreads) S.u2[i] = S.I[i * Pp + rank] * sc;
+            // the column that left: exact zeros in the dense vectors, out of the lists
+            if (tid == 0) { x[idx] = 0.f; d[idx] = 0.f; }
+            if (tid < K) S.cn[tid] = cnv;
+            __syncthreads();
+            uint32_t ng = 0, ns = 0;
+            float nx = 0.f, ncn = 0.f;
+            if (tid < K_new) {
+                const uint32_t o = tid + (tid >= rank ? 1u : 0u);
+                ng = S.gam[o]; ns = S.slt[o]; nx = S.xs[o]; ncn = S.cn[o];
+            }
+            __syncthreads();
+            if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; }
+        }
+        __syncthreads();
+        ts[5] = wall_clock64();
+        // sign(c[Gamma]) with dead zone tol (homotopy-cpu.cpp:259-260), direction = inv * sign (:263).
+        // The new inverse is not stored yet: its elements are formed on the fly, by the same
+        // expressions the store pass uses, so that the next iteration can be published at once;
+        // the store pass runs while the workers are busy with it.
+        if (tid < K_new) S.sg[tid] = sign_tol(S.cn[tid], tol);
+        __syncthreads();
+        for (uint32_t a0 = wave; a0 < K_new; a0 += 4 * NW) {
+            float acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t a = a0 + (uint32_t)r * NW;
+                acc[r] = 0.f;
+                if (a < K_new)
+                    for (uint32_t b = lane; b < K_new; b += 64)
+                        acc[r] += new_inverse_elem(S.I, Pp, S.u2, added, rank, dv, a, b) * S.sg[b];
+            }
+            wave_sum4(acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t a = a0 + (uint32_t)r * NW;
+                if (lane == 0 && a < K_new) S.ds[a] = acc[r];
+            }
+        }
+        __syncthreads();
+        pend = true; pend_added = added; pend_rk = rank; pend_dv = dv; pend_K = K_new;
+        K = K_new;
+        tog_idx = idx;
+        tog_added = added ? 1u : 0u;
+        if (dbg != nullptr && tid == 0 && round < 1024u) {
+            ts[6] = wall_clock64();
+            ts[7] = K;
+            for (int k2 = 0; k2 < 8; ++k2) dbg[(size_t)round * 8 + k2] = ts[k2];
+        }
+    }
+
+    // ---- end of the launch: release the workers, hand the state back in the global layout -----------
+    // (exit 3 broke out before taking a new tick, so `tick` is the last published one in every case)
+    if (tid == 0) st_u64(&pub[0], (0xffffffffull << 32) | (uint64_t)myseq);
+    const uint32_t tick_out = tick;
+    if (save_lists_for_update) {
+        // the pick is made (x updated, K_new columns) but the inverse still describes the old support:
+        // buffer `cur` keeps the old support and inverse, buffer cur^1 receives the new sorted support
+        // — exactly what select_toggle leaves behind for k_gramupd
+        const uint32_t K_new = K + 1u;
+        if (tid < K_new) {
+            const uint32_t o = tid - (tid > pend_rank ? 1u : 0u);
+            gam_alt[tid] = (tid == pend_rank) ? pend_idx : S.gam[o];
+        }
+    }
+    for (uint32_t e = tid; e < K * K; e += kPsThreads) {
+        const uint32_t a = e / K, b = e - a * K;
+        Ig[(size_t)a * kcap + b] = S.I[a * Pp + b];
+    }
+    if (tid < K) {
+        const uint32_t cl = S.gam[tid];
+        gam_cur[tid] = cl;
+        x[cl] = S.xs[tid];
+        d[cl] = S.ds[tid];
+    }
+    if (tid == 0) {
+        sy->tick = tick_out;
+        st->K = report_empty ? 0u : (save_lists_for_update ? K + 1u : K);
+        st->iter = iter;
+        st->c_inf = (double)c_inf_rep;
+        st->gamma = (double)gamma_last;
+        st->idx = last_idx;
+        st->rank = last_rank;
+        st->added = last_added;
+        if (exit_code == 4) { status = SS_HIP_ERUNTIME; done_round = iter + 1u; }
+        if (status != 0u) st->status = status;
+        if (exit_code == 1 || exit_code == 4) {
+            st->done_round = done_round;
+            st->need_sweep = 0;
+            st->done = 1;
+            signal_done(hflags, nullptr, 1u, done_round);
+        } else if (exit_code == 2) {
+            st->need_sweep = 1;
+            const uint32_t nm = st->nmiss + 1u;
+            st->nmiss = nm;
+            __hip_atomic_store(&hflags[2], nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            __hip_atomic_store(&hflags[3], K + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        bump_seq(st, hflags);
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+static size_t persist_lds_bytes(uint32_t P) { return ps_lds_words(P) * sizeof(float); }
+
+// worker workgroups the device can keep resident next to the master for LDS tier P (0: unusable)
+static int persist_workers(ss_hip_ctx* ctx, uint32_t P)
+{
+    const int tier = P > kLaLdsSmall ? 1 : 0;
+    if (ctx->persist_workers[tier] >= 0) return ctx->persist_workers[tier];
+    int result = 0;
+    const size_t lds = persist_lds_bytes(tier ? kLaLdsLarge : kLaLdsSmall);
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_la_persist),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->persist_workers[tier] = 0;
+            return 0;
+        }
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_la_persist, kPsThreads, lds) == hipSuccess && per_cu > 0) {
+        // keep a margin: at most 2 workgroups per CU, and never the last resident slot
+        const long cap = (long)std::min(per_cu, 2) * ctx->num_cus - 1;
+        result = (int)std::min<long>(kLaSlotStride, std::max<long>(0, cap - 1));
+    } else {
+        (void)hipGetLastError();
+    }
+    ctx->persist_workers[tier] = result;
+    return result;
+}
+
+static uint32_t persist_grid_workers(ss_hip_ctx* ctx, uint32_t P)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    const uint32_t cap = (uint32_t)persist_workers(ctx, P);
+    const uint32_t want = (n + kPsThreads - 1) / kPsThreads;
+    const uint32_t nw = std::min(want, cap);
+    if (nw == 0 || (uint64_t)nw * kPsThreads * kPsCols < n) return 0;
+    return nw;
+}
+
+bool la_persist_usable(ss_hip_ctx* ctx, uint32_t lds_cols)
+{
+    if (ctx->n > 0xfffffff0u || lds_cols > kLaLdsLarge) return false;
+    return persist_grid_workers(ctx, lds_cols) != 0;
+}
+
+hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, uint32_t lds_cols)
+{
+    const uint32_t P = lds_cols;
+    const uint32_t nw = persist_grid_workers(ctx, P);
+    if (nw == 0 || P > kLaLdsLarge || P > kLaPubStride) return hipErrorInvalidConfiguration;
+    // the LDS tier fixes the allocation (and with it the residency the grid was sized for)
+    const size_t lds = persist_lds_bytes(P > kLaLdsSmall ? kLaLdsLarge : kLaLdsSmall);
+    uint64_t* pub = reinterpret_cast<uint64_t*>(ws.la_sync + 1);
+    uint64_t* smax = pub + kLaPubWords;
+    uint64_t* smin = smax + 2 * kLaSlotStride;
+    hipLaunchKernelGGL(k_la_persist, dim3(nw + 1), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P,
+                       (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
+                       ws.c, ws.q, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
+                       ws.la_sync, pub, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg);
+    return hipGetLastError();
+}
+
+}  // namespace sship

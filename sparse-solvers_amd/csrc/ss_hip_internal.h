@@ -49,7 +49,8 @@ struct DevState {
     uint32_t nsweeps;     // lookahead sweeps that did work in this solve
     uint32_t seq;         // k_la_iter launches executed so far (mirrored to hflags[0])
     uint32_t nmiss;       // iterations that had to wait for a lookahead sweep (mirrored to hflags[2])
-    uint32_t pad0_[13];
+    uint32_t bar_rounds;  // k_la_iter launches that went through the grid barrier (bar_count = this * grid)
+    uint32_t pad0_[12];
     // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
     uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
     uint32_t pad1_[31];
@@ -61,6 +62,30 @@ struct DevState {
     uint32_t pad4_[31];
 };
 static_assert(sizeof(DevState) == 640, "DevState layout");
+
+// Hand-off area of the resident lookahead kernel (k_la_persist).  Everything that crosses
+// workgroups inside a launch is accessed with L2-bypassing (agent-scope atomic) loads and stores.
+struct LaSync {
+    uint32_t tick;         // iterations published so far in this solve (carried across launches)
+    uint32_t pad_[31];
+};
+static_assert(sizeof(LaSync) == 128, "LaSync layout");
+// The allocation continues with the published iteration — 64-bit words (tick << 32 | payload): one
+// header word (previous toggle, or 0xffffffff << 32 | launch seq to end the launch) and three
+// arrays of kLaPubStride words (cache slot, x, d of each support column); a reader polls the
+// words it needs until they all carry the tick it waits for — and the per-worker offer slots: smax[2][kLaSlotStride], smin[2][kLaSlotStride] (64-bit,
+// indexed by tick parity and worker).  A worker posts (bits(max |c_i|) << 32 | ~i) and later
+// (bits(min t_i) << 32 | i) in its own slots; the master sets the slots of the next tick back to
+// "empty" before it publishes it.  No read-modify-write atomics: 2 x 256 of them per iteration on
+// one cache line cost more than everything else in the iteration.
+constexpr uint32_t kLaSlotStride = 512;                       // workers at most
+constexpr uint64_t kLaSlotEmpty = ~0ull;                      // not posted yet
+constexpr uint64_t kLaSlotNone = 0x7f7fffffffffffffull;       // posted: no step-length candidate
+constexpr uint32_t kLaPubWords = 1 + 3 * 256;                 // header + three arrays of kLaPubStride
+constexpr size_t kLaSyncBytes = 128 + (size_t)kLaPubWords * 8 + 4 * 512 * 8;
+constexpr uint32_t kLaPubStride = 256;    // published (slot, x, d) triples: three arrays of this many words
+constexpr uint32_t kLaLdsSmall = 96;      // support sizes the resident kernel holds in LDS: first tier ...
+constexpr uint32_t kLaLdsLarge = 192;     // ... and the one that takes a whole CU's LDS
 
 // optional per-iteration record of the homotopy path (ss_hip_get_trace)
 struct TraceEntry {
@@ -117,6 +142,7 @@ struct Workspace {
     T* c0 = nullptr;              // [n_pad] A^T y
     T* tcand = nullptr;           // [n_pad] per-column step-length candidate of the last scan
     uint32_t* sw_list = nullptr;  // [64] rcols[32] then drows[32] of the next lookahead sweep
+    LaSync* la_sync = nullptr;    // hand-off area of k_la_persist, followed by the published triples
     uint64_t* la_dbg = nullptr;   // [1024][8] stage timestamps of k_la_iter (option "la_debug"), else null
     uint32_t la_nparts = 0;       // partial maxima written by the last k_la_cq launch
     uint32_t* tile_skip = nullptr; // [b_pad/128 + 1] compact list of GEMM row tiles with a running signal + count
@@ -152,7 +178,7 @@ struct ss_hip_ctx {
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
     long cache_mib = 2048;   // budget of the lookahead engine's Gram-column cache
     int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns), 0 = one fused sweep per iteration
-    int la_fused = 1;        // lookahead engine: 1 = one kernel per iteration (k_la_iter), 0 = scan / update / cq kernels
+    int la_fused = 2;        // lookahead engine: 2 = resident kernel (k_la_persist), 1 = one kernel per iteration (k_la_iter), 0 = scan / update / cq kernels
     int batch_min = 4;       // batches of at least this many fp32 signals run in lock-step on the MFMA GEMM
     int batch_chunk = 4096;  // signals processed together by the batched path
     int tracing = 0;
@@ -168,6 +194,7 @@ struct ss_hip_ctx {
     std::vector<hipEvent_t> prof_events;   // pairs (start, stop) for sweeps of the current solve
     std::vector<int> prof_kind;            // 2 = fused sweep, 1 = single-RHS sweep
     hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;
+    int persist_workers[2] = { -1, -1 };   // worker workgroups of k_la_persist per LDS tier (-1 = not queried, 0 = unusable)
 
     ss_hip_stats stats{};
 };
@@ -214,6 +241,12 @@ hipError_t launch_la_iter(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32
 template <typename T>
 hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol,
                              uint32_t max_iter);
+// resident form (persist.hip): one launch runs iterations until the solve ends, a Gram column is
+// missing or the support outgrows `lds_cols`; returns hipErrorInvalidConfiguration if the device
+// cannot keep the whole grid resident for this n
+hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, uint32_t lds_cols);
+// true if k_la_persist can serve this context (column count vs resident workgroups)
+bool la_persist_usable(ss_hip_ctx* ctx, uint32_t lds_cols);
 // per-slot partial (max |c|, first index) over chunks of the correlation rows (batched path)
 template <typename T>
 hipError_t launch_absmax(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t* nparts_out);
