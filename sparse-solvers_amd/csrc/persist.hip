@@ -250,8 +250,12 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
                 if (!got) return;                         // uniform: the votes are block-wide
             }
             ts[1] = wall_clock64();
-            const uint32_t tog_idx = hdr == 0xffffffffu ? 0xffffffffu : (hdr >> 1);
-            const uint32_t tog_added = hdr & 1u;
+            // header payload: bit 31 = probe tick (only lambda is wanted: no scan, nothing stored),
+            // low 31 bits = (toggled column << 1 | entered), all ones = no toggle to apply
+            const bool probe = (hdr >> 31) != 0u;
+            const uint32_t togw = hdr & 0x7fffffffu;
+            const uint32_t tog_idx = togw == 0x7fffffffu ? 0xffffffffu : (togw >> 1);
+            const uint32_t tog_added = togw & 1u;
             if (tid < P) { S.slt[tid] = e_slot; S.xs[tid] = __uint_as_float(e_x); S.ds[tid] = __uint_as_float(e_d); }
             const uint32_t K = (uint32_t)__syncthreads_count((tid < P && e_slot != 0xffffffffu) ? 1 : 0);
             ts[2] = wall_clock64();
@@ -294,8 +298,10 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
                 }
                 cv[k] = c0v[k] - ax;
                 qv[k] = ad;
-                st_f32(&c[col[k]], cv[k]);                // the master reads c, q on the support
-                st_f32(&q[col[k]], qv[k]);
+                if (!probe) {
+                    st_f32(&c[col[k]], cv[k]);            // the master reads c, q on the support
+                    st_f32(&q[col[k]], qv[k]);
+                }
                 const float a = cv[k] < 0.f ? -cv[k] : cv[k];
                 if (better_max(a, col[k], bv, bi)) { bv = a; bi = col[k]; }
             }
@@ -339,7 +345,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
             uint32_t best_i = 0xffffffffu;
 #pragma unroll
             for (int k = 0; k < kPsCols; ++k) {
-                if (!in[k]) continue;
+                if (!in[k] || probe) continue;
                 float m = Lim<float>::max();
                 if (!act[k]) {
                     const float qi = qv[k], ci = cv[k];
@@ -428,7 +434,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
                 st_u64(&pub[1 + kLaPubStride + tid], tag | (uint64_t)__float_as_uint(tid < K ? S.xs[tid] : 0.f));
                 st_u64(&pub[1 + 2 * kLaPubStride + tid], tag | (uint64_t)__float_as_uint(tid < K ? S.ds[tid] : 0.f));
             }
-            if (tid == 0) st_u64(&pub[0], tag | (uint64_t)(tog_idx == 0xffffffffu ? 0xffffffffu : ((tog_idx << 1) | tog_added)));
+            if (tid == 0) st_u64(&pub[0], tag | (uint64_t)(tog_idx == 0xffffffffu ? 0x7fffffffu : ((tog_idx << 1) | tog_added)));
         }
         ts[1] = wall_clock64();
         // the workers are busy now: bring the stored inverse up to date with the last toggle
@@ -551,7 +557,55 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
         ts[3] = wall_clock64();
 
         if (added && slot < 0) {
-            // no cached Gram column: hand the pending inverse update to k_gramupd
+            // No cached Gram column.  Before A is swept for it: the while-test of this iteration only
+            // needs lambda = ||A^T(y - A x)||_inf for the x just updated, and the entering column
+            // carries x = 0, so a probe tick over the old support answers it exactly.  If the solve
+            // ends here (homotopy-cpu.cpp:272) the pending inverse update would never be used.
+            ++tick;
+            {
+                const uint64_t tag = (uint64_t)tick << 32;
+                if (tid < P) {
+                    st_u64(&pub[1 + tid], tag | (uint64_t)(tid < K ? S.slt[tid] : 0xffffffffu));
+                    st_u64(&pub[1 + kLaPubStride + tid], tag | (uint64_t)__float_as_uint(tid < K ? S.xs[tid] : 0.f));
+                    st_u64(&pub[1 + 2 * kLaPubStride + tid], tag | 0ull);
+                }
+                if (tid == 0) st_u64(&pub[0], tag | 0xffffffffull);      // probe, no toggle
+            }
+            float lam = -1.f;
+            uint32_t lam_i = 0xffffffffu;
+            {
+                const uint32_t par2 = (tick & 1u) * kLaSlotStride, par2n = ((tick + 1u) & 1u) * kLaSlotStride;
+                bool ok = true;
+                for (uint32_t s0 = 0; s0 < nw; s0 += kPsThreads) {
+                    const uint32_t sidx = s0 + tid;
+                    if (sidx < nw) {
+                        uint64_t pk = kLaSlotEmpty, pm = 0ull;
+                        for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
+                            pm = ld_u64(&smax[par2 + sidx]);
+                            pk = ld_u64(&smin[par2 + sidx]);
+                            if (pk != kLaSlotEmpty) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (pk == kLaSlotEmpty) ok = false;
+                        if (pm != 0ull && pm != kLaSlotEmpty) {
+                            const float v = __uint_as_float((uint32_t)(pm >> 32));
+                            const uint32_t i2 = 0xffffffffu - (uint32_t)pm;
+                            if (better_max(v, i2, lam, lam_i)) { lam = v; lam_i = i2; }
+                        }
+                        st_u64(&smax[par2n + sidx], kLaSlotEmpty);
+                        st_u64(&smin[par2n + sidx], kLaSlotEmpty);
+                    }
+                }
+                if (__syncthreads_or(ok ? 0 : 1)) { exit_code = 4; break; }
+                block_reduce_pair<float, true>(lam, lam_i, sv, si);
+            }
+            if (!(lam > tol) || round + 1u > max_iter) {
+                c_inf_rep = lam;                         // iter = round already
+                done_round = round + 1u;
+                exit_code = 1;
+                break;
+            }
+            // the path goes on: hand the pending inverse update to k_gramupd
             save_lists_for_update = true;
             pend_rank = rank;
             pend_idx = idx;
@@ -768,7 +822,7 @@ static uint32_t persist_grid_workers(ss_hip_ctx* ctx, uint32_t P)
 
 bool la_persist_usable(ss_hip_ctx* ctx, uint32_t lds_cols)
 {
-    if (ctx->n > 0xfffffff0u || lds_cols > kLaLdsLarge) return false;
+    if (ctx->n >= (1u << 30) || lds_cols > kLaLdsLarge) return false;      // column indices travel in 30 bits
     return persist_grid_workers(ctx, lds_cols) != 0;
 }
 
