@@ -174,6 +174,7 @@ typedef struct ss_hip_stats {
     uint64_t sweep32_launches;     /* ... of which timed with HIP events (profiling on)         */
     double   sweep32_ms;           /* sum of their durations                                    */
     uint64_t sweep32_bytes;        /* algorithmic bytes of ONE lookahead sweep: m*n*s + 32*m*s + 32*n*s */
+    uint64_t gram_fallbacks;       /* solves re-run in residual form: tolerance too tight for Gram-form correlations */
 } ss_hip_stats;
 
 /* profiling != 0: bracket every sweep launch with HIP events on the context's stream. */
@@ -190,8 +191,12 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "trace"          1 = record the homotopy path of each solve (ss_hip_get_trace)
  *   "engine"         fp32 single-signal Homotopy: 1 (default) = lookahead engine — Gram
  *                    columns A^T a_j of active columns are cached and A is swept (32 right-hand
- *                    sides per pass) only when an uncached column enters; 0 = one fused 2-RHS
- *                    sweep per iteration.  fp64 always uses 0.
+ *                    sides per pass) only when an uncached column enters — unless the tolerance
+ *                    is below 2^-14 * ||A^T y||_inf, too tight for Gram-form correlations in
+ *                    fp32: such a solve runs as 0; 2 = lookahead engine unconditionally;
+ *                    0 = one fused 2-RHS sweep per iteration (residual form).  fp64 always uses 0.
+ *   "la_fused"       form of the lookahead engine's iterations: 2 (default) = one resident launch
+ *                    (k_la_persist), 1 = one launch per iteration, 0 = separate kernels
  *   "cache_mib"      memory budget of the lookahead engine's Gram-column cache (default 2048)
  *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 4)
  *   "batch_chunk"    signals processed together by the batched path (default 4096)

@@ -408,13 +408,25 @@ template <typename T>
 __global__ __launch_bounds__(kSmallThreads)
 void k_la_init_pick(const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
                     uint8_t* __restrict__ insup, uint32_t* __restrict__ gam, uint32_t* __restrict__ touched,
-                    DevState* st, TraceEntry* trace)
+                    DevState* st, TraceEntry* trace, T tol, T gram_guard, uint32_t* hflags)
 {
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
     T c_inf;
     uint32_t idx;
     reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, idx, sv, si);
+    // Gram form computes c = c0 - sum_j x_j g_j: its absolute error is ~eps * ||c0||_inf * sqrt(K), which
+    // must stay far below the lambda the path is asked to reach.  A tolerance below gram_guard * ||c0||_inf
+    // is answered with "retry in residual form" (the host re-runs the solve with one sweep per iteration).
+    if (gram_guard > T(0) && tol < gram_guard * c_inf) {
+        if (threadIdx.x == 0) {
+            st->status = kStatusRetryResidual;
+            st->need_sweep = 0;
+            st->done = 1;
+            signal_done(hflags, nullptr, 1u, 0u);
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         insup[idx] = 1;
         gam[0] = idx;
@@ -1261,10 +1273,12 @@ hipError_t launch_omp_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsl
 
 // ---- lookahead engine launchers -------------------------------------------------------------
 template <typename T>
-hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts)
+hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol)
 {
+    // option "engine" = 1: guard on (tolerance vs ||A^T y||_inf), 2: lookahead engine unconditionally
+    const T guard = ctx->engine == 1 ? (T)kGramGuard : T(0);
     hipLaunchKernelGGL((k_la_init_pick<T>), dim3(1), dim3(kSmallThreads), 0, ctx->stream, ws.pmax_val,
-                       ws.pmax_idx, nparts, ws.insup, ws.gam, ws.touched, ws.st, ws.trace);
+                       ws.pmax_idx, nparts, ws.insup, ws.gam, ws.touched, ws.st, ws.trace, tol, guard, ctx->dev_flags);
     return hipGetLastError();
 }
 
@@ -1365,7 +1379,7 @@ template hipError_t launch_omp_tail<float>(const ss_hip_ctx*, Workspace<float>&,
                                            uint32_t, float, uint32_t);
 template hipError_t launch_omp_tail<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t,
                                             uint32_t, double, uint32_t);
-template hipError_t launch_la_init_pick<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t);
+template hipError_t launch_la_init_pick<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
 template hipError_t launch_la_top<float>(const ss_hip_ctx*, Workspace<float>&, int);
 template hipError_t launch_la_update<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
 template hipError_t launch_la_cq<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t*);

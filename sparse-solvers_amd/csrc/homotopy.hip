@@ -161,7 +161,7 @@ void release_arrays(Workspace<T>* w)
     void* ptrs[] = { w->y, w->rhs, w->cq, w->x, w->d, w->insup, w->pmax_val, w->pmax_idx,
                      w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->u1,
                      w->u2, w->sgn, w->st, w->ndone, w->tile_skip, w->gcache, w->slot_of, w->c0,
-                     w->tcand, w->sw_list, w->la_dbg, w->la_sync };
+                     w->tcand, w->sw_list, w->la_dbg, w->la_sync, w->cq_alt };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     TraceEntry* tr = w->trace;
@@ -341,6 +341,7 @@ template <> struct Lookahead<float> {
         // developer aid: SS_HIP_LA_DEBUG=<file> dumps the stage timestamps of k_la_iter after each solve
         if (!ws.la_dbg && std::getenv("SS_HIP_LA_DEBUG")) HIPCHK(hipMalloc(&ws.la_dbg, 2048 * 8 * sizeof(uint64_t)));
         if (!ws.la_sync) HIPCHK(hipMalloc(&ws.la_sync, kLaSyncBytes));
+        if (!ws.cq_alt) HIPCHK(hipMalloc(&ws.cq_alt, 2 * (size_t)ctx->n_pad * sizeof(T)));
     }
 
     // c0 = A^T y has been swept into ws.c0 (partials in pmax): first pick, first lookahead sweep
@@ -349,13 +350,13 @@ template <> struct Lookahead<float> {
         hipStream_t st = ctx->stream;
         HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // -1
         {   // hand-off area of the resident kernel: header and triples zero, offer slots "empty"
-            const size_t head = sizeof(LaSync) + (size_t)kLaPubWords * sizeof(uint64_t);
+            const size_t head = sizeof(LaSync);
             HIPCHK(hipMemsetAsync(ws.la_sync, 0, head, st));
             HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(ws.la_sync) + head, 0xff, kLaSyncBytes - head, st));
         }
         if (ws.la_dbg) HIPCHK(hipMemsetAsync(ws.la_dbg, 0, 2048 * 8 * sizeof(uint64_t), st));
         HIPCHK(hipMemcpyAsync(ws.c, ws.c0, (size_t)ctx->n_pad * sizeof(T), hipMemcpyDeviceToDevice, st));
-        HIPCHK(launch_la_init_pick<T>(ctx, ws, nparts));
+        HIPCHK(launch_la_init_pick<T>(ctx, ws, nparts, tol));
         HIPCHK(launch_la_top<T>(ctx, ws, 1));
         HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
         HIPCHK(launch_la_update<T>(ctx, ws, 0, tol));
@@ -436,7 +437,7 @@ hipEvent_t prof_event(ss_hip_ctx* ctx, size_t i)
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
                ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
-               bool omp = false)
+               bool omp = false, bool force_residual = false)
 {
     if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
     if (ctx->is_f64 != (sizeof(T) == 8)) {
@@ -491,7 +492,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         HIPCHK(hipMemcpyAsync(ws.rhs, ws.y, (size_t)ctx->ldm * sizeof(T), hipMemcpyDeviceToDevice, st));
         const size_t rhs_stride = (size_t)ws.dims.b_pad * ctx->ldm;   // r-block -> p-block
 
-        const bool la = !omp && Lookahead<T>::supported && ctx->engine == 1;
+        const bool la = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual;
         if (la) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             uint32_t nb1 = 0;
@@ -623,8 +624,15 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             set_err(err, errlen, "solve: internal error, device loop did not terminate");
             return SS_HIP_ERUNTIME;
         }
+        if (la && hs.status == kStatusRetryResidual) {
+            // tolerance too tight for Gram-form correlations (see k_la_init_pick): residual form
+            ctx->stats.gram_fallbacks += 1;
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, true);
+        }
         if (hs.status != 0) {
-            set_err(err, errlen, "solve: active set outgrew the workspace capacity (4096 columns)");
+            set_err(err, errlen, hs.status == SS_HIP_ECAPACITY
+                                     ? "solve: active set outgrew the workspace capacity (4096 columns)"
+                                     : "solve: internal error, a device-side wait expired");
             return (int)hs.status;
         }
         if (iter_out) *iter_out = hs.iter;
@@ -1128,7 +1136,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "zero_on_removal")) { ctx->zero_on_removal = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
-    if (!std::strcmp(key, "engine"))        { ctx->engine = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { ctx->cache_mib = std::max<long>(16, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }

@@ -3,33 +3,37 @@
 // k_la_iter (activeset.hip) already runs a whole Homotopy iteration per launch, but every
 // iteration still pays a launch, two fenced hand-offs and a chain of dependent global-memory
 // round trips through the (A_S^T A_S)^-1 matrix: ~34 us for ~2 us of arithmetic.  Here the
-// launch stays resident for as many iterations as it can:
+// launch stays resident for as many iterations as it can, and every workgroup is the same:
 //
-//   workgroup 0 ("master")     keeps the active set in LDS — sorted support, cache slots, x_S, d_S
-//                              and the explicit inverse — and does the serial part of every
-//                              iteration there: loop control, pick, toggle, x update, bordering /
-//                              deflation of the inverse (online_inverse.h:183-293), new direction
-//                              (homotopy-cpu.cpp:236-272).
-//   workgroups 1.. ("workers") own the n columns: c_i = c0_i - sum_j x_j G[j][i], q_i = sum_j d_j G[j][i]
-//                              from the cached Gram columns, max |c_i|, find_max_gamma's scan
-//                              (homotopy-cpu.cpp:122-163) over the inactive columns.
+//   * it owns a slice of the n columns: c_i = c0_i - sum_j x_j G[j][i], q_i = sum_j d_j G[j][i] from
+//     the cached Gram columns, max |c_i|, and find_max_gamma's scan (homotopy-cpu.cpp:122-163);
+//   * it keeps a full replica of the active set in LDS — sorted support, cache slots, x_S, d_S and
+//     the explicit inverse — and performs the serial part of every iteration on it: loop control,
+//     pick, toggle, x update, bordering / deflation of the inverse (online_inverse.h:183-293), new
+//     direction (homotopy-cpu.cpp:236-272).  Same code, same inputs, same order in every
+//     workgroup, hence the same bits: nothing has to be broadcast.
 //
-// Per iteration: the master publishes (slot_j, x_j, d_j) of the support, the workers form c, q
-// and agree on lambda = ||c||_inf through one 64-bit atomic max, scan, and hand their best
-// step-length candidate to the master through a second one.  Every word that crosses
-// workgroups inside the launch is moved with agent-scope atomic (L2-bypassing) accesses, so no
-// cache write-back / invalidate fences are needed and everything else stays cached.
+// Two exchanges per iteration remain, both all-to-all through per-workgroup slots in global
+// memory: lambda = ||c||_inf (every workgroup posts its maximum and reads all of them) and the
+// step length (every workgroup posts its best candidate and reads all of them).  Slots and the
+// c, q values read across workgroups are moved with agent-scope atomic (L2-bypassing) loads and
+// stores, so no cache write-back / invalidate fences are needed and everything else stays cached.
+// A slot is set back to "empty" by its owner two exchanges later, when every reader is provably
+// past it (see the loop).
 //
-// The launch ends when the solve terminates, when the entering column has no cached Gram
-// column (the host then runs k_la_top + the lookahead sweep + k_gramupd and launches again), or
-// when the support outgrows the LDS tier it was launched with.  State is handed over in the
-// global-memory layout k_la_iter / k_gramupd use, so the three forms can follow one another.
+// The launch ends when the solve terminates, when the entering column has no cached Gram column
+// (the host then runs k_la_top + the lookahead sweep + k_gramupd and launches again) or when the
+// support outgrows the LDS tier it was launched with.  Before A is swept for a missing column the
+// loop's while-test is answered with a probe exchange (the entering column carries x = 0, so
+// lambda does not need its Gram column); if the solve ends there the sweep is never made.
+// State is handed over by workgroup 0 in the global-memory layout k_la_iter / k_gramupd use, so
+// the three forms can follow one another.
 //
-// Residency: the grid is sized by the host from the occupancy of this kernel, every wait is a
-// bounded spin, and a workgroup that gives up makes every other one give up within the bound.
+// Residency: the grid is sized by the host from the occupancy of this kernel and every wait is a
+// bounded spin; a workgroup that gives up returns, and the others give up within the bound.
 //
 // The arithmetic is the same, in the same order, as k_la_iter's (sorted support, sequential
-// accumulation over j, the same block reductions), so the two produce identical paths.
+// accumulation over j, the same reductions), so the two produce identical paths, bit for bit.
 // Requires option zero_on_removal = 1 (columns that left the support carry exact zeros).
 // Compiled with -ffp-contract=off like activeset.hip.
 #include "ss_hip_internal.h"
@@ -40,7 +44,7 @@
 namespace sship {
 
 constexpr int kPsThreads = 512;
-constexpr int kPsCols = 2;                      // columns a worker thread owns at most
+constexpr int kPsCols = 2;                      // columns a thread owns at most
 constexpr uint32_t kPsSpinLimit = 1u << 20;     // polls (~1 us each) before a wait gives up
 
 // ---- L2-bypassing accessors for words that cross workgroups inside the launch ----------------
@@ -87,17 +91,11 @@ struct PsLds {
 };
 __host__ __device__ inline size_t ps_lds_words(uint32_t P) { return (size_t)P * (P + 1) + 8 * (size_t)P; }
 
-// four independent wave sums with their butterflies interleaved (same order of additions as wave_sum)
+// four independent wave sums (same order of additions as wave_sum)
 __device__ __forceinline__ void wave_sum4(float (&v)[4])
 {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = __shfl_xor(v[r], off, 64);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += o[r];
-    }
+    for (int r = 0; r < 4; ++r) v[r] = wave_sum(v[r]);
 }
 
 // In-place update of the LDS inverse I (pitch Pp) to the new sorted support; every pass reads all
@@ -155,25 +153,49 @@ __device__ __forceinline__ void store_new_inverse(float* I, uint32_t Pp, const f
     }
 }
 
+// one exchange: post this workgroup's word, read everybody's.  `slots` = the parity row of the
+// exchange (kLaSlotStride words); returns false if a slot stayed empty for the whole bound.
+// reduce(pk) is called by each thread for the slots it read.
+template <typename F>
+__device__ __forceinline__ bool exchange_all(uint64_t* slots, uint32_t nb, uint32_t w, uint64_t mine, F&& reduce)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) st_u64(&slots[w], mine);
+    bool ok = true;
+    for (uint32_t s0 = 0; s0 < nb; s0 += kPsThreads) {
+        const uint32_t sidx = s0 + tid;
+        if (sidx < nb) {
+            uint64_t pk = kLaSlotEmpty;
+            for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
+                pk = ld_u64(&slots[sidx]);
+                if (pk != kLaSlotEmpty) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (pk == kLaSlotEmpty) ok = false;
+            else reduce(pk);
+        }
+    }
+    return __syncthreads_or(ok ? 0 : 1) == 0;
+}
+
 __global__ __launch_bounds__(kPsThreads)
 void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
                   const float* __restrict__ gcache, const int32_t* __restrict__ slot_of,
                   const float* __restrict__ c0, uint32_t gpitch,
-                  float* c, float* q, float* x, float* d, uint8_t* insup,
+                  float* c, float* q, float* c_alt, float* q_alt, float* x, float* d, uint8_t* insup,
                   uint32_t* gam2, float* inv0, float* inv1, float* __restrict__ tcand,
-                  SlotDims L, DevState* st, LaSync* sy, uint64_t* pub, uint64_t* smax, uint64_t* smin, uint32_t* hflags,
+                  SlotDims L, DevState* st, LaSync* sy, uint64_t* smax, uint64_t* smin, uint32_t* hflags,
                   TraceEntry* trace, uint32_t trace_cap, int tie_guard, uint64_t* dbg)
 {
     extern __shared__ float smem[];
     __shared__ float sv[16];
     __shared__ uint32_t si[16];
     __shared__ uint32_t s_cnt[2];
-    __shared__ uint32_t s_flag;
     __shared__ float s_dd;
-    __shared__ uint64_t s_w64[2];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t nw = gridDim.x - 1u;
+    const uint32_t nb = gridDim.x, w = blockIdx.x;
+    const bool lead = w == 0;                    // the workgroup that writes the shared state
     const uint32_t kcap = L.kcap;
     const uint32_t Pp = P + 1u;
     PsLds S;
@@ -190,195 +212,35 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
     // ---- nothing to do in this launch? (same answer in every workgroup: DevState was written
     // ---- by earlier launches only) --------------------------------------------------------------
     const uint32_t K0 = st->K;
-    const bool grow = (K0 + 1u > P) && (P < kcap);
-    if (st->done || st->need_sweep || grow) {
-        if (blockIdx.x == 0 && tid == 0) {
+    const bool grow0 = (K0 + 1u > P) && (P < kcap);
+    if (st->done || st->need_sweep || grow0) {
+        if (lead && tid == 0) {
             if (!st->done && !st->need_sweep)
                 __hip_atomic_store(&hflags[3], K0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             bump_seq(st, hflags);
         }
         return;
     }
-    const uint32_t myseq = st->seq + 1u;
     uint32_t tick = sy->tick;
 
-    // =============================================================================================
-    // workers
-    // =============================================================================================
-    if (blockIdx.x != 0) {
-        const uint32_t w = blockIdx.x - 1u;
-        uint32_t col[kPsCols];
-        bool in[kPsCols], cached[kPsCols];
-        uint32_t act[kPsCols];
-        float c0v[kPsCols];
+    // ---- this workgroup's columns -------------------------------------------------------------------
+    uint32_t col[kPsCols];
+    bool in[kPsCols], cached[kPsCols];
+    uint32_t act[kPsCols];
+    float c0v[kPsCols];
 #pragma unroll
-        for (int k = 0; k < kPsCols; ++k) {
-            col[k] = w * kPsThreads + tid + (uint32_t)k * nw * kPsThreads;
-            in[k] = col[k] < n;
-            c0v[k] = 0.f; act[k] = 0; cached[k] = false;
-            if (in[k]) {
-                c0v[k] = c0[col[k]];
-                act[k] = insup[col[k]];
-                cached[k] = slot_of[col[k]] >= 0;
-            }
-        }
-        uint64_t ts[6];
-        for (;;) {
-            ++tick;
-            ts[0] = wall_clock64();
-            // wait for iteration `tick`: every published word carries its tick in the upper half, so the
-            // poll IS the load (one round trip); the header word may instead end the launch
-            uint32_t e_slot = 0xffffffffu, e_x = 0u, e_d = 0u, hdr = 0xffffffffu;
-            {
-                bool got = false;
-                for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
-                    const uint64_t h = ld_u64(&pub[0]);
-                    bool ready = (uint32_t)(h >> 32) == tick;
-                    const bool bye = (uint32_t)(h >> 32) == 0xffffffffu && (uint32_t)h == myseq;
-                    if (tid < P) {
-                        const uint64_t w0 = ld_u64(&pub[1 + tid]);
-                        const uint64_t w1 = ld_u64(&pub[1 + kLaPubStride + tid]);
-                        const uint64_t w2 = ld_u64(&pub[1 + 2 * kLaPubStride + tid]);
-                        ready = ready && (uint32_t)(w0 >> 32) == tick && (uint32_t)(w1 >> 32) == tick && (uint32_t)(w2 >> 32) == tick;
-                        e_slot = (uint32_t)w0; e_x = (uint32_t)w1; e_d = (uint32_t)w2;
-                    }
-                    hdr = (uint32_t)h;
-                    if (__syncthreads_or(bye ? 1 : 0)) return;
-                    if (__syncthreads_and(ready ? 1 : 0)) { got = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (!got) return;                         // uniform: the votes are block-wide
-            }
-            ts[1] = wall_clock64();
-            // header payload: bit 31 = probe tick (only lambda is wanted: no scan, nothing stored),
-            // low 31 bits = (toggled column << 1 | entered), all ones = no toggle to apply
-            const bool probe = (hdr >> 31) != 0u;
-            const uint32_t togw = hdr & 0x7fffffffu;
-            const uint32_t tog_idx = togw == 0x7fffffffu ? 0xffffffffu : (togw >> 1);
-            const uint32_t tog_added = togw & 1u;
-            if (tid < P) { S.slt[tid] = e_slot; S.xs[tid] = __uint_as_float(e_x); S.ds[tid] = __uint_as_float(e_d); }
-            const uint32_t K = (uint32_t)__syncthreads_count((tid < P && e_slot != 0xffffffffu) ? 1 : 0);
-            ts[2] = wall_clock64();
-
-            // ---- c, q in Gram form; partial maximum of |c| ------------------------------------
-            float bv = -1.f;
-            uint32_t bi = 0xffffffffu;
-            float cv[kPsCols], qv[kPsCols];
-#pragma unroll
-            for (int k = 0; k < kPsCols; ++k) {
-                cv[k] = 0.f; qv[k] = 0.f;
-                if (!in[k]) continue;
-                if (col[k] == tog_idx) act[k] = tog_added;
-                // the row base is uniform (scalar registers), the column offset is this lane's constant
-                const uint32_t cofs = col[k];
-                auto grow = [&](uint32_t jj) -> float {
-                    const uint32_t sl = __builtin_amdgcn_readfirstlane(S.slt[jj]);
-                    return (gcache + (size_t)sl * gpitch)[cofs];
-                };
-                float ax = 0.f, ad = 0.f;
-                uint32_t j = 0;
-                for (; j + 32 <= K; j += 32) {
-                    float gv[32];
-#pragma unroll
-                    for (int u = 0; u < 32; ++u) gv[u] = grow(j + u);
-#pragma unroll
-                    for (int u = 0; u < 32; ++u) { ax += S.xs[j + u] * gv[u]; ad += S.ds[j + u] * gv[u]; }
-                }
-                for (; j + 8 <= K; j += 8) {
-                    float gv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) gv[u] = grow(j + u);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { ax += S.xs[j + u] * gv[u]; ad += S.ds[j + u] * gv[u]; }
-                }
-                for (; j < K; ++j) {
-                    const float gvv = grow(j);
-                    ax += S.xs[j] * gvv;
-                    ad += S.ds[j] * gvv;
-                }
-                cv[k] = c0v[k] - ax;
-                qv[k] = ad;
-                if (!probe) {
-                    st_f32(&c[col[k]], cv[k]);            // the master reads c, q on the support
-                    st_f32(&q[col[k]], qv[k]);
-                }
-                const float a = cv[k] < 0.f ? -cv[k] : cv[k];
-                if (better_max(a, col[k], bv, bi)) { bv = a; bi = col[k]; }
-            }
-            block_reduce_pair<float, true>(bv, bi, sv, si);
-            ts[3] = wall_clock64();
-            // ---- lambda = ||c||_inf: every worker posts its maximum in its own slot and reads all of them
-            const uint32_t par = (tick & 1u) * kLaSlotStride;
-            if (tid == 0)
-                st_u64(&smax[par + w], bi != 0xffffffffu ? (((uint64_t)__float_as_uint(bv) << 32) | (uint64_t)(0xffffffffu - bi)) : 0ull);
-            float c_inf;
-            {
-                float mv = -1.f;
-                uint32_t mi = 0xffffffffu;
-                bool ok = true;
-                for (uint32_t s0 = 0; s0 < nw; s0 += kPsThreads) {
-                    const uint32_t sidx = s0 + tid;
-                    uint64_t pk = 0ull;
-                    if (sidx < nw) {
-                        pk = kLaSlotEmpty;
-                        for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
-                            pk = ld_u64(&smax[par + sidx]);
-                            if (pk != kLaSlotEmpty) break;
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        if (pk == kLaSlotEmpty) { ok = false; pk = 0ull; }
-                    }
-                    if (pk != 0ull) {
-                        const float v = __uint_as_float((uint32_t)(pk >> 32));
-                        const uint32_t i2 = 0xffffffffu - (uint32_t)pk;
-                        if (better_max(v, i2, mv, mi)) { mv = v; mi = i2; }
-                    }
-                }
-                if (__syncthreads_or(ok ? 0 : 1)) return;          // a slot never filled: give up (uniform)
-                block_reduce_pair<float, true>(mv, mi, sv, si);
-                c_inf = mv;
-            }
-            ts[4] = wall_clock64();
-
-            // ---- step-length candidates of the inactive columns (same expressions as k_scansel) --
-            float best = Lim<float>::max();
-            uint32_t best_i = 0xffffffffu;
-#pragma unroll
-            for (int k = 0; k < kPsCols; ++k) {
-                if (!in[k] || probe) continue;
-                float m = Lim<float>::max();
-                if (!act[k]) {
-                    const float qi = qv[k], ci = cv[k];
-                    const float dl = 1.f - qi, dr = 1.f + qi;
-                    if (dl != 0.f) {
-                        float t = (c_inf - ci) / dl;
-                        if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
-                        if (t > 0.f && t < m) m = t;
-                    }
-                    if (dr != 0.f) {
-                        float t = (c_inf + ci) / dr;
-                        if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
-                        if (t > 0.f && t < m) m = t;
-                    }
-                }
-                tcand[col[k]] = (act[k] || cached[k]) ? Lim<float>::max() : m;
-                if (m < Lim<float>::max() && better_min(m, col[k], best, best_i)) { best = m; best_i = col[k]; }
-            }
-            block_reduce_pair<float, false>(best, best_i, sv, si);
-            drain_vmem();                                  // this wave's c, q stores are performed
-            __syncthreads();
-            if (tid == 0)
-                st_u64(&smin[par + w], best_i != 0xffffffffu ? (((uint64_t)__float_as_uint(best) << 32) | (uint64_t)best_i) : kLaSlotNone);
-            if (dbg != nullptr && w == 0 && tid == 0) {
-                ts[5] = wall_clock64();
-                for (int k2 = 0; k2 < 6; ++k2) dbg[(size_t)(1024u + (tick & 1023u)) * 8 + k2] = ts[k2];
-            }
+    for (int k = 0; k < kPsCols; ++k) {
+        col[k] = w * kPsThreads + tid + (uint32_t)k * nb * kPsThreads;
+        in[k] = col[k] < n;
+        c0v[k] = 0.f; act[k] = 0; cached[k] = false;
+        if (in[k]) {
+            c0v[k] = c0[col[k]];
+            act[k] = insup[col[k]];
+            cached[k] = slot_of[col[k]] >= 0;
         }
     }
 
-    // =============================================================================================
-    // master
-    // =============================================================================================
+    // ---- replica of the active set ---------------------------------------------------------------------
     const uint32_t cur = st->cur;
     float* const Ig = cur ? inv1 : inv0;
     uint32_t* const gam_cur = gam2 + (size_t)cur * kcap;
@@ -404,18 +266,101 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
     float c_inf_rep = (float)st->c_inf;      // what the report will carry
     float gamma_last = (float)st->gamma;
     uint32_t last_idx = st->idx, last_rank = st->rank, last_added = st->added;
-    uint32_t tog_idx = 0xffffffffu, tog_added = 0u;
     uint32_t done_round = 0u, status = 0u;
     // 1 = solve finished, 2 = Gram column missing, 3 = support outgrew the LDS tier, 4 = wait expired
     int exit_code = 0;
     bool report_empty = false;               // the support became empty (DevState::K = 0)
     bool save_lists_for_update = false;      // exit 2: the pick is made, the inverse update is pending
     uint32_t pend_rank = 0, pend_idx = 0;
-    uint64_t ts[8];
-
     bool pend = false, pend_added = false;   // the LDS inverse still has to take the last toggle
     uint32_t pend_rk = 0, pend_K = 0;
     float pend_dv = 0.f;
+    uint64_t ts[8];
+
+    // c, q of this thread's columns from the replica (Gram form), partial maximum of |c|
+    // (cdst, qdst: where the values are published for the other workgroups, or null)
+    auto gram_form = [&](float (&cv)[kPsCols], float (&qv)[kPsCols], float& bv, uint32_t& bi, float* cdst, float* qdst) {
+        bv = -1.f;
+        bi = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < kPsCols; ++k) {
+            cv[k] = 0.f; qv[k] = 0.f;
+            // whole waves only: the lanes exchange support entries below, so a lane without a column
+            // of its own computes along on column 0 and discards the result
+            if (__ballot(in[k]) == 0ull) continue;
+            // Each lane fetches one support entry (slot, x, d) from the replica; the loop then takes
+            // them out of the lanes as scalars: the row base of every load is uniform, its column
+            // offset is this lane's constant, and no LDS access sits between the loads.
+            const uint32_t cofs = in[k] ? col[k] : 0u;
+            float ax = 0.f, ad = 0.f;
+            for (uint32_t j0 = 0; j0 < K; j0 += 64) {
+                const uint32_t jl = j0 + (uint32_t)lane;
+                const uint32_t vs = jl < K ? S.slt[jl] : 0u;
+                const uint32_t vx = jl < K ? __float_as_uint(S.xs[jl]) : 0u;
+                const uint32_t vd = jl < K ? __float_as_uint(S.ds[jl]) : 0u;
+                const uint32_t cnt = K - j0 < 64u ? K - j0 : 64u;
+                auto grow = [&](uint32_t u) -> float {
+                    const uint32_t sl = __builtin_amdgcn_readlane(vs, u);
+                    return (gcache + (size_t)sl * gpitch)[cofs];
+                };
+                uint32_t u = 0;
+                for (; u + 32 <= cnt; u += 32) {
+                    float gv[32];
+#pragma unroll
+                    for (int t = 0; t < 32; ++t) gv[t] = grow(u + t);
+#pragma unroll
+                    for (int t = 0; t < 32; ++t) {
+                        ax += __uint_as_float(__builtin_amdgcn_readlane(vx, u + t)) * gv[t];
+                        ad += __uint_as_float(__builtin_amdgcn_readlane(vd, u + t)) * gv[t];
+                    }
+                }
+                for (; u + 8 <= cnt; u += 8) {
+                    float gv[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) gv[t] = grow(u + t);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        ax += __uint_as_float(__builtin_amdgcn_readlane(vx, u + t)) * gv[t];
+                        ad += __uint_as_float(__builtin_amdgcn_readlane(vd, u + t)) * gv[t];
+                    }
+                }
+                for (; u < cnt; ++u) {
+                    const float gvv = grow(u);
+                    ax += __uint_as_float(__builtin_amdgcn_readlane(vx, u)) * gvv;
+                    ad += __uint_as_float(__builtin_amdgcn_readlane(vd, u)) * gvv;
+                }
+            }
+            if (k == 0) ts[7] = wall_clock64();
+            if (!in[k]) continue;
+            cv[k] = c0v[k] - ax;
+            qv[k] = ad;
+            if (cdst != nullptr) {
+                st_f32(&cdst[col[k]], cv[k]);             // read across workgroups on the support
+                st_f32(&qdst[col[k]], qv[k]);
+            }
+            const float a = cv[k] < 0.f ? -cv[k] : cv[k];
+            if (better_max(a, col[k], bv, bi)) { bv = a; bi = col[k]; }
+        }
+        block_reduce_pair<float, true>(bv, bi, sv, si);
+    };
+    // lambda = ||c||_inf: post this workgroup's maximum, read all of them (false: a wait expired)
+    auto exchange_max = [&](uint32_t par, float bv, uint32_t bi, float& lam) -> bool {
+        float mv = -1.f;
+        uint32_t mi = 0xffffffffu;
+        const uint64_t mine = bi != 0xffffffffu ? (((uint64_t)__float_as_uint(bv) << 32) | (uint64_t)(0xffffffffu - bi)) : 0ull;
+        const bool ok = exchange_all(smax + par, nb, w, mine, [&](uint64_t pk) {
+            if (pk != 0ull) {
+                const float v = __uint_as_float((uint32_t)(pk >> 32));
+                const uint32_t i2 = 0xffffffffu - (uint32_t)pk;
+                if (better_max(v, i2, mv, mi)) { mv = v; mi = i2; }
+            }
+        });
+        if (!ok) return false;
+        block_reduce_pair<float, true>(mv, mi, sv, si);
+        lam = mv;
+        return true;
+    };
+
     for (;;) {
         if (K + 1u > P && P < kcap) {
             if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
@@ -424,66 +369,48 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
         }
         ++tick;
         const uint32_t round = iter + 1u;
+        const uint32_t par = (tick & 1u) * kLaSlotStride, par_prev = ((tick + 1u) & 1u) * kLaSlotStride;
         ts[0] = wall_clock64();
 
-        // ---- publish the support's (slot, x, d) and the previous toggle: every word tagged with the tick --
-        {
-            const uint64_t tag = (uint64_t)tick << 32;
-            if (tid < P) {
-                st_u64(&pub[1 + tid], tag | (uint64_t)(tid < K ? S.slt[tid] : 0xffffffffu));
-                st_u64(&pub[1 + kLaPubStride + tid], tag | (uint64_t)__float_as_uint(tid < K ? S.xs[tid] : 0.f));
-                st_u64(&pub[1 + 2 * kLaPubStride + tid], tag | (uint64_t)__float_as_uint(tid < K ? S.ds[tid] : 0.f));
-            }
-            if (tid == 0) st_u64(&pub[0], tag | (uint64_t)(tog_idx == 0xffffffffu ? 0x7fffffffu : ((tog_idx << 1) | tog_added)));
-        }
+        // ---- c, q of the own columns; lambda ----------------------------------------------------------
+        // c, q cross workgroups through the buffer of this tick's parity: a workgroup may already be
+        // writing the next tick's values while a slower one still reads this tick's on the support
+        float* const cbuf = (tick & 1u) ? c_alt : c;
+        float* const qbuf = (tick & 1u) ? q_alt : q;
+        float cv[kPsCols], qv[kPsCols];
+        float bv, c_inf;
+        uint32_t bi;
+        gram_form(cv, qv, bv, bi, cbuf, qbuf);
         ts[1] = wall_clock64();
-        // the workers are busy now: bring the stored inverse up to date with the last toggle
-        if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
-
-        // ---- candidates of the active columns, -x_j / d_j (homotopy-cpu.cpp:128-135) -----------------
-        float best = Lim<float>::max();
-        uint32_t best_i = 0xffffffffu;
-        if (tid < K) {
-            const float t = -S.xs[tid] / S.ds[tid];
-            if (t > 0.f && t < Lim<float>::max()) { best = t; best_i = S.gam[tid]; }
-        }
-        block_reduce_pair<float, false>(best, best_i, sv, si);
-
-        // ---- collect every worker's (min gamma, idx) and maximum; clear the slots of the next tick ------
-        const uint32_t par = (tick & 1u) * kLaSlotStride, par_next = ((tick + 1u) & 1u) * kLaSlotStride;
-        float c_inf = -1.f, tw = Lim<float>::max();
-        uint32_t ci_idx = 0xffffffffu, iw = 0xffffffffu;
+        if (tid == 0) st_u64(&smax[par + w], bi != 0xffffffffu ? (((uint64_t)__float_as_uint(bv) << 32) | (uint64_t)(0xffffffffu - bi)) : 0ull);
         {
+            float mv = -1.f;
+            uint32_t mi = 0xffffffffu;
             bool ok = true;
-            for (uint32_t s0 = 0; s0 < nw; s0 += kPsThreads) {
+            for (uint32_t s0 = 0; s0 < nb; s0 += kPsThreads) {
                 const uint32_t sidx = s0 + tid;
-                if (sidx < nw) {
-                    uint64_t pk = kLaSlotEmpty, pm = 0ull;
+                if (sidx < nb) {
+                    uint64_t pk = kLaSlotEmpty;
                     for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
-                        pm = ld_u64(&smax[par + sidx]);                 // posted before the worker's minimum
-                        pk = ld_u64(&smin[par + sidx]);
+                        pk = ld_u64(&smax[par + sidx]);
                         if (pk != kLaSlotEmpty) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
                     if (pk == kLaSlotEmpty) ok = false;
-                    else if (pk != kLaSlotNone) {
+                    else if (pk != 0ull) {
                         const float v = __uint_as_float((uint32_t)(pk >> 32));
-                        const uint32_t i2 = (uint32_t)pk;
-                        if (better_min(v, i2, tw, iw)) { tw = v; iw = i2; }
+                        const uint32_t i2 = 0xffffffffu - (uint32_t)pk;
+                        if (better_max(v, i2, mv, mi)) { mv = v; mi = i2; }
                     }
-                    if (pm != 0ull && pm != kLaSlotEmpty) {
-                        const float v = __uint_as_float((uint32_t)(pm >> 32));
-                        const uint32_t i2 = 0xffffffffu - (uint32_t)pm;
-                        if (better_max(v, i2, c_inf, ci_idx)) { c_inf = v; ci_idx = i2; }
-                    }
-                    st_u64(&smax[par_next + sidx], kLaSlotEmpty);
-                    st_u64(&smin[par_next + sidx], kLaSlotEmpty);
                 }
             }
             if (__syncthreads_or(ok ? 0 : 1)) { exit_code = 4; break; }
-            block_reduce_pair<float, false>(tw, iw, sv, si);
-            block_reduce_pair<float, true>(c_inf, ci_idx, sv, si);
+            block_reduce_pair<float, true>(mv, mi, sv, si);
+            c_inf = mv;
         }
+        // every workgroup is past the previous step-length exchange (it posted a maximum after it):
+        // this workgroup's slot of that exchange can be cleared for its next use
+        if (tid == 0) st_u64(&smin[par_prev + w], kLaSlotEmpty);
         ts[2] = wall_clock64();
 
         // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
@@ -495,11 +422,76 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
             break;
         }
 
-        // ---- final (gamma, idx): smallest positive candidate, left-most index (:123-124) -------------
-        float g = best;
-        uint32_t idx = best_i;
-        if (iw != 0xffffffffu && better_min(tw, iw, g, idx)) { g = tw; idx = iw; }
+        // ---- step-length candidates: own inactive columns (same expressions as k_scansel) ... ----------
+        float best = Lim<float>::max();
+        uint32_t best_i = 0xffffffffu;
+        float mk[kPsCols];
+#pragma unroll
+        for (int k = 0; k < kPsCols; ++k) {
+            mk[k] = Lim<float>::max();
+            if (!in[k]) continue;
+            float m = Lim<float>::max();
+            if (!act[k]) {
+                const float qi = qv[k], ci = cv[k];
+                const float dl = 1.f - qi, dr = 1.f + qi;
+                if (dl != 0.f) {
+                    float t = (c_inf - ci) / dl;
+                    if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
+                    if (t > 0.f && t < m) m = t;
+                }
+                if (dr != 0.f) {
+                    float t = (c_inf + ci) / dr;
+                    if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
+                    if (t > 0.f && t < m) m = t;
+                }
+            }
+            mk[k] = m;
+            if (m < Lim<float>::max() && better_min(m, col[k], best, best_i)) { best = m; best_i = col[k]; }
+        }
+        drain_vmem();                                      // this wave's c, q stores are performed (issued long ago)
+        block_reduce_pair<float, false>(best, best_i, sv, si);
+        if (tid == 0)
+            st_u64(&smin[par + w], best_i != 0xffffffffu ? (((uint64_t)__float_as_uint(best) << 32) | (uint64_t)best_i) : kLaSlotNone);
+        // per-column candidates for k_la_top's ranking: nobody reads them inside the launch
+#pragma unroll
+        for (int k = 0; k < kPsCols; ++k)
+            if (in[k]) tcand[col[k]] = (act[k] || cached[k]) ? Lim<float>::max() : mk[k];
+        // while the candidates travel: bring the stored inverse up to date with the last toggle
+        if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
+        // ... and the active columns, -x_j / d_j (homotopy-cpu.cpp:128-135), from the replica
+        float g = Lim<float>::max();
+        uint32_t idx = 0xffffffffu;
+        if (tid < K) {
+            const float t = -S.xs[tid] / S.ds[tid];
+            if (t > 0.f && t < Lim<float>::max()) { g = t; idx = S.gam[tid]; }
+        }
+        {
+            bool ok = true;
+            for (uint32_t s0 = 0; s0 < nb; s0 += kPsThreads) {
+                const uint32_t sidx = s0 + tid;
+                if (sidx < nb) {
+                    uint64_t pk = kLaSlotEmpty;
+                    for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
+                        pk = ld_u64(&smin[par + sidx]);
+                        if (pk != kLaSlotEmpty) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (pk == kLaSlotEmpty) ok = false;
+                    else if (pk != kLaSlotNone) {
+                        const float v = __uint_as_float((uint32_t)(pk >> 32));
+                        const uint32_t i2 = (uint32_t)pk;
+                        if (better_min(v, i2, g, idx)) { g = v; idx = i2; }
+                    }
+                }
+            }
+            if (__syncthreads_or(ok ? 0 : 1)) { exit_code = 4; break; }
+            // final (gamma, idx): smallest positive candidate, left-most index (:123-124)
+            block_reduce_pair<float, false>(g, idx, sv, si);
+        }
+        // every workgroup has read all maxima of this tick (it posted its candidate after that)
+        if (tid == 0) st_u64(&smax[par + w], kLaSlotEmpty);
         if (!(g < Lim<float>::max())) idx = 0u;
+        ts[3] = wall_clock64();
 
         // rank of idx in the sorted support, membership (rank_index.h:65-83)
         if (tid < 2) s_cnt[tid] = 0u;
@@ -513,7 +505,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
         const uint32_t rank = s_cnt[0];
         const bool added = s_cnt[1] == 0u;
         const uint32_t K_new = added ? K + 1u : K - 1u;
-        if (trace != nullptr && tid == 0 && round < trace_cap) {
+        if (lead && trace != nullptr && tid == 0 && round < trace_cap) {
             trace[round].idx = idx;
             trace[round].added = added ? 1u : 0u;
             trace[round].gamma = (double)g;
@@ -522,7 +514,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
         if (K_new == 0u || K_new > kcap) {
             // homotopy-cpu.cpp:248-249 (support became empty: break before x is updated) / workspace full
             if (K_new == 0u) {
-                if (tid == 0) insup[idx] = 0;
+                if (lead && tid == 0) insup[idx] = 0;
                 report_empty = true;                     // the lists keep the one column: its x is handed back
                 last_idx = idx; last_rank = rank; last_added = 0u; gamma_last = g;
                 iter = round;
@@ -538,8 +530,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
 
         // loads that only need idx: c, q on the support (and at idx), the cache slot of idx
         float cj = 0.f, qj = 0.f;
-        if (tid < K) { cj = ld_f32(&c[S.gam[tid]]); qj = ld_f32(&q[S.gam[tid]]); }
-        else if (tid == K && added) { cj = ld_f32(&c[idx]); qj = ld_f32(&q[idx]); }
+        if (tid < K) { cj = ld_f32(&cbuf[S.gam[tid]]); qj = ld_f32(&qbuf[S.gam[tid]]); }
+        else if (tid == K && added) { cj = ld_f32(&cbuf[idx]); qj = ld_f32(&qbuf[idx]); }
         int32_t slot = 0;
         if (added) slot = slot_of[idx];
 
@@ -548,64 +540,49 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
             const float xn = S.xs[tid] + g * S.ds[tid];
             S.xs[tid] = (!added && tid == rank) ? 0.f : xn;
         }
-        if (tid == 0) insup[idx] = added ? 1 : 0;
+        if (lead && tid == 0) insup[idx] = added ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < kPsCols; ++k)
+            if (in[k] && col[k] == idx) act[k] = added ? 1u : 0u;
         iter = round;
         c_inf_rep = c_inf;
         gamma_last = g;
         last_idx = idx; last_rank = rank; last_added = added ? 1u : 0u;
         __syncthreads();
-        ts[3] = wall_clock64();
 
         if (added && slot < 0) {
             // No cached Gram column.  Before A is swept for it: the while-test of this iteration only
             // needs lambda = ||A^T(y - A x)||_inf for the x just updated, and the entering column
-            // carries x = 0, so a probe tick over the old support answers it exactly.  If the solve
-            // ends here (homotopy-cpu.cpp:272) the pending inverse update would never be used.
+            // carries x = 0, so a probe exchange over the old support answers it exactly.  If the
+            // solve ends here (homotopy-cpu.cpp:272) the pending inverse update would never be used.
             ++tick;
+            const uint32_t par2 = (tick & 1u) * kLaSlotStride, par2_prev = ((tick + 1u) & 1u) * kLaSlotStride;
+            float pv, lam;
+            uint32_t pi;
+            float pc[kPsCols], pq[kPsCols];
+            gram_form(pc, pq, pv, pi, nullptr, nullptr); // c, q, tcand stay those of the iteration
+            if (!exchange_max(par2, pv, pi, lam)) { exit_code = 4; break; }
+            if (tid == 0) st_u64(&smin[par2_prev + w], kLaSlotEmpty);
+            // the probe has no step-length exchange of its own: an (empty-handed) one keeps the
+            // slot discipline — it proves every workgroup has read the probe's maxima
             {
-                const uint64_t tag = (uint64_t)tick << 32;
-                if (tid < P) {
-                    st_u64(&pub[1 + tid], tag | (uint64_t)(tid < K ? S.slt[tid] : 0xffffffffu));
-                    st_u64(&pub[1 + kLaPubStride + tid], tag | (uint64_t)__float_as_uint(tid < K ? S.xs[tid] : 0.f));
-                    st_u64(&pub[1 + 2 * kLaPubStride + tid], tag | 0ull);
-                }
-                if (tid == 0) st_u64(&pub[0], tag | 0xffffffffull);      // probe, no toggle
+                const bool ok = exchange_all(smin + par2, nb, w, kLaSlotNone, [&](uint64_t) {});
+                if (!ok) { exit_code = 4; break; }
             }
-            float lam = -1.f;
-            uint32_t lam_i = 0xffffffffu;
-            {
-                const uint32_t par2 = (tick & 1u) * kLaSlotStride, par2n = ((tick + 1u) & 1u) * kLaSlotStride;
-                bool ok = true;
-                for (uint32_t s0 = 0; s0 < nw; s0 += kPsThreads) {
-                    const uint32_t sidx = s0 + tid;
-                    if (sidx < nw) {
-                        uint64_t pk = kLaSlotEmpty, pm = 0ull;
-                        for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
-                            pm = ld_u64(&smax[par2 + sidx]);
-                            pk = ld_u64(&smin[par2 + sidx]);
-                            if (pk != kLaSlotEmpty) break;
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        if (pk == kLaSlotEmpty) ok = false;
-                        if (pm != 0ull && pm != kLaSlotEmpty) {
-                            const float v = __uint_as_float((uint32_t)(pm >> 32));
-                            const uint32_t i2 = 0xffffffffu - (uint32_t)pm;
-                            if (better_max(v, i2, lam, lam_i)) { lam = v; lam_i = i2; }
-                        }
-                        st_u64(&smax[par2n + sidx], kLaSlotEmpty);
-                        st_u64(&smin[par2n + sidx], kLaSlotEmpty);
-                    }
-                }
-                if (__syncthreads_or(ok ? 0 : 1)) { exit_code = 4; break; }
-                block_reduce_pair<float, true>(lam, lam_i, sv, si);
-            }
+            if (tid == 0) st_u64(&smax[par2 + w], kLaSlotEmpty);
             if (!(lam > tol) || round + 1u > max_iter) {
                 c_inf_rep = lam;                         // iter = round already
                 done_round = round + 1u;
                 exit_code = 1;
                 break;
             }
-            // the path goes on: hand the pending inverse update to k_gramupd
+            // the path goes on: hand the pending inverse update to k_gramupd, which reads the
+            // iteration's c and q from the primary buffers
+            if (cbuf != c) {
+#pragma unroll
+                for (int k = 0; k < kPsCols; ++k)
+                    if (in[k]) { c[col[k]] = cv[k]; q[col[k]] = qv[k]; }
+            }
             save_lists_for_update = true;
             pend_rank = rank;
             pend_idx = idx;
@@ -679,7 +656,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
             __syncthreads();
             for (uint32_t i = tid; i < nn; i += kPsThreads) S.u2[i] = S.I[i * Pp + rank] * sc;
             // the column that left: exact zeros in the dense vectors, out of the lists
-            if (tid == 0) { x[idx] = 0.f; d[idx] = 0.f; }
+            if (lead && tid == 0) { x[idx] = 0.f; d[idx] = 0.f; }
             if (tid < K) S.cn[tid] = cnv;
             __syncthreads();
             uint32_t ng = 0, ns = 0;
@@ -695,8 +672,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
         ts[5] = wall_clock64();
         // sign(c[Gamma]) with dead zone tol (homotopy-cpu.cpp:259-260), direction = inv * sign (:263).
         // The new inverse is not stored yet: its elements are formed on the fly, by the same
-        // expressions the store pass uses, so that the next iteration can be published at once;
-        // the store pass runs while the workers are busy with it.
+        // expressions the store pass uses, so that the next iteration can start at once; the store
+        // pass runs while that iteration's maxima travel.
         if (tid < K_new) S.sg[tid] = sign_tol(S.cn[tid], tol);
         __syncthreads();
         for (uint32_t a0 = wave; a0 < K_new; a0 += 4 * NW) {
@@ -719,19 +696,15 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
         __syncthreads();
         pend = true; pend_added = added; pend_rk = rank; pend_dv = dv; pend_K = K_new;
         K = K_new;
-        tog_idx = idx;
-        tog_added = added ? 1u : 0u;
-        if (dbg != nullptr && tid == 0 && round < 1024u) {
+        if (dbg != nullptr && lead && tid == 0 && round < 1024u) {
             ts[6] = wall_clock64();
-            ts[7] = K;
+            ts[7] = ((ts[7] - ts[0]) << 16) | K;        // debug: time to the end of the Gram-form loads, support size
             for (int k2 = 0; k2 < 8; ++k2) dbg[(size_t)round * 8 + k2] = ts[k2];
         }
     }
 
-    // ---- end of the launch: release the workers, hand the state back in the global layout -----------
-    // (exit 3 broke out before taking a new tick, so `tick` is the last published one in every case)
-    if (tid == 0) st_u64(&pub[0], (0xffffffffull << 32) | (uint64_t)myseq);
-    const uint32_t tick_out = tick;
+    // ---- end of the launch: workgroup 0 hands the state back in the global layout --------------------
+    if (!lead) return;
     if (save_lists_for_update) {
         // the pick is made (x updated, K_new columns) but the inverse still describes the old support:
         // buffer `cur` keeps the old support and inverse, buffer cur^1 receives the new sorted support
@@ -753,7 +726,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
         d[cl] = S.ds[tid];
     }
     if (tid == 0) {
-        sy->tick = tick_out;
+        sy->tick = tick;
         st->K = report_empty ? 0u : (save_lists_for_update ? K + 1u : K);
         st->iter = iter;
         st->c_inf = (double)c_inf_rep;
@@ -783,7 +756,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
 // ---- host side -------------------------------------------------------------------------------------
 static size_t persist_lds_bytes(uint32_t P) { return ps_lds_words(P) * sizeof(float); }
 
-// worker workgroups the device can keep resident next to the master for LDS tier P (0: unusable)
+// workgroups of k_la_persist the device can keep resident for LDS tier P (0: unusable)
 static int persist_workers(ss_hip_ctx* ctx, uint32_t P)
 {
     const int tier = P > kLaLdsSmall ? 1 : 0;
@@ -802,7 +775,7 @@ static int persist_workers(ss_hip_ctx* ctx, uint32_t P)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_la_persist, kPsThreads, lds) == hipSuccess && per_cu > 0) {
         // keep a margin: at most 2 workgroups per CU, and never the last resident slot
         const long cap = (long)std::min(per_cu, 2) * ctx->num_cus - 1;
-        result = (int)std::min<long>(kLaSlotStride, std::max<long>(0, cap - 1));
+        result = (int)std::min<long>(kLaSlotStride, std::max<long>(0, cap));
     } else {
         (void)hipGetLastError();
     }
@@ -830,16 +803,15 @@ hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float to
 {
     const uint32_t P = lds_cols;
     const uint32_t nw = persist_grid_workers(ctx, P);
-    if (nw == 0 || P > kLaLdsLarge || P > kLaPubStride) return hipErrorInvalidConfiguration;
+    if (nw == 0 || P > kLaLdsLarge || ws.cq_alt == nullptr) return hipErrorInvalidConfiguration;
     // the LDS tier fixes the allocation (and with it the residency the grid was sized for)
     const size_t lds = persist_lds_bytes(P > kLaLdsSmall ? kLaLdsLarge : kLaLdsSmall);
-    uint64_t* pub = reinterpret_cast<uint64_t*>(ws.la_sync + 1);
-    uint64_t* smax = pub + kLaPubWords;
+    uint64_t* smax = reinterpret_cast<uint64_t*>(ws.la_sync + 1);
     uint64_t* smin = smax + 2 * kLaSlotStride;
-    hipLaunchKernelGGL(k_la_persist, dim3(nw + 1), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P,
+    hipLaunchKernelGGL(k_la_persist, dim3(nw), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P,
                        (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
-                       ws.c, ws.q, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
-                       ws.la_sync, pub, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg);
+                       ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
+                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg);
     return hipGetLastError();
 }
 

@@ -33,16 +33,65 @@ __device__ __forceinline__ bool better_min(T v, uint32_t i, T bv, uint32_t bi)
     return v < bv || (v == bv && i < bi);
 }
 
+// ---- wave-level data movement on the DPP path (one VALU op each; __shfl_xor goes through the
+// ---- LDS crossbar, ~100 cycles per step) ---------------------------------------------------------
+// Within a row of 16 lanes: xor 1, xor 2 (quad permutes), then mirror within 8 and within 16 —
+// applied to values that are already uniform per quad / per 8 these complete the butterfly.
+constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;   // row_half_mirror
+constexpr int kDppMirror = 0x140;       // row_mirror
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) { return __uint_as_float(dpp_mov<CTRL>(__float_as_uint(v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = dpp_mov<CTRL>((uint32_t)b), hi = dpp_mov<CTRL>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float lane_value(float v, int l) { return __uint_as_float(lane_value(__float_as_uint(v), l)); }
+__device__ __forceinline__ double lane_value(double v, int l)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = lane_value((uint32_t)b, l), hi = lane_value((uint32_t)(b >> 32), l);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// every lane receives the best (value, index) pair of the wave
 template <typename T, bool MAX>
 __device__ __forceinline__ void wave_reduce_pair(T& v, uint32_t& i)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const T ov = __shfl_xor(v, off, 64);
-        const uint32_t oi = __shfl_xor(i, off, 64);
-        const bool take = MAX ? better_max(ov, oi, v, i) : better_min(ov, oi, v, i);
-        if (take) { v = ov; i = oi; }
+#define SSHIP_PAIR_STEP(CTRL)                                                                   \
+    {                                                                                           \
+        const T ov = dpp_mov<CTRL>(v);                                                          \
+        const uint32_t oi = dpp_mov<CTRL>(i);                                                   \
+        const bool take = MAX ? better_max(ov, oi, v, i) : better_min(ov, oi, v, i);            \
+        if (take) { v = ov; i = oi; }                                                           \
     }
+    SSHIP_PAIR_STEP(kDppXor1)
+    SSHIP_PAIR_STEP(kDppXor2)
+    SSHIP_PAIR_STEP(kDppHalfMirror)
+    SSHIP_PAIR_STEP(kDppMirror)
+#undef SSHIP_PAIR_STEP
+    // the four rows (the order of a max / min with its index tie-break does not matter)
+    T bv = lane_value(v, 0);
+    uint32_t bi = lane_value(i, 0);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        const T ov = lane_value(v, 16 * r);
+        const uint32_t oi = lane_value(i, 16 * r);
+        const bool take = MAX ? better_max(ov, oi, bv, bi) : better_min(ov, oi, bv, bi);
+        if (take) { bv = ov; bi = oi; }
+    }
+    v = bv;
+    i = bi;
 }
 
 // all threads of the block receive the reduced pair; sv/si: LDS scratch of >= 16 entries
@@ -66,12 +115,16 @@ __device__ __forceinline__ void block_reduce_pair(T& v, uint32_t& i, T* sv, uint
     i = bi;
 }
 
+// Sum over the wave, the same value in every lane.  Fixed association: butterfly inside each row
+// of 16 lanes (1, 2, 4, 8 apart), then ((row0 + row1) + row2) + row3.
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov<kDppXor1>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppHalfMirror>(v);
+    v += dpp_mov<kDppMirror>(v);
+    return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
 }
 
 template <typename T>

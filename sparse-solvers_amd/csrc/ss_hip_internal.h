@@ -20,6 +20,11 @@ constexpr uint32_t kRowPad = 256;
 // Columns are padded (zero-filled) to a multiple of this so the sweep needs no tail code
 // and the MFMA GEMM of the batched path sees whole 128-column tiles.
 constexpr uint32_t kColPad = 256;
+// DevState::status raised by the lookahead engine when the tolerance is too tight for Gram-form
+// correlations (never leaves the library: the host re-runs the solve in residual form).
+constexpr uint32_t kStatusRetryResidual = 100;
+// Gram form is used while tolerance >= kGramGuard * ||A^T y||_inf (2^-14: fp32 eps x ~1000).
+constexpr double kGramGuard = 1.0 / 16384.0;
 // Hard cap of the active-set capacity (workspace is 2 * Kcap^2 elements).
 constexpr uint32_t kKcapLimit = 4096;
 // Upper bound of workgroups any sweep variant launches (size of the partial-max arrays).
@@ -70,20 +75,15 @@ struct LaSync {
     uint32_t pad_[31];
 };
 static_assert(sizeof(LaSync) == 128, "LaSync layout");
-// The allocation continues with the published iteration — 64-bit words (tick << 32 | payload): one
-// header word (previous toggle, or 0xffffffff << 32 | launch seq to end the launch) and three
-// arrays of kLaPubStride words (cache slot, x, d of each support column); a reader polls the
-// words it needs until they all carry the tick it waits for — and the per-worker offer slots: smax[2][kLaSlotStride], smin[2][kLaSlotStride] (64-bit,
-// indexed by tick parity and worker).  A worker posts (bits(max |c_i|) << 32 | ~i) and later
-// (bits(min t_i) << 32 | i) in its own slots; the master sets the slots of the next tick back to
-// "empty" before it publishes it.  No read-modify-write atomics: 2 x 256 of them per iteration on
-// one cache line cost more than everything else in the iteration.
+// The allocation continues with the per-workgroup offer slots smax[2][kLaSlotStride] and
+// smin[2][kLaSlotStride] (64-bit, indexed by tick parity and workgroup).  A workgroup posts
+// (bits(max |c_i|) << 32 | ~i) and later (bits(min t_i) << 32 | i) in its own slots and reads
+// everybody's; it sets a slot back to "empty" two exchanges later.  No read-modify-write atomics:
+// 2 x 256 of them per iteration on one cache line cost more than everything else in the iteration.
 constexpr uint32_t kLaSlotStride = 512;                       // workers at most
 constexpr uint64_t kLaSlotEmpty = ~0ull;                      // not posted yet
 constexpr uint64_t kLaSlotNone = 0x7f7fffffffffffffull;       // posted: no step-length candidate
-constexpr uint32_t kLaPubWords = 1 + 3 * 256;                 // header + three arrays of kLaPubStride
-constexpr size_t kLaSyncBytes = 128 + (size_t)kLaPubWords * 8 + 4 * 512 * 8;
-constexpr uint32_t kLaPubStride = 256;    // published (slot, x, d) triples: three arrays of this many words
+constexpr size_t kLaSyncBytes = 128 + 4 * 512 * 8;
 constexpr uint32_t kLaLdsSmall = 96;      // support sizes the resident kernel holds in LDS: first tier ...
 constexpr uint32_t kLaLdsLarge = 192;     // ... and the one that takes a whole CU's LDS
 
@@ -142,7 +142,8 @@ struct Workspace {
     T* c0 = nullptr;              // [n_pad] A^T y
     T* tcand = nullptr;           // [n_pad] per-column step-length candidate of the last scan
     uint32_t* sw_list = nullptr;  // [64] rcols[32] then drows[32] of the next lookahead sweep
-    LaSync* la_sync = nullptr;    // hand-off area of k_la_persist, followed by the published triples
+    LaSync* la_sync = nullptr;    // hand-off area of k_la_persist, followed by the offer slots
+    T* cq_alt = nullptr;          // [2][n_pad] second (c, q) pair: k_la_persist alternates by tick parity
     uint64_t* la_dbg = nullptr;   // [1024][8] stage timestamps of k_la_iter (option "la_debug"), else null
     uint32_t la_nparts = 0;       // partial maxima written by the last k_la_cq launch
     uint32_t* tile_skip = nullptr; // [b_pad/128 + 1] compact list of GEMM row tiles with a running signal + count
@@ -177,7 +178,7 @@ struct ss_hip_ctx {
     int profiling = 0;
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
     long cache_mib = 2048;   // budget of the lookahead engine's Gram-column cache
-    int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns), 0 = one fused sweep per iteration
+    int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns) unless the tolerance is too tight for it, 2 = lookahead always, 0 = one fused sweep per iteration
     int la_fused = 2;        // lookahead engine: 2 = resident kernel (k_la_persist), 1 = one kernel per iteration (k_la_iter), 0 = scan / update / cq kernels
     int batch_min = 4;       // batches of at least this many fp32 signals run in lock-step on the MFMA GEMM
     int batch_chunk = 4096;  // signals processed together by the batched path
@@ -228,7 +229,7 @@ hipError_t launch_omp_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsl
                            uint32_t nparts, T tol, uint32_t max_iter);
 // lookahead engine launchers (activeset.hip); see homotopy.hip for the round structure
 template <typename T>
-hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts);
+hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol);
 template <typename T>
 hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode);
 template <typename T>

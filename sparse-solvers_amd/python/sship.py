@@ -48,6 +48,7 @@ class Stats(ctypes.Structure):
         ("sweep32_launches", ctypes.c_uint64),
         ("sweep32_ms", ctypes.c_double),
         ("sweep32_bytes", ctypes.c_uint64),
+        ("gram_fallbacks", ctypes.c_uint64),
     ]
 
 
