@@ -175,6 +175,7 @@ typedef struct ss_hip_stats {
     double   sweep32_ms;           /* sum of their durations                                    */
     uint64_t sweep32_bytes;        /* algorithmic bytes of ONE lookahead sweep: m*n*s + 32*m*s + 32*n*s */
     uint64_t gram_fallbacks;       /* solves re-run in residual form: tolerance too tight for Gram-form correlations */
+    uint64_t persist_fallbacks;    /* solves re-run without the resident kernel (its grid was not resident)         */
 } ss_hip_stats;
 
 /* profiling != 0: bracket every sweep launch with HIP events on the context's stream. */

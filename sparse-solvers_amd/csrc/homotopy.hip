@@ -323,7 +323,8 @@ template <> struct Lookahead<float> {
         const uint32_t gpitch = (ctx->n_pad + 1023u) / 1024u * 1024u;
         // every sweep caches up to 32 columns; a solve needs at most one sweep per inserted column
         uint64_t want = 32ull * ((uint64_t)kcap + 2);
-        const uint64_t budget = (uint64_t)ctx->cache_mib << 20;
+        // (the resident kernel addresses cache rows with 32-bit byte offsets: stay below 4 GiB)
+        const uint64_t budget = std::min<uint64_t>((uint64_t)ctx->cache_mib << 20, (4095ull << 20));
         const uint64_t fit = std::max<uint64_t>(64, budget / ((uint64_t)gpitch * sizeof(T)));
         if (want > fit) want = fit;
         if (ws.gcache && ws.gcap >= want && ws.gpitch == gpitch) return;
@@ -527,7 +528,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             uint32_t lds_cols = 0;
             const uint32_t kcap_ws = ws.dims.kcap;       // what the device checks K against (>= this solve's kcap)
             if (ctx->la_fused >= 2 && ctx->zero_on_removal) {
-                lds_cols = std::min<uint32_t>(kcap_ws, kLaLdsSmall);
+                lds_cols = std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsSmall);
                 if (!la_persist_usable(ctx, lds_cols)) lds_cols = 0;
             }
             const uint64_t max_launch = 4 * ((uint64_t)max_iter + 2) + 64;
@@ -553,7 +554,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 }
                 if (lds_cols != 0 && hf[3] > lds_cols) {
                     // the support outgrew the tier: take the large one, or go on one launch per iteration
-                    const uint32_t big = std::min<uint32_t>(kcap_ws, kLaLdsLarge);
+                    const uint32_t big = std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsLarge);
                     lds_cols = (hf[3] <= big && big > lds_cols && la_persist_usable(ctx, big)) ? big : 0u;
                 }
                 if (enq >= max_launch) { stuck = true; break; }
@@ -628,6 +629,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             // tolerance too tight for Gram-form correlations (see k_la_init_pick): residual form
             ctx->stats.gram_fallbacks += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, true);
+        }
+        if (la && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 2 && (ctx->persist_workers[0] != 0 || ctx->persist_workers[1] != 0)) {
+            // the resident kernel gave up on a wait (its grid was not fully resident): this context
+            // goes on with one launch per iteration
+            ctx->persist_workers[0] = 0;
+            ctx->persist_workers[1] = 0;
+            ctx->stats.persist_fallbacks += 1;
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual);
         }
         if (hs.status != 0) {
             set_err(err, errlen, hs.status == SS_HIP_ECAPACITY

@@ -44,6 +44,8 @@
 namespace sship {
 
 constexpr int kPsThreads = 512;
+constexpr uint32_t kPsWidth = 256;              // columns a workgroup owns per pass (threads 0..255 carry them)
+constexpr uint32_t kPsLdsBudget = 160 * 1024 - 1024;   // dynamic LDS a workgroup may take (static scratch aside)
 constexpr int kPsCols = 2;                      // columns a thread owns at most
 constexpr uint32_t kPsSpinLimit = 1u << 20;     // polls (~1 us each) before a wait gives up
 
@@ -77,7 +79,9 @@ __device__ __forceinline__ void drain_vmem()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// LDS carve-up (floats / 32-bit words), P = columns the launch can hold
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// LDS carve-up (floats / 32-bit words), P = columns the launch can hold (a multiple of 16)
 struct PsLds {
     float* I;        // [P][P + 1] explicit inverse, sorted-support order (master)
     uint32_t* gam;   // [P] sorted support (master)
@@ -88,8 +92,9 @@ struct PsLds {
     float* u2;       // [P]
     float* sg;       // [P] sign vector
     float* cn;       // [P] correlations after the step, support order
+    v2f* xd;         // [P] (x, d) pairs, what the Gram-form loop reads
 };
-__host__ __device__ inline size_t ps_lds_words(uint32_t P) { return (size_t)P * (P + 1) + 8 * (size_t)P; }
+__host__ __device__ inline size_t ps_lds_words(uint32_t P) { return (size_t)P * (P + 1) + 10 * (size_t)P; }
 
 // four independent wave sums (same order of additions as wave_sum)
 __device__ __forceinline__ void wave_sum4(float (&v)[4])
@@ -179,7 +184,7 @@ __device__ __forceinline__ bool exchange_all(uint64_t* slots, uint32_t nb, uint3
 }
 
 __global__ __launch_bounds__(kPsThreads)
-void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
+void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t gl_rows,
                   const float* __restrict__ gcache, const int32_t* __restrict__ slot_of,
                   const float* __restrict__ c0, uint32_t gpitch,
                   float* c, float* q, float* c_alt, float* q_alt, float* x, float* d, uint8_t* insup,
@@ -208,6 +213,9 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
     S.u2 = S.u1 + P;
     S.sg = S.u2 + P;
     S.cn = S.sg + P;
+    S.xd = reinterpret_cast<v2f*>(S.cn + P);
+    // the workgroup's slice of the first gl_rows cache rows: [gl_rows][kPsWidth]
+    float* const Glds = reinterpret_cast<float*>(S.xd + P);
 
     // ---- nothing to do in this launch? (same answer in every workgroup: DevState was written
     // ---- by earlier launches only) --------------------------------------------------------------
@@ -230,8 +238,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
     float c0v[kPsCols];
 #pragma unroll
     for (int k = 0; k < kPsCols; ++k) {
-        col[k] = w * kPsThreads + tid + (uint32_t)k * nb * kPsThreads;
-        in[k] = col[k] < n;
+        col[k] = w * kPsWidth + (tid & (kPsWidth - 1u)) + (uint32_t)k * nb * kPsWidth;
+        in[k] = tid < kPsWidth && col[k] < n;
         c0v[k] = 0.f; act[k] = 0; cached[k] = false;
         if (in[k]) {
             c0v[k] = c0[col[k]];
@@ -257,10 +265,40 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
         const uint32_t cl = gam_cur[tid];
         S.gam[tid] = cl;
         S.slt[tid] = (uint32_t)slot_of[cl];
-        S.xs[tid] = x[cl];
-        S.ds[tid] = d[cl];
+        const float x0 = x[cl], d0 = d[cl];
+        S.xs[tid] = x0;
+        S.ds[tid] = d0;
+        S.xd[tid] = v2f{ x0, d0 };
+    } else if (tid < P) {
+        S.xd[tid] = v2f{ 0.f, 0.f };                 // padding of the Gram-form loop (whole groups of 16)
     }
     __syncthreads();
+    // the Gram-column cache as a buffer: row offsets go in the scalar offset of the loads
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gcache), 0, -1, 0x00020000);
+    // This workgroup's slice of the cached Gram rows, kept in LDS for the whole launch: the per-CU
+    // limit on outstanding L1 misses makes K row reads from L2 cost ~40 ns each, every iteration.
+    const uint32_t gl_used = st->cache_used < gl_rows ? st->cache_used : gl_rows;
+    {
+        const uint32_t tcol = tid & (kPsWidth - 1u), half = tid / kPsWidth;          // two rows per pass
+        const uint32_t cg = w * kPsWidth + tcol;
+        const uint32_t cofs4 = (cg < n ? cg : 0u) * 4u;
+        for (uint32_t r0 = 0; r0 < gl_used; r0 += 16) {
+            float gv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint32_t r = r0 + 2u * t + half;
+                gv[t] = 0.f;
+                if (r < gl_used) gv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, cofs4, r * (gpitch * 4u), 0));
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint32_t r = r0 + 2u * t + half;
+                if (r < gl_used) Glds[r * kPsWidth + tcol] = gv[t];
+            }
+        }
+    }
+    __syncthreads();
+    if (dbg != nullptr && lead && tid == 0) { dbg[0] = gl_used; dbg[1] = nb; dbg[2] = gl_rows; dbg[3] = K0; }
 
     uint32_t iter = st->iter;
     float c_inf_rep = (float)st->c_inf;      // what the report will carry
@@ -288,48 +326,46 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
             // whole waves only: the lanes exchange support entries below, so a lane without a column
             // of its own computes along on column 0 and discards the result
             if (__ballot(in[k]) == 0ull) continue;
-            // Each lane fetches one support entry (slot, x, d) from the replica; the loop then takes
-            // them out of the lanes as scalars: the row base of every load is uniform, its column
-            // offset is this lane's constant, and no LDS access sits between the loads.
-            const uint32_t cofs = in[k] ? col[k] : 0u;
-            float ax = 0.f, ad = 0.f;
-            for (uint32_t j0 = 0; j0 < K; j0 += 64) {
+            // Each lane fetches one cache slot of the support from the replica; the loop takes them out
+            // of the lanes as scalars and uses them as the scalar offset of a buffer load (the column
+            // offset is this lane's constant), so no vector ALU work goes into addressing.  (x, d) come
+            // as one LDS broadcast; multiply and add are the packed forms of the separate roundings.
+            const uint32_t cofs4 = (in[k] ? col[k] : 0u) * 4u;
+            v2f acc = { 0.f, 0.f };
+            // (entries K .. K16-1 are padding: x = d = 0 on a valid row, they add exact zeros)
+            const uint32_t K16 = (K + 15u) & ~15u;
+            const uint32_t lds_lim = k == 0 ? gl_used : 0u;   // rows below it are in the LDS slice (first column set)
+            const uint32_t tcol = tid & (kPsWidth - 1u);
+            for (uint32_t j0 = 0; j0 < K16; j0 += 64) {
                 const uint32_t jl = j0 + (uint32_t)lane;
-                const uint32_t vs = jl < K ? S.slt[jl] : 0u;
-                const uint32_t vx = jl < K ? __float_as_uint(S.xs[jl]) : 0u;
-                const uint32_t vd = jl < K ? __float_as_uint(S.ds[jl]) : 0u;
-                const uint32_t cnt = K - j0 < 64u ? K - j0 : 64u;
-                auto grow = [&](uint32_t u) -> float {
-                    const uint32_t sl = __builtin_amdgcn_readlane(vs, u);
-                    return (gcache + (size_t)sl * gpitch)[cofs];
-                };
-                uint32_t u = 0;
-                for (; u + 32 <= cnt; u += 32) {
-                    float gv[32];
+                const uint32_t vs = S.slt[jl < K ? jl : 0u];
+                const uint32_t cnt = K16 - j0 < 64u ? K16 - j0 : 64u;
+                const v2f* xdp = S.xd + j0;
+                const uint64_t out_of_lds = __ballot(vs >= lds_lim);      // lanes whose row must come from L2
+                for (uint32_t u = 0; u < cnt; u += 16) {
+                    float gv[16];
+                    if (((out_of_lds >> u) & 0xffffull) == 0ull) {
+                        // all sixteen rows in LDS: no branches, sixteen reads in flight
 #pragma unroll
-                    for (int t = 0; t < 32; ++t) gv[t] = grow(u + t);
+                        for (int t = 0; t < 16; ++t) gv[t] = Glds[__builtin_amdgcn_readlane(vs, u + t) * kPsWidth + tcol];
+                    } else {
 #pragma unroll
-                    for (int t = 0; t < 32; ++t) {
-                        ax += __uint_as_float(__builtin_amdgcn_readlane(vx, u + t)) * gv[t];
-                        ad += __uint_as_float(__builtin_amdgcn_readlane(vd, u + t)) * gv[t];
+                        for (int t = 0; t < 16; ++t) {
+                            const uint32_t sl = __builtin_amdgcn_readlane(vs, u + t);
+                            gv[t] = 0.f;
+                            if (sl >= lds_lim) gv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, cofs4, sl * (gpitch * 4u), 0));
+                        }
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const uint32_t sl = __builtin_amdgcn_readlane(vs, u + t);
+                            if (sl < lds_lim) gv[t] = Glds[sl * kPsWidth + tcol];
+                        }
                     }
-                }
-                for (; u + 8 <= cnt; u += 8) {
-                    float gv[8];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) gv[t] = grow(u + t);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        ax += __uint_as_float(__builtin_amdgcn_readlane(vx, u + t)) * gv[t];
-                        ad += __uint_as_float(__builtin_amdgcn_readlane(vd, u + t)) * gv[t];
-                    }
-                }
-                for (; u < cnt; ++u) {
-                    const float gvv = grow(u);
-                    ax += __uint_as_float(__builtin_amdgcn_readlane(vx, u)) * gvv;
-                    ad += __uint_as_float(__builtin_amdgcn_readlane(vd, u)) * gvv;
+                    for (int t = 0; t < 16; ++t) acc += xdp[u + t] * v2f{ gv[t], gv[t] };
                 }
             }
+            const float ax = acc.x, ad = acc.y;
             if (k == 0) ts[7] = wall_clock64();
             if (!in[k]) continue;
             cv[k] = c0v[k] - ax;
@@ -560,6 +596,9 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
             float pv, lam;
             uint32_t pi;
             float pc[kPsCols], pq[kPsCols];
+            if (tid < K) S.xd[tid] = v2f{ S.xs[tid], 0.f };
+            else if (tid < P) S.xd[tid] = v2f{ 0.f, 0.f };
+            __syncthreads();
             gram_form(pc, pq, pv, pi, nullptr, nullptr); // c, q, tcand stay those of the iteration
             if (!exchange_max(par2, pv, pi, lam)) { exit_code = 4; break; }
             if (tid == 0) st_u64(&smin[par2_prev + w], kLaSlotEmpty);
@@ -694,6 +733,9 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
             }
         }
         __syncthreads();
+        if (tid < K_new) S.xd[tid] = v2f{ S.xs[tid], S.ds[tid] };
+        else if (tid < P) S.xd[tid] = v2f{ 0.f, 0.f };
+        __syncthreads();
         pend = true; pend_added = added; pend_rk = rank; pend_dv = dv; pend_K = K_new;
         K = K_new;
         if (dbg != nullptr && lead && tid == 0 && round < 1024u) {
@@ -754,7 +796,19 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P,
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-static size_t persist_lds_bytes(uint32_t P) { return ps_lds_words(P) * sizeof(float); }
+// LDS of a launch: the replica of the active set for the tier, the rest (whole rows) for the
+// workgroup's slice of the cached Gram rows
+static uint32_t persist_tier_cols(uint32_t P) { return P > kLaLdsSmall ? kLaLdsLarge : kLaLdsSmall; }
+static uint32_t persist_gl_rows(uint32_t P)
+{
+    const size_t replica = ps_lds_words(persist_tier_cols(P)) * sizeof(float);
+    if (replica >= kPsLdsBudget) return 0;
+    return (uint32_t)((kPsLdsBudget - replica) / (kPsWidth * sizeof(float))) & ~15u;
+}
+static size_t persist_lds_bytes(uint32_t P)
+{
+    return ps_lds_words(persist_tier_cols(P)) * sizeof(float) + (size_t)persist_gl_rows(P) * kPsWidth * sizeof(float);
+}
 
 // workgroups of k_la_persist the device can keep resident for LDS tier P (0: unusable)
 static int persist_workers(ss_hip_ctx* ctx, uint32_t P)
@@ -762,19 +816,18 @@ static int persist_workers(ss_hip_ctx* ctx, uint32_t P)
     const int tier = P > kLaLdsSmall ? 1 : 0;
     if (ctx->persist_workers[tier] >= 0) return ctx->persist_workers[tier];
     int result = 0;
-    const size_t lds = persist_lds_bytes(tier ? kLaLdsLarge : kLaLdsSmall);
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_la_persist),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->persist_workers[tier] = 0;
-            return 0;
-        }
+    const size_t lds = persist_lds_bytes(P);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_la_persist),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPsLdsBudget) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->persist_workers[tier] = 0;
+        return 0;
     }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_la_persist, kPsThreads, lds) == hipSuccess && per_cu > 0) {
-        // keep a margin: at most 2 workgroups per CU, and never the last resident slot
-        const long cap = (long)std::min(per_cu, 2) * ctx->num_cus - 1;
+        // the whole grid must be resident: at most what the occupancy allows (a launch that does not
+        // get there gives up through its bounded waits and the solve falls back to k_la_iter)
+        const long cap = (long)std::min(per_cu, 2) * ctx->num_cus;
         result = (int)std::min<long>(kLaSlotStride, std::max<long>(0, cap));
     } else {
         (void)hipGetLastError();
@@ -787,9 +840,9 @@ static uint32_t persist_grid_workers(ss_hip_ctx* ctx, uint32_t P)
 {
     const uint32_t n = (uint32_t)ctx->n;
     const uint32_t cap = (uint32_t)persist_workers(ctx, P);
-    const uint32_t want = (n + kPsThreads - 1) / kPsThreads;
+    const uint32_t want = (n + kPsWidth - 1) / kPsWidth;
     const uint32_t nw = std::min(want, cap);
-    if (nw == 0 || (uint64_t)nw * kPsThreads * kPsCols < n) return 0;
+    if (nw == 0 || (uint64_t)nw * kPsWidth * kPsCols < n) return 0;
     return nw;
 }
 
@@ -805,10 +858,10 @@ hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float to
     const uint32_t nw = persist_grid_workers(ctx, P);
     if (nw == 0 || P > kLaLdsLarge || ws.cq_alt == nullptr) return hipErrorInvalidConfiguration;
     // the LDS tier fixes the allocation (and with it the residency the grid was sized for)
-    const size_t lds = persist_lds_bytes(P > kLaLdsSmall ? kLaLdsLarge : kLaLdsSmall);
+    const size_t lds = persist_lds_bytes(P);
     uint64_t* smax = reinterpret_cast<uint64_t*>(ws.la_sync + 1);
     uint64_t* smin = smax + 2 * kLaSlotStride;
-    hipLaunchKernelGGL(k_la_persist, dim3(nw), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P,
+    hipLaunchKernelGGL(k_la_persist, dim3(nw), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, persist_gl_rows(P),
                        (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
                        ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg);

@@ -49,6 +49,7 @@ class Stats(ctypes.Structure):
         ("sweep32_ms", ctypes.c_double),
         ("sweep32_bytes", ctypes.c_uint64),
         ("gram_fallbacks", ctypes.c_uint64),
+        ("persist_fallbacks", ctypes.c_uint64),
     ]
 
 

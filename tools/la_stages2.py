@@ -6,6 +6,7 @@ a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(2048, 8)
 rows = [r for r in range(1, 1024) if a[r, 0] != 0 and a[r, 6] > a[r, 0]]
 names = ["c,q (gram form)", "lambda exchange", "scan + step exchange", "pick, x, loads", "u2, d, lists", "sign + direction"]
 d = np.array([[(int(a[r, k + 1]) - int(a[r, k])) / 100.0 for k in range(6)] for r in rows])
+print("launch info (last): lds rows used %d, workgroups %d, lds rows %d, K at entry %d" % tuple(int(v) for v in a[0, :4]))
 print("iterations recorded:", len(rows))
 for k, nme in enumerate(names):
     print("  %-22s mean %6.2f us   min %6.2f   max %6.2f" % (nme, d[:, k].mean(), d[:, k].min(), d[:, k].max()))
