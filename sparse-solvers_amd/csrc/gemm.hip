@@ -147,13 +147,14 @@ void k_gemm_tn_f32(const float* __restrict__ R, const float* __restrict__ Q, flo
 // output row s goes to D + drows[s]*ldd (scattered into the Gram-column cache).
 // Tile 32 x 256 x 32 per 256-thread workgroup: wave w owns dictionary columns [64w, 64w+64) as
 // two 32x32 MFMA tiles; same K-contiguous ds_read_b128 feeding as above.
-constexpr int HM = 32, HN = 256, HT = 512;
+constexpr int HM = 32;
 
 // One workgroup per CU (83 KiB LDS), 8 waves, each wave one 32x32 accumulator (32 dictionary
 // columns).  To keep enough HBM requests in flight from a single workgroup the global loads
 // run THREE K-steps ahead through a ring of register sets (3 x 36 KiB per workgroup), LDS is
 // double buffered, one barrier per K-step.
-__global__ __launch_bounds__(HT, 1)
+template <int HN, int HT, int BPC>
+__global__ __launch_bounds__(HT, BPC)
 void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
                      const uint32_t* __restrict__ drows, float* __restrict__ D,
                      uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
@@ -166,7 +167,9 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t h = lane >> 5, l31 = lane & 31u;
-    const uint32_t srow = tid >> 3, squad = tid & 7u;          // staging: rows srow + 64j, k-quad squad
+    constexpr int RPP = HT / 8;                                 // rows staged per pass
+    constexpr int NJ = HN / RPP;                                // passes per column tile
+    const uint32_t srow = tid >> 3, squad = tid & 7u;          // staging: rows srow + RPP*j, k-quad squad
     const bool has_r = tid < 256;                               // R tile: 32 rows x 8 quads
 
     const uint32_t rc = rcols[srow & 31u];
@@ -181,20 +184,20 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
-        v4f rR[3], rQ[3][4];
+        v4f rR[3], rQ[3][NJ];
 #define G32_LOAD(SET, KT)                                                                      \
     {                                                                                          \
         const uint32_t koff_ = (KT) * GK;                                                      \
         rR[SET] = rvalid ? *reinterpret_cast<const v4f*>(gR + koff_) : zero4;                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                         \
             rQ[SET][j] = __builtin_nontemporal_load(                                           \
-                reinterpret_cast<const v4f*>(gQ + (size_t)(64 * j) * ldq + koff_));            \
+                reinterpret_cast<const v4f*>(gQ + (size_t)(RPP * j) * ldq + koff_));           \
     }
 #define G32_STORE(SET, BUF)                                                                    \
     {                                                                                          \
         if (has_r) *reinterpret_cast<v4f*>(&sR[BUF][srow][squad * 4]) = rR[SET];               \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
-            *reinterpret_cast<v4f*>(&sQ[BUF][srow + 64 * j][squad * 4]) = rQ[SET][j];          \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                         \
+            *reinterpret_cast<v4f*>(&sQ[BUF][srow + RPP * j][squad * 4]) = rQ[SET][j];         \
     }
 #define G32_COMPUTE(BUF)                                                                       \
     _Pragma("unroll") for (int g = 0; g < GK / 8; ++g) {                                       \
@@ -261,12 +264,28 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
 hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
                                 float* D, uint32_t ldd, const DevState* st)
 {
-    if (ctx->n_pad % HN != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
-    const uint32_t ntiles = ctx->n_pad / HN;
-    const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
-    hipLaunchKernelGGL(k_gemm32_tn_f32, dim3(grid), dim3(HT), 0, ctx->stream,
-                       static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles,
-                       st);
+    if (ctx->n_pad % 256 != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
+    const float* At = static_cast<const float*>(ctx->At);
+    if (ctx->sweep32_variant == 0) {
+        // one 256-column tile per workgroup of 512 threads, one workgroup per CU
+        const uint32_t ntiles = ctx->n_pad / 256;
+        const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
+        hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1>), dim3(grid), dim3(512), 0, ctx->stream,
+                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+    } else {
+        // 128-column tiles, 256 threads, several workgroups per CU: one's barrier waits are
+        // another's compute
+        const uint32_t ntiles = ctx->n_pad / 128;
+        const uint32_t per_cu = ctx->sweep32_variant == 1 ? 2u : 3u;
+        const uint32_t cap = per_cu * (uint32_t)ctx->num_cus;
+        const uint32_t grid = ntiles < cap ? ntiles : cap;
+        if (ctx->sweep32_variant == 1)
+            hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 2>), dim3(grid), dim3(256), 0, ctx->stream,
+                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+        else
+            hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3>), dim3(grid), dim3(256), 0, ctx->stream,
+                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+    }
     return hipGetLastError();
 }
 

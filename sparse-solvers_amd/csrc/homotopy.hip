@@ -1146,6 +1146,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { ctx->cache_mib = std::max<long>(16, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }
@@ -1195,6 +1196,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     }
     if (!std::strcmp(key, "engine"))        { *value = ctx->engine; return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { *value = ctx->la_fused; return SS_HIP_OK; }
+    if (!std::strcmp(key, "sweep32_variant")) { *value = ctx->sweep32_variant; return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { *value = ctx->cache_mib; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { *value = ctx->batch_chunk; return SS_HIP_OK; }
