@@ -229,8 +229,8 @@ def main():
                 tj = json.load(open(tpath))
             except Exception:
                 tj = {}
-        if engine == 1:
-            # dominant kernel of the lookahead engine: the 32-RHS sweep G = A^T [a_j1 .. a_j32]
+        if engine >= 1:
+            # dominant HBM kernel of the lookahead engine: the 32-RHS sweep G = A^T [a_j1 .. a_j32]
             launches, ms_sum, nbytes = st["sweep32_launches"], st["sweep32_ms"], st["sweep32_bytes"]
             kname = "k_gemm32_tn_f32: lookahead sweep, 32 Gram columns A^T a_j per pass over A (fp32 MFMA, HBM-bound)"
             traffic = tj.get("gemm32_hbm_bytes_per_launch")
@@ -242,6 +242,7 @@ def main():
         achieved = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         s1_ms = st["sweep1_ms"] / max(1, st["sweep1_launches"])
         s1_gbs = st["sweep1_bytes"] / (s1_ms * 1e-3) / 1e9 if s1_ms > 0 else 0.0
+        ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "signals recovered/sec (Homotopy l1, m=8192 n=65536 k=64 fp32)",
             "value": world * args.steps / elapsed,
@@ -280,9 +281,16 @@ def main():
                          "avg_launch_ms": s1_ms, "launches_timed": st["sweep1_launches"]},
             "sweeps_per_solve": {"lookahead_32rhs": st["lookahead_sweeps"] / max(1, st["solves"]),
                                  "atr_1rhs": 1, "reference_gemv_per_iteration": 4},
+            # where a solve's time goes (event-timed sweeps; the rest is the resident iteration kernel
+            # k_la_persist, which is latency-bound: two all-to-all exchanges per iteration)
+            "ms_per_solve": {"total": ms_per_step,
+                             "atr_1rhs_sweep": s1_ms,
+                             "lookahead_sweeps": avg_ms * st["lookahead_sweeps"] / max(1, st["solves"]) if engine >= 1 else None,
+                             "iterations_and_rest": (ms_per_step - s1_ms - avg_ms * st["lookahead_sweeps"] / max(1, st["solves"])) if engine >= 1 else None,
+                             "us_per_iteration": (1e3 * (ms_per_step - s1_ms - avg_ms * st["lookahead_sweeps"] / max(1, st["solves"])) / max(1.0, st["iterations"] / max(1, st["solves"]))) if engine >= 1 else None},
             "batched": batched,
             "iterations_mean": float(iters.mean()),
-            "engine": "lookahead (cached Gram columns)" if engine == 1 else "one fused sweep per iteration",
+            "engine": "lookahead (cached Gram columns), resident iteration kernel" if engine >= 1 else "one fused sweep per iteration",
             "recovered": {"signals": world * args.steps, "support_exact": recovered_total,
                           "max_rel_coef_err_rank0": coef_err, "gathered_records_ok": bool(gather_ok)},
         }

@@ -463,13 +463,24 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
     // cached yet and only idx is active.
     T v1 = Lim<T>::max(), v2 = Lim<T>::max();
     uint32_t i1 = 0xffffffffu, i2 = 0xffffffffu;
-    for (uint32_t i = tid; i < n; i += kUpdThreads) {
-        T v;
-        if (init_mode) { const T a = c[i] < T(0) ? -c[i] : c[i]; v = -a; }
-        else v = tcand[i];
-        if (i == idx) v = -Lim<T>::max();                       // the entering column always wins
-        if (better_min(v, i, v1, i1)) { v2 = v1; i2 = i1; v1 = v; i1 = i; }
-        else if (better_min(v, i, v2, i2)) { v2 = v; i2 = i; }
+    const T* __restrict__ src = init_mode ? c : tcand;
+    for (uint32_t i0 = tid; i0 < n; i0 += 8 * kUpdThreads) {
+        T raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                               // eight independent loads in flight
+            const uint32_t i = i0 + (uint32_t)u * kUpdThreads;
+            raw[u] = i < n ? src[i] : Lim<T>::max();
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * kUpdThreads;
+            if (i >= n) break;
+            T v = raw[u];
+            if (init_mode) v = v < T(0) ? v : -v;                   // -|c0|: large correlations first
+            if (i == idx) v = -Lim<T>::max();                       // the entering column always wins
+            if (better_min(v, i, v1, i1)) { v2 = v1; i2 = i1; v1 = v; i1 = i; }
+            else if (better_min(v, i, v2, i2)) { v2 = v; i2 = i; }
+        }
     }
     // stage 1: every wave extracts the 6 best of its 128 offers (wave-level reductions only)
     constexpr int kPerWave = 6;
