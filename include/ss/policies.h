@@ -82,6 +82,62 @@ namespace ss
             state_type<double>&, const ndspan<double>, double, uint32_t, ndspan<double>);
     };
 
+    /* IRLS ---------------------------------------------------------------- */
+
+    /* reference: include/ss/policies.h:58-72 */
+    struct irls_report
+    {
+        /* The number of iterations performed. */
+        uint32_t iter;
+
+        /* The solution error */
+        double solution_error;
+
+        /* Whether IRLS stopped because an iteration met a matrix that is not symmetric
+           positive definite (no full Cholesky decomposition). */
+        bool spd_failure;
+    };
+
+    inline bool operator== (const irls_report&, const irls_report&) { return false; }
+
+    /* Device-side state of one IRLS solver (reference: irls_state holds the QR decomposition of
+       A, policies.h:77-85): the factorisation lives on the MI355X.  Needs rows >= columns. */
+    template <typename T>
+    class irls_device_state
+    {
+      public:
+        explicit irls_device_state(const ndspan<T, 2> A, int device = 0);
+        ~irls_device_state();
+
+        irls_device_state(const irls_device_state&) = delete;
+        irls_device_state& operator=(const irls_device_state&) = delete;
+
+        ss_hip_ctx* ctx() const { return _ctx; }
+        size_t rows() const { return _m; }
+        size_t cols() const { return _n; }
+        const std::string& error() const { return _error; }
+
+      private:
+        ss_hip_ctx* _ctx;
+        size_t      _m, _n;
+        std::string _error;
+    };
+
+    /* A solver policy which implements the Iteratively Reweighted Least Squares method
+       (reference: policies.h:88-100) */
+    struct irls_policy
+    {
+        using report_type = irls_report;
+
+        template <typename T> using state_type = irls_device_state<T>;
+
+        static kernelpp::maybe<irls_report> run(
+            state_type<float>&, const ndspan<float>, float, uint32_t, ndspan<float>);
+
+        static kernelpp::maybe<irls_report> run(
+            state_type<double>&, const ndspan<double>, double, uint32_t, ndspan<double>);
+    };
+
     /* A solver policy which implements the homotopy method on an MI355X */
     struct homotopy_policy
     {

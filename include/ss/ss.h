@@ -77,6 +77,9 @@ namespace ss
     /* orthogonal matching pursuit — an addition, the reference has no OMP */
     template <typename T> using omp = solver<T, omp_policy>;
 
+    /* iteratively reweighted least squares (reference: ss.h:63-64); rows(A) >= columns(A) */
+    template <typename T> using irls = solver<T, irls_policy>;
+
 
     /* y = A x: rebuilds a signal from its sparse representation (reference: ss.h:67-83).
        A is m x n, x has n entries, y receives m entries. */

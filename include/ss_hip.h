@@ -178,6 +178,27 @@ typedef struct ss_hip_stats {
     uint64_t persist_fallbacks;    /* solves re-run without the resident kernel (its grid was not resident)         */
 } ss_hip_stats;
 
+/* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------
+ *
+ * Replaces construction of solver<T, irls_policy>'s state — irls_state(A) = qr_decomposition<T>(A)
+ * (include/ss/policies.h:77-85, src/lib.cpp:51-57, src/linalg/qr_decomposition.h:93-139) — and
+ * solve_irls::op<mode, T> (src/solvers/irls.h:27-38).  Requires m >= n (the reference asserts it).
+ * create: uploads A like ss_hip_homotopy_create_*, factorises it on the device (Householder QR,
+ * thin Q, R, Q^T Q).  solve: outputs are irls_report{iter, solution_error, spd_failure}
+ * (policies.h:58-72); x is normalised to sum 1 like the reference's (irls-cpu.cpp:121).
+ * An IRLS context is not a Homotopy context: each family of entry points rejects the other's. */
+ss_hip_ctx* ss_hip_irls_create_f32(const float* A, size_t m, size_t n, ptrdiff_t stride_row, ptrdiff_t stride_col,
+                                   int device, char* err, size_t errlen);
+ss_hip_ctx* ss_hip_irls_create_f64(const double* A, size_t m, size_t n, ptrdiff_t stride_row, ptrdiff_t stride_col,
+                                   int device, char* err, size_t errlen);
+int ss_hip_irls_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_t incy, float tolerance, uint32_t max_iterations,
+                          float* x, ptrdiff_t incx, uint32_t* iter_out, double* solution_error_out,
+                          int* spd_failure_out, char* err, size_t errlen);
+int ss_hip_irls_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy, double tolerance, uint32_t max_iterations,
+                          double* x, ptrdiff_t incx, uint32_t* iter_out, double* solution_error_out,
+                          int* spd_failure_out, char* err, size_t errlen);
+void ss_hip_irls_destroy(ss_hip_ctx* ctx);
+
 /* profiling != 0: bracket every sweep launch with HIP events on the context's stream. */
 int ss_hip_set_profiling(ss_hip_ctx* ctx, int profiling);
 int ss_hip_get_stats(ss_hip_ctx* ctx, ss_hip_stats* out);

@@ -37,7 +37,7 @@ class _Trace(ctypes.Structure):
 
 def build(force=False):
     """Compile libss_oracle.so with the committed Makefile (gcc, a few seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("ss_oracle.c", "ss_oracle_impl.inc", "ss_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ss_oracle.c", "ss_oracle_impl.inc", "ss_oracle_irls.inc", "ss_oracle.h")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
@@ -93,6 +93,19 @@ def lib():
             g = getattr(L, "ss_oracle_square_permute_" + suf)
             g.restype = None
             g.argtypes = [vp, sz, sz, sz]
+            for name, args, res in (
+                    ("ss_oracle_qr_", [vp, sz, sz, vp, vp], None),
+                    ("ss_oracle_qr_q_", [vp, sz, sz, vp], None),
+                    ("ss_oracle_qr_r_", [vp, vp, sz, vp], None),
+                    ("ss_oracle_qr_solve_", [vp, vp, sz, sz, vp, vp], None),
+                    ("ss_oracle_cholesky_", [vp, sz, vp], ctypes.c_int),
+                    ("ss_oracle_cholesky_solve_", [vp, sz, vp, vp], None),
+                    ("ss_oracle_irls_", [vp, sz, sz, vp, ct, ctypes.c_uint32, vp,
+                                         ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_int)], ctypes.c_int)):
+                g = getattr(L, name + suf)
+                g.argtypes = args
+                g.restype = res
         L.ss_oracle_erase_last_rowcol_f32.restype = None
         L.ss_oracle_erase_last_rowcol_f32.argtypes = [vp, sz, sz]
         L.ss_oracle_insert_last_rowcol_f32.restype = None
@@ -315,3 +328,80 @@ class RankIndex:
 
     def size(self):
         return lib().ss_oracle_rank_index_size(self._h)
+
+
+# ---- IRLS and the factorisations under it (ss_oracle_irls.inc) ---------------------------------
+
+def _rowmajor(A):
+    A = np.ascontiguousarray(A)
+    _suffix(A.dtype)
+    return A
+
+
+class QR:
+    """qr_decomposition<T> (qr_decomposition.h:93-227): Householder QR of an M x N matrix, M >= N."""
+
+    def __init__(self, A):
+        A = _rowmajor(A)
+        self.M, self.N = A.shape
+        assert self.M >= self.N
+        self.suf = _suffix(A.dtype)
+        self.qr = np.empty_like(A)
+        self.rdiag = np.empty(self.N, A.dtype)
+        getattr(lib(), "ss_oracle_qr_" + self.suf)(A.ctypes.data, self.M, self.N, self.qr.ctypes.data,
+                                                   self.rdiag.ctypes.data)
+
+    def q(self):
+        q = np.empty_like(self.qr)
+        getattr(lib(), "ss_oracle_qr_q_" + self.suf)(self.qr.ctypes.data, self.M, self.N, q.ctypes.data)
+        return q
+
+    def r(self):
+        r = np.empty((self.N, self.N), self.qr.dtype)
+        getattr(lib(), "ss_oracle_qr_r_" + self.suf)(self.qr.ctypes.data, self.rdiag.ctypes.data, self.N,
+                                                     r.ctypes.data)
+        return r
+
+    def solve(self, b):
+        b = np.ascontiguousarray(b, dtype=self.qr.dtype)
+        x = np.empty(self.N, self.qr.dtype)
+        getattr(lib(), "ss_oracle_qr_solve_" + self.suf)(self.qr.ctypes.data, self.rdiag.ctypes.data, self.M,
+                                                         self.N, b.ctypes.data, x.ctypes.data)
+        return x
+
+
+def cholesky(A):
+    """cholesky_decomposition<T> (cholesky_decomposition.h:56-83) -> (L lower, isspd)"""
+    A = _rowmajor(A)
+    N = A.shape[0]
+    L = np.empty_like(A)
+    ok = getattr(lib(), "ss_oracle_cholesky_" + _suffix(A.dtype))(A.ctypes.data, N, L.ctypes.data)
+    return L, bool(ok)
+
+
+def cholesky_solve(L, b):
+    L = _rowmajor(L)
+    b = np.ascontiguousarray(b, dtype=L.dtype)
+    x = np.empty_like(b)
+    getattr(lib(), "ss_oracle_cholesky_solve_" + _suffix(L.dtype))(L.ctypes.data, L.shape[0], b.ctypes.data,
+                                                                   x.ctypes.data)
+    return x
+
+
+def irls(A, y, tolerance, max_iterations):
+    """run_solver<T> of irls-cpu.cpp:63-124 on the CPU -> (x, iter, solution_error (eps), spd_failure)"""
+    A = _rowmajor(A)
+    y = np.ascontiguousarray(y)
+    if y.dtype != A.dtype:
+        raise TypeError("dtype of y must match A")
+    M, N = A.shape
+    x = np.zeros(N, A.dtype)
+    it = ctypes.c_uint32(0)
+    eps = ctypes.c_double(0.0)
+    spd = ctypes.c_int(0)
+    rc = getattr(lib(), "ss_oracle_irls_" + _suffix(A.dtype))(
+        A.ctypes.data, M, N, y.ctypes.data, tolerance, int(max_iterations), x.ctypes.data,
+        ctypes.byref(it), ctypes.byref(eps), ctypes.byref(spd))
+    if rc != 0:
+        raise RuntimeError("oracle irls failed with code %d" % rc)
+    return x, int(it.value), float(eps.value), bool(spd.value)

@@ -19,21 +19,27 @@
 #define SUF    f32
 #define T_MAX  FLT_MAX
 #define T_EPS  FLT_EPSILON
+#define T_HYPOT hypotf
 #include "ss_oracle_impl.inc"
+#include "ss_oracle_irls.inc"
 #undef T
 #undef SUF
 #undef T_MAX
 #undef T_EPS
+#undef T_HYPOT
 
 #define T      double
 #define SUF    f64
 #define T_MAX  DBL_MAX
 #define T_EPS  DBL_EPSILON
+#define T_HYPOT hypot
 #include "ss_oracle_impl.inc"
+#include "ss_oracle_irls.inc"
 #undef T
 #undef SUF
 #undef T_MAX
 #undef T_EPS
+#undef T_HYPOT
 
 int ss_oracle_num_threads(void)
 {

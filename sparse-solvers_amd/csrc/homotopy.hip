@@ -240,8 +240,13 @@ void ensure_workspace(ss_hip_ctx* ctx, uint32_t nslots, uint32_t kcap)
 
 template <typename T>
 ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, int device,
-                        char* err, size_t errlen)
+                        char* err, size_t errlen, int kind = 0)
 {
+    if (kind == 1 && m < n) {
+        // irls-cpu.cpp / qr_decomposition.h:101 assert M >= N ("underdetermined systems not supported")
+        set_err(err, errlen, "ss_hip_irls_create: IRLS needs a matrix with at least as many rows as columns");
+        return nullptr;
+    }
     if (!A || m == 0 || n == 0) {
         set_err(err, errlen, "ss_hip_homotopy_create: A must be a non-empty m x n matrix");
         return nullptr;
@@ -282,7 +287,9 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
         HIPCHK(hipMemsetAsync(ctx->At, 0, bytes, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         upload_matrix<T>(ctx, A, rs, cs);
-        ensure_workspace<T>(ctx, 1, 64);
+        ctx->kind = kind;
+        if (kind == 1) HIPCHK(irls_factor<T>(ctx));
+        else ensure_workspace<T>(ctx, 1, 64);
         HIPCHK(hipHostMalloc(&ctx->host_flags, 64 * sizeof(uint32_t), hipHostMallocMapped));
         std::memset(ctx->host_flags, 0, 64 * sizeof(uint32_t));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->dev_flags), ctx->host_flags, 0));
@@ -441,6 +448,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                bool omp = false, bool force_residual = false)
 {
     if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
+    if (ctx->kind != 0) { set_err(err, errlen, "solve: this context was created for IRLS"); return SS_HIP_EINVAL; }
     if (ctx->is_f64 != (sizeof(T) == 8)) {
         set_err(err, errlen, "solve: element type of the call does not match the context");
         return SS_HIP_ETYPE;
@@ -847,6 +855,7 @@ int solve_batch_impl(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, 
                      double* err_out, char* err, size_t errlen)
 {
     if (!ctx) { set_err(err, errlen, "solve_batch: null context"); return SS_HIP_EINVAL; }
+    if (ctx->kind != 0) { set_err(err, errlen, "solve_batch: this context was created for IRLS"); return SS_HIP_EINVAL; }
     if (ctx->is_f64 != (sizeof(T) == 8)) { set_err(err, errlen, "solve_batch: element type mismatch"); return SS_HIP_ETYPE; }
     if (!Y || !X) { set_err(err, errlen, "solve_batch: Y and X must not be null"); return SS_HIP_EINVAL; }
     if (B == 0) return SS_HIP_OK;
@@ -856,6 +865,7 @@ int solve_batch_impl(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, 
 template <typename T>
 int gemv_t_impl(ss_hip_ctx* ctx, const T* r, T* c, int repeats, float* ms_out, char* err, size_t errlen)
 {
+    if (ctx && ctx->kind != 0) { set_err(err, errlen, "this entry point needs a Homotopy context (an IRLS context holds the factorised matrix)"); return SS_HIP_EINVAL; }
     if (!ctx || !r || !c) { set_err(err, errlen, "gemv_t: null argument"); return SS_HIP_EINVAL; }
     if (ctx->is_f64 != (sizeof(T) == 8)) { set_err(err, errlen, "gemv_t: type mismatch"); return SS_HIP_ETYPE; }
     if (repeats < 1) repeats = 1;
@@ -887,6 +897,7 @@ int gemv_t_impl(ss_hip_ctx* ctx, const T* r, T* c, int repeats, float* ms_out, c
 int gemm_t_impl(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, float* C, ptrdiff_t ldC,
                 int repeats, float* ms_out, char* err, size_t errlen)
 {
+    if (ctx && ctx->kind != 0) { set_err(err, errlen, "this entry point needs a Homotopy context (an IRLS context holds the factorised matrix)"); return SS_HIP_EINVAL; }
     if (!ctx || !R || !C || B == 0) { set_err(err, errlen, "gemm_t: null/empty argument"); return SS_HIP_EINVAL; }
     if (ctx->is_f64) { set_err(err, errlen, "gemm_t: fp32 contexts only"); return SS_HIP_ETYPE; }
     if (repeats < 1) repeats = 1;
@@ -925,6 +936,7 @@ int gemm_t_impl(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, float*
 int gram_cols_impl(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, float* G, ptrdiff_t ldG, int repeats,
                    float* ms_out, char* err, size_t errlen)
 {
+    if (ctx && ctx->kind != 0) { set_err(err, errlen, "this entry point needs a Homotopy context (an IRLS context holds the factorised matrix)"); return SS_HIP_EINVAL; }
     if (!ctx || !cols || !G || S == 0 || S > 32) { set_err(err, errlen, "gram_cols: need 1..32 columns"); return SS_HIP_EINVAL; }
     if (ctx->is_f64) { set_err(err, errlen, "gram_cols: fp32 contexts only"); return SS_HIP_ETYPE; }
     for (size_t s = 0; s < S; ++s)
@@ -966,6 +978,7 @@ int gram_cols_impl(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, float* G, pt
 template <typename T>
 int reconstruct_impl(ss_hip_ctx* ctx, const T* x, T* y, char* err, size_t errlen)
 {
+    if (ctx && ctx->kind != 0) { set_err(err, errlen, "this entry point needs a Homotopy context (an IRLS context holds the factorised matrix)"); return SS_HIP_EINVAL; }
     if (!ctx || !x || !y) { set_err(err, errlen, "reconstruct: null argument"); return SS_HIP_EINVAL; }
     if (ctx->is_f64 != (sizeof(T) == 8)) { set_err(err, errlen, "reconstruct: type mismatch"); return SS_HIP_ETYPE; }
     try {
@@ -976,6 +989,40 @@ int reconstruct_impl(ss_hip_ctx* ctx, const T* x, T* y, char* err, size_t errlen
         copy_out<T>(ctx, y, 1, ws.rhs, ctx->m);
         HIPCHK(hipStreamSynchronize(ctx->stream));
         // rhs padding must stay zero for the sweeps: rows >= m were not written
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        return SS_HIP_ERUNTIME;
+    }
+    return SS_HIP_OK;
+}
+
+
+// ---- IRLS (irls.hip): y up, one launch, x and the report down ---------------------------------
+template <typename T>
+int irls_solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x, ptrdiff_t incx,
+                    uint32_t* iter_out, double* err_out, int* spd_failure, char* err, size_t errlen)
+{
+    if (!ctx) { set_err(err, errlen, "irls_solve: null context"); return SS_HIP_EINVAL; }
+    if (ctx->kind != 1) { set_err(err, errlen, "irls_solve: this context was not created for IRLS"); return SS_HIP_EINVAL; }
+    if (ctx->is_f64 != (sizeof(T) == 8)) {
+        set_err(err, errlen, "irls_solve: element type of the call does not match the context");
+        return SS_HIP_ETYPE;
+    }
+    if (!y || !x) { set_err(err, errlen, "irls_solve: y and x must not be null"); return SS_HIP_EINVAL; }
+    if (max_iter == 0) { set_err(err, errlen, "irls_solve: max_iterations must be > 0"); return SS_HIP_EINVAL; }   // irls-cpu.cpp:78
+    if (incy <= 0 || incx <= 0) { set_err(err, errlen, "irls_solve: vector increments must be positive"); return SS_HIP_EINVAL; }
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        copy_in<T>(ctx, irls_y_buffer<T>(ctx), y, incy, ctx->m);
+        IrlsResult res{};
+        HIPCHK(irls_solve<T>(ctx, tol, max_iter, &res));
+        copy_out<T>(ctx, x, incx, irls_x_buffer<T>(ctx), ctx->n);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (iter_out) *iter_out = res.iter;
+        if (err_out) *err_out = res.solution_error;
+        if (spd_failure) *spd_failure = (int)res.spd_failure;
+        ctx->stats.solves += 1;
+        ctx->stats.iterations += res.iter;
     } catch (const HipFail& f) {
         set_err(err, errlen, hip_msg(f));
         return SS_HIP_ERUNTIME;
@@ -1013,6 +1060,32 @@ ss_hip_ctx* ss_hip_homotopy_create_f64(const double* A, size_t m, size_t n, ptrd
     return create_impl<double>(A, m, n, stride_row, stride_col, device, err, errlen);
 }
 
+ss_hip_ctx* ss_hip_irls_create_f32(const float* A, size_t m, size_t n, ptrdiff_t stride_row, ptrdiff_t stride_col,
+                                   int device, char* err, size_t errlen)
+{
+    return create_impl<float>(A, m, n, stride_row, stride_col, device, err, errlen, 1);
+}
+
+ss_hip_ctx* ss_hip_irls_create_f64(const double* A, size_t m, size_t n, ptrdiff_t stride_row, ptrdiff_t stride_col,
+                                   int device, char* err, size_t errlen)
+{
+    return create_impl<double>(A, m, n, stride_row, stride_col, device, err, errlen, 1);
+}
+
+int ss_hip_irls_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_t incy, float tol, uint32_t max_iter, float* x,
+                          ptrdiff_t incx, uint32_t* iter_out, double* err_out, int* spd_failure, char* err, size_t errlen)
+{
+    return irls_solve_impl<float>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, spd_failure, err, errlen);
+}
+
+int ss_hip_irls_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy, double tol, uint32_t max_iter, double* x,
+                          ptrdiff_t incx, uint32_t* iter_out, double* err_out, int* spd_failure, char* err, size_t errlen)
+{
+    return irls_solve_impl<double>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, spd_failure, err, errlen);
+}
+
+void ss_hip_irls_destroy(ss_hip_ctx* ctx) { ss_hip_homotopy_destroy(ctx); }
+
 void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
 {
     if (!ctx) return;
@@ -1022,6 +1095,7 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
         if (ctx->is_f64) free_ws(static_cast<Workspace<double>*>(ctx->ws));
         else free_ws(static_cast<Workspace<float>*>(ctx->ws));
     }
+    sship::irls_free(ctx);
     if (ctx->At) (void)hipFree(ctx->At);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);

@@ -1,0 +1,416 @@
+// irls.hip — the reference's second solver, IRLS (iteratively reweighted least squares), on the device.
+//
+// Reference (paths under /root/reference):
+//   qr_decomposition<T>        src/linalg/qr_decomposition.h:93-190   -> k_qr_step, k_qr_formq, k_irls_setup
+//   cholesky_decomposition<T>  src/linalg/cholesky_decomposition.h:56-100 -> k_irls_solve (in place)
+//   irls_newton / run_solver   src/solvers/irls-cpu.cpp:39-124        -> k_irls_solve
+//
+// IRLS needs M >= N (a tall sensing matrix) and is dense O(M N^2) once + O(N^3) per iteration: it is
+// off the Homotopy hot path and off the benchmark; it is here so that the reference's public API
+// (ss::irls<T>, sparsesolvers.Irls) is complete on the device.  What the device layout buys:
+//
+//   * the factorisation runs once, at construction, on the column-contiguous copy of A every
+//     other kernel of this library uses: one launch per Householder column, one workgroup per
+//     trailing column (each recomputes the reflector from the read-only pivot column, so the
+//     launch has no internal hand-off);
+//   * irls_newton's N x N x M product Q^T (Q W) — recomputed by the reference in every iteration —
+//     is (Q^T Q) with its columns scaled by w: Q^T Q is formed once (k_irls_setup) and the
+//     iteration only scales it (same values up to the rounding of q*w before or after the sum);
+//   * the whole iteration loop — scale, Cholesky, two triangular solves, t = Q s, x = Q^T t,
+//     R x = x, threshold, second largest, reweighting, loop control — is one launch of one
+//     workgroup: no host round trips; the O(M N) products are coalesced over the columns of Q^T.
+//
+// Summation orders differ from the reference's BLAS (unpinned there); parity is by tolerance.
+#include "ss_hip_internal.h"
+#include "ss_hip_device.h"
+
+#include <algorithm>
+
+namespace sship {
+
+template <typename T>
+struct IrlsState {
+    T* Vt = nullptr;      // [n][ldm] Householder vectors, column k in row k (zero above the diagonal)
+    T* Qt = nullptr;      // [n][ldm] Q^T: row j = column j of the thin Q
+    T* R = nullptr;       // [n][n] upper triangular, row-major
+    T* G0 = nullptr;      // [n][n] lower triangle of Q^T Q, row-major
+    T* L = nullptr;       // [n][n] scratch: scaled matrix, then its Cholesky factor
+    T* rdiag = nullptr;   // [n]
+    T* vec = nullptr;     // qTb, s, xnext, w, x: 5 x [n]; then t, y: 2 x [ldm]
+    IrlsResult* res = nullptr;   // device copy of the report
+};
+
+constexpr int kQrThreads = 256;
+constexpr int kIrlsThreads = 1024;
+
+template <typename T> __device__ __forceinline__ T t_abs(T v) { return v < T(0) ? -v : v; }
+
+// maximum over the workgroup, the same value in every thread (sv: LDS scratch of >= 16 entries)
+template <typename T>
+__device__ __forceinline__ T block_max(T v, T* sv)
+{
+    v = max(v, dpp_mov<kDppXor1>(v));
+    v = max(v, dpp_mov<kDppXor2>(v));
+    v = max(v, dpp_mov<kDppHalfMirror>(v));
+    v = max(v, dpp_mov<kDppMirror>(v));
+    v = max(max(lane_value(v, 0), lane_value(v, 16)), max(lane_value(v, 32), lane_value(v, 48)));
+    const int nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T r = sv[0];
+    for (int w = 1; w < nw; ++w) r = max(r, sv[w]);
+    __syncthreads();
+    return r;
+}
+
+// One Householder step (qr_decomposition.h:111-134).  Workgroup j handles column k + j; the pivot
+// column k is read-only in this launch (its reflector is written to Vt), so every workgroup forms the
+// reflector for itself.
+template <typename T>
+__global__ __launch_bounds__(kQrThreads)
+void k_qr_step(T* __restrict__ At, T* __restrict__ Vt, T* __restrict__ rdiag, uint32_t ldm, uint32_t m, uint32_t k)
+{
+    __shared__ T sv[16];
+    const T* piv = At + (size_t)k * ldm;
+    // 2-norm of piv[k..m) without overflow: scale by the largest magnitude
+    T amax = T(0);
+    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) amax = max(amax, t_abs(piv[i]));
+    amax = block_max(amax, sv);
+    T nrm2 = T(0);
+    if (amax > T(0)) {
+        T part = T(0);
+        for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) { const T z = piv[i] / amax; part += z * z; }
+        nrm2 = amax * sqrt(block_sum(part, sv));
+        __syncthreads();
+    }
+    const uint32_t col = k + blockIdx.x;
+    if (nrm2 == T(0)) {
+        if (blockIdx.x == 0) {
+            for (uint32_t i = threadIdx.x; i < ldm; i += kQrThreads) Vt[(size_t)k * ldm + i] = T(0);
+            if (threadIdx.x == 0) rdiag[k] = -nrm2;
+        }
+        return;
+    }
+    if (piv[k] < T(0)) nrm2 = -nrm2;
+    const T vk = piv[k] / nrm2 + T(1);
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < ldm; i += kQrThreads)
+            Vt[(size_t)k * ldm + i] = (i < k || i >= m) ? T(0) : (i == k ? vk : piv[i] / nrm2);
+        if (threadIdx.x == 0) rdiag[k] = -nrm2;
+        return;
+    }
+    // apply the reflector to column `col`: s = v . a / (-v_k); a += v s
+    T* a = At + (size_t)col * ldm;
+    T part = T(0);
+    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) {
+        const T v = (i == k) ? vk : piv[i] / nrm2;
+        part += v * a[i];
+    }
+    const T s = block_sum(part, sv) / -vk;
+    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) {
+        const T v = (i == k) ? vk : piv[i] / nrm2;
+        a[i] += v * s;
+    }
+}
+
+// Back-accumulation of the thin Q (qr_decomposition.h:141-172), step k (run for k = N-1 .. 0):
+// workgroup j handles column k + j of Q (row k + j of Qt).
+template <typename T>
+__global__ __launch_bounds__(kQrThreads)
+void k_qr_formq(const T* __restrict__ Vt, T* __restrict__ Qt, uint32_t ldm, uint32_t m, uint32_t k)
+{
+    __shared__ T sv[16];
+    const T* v = Vt + (size_t)k * ldm;
+    T* qc = Qt + (size_t)(k + blockIdx.x) * ldm;
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < ldm; i += kQrThreads) qc[i] = (i == k) ? T(1) : T(0);
+        __syncthreads();
+    }
+    const T vk = v[k];
+    if (vk == T(0)) return;
+    T part = T(0);
+    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) part += v[i] * qc[i];
+    const T s = -block_sum(part, sv) / vk;
+    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) qc[i] += s * v[i];
+}
+
+// R (qr_decomposition.h:174-190) and the lower triangle of Q^T Q; workgroup i does row i
+template <typename T>
+__global__ __launch_bounds__(kQrThreads)
+void k_irls_setup(const T* __restrict__ At, const T* __restrict__ Qt, const T* __restrict__ rdiag,
+                  T* __restrict__ R, T* __restrict__ G0, uint32_t ldm, uint32_t m, uint32_t n)
+{
+    const uint32_t i = blockIdx.x;
+    for (uint32_t j = threadIdx.x; j < n; j += kQrThreads)
+        R[(size_t)i * n + j] = j > i ? At[(size_t)j * ldm + i] : (j == i ? rdiag[i] : T(0));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* qi = Qt + (size_t)i * ldm;
+    for (uint32_t j = wave; j < n; j += kQrThreads / 64) {
+        T acc = T(0);
+        if (j <= i) {
+            const T* qj = Qt + (size_t)j * ldm;
+            for (uint32_t r = lane; r < m; r += 64) acc += qi[r] * qj[r];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) G0[(size_t)i * n + j] = j <= i ? acc : T(0);
+    }
+}
+
+// block-wide (value, index) maximum by value, first index on ties; excl: index to leave out
+template <typename T>
+__device__ __forceinline__ void block_max_excl(const T* v, uint32_t n, uint32_t excl, T& mv, uint32_t& mi, T* sv, uint32_t* si)
+{
+    mv = -Lim<T>::max();
+    mi = 0xffffffffu;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (i != excl && better_max(v[i], i, mv, mi)) { mv = v[i]; mi = i; }
+    block_reduce_pair<T, true>(mv, mi, sv, si);
+    __syncthreads();
+}
+
+// The whole solve: irls-cpu.cpp:63-124 with irls_newton :39-61 inlined.  One workgroup.
+template <typename T>
+__global__ __launch_bounds__(kIrlsThreads)
+void k_irls_solve(const T* __restrict__ Qt, const T* __restrict__ R, const T* __restrict__ G0, T* __restrict__ L,
+                  T* __restrict__ vec, uint32_t ldm, uint32_t m, uint32_t n, T tol, uint32_t max_iter,
+                  IrlsResult* res)
+{
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    T* qTb = vec;
+    T* s = vec + n;
+    T* xnext = vec + 2 * (size_t)n;
+    T* w = vec + 3 * (size_t)n;
+    T* x = vec + 4 * (size_t)n;
+    T* t = vec + 5 * (size_t)n;
+    const T* y = t + ldm;
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = kIrlsThreads / 64;
+    const T p = T(0.9);
+
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) { x[i] = T(0); w[i] = T(1); xnext[i] = T(1); }
+    // qTb = Q^T y (:54) does not change over the iterations
+    for (uint32_t j = wave; j < n; j += NW) {
+        T acc = T(0);
+        const T* qj = Qt + (size_t)j * ldm;
+        for (uint32_t r = lane; r < m; r += 64) acc += qj[r] * y[r];
+        acc = wave_sum(acc);
+        if (lane == 0) qTb[j] = acc;
+    }
+    __syncthreads();
+
+    uint32_t iter = 0;
+    int spd_error = 0;
+    T abstol = T(1), eps = T(1), second = T(0);
+    do {
+        // ---- irls_newton ---------------------------------------------------------------------
+        // tril(Q^T (Q w)) = tril(Q^T Q) with column j scaled by w_j (:48-49, cholesky_decomposition.h:67)
+        for (size_t e = tid; e < (size_t)n * n; e += kIrlsThreads) {
+            const uint32_t i = (uint32_t)(e / n), j = (uint32_t)(e - (size_t)i * n);
+            L[e] = j <= i ? G0[e] * w[j] : T(0);
+        }
+        __syncthreads();
+        // Cholesky, column by column (cholesky_decomposition.h:69-82)
+        bool isspd = true;
+        for (uint32_t j = 0; j < n; ++j) {
+            if (j > 0) {
+                const T* lj = L + (size_t)j * n;
+                for (uint32_t i = j + wave; i < n; i += NW) {
+                    const T* li = L + (size_t)i * n;
+                    T acc = T(0);
+                    for (uint32_t k2 = lane; k2 < j; k2 += 64) acc += li[k2] * lj[k2];
+                    acc = wave_sum(acc);
+                    if (lane == 0) s[i] = acc;                   // column update, applied below
+                }
+                __syncthreads();
+                for (uint32_t i = j + tid; i < n; i += kIrlsThreads) L[(size_t)i * n + j] -= s[i];
+                __syncthreads();
+            }
+            const T ajj = sqrt(L[(size_t)j * n + j]);
+            if (ajj <= Lim<T>::eps()) isspd = false;          // :78 (a NaN pivot passes, as in the reference)
+            const T inv = T(1) / ajj;
+            __syncthreads();
+            for (uint32_t i = j + tid; i < n; i += kIrlsThreads) L[(size_t)i * n + j] *= inv;
+            __syncthreads();
+        }
+        if (!isspd) { spd_error = 1; break; }                   // uniform: every thread saw the same pivots
+        // s = (L L^T)^-1 qTb (:55, cholesky_decomposition.h:90-100)
+        for (uint32_t i = tid; i < n; i += kIrlsThreads) s[i] = qTb[i];
+        __syncthreads();
+        for (uint32_t i = 0; i < n; ++i) {                       // L z = b
+            T part = T(0);
+            for (uint32_t k2 = tid; k2 < i; k2 += kIrlsThreads) part += L[(size_t)i * n + k2] * s[k2];
+            const T acc = block_sum(part, sv);
+            __syncthreads();
+            if (tid == 0) s[i] = (s[i] - acc) / L[(size_t)i * n + i];
+            __syncthreads();
+        }
+        for (uint32_t ii = n; ii-- > 0;) {                       // L^T x = z
+            T part = T(0);
+            for (uint32_t k2 = ii + 1 + tid; k2 < n; k2 += kIrlsThreads) part += L[(size_t)k2 * n + ii] * s[k2];
+            const T acc = block_sum(part, sv);
+            __syncthreads();
+            if (tid == 0) s[ii] = (s[ii] - acc) / L[(size_t)ii * n + ii];
+            __syncthreads();
+        }
+        // t = Q s (:56): thread per row, coalesced over the rows of Q^T
+        for (uint32_t r = tid; r < m; r += kIrlsThreads) {
+            T acc = T(0);
+            for (uint32_t j = 0; j < n; ++j) acc += Qt[(size_t)j * ldm + r] * s[j];
+            t[r] = acc;
+        }
+        __syncthreads();
+        // xnext = Q^T t (:58)
+        for (uint32_t j = wave; j < n; j += NW) {
+            T acc = T(0);
+            const T* qj = Qt + (size_t)j * ldm;
+            for (uint32_t r = lane; r < m; r += 64) acc += qj[r] * t[r];
+            acc = wave_sum(acc);
+            if (lane == 0) xnext[j] = acc;
+        }
+        __syncthreads();
+        // R x = x, upper triangular (:59)
+        for (uint32_t ii = n; ii-- > 0;) {
+            T part = T(0);
+            for (uint32_t k2 = ii + 1 + tid; k2 < n; k2 += kIrlsThreads) part += R[(size_t)ii * n + k2] * xnext[k2];
+            const T acc = block_sum(part, sv);
+            __syncthreads();
+            if (tid == 0) xnext[ii] = (xnext[ii] - acc) / R[(size_t)ii * n + ii];
+            __syncthreads();
+        }
+        // ---- run_solver --------------------------------------------------------------------------
+        T mx;
+        uint32_t mi;
+        block_max_excl(xnext, n, 0xffffffffu, mx, mi, sv, si);
+        abstol = mx * tol;                                        // :100
+        for (uint32_t i = tid; i < n; i += kIrlsThreads) {        // :103-104
+            const T v = xnext[i] < abstol ? T(0) : xnext[i];
+            xnext[i] = v;
+            x[i] = v;
+        }
+        __syncthreads();
+        // second largest value (:107): the largest once the (first) largest is left out
+        block_max_excl(xnext, n, 0xffffffffu, mx, mi, sv, si);
+        if (n >= 2) {
+            T m2;
+            uint32_t i2;
+            block_max_excl(xnext, n, mi, m2, i2, sv, si);
+            second = m2;
+        } else {
+            second = mx;
+        }
+        {
+            const T cand = second / T(n);                         // :110
+            if (cand < eps) eps = cand;
+        }
+        T part = T(0);
+        for (uint32_t i = tid; i < n; i += kIrlsThreads) {        // :113
+            const T v = (T)pow((double)(x[i] * x[i] + eps), (double)p / 2.0 - 1.0);
+            w[i] = v;
+            part += v;
+        }
+        const T sum = block_sum(part, sv);
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kIrlsThreads) w[i] /= sum;   // :114
+        __syncthreads();
+        ++iter;
+    } while (iter < max_iter && second > abstol);
+
+    // finally, normalise x (:121)
+    T part = T(0);
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) part += x[i];
+    const T sum = block_sum(part, sv);
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) x[i] /= sum;
+    if (tid == 0) {
+        res->iter = iter;
+        res->spd_failure = (uint32_t)spd_error;
+        res->solution_error = (double)eps;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+template <typename T>
+static IrlsState<T>* state_of(ss_hip_ctx* ctx) { return static_cast<IrlsState<T>*>(ctx->irls); }
+
+template <typename T>
+hipError_t irls_factor(ss_hip_ctx* ctx)
+{
+    const uint32_t m = (uint32_t)ctx->m, n = (uint32_t)ctx->n, ldm = ctx->ldm;
+    auto* S = new IrlsState<T>();
+    ctx->irls = S;
+    hipError_t e;
+#define IRLS_TRY(call) do { e = (call); if (e != hipSuccess) return e; } while (0)
+    IRLS_TRY(hipMalloc(&S->Vt, (size_t)n * ldm * sizeof(T)));
+    IRLS_TRY(hipMalloc(&S->Qt, (size_t)n * ldm * sizeof(T)));
+    IRLS_TRY(hipMalloc(&S->R, (size_t)n * n * sizeof(T)));
+    IRLS_TRY(hipMalloc(&S->G0, (size_t)n * n * sizeof(T)));
+    IRLS_TRY(hipMalloc(&S->L, (size_t)n * n * sizeof(T)));
+    IRLS_TRY(hipMalloc(&S->rdiag, (size_t)n * sizeof(T)));
+    IRLS_TRY(hipMalloc(&S->vec, (5 * (size_t)n + 2 * (size_t)ldm) * sizeof(T)));
+    IRLS_TRY(hipMalloc(&S->res, sizeof(IrlsResult)));
+    IRLS_TRY(hipMemsetAsync(S->Qt, 0, (size_t)n * ldm * sizeof(T), ctx->stream));
+    IRLS_TRY(hipMemsetAsync(S->vec, 0, (5 * (size_t)n + 2 * (size_t)ldm) * sizeof(T), ctx->stream));
+    T* At = static_cast<T*>(ctx->At);
+    for (uint32_t k = 0; k < n; ++k) {
+        hipLaunchKernelGGL((k_qr_step<T>), dim3(n - k), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k);
+        IRLS_TRY(hipGetLastError());
+    }
+    for (uint32_t kk = n; kk-- > 0;) {
+        hipLaunchKernelGGL((k_qr_formq<T>), dim3(n - kk), dim3(kQrThreads), 0, ctx->stream, (const T*)S->Vt, S->Qt, ldm, m, kk);
+        IRLS_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL((k_irls_setup<T>), dim3(n), dim3(kQrThreads), 0, ctx->stream, (const T*)At, (const T*)S->Qt,
+                       (const T*)S->rdiag, S->R, S->G0, ldm, m, n);
+    IRLS_TRY(hipGetLastError());
+    IRLS_TRY(hipStreamSynchronize(ctx->stream));
+    return hipSuccess;
+}
+
+// y_dev -> the state's y buffer is the caller's job (irls_y_buffer); x is left in irls_x_buffer
+template <typename T>
+hipError_t irls_solve(ss_hip_ctx* ctx, T tol, uint32_t max_iter, IrlsResult* res_host)
+{
+    IrlsState<T>* S = state_of<T>(ctx);
+    hipError_t e;
+    hipLaunchKernelGGL((k_irls_solve<T>), dim3(1), dim3(kIrlsThreads), 0, ctx->stream, (const T*)S->Qt, (const T*)S->R,
+                       (const T*)S->G0, S->L, S->vec, ctx->ldm, (uint32_t)ctx->m, (uint32_t)ctx->n, tol, max_iter, S->res);
+    IRLS_TRY(hipGetLastError());
+    IRLS_TRY(hipMemcpyAsync(res_host, S->res, sizeof(IrlsResult), hipMemcpyDeviceToHost, ctx->stream));
+    return hipSuccess;
+#undef IRLS_TRY
+}
+
+template <typename T> T* irls_y_buffer(ss_hip_ctx* ctx) { return state_of<T>(ctx)->vec + 5 * ctx->n + ctx->ldm; }
+template <typename T> T* irls_x_buffer(ss_hip_ctx* ctx) { return state_of<T>(ctx)->vec + 4 * ctx->n; }
+
+template <typename T>
+static void free_state(IrlsState<T>* S)
+{
+    if (!S) return;
+    void* ptrs[] = { S->Vt, S->Qt, S->R, S->G0, S->L, S->rdiag, S->vec, S->res };
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete S;
+}
+
+void irls_free(ss_hip_ctx* ctx)
+{
+    if (!ctx->irls) return;
+    if (ctx->is_f64) free_state(static_cast<IrlsState<double>*>(ctx->irls));
+    else free_state(static_cast<IrlsState<float>*>(ctx->irls));
+    ctx->irls = nullptr;
+}
+
+template hipError_t irls_factor<float>(ss_hip_ctx*);
+template hipError_t irls_factor<double>(ss_hip_ctx*);
+template hipError_t irls_solve<float>(ss_hip_ctx*, float, uint32_t, IrlsResult*);
+template hipError_t irls_solve<double>(ss_hip_ctx*, double, uint32_t, IrlsResult*);
+template float* irls_y_buffer<float>(ss_hip_ctx*);
+template double* irls_y_buffer<double>(ss_hip_ctx*);
+template float* irls_x_buffer<float>(ss_hip_ctx*);
+template double* irls_x_buffer<double>(ss_hip_ctx*);
+
+}  // namespace sship

@@ -9,8 +9,8 @@
 namespace sship {
 
 template <typename T> struct Lim;
-template <> struct Lim<float>  { static constexpr float  max() { return FLT_MAX; } static constexpr float  tiny() { return FLT_MIN; } };
-template <> struct Lim<double> { static constexpr double max() { return DBL_MAX; } static constexpr double tiny() { return DBL_MIN; } };
+template <> struct Lim<float>  { static constexpr float  max() { return FLT_MAX; } static constexpr float  tiny() { return FLT_MIN; } static constexpr float  eps() { return FLT_EPSILON; } };
+template <> struct Lim<double> { static constexpr double max() { return DBL_MAX; } static constexpr double tiny() { return DBL_MIN; } static constexpr double eps() { return DBL_EPSILON; } };
 
 typedef float  v4f __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));

@@ -158,6 +158,8 @@ struct SweepConfig {
 }  // namespace sship
 
 struct ss_hip_ctx {
+    int kind = 0;            // 0 = Homotopy / OMP context, 1 = IRLS context
+    void* irls = nullptr;    // sship::IrlsState<T>* of an IRLS context
     int device = 0;
     int is_f64 = 0;
     size_t m = 0, n = 0;
@@ -266,6 +268,20 @@ hipError_t launch_gemm_tn_f32(const ss_hip_ctx* ctx, const float* R, uint32_t Mg
 // is a no-op unless st->need_sweep is set and the solve is still running)
 hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
                                 float* D, uint32_t ldd, const DevState* st);
+
+// ---- IRLS (irls.hip) ---------------------------------------------------------------------
+struct IrlsResult {
+    uint32_t iter;
+    uint32_t spd_failure;
+    double solution_error;
+};
+// Householder QR of the device copy of A (in place), thin Q, R and Q^T Q; M >= N
+template <typename T> hipError_t irls_factor(ss_hip_ctx* ctx);
+// the solve: y in irls_y_buffer, x left in irls_x_buffer, report copied to res_host (stream-ordered)
+template <typename T> hipError_t irls_solve(ss_hip_ctx* ctx, T tol, uint32_t max_iter, IrlsResult* res_host);
+template <typename T> T* irls_y_buffer(ss_hip_ctx* ctx);
+template <typename T> T* irls_x_buffer(ss_hip_ctx* ctx);
+void irls_free(ss_hip_ctx* ctx);
 
 // ---- helpers implemented in homotopy.hip ---------------------------------------
 void set_err(char* err, size_t errlen, const std::string& msg);

@@ -20,4 +20,4 @@ import _hip_runtime  # noqa: E402
 _hip_runtime.preload()
 
 from sparsesolvers.binding import *  # noqa: E402,F401,F403
-from sparsesolvers.binding import Homotopy, HomotopyReport, Omp, OmpReport, version  # noqa: E402,F401
+from sparsesolvers.binding import Homotopy, HomotopyReport, Irls, IrlsReport, Omp, OmpReport, version  # noqa: E402,F401

@@ -70,6 +70,7 @@ namespace
     };
     using py_homotopy = py_solver<ss::homotopy_policy>;
     using py_omp = py_solver<ss::omp_policy>;
+    using py_irls = py_solver<ss::irls_policy>;
 
     template <typename T, typename P> struct slot_of;
     template <typename P> struct slot_of<float, P>  { static std::unique_ptr<ss::solver<float, P>>&  get(py_solver<P>& s) { return s.f32; } };
@@ -99,7 +100,7 @@ namespace
                 py::array_t<T> x((py::ssize_t)self.shape[1]);
                 auto bs = view_of<1>(b);
                 auto xs = view_of<1>(x);
-                kernelpp::maybe<report_type> result = report_type{ 0u, 0.0 };
+                kernelpp::maybe<report_type> result = report_type{};
                 {
                     py::gil_scoped_release release;
                     result = s->solve(bs, tol, maxiter, xs);
@@ -132,6 +133,18 @@ PYBIND11_MODULE(binding, m)
     def_init<double, ss::homotopy_policy>(homotopy);
     def_solve<float, ss::homotopy_policy>(homotopy);
     def_solve<double, ss::homotopy_policy>(homotopy);
+
+    /* irls report and solver (reference: binding.cpp:133-146) */
+    py::class_<ss::irls_report>(m, "IrlsReport")
+        .def(py::init([]() { return ss::irls_report{ 0u, 0.0, false }; }))
+        .def_readwrite("iter", &ss::irls_report::iter)
+        .def_readwrite("spd_failure", &ss::irls_report::spd_failure)
+        .def_readwrite("solution_error", &ss::irls_report::solution_error);
+    auto irls = py::class_<py_irls>(m, "Irls");
+    def_init<float, ss::irls_policy>(irls);
+    def_init<double, ss::irls_policy>(irls);
+    def_solve<float, ss::irls_policy>(irls);
+    def_solve<double, ss::irls_policy>(irls);
 
     /* orthogonal matching pursuit (an addition; the reference exposes Homotopy and Irls) */
     py::class_<ss::omp_report>(m, "OmpReport")

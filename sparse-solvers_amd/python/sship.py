@@ -29,6 +29,8 @@ SYMBOLS = [
     "ss_hip_reconstruct_f32", "ss_hip_reconstruct_f64",
     "ss_hip_set_profiling", "ss_hip_get_stats", "ss_hip_reset_stats",
     "ss_hip_set_option", "ss_hip_get_option", "ss_hip_get_trace", "ss_hip_ctx_info",
+    "ss_hip_irls_create_f32", "ss_hip_irls_create_f64", "ss_hip_irls_solve_f32", "ss_hip_irls_solve_f64",
+    "ss_hip_irls_destroy",
 ]
 
 
@@ -91,12 +93,21 @@ def lib():
         f = getattr(L, "ss_hip_reconstruct_" + suf)
         f.restype = ctypes.c_int
         f.argtypes = [vp, vp, vp, cp, sz]
+        f = getattr(L, "ss_hip_irls_create_" + suf)
+        f.restype = vp
+        f.argtypes = [vp, sz, sz, pd, pd, ctypes.c_int, cp, sz]
+        f = getattr(L, "ss_hip_irls_solve_" + suf)
+        f.restype = ctypes.c_int
+        f.argtypes = [vp, vp, pd, ct, u32, vp, pd, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_double),
+                      ctypes.POINTER(ctypes.c_int), cp, sz]
     L.ss_hip_gemm_t_f32.restype = ctypes.c_int
     L.ss_hip_gemm_t_f32.argtypes = [vp, vp, sz, pd, vp, pd, ctypes.c_int, ctypes.POINTER(ctypes.c_float), cp, sz]
     L.ss_hip_gram_cols_f32.restype = ctypes.c_int
     L.ss_hip_gram_cols_f32.argtypes = [vp, vp, sz, vp, pd, ctypes.c_int, ctypes.POINTER(ctypes.c_float), cp, sz]
     L.ss_hip_homotopy_destroy.restype = None
     L.ss_hip_homotopy_destroy.argtypes = [vp]
+    L.ss_hip_irls_destroy.restype = None
+    L.ss_hip_irls_destroy.argtypes = [vp]
     L.ss_hip_set_profiling.argtypes = [vp, ctypes.c_int]
     L.ss_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     L.ss_hip_reset_stats.argtypes = [vp]
@@ -315,3 +326,63 @@ class Homotopy:
         if rc != 0:
             raise SsHipError(rc, "unknown option %r" % key)
         return int(v.value)
+
+
+class Irls:
+    """IRLS on the device (the reference's ss::irls<T>): Householder QR of A at construction
+    (rows >= columns), the reweighting loop in one launch per solve."""
+
+    def __init__(self, A, device=0):
+        ptr, shape, strides, dt, keep = _describe(A)
+        if len(shape) != 2:
+            raise ValueError("A must be 2-D")
+        self.suffix, self.ctype = _suffix(dt)
+        self.dtype = dt
+        self.m, self.n = int(shape[0]), int(shape[1])
+        err = ctypes.create_string_buffer(512)
+        fn = getattr(lib(), "ss_hip_irls_create_" + self.suffix)
+        self._h = fn(ptr, self.m, self.n, strides[0], strides[1], device, err, len(err))
+        if not self._h:
+            raise SsHipError(-1, err.value.decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ss_hip_irls_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def solve(self, y, tolerance=None, max_iterations=100, out=None):
+        """-> (x, iter, solution_error, spd_failure); defaults mirror the reference binding (binding.cpp:94-95)"""
+        yp, yshape, ystr, ydt, keep = _describe(y)
+        if ydt != self.dtype:
+            raise TypeError("dtype of y (%s) does not match the matrix (%s)" % (ydt, self.dtype))
+        if len(yshape) != 1 or yshape[0] != self.m:
+            raise ValueError("y must have length m = %d" % self.m)
+        if tolerance is None:
+            tolerance = float(np.finfo(self.dtype).eps) * 10
+        if out is None:
+            out = np.empty(self.n, dtype=self.dtype)
+        xp, xshape, xstr, xdt, keepx = _describe(out)
+        if xdt != self.dtype or len(xshape) != 1 or xshape[0] != self.n:
+            raise ValueError("out must be a length-n vector of the matrix dtype")
+        it = ctypes.c_uint32(0)
+        e = ctypes.c_double(0.0)
+        spd = ctypes.c_int(0)
+        err = ctypes.create_string_buffer(512)
+        fn = getattr(lib(), "ss_hip_irls_solve_" + self.suffix)
+        rc = fn(self._h, yp, ystr[0], self.ctype(tolerance), int(max_iterations), xp, xstr[0],
+                ctypes.byref(it), ctypes.byref(e), ctypes.byref(spd), err, len(err))
+        if rc != 0:
+            raise SsHipError(rc, err.value.decode())
+        return out, int(it.value), float(e.value), bool(spd.value)

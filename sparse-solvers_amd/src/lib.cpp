@@ -129,6 +129,75 @@ namespace ss
         return run_hip_omp<double>(st, y, tol, maxiter, x);
     }
 
+    /* IRLS ---------------------------------------------------------------- */
+
+    namespace
+    {
+        inline ss_hip_ctx* create_irls(const float* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, int dev, char* err, size_t len)
+        { return ss_hip_irls_create_f32(A, m, n, rs, cs, dev, err, len); }
+        inline ss_hip_ctx* create_irls(const double* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, int dev, char* err, size_t len)
+        { return ss_hip_irls_create_f64(A, m, n, rs, cs, dev, err, len); }
+        inline int solve_irls(ss_hip_ctx* c, const float* y, ptrdiff_t incy, float tol, uint32_t it, float* x, ptrdiff_t incx,
+                              uint32_t* io, double* eo, int* spd, char* err, size_t len)
+        { return ss_hip_irls_solve_f32(c, y, incy, tol, it, x, incx, io, eo, spd, err, len); }
+        inline int solve_irls(ss_hip_ctx* c, const double* y, ptrdiff_t incy, double tol, uint32_t it, double* x, ptrdiff_t incx,
+                              uint32_t* io, double* eo, int* spd, char* err, size_t len)
+        { return ss_hip_irls_solve_f64(c, y, incy, tol, it, x, incx, io, eo, spd, err, len); }
+
+        template <typename T>
+        kernelpp::maybe<irls_report> run_hip_irls(
+            irls_device_state<T>& st, const ndspan<T> y, T tol, uint32_t maxiter, ndspan<T> x)
+        {
+            if (!st.ctx())
+                return kernelpp::error(st.error().empty() ? "irls: no device context" : st.error());
+            if (y.size() != st.rows() || x.size() != st.cols())
+                return kernelpp::error("irls: vector lengths do not match the shape of A",
+                                       kernelpp::error_code::INVALID_ARGUMENT);
+            char msg[512] = { 0 };
+            irls_report rep{ 0u, 0.0, false };
+            int spd = 0;
+            const int rc = solve_irls(st.ctx(), y.data(), (ptrdiff_t)y.strides()[0], tol, maxiter,
+                                      x.data(), (ptrdiff_t)x.strides()[0], &rep.iter, &rep.solution_error, &spd,
+                                      msg, sizeof(msg));
+            if (rc != SS_HIP_OK)
+                return kernelpp::error(msg, rc == SS_HIP_EINVAL ? kernelpp::error_code::INVALID_ARGUMENT
+                                                                : kernelpp::error_code::KERNEL_FAILED);
+            rep.spd_failure = spd != 0;
+            return rep;
+        }
+    }
+
+    template <typename T>
+    irls_device_state<T>::irls_device_state(const ndspan<T, 2> A, int device)
+        : _ctx(nullptr), _m(A.shape()[0]), _n(A.shape()[1])
+    {
+        char msg[512] = { 0 };
+        _ctx = create_irls(A.data(), _m, _n, (ptrdiff_t)A.strides()[0], (ptrdiff_t)A.strides()[1],
+                           device, msg, sizeof(msg));
+        if (!_ctx) _error = msg;
+    }
+
+    template <typename T>
+    irls_device_state<T>::~irls_device_state()
+    {
+        if (_ctx) ss_hip_irls_destroy(_ctx);
+    }
+
+    template class irls_device_state<float>;
+    template class irls_device_state<double>;
+
+    kernelpp::maybe<irls_report> irls_policy::run(
+        irls_device_state<float>& st, const ndspan<float> y, float tol, uint32_t maxiter, ndspan<float> x)
+    {
+        return run_hip_irls<float>(st, y, tol, maxiter, x);
+    }
+
+    kernelpp::maybe<irls_report> irls_policy::run(
+        irls_device_state<double>& st, const ndspan<double> y, double tol, uint32_t maxiter, ndspan<double> x)
+    {
+        return run_hip_irls<double>(st, y, tol, maxiter, x);
+    }
+
     /* Utils --------------------------------------------------------------- */
 
     namespace detail

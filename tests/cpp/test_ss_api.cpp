@@ -105,6 +105,30 @@ void omp_api()
     CHECK(x == y);
 }
 
+void irls_api()
+{
+    // ss::irls<T> (reference: ss.h:63-64, irls_test.cpp smoke_test): identity => x == y, one iteration
+    const size_t N = 5;
+    std::vector<float> A(N * N, 0.f);
+    for (size_t i = 0; i < N; i++) A[i * N + i] = 1.f;
+    ss::irls<float> solver(ss::as_span<2>(A.data(), { N, N }));
+    for (size_t n = 0; n < N; n++) {
+        std::vector<float> y(N, 0.f), x(N, -1.f);
+        y[n] = 1.f;
+        auto r = solver.solve(ss::as_span(y), 0.001f, 5, ss::as_span(x));
+        CHECK(r.is<ss::irls_report>());
+        if (r.is<ss::irls_report>()) {
+            const auto rep = r.get<ss::irls_report>();
+            CHECK(rep.iter == 1 && !rep.spd_failure && rep.solution_error == 0.0);
+        }
+        CHECK(x == y);
+    }
+    // rows < columns is a construction error, reported by solve() (no exceptions)
+    std::vector<double> W(2 * 3, 1.0), yw(2, 1.0), xw(3, 0.0);
+    ss::irls<double> wide(ss::as_span<2>(W.data(), { size_t(2), size_t(3) }));
+    CHECK(wide.solve(ss::as_span(yw), 0.1, 3, ss::as_span(xw)).is<kernelpp::error>());
+}
+
 void utilities()
 {
     // norm_l1 literal (reference: src/linalg/norms_test.cpp) and reconstruct_signal
@@ -132,6 +156,7 @@ int main(int argc, char** argv)
     static_assert(ss::detail::is_solver<ss::homotopy_policy, float>::value, "f32");
     static_assert(ss::detail::is_solver<ss::homotopy_policy, double>::value, "f64");
     static_assert(ss::detail::is_solver<ss::omp_policy, float>::value, "omp f32");
+    static_assert(ss::detail::is_solver<ss::irls_policy, double>::value, "irls f64");
     if (argc > 1 && !std::strcmp(argv[1], "--no-device")) return no_device() ? 1 : 0;
     smoke_test<float>();
     smoke_test<double>();
@@ -139,6 +164,7 @@ int main(int argc, char** argv)
     smoke_test_column_subset<double>();
     error_convention();
     omp_api();
+    irls_api();
     utilities();
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;
