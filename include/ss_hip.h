@@ -149,6 +149,9 @@ int ss_hip_gemm_t_f32(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, 
  */
 int ss_hip_gram_cols_f32(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, float* G, ptrdiff_t ldG,
                          int repeats, float* ms_out, char* err, size_t errlen);
+/* the same pass in double precision (v_mfma_f64_16x16x4_f64) */
+int ss_hip_gram_cols_f64(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, double* G, ptrdiff_t ldG,
+                         int repeats, float* ms_out, char* err, size_t errlen);
 
 /*
  * y = A x on the device copy — ss::reconstruct_signal (src/lib.cpp:78-104).
@@ -211,14 +214,14 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "strict_sign"    1 = seed the first direction with sign(c[idx]) instead of the
  *                    reference's sign(|c[idx]|) (homotopy-cpu.cpp:223-227); default 0
  *   "trace"          1 = record the homotopy path of each solve (ss_hip_get_trace)
- *   "engine"         fp32 single-signal Homotopy: 1 (default) = lookahead engine — Gram
+ *   "engine"         single-signal Homotopy: 1 (default) = lookahead engine — Gram
  *                    columns A^T a_j of active columns are cached and A is swept (32 right-hand
  *                    sides per pass) only when an uncached column enters — unless the tolerance
- *                    is below 2^-14 * ||A^T y||_inf, too tight for Gram-form correlations in
- *                    fp32: such a solve runs as 0; 2 = lookahead engine unconditionally;
- *                    0 = one fused 2-RHS sweep per iteration (residual form).  fp64 always uses 0.
+ *                    is below 2^-14 (fp32) / 2^-42 (fp64) * ||A^T y||_inf, too tight for Gram-form
+ *                    correlations: such a solve runs as 0; 2 = lookahead engine unconditionally;
+ *                    0 = one fused 2-RHS sweep per iteration (residual form).
  *   "la_fused"       form of the lookahead engine's iterations: 2 (default) = one resident launch
- *                    (k_la_persist), 1 = one launch per iteration, 0 = separate kernels
+ *                    (k_la_persist, fp32; fp64 runs as 1), 1 = one launch per iteration, 0 = separate kernels
  *   "cache_mib"      memory budget of the lookahead engine's Gram-column cache (default 2048)
  *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 4)
  *   "batch_chunk"    signals processed together by the batched path (default 4096)

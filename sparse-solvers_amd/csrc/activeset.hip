@@ -1287,7 +1287,7 @@ template <typename T>
 hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol)
 {
     // option "engine" = 1: guard on (tolerance vs ||A^T y||_inf), 2: lookahead engine unconditionally
-    const T guard = ctx->engine == 1 ? (T)kGramGuard : T(0);
+    const T guard = ctx->engine == 1 ? (T)(sizeof(T) == 4 ? kGramGuard : kGramGuard64) : T(0);
     hipLaunchKernelGGL((k_la_init_pick<T>), dim3(1), dim3(kSmallThreads), 0, ctx->stream, ws.pmax_val,
                        ws.pmax_idx, nparts, ws.insup, ws.gam, ws.touched, ws.st, ws.trace, tol, guard, ctx->dev_flags);
     return hipGetLastError();
@@ -1391,11 +1391,17 @@ template hipError_t launch_omp_tail<float>(const ss_hip_ctx*, Workspace<float>&,
 template hipError_t launch_omp_tail<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t,
                                             uint32_t, double, uint32_t);
 template hipError_t launch_la_init_pick<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
+template hipError_t launch_la_init_pick<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double);
 template hipError_t launch_la_top<float>(const ss_hip_ctx*, Workspace<float>&, int);
+template hipError_t launch_la_top<double>(const ss_hip_ctx*, Workspace<double>&, int);
 template hipError_t launch_la_update<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
+template hipError_t launch_la_update<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double);
 template hipError_t launch_la_cq<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t*);
+template hipError_t launch_la_cq<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t*);
 template hipError_t launch_la_iter<float>(const ss_hip_ctx*, Workspace<float>&, float, uint32_t);
+template hipError_t launch_la_iter<double>(const ss_hip_ctx*, Workspace<double>&, double, uint32_t);
 template hipError_t launch_la_scansel<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, float, uint32_t);
+template hipError_t launch_la_scansel<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t, double, uint32_t);
 template hipError_t launch_absmax<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t*);
 template hipError_t launch_absmax<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t*);
 template hipError_t launch_gemv_n<float>(const ss_hip_ctx*, const float*, float*);

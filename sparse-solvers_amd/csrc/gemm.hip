@@ -260,6 +260,143 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
     }
 }
 
+// ---- the same pass in fp64 (engine 1 for double): v_mfma_f64_16x16x4_f64 -------------------------
+// 32 right-hand sides x 256 columns per 512-thread workgroup, K-step 16 doubles (128 B per row, the
+// same bytes per step as the fp32 kernel): wave w owns 32 columns as 2 x 2 tiles of 16 x 16.  Per
+// K-step a wave issues 16 MFMAs (4 k-groups of 4 x 4 tiles).  At C5 (16384 x 131072) the pass moves
+// 16 GiB (2.15 ms at 8 TB/s) and needs 137 GFLOP (1.75 ms at the 78.6 TFLOP/s fp64 peak): HBM-bound
+// on paper, close to both roofs in practice — like its fp32 sibling.
+// MFMA operand layout (CDNA3 ISA, 16x16x4 f64): A: lane -> (row lane%16, k lane/16); B: lane ->
+// (k lane/16, col lane%16); D (4 doubles per lane): element j -> (row 4*j + lane/16, col lane%16)
+// (checked against numpy: test_gram_cols_vs_numpy[float64]).
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+constexpr int DK = 16;                       // doubles per K-step
+constexpr int DLD = DK + 2;                  // LDS row pitch in doubles (144 B, as in the fp32 kernel)
+
+__global__ __launch_bounds__(512, 1)
+void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__ rcols,
+                     const uint32_t* __restrict__ drows, double* __restrict__ D,
+                     uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
+                     const DevState* __restrict__ st)
+{
+    if (st != nullptr && (st->done != 0 || st->need_sweep == 0)) return;   // no sweep needed this round
+    constexpr int HN = 256, HT = 512;
+    __shared__ __attribute__((aligned(16))) double sR[2][HM][DLD];
+    __shared__ __attribute__((aligned(16))) double sQ[2][HN][DLD];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t l15 = lane & 15u, kq = lane >> 4;           // MFMA: row / column within the tile, k within the group
+    constexpr int RPP = HT / 8;                                 // rows staged per pass (64)
+    constexpr int NJ = HN / RPP;                                // passes per column tile (4)
+    const uint32_t srow = tid >> 3, spair = tid & 7u;          // staging: rows srow + RPP*j, doubles 2*spair, 2*spair+1
+    const bool has_r = tid < 256;                               // R tile: 32 rows x 8 pairs
+
+    const uint32_t rc = rcols[srow & 31u];
+    const bool rvalid = has_r && rc != 0xffffffffu;
+    const double* gR = At + (size_t)(rvalid ? rc : 0u) * ldq + spair * 2;
+    const v2d_t zero2 = { 0.0, 0.0 };
+    const uint32_t nk = K / DK;
+
+    for (uint32_t bn = blockIdx.x; bn < ntiles; bn += gridDim.x) {
+        const double* gQ = At + (size_t)(bn * HN + srow) * ldq + spair * 2;
+        v4d_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = v4d_t{ 0.0, 0.0, 0.0, 0.0 };
+
+        v2d_t rR[3], rQ[3][NJ];
+#define D32_LOAD(SET, KT)                                                                      \
+    {                                                                                          \
+        const uint32_t koff_ = (KT) * DK;                                                      \
+        rR[SET] = rvalid ? *reinterpret_cast<const v2d_t*>(gR + koff_) : zero2;                \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                         \
+            rQ[SET][j] = __builtin_nontemporal_load(                                           \
+                reinterpret_cast<const v2d_t*>(gQ + (size_t)(RPP * j) * ldq + koff_));         \
+    }
+#define D32_STORE(SET, BUF)                                                                    \
+    {                                                                                          \
+        if (has_r) *reinterpret_cast<v2d_t*>(&sR[BUF][srow][spair * 2]) = rR[SET];             \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                         \
+            *reinterpret_cast<v2d_t*>(&sQ[BUF][srow + RPP * j][spair * 2]) = rQ[SET][j];       \
+    }
+#define D32_COMPUTE(BUF)                                                                       \
+    _Pragma("unroll") for (int g = 0; g < DK / 4; ++g) {                                       \
+        const uint32_t k_ = 4u * g + kq;                                                       \
+        const double a0_ = sR[BUF][l15][k_], a1_ = sR[BUF][16 + l15][k_];                      \
+        const double b0_ = sQ[BUF][wave * 32 + l15][k_], b1_ = sQ[BUF][wave * 32 + 16 + l15][k_]; \
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0_, b0_, acc[0][0], 0, 0, 0);        \
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0_, b1_, acc[0][1], 0, 0, 0);        \
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_, b0_, acc[1][0], 0, 0, 0);        \
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_, b1_, acc[1][1], 0, 0, 0);        \
+    }
+
+        D32_LOAD(0, 0u)
+        if (nk > 1) D32_LOAD(1, 1u)
+        if (nk > 2) D32_LOAD(2, 2u)
+        __syncthreads();                                        // previous column tile fully consumed
+        D32_STORE(0, 0)
+        if (nk > 3) D32_LOAD(0, 3u)
+        __syncthreads();
+
+        uint32_t kt = 0;
+        for (; kt + 3 <= nk; kt += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const uint32_t k = kt + (uint32_t)u;
+                const int buf = (int)(k & 1u);
+                if (buf == 0) { D32_COMPUTE(0) } else { D32_COMPUTE(1) }
+                if (k + 1 < nk) {
+                    const int set = (u + 1) % 3;
+                    if (buf == 0) { D32_STORE(set, 1) } else { D32_STORE(set, 0) }
+                    if (k + 4 < nk) D32_LOAD(set, k + 4)
+                }
+                __syncthreads();
+            }
+        }
+        for (; kt < nk; ++kt) {                                 // nk % 3 leftovers
+            const int buf = (int)(kt & 1u);
+            if (buf == 0) { D32_COMPUTE(0) } else { D32_COMPUTE(1) }
+            if (kt + 1 < nk) {
+                const uint32_t set = (kt + 1) % 3;
+                if (set == 0) { if (buf == 0) { D32_STORE(0, 1) } else { D32_STORE(0, 0) } if (kt + 4 < nk) D32_LOAD(0, kt + 4) }
+                else if (set == 1) { if (buf == 0) { D32_STORE(1, 1) } else { D32_STORE(1, 0) } if (kt + 4 < nk) D32_LOAD(1, kt + 4) }
+                else { if (buf == 0) { D32_STORE(2, 1) } else { D32_STORE(2, 0) } if (kt + 4 < nk) D32_LOAD(2, kt + 4) }
+            }
+            __syncthreads();
+        }
+#undef D32_LOAD
+#undef D32_STORE
+#undef D32_COMPUTE
+
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t col = bn * HN + wave * 32 + 16 * j + l15;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t row = 16 * i + 4 * e + kq;
+                    const uint32_t dr = drows[row];
+                    if (dr != 0xffffffffu) D[(size_t)dr * ldd + col] = acc[i][j][e];
+                }
+            }
+    }
+}
+
+hipError_t launch_gemm32_tn_f64(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
+                                double* D, uint32_t ldd, const DevState* st)
+{
+    if (ctx->n_pad % 256 != 0 || ctx->ldm % DK != 0) return hipErrorInvalidValue;
+    const uint32_t ntiles = ctx->n_pad / 256;
+    const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
+    hipLaunchKernelGGL(k_gemm32_tn_f64, dim3(grid), dim3(512), 0, ctx->stream, static_cast<const double*>(ctx->At),
+                       rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+    return hipGetLastError();
+}
+
 // D[drows[s]][:] = At · At[rcols[s]][:] for s < 32 (entries 0xffffffff are skipped)
 hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
                                 float* D, uint32_t ldd, const DevState* st)

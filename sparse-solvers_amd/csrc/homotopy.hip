@@ -312,17 +312,17 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
 }
 
 // ---- lookahead engine (fp32): Gram-column cache management and round launches -------------
-template <typename T> struct Lookahead {
-    static constexpr bool supported = false;
-    static void ensure(ss_hip_ctx*, Workspace<T>&, uint32_t) {}
-    static void init(ss_hip_ctx*, Workspace<T>&, uint32_t, T) {}
-    static void round(ss_hip_ctx*, Workspace<T>&, uint32_t, T, uint32_t, hipEvent_t = nullptr, hipEvent_t = nullptr) {}
-    static void iterate(ss_hip_ctx*, Workspace<T>&, T, uint32_t, uint32_t) {}
-    static void fetch(ss_hip_ctx*, Workspace<T>&, T, hipEvent_t = nullptr, hipEvent_t = nullptr) {}
-};
+// the 32-RHS lookahead sweep of either precision, and the resident iteration kernel (fp32 only)
+inline hipError_t launch_gemm32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd, const DevState* st)
+{ return launch_gemm32_tn_f32(ctx, rcols, drows, D, ldd, st); }
+inline hipError_t launch_gemm32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows, double* D, uint32_t ldd, const DevState* st)
+{ return launch_gemm32_tn_f64(ctx, rcols, drows, D, ldd, st); }
+inline hipError_t launch_persist(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, uint32_t lds_cols)
+{ return launch_la_persist_f32(ctx, ws, tol, max_iter, lds_cols); }
+inline hipError_t launch_persist(ss_hip_ctx*, Workspace<double>&, double, uint32_t, uint32_t)
+{ return hipErrorInvalidConfiguration; }
 
-template <> struct Lookahead<float> {
-    using T = float;
+template <typename T> struct Lookahead {
     static constexpr bool supported = true;
 
     static void ensure(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t kcap)
@@ -366,7 +366,7 @@ template <> struct Lookahead<float> {
         HIPCHK(hipMemcpyAsync(ws.c, ws.c0, (size_t)ctx->n_pad * sizeof(T), hipMemcpyDeviceToDevice, st));
         HIPCHK(launch_la_init_pick<T>(ctx, ws, nparts, tol));
         HIPCHK(launch_la_top<T>(ctx, ws, 1));
-        HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
         HIPCHK(launch_la_update<T>(ctx, ws, 0, tol));
         if (ctx->la_fused) return;                 // k_la_iter forms c and q itself
         uint32_t np2 = 0;
@@ -378,7 +378,7 @@ template <> struct Lookahead<float> {
     // lds_cols != 0: resident form holding up to that many support columns in LDS
     static void iterate(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter, uint32_t lds_cols)
     {
-        if (lds_cols != 0) HIPCHK(launch_la_persist_f32(ctx, ws, tol, max_iter, lds_cols));
+        if (lds_cols != 0) HIPCHK(launch_persist(ctx, ws, tol, max_iter, lds_cols));
         else HIPCHK(launch_la_iter<T>(ctx, ws, tol, max_iter));
     }
     // ... and, when the device reports an entering column without cached Gram column, the sweep
@@ -387,7 +387,7 @@ template <> struct Lookahead<float> {
     {
         HIPCHK(launch_la_top<T>(ctx, ws, 0));
         if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
-        HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
         if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
         HIPCHK(launch_la_update<T>(ctx, ws, 1, tol));
     }
@@ -400,7 +400,7 @@ template <> struct Lookahead<float> {
         HIPCHK(launch_la_scansel<T>(ctx, ws, rnd, ws.la_nparts, tol, max_iter));
         HIPCHK(launch_la_top<T>(ctx, ws, 0));
         if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
-        HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
         if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
         HIPCHK(launch_la_update<T>(ctx, ws, rnd, tol));
         uint32_t np2 = 0;
@@ -535,7 +535,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             // resident kernel: LDS tier (support columns it can hold); 0 = one launch per iteration
             uint32_t lds_cols = 0;
             const uint32_t kcap_ws = ws.dims.kcap;       // what the device checks K against (>= this solve's kcap)
-            if (ctx->la_fused >= 2 && ctx->zero_on_removal) {
+            if (ctx->la_fused >= 2 && ctx->zero_on_removal && sizeof(T) == 4) {
                 lds_cols = std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsSmall);
                 if (!la_persist_usable(ctx, lds_cols)) lds_cols = 0;
             }
@@ -933,17 +933,18 @@ int gemm_t_impl(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, float*
 }
 
 // G[s][:] = A^T a_{cols[s]} for up to 32 columns in one HBM-bound pass (lookahead sweep kernel)
-int gram_cols_impl(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, float* G, ptrdiff_t ldG, int repeats,
+template <typename T>
+int gram_cols_impl(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, T* G, ptrdiff_t ldG, int repeats,
                    float* ms_out, char* err, size_t errlen)
 {
     if (ctx && ctx->kind != 0) { set_err(err, errlen, "this entry point needs a Homotopy context (an IRLS context holds the factorised matrix)"); return SS_HIP_EINVAL; }
     if (!ctx || !cols || !G || S == 0 || S > 32) { set_err(err, errlen, "gram_cols: need 1..32 columns"); return SS_HIP_EINVAL; }
-    if (ctx->is_f64) { set_err(err, errlen, "gram_cols: fp32 contexts only"); return SS_HIP_ETYPE; }
+    if (ctx->is_f64 != (sizeof(T) == 8)) { set_err(err, errlen, "gram_cols: element type of the call does not match the context"); return SS_HIP_ETYPE; }
     for (size_t s = 0; s < S; ++s)
         if (cols[s] >= ctx->n) { set_err(err, errlen, "gram_cols: column index out of range"); return SS_HIP_EINVAL; }
     if (repeats < 1) repeats = 1;
     uint32_t* dlist = nullptr;
-    float* Dd = nullptr;
+    T* Dd = nullptr;
     int rc = SS_HIP_OK;
     try {
         HIPCHK(hipSetDevice(ctx->device));
@@ -954,13 +955,13 @@ int gram_cols_impl(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, float* G, pt
         }
         const size_t np = ctx->n_pad;
         HIPCHK(hipMalloc(&dlist, sizeof(h)));
-        HIPCHK(hipMalloc(&Dd, 32 * np * sizeof(float)));
+        HIPCHK(hipMalloc(&Dd, 32 * np * sizeof(T)));
         HIPCHK(hipMemcpyAsync(dlist, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev_solve0, ctx->stream));
         for (int i = 0; i < repeats; ++i)
-            HIPCHK(launch_gemm32_tn_f32(ctx, dlist, dlist + 32, Dd, (uint32_t)np, nullptr));
+            HIPCHK(launch_gemm32(ctx, dlist, dlist + 32, Dd, (uint32_t)np, nullptr));
         HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
-        HIPCHK(hipMemcpy2DAsync(G, (size_t)ldG * sizeof(float), Dd, np * sizeof(float), ctx->n * sizeof(float), S,
+        HIPCHK(hipMemcpy2DAsync(G, (size_t)ldG * sizeof(T), Dd, np * sizeof(T), ctx->n * sizeof(T), S,
                                 hipMemcpyDefault, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         float ms = 0.f;
@@ -1170,7 +1171,13 @@ int ss_hip_gemm_t_f32(ss_hip_ctx* ctx, const float* R, size_t B, ptrdiff_t ldR, 
 int ss_hip_gram_cols_f32(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, float* G, ptrdiff_t ldG, int repeats,
                          float* ms_out, char* err, size_t errlen)
 {
-    return gram_cols_impl(ctx, cols, S, G, ldG, repeats, ms_out, err, errlen);
+    return gram_cols_impl<float>(ctx, cols, S, G, ldG, repeats, ms_out, err, errlen);
+}
+
+int ss_hip_gram_cols_f64(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, double* G, ptrdiff_t ldG, int repeats,
+                         float* ms_out, char* err, size_t errlen)
+{
+    return gram_cols_impl<double>(ctx, cols, S, G, ldG, repeats, ms_out, err, errlen);
 }
 
 int ss_hip_reconstruct_f32(ss_hip_ctx* ctx, const float* x, float* y, char* err, size_t errlen)

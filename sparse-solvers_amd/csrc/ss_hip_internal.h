@@ -23,8 +23,9 @@ constexpr uint32_t kColPad = 256;
 // DevState::status raised by the lookahead engine when the tolerance is too tight for Gram-form
 // correlations (never leaves the library: the host re-runs the solve in residual form).
 constexpr uint32_t kStatusRetryResidual = 100;
-// Gram form is used while tolerance >= kGramGuard * ||A^T y||_inf (2^-14: fp32 eps x ~1000).
+// Gram form is used while tolerance >= guard * ||A^T y||_inf: 2^-14 in fp32, 2^-42 in fp64 (eps x ~1000)
 constexpr double kGramGuard = 1.0 / 16384.0;
+constexpr double kGramGuard64 = 1.0 / 4398046511104.0;
 // Hard cap of the active-set capacity (workspace is 2 * Kcap^2 elements).
 constexpr uint32_t kKcapLimit = 4096;
 // Upper bound of workgroups any sweep variant launches (size of the partial-max arrays).
@@ -282,6 +283,10 @@ template <typename T> hipError_t irls_solve(ss_hip_ctx* ctx, T tol, uint32_t max
 template <typename T> T* irls_y_buffer(ss_hip_ctx* ctx);
 template <typename T> T* irls_x_buffer(ss_hip_ctx* ctx);
 void irls_free(ss_hip_ctx* ctx);
+
+// the same pass in fp64 (v_mfma_f64_16x16x4_f64)
+hipError_t launch_gemm32_tn_f64(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
+                                double* D, uint32_t ldd, const DevState* st);
 
 // ---- helpers implemented in homotopy.hip ---------------------------------------
 void set_err(char* err, size_t errlen, const std::string& msg);

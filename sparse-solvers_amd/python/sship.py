@@ -25,7 +25,7 @@ SYMBOLS = [
     "ss_hip_homotopy_solve_f32", "ss_hip_homotopy_solve_f64",
     "ss_hip_omp_solve_f32", "ss_hip_omp_solve_f64",
     "ss_hip_homotopy_solve_batch_f32", "ss_hip_homotopy_solve_batch_f64",
-    "ss_hip_gemv_t_f32", "ss_hip_gemv_t_f64", "ss_hip_gemm_t_f32", "ss_hip_gram_cols_f32",
+    "ss_hip_gemv_t_f32", "ss_hip_gemv_t_f64", "ss_hip_gemm_t_f32", "ss_hip_gram_cols_f32", "ss_hip_gram_cols_f64",
     "ss_hip_reconstruct_f32", "ss_hip_reconstruct_f64",
     "ss_hip_set_profiling", "ss_hip_get_stats", "ss_hip_reset_stats",
     "ss_hip_set_option", "ss_hip_get_option", "ss_hip_get_trace", "ss_hip_ctx_info",
@@ -102,8 +102,9 @@ def lib():
                       ctypes.POINTER(ctypes.c_int), cp, sz]
     L.ss_hip_gemm_t_f32.restype = ctypes.c_int
     L.ss_hip_gemm_t_f32.argtypes = [vp, vp, sz, pd, vp, pd, ctypes.c_int, ctypes.POINTER(ctypes.c_float), cp, sz]
-    L.ss_hip_gram_cols_f32.restype = ctypes.c_int
-    L.ss_hip_gram_cols_f32.argtypes = [vp, vp, sz, vp, pd, ctypes.c_int, ctypes.POINTER(ctypes.c_float), cp, sz]
+    for nme in ("ss_hip_gram_cols_f32", "ss_hip_gram_cols_f64"):
+        getattr(L, nme).restype = ctypes.c_int
+        getattr(L, nme).argtypes = [vp, vp, sz, vp, pd, ctypes.c_int, ctypes.POINTER(ctypes.c_float), cp, sz]
     L.ss_hip_homotopy_destroy.restype = None
     L.ss_hip_homotopy_destroy.argtypes = [vp]
     L.ss_hip_irls_destroy.restype = None
@@ -272,10 +273,10 @@ class Homotopy:
     def gram_cols(self, cols, repeats=1):
         """G[s] = A^T a_{cols[s]} for up to 32 columns in one pass -> (G (S, n), mean ms)"""
         cols = np.ascontiguousarray(cols, dtype=np.uint32)
-        G = np.empty((len(cols), self.n), dtype=np.float32)
+        G = np.empty((len(cols), self.n), dtype=self.dtype)
         ms = ctypes.c_float(0.0)
         err = ctypes.create_string_buffer(512)
-        self._check(lib().ss_hip_gram_cols_f32(self._h, cols.ctypes.data, len(cols), G.ctypes.data, self.n,
+        self._check(getattr(lib(), "ss_hip_gram_cols_" + self.suffix)(self._h, cols.ctypes.data, len(cols), G.ctypes.data, self.n,
                                                int(repeats), ctypes.byref(ms), err, len(err)), err)
         return G, float(ms.value)
 

@@ -676,3 +676,40 @@ def test_resident_kernel_matches_launch_per_iteration(sship, shape):
     assert np.array_equal(x1, x2) and e1 == e2
     if it2 == k:       # recovered along a removal-free path
         assert np.array_equal(significant_support(x2, 1e-4), sup)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gram_cols_vs_numpy(sship, dtype):
+    """the lookahead sweep G[s] = A^T a_{cols[s]} (fp32: v_mfma_f32_32x32x2, fp64: v_mfma_f64_16x16x4)"""
+    rng = np.random.default_rng(11)
+    m, n = 700, 3000
+    A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(dtype)
+    cols = rng.choice(n, 32, replace=False).astype(np.uint32)
+    with sship.Homotopy(A) as h:
+        for S in (32, 5, 1):
+            G, ms = h.gram_cols(cols[:S])
+            ref = (A.astype(np.float64).T @ A.astype(np.float64)[:, cols[:S]]).T
+            assert G.shape == (S, n) and G.dtype == dtype
+            assert np.abs(G - ref).max() <= (2e-6 if dtype == np.float32 else 1e-14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 1000, 10), (512, 4096, 24)])
+def test_engines_agree_f64(sship, shape):
+    """fp64: residual form vs the lookahead engine (separate kernels / one launch per iteration)"""
+    m, n, k = shape
+    A, y, x0, sup = make_gaussian_problem(4200 + m, m, n, k, np.float64)
+    xo, ito, eo, tro = oracle.homotopy(A, y, 1e-9, 4 * k, trace=True)
+    with sship.Homotopy(A) as h:
+        h.set_option("trace", 1)
+        for name, opts in ENGINES.items():
+            for key, val in opts.items():
+                h.set_option(key, val)
+            xg, itg, eg = h.solve(y, 1e-9, 4 * k)
+            trg = h.trace()
+            assert_parity(xg, itg, eg, xo, ito, eo, np.float64)
+            assert np.array_equal(trg["idx"][:-1], tro["idx"][:-1]), name
+            assert np.allclose(trg["gamma"][:-1], tro["gamma"][:-1], rtol=1e-8, atol=1e-12), name
+        st = h.stats()
+        assert st["lookahead_sweeps"] >= 3       # the lookahead forms really ran in double precision
