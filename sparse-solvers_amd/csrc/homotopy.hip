@@ -646,6 +646,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             ctx->stats.persist_fallbacks += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual);
         }
+        if (la && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 1) {
+            // k_la_iter's grid barrier expired as well (the GPU is shared with another resident grid):
+            // from here on this context uses the form without in-kernel grid synchronisation
+            ctx->la_fused = 0;
+            ctx->stats.persist_fallbacks += 1;
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual);
+        }
         if (hs.status != 0) {
             set_err(err, errlen, hs.status == SS_HIP_ECAPACITY
                                      ? "solve: active set outgrew the workspace capacity (4096 columns)"
