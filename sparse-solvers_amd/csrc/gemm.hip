@@ -260,6 +260,101 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
     }
 }
 
+// ---- barrier-free form of the fp32 pass -------------------------------------------------------------
+// Every wave is on its own: it streams ITS 32 columns of A (coalesced: 8 lanes per 128-B row
+// segment, 8 rows per instruction) and its own copy of the 32 right-hand-side rows (L2 hits) three
+// K-steps ahead in registers, turns each K-step into MFMA layout through a wave-private LDS tile
+// (write, wait, read back as k-quads) and issues its 16 MFMAs.  No workgroup barrier anywhere, so a
+// wave waiting for memory never stalls the other waves of its SIMD.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2)
+void k_gemm32w_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
+                      const uint32_t* __restrict__ drows, float* __restrict__ D,
+                      uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
+                      const DevState* __restrict__ st)
+{
+    if (st != nullptr && (st->done != 0 || st->need_sweep == 0)) return;   // no sweep needed this round
+    __shared__ __attribute__((aligned(16))) float sT[WAVES][2][32][GLD];    // per wave: R tile, Q tile
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t h = lane >> 5, l31 = lane & 31u;
+    const uint32_t r8 = lane >> 3, quad = lane & 7u;            // staging: rows r8 + 8j, k-quad `quad`
+    float (*sR)[GLD] = sT[wave][0];
+    float (*sQ)[GLD] = sT[wave][1];
+    const v4f zero4 = { 0.f, 0.f, 0.f, 0.f };
+    const uint32_t nk = K / GK;
+
+    const float* gR[4];
+    bool rvalid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t rc = rcols[r8 + 8 * j];
+        rvalid[j] = rc != 0xffffffffu;
+        gR[j] = At + (size_t)(rvalid[j] ? rc : 0u) * ldq + quad * 4;
+    }
+
+    for (uint32_t tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
+        const float* gQ = At + (size_t)(tile * 32 + r8) * ldq + quad * 4;
+        v16f acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        v4f rR[3][4], rQ[3][4];
+#define W32_LOAD(SET, KT)                                                                      \
+    {                                                                                          \
+        const uint32_t koff_ = (KT) * GK;                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
+            rR[SET][j] = rvalid[j] ? *reinterpret_cast<const v4f*>(gR[j] + koff_) : zero4;     \
+            rQ[SET][j] = __builtin_nontemporal_load(                                           \
+                reinterpret_cast<const v4f*>(gQ + (size_t)(8 * j) * ldq + koff_));             \
+        }                                                                                      \
+    }
+#define W32_STEP(SET)                                                                          \
+    {                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
+            *reinterpret_cast<v4f*>(&sR[r8 + 8 * j][quad * 4]) = rR[SET][j];                   \
+            *reinterpret_cast<v4f*>(&sQ[r8 + 8 * j][quad * 4]) = rQ[SET][j];                   \
+        }                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                       \
+        v4f a_[GK / 8], b_[GK / 8];                                                            \
+        _Pragma("unroll") for (int g = 0; g < GK / 8; ++g) {                                   \
+            const uint32_t kq_ = (2u * g + h) * 4u;                                            \
+            a_[g] = *reinterpret_cast<const v4f*>(&sR[l31][kq_]);                              \
+            b_[g] = *reinterpret_cast<const v4f*>(&sQ[l31][kq_]);                              \
+        }                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                       \
+        _Pragma("unroll") for (int g = 0; g < GK / 8; ++g)                                     \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                      \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[g][t], b_[g][t], acc, 0, 0, 0);  \
+    }
+
+        W32_LOAD(0, 0u)
+        if (nk > 1) W32_LOAD(1, 1u)
+        if (nk > 2) W32_LOAD(2, 2u)
+        uint32_t kt = 0;
+        for (; kt + 3 <= nk; kt += 3) {
+            W32_STEP(0)
+            if (kt + 3 < nk) W32_LOAD(0, kt + 3)
+            W32_STEP(1)
+            if (kt + 4 < nk) W32_LOAD(1, kt + 4)
+            W32_STEP(2)
+            if (kt + 5 < nk) W32_LOAD(2, kt + 5)
+        }
+        if (kt < nk) { W32_STEP(0) ++kt; }
+        if (kt < nk) { W32_STEP(1) ++kt; }
+#undef W32_LOAD
+#undef W32_STEP
+
+        const uint32_t col = tile * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const uint32_t dr = drows[row];
+            if (dr != 0xffffffffu) D[(size_t)dr * ldd + col] = acc[e];
+        }
+    }
+}
+
 // ---- the same pass in fp64 (engine 1 for double): v_mfma_f64_16x16x4_f64 -------------------------
 // 32 right-hand sides x 256 columns per 512-thread workgroup, K-step 16 doubles (128 B per row, the
 // same bytes per step as the fp32 kernel): wave w owns 32 columns as 2 x 2 tiles of 16 x 16.  Per
@@ -403,7 +498,14 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
 {
     if (ctx->n_pad % 256 != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
     const float* At = static_cast<const float*>(ctx->At);
-    if (ctx->sweep32_variant == 0) {
+    if (ctx->sweep32_variant == 3) {
+        // barrier-free: 32-column tiles, one per wave, 4 waves per workgroup, 2 workgroups per CU
+        const uint32_t ntiles = ctx->n_pad / 32;
+        const uint32_t cap = 2u * (uint32_t)ctx->num_cus;
+        const uint32_t want = (ntiles + 3u) / 4u;
+        hipLaunchKernelGGL((k_gemm32w_tn_f32<4>), dim3(want < cap ? want : cap), dim3(256), 0, ctx->stream,
+                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+    } else if (ctx->sweep32_variant == 0) {
         // one 256-column tile per workgroup of 512 threads, one workgroup per CU
         const uint32_t ntiles = ctx->n_pad / 256;
         const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;

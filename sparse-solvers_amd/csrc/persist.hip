@@ -79,8 +79,6 @@ __device__ __forceinline__ void drain_vmem()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 // LDS carve-up (floats / 32-bit words), P = columns the launch can hold (a multiple of 16)
 struct PsLds {
     float* I;        // [P][P + 1] explicit inverse, sorted-support order (master)
@@ -92,9 +90,8 @@ struct PsLds {
     float* u2;       // [P]
     float* sg;       // [P] sign vector
     float* cn;       // [P] correlations after the step, support order
-    v2f* xd;         // [P] (x, d) pairs, what the Gram-form loop reads
 };
-__host__ __device__ inline size_t ps_lds_words(uint32_t P) { return (size_t)P * (P + 1) + 10 * (size_t)P; }
+__host__ __device__ inline size_t ps_lds_words(uint32_t P) { return (size_t)P * (P + 1) + 8 * (size_t)P; }
 
 // four independent wave sums (same order of additions as wave_sum)
 __device__ __forceinline__ void wave_sum4(float (&v)[4])
@@ -213,9 +210,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     S.u2 = S.u1 + P;
     S.sg = S.u2 + P;
     S.cn = S.sg + P;
-    S.xd = reinterpret_cast<v2f*>(S.cn + P);
     // the workgroup's slice of the first gl_rows cache rows: [gl_rows][kPsWidth]
-    float* const Glds = reinterpret_cast<float*>(S.xd + P);
+    float* const Glds = S.cn + P;
 
     // ---- nothing to do in this launch? (same answer in every workgroup: DevState was written
     // ---- by earlier launches only) --------------------------------------------------------------
@@ -265,12 +261,11 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         const uint32_t cl = gam_cur[tid];
         S.gam[tid] = cl;
         S.slt[tid] = (uint32_t)slot_of[cl];
-        const float x0 = x[cl], d0 = d[cl];
-        S.xs[tid] = x0;
-        S.ds[tid] = d0;
-        S.xd[tid] = v2f{ x0, d0 };
+        S.xs[tid] = x[cl];
+        S.ds[tid] = d[cl];
     } else if (tid < P) {
-        S.xd[tid] = v2f{ 0.f, 0.f };                 // padding of the Gram-form loop (whole groups of 16)
+        S.xs[tid] = 0.f;                             // padding of the Gram-form loops (whole groups of 16)
+        S.ds[tid] = 0.f;
     }
     __syncthreads();
     // the Gram-column cache as a buffer: row offsets go in the scalar offset of the loads
@@ -315,37 +310,30 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     float pend_dv = 0.f;
     uint64_t ts[8];
 
-    // c, q of this thread's columns from the replica (Gram form), partial maximum of |c|
-    // (cdst, qdst: where the values are published for the other workgroups, or null)
-    auto gram_form = [&](float (&cv)[kPsCols], float (&qv)[kPsCols], float& bv, uint32_t& bi, float* cdst, float* qdst) {
-        bv = -1.f;
-        bi = 0xffffffffu;
+    // sum_j coef[j] * G[slt[j]][col] over the first Kc list entries, for this thread's columns.
+    // Each lane fetches one cache slot of the lists; the loop takes them out of the lanes as scalars.
+    // Rows below gl_used come from the LDS slice (first column set), the others by buffer loads
+    // whose row offset is a scalar register.  Entries Kc .. roundup16(Kc)-1 are padding (coef = 0
+    // on a valid row: exact zeros), so the loop runs in whole groups of sixteen without branches.
+    auto gram_pass = [&](const float* coef, uint32_t Kc, float (&out)[kPsCols]) {
 #pragma unroll
         for (int k = 0; k < kPsCols; ++k) {
-            cv[k] = 0.f; qv[k] = 0.f;
-            // whole waves only: the lanes exchange support entries below, so a lane without a column
-            // of its own computes along on column 0 and discards the result
-            if (__ballot(in[k]) == 0ull) continue;
-            // Each lane fetches one cache slot of the support from the replica; the loop takes them out
-            // of the lanes as scalars and uses them as the scalar offset of a buffer load (the column
-            // offset is this lane's constant), so no vector ALU work goes into addressing.  (x, d) come
-            // as one LDS broadcast; multiply and add are the packed forms of the separate roundings.
+            out[k] = 0.f;
+            if (__ballot(in[k]) == 0ull) continue;            // whole waves only (lanes exchange entries)
             const uint32_t cofs4 = (in[k] ? col[k] : 0u) * 4u;
-            v2f acc = { 0.f, 0.f };
-            // (entries K .. K16-1 are padding: x = d = 0 on a valid row, they add exact zeros)
-            const uint32_t K16 = (K + 15u) & ~15u;
-            const uint32_t lds_lim = k == 0 ? gl_used : 0u;   // rows below it are in the LDS slice (first column set)
+            const uint32_t K16 = (Kc + 15u) & ~15u;
+            const uint32_t lds_lim = k == 0 ? gl_used : 0u;
             const uint32_t tcol = tid & (kPsWidth - 1u);
+            float acc = 0.f;
             for (uint32_t j0 = 0; j0 < K16; j0 += 64) {
                 const uint32_t jl = j0 + (uint32_t)lane;
-                const uint32_t vs = S.slt[jl < K ? jl : 0u];
+                const uint32_t vs = S.slt[jl < Kc ? jl : 0u];
                 const uint32_t cnt = K16 - j0 < 64u ? K16 - j0 : 64u;
-                const v2f* xdp = S.xd + j0;
+                const float* cf = coef + j0;
                 const uint64_t out_of_lds = __ballot(vs >= lds_lim);      // lanes whose row must come from L2
                 for (uint32_t u = 0; u < cnt; u += 16) {
                     float gv[16];
                     if (((out_of_lds >> u) & 0xffffull) == 0ull) {
-                        // all sixteen rows in LDS: no branches, sixteen reads in flight
 #pragma unroll
                         for (int t = 0; t < 16; ++t) gv[t] = Glds[__builtin_amdgcn_readlane(vs, u + t) * kPsWidth + tcol];
                     } else {
@@ -362,95 +350,99 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                         }
                     }
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) acc += xdp[u + t] * v2f{ gv[t], gv[t] };
+                    for (int t = 0; t < 16; ++t) acc += cf[u + t] * gv[t];
                 }
             }
-            const float ax = acc.x, ad = acc.y;
-            if (k == 0) ts[7] = wall_clock64();
+            out[k] = acc;
+        }
+    };
+
+    float cv[kPsCols], qv[kPsCols];
+    // c = c0 - sum_j x_j g_j over the lists as they stand (entries with x = 0 add exact zeros), the
+    // partial maximum of |c|, and this workgroup's word of the lambda exchange of a new tick
+    auto c_pass_and_post = [&]() {
+        ++tick;
+        float ax[kPsCols];
+        gram_pass(S.xs, K, ax);
+        float bv = -1.f;
+        uint32_t bi = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < kPsCols; ++k) {
+            cv[k] = 0.f;
             if (!in[k]) continue;
-            cv[k] = c0v[k] - ax;
-            qv[k] = ad;
-            if (cdst != nullptr) {
-                st_f32(&cdst[col[k]], cv[k]);             // read across workgroups on the support
-                st_f32(&qdst[col[k]], qv[k]);
-            }
+            cv[k] = c0v[k] - ax[k];
             const float a = cv[k] < 0.f ? -cv[k] : cv[k];
             if (better_max(a, col[k], bv, bi)) { bv = a; bi = col[k]; }
         }
         block_reduce_pair<float, true>(bv, bi, sv, si);
+        if (tid == 0)
+            st_u64(&smax[(tick & 1u) * kLaSlotStride + w],
+                   bi != 0xffffffffu ? (((uint64_t)__float_as_uint(bv) << 32) | (uint64_t)(0xffffffffu - bi)) : 0ull);
     };
-    // lambda = ||c||_inf: post this workgroup's maximum, read all of them (false: a wait expired)
-    auto exchange_max = [&](uint32_t par, float bv, uint32_t bi, float& lam) -> bool {
+    // read everybody's word of the lambda exchange of the current tick (false: a wait expired)
+    auto poll_lambda = [&](float& lam) -> bool {
+        const uint32_t par = (tick & 1u) * kLaSlotStride;
         float mv = -1.f;
         uint32_t mi = 0xffffffffu;
-        const uint64_t mine = bi != 0xffffffffu ? (((uint64_t)__float_as_uint(bv) << 32) | (uint64_t)(0xffffffffu - bi)) : 0ull;
-        const bool ok = exchange_all(smax + par, nb, w, mine, [&](uint64_t pk) {
-            if (pk != 0ull) {
-                const float v = __uint_as_float((uint32_t)(pk >> 32));
-                const uint32_t i2 = 0xffffffffu - (uint32_t)pk;
-                if (better_max(v, i2, mv, mi)) { mv = v; mi = i2; }
+        bool ok = true;
+        for (uint32_t s0 = 0; s0 < nb; s0 += kPsThreads) {
+            const uint32_t sidx = s0 + tid;
+            if (sidx < nb) {
+                uint64_t pk = kLaSlotEmpty;
+                for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
+                    pk = ld_u64(&smax[par + sidx]);
+                    if (pk != kLaSlotEmpty) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (pk == kLaSlotEmpty) ok = false;
+                else if (pk != 0ull) {
+                    const float v = __uint_as_float((uint32_t)(pk >> 32));
+                    const uint32_t i2 = 0xffffffffu - (uint32_t)pk;
+                    if (better_max(v, i2, mv, mi)) { mv = v; mi = i2; }
+                }
             }
-        });
-        if (!ok) return false;
+        }
+        if (__syncthreads_or(ok ? 0 : 1)) return false;
         block_reduce_pair<float, true>(mv, mi, sv, si);
         lam = mv;
+        // every workgroup is past the previous step-length exchange (it posted a maximum after it):
+        // this workgroup's slot of that exchange can be cleared for its next use
+        if (tid == 0) st_u64(&smin[((tick + 1u) & 1u) * kLaSlotStride + w], kLaSlotEmpty);
         return true;
     };
 
-    for (;;) {
-        if (K + 1u > P && P < kcap) {
-            if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
-            exit_code = 3;
-            break;
-        }
-        ++tick;
+    // Software pipeline.  The lambda exchange of an iteration is posted as soon as its x is known
+    // (right after the previous pick) and read only after the inverse update and the q pass, which
+    // hide its latency; the step-length exchange hides the in-place store pass of the inverse.
+    if (K + 1u > P && P < kcap) {
+        exit_code = 3;                               // (also caught at entry; kept for clarity)
+    } else {
+        c_pass_and_post();
+    }
+    while (exit_code == 0) {
         const uint32_t round = iter + 1u;
-        const uint32_t par = (tick & 1u) * kLaSlotStride, par_prev = ((tick + 1u) & 1u) * kLaSlotStride;
+        const uint32_t par = (tick & 1u) * kLaSlotStride;
         ts[0] = wall_clock64();
 
-        // ---- c, q of the own columns; lambda ----------------------------------------------------------
-        // c, q cross workgroups through the buffer of this tick's parity: a workgroup may already be
-        // writing the next tick's values while a slower one still reads this tick's on the support
+        // ---- q = sum_j d_j g_j; publish c, q for the reads on the support -----------------------------
+        // (buffer of this tick's parity: a workgroup may already be writing the next tick's values
+        // while a slower one still reads this tick's)
         float* const cbuf = (tick & 1u) ? c_alt : c;
         float* const qbuf = (tick & 1u) ? q_alt : q;
-        float cv[kPsCols], qv[kPsCols];
-        float bv, c_inf;
-        uint32_t bi;
-        gram_form(cv, qv, bv, bi, cbuf, qbuf);
+        gram_pass(S.ds, K, qv);
+#pragma unroll
+        for (int k = 0; k < kPsCols; ++k)
+            if (in[k]) { st_f32(&cbuf[col[k]], cv[k]); st_f32(&qbuf[col[k]], qv[k]); }
         ts[1] = wall_clock64();
-        if (tid == 0) st_u64(&smax[par + w], bi != 0xffffffffu ? (((uint64_t)__float_as_uint(bv) << 32) | (uint64_t)(0xffffffffu - bi)) : 0ull);
-        {
-            float mv = -1.f;
-            uint32_t mi = 0xffffffffu;
-            bool ok = true;
-            for (uint32_t s0 = 0; s0 < nb; s0 += kPsThreads) {
-                const uint32_t sidx = s0 + tid;
-                if (sidx < nb) {
-                    uint64_t pk = kLaSlotEmpty;
-                    for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
-                        pk = ld_u64(&smax[par + sidx]);
-                        if (pk != kLaSlotEmpty) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (pk == kLaSlotEmpty) ok = false;
-                    else if (pk != 0ull) {
-                        const float v = __uint_as_float((uint32_t)(pk >> 32));
-                        const uint32_t i2 = 0xffffffffu - (uint32_t)pk;
-                        if (better_max(v, i2, mv, mi)) { mv = v; mi = i2; }
-                    }
-                }
-            }
-            if (__syncthreads_or(ok ? 0 : 1)) { exit_code = 4; break; }
-            block_reduce_pair<float, true>(mv, mi, sv, si);
-            c_inf = mv;
-        }
-        // every workgroup is past the previous step-length exchange (it posted a maximum after it):
-        // this workgroup's slot of that exchange can be cleared for its next use
-        if (tid == 0) st_u64(&smin[par_prev + w], kLaSlotEmpty);
+
+        // ---- lambda (posted before the inverse update) ---------------------------------------------------
+        float c_inf;
+        if (!poll_lambda(c_inf)) { exit_code = 4; break; }
         ts[2] = wall_clock64();
 
         // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
         if ((round > 1u && !(c_inf > tol)) || round > max_iter) {
+            if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
             c_inf_rep = c_inf;
             iter = round - 1u;
             done_round = round;
@@ -484,7 +476,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             mk[k] = m;
             if (m < Lim<float>::max() && better_min(m, col[k], best, best_i)) { best = m; best_i = col[k]; }
         }
-        drain_vmem();                                      // this wave's c, q stores are performed (issued long ago)
+        drain_vmem();                                      // this wave's c, q stores are performed
         block_reduce_pair<float, false>(best, best_i, sv, si);
         if (tid == 0)
             st_u64(&smin[par + w], best_i != 0xffffffffu ? (((uint64_t)__float_as_uint(best) << 32) | (uint64_t)best_i) : kLaSlotNone);
@@ -586,29 +578,26 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         last_idx = idx; last_rank = rank; last_added = added ? 1u : 0u;
         __syncthreads();
 
-        if (added && slot < 0) {
+        const bool miss = added && slot < 0;
+        const bool grow_next = !miss && (K_new + 1u > P) && (P < kcap);
+        // The next iteration's c only needs the x just updated (a column that entered carries x = 0, one
+        // that left carries an exact 0 in its old list entry): form it and start its lambda exchange now.
+        if (!grow_next) c_pass_and_post();
+
+        if (miss) {
             // No cached Gram column.  Before A is swept for it: the while-test of this iteration only
-            // needs lambda = ||A^T(y - A x)||_inf for the x just updated, and the entering column
-            // carries x = 0, so a probe exchange over the old support answers it exactly.  If the
-            // solve ends here (homotopy-cpu.cpp:272) the pending inverse update would never be used.
-            ++tick;
-            const uint32_t par2 = (tick & 1u) * kLaSlotStride, par2_prev = ((tick + 1u) & 1u) * kLaSlotStride;
-            float pv, lam;
-            uint32_t pi;
-            float pc[kPsCols], pq[kPsCols];
-            if (tid < K) S.xd[tid] = v2f{ S.xs[tid], 0.f };
-            else if (tid < P) S.xd[tid] = v2f{ 0.f, 0.f };
-            __syncthreads();
-            gram_form(pc, pq, pv, pi, nullptr, nullptr); // c, q, tcand stay those of the iteration
-            if (!exchange_max(par2, pv, pi, lam)) { exit_code = 4; break; }
-            if (tid == 0) st_u64(&smin[par2_prev + w], kLaSlotEmpty);
-            // the probe has no step-length exchange of its own: an (empty-handed) one keeps the
-            // slot discipline — it proves every workgroup has read the probe's maxima
+            // needs lambda = ||A^T(y - A x)||_inf for the x just updated — the exchange just started.
+            // If the solve ends here (homotopy-cpu.cpp:272) the pending inverse update is never used.
+            float lam;
+            if (!poll_lambda(lam)) { exit_code = 4; break; }
+            // this tick has no step-length exchange of its own: an (empty-handed) one keeps the slot
+            // discipline — it proves every workgroup has read the maxima
             {
+                const uint32_t par2 = (tick & 1u) * kLaSlotStride;
                 const bool ok = exchange_all(smin + par2, nb, w, kLaSlotNone, [&](uint64_t) {});
                 if (!ok) { exit_code = 4; break; }
+                if (tid == 0) st_u64(&smax[par2 + w], kLaSlotEmpty);
             }
-            if (tid == 0) st_u64(&smax[par2 + w], kLaSlotEmpty);
             if (!(lam > tol) || round + 1u > max_iter) {
                 c_inf_rep = lam;                         // iter = round already
                 done_round = round + 1u;
@@ -616,18 +605,17 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 break;
             }
             // the path goes on: hand the pending inverse update to k_gramupd, which reads the
-            // iteration's c and q from the primary buffers
-            if (cbuf != c) {
+            // iteration's c and q from the primary buffers (the c just formed belongs to the next one)
 #pragma unroll
-                for (int k = 0; k < kPsCols; ++k)
-                    if (in[k]) { c[col[k]] = cv[k]; q[col[k]] = qv[k]; }
-            }
+            for (int k = 0; k < kPsCols; ++k)
+                if (in[k]) { c[col[k]] = ld_f32(&cbuf[col[k]]); q[col[k]] = qv[k]; }
             save_lists_for_update = true;
             pend_rank = rank;
             pend_idx = idx;
             exit_code = 2;
             break;
         }
+        ts[4] = wall_clock64();
 
         // correlations after the step on the new support, c - gamma*q (their sign is all that is used)
         const float cnv = cj - g * qj;
@@ -641,7 +629,6 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             if (tid < K) S.u1[tid] = u1v;
             else if (tid == K) s_dd = u1v;                       // dot, replaced by d below
             __syncthreads();
-            ts[4] = wall_clock64();
             const uint32_t nn = K;
             // u2 = inv * u1 (online_inverse.h:224-225), one wave per row
             for (uint32_t i0 = wave; i0 < nn; i0 += 4 * NW) {
@@ -687,7 +674,6 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             __syncthreads();
             if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; }
         } else {
-            ts[4] = wall_clock64();
             // remove row/column `rank` (online_inverse.h:275-290)
             const uint32_t nn = K;
             dv = S.I[rank * Pp + rank];                            // d of the reference; (-d u3) u3^T below
@@ -706,13 +692,13 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             }
             __syncthreads();
             if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; }
+            else if (tid == K_new) { S.xs[tid] = 0.f; S.ds[tid] = 0.f; }     // the vacated entry is padding again
         }
         __syncthreads();
         ts[5] = wall_clock64();
         // sign(c[Gamma]) with dead zone tol (homotopy-cpu.cpp:259-260), direction = inv * sign (:263).
         // The new inverse is not stored yet: its elements are formed on the fly, by the same
-        // expressions the store pass uses, so that the next iteration can start at once; the store
-        // pass runs while that iteration's maxima travel.
+        // expressions the store pass uses; the store pass runs during the next step-length exchange.
         if (tid < K_new) S.sg[tid] = sign_tol(S.cn[tid], tol);
         __syncthreads();
         for (uint32_t a0 = wave; a0 < K_new; a0 += 4 * NW) {
@@ -733,15 +719,17 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             }
         }
         __syncthreads();
-        if (tid < K_new) S.xd[tid] = v2f{ S.xs[tid], S.ds[tid] };
-        else if (tid < P) S.xd[tid] = v2f{ 0.f, 0.f };
-        __syncthreads();
         pend = true; pend_added = added; pend_rk = rank; pend_dv = dv; pend_K = K_new;
         K = K_new;
         if (dbg != nullptr && lead && tid == 0 && round < 1024u) {
             ts[6] = wall_clock64();
-            ts[7] = ((ts[7] - ts[0]) << 16) | K;        // debug: time to the end of the Gram-form loads, support size
+            ts[7] = K;
             for (int k2 = 0; k2 < 8; ++k2) dbg[(size_t)round * 8 + k2] = ts[k2];
+        }
+        if (grow_next) {
+            store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K);
+            pend = false;
+            exit_code = 3;
         }
     }
 

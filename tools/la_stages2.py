@@ -4,18 +4,16 @@ import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(2048, 8)
 rows = [r for r in range(1, 1024) if a[r, 0] != 0 and a[r, 6] > a[r, 0]]
-names = ["c,q (gram form)", "lambda exchange", "scan + step exchange", "pick, x, loads", "u2, d, lists", "sign + direction"]
+names = ["q pass + stores", "lambda poll", "scan + step exchange", "pick, x, c pass, post", "u2, d, lists", "sign + direction"]
 d = np.array([[(int(a[r, k + 1]) - int(a[r, k])) / 100.0 for k in range(6)] for r in rows])
 print("launch info (last): lds rows used %d, workgroups %d, lds rows %d, K at entry %d" % tuple(int(v) for v in a[0, :4]))
 print("iterations recorded:", len(rows))
 for k, nme in enumerate(names):
     print("  %-22s mean %6.2f us   min %6.2f   max %6.2f" % (nme, d[:, k].mean(), d[:, k].min(), d[:, k].max()))
 print("  total                  mean %6.2f us" % d.sum(1).mean())
-inner = np.array([(int(a[r, 7]) >> 16) / 100.0 for r in rows])
-print("  (gram form up to the last accumulate: mean %6.2f us, max %6.2f)" % (inner.mean(), inner.max()))
 gaps = [(int(a[rows[i + 1], 0]) - int(a[rows[i], 6])) / 100.0 for i in range(len(rows) - 1) if rows[i + 1] == rows[i] + 1]
 if gaps:
     print("  iteration to iteration mean %6.2f us (end of one to start of the next)" % np.mean(gaps))
 if len(sys.argv) > 2:
     for r, row in zip(rows, d):
-        print(r, " ".join("%6.2f" % v for v in row), "K", int(a[r, 7]) & 0xffff)
+        print(r, " ".join("%6.2f" % v for v in row), "K", int(a[r, 7]))
