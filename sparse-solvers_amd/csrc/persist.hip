@@ -360,8 +360,9 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     float cv[kPsCols], qv[kPsCols];
     // c = c0 - sum_j x_j g_j over the lists as they stand (entries with x = 0 add exact zeros), the
     // partial maximum of |c|, and this workgroup's word of the lambda exchange of a new tick
-    auto c_pass_and_post = [&]() {
-        ++tick;
+    float cmax_v = -1.f;
+    uint32_t cmax_i = 0xffffffffu;
+    auto c_pass = [&]() {
         float ax[kPsCols];
         gram_pass(S.xs, K, ax);
         float bv = -1.f;
@@ -375,10 +376,16 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             if (better_max(a, col[k], bv, bi)) { bv = a; bi = col[k]; }
         }
         block_reduce_pair<float, true>(bv, bi, sv, si);
+        cmax_v = bv;
+        cmax_i = bi;
+    };
+    auto post_lambda = [&]() {
+        ++tick;
         if (tid == 0)
             st_u64(&smax[(tick & 1u) * kLaSlotStride + w],
-                   bi != 0xffffffffu ? (((uint64_t)__float_as_uint(bv) << 32) | (uint64_t)(0xffffffffu - bi)) : 0ull);
+                   cmax_i != 0xffffffffu ? (((uint64_t)__float_as_uint(cmax_v) << 32) | (uint64_t)(0xffffffffu - cmax_i)) : 0ull);
     };
+    auto c_pass_and_post = [&]() { c_pass(); post_lambda(); };
     // read everybody's word of the lambda exchange of the current tick (false: a wait expired)
     auto poll_lambda = [&](float& lam) -> bool {
         const uint32_t par = (tick & 1u) * kLaSlotStride;
@@ -578,11 +585,13 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         last_idx = idx; last_rank = rank; last_added = added ? 1u : 0u;
         __syncthreads();
 
+        // The next iteration's c only needs the x just updated (a column that entered carries x = 0, one
+        // that left carries an exact 0 in its old list entry): form it (the loads above are still in
+        // flight) and start its lambda exchange now.
+        c_pass();
         const bool miss = added && slot < 0;
         const bool grow_next = !miss && (K_new + 1u > P) && (P < kcap);
-        // The next iteration's c only needs the x just updated (a column that entered carries x = 0, one
-        // that left carries an exact 0 in its old list entry): form it and start its lambda exchange now.
-        if (!grow_next) c_pass_and_post();
+        if (!grow_next) post_lambda();
 
         if (miss) {
             // No cached Gram column.  Before A is swept for it: the while-test of this iteration only
