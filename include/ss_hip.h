@@ -103,9 +103,9 @@ int ss_hip_omp_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy,
  * Batch of B signals sharing the context's sensing matrix: signal b is
  * Y[b*y_stride + i*incy], its solution X[b*x_stride + j*incx].
  * iter_out[B], err_out[B] receive the per-signal reports.
- * fp32 batches of >= "batch_min" (default 4) signals advance in lock-step: the 2B
+ * fp32 batches of >= "batch_min" (default 192) signals advance in lock-step: the 2B
  * correlation GEMVs of a round become MFMA GEMMs over the shared matrix.  Smaller batches
- * and fp64 run one signal at a time on the memory-bound sweep path.
+ * and fp64 run one signal at a time (the single-signal engine, see option "engine").
  */
 int ss_hip_homotopy_solve_batch_f32(ss_hip_ctx* ctx, const float* Y, size_t B,
                                     ptrdiff_t y_stride, ptrdiff_t incy,
@@ -223,7 +223,8 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "la_fused"       form of the lookahead engine's iterations: 2 (default) = one resident launch
  *                    (k_la_persist, fp32; fp64 runs as 1), 1 = one launch per iteration, 0 = separate kernels
  *   "cache_mib"      memory budget of the lookahead engine's Gram-column cache (default 2048)
- *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 4)
+ *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 192: below
+ *                    that, one lookahead solve per signal is faster)
  *   "batch_chunk"    signals processed together by the batched path (default 4096)
  *   "profile_every"  with profiling on, bracket only every k-th fused sweep with events
  *   "tie_guard"      1 (default) = an off-support column that attains max|c| exactly (it

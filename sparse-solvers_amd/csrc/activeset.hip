@@ -527,8 +527,8 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
         st->cache_used = used;
         st->nsweeps += 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (slot_of[idx] < 0) {                 // cache exhausted: the column cannot be inserted
-            st->status = SS_HIP_ECAPACITY;
+        if (slot_of[idx] < 0) {                 // cache budget exhausted: the host re-runs the solve in residual form
+            st->status = kStatusRetryResidual;
             st->need_sweep = 0;
             st->done = 1;
             signal_done(hflags, nullptr, 1u, st->iter);

@@ -842,7 +842,7 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                          uint32_t max_iter, float* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
                          double* err_out, char* err, size_t errlen)
 {
-    // lock-step MFMA path once enough signals share the matrix (batch_min option, default 4)
+    // lock-step MFMA path once enough signals share the matrix (batch_min option, default 192)
     if (B >= (size_t)std::max(2, ctx->batch_min))
         return solve_batch_gemm_f32(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen);
     return solve_batch_seq<float>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen);

@@ -184,7 +184,7 @@ struct ss_hip_ctx {
     int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns) unless the tolerance is too tight for it, 2 = lookahead always, 0 = one fused sweep per iteration
     int sweep32_variant = 0; // lookahead sweep tiling: 0 = 256 columns x 512 threads (1 per CU), 1 / 2 = 128 columns x 256 threads (2 / 3 per CU)
     int la_fused = 2;        // lookahead engine: 2 = resident kernel (k_la_persist), 1 = one kernel per iteration (k_la_iter), 0 = scan / update / cq kernels
-    int batch_min = 4;       // batches of at least this many fp32 signals run in lock-step on the MFMA GEMM
+    int batch_min = 192;     // batches of at least this many fp32 signals run in lock-step on the MFMA GEMM (below: one lookahead solve per signal, ~2.4 ms each at C2, is faster)
     int batch_chunk = 4096;  // signals processed together by the batched path
     int tracing = 0;
     std::vector<sship::TraceEntry> last_trace;   // host copy of the last solve's path

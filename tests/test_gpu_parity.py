@@ -260,10 +260,12 @@ def _batch_problem(seed, m, n, B, kmin, kmax, dtype):
 
 @pytest.mark.parametrize("B", [1, 3, 9, 130])
 def test_batch_vs_oracle(sship, B):
-    """ss_hip_homotopy_solve_batch_*: B < 4 runs signal by signal on the sweep path, B >= 4 in
-    lock-step on the MFMA GEMM (signals of different sparsity finish in different rounds)."""
+    """ss_hip_homotopy_solve_batch_*: B < batch_min runs signal by signal, B >= batch_min in
+    lock-step on the MFMA GEMM (signals of different sparsity finish in different rounds).  The
+    default batch_min (192) is where lock-step starts to pay; 4 here to exercise it on small batches."""
     A, Y, sups = _batch_problem(500 + B, 256, 640, B, 3, 9, np.float32)   # m >> k log(n/k): well-posed recovery
     with sship.Homotopy(A) as h:
+        h.set_option("batch_min", 4)
         X, iters, errs = h.solve_batch(Y, 1e-3, 40)
         if B >= 4:
             assert h.stats()["batch_rounds"] > 0
@@ -281,6 +283,7 @@ def test_batch_device_io_and_strides(sship):
     import torch
     A, Y, sups = _batch_problem(77, 256, 1024, 6, 4, 8, np.float32)
     with sship.Homotopy(A) as h:
+        h.set_option("batch_min", 4)
         Xh, ih, eh = h.solve_batch(Y, 1e-3, 40)
         Yd = torch.from_numpy(Y).to("cuda:0")
         Xd = torch.zeros((6, 1024), device="cuda:0", dtype=torch.float32)
@@ -713,3 +716,31 @@ def test_engines_agree_f64(sship, shape):
             assert np.allclose(trg["gamma"][:-1], tro["gamma"][:-1], rtol=1e-8, atol=1e-12), name
         st = h.stats()
         assert st["lookahead_sweeps"] >= 3       # the lookahead forms really ran in double precision
+
+
+@pytest.mark.gpu
+def test_small_batches_run_signal_by_signal(sship):
+    """below batch_min (default 192) a batch is a loop of single-signal solves (lookahead engine):
+    same answers as solve(), no lock-step rounds"""
+    A, Y, sups = _batch_problem(91, 256, 2048, 6, 4, 9, np.float32)
+    with sship.Homotopy(A) as h:
+        X, iters, errs = h.solve_batch(Y, 1e-3, 40)
+        assert h.stats()["batch_rounds"] == 0
+        for b in range(6):
+            x1, it1, e1 = h.solve(Y[b], 1e-3, 40)
+            assert it1 == iters[b] and np.array_equal(x1, X[b])
+            assert np.array_equal(significant_support(X[b], 1e-3), sups[b])
+
+
+@pytest.mark.gpu
+def test_cache_budget_exhausted_falls_back(sship):
+    """a Gram-column cache too small for the path (option cache_mib) is not an error: the solve is
+    re-run in residual form"""
+    m, n, k = 2048, 65536, 72
+    A, y, x0, sup = make_gaussian_problem(612, m, n, k, np.float32)
+    xo, ito, eo = oracle.homotopy(A, y, 1e-3, 4 * k)
+    with sship.Homotopy(A) as h:
+        h.set_option("cache_mib", 16)         # 64 rows of 256 KiB: fewer than the support needs
+        xg, itg, eg = h.solve(y, 1e-3, 4 * k)
+        assert h.stats()["gram_fallbacks"] == 1
+    assert_parity(xg, itg, eg, xo, ito, eo, np.float32)
