@@ -476,7 +476,8 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
             const uint32_t i = i0 + (uint32_t)u * kUpdThreads;
             if (i >= n) break;
             T v = raw[u];
-            if (init_mode) v = v < T(0) ? v : -v;                   // -|c0|: large correlations first
+            if (init_mode) v = v < T(0) ? v : -v;                   // -|c|: large correlations first
+            if (init_mode == 2 && (insup[i] || slot_of[i] >= 0)) v = Lim<T>::max();   // OMP: active / cached columns are out
             if (i == idx) v = -Lim<T>::max();                       // the entering column always wins
             if (better_min(v, i, v1, i1)) { v2 = v1; i2 = i1; v1 = v; i1 = i; }
             else if (better_min(v, i, v2, i2)) { v2 = v; i2 = i; }
@@ -822,7 +823,8 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
     const uint32_t ldm = L.ldm, kcap = L.kcap;
     {   // slot = blockIdx.y
         const size_t s = blockIdx.y;
-        if (omp) { y += s * ldm; x += s * L.n_pad; }
+        if (omp && gcache == nullptr) y += s * ldm;
+        if (omp) x += s * L.n_pad;
         gam2 += s * 2 * kcap;
         inv0 += s * 2 * (size_t)kcap * kcap; inv1 += s * 2 * (size_t)kcap * kcap;
         u1 += s * kcap; u2 += s * kcap; sgn += s * kcap;
@@ -853,6 +855,7 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
                 const T v = gi[gam_new[b]];
                 if (b == rank) st->dot = (double)v;
                 else u1[b - (b > rank ? 1u : 0u)] = v;
+                if (omp) sgn[b] = y[gam_new[b]];          // b_S = A_S^T y = c0[S] (y carries c0 here)
             }
         }
         __syncthreads();
@@ -1143,6 +1146,174 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
     }
 }
 
+// ---- k_la_omp: one iteration of orthogonal matching pursuit in Gram form ------------------------------
+// c = A^T(y - A_S x_S) = c0 - sum_j x_j g_j from the cached Gram columns (every workgroup, its columns),
+// grid barrier for ||c||_inf and its first index, then workgroup 0 alone: loop control and pick (as
+// k_omp_select), and — if the Gram column of the pick is cached — the bordered inverse and the
+// least-squares coefficients x_S = (A_S^T A_S)^-1 A_S^T y with A_S^T y = c0[S].  A pick without cached
+// Gram column raises need_sweep: the host runs k_la_top (ranking by |c|: the next picks are the
+// largest correlations) + the 32-column sweep + k_gramupd and launches again.
+template <typename T>
+__global__ __launch_bounds__(kItThreads)
+void k_la_omp(T tol, uint32_t max_iter, uint32_t n, T gram_guard,
+              const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, const T* __restrict__ c0,
+              uint32_t gpitch, T* c, T* x, uint8_t* insup, T* pmax_val, uint32_t* pmax_idx,
+              uint32_t* gam2, uint32_t* touched2, T* inv0, T* inv1, T* u1, T* u2, T* sgn, T* q_unused, T* d_unused,
+              SlotDims L, DevState* st, uint32_t* hflags, TraceEntry* trace, uint32_t trace_cap)
+{
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_flag;
+    __shared__ uint32_t s_cnt;
+    __shared__ T s_dd;
+    __shared__ uint32_t s_slot[kCqTile];
+    __shared__ T s_x[kCqTile];
+    const uint32_t kcap = L.kcap;
+    const uint32_t tid = threadIdx.x;
+
+    if (st->done || st->need_sweep) {
+        if (blockIdx.x == 0 && tid == 0) bump_seq(st, hflags);
+        return;
+    }
+    const uint32_t round = st->iter + 1u;
+    const uint32_t cur0 = st->cur;
+    const uint32_t K = st->K;
+    const uint32_t* gam = gam2 + (size_t)cur0 * kcap;
+
+    // ---- c in Gram form over this workgroup's columns ---------------------------------------------------
+    T bv = T(-1);
+    uint32_t bi = 0xffffffffu;
+    for (uint32_t base = blockIdx.x * kItChunk; base < n; base += gridDim.x * kItChunk) {
+        const T* gbase = gcache + base + tid;
+        T ax[kItCols];
+#pragma unroll
+        for (int k = 0; k < kItCols; ++k) ax[k] = T(0);
+        for (uint32_t j0 = 0; j0 < K; j0 += kCqTile) {
+            const uint32_t cnt = (K - j0 < kCqTile) ? (K - j0) : kCqTile;
+            __syncthreads();
+            if (tid < cnt) {
+                const uint32_t cl = gam[j0 + tid];
+                s_slot[tid] = (uint32_t)slot_of[cl];
+                s_x[tid] = x[cl];
+            }
+            __syncthreads();
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const T* g = gbase + (size_t)s_slot[j] * gpitch;
+                const T xj = s_x[j];
+#pragma unroll
+                for (int k = 0; k < kItCols; ++k) ax[k] += xj * g[k * kItThreads];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kItCols; ++k) {
+            const uint32_t i = base + k * kItThreads + tid;
+            if (i < n) {
+                const T cv = c0[i] - ax[k];
+                c[i] = cv;
+                const T a = cv < T(0) ? -cv : cv;
+                if (better_max(a, i, bv, bi)) { bv = a; bi = i; }
+            }
+        }
+    }
+    block_reduce_pair<T, true>(bv, bi, sv, si);
+    if (tid == 0) { pmax_val[blockIdx.x] = bv; pmax_idx[blockIdx.x] = bi; }
+    const uint32_t bar_round = st->bar_rounds + 1u;
+    if (!grid_barrier(&st->bar_count, bar_round * gridDim.x, &s_flag)) {
+        if (blockIdx.x == 0 && tid == 0) {
+            st->status = SS_HIP_ERUNTIME;
+            st->done = 1;
+            signal_done(hflags, nullptr, 1u, round);
+        }
+        return;
+    }
+    if (blockIdx.x != 0) return;                       // the serial part belongs to workgroup 0
+    if (tid == 0) st->bar_rounds = bar_round;
+
+    T c_inf;
+    uint32_t idx;
+    reduce_sweep_partials(pmax_val, pmax_idx, gridDim.x, c_inf, idx, sv, si);
+    if (round == 1u && gram_guard > T(0) && tol < gram_guard * c_inf) {
+        // tolerance too tight for Gram-form correlations: the host re-runs in residual form
+        if (tid == 0) {
+            st->status = kStatusRetryResidual;
+            st->done = 1;
+            signal_done(hflags, nullptr, 1u, 0u);
+            bump_seq(st, hflags);
+        }
+        return;
+    }
+    // stop: tolerance reached, iteration budget spent, the support is full, or the best column is
+    // already active (numerical stall) — k_omp_select's rules
+    const bool stall = insup[idx] != 0;
+    if (!(c_inf > tol) || round > max_iter || K >= kcap || stall) {
+        if (tid == 0) {
+            st->c_inf = (double)c_inf;
+            st->iter = round - 1;
+            st->done_round = round;
+            if (K >= kcap && c_inf > tol && round <= max_iter && !stall) st->status = SS_HIP_ECAPACITY;
+            st->done = 1;
+            signal_done(hflags, nullptr, 1u, round);
+            bump_seq(st, hflags);
+        }
+        return;
+    }
+    uint32_t* gam_new = gam2 + (size_t)(cur0 ^ 1u) * kcap;
+    uint32_t* tch_new = touched2 + (size_t)(cur0 ^ 1u) * kcap;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t lr = 0;
+    for (uint32_t j = tid; j < K; j += blockDim.x) lr += (gam[j] < idx) ? 1u : 0u;
+    if (lr) atomicAdd(&s_cnt, lr);
+    __syncthreads();
+    const uint32_t rank = s_cnt;
+    const uint32_t K_new = K + 1;
+    for (uint32_t j = tid; j < K_new; j += blockDim.x) {
+        const uint32_t v = (j < rank) ? gam[j] : (j == rank ? idx : gam[j - 1]);
+        gam_new[j] = v;
+        tch_new[j] = v;
+    }
+    const int32_t slot = slot_of[idx];
+    if (tid == 0) {
+        insup[idx] = 1;
+        st->K = K_new;
+        st->ntouched = K_new;
+        st->idx = idx;
+        st->rank = rank;
+        st->added = 1;
+        st->gamma = 0.0;
+        st->c_inf = (double)c_inf;
+        st->iter = round;
+        if (trace != nullptr && round < trace_cap) {
+            trace[round].idx = idx;
+            trace[round].added = 1;
+            trace[round].gamma = 0.0;
+            trace[round].c_inf = (double)c_inf;
+        }
+        if (slot < 0) {
+            st->need_sweep = 1;
+            const uint32_t nm = st->nmiss + 1u;
+            st->nmiss = nm;
+            __hip_atomic_store(&hflags[2], nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            bump_seq(st, hflags);
+        }
+    }
+    if (slot < 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const T* gi = gcache + (size_t)slot * gpitch;
+    for (uint32_t b = tid; b < K_new; b += blockDim.x) {
+        const T v = gi[gam_new[b]];
+        if (b == rank) st->dot = (double)v;
+        else u1[b - (b > rank ? 1u : 0u)] = v;
+        sgn[b] = c0[gam_new[b]];                       // b_S = A_S^T y
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    update_direction<T>(cur0, K_new, rank, true, gam, gam_new, inv0, inv1, u1, u2, sgn, c, q_unused, d_unused, tol, st, 1,
+                        x, 0, 0, kcap, sv, &s_dd, T(0));
+    if (tid == 0) bump_seq(st, hflags);
+}
+
 // ---- y = A x (reconstruct_signal, lib.cpp:78-104) -------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kSmallThreads)
@@ -1296,7 +1467,8 @@ hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t
 template <typename T>
 hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode)
 {
-    hipLaunchKernelGGL((k_la_top<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, ws.tcand, ws.c0,
+    // init_mode 1: rank by |c0| (first batch of a Homotopy solve); 2: by the current |c| (OMP)
+    hipLaunchKernelGGL((k_la_top<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, ws.tcand, init_mode == 2 ? ws.c : ws.c0,
                        (uint32_t)ctx->n, init_mode, ws.insup, ws.slot_of, ws.gcap, ws.sw_list, ws.st, ctx->dev_flags);
     return hipGetLastError();
 }
@@ -1337,6 +1509,33 @@ hipError_t launch_la_iter(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32
                        ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx, ws.pmin_val, ws.pmin_idx,
                        ws.gam, ws.touched, ws.inv[0], ws.inv[1], ws.u1, ws.u2, ws.sgn, ws.tcand, ws.dims, ws.st,
                        ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.la_dbg);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_la_omp(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    uint32_t nb = (n + kItChunk - 1) / kItChunk;
+    const uint32_t cap = std::min<uint32_t>(std::min<uint32_t>(kItMaxBlocks, (uint32_t)ctx->num_cus), ws.dims.pmax_stride);
+    if (nb > cap) nb = cap;
+    if (nb == 0) nb = 1;
+    const T guard = ctx->engine == 1 ? (T)(sizeof(T) == 4 ? kGramGuard : kGramGuard64) : T(0);
+    hipLaunchKernelGGL((k_la_omp<T>), dim3(nb), dim3(kItThreads), 0, ctx->stream, tol, max_iter, n, guard,
+                       (const T*)ws.gcache, (const int32_t*)ws.slot_of, (const T*)ws.c0, ws.gpitch,
+                       ws.c, ws.x, ws.insup, ws.pmax_val, ws.pmax_idx, ws.gam, ws.touched, ws.inv[0], ws.inv[1],
+                       ws.u1, ws.u2, ws.sgn, ws.q, ws.d, ws.dims, ws.st, ctx->dev_flags, ws.trace, ws.trace_cap);
+    return hipGetLastError();
+}
+
+// the inverse update k_la_omp left pending (its pick was not cached): k_gramupd, cached + OMP mode
+template <typename T>
+hipError_t launch_la_omp_update(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol)
+{
+    hipLaunchKernelGGL((k_gramupd<T>), dim3(1, 1), dim3(kUpdThreads), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ws.dims, ws.gam, ws.inv[0], ws.inv[1],
+                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 1, (const T*)ws.c0, ws.x,
+                       (const T*)ws.gcache, (const int32_t*)ws.slot_of, ws.gpitch, 0, 0);
     return hipGetLastError();
 }
 
@@ -1399,6 +1598,10 @@ template hipError_t launch_la_update<double>(const ss_hip_ctx*, Workspace<double
 template hipError_t launch_la_cq<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t*);
 template hipError_t launch_la_cq<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t*);
 template hipError_t launch_la_iter<float>(const ss_hip_ctx*, Workspace<float>&, float, uint32_t);
+template hipError_t launch_la_omp<float>(const ss_hip_ctx*, Workspace<float>&, float, uint32_t);
+template hipError_t launch_la_omp<double>(const ss_hip_ctx*, Workspace<double>&, double, uint32_t);
+template hipError_t launch_la_omp_update<float>(const ss_hip_ctx*, Workspace<float>&, float);
+template hipError_t launch_la_omp_update<double>(const ss_hip_ctx*, Workspace<double>&, double);
 template hipError_t launch_la_iter<double>(const ss_hip_ctx*, Workspace<double>&, double, uint32_t);
 template hipError_t launch_la_scansel<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, float, uint32_t);
 template hipError_t launch_la_scansel<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t, double, uint32_t);

@@ -391,6 +391,15 @@ template <typename T> struct Lookahead {
         if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
         HIPCHK(launch_la_update<T>(ctx, ws, 1, tol));
     }
+    // OMP: the next picks are the largest correlations; the pending update is k_gramupd in OMP mode
+    static void fetch_omp(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+    {
+        HIPCHK(launch_la_top<T>(ctx, ws, 2));
+        if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
+        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
+        HIPCHK(launch_la_omp_update<T>(ctx, ws, tol));
+    }
 
     // one homotopy iteration: scan + select, (sweep if the entering column is not cached),
     // inverse update + direction from the cache, Gram-form c and q
@@ -502,7 +511,16 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const size_t rhs_stride = (size_t)ws.dims.b_pad * ctx->ldm;   // r-block -> p-block
 
         const bool la = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual;
-        if (la) {
+        // orthogonal matching pursuit in Gram form (k_la_omp): same cache, same sweeps
+        const bool la_omp = omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && ctx->la_fused >= 1;
+        if (la_omp) {
+            Lookahead<T>::ensure(ctx, ws, kcap);
+            uint32_t nb1 = 0;
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+            HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // nothing cached yet
+        } else if (la) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             uint32_t nb1 = 0;
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
@@ -526,7 +544,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
         volatile uint32_t* hf = ctx->host_flags;
         const uint64_t last_round = (uint64_t)max_iter + 1;
-        if (la && ctx->la_fused) {
+        if ((la && ctx->la_fused) || la_omp) {
             // Fused lookahead engine: every launch of k_la_iter performs the next iteration, or
             // nothing while the device waits for a Gram column (hf[2] counts those waits).  The
             // host keeps L launches queued ahead and answers each wait with one fetch.
@@ -535,7 +553,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             // resident kernel: LDS tier (support columns it can hold); 0 = one launch per iteration
             uint32_t lds_cols = 0;
             const uint32_t kcap_ws = ws.dims.kcap;       // what the device checks K against (>= this solve's kcap)
-            if (ctx->la_fused >= 2 && ctx->zero_on_removal && sizeof(T) == 4) {
+            if (la && ctx->la_fused >= 2 && ctx->zero_on_removal && sizeof(T) == 4) {
                 lds_cols = std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsSmall);
                 if (!la_persist_usable(ctx, lds_cols)) lds_cols = 0;
             }
@@ -556,7 +574,8 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     const bool timed_la = prof && (timed_fetches++ % (uint32_t)std::max(1, ctx->profile_every) == 0);
                     hipEvent_t e0 = nullptr, e1 = nullptr;
                     if (timed_la) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
-                    Lookahead<T>::fetch(ctx, ws, tol, e0, e1);
+                    if (la_omp) Lookahead<T>::fetch_omp(ctx, ws, tol, e0, e1);
+                    else Lookahead<T>::fetch(ctx, ws, tol, e0, e1);
                     if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
                     ++handled;
                 }
@@ -566,7 +585,8 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     lds_cols = (hf[3] <= big && big > lds_cols && la_persist_usable(ctx, big)) ? big : 0u;
                 }
                 if (enq >= max_launch) { stuck = true; break; }
-                Lookahead<T>::iterate(ctx, ws, tol, max_iter, lds_cols);
+                if (la_omp) HIPCHK(launch_la_omp<T>(ctx, ws, tol, max_iter));
+                else Lookahead<T>::iterate(ctx, ws, tol, max_iter, lds_cols);
                 ++enq;
             }
             if (stuck) {
@@ -633,7 +653,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             set_err(err, errlen, "solve: internal error, device loop did not terminate");
             return SS_HIP_ERUNTIME;
         }
-        if (la && hs.status == kStatusRetryResidual) {
+        if ((la || la_omp) && hs.status == kStatusRetryResidual) {
             // tolerance too tight for Gram-form correlations (see k_la_init_pick): residual form
             ctx->stats.gram_fallbacks += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, true);
@@ -646,7 +666,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             ctx->stats.persist_fallbacks += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual);
         }
-        if (la && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 1) {
+        if ((la || la_omp) && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 1) {
             // k_la_iter's grid barrier expired as well (the GPU is shared with another resident grid):
             // from here on this context uses the form without in-kernel grid synchronisation
             ctx->la_fused = 0;
@@ -678,7 +698,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
 
         ctx->stats.solves += 1;
         ctx->stats.iterations += hs.iter;
-        if (la) ctx->stats.lookahead_sweeps += hs.nsweeps;
+        if (la || la_omp) ctx->stats.lookahead_sweeps += hs.nsweeps;
         if (prof) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));

@@ -246,6 +246,11 @@ hipError_t launch_la_iter(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32
 template <typename T>
 hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol,
                              uint32_t max_iter);
+// orthogonal matching pursuit in Gram form: one launch per iteration, and the pending update after a fetch
+template <typename T>
+hipError_t launch_la_omp(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter);
+template <typename T>
+hipError_t launch_la_omp_update(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol);
 // resident form (persist.hip): one launch runs iterations until the solve ends, a Gram column is
 // missing or the support outgrows `lds_cols`; returns hipErrorInvalidConfiguration if the device
 // cannot keep the whole grid resident for this n

@@ -744,3 +744,27 @@ def test_cache_budget_exhausted_falls_back(sship):
         xg, itg, eg = h.solve(y, 1e-3, 4 * k)
         assert h.stats()["gram_fallbacks"] == 1
     assert_parity(xg, itg, eg, xo, ito, eo, np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_omp_engines_agree(sship, dtype):
+    """orthogonal matching pursuit: residual form (one sweep per iteration) vs Gram form (k_la_omp)"""
+    m, n, k = 384, 3000, 40
+    A, y, x0, sup = make_gaussian_problem(7100, m, n, k, dtype)
+    tol = 1e-3 if dtype == np.float32 else 1e-9
+    res = {}
+    with sship.Homotopy(A) as h:
+        h.set_option("trace", 1)
+        for eng in (0, 1):
+            h.set_option("engine", eng)
+            h.reset_stats()
+            x, it, e = h.solve_omp(y, tol, 2 * k)
+            res[eng] = (x.copy(), it, e, h.trace(), h.stats()["lookahead_sweeps"])
+    (x0_, it0, e0, t0, s0), (x1_, it1, e1, t1, s1) = res[0], res[1]
+    assert s0 == 0 and s1 >= 2                      # the Gram form really ran, with more than one fetch
+    assert it0 == it1 == k
+    assert np.array_equal(t0["idx"], t1["idx"])     # same picks in the same order
+    assert np.array_equal(np.nonzero(x1_)[0], sup)
+    rtol = 1e-5 if dtype == np.float32 else 1e-10
+    assert np.abs(x1_ - x0_).max() <= rtol * np.abs(x0_).max()
