@@ -179,6 +179,7 @@ typedef struct ss_hip_stats {
     uint64_t sweep32_bytes;        /* algorithmic bytes of ONE lookahead sweep: m*n*s + 32*m*s + 32*n*s */
     uint64_t gram_fallbacks;       /* solves re-run in residual form: tolerance too tight for Gram-form correlations */
     uint64_t persist_fallbacks;    /* solves re-run without the resident kernel (its grid was not resident)         */
+    uint64_t gram_full_builds;     /* times the full Gram matrix A^T A was formed for the batched Gram form        */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------
@@ -226,6 +227,10 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 192: below
  *                    that, one lookahead solve per signal is faster)
  *   "batch_chunk"    signals processed together by the batched path (default 4096)
+ *   "batch_gram_min" smallest lock-step batch that forms G = A^T A (n^2 fp32, 2 m n^2 flops once) and then
+ *                    takes every signal's correlations from rows of G instead of two GEMMs per round
+ *                    (default 512; once G exists every lock-step batch uses it; 0 = never)
+ *   "gram_full_gib"  largest G the batched Gram form may allocate (default 64 GiB)
  *   "profile_every"  with profiling on, bracket only every k-th fused sweep with events
  *   "tie_guard"      1 (default) = an off-support column that attains max|c| exactly (it
  *                    tied with an inserted column within an ulp) enters by a zero-length step

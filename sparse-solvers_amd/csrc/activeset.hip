@@ -548,6 +548,13 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
              uint32_t n, uint32_t gpitch, SlotDims L, T* __restrict__ c, T* __restrict__ q,
              T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx, const DevState* st)
 {
+    {   // slot = blockIdx.y (batched Gram form: one signal per slot, gcache = the full A^T A, slot_of = null)
+        const size_t s = blockIdx.y;
+        c0 += s * L.n_pad; x += s * L.n_pad; d += s * L.n_pad; c += s * L.n_pad; q += s * L.n_pad;
+        touched2 += s * 2 * L.kcap;
+        pmax_val += s * L.pmax_stride; pmax_idx += s * L.pmax_stride;
+        st += s;
+    }
     if (st->done) return;
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
@@ -564,7 +571,7 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
         __syncthreads();
         if (threadIdx.x < cnt) {
             const uint32_t col = touched[j0 + threadIdx.x];
-            s_slot[threadIdx.x] = (uint32_t)slot_of[col];
+            s_slot[threadIdx.x] = slot_of != nullptr ? (uint32_t)slot_of[col] : col;
             s_x[threadIdx.x] = x[col];
             s_d[threadIdx.x] = d[col];
         }
@@ -850,7 +857,7 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
         // Gram column of the entering column
         if (st->status != 0) return;
         if (added) {
-            const T* gi = gcache + (size_t)slot_of[st->idx] * gpitch;
+            const T* gi = gcache + (size_t)(slot_of != nullptr ? (uint32_t)slot_of[st->idx] : st->idx) * gpitch;
             for (uint32_t b = threadIdx.x; b < K_new; b += blockDim.x) {
                 const T v = gi[gam_new[b]];
                 if (b == rank) st->dot = (double)v;
@@ -1539,6 +1546,62 @@ hipError_t launch_la_omp_update(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol)
     return hipGetLastError();
 }
 
+// batched Gram form: is the tolerance too tight for Gram-form correlations in any slot? (k_la_init_pick's
+// rule, against the ||A^T y||_inf k_init left in DevState::c_inf) -> hflags[4] = 1
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_gram_guard_batched(const DevState* __restrict__ st, uint32_t nslots, T tol, T guard, uint32_t* hflags)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nslots && tol < guard * (T)st[s].c_inf)
+        __hip_atomic_store(&hflags[4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <typename T>
+hipError_t launch_gram_guard_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, T tol)
+{
+    const T guard = (T)(sizeof(T) == 4 ? kGramGuard : kGramGuard64);
+    hipLaunchKernelGGL((k_gram_guard_batched<T>), dim3((nslots + kSmallThreads - 1) / kSmallThreads), dim3(kSmallThreads), 0,
+                       ctx->stream, (const DevState*)ws.st, nslots, tol, guard, ctx->dev_flags);
+    return hipGetLastError();
+}
+
+// ---- batched Gram form: every signal slot against the full Gram matrix G = A^T A ------------------------
+template <typename T>
+hipError_t launch_cq_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, const T* G, uint32_t gpitch,
+                                  const T* c0b, uint32_t* nparts_out)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    const uint32_t nb = (n + kCqChunk - 1) / kCqChunk;
+    if (nb > ws.dims.pmax_stride) return hipErrorInvalidValue;
+    if (nparts_out) *nparts_out = nb;
+    hipLaunchKernelGGL((k_la_cq<T>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, (const int32_t*)nullptr,
+                       c0b, (const T*)ws.x, (const T*)ws.d, (const uint32_t*)ws.touched, n, gpitch, ws.dims, ws.c, ws.q,
+                       ws.pmax_val, ws.pmax_idx, (const DevState*)ws.st);
+    return hipGetLastError();
+}
+
+// scan + select, then the inverse update with u1 gathered from row idx of G, for all slots
+template <typename T>
+hipError_t launch_tail_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts,
+                                    T tol, uint32_t max_iter, const T* G, uint32_t gpitch)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    const uint32_t per_block = kSmallThreads * kScanPerThread;
+    uint32_t ns = (n + per_block - 1) / per_block;
+    if (ns > ws.dims.pmin_stride) ns = ws.dims.pmin_stride;
+    hipLaunchKernelGGL((k_scansel<T>), dim3(ns, nslots), dim3(kSmallThreads), 0, ctx->stream, round, tol,
+                       max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
+                       nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
+                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,
+                       (T*)nullptr, (const int32_t*)nullptr);
+    hipLaunchKernelGGL((k_gramupd<T>), dim3(1, nslots), dim3(kUpdThreads), 0, ctx->stream,
+                       static_cast<const T*>(ctx->At), ws.dims, ws.gam, ws.inv[0], ws.inv[1],
+                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 0, (const T*)nullptr, (T*)nullptr,
+                       G, (const int32_t*)nullptr, gpitch, 0, ctx->strict_sign);
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol,
                              uint32_t max_iter)
@@ -1596,6 +1659,9 @@ template hipError_t launch_la_top<double>(const ss_hip_ctx*, Workspace<double>&,
 template hipError_t launch_la_update<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
 template hipError_t launch_la_update<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double);
 template hipError_t launch_la_cq<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t*);
+template hipError_t launch_gram_guard_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
+template hipError_t launch_cq_gram_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, const float*, uint32_t, const float*, uint32_t*);
+template hipError_t launch_tail_gram_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, uint32_t, float, uint32_t, const float*, uint32_t);
 template hipError_t launch_la_cq<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t*);
 template hipError_t launch_la_iter<float>(const ss_hip_ctx*, Workspace<float>&, float, uint32_t);
 template hipError_t launch_la_omp<float>(const ss_hip_ctx*, Workspace<float>&, float, uint32_t);

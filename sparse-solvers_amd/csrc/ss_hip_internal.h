@@ -159,6 +159,14 @@ struct SweepConfig {
 }  // namespace sship
 
 struct ss_hip_ctx {
+    // batched Gram form: the full G = A^T A ([n_pad][gram_pitch] fp32, made by the first large batch) and
+    // the per-signal c0 = A^T y rows of the current chunk
+    float* gram_full = nullptr;
+    uint32_t gram_pitch = 0;
+    float* c0_batch = nullptr;
+    size_t c0_batch_rows = 0;
+    long gram_full_gib = 64;     // option: largest G the batched Gram form may allocate
+    int batch_gram_min = 512;    // option: smallest batch that pays for making G (0 = never)
     int kind = 0;            // 0 = Homotopy / OMP context, 1 = IRLS context
     void* irls = nullptr;    // sship::IrlsState<T>* of an IRLS context
     int device = 0;
@@ -246,6 +254,15 @@ hipError_t launch_la_iter(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32
 template <typename T>
 hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol,
                              uint32_t max_iter);
+// batched Gram form (activeset.hip): c, q of every slot from rows of the full G = A^T A; scan + inverse update
+template <typename T>
+hipError_t launch_gram_guard_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, T tol);
+template <typename T>
+hipError_t launch_cq_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, const T* G, uint32_t gpitch,
+                                  const T* c0b, uint32_t* nparts_out);
+template <typename T>
+hipError_t launch_tail_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts,
+                                    T tol, uint32_t max_iter, const T* G, uint32_t gpitch);
 // orthogonal matching pursuit in Gram form: one launch per iteration, and the pending update after a fetch
 template <typename T>
 hipError_t launch_la_omp(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter);

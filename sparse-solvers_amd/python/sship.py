@@ -52,6 +52,7 @@ class Stats(ctypes.Structure):
         ("sweep32_bytes", ctypes.c_uint64),
         ("gram_fallbacks", ctypes.c_uint64),
         ("persist_fallbacks", ctypes.c_uint64),
+        ("gram_full_builds", ctypes.c_uint64),
     ]
 
 

@@ -768,3 +768,26 @@ def test_omp_engines_agree(sship, dtype):
     assert np.array_equal(np.nonzero(x1_)[0], sup)
     rtol = 1e-5 if dtype == np.float32 else 1e-10
     assert np.abs(x1_ - x0_).max() <= rtol * np.abs(x0_).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [9, 130])
+def test_batch_gram_form_vs_oracle(sship, B):
+    """lock-step batch in Gram form: correlations from rows of the full G = A^T A instead of two GEMMs
+    per round (options batch_min / batch_gram_min lowered to exercise it on a small batch)"""
+    A, Y, sups = _batch_problem(640 + B, 256, 640, B, 3, 9, np.float32)
+    with sship.Homotopy(A) as h:
+        h.set_option("batch_min", 4)
+        h.set_option("batch_gram_min", 4)
+        X, iters, errs = h.solve_batch(Y, 1e-3, 40)
+        st = h.stats()
+        assert st["batch_rounds"] > 0 and st["gram_full_builds"] == 1
+        X2, iters2, errs2 = h.solve_batch(Y[: B // 2 + 1], 1e-3, 40)       # G is kept: no second build
+        assert h.stats()["gram_full_builds"] == 1
+        assert np.array_equal(X2, X[: B // 2 + 1]) and np.array_equal(iters2, iters[: B // 2 + 1])
+        h.set_option("batch_gram_min", 0)                                  # the GEMM form of the same batch
+        h.set_option("gram_full_gib", 0)
+    for b in range(B):
+        xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 40)
+        assert_parity(X[b], int(iters[b]), float(errs[b]), xo, ito, eo, np.float32)
+        assert np.array_equal(significant_support(X[b], 1e-3), sups[b])
