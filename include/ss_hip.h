@@ -230,7 +230,10 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "batch_gram_min" smallest lock-step batch that forms G = A^T A (n^2 fp32, 2 m n^2 flops once) and then
  *                    takes every signal's correlations from rows of G instead of two GEMMs per round
  *                    (default 512; once G exists every lock-step batch uses it; 0 = never)
- *   "gram_full_gib"  largest G the batched Gram form may allocate (default 64 GiB)
+ *   "gram_full_gib"  largest G the Gram forms may allocate (default 64 GiB; 0 = never form G)
+ *   "gram_full_after" single-signal solves (fp32) after which the context forms G for them as well: with G
+ *                    in HBM every Gram column is at hand and a solve needs no pass over A beyond A^T y
+ *                    (default 512 solves; 1 = from the first solve; 0 = only if a batch formed G)
  *   "profile_every"  with profiling on, bracket only every k-th fused sweep with events
  *   "tie_guard"      1 (default) = an off-support column that attains max|c| exactly (it
  *                    tied with an inserted column within an ulp) enters by a zero-length step

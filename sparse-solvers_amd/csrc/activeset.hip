@@ -408,7 +408,7 @@ template <typename T>
 __global__ __launch_bounds__(kSmallThreads)
 void k_la_init_pick(const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
                     uint8_t* __restrict__ insup, uint32_t* __restrict__ gam, uint32_t* __restrict__ touched,
-                    DevState* st, TraceEntry* trace, T tol, T gram_guard, uint32_t* hflags)
+                    DevState* st, TraceEntry* trace, T tol, T gram_guard, uint32_t* hflags, uint32_t full_rows)
 {
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
@@ -437,7 +437,8 @@ void k_la_init_pick(const T* __restrict__ pmax_val, const uint32_t* __restrict__
         st->done_round = 0;
         st->c_inf = (double)c_inf;
         st->gamma = 0.0;
-        st->need_sweep = 1; st->cache_used = 0; st->nsweeps = 0;
+        // (full_rows != 0: the full Gram matrix is the cache — every column is there already)
+        st->need_sweep = full_rows ? 0u : 1u; st->cache_used = full_rows; st->nsweeps = 0;
         if (trace != nullptr) { trace[0].idx = idx; trace[0].added = 1; trace[0].gamma = 0.0; trace[0].c_inf = (double)c_inf; }
     }
 }
@@ -1462,12 +1463,13 @@ hipError_t launch_omp_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsl
 
 // ---- lookahead engine launchers -------------------------------------------------------------
 template <typename T>
-hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol)
+hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, bool full_gram)
 {
     // option "engine" = 1: guard on (tolerance vs ||A^T y||_inf), 2: lookahead engine unconditionally
     const T guard = ctx->engine == 1 ? (T)(sizeof(T) == 4 ? kGramGuard : kGramGuard64) : T(0);
     hipLaunchKernelGGL((k_la_init_pick<T>), dim3(1), dim3(kSmallThreads), 0, ctx->stream, ws.pmax_val,
-                       ws.pmax_idx, nparts, ws.insup, ws.gam, ws.touched, ws.st, ws.trace, tol, guard, ctx->dev_flags);
+                       ws.pmax_idx, nparts, ws.insup, ws.gam, ws.touched, ws.st, ws.trace, tol, guard, ctx->dev_flags,
+                       full_gram ? ctx->n_pad : 0u);
     return hipGetLastError();
 }
 
@@ -1652,8 +1654,8 @@ template hipError_t launch_omp_tail<float>(const ss_hip_ctx*, Workspace<float>&,
                                            uint32_t, float, uint32_t);
 template hipError_t launch_omp_tail<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t,
                                             uint32_t, double, uint32_t);
-template hipError_t launch_la_init_pick<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
-template hipError_t launch_la_init_pick<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double);
+template hipError_t launch_la_init_pick<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float, bool);
+template hipError_t launch_la_init_pick<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double, bool);
 template hipError_t launch_la_top<float>(const ss_hip_ctx*, Workspace<float>&, int);
 template hipError_t launch_la_top<double>(const ss_hip_ctx*, Workspace<double>&, int);
 template hipError_t launch_la_update<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);

@@ -90,8 +90,10 @@ struct PsLds {
     float* u2;       // [P]
     float* sg;       // [P] sign vector
     float* cn;       // [P] correlations after the step, support order
+    uint32_t* lrw;   // [P] row of the LDS Gram slice that holds each support column (kNoLdsRow: none)
 };
-__host__ __device__ inline size_t ps_lds_words(uint32_t P) { return (size_t)P * (P + 1) + 8 * (size_t)P; }
+constexpr uint32_t kNoLdsRow = 0xffffffffu;
+__host__ __device__ inline size_t ps_lds_words(uint32_t P) { return (size_t)P * (P + 1) + 9 * (size_t)P; }
 
 // four independent wave sums (same order of additions as wave_sum)
 __device__ __forceinline__ void wave_sum4(float (&v)[4])
@@ -181,7 +183,7 @@ __device__ __forceinline__ bool exchange_all(uint64_t* slots, uint32_t nb, uint3
 }
 
 __global__ __launch_bounds__(kPsThreads)
-void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t gl_rows,
+void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t gl_rows, int full_g,
                   const float* __restrict__ gcache, const int32_t* __restrict__ slot_of,
                   const float* __restrict__ c0, uint32_t gpitch,
                   float* c, float* q, float* c_alt, float* q_alt, float* x, float* d, uint8_t* insup,
@@ -211,7 +213,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     S.sg = S.u2 + P;
     S.cn = S.sg + P;
     // the workgroup's slice of the first gl_rows cache rows: [gl_rows][kPsWidth]
-    float* const Glds = S.cn + P;
+    S.lrw = reinterpret_cast<uint32_t*>(S.cn + P);
+    float* const Glds = reinterpret_cast<float*>(S.lrw + P);
 
     // ---- nothing to do in this launch? (same answer in every workgroup: DevState was written
     // ---- by earlier launches only) --------------------------------------------------------------
@@ -268,11 +271,25 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         S.ds[tid] = 0.f;
     }
     __syncthreads();
-    // the Gram-column cache as a buffer: row offsets go in the scalar offset of the loads
+    // the Gram-column cache as a buffer: row offsets go in the scalar offset of the loads (cache mode;
+    // with the full Gram matrix as "cache" rows lie up to n * pitch * 4 B apart: 64-bit addressing there)
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gcache), 0, -1, 0x00020000);
-    // This workgroup's slice of the cached Gram rows, kept in LDS for the whole launch: the per-CU
-    // limit on outstanding L1 misses makes K row reads from L2 cost ~40 ns each, every iteration.
-    const uint32_t gl_used = st->cache_used < gl_rows ? st->cache_used : gl_rows;
+    auto grow_global = [&](uint32_t row, uint32_t cofs4) -> float {
+        if (full_g) return gcache[(size_t)row * gpitch + (cofs4 >> 2)];
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, cofs4, row * (gpitch * 4u), 0));
+    };
+    // This workgroup's slice of Gram rows, kept in LDS for the whole launch: the per-CU limit on
+    // outstanding L1 misses makes K row reads from L2 cost ~40 ns each, every iteration.
+    //   cache mode : LDS row r = cache slot r, for the first gl_rows slots handed out;
+    //   full-G mode: LDS rows are handed out as columns enter (the support at entry takes rows 0..K0-1),
+    //                each workgroup fetching its 1 KiB of row idx of G at that moment.
+    const uint32_t gl_used = full_g ? (K0 < gl_rows ? K0 : gl_rows) : (st->cache_used < gl_rows ? st->cache_used : gl_rows);
+    uint32_t lds_rows_used = gl_used;                  // full-G mode: next free LDS row (same in every workgroup)
+    if (tid < P) {
+        uint32_t lr = kNoLdsRow;
+        if (tid < K0) lr = full_g ? (tid < gl_rows ? tid : kNoLdsRow) : (S.slt[tid] < gl_used ? S.slt[tid] : kNoLdsRow);
+        S.lrw[tid] = lr;
+    }
     {
         const uint32_t tcol = tid & (kPsWidth - 1u), half = tid / kPsWidth;          // two rows per pass
         const uint32_t cg = w * kPsWidth + tcol;
@@ -283,7 +300,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             for (int t = 0; t < 8; ++t) {
                 const uint32_t r = r0 + 2u * t + half;
                 gv[t] = 0.f;
-                if (r < gl_used) gv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, cofs4, r * (gpitch * 4u), 0));
+                if (r < gl_used) gv[t] = grow_global(full_g ? S.slt[r] : r, cofs4);
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -322,31 +339,31 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             if (__ballot(in[k]) == 0ull) continue;            // whole waves only (lanes exchange entries)
             const uint32_t cofs4 = (in[k] ? col[k] : 0u) * 4u;
             const uint32_t K16 = (Kc + 15u) & ~15u;
-            const uint32_t lds_lim = k == 0 ? gl_used : 0u;
             const uint32_t tcol = tid & (kPsWidth - 1u);
             float acc = 0.f;
             for (uint32_t j0 = 0; j0 < K16; j0 += 64) {
                 const uint32_t jl = j0 + (uint32_t)lane;
-                const uint32_t vs = S.slt[jl < Kc ? jl : 0u];
+                const uint32_t vs = S.slt[jl < Kc ? jl : 0u];                          // global row
+                const uint32_t vl = k == 0 ? S.lrw[jl < Kc ? jl : 0u] : kNoLdsRow;     // LDS row (first column set)
                 const uint32_t cnt = K16 - j0 < 64u ? K16 - j0 : 64u;
                 const float* cf = coef + j0;
-                const uint64_t out_of_lds = __ballot(vs >= lds_lim);      // lanes whose row must come from L2
+                const uint64_t out_of_lds = __ballot(vl == kNoLdsRow);    // lanes whose row must come from L2
                 for (uint32_t u = 0; u < cnt; u += 16) {
                     float gv[16];
                     if (((out_of_lds >> u) & 0xffffull) == 0ull) {
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) gv[t] = Glds[__builtin_amdgcn_readlane(vs, u + t) * kPsWidth + tcol];
+                        for (int t = 0; t < 16; ++t) gv[t] = Glds[__builtin_amdgcn_readlane(vl, u + t) * kPsWidth + tcol];
                     } else {
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
-                            const uint32_t sl = __builtin_amdgcn_readlane(vs, u + t);
+                            const uint32_t lr = __builtin_amdgcn_readlane(vl, u + t);
                             gv[t] = 0.f;
-                            if (sl >= lds_lim) gv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, cofs4, sl * (gpitch * 4u), 0));
+                            if (lr == kNoLdsRow) gv[t] = grow_global(__builtin_amdgcn_readlane(vs, u + t), cofs4);
                         }
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
-                            const uint32_t sl = __builtin_amdgcn_readlane(vs, u + t);
-                            if (sl < lds_lim) gv[t] = Glds[sl * kPsWidth + tcol];
+                            const uint32_t lr = __builtin_amdgcn_readlane(vl, u + t);
+                            if (lr != kNoLdsRow) gv[t] = Glds[lr * kPsWidth + tcol];
                         }
                     }
 #pragma unroll
@@ -665,13 +682,27 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             if (tid == 0) s_dd = 1.f / (s_dd - ssum);
             __syncthreads();
             dv = s_dd;
+            // full-G mode: the entering column gets the next LDS row; this workgroup fetches its slice of row
+            // idx of G (used first by the q pass below, after several barriers)
+            uint32_t new_lrow = kNoLdsRow;
+            if (full_g) {
+                if (lds_rows_used < gl_rows) {
+                    new_lrow = lds_rows_used++;
+                    if (tid < kPsWidth) {
+                        const uint32_t cg = w * kPsWidth + tid;
+                        Glds[new_lrow * kPsWidth + tid] = gcache[(size_t)idx * gpitch + (cg < n ? cg : 0u)];
+                    }
+                }
+            } else if ((uint32_t)slot < gl_used) {
+                new_lrow = (uint32_t)slot;
+            }
             // lists: insert at `rank`
-            uint32_t ng = 0, ns = 0;
+            uint32_t ng = 0, ns = 0, nl = kNoLdsRow;
             float nx = 0.f, ncn = 0.f;
             if (tid < K_new) {
                 const uint32_t o = tid - (tid > rank ? 1u : 0u);
-                if (tid == rank) { ng = idx; ns = (uint32_t)slot; nx = 0.f; }
-                else { ng = S.gam[o]; ns = S.slt[o]; nx = S.xs[o]; }
+                if (tid == rank) { ng = idx; ns = (uint32_t)slot; nx = 0.f; nl = new_lrow; }
+                else { ng = S.gam[o]; ns = S.slt[o]; nx = S.xs[o]; nl = S.lrw[o]; }
             }
             // cnv sits in thread j (old position) / thread K (idx): move through LDS
             if (tid <= K) S.cn[tid] = cnv;
@@ -681,7 +712,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 ncn = (tid == rank) ? S.cn[K] : S.cn[o];
             }
             __syncthreads();
-            if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; }
+            if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; S.lrw[tid] = nl; }
         } else {
             // remove row/column `rank` (online_inverse.h:275-290)
             const uint32_t nn = K;
@@ -693,14 +724,14 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             if (lead && tid == 0) { x[idx] = 0.f; d[idx] = 0.f; }
             if (tid < K) S.cn[tid] = cnv;
             __syncthreads();
-            uint32_t ng = 0, ns = 0;
+            uint32_t ng = 0, ns = 0, nl = kNoLdsRow;
             float nx = 0.f, ncn = 0.f;
             if (tid < K_new) {
                 const uint32_t o = tid + (tid >= rank ? 1u : 0u);
-                ng = S.gam[o]; ns = S.slt[o]; nx = S.xs[o]; ncn = S.cn[o];
+                ng = S.gam[o]; ns = S.slt[o]; nx = S.xs[o]; ncn = S.cn[o]; nl = S.lrw[o];
             }
             __syncthreads();
-            if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; }
+            if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; S.lrw[tid] = nl; }
             else if (tid == K_new) { S.xs[tid] = 0.f; S.ds[tid] = 0.f; }     // the vacated entry is padding again
         }
         __syncthreads();
@@ -858,7 +889,7 @@ hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float to
     const size_t lds = persist_lds_bytes(P);
     uint64_t* smax = reinterpret_cast<uint64_t*>(ws.la_sync + 1);
     uint64_t* smin = smax + 2 * kLaSlotStride;
-    hipLaunchKernelGGL(k_la_persist, dim3(nw), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, persist_gl_rows(P),
+    hipLaunchKernelGGL(k_la_persist, dim3(nw), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, persist_gl_rows(P), ws.gram_is_full ? 1 : 0,
                        (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
                        ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg);

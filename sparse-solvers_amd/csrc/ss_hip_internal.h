@@ -145,6 +145,15 @@ struct Workspace {
     uint32_t* sw_list = nullptr;  // [64] rcols[32] then drows[32] of the next lookahead sweep
     LaSync* la_sync = nullptr;    // hand-off area of k_la_persist, followed by the offer slots
     T* cq_alt = nullptr;          // [2][n_pad] second (c, q) pair: k_la_persist alternates by tick parity
+    // full-G mode of the single-signal engine (fp32): the context's G = A^T A serves as the cache — every
+    // column is "cached" in row = its own index, so no lookahead sweep is ever needed.  While a solve runs
+    // in this mode gcache / gpitch / slot_of point at G / its pitch / slot_identity; the *_own fields keep
+    // the workspace's own cache.
+    bool gram_is_full = false;
+    T* gcache_own = nullptr;
+    uint32_t gpitch_own = 0;
+    int32_t* slot_of_own = nullptr;
+    int32_t* slot_identity = nullptr;   // [n_pad] 0, 1, 2, ...
     uint64_t* la_dbg = nullptr;   // [1024][8] stage timestamps of k_la_iter (option "la_debug"), else null
     uint32_t la_nparts = 0;       // partial maxima written by the last k_la_cq launch
     uint32_t* tile_skip = nullptr; // [b_pad/128 + 1] compact list of GEMM row tiles with a running signal + count
@@ -167,6 +176,7 @@ struct ss_hip_ctx {
     size_t c0_batch_rows = 0;
     long gram_full_gib = 64;     // option: largest G the batched Gram form may allocate
     int batch_gram_min = 512;    // option: smallest batch that pays for making G (0 = never)
+    long gram_full_after = 512;  // option: single-signal solves on this context after which G is made for them too (0 = never)
     int kind = 0;            // 0 = Homotopy / OMP context, 1 = IRLS context
     void* irls = nullptr;    // sship::IrlsState<T>* of an IRLS context
     int device = 0;
@@ -241,7 +251,7 @@ hipError_t launch_omp_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsl
                            uint32_t nparts, T tol, uint32_t max_iter);
 // lookahead engine launchers (activeset.hip); see homotopy.hip for the round structure
 template <typename T>
-hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol);
+hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, bool full_gram = false);
 template <typename T>
 hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode);
 template <typename T>

@@ -791,3 +791,29 @@ def test_batch_gram_form_vs_oracle(sship, B):
         xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 40)
         assert_parity(X[b], int(iters[b]), float(errs[b]), xo, ito, eo, np.float32)
         assert np.array_equal(significant_support(X[b], 1e-3), sups[b])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("la_fused", [2, 1])
+def test_full_gram_single_signal(sship, la_fused):
+    """option gram_full_after = 1: G = A^T A is formed at the first solve and serves as the Gram-column
+    cache — no lookahead sweep; Homotopy (resident kernel / one launch per iteration) and OMP vs the oracle"""
+    m, n, k = 512, 4096, 30
+    A, y, x0, sup = make_gaussian_problem(8100, m, n, k, np.float32)
+    xo, ito, eo, tro = oracle.homotopy(A, y, 1e-3, 4 * k, trace=True)
+    with sship.Homotopy(A) as h:
+        h.set_option("gram_full_after", 1)
+        h.set_option("la_fused", la_fused)
+        h.set_option("trace", 1)
+        for rep in range(2):
+            xg, itg, eg = h.solve(y, 1e-3, 4 * k)
+            trg = h.trace()
+            assert_parity(xg, itg, eg, xo, ito, eo, np.float32)
+            assert np.array_equal(trg["idx"][:-1], tro["idx"][:-1])
+        st = h.stats()
+        assert st["gram_full_builds"] == 1 and st["lookahead_sweeps"] == 0
+        xq, itq, eq = h.solve_omp(y, 1e-3, 2 * k)
+        xoo, itoo, eoo, _ = oracle.omp(A, y, 1e-3, 2 * k)
+        assert itq == itoo and np.array_equal(np.nonzero(xq)[0], np.nonzero(xoo)[0])
+        assert np.abs(xq - xoo).max() <= 1e-5 * np.abs(xoo).max()
+        assert h.stats()["lookahead_sweeps"] == 0
