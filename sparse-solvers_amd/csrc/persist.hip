@@ -294,17 +294,18 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         const uint32_t tcol = tid & (kPsWidth - 1u), half = tid / kPsWidth;          // two rows per pass
         const uint32_t cg = w * kPsWidth + tcol;
         const uint32_t cofs4 = (cg < n ? cg : 0u) * 4u;
-        for (uint32_t r0 = 0; r0 < gl_used; r0 += 16) {
+        constexpr uint32_t rpp = kPsThreads / kPsWidth;      // rows per pass
+        for (uint32_t r0 = 0; r0 < gl_used; r0 += 8 * rpp) {
             float gv[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const uint32_t r = r0 + 2u * t + half;
+                const uint32_t r = r0 + rpp * t + half;
                 gv[t] = 0.f;
                 if (r < gl_used) gv[t] = grow_global(full_g ? S.slt[r] : r, cofs4);
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const uint32_t r = r0 + 2u * t + half;
+                const uint32_t r = r0 + rpp * t + half;
                 if (r < gl_used) Glds[r * kPsWidth + tcol] = gv[t];
             }
         }
@@ -404,7 +405,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     };
     auto c_pass_and_post = [&]() { c_pass(); post_lambda(); };
     // read everybody's word of the lambda exchange of the current tick (false: a wait expired)
-    auto poll_lambda = [&](float& lam) -> bool {
+    // `early`: what this thread read from slot `tid` before the q pass (usually the word is there by then)
+    auto poll_lambda = [&](float& lam, uint64_t early = kLaSlotEmpty) -> bool {
         const uint32_t par = (tick & 1u) * kLaSlotStride;
         float mv = -1.f;
         uint32_t mi = 0xffffffffu;
@@ -412,8 +414,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         for (uint32_t s0 = 0; s0 < nb; s0 += kPsThreads) {
             const uint32_t sidx = s0 + tid;
             if (sidx < nb) {
-                uint64_t pk = kLaSlotEmpty;
-                for (uint32_t spin = 0; spin < kPsSpinLimit; ++spin) {
+                uint64_t pk = s0 == 0 ? early : kLaSlotEmpty;
+                for (uint32_t spin = 0; pk == kLaSlotEmpty && spin < kPsSpinLimit; ++spin) {
                     pk = ld_u64(&smax[par + sidx]);
                     if (pk != kLaSlotEmpty) break;
                     __builtin_amdgcn_s_sleep(1);
@@ -453,6 +455,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         // while a slower one still reads this tick's)
         float* const cbuf = (tick & 1u) ? c_alt : c;
         float* const qbuf = (tick & 1u) ? q_alt : q;
+        // (the lambda words were posted before the inverse update: read this thread's slot now, use it below)
+        const uint64_t early = tid < nb ? ld_u64(&smax[par + tid]) : kLaSlotEmpty;
         gram_pass(S.ds, K, qv);
 #pragma unroll
         for (int k = 0; k < kPsCols; ++k)
@@ -461,7 +465,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
 
         // ---- lambda (posted before the inverse update) ---------------------------------------------------
         float c_inf;
-        if (!poll_lambda(c_inf)) { exit_code = 4; break; }
+        if (!poll_lambda(c_inf, early)) { exit_code = 4; break; }
         ts[2] = wall_clock64();
 
         // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
@@ -586,6 +590,14 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         else if (tid == K && added) { cj = ld_f32(&cbuf[idx]); qj = ld_f32(&qbuf[idx]); }
         int32_t slot = 0;
         if (added) slot = slot_of[idx];
+        // u1 = A_S^T a_idx, dot = a_idx.a_idx from the Gram column of idx (online_inverse.h:209-218): issued
+        // here (the slot permitting), consumed in the inverse update after the c pass
+        float u1v = 0.f;
+        if (added && slot >= 0) {
+            const float* gi = gcache + (size_t)slot * gpitch;
+            if (tid < K) u1v = gi[S.gam[tid]];
+            else if (tid == K) u1v = gi[idx];
+        }
 
         // x += gamma * direction over the OLD support (:252); the leaving column lands on exactly 0
         if (tid < K) {
@@ -647,11 +659,6 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         const float cnv = cj - g * qj;
         float dv;
         if (added) {
-            // u1 = A_S^T a_idx, dot = a_idx.a_idx from the cached Gram column (online_inverse.h:209-218)
-            const float* gi = gcache + (size_t)slot * gpitch;
-            float u1v = 0.f;
-            if (tid < K) u1v = gi[S.gam[tid]];
-            else if (tid == K) u1v = gi[idx];
             if (tid < K) S.u1[tid] = u1v;
             else if (tid == K) s_dd = u1v;                       // dot, replaced by d below
             __syncthreads();
