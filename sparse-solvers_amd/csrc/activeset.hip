@@ -182,8 +182,8 @@ __device__ __forceinline__ bool select_toggle(uint32_t round, T c_inf, uint32_t 
         T g = Lim<T>::max();
     uint32_t idx = 0xffffffffu;
     for (uint32_t b = threadIdx.x; b < ns; b += blockDim.x) {
-        const T ov = pmin_val[b];
-        const uint32_t oi = pmin_idx[b];
+        const T ov = __hip_atomic_load(&pmin_val[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t oi = __hip_atomic_load(&pmin_idx[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (better_min(ov, oi, g, idx)) { g = ov; idx = oi; }
     }
     block_reduce_pair<T, false>(g, idx, sv, si);
@@ -383,10 +383,12 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
     }
     block_reduce_pair<T, false>(best, best_i, sv, si);
     if (threadIdx.x == 0) {
-        pmin_val[blockIdx.x] = best;
-        pmin_idx[blockIdx.x] = best_i;
+        // the partials are the only data that crosses workgroups in this launch (x, d, insup and the
+        // lists are inputs): moved with L2-bypassing stores / loads, so the ticket needs no cache fences
+        __hip_atomic_store(&pmin_val[blockIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pmin_idx[blockIdx.x], best_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!arrive_last(&st->ticket_scan, gridDim.x, &s_flag)) return;
+    if (!arrive_last_relaxed(&st->ticket_scan, gridDim.x, &s_flag)) return;
 
     select_toggle<T>(round, c_inf, gridDim.x, pmin_val, pmin_idx, x, d, insup, gam2, touched2, kcap, st, hflags,
                      true, trace, trace_cap, zero_on_removal, ndone, nslots, slot_of, sv, si, s_cnt);

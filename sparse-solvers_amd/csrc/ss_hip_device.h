@@ -201,6 +201,24 @@ __device__ __forceinline__ bool arrive_last(uint32_t* counter, uint32_t total, u
     return *s_flag != 0u;
 }
 
+// The same ticket without cache fences, for hand-offs whose payload is itself moved with agent-scope
+// atomic (L2-bypassing) stores and loads: every wave drains its stores, the leader takes a ticket.
+// (A release fence writes back the whole L2 and an acquire invalidates it: with thousands of
+// workgroups per launch — the batched kernels — that alone costs milliseconds.)
+__device__ __forceinline__ bool arrive_last_relaxed(uint32_t* counter, uint32_t total, uint32_t* s_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t last = (t == total - 1u) ? 1u : 0u;
+        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = last;
+    }
+    __syncthreads();
+    return *s_flag != 0u;
+}
+
 // a scalar another workgroup stored in this launch: read it on the vector path, L1 bypassed
 __device__ __forceinline__ double load_handoff(const double* p)
 {
