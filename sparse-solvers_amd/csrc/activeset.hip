@@ -709,7 +709,7 @@ __device__ __forceinline__ void update_direction(uint32_t cur, uint32_t K_new, u
                                                  T* inv0, T* inv1, T* u1, T* u2, T* sgn,
                                                  const T* __restrict__ c, const T* __restrict__ q, T* __restrict__ d,
                                                  T tol, DevState* st, int omp, T* __restrict__ x, int first, int strict_sign,
-                                                 uint32_t kcap, T* sv, T* s_dp, T g)
+                                                 uint32_t kcap, T* sv, T* s_dp, T g, bool cq_agent = false)
 {
     T& s_d = *s_dp;
     // ---- last workgroup --------------------------------------------------------------
@@ -798,9 +798,12 @@ __device__ __forceinline__ void update_direction(uint32_t cur, uint32_t K_new, u
     // their sign is used here, the next sweep recomputes c itself from r.
     for (uint32_t a = threadIdx.x; a < K_new; a += blockDim.x) {
         const uint32_t col = gam_new[a];
-        T cn = c[col] - g * q[col];
+        // (cq_agent: c, q were stored by other workgroups of this launch with agent-scope atomic stores)
+        const T cc = cq_agent ? __hip_atomic_load(&c[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : c[col];
+        const T qq = cq_agent ? __hip_atomic_load(&q[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : q[col];
+        T cn = cc - g * qq;
         // first-step quirk (homotopy-cpu.cpp:223-227): the seed is sign(|c[idx]|) = +1
-        if (first) cn = strict_sign ? c[col] : (c[col] < T(0) ? -c[col] : c[col]);
+        if (first) cn = strict_sign ? cc : (cc < T(0) ? -cc : cc);
         sgn[a] = sign_tol(cn, tol);
     }
     // clear the old direction
@@ -949,6 +952,25 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target,
     return *s_flag != 0u;
 }
 
+// The same barrier without cache fences, for launches whose cross-workgroup data moves with agent-scope
+// atomic stores and loads (a release fence writes the whole L2 back, an acquire invalidates it).
+__device__ __forceinline__ bool grid_barrier_relaxed(uint32_t* counter, uint32_t target, uint32_t* s_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t ok = 0;
+        for (uint32_t spin = 0; spin < (1u << 21); ++spin) {
+            if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *s_flag = ok;
+    }
+    __syncthreads();
+    return *s_flag != 0u;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kItThreads)
 void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
@@ -1029,19 +1051,24 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
             const uint32_t i = base + k * kItThreads + tid;
             if (i < n) {
                 const T cv = c0[i] - ax[k];
-                c[i] = cv;
-                q[i] = ad[k];
+                // (everything that crosses workgroups in this launch moves with L2-bypassing stores and
+                // loads: no cache fences at the barrier or at the ticket)
+                __hip_atomic_store(&c[i], cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&q[i], ad[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const T a = cv < T(0) ? -cv : cv;
                 if (better_max(a, i, bv, bi)) { bv = a; bi = i; }
             }
         }
     }
     block_reduce_pair<T, true>(bv, bi, sv, si);
-    if (tid == 0) { pmax_val[blockIdx.x] = bv; pmax_idx[blockIdx.x] = bi; }
+    if (tid == 0) {
+        __hip_atomic_store(&pmax_val[blockIdx.x], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pmax_idx[blockIdx.x], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     ts[1] = wall_clock64();
 
     const uint32_t bar_round = st->bar_rounds + 1u;
-    if (!grid_barrier(&st->bar_count, bar_round * gridDim.x, &s_flag)) {
+    if (!grid_barrier_relaxed(&st->bar_count, bar_round * gridDim.x, &s_flag)) {
         if (blockIdx.x == 0 && tid == 0) {               // cannot happen with a resident grid
             st->status = SS_HIP_ERUNTIME;
             st->done = 1;
@@ -1054,7 +1081,7 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
     // lambda = ||c||_inf (homotopy-cpu.cpp:270 / :219); same exact value in every workgroup
     T c_inf;
     uint32_t imax;
-    reduce_sweep_partials(pmax_val, pmax_idx, gridDim.x, c_inf, imax, sv, si);
+    reduce_partials_agent(pmax_val, pmax_idx, gridDim.x, c_inf, imax, sv, si);
 
     // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
     if ((round > 1 && !(c_inf > tol)) || round > max_iter) {
@@ -1085,7 +1112,8 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
                 const T t = -x[i] / d[i];
                 if (t > T(0) && t < m) m = t;
             } else {
-                const T qi = q[i], ci = c[i];
+                const T qi = __hip_atomic_load(&q[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const T ci = __hip_atomic_load(&c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const T dl = T(1) - qi, dr = T(1) + qi;
                 if (dl != T(0)) {
                     T t = (c_inf - ci) / dl;
@@ -1103,9 +1131,12 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
         }
     }
     block_reduce_pair<T, false>(best, best_i, sv, si);
-    if (tid == 0) { pmin_val[blockIdx.x] = best; pmin_idx[blockIdx.x] = best_i; }
+    if (tid == 0) {
+        __hip_atomic_store(&pmin_val[blockIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pmin_idx[blockIdx.x], best_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     ts[3] = wall_clock64();
-    if (!arrive_last(&st->ticket_scan, gridDim.x, &s_flag)) return;
+    if (!arrive_last_relaxed(&st->ticket_scan, gridDim.x, &s_flag)) return;
     ts[4] = wall_clock64();
 
     // ---- last workgroup -----------------------------------------------------------------------
@@ -1147,7 +1178,7 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     update_direction<T>(cur0, K_new, rank, added != 0, gam_old, gam_new, inv0, inv1, u1, u2, sgn, c, q, d, tol, st, 0,
-                        x, 0, 0, kcap, sv, &s_dd, g);
+                        x, 0, 0, kcap, sv, &s_dd, g, true);
     if (tid == 0) bump_seq(st, hflags);
     if (dbg != nullptr && tid == 0 && round < 1024u) {     // stage timestamps of the last workgroup (100 MHz)
         ts[6] = wall_clock64();
@@ -1226,9 +1257,13 @@ void k_la_omp(T tol, uint32_t max_iter, uint32_t n, T gram_guard,
         }
     }
     block_reduce_pair<T, true>(bv, bi, sv, si);
-    if (tid == 0) { pmax_val[blockIdx.x] = bv; pmax_idx[blockIdx.x] = bi; }
+    // (the partial maxima are all that crosses workgroups here: L2-bypassing stores, no fences)
+    if (tid == 0) {
+        __hip_atomic_store(&pmax_val[blockIdx.x], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pmax_idx[blockIdx.x], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const uint32_t bar_round = st->bar_rounds + 1u;
-    if (!grid_barrier(&st->bar_count, bar_round * gridDim.x, &s_flag)) {
+    if (!grid_barrier_relaxed(&st->bar_count, bar_round * gridDim.x, &s_flag)) {
         if (blockIdx.x == 0 && tid == 0) {
             st->status = SS_HIP_ERUNTIME;
             st->done = 1;
@@ -1241,7 +1276,7 @@ void k_la_omp(T tol, uint32_t max_iter, uint32_t n, T gram_guard,
 
     T c_inf;
     uint32_t idx;
-    reduce_sweep_partials(pmax_val, pmax_idx, gridDim.x, c_inf, idx, sv, si);
+    reduce_partials_agent(pmax_val, pmax_idx, gridDim.x, c_inf, idx, sv, si);
     if (round == 1u && gram_guard > T(0) && tol < gram_guard * c_inf) {
         // tolerance too tight for Gram-form correlations: the host re-runs in residual form
         if (tid == 0) {

@@ -158,6 +158,24 @@ __device__ __forceinline__ void reduce_sweep_partials(const T* pv, const uint32_
     idx = ix;
 }
 
+// the same over partials that other workgroups of THIS launch stored with agent-scope atomic stores
+template <typename T>
+__device__ __forceinline__ void reduce_partials_agent(const T* pv, const uint32_t* pi, uint32_t nb,
+                                                      T& val, uint32_t& idx, T* sv, uint32_t* si)
+{
+    T v = T(-1);
+    uint32_t ix = 0xffffffffu;
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+        const T ov = __hip_atomic_load(&pv[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t oi = __hip_atomic_load(&pi[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (better_max(ov, oi, v, ix)) { v = ov; ix = oi; }
+    }
+    block_reduce_pair<T, true>(v, ix, sv, si);
+    if (ix == 0xffffffffu) ix = 0;
+    val = v;
+    idx = ix;
+}
+
 template <typename T>
 __device__ __forceinline__ T sign_tol(T v, T tol)   // homotopy-cpu.cpp:59-67
 {
