@@ -116,7 +116,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SS_BENCH_DIST=1 under torch.distributed.run with one rank walks the RCCL path (init, barrier,
+    # all_reduce, all_gather) on a single GPU: a rehearsal of what the N > 1 launch executes
+    use_dist = world > 1 or (os.environ.get("SS_BENCH_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -139,13 +142,13 @@ def main():
     for s in range(args.warmup):
         h.solve(sigs[s][0], TOL, MAX_ITER, out=xw)
     # warm up the record packing / gather too (first use of a torch kernel loads its code object)
-    sharding.gather_records(sharding.pack_records(xw.unsqueeze(0).expand(args.steps, N).contiguous(), KMAX_RECORD), world)
+    sharding.gather_records(sharding.pack_records(xw.unsqueeze(0).expand(args.steps, N).contiguous(), KMAX_RECORD), world, collective=use_dist)
 
     h.set_profiling(True)
     h.set_option("profile_every", args.profile_every)
     h.reset_stats()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -155,15 +158,15 @@ def main():
         errs[s] = e
     # fixed-size support records {idx[KMAX], val[KMAX]} per signal; one gather over xGMI
     rec = sharding.pack_records(X, KMAX_RECORD)
-    allrec = sharding.gather_records(rec, world)
+    allrec = sharding.gather_records(rec, world, collective=use_dist)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     h.set_profiling(False)
 
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -178,7 +181,7 @@ def main():
             recovered += 1
             coef_err = max(coef_err, float(np.abs(Xh[s][sup] - coef).max() / coef.max()))
     rc = torch.tensor([recovered], device=dev, dtype=torch.int64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(rc)
     recovered_total = int(rc.item())
     # the gathered records of this rank's own block decode back to its solutions
@@ -324,7 +327,7 @@ def main():
         out["cpu_baseline"] = base
         out["parity_vs_oracle"] = parity
     h.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

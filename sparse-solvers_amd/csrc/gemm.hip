@@ -153,7 +153,7 @@ constexpr int HM = 32;
 // columns).  To keep enough HBM requests in flight from a single workgroup the global loads
 // run THREE K-steps ahead through a ring of register sets (3 x 36 KiB per workgroup), LDS is
 // double buffered, one barrier per K-step.
-template <int HN, int HT, int BPC>
+template <int HN, int HT, int BPC, int KS = GK, bool DRY = false>
 __global__ __launch_bounds__(HT, BPC)
 void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
                      const uint32_t* __restrict__ drows, float* __restrict__ D,
@@ -161,22 +161,24 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
                      const DevState* __restrict__ st)
 {
     if (st != nullptr && (st->done != 0 || st->need_sweep == 0)) return;   // no sweep needed this round
-    __shared__ __attribute__((aligned(16))) float sR[2][HM][GLD];
-    __shared__ __attribute__((aligned(16))) float sQ[2][HN][GLD];
+    constexpr int LD = KS + GPAD;                               // LDS row pitch in floats
+    __shared__ __attribute__((aligned(16))) float sR[2][HM][LD];
+    __shared__ __attribute__((aligned(16))) float sQ[2][HN][LD];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t h = lane >> 5, l31 = lane & 31u;
-    constexpr int RPP = HT / 8;                                 // rows staged per pass
+    constexpr int TPR = KS / 4;                                 // threads per staged row (one k-quad each)
+    constexpr int RPP = HT / TPR;                               // rows staged per pass
     constexpr int NJ = HN / RPP;                                // passes per column tile
-    const uint32_t srow = tid >> 3, squad = tid & 7u;          // staging: rows srow + RPP*j, k-quad squad
-    const bool has_r = tid < 256;                               // R tile: 32 rows x 8 quads
+    const uint32_t srow = tid / TPR, squad = tid % TPR;        // staging: rows srow + RPP*j, k-quad squad
+    const bool has_r = tid < 32 * TPR;                          // R tile: 32 rows x TPR quads
 
     const uint32_t rc = rcols[srow & 31u];
     const bool rvalid = has_r && rc != 0xffffffffu;
     const float* gR = At + (size_t)(rvalid ? rc : 0u) * ldq + squad * 4;
     const v4f zero4 = { 0.f, 0.f, 0.f, 0.f };
-    const uint32_t nk = K / GK;
+    const uint32_t nk = K / KS;
 
     for (uint32_t bn = blockIdx.x; bn < ntiles; bn += gridDim.x) {
         const float* gQ = At + (size_t)(bn * HN + srow) * ldq + squad * 4;
@@ -187,7 +189,7 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
         v4f rR[3], rQ[3][NJ];
 #define G32_LOAD(SET, KT)                                                                      \
     {                                                                                          \
-        const uint32_t koff_ = (KT) * GK;                                                      \
+        const uint32_t koff_ = (KT) * KS;                                                      \
         rR[SET] = rvalid ? *reinterpret_cast<const v4f*>(gR + koff_) : zero4;                  \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                         \
             rQ[SET][j] = __builtin_nontemporal_load(                                           \
@@ -200,12 +202,14 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
             *reinterpret_cast<v4f*>(&sQ[BUF][srow + RPP * j][squad * 4]) = rQ[SET][j];         \
     }
 #define G32_COMPUTE(BUF)                                                                       \
-    _Pragma("unroll") for (int g = 0; g < GK / 8; ++g) {                                       \
+    _Pragma("unroll") for (int g = 0; g < KS / 8; ++g) {                                       \
         const uint32_t kq_ = (2u * g + h) * 4u;                                                \
         const v4f a_ = *reinterpret_cast<const v4f*>(&sR[BUF][l31][kq_]);                      \
         const v4f b_ = *reinterpret_cast<const v4f*>(&sQ[BUF][wave * 32 + l31][kq_]);          \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                          \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], b_[t], acc, 0, 0, 0);            \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                        \
+            if (DRY) acc[t] += a_[t] + b_[t];    /* measurement aid: data movement without MFMA */ \
+            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], b_[t], acc, 0, 0, 0);       \
+        }                                                                                      \
     }
 
         // prologue: tiles 0,1,2 in flight; tile 0 -> LDS[0]; tile 3 re-uses set 0
@@ -249,6 +253,101 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
 #undef G32_LOAD
 #undef G32_STORE
 #undef G32_COMPUTE
+
+        const uint32_t col = bn * HN + wave * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const uint32_t dr = drows[row];
+            if (dr != 0xffffffffu) D[(size_t)dr * ldd + col] = acc[e];
+        }
+    }
+}
+
+// ---- deep-ring form: the same tile and arithmetic, RING K-steps of global loads in flight -----------
+// A CU has to keep ~8 TB/s x latency / 256 CUs ≈ 64-96 KiB of HBM requests outstanding; three
+// 36-KiB sets that advance in barrier lock-step are at the edge of that.  Here the ring is RING sets
+// deep (RING even and nk % RING == 0, so LDS buffer and register set are compile-time per unrolled
+// step; ldm is a multiple of 256, hence nk of 8).  Same summation order as k_gemm32_tn_f32: bitwise
+// identical output.
+template <int HN, int HT, int RING>
+__global__ __launch_bounds__(HT, 1)
+void k_gemm32r_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
+                      const uint32_t* __restrict__ drows, float* __restrict__ D,
+                      uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
+                      const DevState* __restrict__ st)
+{
+    static_assert(RING % 2 == 0, "ring depth must be even");
+    if (st != nullptr && (st->done != 0 || st->need_sweep == 0)) return;   // no sweep needed this round
+    __shared__ __attribute__((aligned(16))) float sR[2][HM][GLD];
+    __shared__ __attribute__((aligned(16))) float sQ[2][HN][GLD];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t h = lane >> 5, l31 = lane & 31u;
+    constexpr int RPP = HT / 8;                                 // rows staged per pass
+    constexpr int NJ = HN / RPP;                                // passes per column tile
+    const uint32_t srow = tid >> 3, squad = tid & 7u;
+    const bool has_r = tid < 256;
+
+    const uint32_t rc = rcols[srow & 31u];
+    const bool rvalid = has_r && rc != 0xffffffffu;
+    const float* gR = At + (size_t)(rvalid ? rc : 0u) * ldq + squad * 4;
+    const v4f zero4 = { 0.f, 0.f, 0.f, 0.f };
+    const uint32_t nk = K / GK;
+
+    for (uint32_t bn = blockIdx.x; bn < ntiles; bn += gridDim.x) {
+        const float* gQ = At + (size_t)(bn * HN + srow) * ldq + squad * 4;
+        v16f acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+        v4f rR[RING], rQ[RING][NJ];
+#define R32_LOAD(SET, KT)                                                                      \
+    {                                                                                          \
+        const uint32_t koff_ = (KT) * GK;                                                      \
+        rR[SET] = rvalid ? *reinterpret_cast<const v4f*>(gR + koff_) : zero4;                  \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                         \
+            rQ[SET][j] = __builtin_nontemporal_load(                                           \
+                reinterpret_cast<const v4f*>(gQ + (size_t)(RPP * j) * ldq + koff_));           \
+    }
+#define R32_STORE(SET, BUF)                                                                    \
+    {                                                                                          \
+        if (has_r) *reinterpret_cast<v4f*>(&sR[BUF][srow][squad * 4]) = rR[SET];               \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                         \
+            *reinterpret_cast<v4f*>(&sQ[BUF][srow + RPP * j][squad * 4]) = rQ[SET][j];         \
+    }
+#pragma unroll
+        for (int s = 0; s < RING; ++s) R32_LOAD(s, (uint32_t)s)
+        __syncthreads();                                        // previous column tile fully consumed
+        R32_STORE(0, 0)
+        if ((uint32_t)RING < nk) R32_LOAD(0, (uint32_t)RING)
+        __syncthreads();
+
+        for (uint32_t kt = 0; kt < nk; kt += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                const uint32_t k = kt + (uint32_t)u;
+                const int buf = u & 1;
+#pragma unroll
+                for (int g = 0; g < GK / 8; ++g) {
+                    const uint32_t kq = (2u * g + h) * 4u;
+                    const v4f a = *reinterpret_cast<const v4f*>(&sR[buf][l31][kq]);
+                    const v4f b = *reinterpret_cast<const v4f*>(&sQ[buf][wave * 32 + l31][kq]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+                }
+                if (k + 1 < nk) {
+                    const int set = (u + 1) % RING;
+                    R32_STORE(set, buf ^ 1)
+                    if (k + 1 + RING < nk) R32_LOAD(set, k + 1 + RING)
+                }
+                __syncthreads();
+            }
+        }
+#undef R32_LOAD
+#undef R32_STORE
 
         const uint32_t col = bn * HN + wave * 32 + l31;
 #pragma unroll
@@ -498,7 +597,31 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
 {
     if (ctx->n_pad % 256 != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
     const float* At = static_cast<const float*>(ctx->At);
-    if (ctx->sweep32_variant == 3) {
+    if (ctx->sweep32_variant == 6 || ctx->sweep32_variant == 7) {
+        // deep register ring (4 or 8 K-steps of loads in flight); nk = ldm / 32 is a multiple of 8
+        const uint32_t ntiles = ctx->n_pad / 256;
+        const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
+        if (ctx->ldm % 256 != 0) return hipErrorInvalidValue;
+        if (ctx->sweep32_variant == 6)
+            hipLaunchKernelGGL((k_gemm32r_tn_f32<256, 512, 4>), dim3(grid), dim3(512), 0, ctx->stream,
+                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+        else
+            hipLaunchKernelGGL((k_gemm32r_tn_f32<256, 512, 8>), dim3(grid), dim3(512), 0, ctx->stream,
+                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+    } else if (ctx->sweep32_variant == 5) {
+        // measurement aid: the same data movement (global -> registers -> LDS -> registers) without MFMA
+        const uint32_t ntiles = ctx->n_pad / 256;
+        const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
+        hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1, GK, true>), dim3(grid), dim3(512), 0, ctx->stream,
+                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+    } else if (ctx->sweep32_variant == 4) {
+        // K-step 64: 256 contiguous bytes per row and step (fewer, larger DRAM bursts per stream)
+        const uint32_t ntiles = ctx->n_pad / 256;
+        const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
+        if (ctx->ldm % 64 != 0) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1, 64>), dim3(grid), dim3(512), 0, ctx->stream,
+                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+    } else if (ctx->sweep32_variant == 3) {
         // barrier-free: 32-column tiles, one per wave, 4 waves per workgroup, 2 workgroups per CU
         const uint32_t ntiles = ctx->n_pad / 32;
         const uint32_t cap = 2u * (uint32_t)ctx->num_cus;

@@ -1353,7 +1353,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
-    if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(7, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { ctx->cache_mib = std::max<long>(16, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }

@@ -47,7 +47,7 @@ def unpack_records(rec, kmax, n):
     return out
 
 
-def gather_records(rec, world, max_rows=None):
+def gather_records(rec, world, max_rows=None, collective=None):
     """all_gather of per-rank records.  Ranks may own different numbers of signals: rows are
     padded to `max_rows` (default: this rank's row count, for equal shards).
     Returns a (world, max_rows, width) tensor on every rank."""
@@ -58,7 +58,7 @@ def gather_records(rec, world, max_rows=None):
         pad = torch.full((rows - rec.shape[0], rec.shape[1]), -1, dtype=rec.dtype, device=rec.device)
         rec = torch.cat([rec, pad], dim=0)
     rec = rec.contiguous()
-    if world == 1:
+    if world == 1 and not collective:          # collective=True: run the all_gather even for one rank
         return rec.unsqueeze(0)
     # concatenated form (world*rows, width): accepted by both the nccl (RCCL) and gloo backends
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)

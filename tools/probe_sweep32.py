@@ -13,7 +13,7 @@ cols = np.arange(0, 32 * 1000, 1000, dtype=np.uint32)
 ref = None
 with sship.Homotopy(A) as h:
     bytes_ = m * n * 4 + 32 * m * 4 + 32 * n * 4
-    for v in (0, 3, 0, 3, 1, 3):
+    for v in (0, 6, 7, 0, 6, 7, 0, 6, 7):
         h.set_option("sweep32_variant", v)
         G, ms = h.gram_cols(cols, 20)
         if ref is None:
