@@ -180,6 +180,8 @@ typedef struct ss_hip_stats {
     uint64_t gram_fallbacks;       /* solves re-run in residual form: tolerance too tight for Gram-form correlations */
     uint64_t persist_fallbacks;    /* solves re-run without the resident kernel (its grid was not resident)         */
     uint64_t gram_full_builds;     /* times the full Gram matrix A^T A was formed for the batched Gram form        */
+    uint64_t solo_solves;          /* solves that ran in the speculative form (one workgroup + verification)        */
+    uint64_t solo_retries;         /* speculative launches whose verification failed (the solve went on in the resident form) */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------

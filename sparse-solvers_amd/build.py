@@ -34,6 +34,7 @@ HIP_UNITS = [
     # scalar bookkeeping mirrors the reference's separately-rounded products and sums
     ("activeset.hip", ["-ffp-contract=off"]),
     ("persist.hip", ["-ffp-contract=off"]),
+    ("solo.hip", ["-ffp-contract=off"]),
     ("irls.hip", ["-ffp-contract=off"]),
     ("gemm.hip", []),
     ("homotopy.hip", []),

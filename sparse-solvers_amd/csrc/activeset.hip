@@ -455,7 +455,7 @@ template <typename T>
 __global__ __launch_bounds__(kUpdThreads)
 void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, int init_mode,
               const uint8_t* __restrict__ insup, int32_t* __restrict__ slot_of, uint32_t gcap,
-              uint32_t* __restrict__ sw_list, DevState* st, uint32_t* hflags)
+              uint32_t* __restrict__ sw_list, DevState* st, uint32_t* hflags, uint32_t* __restrict__ slot_col)
 {
     if (st->done || !st->need_sweep) return;
     const uint32_t idx = st->idx;
@@ -522,6 +522,7 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
             sw_list[count] = bi;               // rcols: right-hand side = column bi of A
             sw_list[kTopS + count] = used;     // drows: output row = cache slot
             slot_of[bi] = (int32_t)used;
+            if (slot_col != nullptr) slot_col[used] = bi;      // (the speculative form lists the cached columns)
         }
         ++used;
         ++count;
@@ -1515,7 +1516,8 @@ hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode)
 {
     // init_mode 1: rank by |c0| (first batch of a Homotopy solve); 2: by the current |c| (OMP)
     hipLaunchKernelGGL((k_la_top<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, ws.tcand, init_mode == 2 ? ws.c : ws.c0,
-                       (uint32_t)ctx->n, init_mode, ws.insup, ws.slot_of, ws.gcap, ws.sw_list, ws.st, ctx->dev_flags);
+                       (uint32_t)ctx->n, init_mode, ws.insup, ws.slot_of, ws.gcap, ws.sw_list, ws.st, ctx->dev_flags,
+                       ws.gram_is_full ? (uint32_t*)nullptr : ws.slot_col);
     return hipGetLastError();
 }
 

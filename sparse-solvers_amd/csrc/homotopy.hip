@@ -161,7 +161,8 @@ void release_arrays(Workspace<T>* w)
     void* ptrs[] = { w->y, w->rhs, w->cq, w->x, w->d, w->insup, w->pmax_val, w->pmax_idx,
                      w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->u1,
                      w->u2, w->sgn, w->st, w->ndone, w->tile_skip, w->gcache, w->slot_of, w->c0,
-                     w->tcand, w->sw_list, w->la_dbg, w->la_sync, w->cq_alt, w->slot_identity };
+                     w->tcand, w->sw_list, w->la_dbg, w->la_sync, w->cq_alt, w->slot_identity,
+                     w->slot_col, w->solo_log, w->sub_pos, w->v_max, w->v_min, w->cand_top, w->solo_stage };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     TraceEntry* tr = w->trace;
@@ -323,6 +324,15 @@ inline hipError_t launch_persist(ss_hip_ctx* ctx, Workspace<float>& ws, float to
 { return launch_la_persist_f32(ctx, ws, tol, max_iter, lds_cols); }
 inline hipError_t launch_persist(ss_hip_ctx*, Workspace<double>&, double, uint32_t, uint32_t)
 { return hipErrorInvalidConfiguration; }
+// speculative form (fp32 only): solo launch + verification + publication; seeding of the subset ranking
+inline hipError_t launch_solo_group(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter)
+{
+    const hipError_t e = launch_la_solo_f32(ctx, ws, tol, max_iter);
+    return e != hipSuccess ? e : launch_la_verify_f32(ctx, ws);
+}
+inline hipError_t launch_solo_group(ss_hip_ctx*, Workspace<double>&, double, uint32_t) { return hipErrorInvalidConfiguration; }
+inline hipError_t launch_cand_init(ss_hip_ctx* ctx, Workspace<float>& ws) { return launch_la_cand_init_f32(ctx, ws); }
+inline hipError_t launch_cand_init(ss_hip_ctx*, Workspace<double>&) { return hipErrorInvalidConfiguration; }
 
 template <typename T> struct Lookahead {
     static constexpr bool supported = true;
@@ -337,15 +347,29 @@ template <typename T> struct Lookahead {
         const uint64_t fit = std::max<uint64_t>(64, budget / ((uint64_t)gpitch * sizeof(T)));
         if (want > fit) want = fit;
         if (ws.gcache && ws.gcap >= want && ws.gpitch == gpitch) return;
-        void* olds[] = { ws.gcache, ws.slot_of, ws.c0, ws.tcand, ws.sw_list };
+        void* olds[] = { ws.gcache, ws.slot_of, ws.c0, ws.tcand, ws.sw_list, ws.slot_col, ws.solo_log, ws.sub_pos, ws.v_max, ws.v_min, ws.cand_top, ws.solo_stage };
         for (void* p : olds) if (p) HIPCHK(hipFree(p));
         ws.gcache = nullptr; ws.slot_of = nullptr; ws.c0 = nullptr; ws.tcand = nullptr; ws.sw_list = nullptr;
+        ws.solo_stage = nullptr; ws.slot_col = nullptr; ws.solo_log = nullptr; ws.sub_pos = nullptr; ws.v_max = nullptr; ws.v_min = nullptr; ws.cand_top = nullptr;
         ws.gcap = 0;
         HIPCHK(hipMalloc(&ws.gcache, (size_t)want * gpitch * sizeof(T)));
         HIPCHK(hipMalloc(&ws.slot_of, (size_t)ctx->n_pad * sizeof(int32_t)));
         HIPCHK(hipMalloc(&ws.c0, (size_t)ctx->n_pad * sizeof(T)));
         HIPCHK(hipMalloc(&ws.tcand, (size_t)ctx->n_pad * sizeof(T)));
         HIPCHK(hipMalloc(&ws.sw_list, 64 * sizeof(uint32_t)));
+        if (sizeof(T) == 4) {
+            // speculative form: slot -> column map, breakpoint log, verification partials, subset ranking
+            ws.nvwg = (uint32_t)((ctx->n + kSoloWidth - 1) / kSoloWidth);
+            HIPCHK(hipMalloc(&ws.slot_col, (size_t)want * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(&ws.solo_log, ((size_t)kSoloHeaderWords + (size_t)kSoloLogCap * kSoloEntryWords) * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(&ws.solo_stage, (size_t)kSoloStageWords * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(&ws.sub_pos, (size_t)ctx->n_pad));
+            HIPCHK(hipMemset(ws.sub_pos, 0, (size_t)ctx->n_pad));
+            HIPCHK(hipMalloc(&ws.v_max, (size_t)kSoloLogCap * ws.nvwg * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(&ws.v_min, (size_t)kSoloLogCap * ws.nvwg * sizeof(uint64_t)));
+            HIPCHK(hipMalloc(&ws.cand_top, 2 * (size_t)ws.nvwg * sizeof(uint64_t)));
+            HIPCHK(hipMemset(ws.cand_top, 0xff, 2 * (size_t)ws.nvwg * sizeof(uint64_t)));
+        }
         ws.gcap = (uint32_t)want;
         ws.gpitch = gpitch;
         // developer aid: SS_HIP_LA_DEBUG=<file> dumps the stage timestamps of k_la_iter after each solve
@@ -355,7 +379,7 @@ template <typename T> struct Lookahead {
     }
 
     // c0 = A^T y has been swept into ws.c0 (partials in pmax): first pick, first lookahead sweep
-    static void init(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol)
+    static void init(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, bool solo = false)
     {
         hipStream_t st = ctx->stream;
         const bool full = ws.gram_is_full;                      // every column is "cached": no sweep, ever
@@ -373,6 +397,7 @@ template <typename T> struct Lookahead {
             HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
         }
         HIPCHK(launch_la_update<T>(ctx, ws, 0, tol));
+        if (solo) HIPCHK(launch_cand_init(ctx, ws));           // ranking of the first subset: largest |c0|
         if (ctx->la_fused) return;                 // k_la_iter forms c and q itself
         uint32_t np2 = 0;
         HIPCHK(launch_la_cq<T>(ctx, ws, &np2));
@@ -381,9 +406,11 @@ template <typename T> struct Lookahead {
 
     // fused form: one launch per iteration ...
     // lds_cols != 0: resident form holding up to that many support columns in LDS
-    static void iterate(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter, uint32_t lds_cols)
+    // solo: the speculative form (one workgroup + verification) while the device has not switched it off
+    static void iterate(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter, uint32_t lds_cols, bool solo = false)
     {
-        if (lds_cols != 0) HIPCHK(launch_persist(ctx, ws, tol, max_iter, lds_cols));
+        if (solo && lds_cols != 0) HIPCHK(launch_solo_group(ctx, ws, tol, max_iter));
+        else if (lds_cols != 0) HIPCHK(launch_persist(ctx, ws, tol, max_iter, lds_cols));
         else HIPCHK(launch_la_iter<T>(ctx, ws, tol, max_iter));
     }
     // ... and, when the device reports an entering column without cached Gram column, the sweep
@@ -459,7 +486,7 @@ hipEvent_t prof_event(ss_hip_ctx* ctx, size_t i)
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
                ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
-               bool omp = false, bool force_residual = false)
+               bool omp = false, bool force_residual = false, bool no_solo = false)
 {
     if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
     if (ctx->kind != 0) { set_err(err, errlen, "solve: this context was created for IRLS"); return SS_HIP_EINVAL; }
@@ -505,6 +532,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         ctx->host_flags[1] = 0;
         ctx->host_flags[2] = 0;
         ctx->host_flags[3] = 0;
+        ctx->host_flags[4] = 0;
         if (prof) HIPCHK(hipEventRecord(ctx->ev_solve0, st));
         copy_in<T>(ctx, ws.y, y, incy, m);
         HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)ctx->n_pad * sizeof(T), st));
@@ -518,6 +546,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const bool la = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual;
         // orthogonal matching pursuit in Gram form (k_la_omp): same cache, same sweeps
         const bool la_omp = omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && ctx->la_fused >= 1;
+        bool solo = false, solo_started = false;
         // full-G mode (fp32): G = A^T A of the context as the cache.  G exists once a large batch has run
         // on the context, or is made here after `gram_full_after` single-signal solves (0.55 s and 17 GiB
         // at C2 against ~1 ms saved per solve from then on).
@@ -558,7 +587,12 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
-            Lookahead<T>::init(ctx, ws, nb1, tol);
+            // speculative form: fp32, exact zeros on removal (like the resident kernel), first LDS tier usable
+            solo = ctx->la_fused >= 3 && !no_solo && ctx->solo_off_solves == 0 && ctx->zero_on_removal && sizeof(T) == 4 &&
+                   la_persist_usable(ctx, std::min<uint32_t>((ws.dims.kcap + 15u) & ~15u, kLaLdsSmall)) && la_solo_usable(ctx);
+            if (ctx->la_fused >= 3 && !solo && ctx->solo_off_solves > 0 && !no_solo) ctx->solo_off_solves -= 1;
+            solo_started = solo;
+            Lookahead<T>::init(ctx, ws, nb1, tol, solo);
         } else if (!omp) {
             // c = A^T y  (residual_vector with x = 0, homotopy-cpu.cpp:215)
             uint32_t nb1 = 0;
@@ -617,8 +651,9 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     lds_cols = (hf[3] <= big && big > lds_cols && la_persist_usable(ctx, big)) ? big : 0u;
                 }
                 if (enq >= max_launch) { stuck = true; break; }
+                if (solo && (hf[4] != 0 || lds_cols != std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsSmall))) solo = false;   // the device handed over to the resident form
                 if (la_omp) HIPCHK(launch_la_omp<T>(ctx, ws, tol, max_iter));
-                else Lookahead<T>::iterate(ctx, ws, tol, max_iter, lds_cols);
+                else Lookahead<T>::iterate(ctx, ws, tol, max_iter, lds_cols, solo);
                 ++enq;
             }
             if (stuck) {
@@ -688,7 +723,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         if ((la || la_omp) && hs.status == kStatusRetryResidual) {
             // tolerance too tight for Gram-form correlations (see k_la_init_pick): residual form
             ctx->stats.gram_fallbacks += 1;
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, true);
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, true, no_solo);
         }
         if (la && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 2 && (ctx->persist_workers[0] != 0 || ctx->persist_workers[1] != 0)) {
             // the resident kernel gave up on a wait (its grid was not fully resident): this context
@@ -696,14 +731,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             ctx->persist_workers[0] = 0;
             ctx->persist_workers[1] = 0;
             ctx->stats.persist_fallbacks += 1;
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual);
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo);
         }
         if ((la || la_omp) && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 1) {
             // k_la_iter's grid barrier expired as well (the GPU is shared with another resident grid):
             // from here on this context uses the form without in-kernel grid synchronisation
             ctx->la_fused = 0;
             ctx->stats.persist_fallbacks += 1;
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual);
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo);
         }
         if (hs.status != 0) {
             set_err(err, errlen, hs.status == SS_HIP_ECAPACITY
@@ -729,6 +764,31 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         }
 
         ctx->stats.solves += 1;
+        if (solo_started) {
+            // Speculative launches that failed their check cost a replay and the rest of the solve in the
+            // resident form; contexts whose problems do that on most solves stop speculating for a while.
+            ctx->stats.solo_solves += 1;
+            ctx->stats.solo_retries += hs.solo_fails;
+            if (ctx->stats.solo_solves >= 8 && 2 * ctx->stats.solo_retries > ctx->stats.solo_solves) ctx->solo_off_solves = 64;
+            const char* path = hs.solo_fails ? std::getenv("SS_HIP_SOLO_DEBUG") : nullptr;
+            if (path != nullptr) {
+                // developer aid: the log and the verification partials of the last solo launch
+                const size_t lw = (size_t)kSoloHeaderWords + (size_t)kSoloLogCap * kSoloEntryWords;
+                std::vector<uint32_t> lg(lw), vm((size_t)kSoloLogCap * ws.nvwg);
+                std::vector<uint64_t> vn((size_t)kSoloLogCap * ws.nvwg);
+                HIPCHK(hipMemcpy(lg.data(), ws.solo_log, lw * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(vm.data(), ws.v_max, vm.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(vn.data(), ws.v_min, vn.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                if (FILE* fp = std::fopen(path, "wb")) {
+                    const uint32_t hdr[4] = { hs.solo_nlog, ws.nvwg, kSoloEntryWords, kSoloHeaderWords };
+                    std::fwrite(hdr, 4, 4, fp);
+                    std::fwrite(lg.data(), 4, lg.size(), fp);
+                    std::fwrite(vm.data(), 4, vm.size(), fp);
+                    std::fwrite(vn.data(), 8, vn.size(), fp);
+                    std::fclose(fp);
+                }
+            }
+        }
         ctx->stats.iterations += hs.iter;
         if (la || la_omp) ctx->stats.lookahead_sweeps += hs.nsweeps;
         if (prof) {
@@ -1354,7 +1414,8 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(7, value)); return SS_HIP_OK; }
-    if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "solo_subset"))   { ctx->solo_subset = (int)std::max<long>(0, std::min<long>(256, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { ctx->cache_mib = std::max<long>(16, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_gram_min")) { ctx->batch_gram_min = (int)std::max<long>(0, value); return SS_HIP_OK; }
@@ -1406,6 +1467,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     }
     if (!std::strcmp(key, "engine"))        { *value = ctx->engine; return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { *value = ctx->la_fused; return SS_HIP_OK; }
+    if (!std::strcmp(key, "solo_subset"))   { *value = ctx->solo_subset; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep32_variant")) { *value = ctx->sweep32_variant; return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { *value = ctx->cache_mib; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }

@@ -182,6 +182,22 @@ __device__ __forceinline__ bool exchange_all(uint64_t* slots, uint32_t nb, uint3
     return __syncthreads_or(ok ? 0 : 1) == 0;
 }
 
+// SOLO = the speculative form: ONE workgroup runs the same iterations on a subset of kSoloWidth columns
+// (the support, the cached columns and the best-ranked entrant candidates) with no exchange at all;
+// lambda and the step length come from the subset alone.  Every breakpoint is logged (lists, lambda,
+// pick) and k_la_verify recomputes the decisions over ALL columns afterwards, in the same arithmetic
+// order; the outcome is staged in DevState and reaches the host only after that check (solo.hip).
+struct SoloArgs {
+    const uint32_t* slot_col;   // [cache_used] column of each cache slot
+    const uint64_t* cand_top;   // [ncand] (ordered key << 32 | column) entrant candidates, ~0 = none
+    uint32_t ncand;
+    uint32_t subset_cap;        // columns the launch may hold beyond the support (option solo_subset)
+    uint32_t* log;              // header + [kSoloLogCap][kSoloEntryWords] (ss_hip_internal.h)
+    uint8_t* sub_pos;           // [n_pad] subset position of each of this launch's columns
+    uint32_t* stage;            // [kSoloStageWords] staged hand-over (committed by k_la_vpublish)
+};
+
+template <bool SOLO>
 __global__ __launch_bounds__(kPsThreads)
 void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t gl_rows, int full_g,
                   const float* __restrict__ gcache, const int32_t* __restrict__ slot_of,
@@ -189,16 +205,21 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                   float* c, float* q, float* c_alt, float* q_alt, float* x, float* d, uint8_t* insup,
                   uint32_t* gam2, float* inv0, float* inv1, float* __restrict__ tcand,
                   SlotDims L, DevState* st, LaSync* sy, uint64_t* smax, uint64_t* smin, uint32_t* hflags,
-                  TraceEntry* trace, uint32_t trace_cap, int tie_guard, uint64_t* dbg)
+                  TraceEntry* trace, uint32_t trace_cap, int tie_guard, uint64_t* dbg, SoloArgs sa)
 {
     extern __shared__ float smem[];
     __shared__ float sv[16];
     __shared__ uint32_t si[16];
     __shared__ uint32_t s_cnt[2];
     __shared__ float s_dd;
+    __shared__ uint32_t s_sub[SOLO ? kSoloWidth : 1];          // solo: the columns of this launch
+    __shared__ uint64_t s_off[SOLO ? kPsThreads : 1];          // solo: candidate offers while the subset is built
+    __shared__ uint32_t s_sps[SOLO ? kSoloListPitch : 1];      // solo: subset position of each support column
+    __shared__ uint32_t s_ipos;                                // solo: subset position of the entering column
+    __shared__ float s_cq[SOLO ? 2 * kSoloWidth : 1];          // solo: c, q of the subset (the resident form hands them through global memory)
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t nb = gridDim.x, w = blockIdx.x;
+    const uint32_t nb = SOLO ? 1u : gridDim.x, w = SOLO ? 0u : blockIdx.x;
     const bool lead = w == 0;                    // the workgroup that writes the shared state
     const uint32_t kcap = L.kcap;
     const uint32_t Pp = P + 1u;
@@ -220,7 +241,15 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     // ---- by earlier launches only) --------------------------------------------------------------
     const uint32_t K0 = st->K;
     const bool grow0 = (K0 + 1u > P) && (P < kcap);
-    if (st->done || st->need_sweep || grow0) {
+    if (SOLO) {
+        // (k_la_vpublish counts the launch for the host pump, whether it worked or not)
+        if (st->done || st->need_sweep || st->solo_off) return;
+        if (grow0) {
+            // the support does not fit the solo tier: the resident form takes over (nothing staged: exit code 0)
+            if (tid == 0) { sa.stage[9] = 7u; sa.stage[0] = K0; st->solo_nlog = 0; st->solo_pending = 2; }    // exit code 7: nothing ran
+            return;
+        }
+    } else if (st->done || st->need_sweep || grow0) {
         if (lead && tid == 0) {
             if (!st->done && !st->need_sweep)
                 __hip_atomic_store(&hflags[3], K0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -231,6 +260,66 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     uint32_t tick = sy->tick;
 
     // ---- this workgroup's columns -------------------------------------------------------------------
+    const uint32_t replay = SOLO ? st->solo_replay : 0u;       // > 0: repeat exactly this many (verified) iterations
+    if (SOLO && replay != 0u) {
+        // the same columns as the launch that is being repeated (its header is still in the log)
+        if (tid < kSoloWidth) s_sub[tid] = sa.log[tid];
+        __syncthreads();
+    } else if (SOLO) {
+        // the subset: support, then cached columns outside it (latest slots first), then the best-ranked
+        // entrant candidates of the last scan (k_la_verify) or of |c0| (k_la_cand_init)
+        // (subset_cap counts the columns beyond the support; the support, K0 <= P < kSoloWidth, is always in)
+        const uint32_t cap = K0 + sa.subset_cap < kSoloWidth ? K0 + sa.subset_cap : kSoloWidth;
+        const uint32_t* gam0 = gam2 + (size_t)st->cur * kcap;
+        if (tid < 2) s_cnt[tid] = 0u;
+        if (tid < kSoloWidth) s_sub[tid] = 0xffffffffu;
+        __syncthreads();
+        if (tid < K0) s_sub[tid] = gam0[tid];
+        uint32_t cnt = K0;
+        if (!full_g) {
+            const uint32_t used = st->cache_used;
+            const uint32_t quota = cap > cnt + 32u ? cap - cnt - 32u : 0u;       // room kept for candidates
+            const uint32_t s0 = used > kPsThreads ? used - kPsThreads : 0u;
+            if (s0 + tid < used) {
+                const uint32_t cl = sa.slot_col[used - 1u - tid];
+                if (cl < n && !insup[cl]) {
+                    const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
+                    if (pos < quota) s_sub[cnt + pos] = cl;
+                }
+            }
+            __syncthreads();
+            cnt += s_cnt[0] < quota ? s_cnt[0] : quota;
+        }
+        // candidates: every thread offers the best of its strided share, the offers are ranked by counting
+        uint64_t offer = ~0ull;
+        if (n <= 32u * kPsThreads) {
+            // few columns: the workgroup ranks all of them itself (the per-block tops are too few here)
+            const bool scanned = st->cand_scan != 0;              // tcand of the last verified scan, else |c0|
+            for (uint32_t cl = tid; cl < n; cl += kPsThreads) {
+                if (insup[cl] || (!full_g && slot_of[cl] >= 0)) continue;
+                float key;
+                if (scanned) { key = tcand[cl]; if (!(key < Lim<float>::max())) continue; }
+                else { const float v = c0[cl]; key = v < 0.f ? v : -v; }
+                const uint64_t pk = ((uint64_t)ordered_key(key) << 32) | cl;
+                if (pk < offer) offer = pk;
+            }
+        } else {
+            for (uint32_t e = tid; e < sa.ncand; e += kPsThreads) {
+                const uint64_t pk = sa.cand_top[e];
+                const uint32_t cl = (uint32_t)pk;
+                if (pk == ~0ull || cl >= n || insup[cl] || (!full_g && slot_of[cl] >= 0)) continue;
+                if (pk < offer) offer = pk;
+            }
+        }
+        s_off[tid] = offer;
+        __syncthreads();
+        if (offer != ~0ull) {
+            uint32_t rank = 0;
+            for (uint32_t u = 0; u < kPsThreads; ++u) rank += s_off[u] < offer ? 1u : 0u;
+            if (cnt + rank < cap) s_sub[cnt + rank] = (uint32_t)offer;
+        }
+        __syncthreads();
+    }
     uint32_t col[kPsCols];
     bool in[kPsCols], cached[kPsCols];
     uint32_t act[kPsCols];
@@ -239,6 +328,10 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     for (int k = 0; k < kPsCols; ++k) {
         col[k] = w * kPsWidth + (tid & (kPsWidth - 1u)) + (uint32_t)k * nb * kPsWidth;
         in[k] = tid < kPsWidth && col[k] < n;
+        if (SOLO) {
+            col[k] = (k == 0 && tid < kPsWidth) ? s_sub[tid] : 0xffffffffu;
+            in[k] = col[k] < n;
+        }
         c0v[k] = 0.f; act[k] = 0; cached[k] = false;
         if (in[k]) {
             c0v[k] = c0[col[k]];
@@ -247,6 +340,15 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         }
     }
 
+    if (SOLO) {
+        if (tid < kSoloWidth) {
+            const uint32_t cl = s_sub[tid];
+            sa.log[tid] = cl;
+            sa.log[kSoloWidth + tid] = cl < n ? (full_g ? cl : (uint32_t)slot_of[cl]) : 0xffffffffu;
+            if (cl < n) sa.sub_pos[cl] = (uint8_t)tid;
+        }
+        if (tid < kSoloListPitch) s_sps[tid] = tid;             // the support leads the subset, in order
+    }
     // ---- replica of the active set ---------------------------------------------------------------------
     const uint32_t cur = st->cur;
     float* const Ig = cur ? inv1 : inv0;
@@ -292,7 +394,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     }
     {
         const uint32_t tcol = tid & (kPsWidth - 1u), half = tid / kPsWidth;          // two rows per pass
-        const uint32_t cg = w * kPsWidth + tcol;
+        const uint32_t cg = SOLO ? s_sub[tcol] : w * kPsWidth + tcol;
         const uint32_t cofs4 = (cg < n ? cg : 0u) * 4u;
         constexpr uint32_t rpp = kPsThreads / kPsWidth;      // rows per pass
         for (uint32_t r0 = 0; r0 < gl_used; r0 += 8 * rpp) {
@@ -399,7 +501,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     };
     auto post_lambda = [&]() {
         ++tick;
-        if (tid == 0)
+        if (!SOLO && tid == 0)
             st_u64(&smax[(tick & 1u) * kLaSlotStride + w],
                    cmax_i != 0xffffffffu ? (((uint64_t)__float_as_uint(cmax_v) << 32) | (uint64_t)(0xffffffffu - cmax_i)) : 0ull);
     };
@@ -407,6 +509,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     // read everybody's word of the lambda exchange of the current tick (false: a wait expired)
     // `early`: what this thread read from slot `tid` before the q pass (usually the word is there by then)
     auto poll_lambda = [&](float& lam, uint64_t early = kLaSlotEmpty) -> bool {
+        if (SOLO) { lam = cmax_v; return true; }             // the subset's maximum (uniform after the block reduction)
         const uint32_t par = (tick & 1u) * kLaSlotStride;
         float mv = -1.f;
         uint32_t mi = 0xffffffffu;
@@ -437,6 +540,25 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         return true;
     };
 
+    // solo: one log entry per decision taken from the subset alone (lists as they stand: K entries)
+    uint32_t nlog = 0, nscan = 0;
+    auto log_entry = [&](uint32_t flags, uint32_t round_, float lam, float g_, uint32_t idx_, float gs_, uint32_t is_) {
+        if (!SOLO) return;
+        uint32_t* e = sa.log + kSoloHeaderWords + (size_t)nlog * kSoloEntryWords;
+        if (tid == 0) {
+            e[0] = K; e[1] = flags; e[2] = round_; e[3] = idx_;
+            e[4] = __float_as_uint(lam); e[5] = __float_as_uint(g_); e[6] = __float_as_uint(gs_); e[7] = is_;
+        }
+        if (tid < K) {
+            e[8 + tid] = S.gam[tid];
+            e[8 + kSoloListPitch + tid] = s_sps[tid];
+            e[8 + 2 * kSoloListPitch + tid] = __float_as_uint(S.xs[tid]);
+            e[8 + 3 * kSoloListPitch + tid] = __float_as_uint(S.ds[tid]);
+        }
+        ++nlog;
+        nscan += flags & 1u;
+    };
+
     // Software pipeline.  The lambda exchange of an iteration is posted as soon as its x is known
     // (right after the previous pick) and read only after the inverse update and the q pass, which
     // hide its latency; the step-length exchange hides the in-place store pass of the inverse.
@@ -449,6 +571,12 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         const uint32_t round = iter + 1u;
         const uint32_t par = (tick & 1u) * kLaSlotStride;
         ts[0] = wall_clock64();
+        if (SOLO && (nlog + 2u > kSoloLogCap || (replay != 0u && nscan >= replay))) {
+            // the log is full: end the launch at this iteration boundary (the next one goes on)
+            if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
+            exit_code = 5;
+            break;
+        }
 
         // ---- q = sum_j d_j g_j; publish c, q for the reads on the support -----------------------------
         // (buffer of this tick's parity: a workgroup may already be writing the next tick's values
@@ -456,11 +584,16 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         float* const cbuf = (tick & 1u) ? c_alt : c;
         float* const qbuf = (tick & 1u) ? q_alt : q;
         // (the lambda words were posted before the inverse update: read this thread's slot now, use it below)
-        const uint64_t early = tid < nb ? ld_u64(&smax[par + tid]) : kLaSlotEmpty;
+        const uint64_t early = (!SOLO && tid < nb) ? ld_u64(&smax[par + tid]) : kLaSlotEmpty;
         gram_pass(S.ds, K, qv);
+        if (SOLO) {
+            // (scattered columns: 512 single-line stores per iteration would hold up every later barrier)
+            if (tid < kSoloWidth) { s_cq[tid] = cv[0]; s_cq[kSoloWidth + tid] = qv[0]; }
+        } else {
 #pragma unroll
-        for (int k = 0; k < kPsCols; ++k)
-            if (in[k]) { st_f32(&cbuf[col[k]], cv[k]); st_f32(&qbuf[col[k]], qv[k]); }
+            for (int k = 0; k < kPsCols; ++k)
+                if (in[k]) { st_f32(&cbuf[col[k]], cv[k]); st_f32(&qbuf[col[k]], qv[k]); }
+        }
         ts[1] = wall_clock64();
 
         // ---- lambda (posted before the inverse update) ---------------------------------------------------
@@ -471,6 +604,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
         if ((round > 1u && !(c_inf > tol)) || round > max_iter) {
             if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
+            log_entry(0u, round, c_inf, 0.f, 0u, 0.f, 0u);         // the lambda that ended the loop
             c_inf_rep = c_inf;
             iter = round - 1u;
             done_round = round;
@@ -506,12 +640,13 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         }
         drain_vmem();                                      // this wave's c, q stores are performed
         block_reduce_pair<float, false>(best, best_i, sv, si);
-        if (tid == 0)
+        if (!SOLO && tid == 0)
             st_u64(&smin[par + w], best_i != 0xffffffffu ? (((uint64_t)__float_as_uint(best) << 32) | (uint64_t)best_i) : kLaSlotNone);
         // per-column candidates for k_la_top's ranking: nobody reads them inside the launch
+        // (solo: k_la_verify writes them for all columns)
 #pragma unroll
         for (int k = 0; k < kPsCols; ++k)
-            if (in[k]) tcand[col[k]] = (act[k] || cached[k]) ? Lim<float>::max() : mk[k];
+            if (!SOLO && in[k]) tcand[col[k]] = (act[k] || cached[k]) ? Lim<float>::max() : mk[k];
         // while the candidates travel: bring the stored inverse up to date with the last toggle
         if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
         // ... and the active columns, -x_j / d_j (homotopy-cpu.cpp:128-135), from the replica
@@ -521,7 +656,15 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             const float t = -S.xs[tid] / S.ds[tid];
             if (t > 0.f && t < Lim<float>::max()) { g = t; idx = S.gam[tid]; }
         }
-        {
+        float gs_log = Lim<float>::max();
+        uint32_t is_log = 0xffffffffu;
+        if (SOLO) {
+            // support candidates alone (logged: the verification merges them with ITS candidates), then
+            // merged with the subset's best
+            block_reduce_pair<float, false>(g, idx, sv, si);
+            gs_log = g; is_log = idx;
+            if (best_i != 0xffffffffu && better_min(best, best_i, g, idx)) { g = best; idx = best_i; }
+        } else {
             bool ok = true;
             for (uint32_t s0 = 0; s0 < nb; s0 += kPsThreads) {
                 const uint32_t sidx = s0 + tid;
@@ -545,12 +688,14 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             block_reduce_pair<float, false>(g, idx, sv, si);
         }
         // every workgroup has read all maxima of this tick (it posted its candidate after that)
-        if (tid == 0) st_u64(&smax[par + w], kLaSlotEmpty);
-        if (!(g < Lim<float>::max())) idx = 0u;
+        if (!SOLO && tid == 0) st_u64(&smax[par + w], kLaSlotEmpty);
+        const bool no_candidate = !(g < Lim<float>::max());
+        if (no_candidate) idx = 0u;
         ts[3] = wall_clock64();
 
         // rank of idx in the sorted support, membership (rank_index.h:65-83)
         if (tid < 2) s_cnt[tid] = 0u;
+        if (SOLO && in[0] && col[0] == idx) s_ipos = tid;          // subset position of the pick
         __syncthreads();
         if (tid < K) {
             const uint32_t gj = S.gam[tid];
@@ -561,6 +706,17 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         const uint32_t rank = s_cnt[0];
         const bool added = s_cnt[1] == 0u;
         const uint32_t K_new = added ? K + 1u : K - 1u;
+        if (SOLO) {
+            if (no_candidate || K_new == 0u || K_new > kcap || !(c_inf - g > tol)) {
+                // Left to the resident form (nothing of this iteration has been committed yet): the rare
+                // endings (no step, empty support, workspace full) and the LAST step of a path — it takes
+                // lambda to ~0, where every column's candidate ties within rounding and no subset can know
+                // the winner.
+                exit_code = 6;
+                break;
+            }
+            log_entry(1u, round, c_inf, g, idx, gs_log, is_log);
+        }
         if (lead && trace != nullptr && tid == 0 && round < trace_cap) {
             trace[round].idx = idx;
             trace[round].added = added ? 1u : 0u;
@@ -586,7 +742,10 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
 
         // loads that only need idx: c, q on the support (and at idx), the cache slot of idx
         float cj = 0.f, qj = 0.f;
-        if (tid < K) { cj = ld_f32(&cbuf[S.gam[tid]]); qj = ld_f32(&qbuf[S.gam[tid]]); }
+        if (SOLO) {
+            if (tid < K) { cj = s_cq[s_sps[tid]]; qj = s_cq[kSoloWidth + s_sps[tid]]; }
+            else if (tid == K && added) { cj = s_cq[s_ipos]; qj = s_cq[kSoloWidth + s_ipos]; }
+        } else if (tid < K) { cj = ld_f32(&cbuf[S.gam[tid]]); qj = ld_f32(&qbuf[S.gam[tid]]); }
         else if (tid == K && added) { cj = ld_f32(&cbuf[idx]); qj = ld_f32(&qbuf[idx]); }
         int32_t slot = 0;
         if (added) slot = slot_of[idx];
@@ -604,7 +763,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             const float xn = S.xs[tid] + g * S.ds[tid];
             S.xs[tid] = (!added && tid == rank) ? 0.f : xn;
         }
-        if (lead && tid == 0) insup[idx] = added ? 1 : 0;
+        if (!SOLO && lead && tid == 0) insup[idx] = added ? 1 : 0;      // (solo: membership flags change at the commit)
 #pragma unroll
         for (int k = 0; k < kPsCols; ++k)
             if (in[k] && col[k] == idx) act[k] = added ? 1u : 0u;
@@ -630,12 +789,13 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             if (!poll_lambda(lam)) { exit_code = 4; break; }
             // this tick has no step-length exchange of its own: an (empty-handed) one keeps the slot
             // discipline — it proves every workgroup has read the maxima
-            {
+            if (!SOLO) {
                 const uint32_t par2 = (tick & 1u) * kLaSlotStride;
                 const bool ok = exchange_all(smin + par2, nb, w, kLaSlotNone, [&](uint64_t) {});
                 if (!ok) { exit_code = 4; break; }
                 if (tid == 0) st_u64(&smax[par2 + w], kLaSlotEmpty);
             }
+            log_entry(0u, round + 1u, lam, 0.f, 0u, 0.f, 0u);      // lambda after the step (x updated, K old entries)
             if (!(lam > tol) || round + 1u > max_iter) {
                 c_inf_rep = lam;                         // iter = round already
                 done_round = round + 1u;
@@ -646,7 +806,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             // iteration's c and q from the primary buffers (the c just formed belongs to the next one)
 #pragma unroll
             for (int k = 0; k < kPsCols; ++k)
-                if (in[k]) { c[col[k]] = ld_f32(&cbuf[col[k]]); q[col[k]] = qv[k]; }
+                if (in[k]) { c[col[k]] = SOLO ? s_cq[tid] : ld_f32(&cbuf[col[k]]); q[col[k]] = qv[k]; }
             save_lists_for_update = true;
             pend_rank = rank;
             pend_idx = idx;
@@ -696,7 +856,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 if (lds_rows_used < gl_rows) {
                     new_lrow = lds_rows_used++;
                     if (tid < kPsWidth) {
-                        const uint32_t cg = w * kPsWidth + tid;
+                        const uint32_t cg = SOLO ? s_sub[tid] : w * kPsWidth + tid;
                         Glds[new_lrow * kPsWidth + tid] = gcache[(size_t)idx * gpitch + (cg < n ? cg : 0u)];
                     }
                 }
@@ -704,12 +864,12 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 new_lrow = (uint32_t)slot;
             }
             // lists: insert at `rank`
-            uint32_t ng = 0, ns = 0, nl = kNoLdsRow;
+            uint32_t ng = 0, ns = 0, nl = kNoLdsRow, np = 0;
             float nx = 0.f, ncn = 0.f;
             if (tid < K_new) {
                 const uint32_t o = tid - (tid > rank ? 1u : 0u);
-                if (tid == rank) { ng = idx; ns = (uint32_t)slot; nx = 0.f; nl = new_lrow; }
-                else { ng = S.gam[o]; ns = S.slt[o]; nx = S.xs[o]; nl = S.lrw[o]; }
+                if (tid == rank) { ng = idx; ns = (uint32_t)slot; nx = 0.f; nl = new_lrow; if (SOLO) np = s_ipos; }
+                else { ng = S.gam[o]; ns = S.slt[o]; nx = S.xs[o]; nl = S.lrw[o]; if (SOLO) np = s_sps[o]; }
             }
             // cnv sits in thread j (old position) / thread K (idx): move through LDS
             if (tid <= K) S.cn[tid] = cnv;
@@ -719,7 +879,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 ncn = (tid == rank) ? S.cn[K] : S.cn[o];
             }
             __syncthreads();
-            if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; S.lrw[tid] = nl; }
+            if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; S.lrw[tid] = nl; if (SOLO) s_sps[tid] = np; }
         } else {
             // remove row/column `rank` (online_inverse.h:275-290)
             const uint32_t nn = K;
@@ -728,17 +888,18 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             __syncthreads();
             for (uint32_t i = tid; i < nn; i += kPsThreads) S.u2[i] = S.I[i * Pp + rank] * sc;
             // the column that left: exact zeros in the dense vectors, out of the lists
-            if (lead && tid == 0) { x[idx] = 0.f; d[idx] = 0.f; }
+            if (!SOLO && lead && tid == 0) { x[idx] = 0.f; d[idx] = 0.f; }
             if (tid < K) S.cn[tid] = cnv;
             __syncthreads();
-            uint32_t ng = 0, ns = 0, nl = kNoLdsRow;
+            uint32_t ng = 0, ns = 0, nl = kNoLdsRow, np = 0;
             float nx = 0.f, ncn = 0.f;
             if (tid < K_new) {
                 const uint32_t o = tid + (tid >= rank ? 1u : 0u);
                 ng = S.gam[o]; ns = S.slt[o]; nx = S.xs[o]; ncn = S.cn[o]; nl = S.lrw[o];
+                if (SOLO) np = s_sps[o];
             }
             __syncthreads();
-            if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; S.lrw[tid] = nl; }
+            if (tid < K_new) { S.gam[tid] = ng; S.slt[tid] = ns; S.xs[tid] = nx; S.cn[tid] = ncn; S.lrw[tid] = nl; if (SOLO) s_sps[tid] = np; }
             else if (tid == K_new) { S.xs[tid] = 0.f; S.ds[tid] = 0.f; }     // the vacated entry is padding again
         }
         __syncthreads();
@@ -782,6 +943,32 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
 
     // ---- end of the launch: workgroup 0 hands the state back in the global layout --------------------
     if (!lead) return;
+    if (SOLO) {
+        // staged, in the layout of ss_hip_internal.h: k_la_vpublish commits it once the log is verified
+        uint32_t* sg = sa.stage;
+        constexpr uint32_t LP = kSoloListPitch;
+        if (tid < K) {
+            sg[kSoloStageHead + tid] = S.gam[tid];
+            sg[kSoloStageHead + LP + tid] = __float_as_uint(S.xs[tid]);
+            sg[kSoloStageHead + 2 * LP + tid] = __float_as_uint(S.ds[tid]);
+        }
+        if (save_lists_for_update && tid < K + 1u) {
+            const uint32_t o = tid - (tid > pend_rank ? 1u : 0u);
+            sg[kSoloStageHead + 3 * LP + tid] = (tid == pend_rank) ? pend_idx : S.gam[o];
+        }
+        for (uint32_t e = tid; e < K * K; e += kPsThreads) {
+            const uint32_t a = e / K, b = e - a * K;
+            sg[kSoloStageHead + 4 * LP + 1 + e] = __float_as_uint(S.I[a * Pp + b]);
+        }
+        if (tid == 0) {
+            sg[0] = K; sg[1] = save_lists_for_update ? 1u : 0u; sg[2] = iter;
+            sg[3] = __float_as_uint(c_inf_rep); sg[4] = __float_as_uint(gamma_last);
+            sg[5] = last_idx; sg[6] = last_rank; sg[7] = last_added; sg[8] = tick; sg[9] = (uint32_t)exit_code; sg[10] = done_round;
+            st->solo_nlog = nlog;
+            st->solo_pending = replay != 0u ? 2u : 1u;
+        }
+        return;
+    }
     if (save_lists_for_update) {
         // the pick is made (x updated, K_new columns) but the inverse still describes the old support:
         // buffer `cur` keeps the old support and inverse, buffer cur^1 receives the new sorted support
@@ -852,14 +1039,14 @@ static int persist_workers(ss_hip_ctx* ctx, uint32_t P)
     if (ctx->persist_workers[tier] >= 0) return ctx->persist_workers[tier];
     int result = 0;
     const size_t lds = persist_lds_bytes(P);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_la_persist),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_la_persist<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPsLdsBudget) != hipSuccess) {
         (void)hipGetLastError();
         ctx->persist_workers[tier] = 0;
         return 0;
     }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_la_persist, kPsThreads, lds) == hipSuccess && per_cu > 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_la_persist<false>, kPsThreads, lds) == hipSuccess && per_cu > 0) {
         // the whole grid must be resident: at most what the occupancy allows (a launch that does not
         // get there gives up through its bounded waits and the solve falls back to k_la_iter)
         const long cap = (long)std::min(per_cu, 2) * ctx->num_cus;
@@ -896,10 +1083,45 @@ hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float to
     const size_t lds = persist_lds_bytes(P);
     uint64_t* smax = reinterpret_cast<uint64_t*>(ws.la_sync + 1);
     uint64_t* smin = smax + 2 * kLaSlotStride;
-    hipLaunchKernelGGL(k_la_persist, dim3(nw), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, persist_gl_rows(P), ws.gram_is_full ? 1 : 0,
+    hipLaunchKernelGGL(k_la_persist<false>, dim3(nw), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, persist_gl_rows(P), ws.gram_is_full ? 1 : 0,
                        (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
-                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg);
+                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg, SoloArgs{});
+    return hipGetLastError();
+}
+
+// ---- speculative form: one workgroup, first LDS tier ---------------------------------------------------
+bool la_solo_usable(ss_hip_ctx* ctx)
+{
+    if (ctx->n >= (1u << 30)) return false;
+    if (ctx->solo_attr_set < 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_la_persist<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(kLaLdsSmall));
+        if (e != hipSuccess) (void)hipGetLastError();
+        ctx->solo_attr_set = e == hipSuccess ? 1 : 0;
+    }
+    return ctx->solo_attr_set == 1;
+}
+
+hipError_t launch_la_solo_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter)
+{
+    const uint32_t P = kLaLdsSmall;
+    if (!la_solo_usable(ctx) || ws.cq_alt == nullptr || ws.solo_log == nullptr || ws.solo_stage == nullptr) return hipErrorInvalidConfiguration;
+    const size_t lds = persist_lds_bytes(P);
+    uint64_t* smax = reinterpret_cast<uint64_t*>(ws.la_sync + 1);
+    uint64_t* smin = smax + 2 * kLaSlotStride;
+    SoloArgs sa;
+    sa.slot_col = ws.slot_col;
+    sa.cand_top = ws.cand_top;
+    sa.ncand = 2 * ws.nvwg;
+    sa.subset_cap = (uint32_t)std::max(0, std::min(ctx->solo_subset, (int)kSoloWidth));
+    sa.log = ws.solo_log;
+    sa.sub_pos = ws.sub_pos;
+    sa.stage = ws.solo_stage;
+    hipLaunchKernelGGL(k_la_persist<true>, dim3(1), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, persist_gl_rows(P), ws.gram_is_full ? 1 : 0,
+                       (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
+                       ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
+                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg, sa);
     return hipGetLastError();
 }
 

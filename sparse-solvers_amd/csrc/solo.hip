@@ -1,0 +1,485 @@
+// solo.hip — verification of the speculative ("solo") form of the lookahead engine.
+//
+// A solo launch (k_la_persist<true>, persist.hip) runs Homotopy iterations in ONE workgroup on a subset
+// of 256 columns — the support, the cached columns and the best-ranked entrant candidates — with no
+// exchange between workgroups: lambda = ||c||_inf and the step length (find_max_gamma,
+// /root/reference/src/solvers/homotopy-cpu.cpp:100-164) are taken over the subset alone.  That is the
+// reference's iteration only if no column outside the subset would have changed either of them.  The
+// launch therefore logs every breakpoint (support lists with x_S and d_S, lambda, the pick), and
+//
+//   k_la_verify    recomputes, for ALL columns and all logged breakpoints at once, c = c0 - sum_j x_j g_j
+//                  and q = sum_j d_j g_j from the same Gram rows in the same order of operations (sorted
+//                  support, separately rounded products and sums), then max |c| and the step-length scan
+//                  with the reference's predicates; one pass over the Gram rows serves up to 32
+//                  breakpoints (64 accumulators per column);
+//   k_la_vpublish  reduces the per-workgroup partials and compares them, bit for bit, with what the solo
+//                  launch used.  What a solo launch leaves behind is only STAGED (persist.hip): if every
+//                  breakpoint agrees, the staged state becomes the state of the solve and the outcome
+//                  (finished / Gram column missing / tier outgrown) is released to the host.  If breakpoint
+//                  k* disagrees nothing is committed; the next solo launch repeats exactly the verified
+//                  iterations before k* (same subset, same arithmetic, hence the same state), commits, and
+//                  the resident form goes on from there — no decision taken from a subset reaches the
+//                  caller unchecked.
+//
+// The solo kernel itself stops before the last step of a path (lambda - gamma <= tolerance): there every
+// column's candidate ties within rounding and no subset can know the winner.
+//
+// k_la_verify also leaves what the next steps rank by: tcand (k_la_top's input) and the two best entrant
+// candidates of each workgroup's 256 columns (the next subset); k_la_cand_init seeds the latter from |c0|.
+// Compiled with -ffp-contract=off like persist.hip (the arithmetic has to match it bit for bit).
+#include "ss_hip_internal.h"
+#include "ss_hip_device.h"
+
+namespace sship {
+
+constexpr int kVfThreads = 256;
+constexpr uint32_t kVfUnion = 128;           // support columns a chunk of breakpoints can involve (96 + 32)
+constexpr uint32_t kVfRedPitch = kVfThreads + 8;
+
+// the two best (smallest key, then smallest column) of the block's offers -> out[0], out[1]
+__device__ __forceinline__ void block_top2(float key, uint32_t colv, uint64_t* out, float* sv, uint32_t* si)
+{
+    float k1 = key;
+    uint32_t c1 = colv;
+    block_reduce_pair<float, false>(k1, c1, sv, si);
+    __syncthreads();
+    float k2 = (colv == c1) ? Lim<float>::max() : key;
+    uint32_t c2 = (colv == c1) ? 0xffffffffu : colv;
+    block_reduce_pair<float, false>(k2, c2, sv, si);
+    if (threadIdx.x == 0) {
+        out[0] = c1 != 0xffffffffu ? (((uint64_t)ordered_key(k1) << 32) | c1) : ~0ull;
+        out[1] = c2 != 0xffffffffu ? (((uint64_t)ordered_key(k2) << 32) | c2) : ~0ull;
+    }
+}
+
+// entrant candidates before the first scan: the largest |c0| of every 256-column block
+__global__ __launch_bounds__(kVfThreads)
+void k_la_cand_init(const float* __restrict__ c0, uint32_t n, const DevState* __restrict__ st, uint64_t* __restrict__ cand_top)
+{
+    __shared__ float sv[16];
+    __shared__ uint32_t si[16];
+    if (st->done) return;
+    const uint32_t i = blockIdx.x * kVfThreads + threadIdx.x;
+    float key = Lim<float>::max();
+    uint32_t cl = 0xffffffffu;
+    if (i < n) {
+        const float v = c0[i];
+        key = v < 0.f ? v : -v;
+        cl = i;
+    }
+    block_top2(key, cl, cand_top + 2 * (size_t)blockIdx.x, sv, si);
+}
+
+__global__ __launch_bounds__(kVfThreads)
+void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint32_t gpitch,
+                 const int32_t* __restrict__ slot_of, const float* __restrict__ c0,
+                 const uint32_t* __restrict__ log, const uint8_t* __restrict__ sub_pos,
+                 const DevState* __restrict__ st, uint32_t* __restrict__ v_max, uint64_t* __restrict__ v_min,
+                 uint32_t nvwg, float* __restrict__ tcand, uint64_t* __restrict__ cand_top, int tie_guard, uint32_t nrows)
+{
+    __shared__ float sX[kVfUnion][kSoloChunk];          // x_S of union column r at breakpoint k (0 when absent)
+    __shared__ float sD[kVfUnion][kSoloChunk];
+    __shared__ uint64_t sRed[kSoloChunk * kVfRedPitch]; // reductions: one row per breakpoint
+    __shared__ uint32_t s_sub[kSoloWidth];              // header: columns of the subset
+    __shared__ uint32_t s_row[kSoloWidth];              // header: their Gram rows
+    __shared__ uint32_t s_pres[kSoloWidth];             // bit k: position is in the support at breakpoint k
+    __shared__ uint32_t s_rank[kSoloWidth];             // position -> index in the union (sorted by column)
+    __shared__ uint32_t s_urow[kVfUnion];               // union index -> Gram row
+    __shared__ uint32_t s_hdr[kSoloChunk][8];
+    __shared__ uint32_t s_U;
+    __shared__ float sv[16];
+    __shared__ uint32_t si[16];
+
+    if (st->solo_pending != 1u) return;                  // (2 = a replay: its iterations were verified before)
+    const uint32_t nlog = st->solo_nlog;
+    if (nlog == 0u) return;
+    const uint32_t tid = threadIdx.x, wg = blockIdx.x;
+    const uint32_t i = wg * kVfThreads + tid;
+    const bool valid = i < n;
+    const float c0v = valid ? c0[i] : 0.f;
+    const bool cached = valid && slot_of[i] >= 0;
+    s_sub[tid] = log[tid];
+    s_row[tid] = log[kSoloWidth + tid];
+    __syncthreads();
+    // this thread's column in the subset?  (sub_pos is only trusted if the header agrees)
+    uint32_t mypos = 0xffffffffu;
+    if (valid) {
+        const uint32_t p = sub_pos[i];
+        if (s_sub[p] == i) mypos = p;
+    }
+    // the last entry that carries a scan: its candidates feed tcand and the next subset
+    // (one parallel load of the flag words; s_hdr is free until the first chunk)
+    if (tid < kSoloLogCap) {
+        const uint32_t fl = tid < nlog ? (log[kSoloHeaderWords + (size_t)tid * kSoloEntryWords + 1] & 1u) : 0u;
+        const uint64_t b = __ballot(fl != 0u);
+        if (tid == 0) s_U = b ? 63u - (uint32_t)__builtin_clzll(b) : 0xffffffffu;
+    }
+    __syncthreads();
+    const uint32_t last_scan = s_U;
+
+    const uint32_t* entries = log + kSoloHeaderWords;
+    for (uint32_t k0 = 0; k0 < nlog; k0 += kSoloChunk) {
+        const uint32_t J = nlog - k0 < kSoloChunk ? nlog - k0 : kSoloChunk;
+        __syncthreads();
+        // ---- the chunk's union of support columns, sorted by column; coefficient tables ---------------
+        s_pres[tid] = 0u;
+        for (uint32_t e = tid; e < kVfUnion * kSoloChunk; e += kVfThreads) {
+            (&sX[0][0])[e] = 0.f;
+            (&sD[0][0])[e] = 0.f;
+        }
+        // the chunk's entries, one bulk copy into LDS (the reduction buffer is free here): everything below
+        // reads them from there — loads from the log issued entry by entry cost a memory round trip each
+        uint32_t* const sE = reinterpret_cast<uint32_t*>(sRed);
+        {
+            const uint32_t* src = entries + (size_t)k0 * kSoloEntryWords;
+            const uint32_t tot = J * kSoloEntryWords;
+            for (uint32_t e0 = 0; e0 < tot; e0 += 8 * kVfThreads) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const uint32_t e = e0 + (uint32_t)u * kVfThreads + tid; v[u] = e < tot ? src[e] : 0u; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const uint32_t e = e0 + (uint32_t)u * kVfThreads + tid; if (e < tot) sE[e] = v[u]; }
+            }
+        }
+        if (tid == 0) s_U = 0u;
+        __syncthreads();
+        if (tid < J * 8u) s_hdr[tid >> 3][tid & 7u] = sE[(tid >> 3) * kSoloEntryWords + (tid & 7u)];
+        for (uint32_t pr = tid; pr < J * kSoloListPitch; pr += kVfThreads) {
+            const uint32_t k = pr / kSoloListPitch, j = pr - k * kSoloListPitch;
+            const uint32_t* e = sE + k * kSoloEntryWords;
+            if (j < e[0]) atomicOr(&s_pres[e[8 + kSoloListPitch + j] & (kSoloWidth - 1u)], 1u << k);
+        }
+        __syncthreads();
+        {
+            const bool part = s_pres[tid] != 0u;
+            const uint32_t mycol = s_sub[tid];
+            uint32_t r = 0;
+            if (part) {
+#pragma unroll 16
+                for (uint32_t u = 0; u < kSoloWidth; ++u) r += (s_pres[u] != 0u && s_sub[u] < mycol) ? 1u : 0u;
+            }
+            s_rank[tid] = part ? r : 0xffffffffu;
+            if (part) {
+                atomicAdd(&s_U, 1u);
+                if (r < kVfUnion) s_urow[r] = s_row[tid] < nrows ? s_row[tid] : 0u;   // (a support column always has its Gram row)
+            }
+        }
+        __syncthreads();
+        const uint32_t U = s_U < kVfUnion ? s_U : kVfUnion;      // (U <= 96 + 32 by construction)
+        for (uint32_t pr = tid; pr < J * kSoloListPitch; pr += kVfThreads) {
+            const uint32_t k = pr / kSoloListPitch, j = pr - k * kSoloListPitch;
+            const uint32_t* e = sE + k * kSoloEntryWords;
+            if (j < e[0]) {
+                const uint32_t r = s_rank[e[8 + kSoloListPitch + j] & (kSoloWidth - 1u)];
+                if (r < kVfUnion) {
+                    sX[r][k] = __uint_as_float(e[8 + 2 * kSoloListPitch + j]);
+                    sD[r][k] = __uint_as_float(e[8 + 3 * kSoloListPitch + j]);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- one pass over the union's Gram rows: 2 x 32 sums per column, sorted-support order -------
+        float ax[kSoloChunk], ad[kSoloChunk];
+#pragma unroll
+        for (int k = 0; k < (int)kSoloChunk; ++k) { ax[k] = 0.f; ad[k] = 0.f; }
+        const size_t ci = valid ? i : 0u;
+        for (uint32_t r0 = 0; r0 < U; r0 += 4) {
+            float gv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t r = r0 + (uint32_t)t < U ? r0 + (uint32_t)t : r0;
+                gv[t] = gcache[(size_t)s_urow[r] * gpitch + ci];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (r0 + (uint32_t)t >= U) break;
+                const float g = gv[t];
+                const float* xr = sX[r0 + t];
+                const float* dr = sD[r0 + t];
+#pragma unroll
+                for (int k = 0; k < (int)kSoloChunk; ++k) {
+                    ax[k] += xr[k] * g;
+                    ad[k] += dr[k] * g;
+                }
+            }
+        }
+
+        // ---- max |c| per breakpoint ---------------------------------------------------------------------
+        uint32_t* red32 = reinterpret_cast<uint32_t*>(sRed);
+#pragma unroll
+        for (int k = 0; k < (int)kSoloChunk; ++k) {
+            const float cv = c0v - ax[k];
+            const float a = cv < 0.f ? -cv : cv;
+            red32[k * kVfRedPitch + tid] = (valid && (uint32_t)k < J) ? (__float_as_uint(a) & 0x7fffffffu) : 0u;
+        }
+        __syncthreads();
+        {
+            const uint32_t k = tid >> 3, sub = tid & 7u;
+            uint32_t m = 0u;
+            for (uint32_t j = 0; j < kVfThreads / 8; ++j) {
+                const uint32_t v = red32[k * kVfRedPitch + j * 8u + sub];
+                m = v > m ? v : m;                      // (|c| >= 0: the bit patterns order like the values; NaN wins)
+            }
+            m = max(m, (uint32_t)__shfl_xor((int)m, 1));
+            m = max(m, (uint32_t)__shfl_xor((int)m, 2));
+            m = max(m, (uint32_t)__shfl_xor((int)m, 4));
+            if (sub == 0 && k < J) v_max[(size_t)(k0 + k) * nvwg + wg] = m;
+        }
+        __syncthreads();
+
+        // ---- step-length candidates per breakpoint (find_max_gamma's off-support part, :137-159) --------
+        const uint32_t pres = mypos != 0xffffffffu ? s_pres[mypos] : 0u;
+        float m_last = Lim<float>::max();
+        bool act_last = false;
+#pragma unroll
+        for (int k = 0; k < (int)kSoloChunk; ++k) {
+            uint64_t pk = ~0ull;
+            if (valid && (uint32_t)k < J && (s_hdr[k][1] & 1u)) {
+                const bool act = (pres >> k) & 1u;
+                float m = Lim<float>::max();
+                if (!act) {
+                    const float c_inf = __uint_as_float(s_hdr[k][4]);
+                    const float ci2 = c0v - ax[k], qi = ad[k];
+                    const float dl = 1.f - qi, dr = 1.f + qi;
+                    if (dl != 0.f) {
+                        float t = (c_inf - ci2) / dl;
+                        if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
+                        if (t > 0.f && t < m) m = t;
+                    }
+                    if (dr != 0.f) {
+                        float t = (c_inf + ci2) / dr;
+                        if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
+                        if (t > 0.f && t < m) m = t;
+                    }
+                }
+                if (m < Lim<float>::max()) pk = ((uint64_t)__float_as_uint(m) << 32) | i;
+                if (k0 + (uint32_t)k == last_scan) { m_last = m; act_last = act; }
+            }
+            sRed[k * kVfRedPitch + tid] = pk;
+        }
+        __syncthreads();
+        {
+            const uint32_t k = tid >> 3, sub = tid & 7u;
+            uint64_t m = ~0ull;
+            for (uint32_t j = 0; j < kVfThreads / 8; ++j) {
+                const uint64_t v = sRed[k * kVfRedPitch + j * 8u + sub];
+                m = v < m ? v : m;                      // positive floats order like their bits; ties -> left-most column
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)m, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(m >> 32), o);
+                const uint64_t v = ((uint64_t)hi << 32) | lo;
+                m = v < m ? v : m;
+            }
+            if (sub == 0 && k < J) v_min[(size_t)(k0 + k) * nvwg + wg] = m;
+        }
+        // ---- what the next steps rank by (from the last scan of the log) ----------------------------------
+        if (last_scan >= k0 && last_scan < k0 + J) {
+            __syncthreads();
+            // (full-G mode: every column is "cached" and k_la_top never runs; tcand then only ranks subsets)
+            if (valid) tcand[i] = (act_last || (cached && !full_g)) ? Lim<float>::max() : m_last;
+            // next subset: cached columns come in through their slots (cache mode), the support through its lists
+            const bool offer = valid && !act_last && (full_g || !cached) && m_last < Lim<float>::max();
+            block_top2(offer ? m_last : Lim<float>::max(), offer ? i : 0xffffffffu, cand_top + 2 * (size_t)wg, sv, si);
+        }
+    }
+}
+
+// Compares the log with the truth, then commits or withholds what the solo launch staged; always counts
+// the launch group for the host pump.
+//   every entry verified   the staged state becomes the state of the solve (exactly what k_la_persist's own
+//                          hand-over writes) and its outcome is released to the host flags;
+//   entry k* failed        nothing is committed.  With g > 0 verified iterations before it the next solo
+//                          launch repeats exactly those (same subset, same arithmetic: same state) and
+//                          hands over to the resident form; with g = 0 the resident form goes on at once.
+struct CommitArgs {
+    const uint32_t* stage;
+    float* x; float* d; uint8_t* insup; uint32_t* gam2; float* inv0; float* inv1; uint32_t kcap; LaSync* sy;
+};
+
+__global__ __launch_bounds__(kVfThreads)
+void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_t* __restrict__ v_max,
+                   const uint64_t* __restrict__ v_min, uint32_t nvwg, uint32_t* hflags, CommitArgs ca)
+{
+    __shared__ uint32_t s_first, s_good, s_scan;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t pending = st->solo_pending;
+    if (!pending) {
+        if (tid == 0) bump_seq(st, hflags);
+        return;
+    }
+    const uint32_t nlog = st->solo_nlog;
+    if (tid == 0) { s_first = nlog; s_good = 0u; s_scan = 0u; }
+    __syncthreads();
+    // four threads per entry
+    const uint32_t k = tid >> 2, sub = tid & 3u;
+    const bool has_scan = k < nlog && (log[kSoloHeaderWords + (size_t)k * kSoloEntryWords + 1] & 1u);
+    if (pending == 1u && k < nlog) {
+        uint32_t mx = 0u;
+        uint64_t mn = ~0ull;
+        const uint32_t* pm = v_max + (size_t)k * nvwg;
+        const uint64_t* pn = v_min + (size_t)k * nvwg;
+        // this thread's quarter of the partials, sixteen independent loads at a time
+        const uint32_t per = (nvwg + 3u) / 4u;
+        const uint32_t b_lo = sub * per, b_hi = (b_lo + per < nvwg) ? b_lo + per : nvwg;
+        for (uint32_t b0 = b_lo; b0 < b_hi; b0 += 16) {
+            uint32_t a[16];
+            uint64_t c[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const uint32_t b = b0 + (uint32_t)t;
+                a[t] = b < b_hi ? pm[b] : 0u;
+                c[t] = b < b_hi ? pn[b] : ~0ull;
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { mx = a[t] > mx ? a[t] : mx; mn = c[t] < mn ? c[t] : mn; }
+        }
+#pragma unroll
+        for (int o = 1; o < 4; o <<= 1) {
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mn, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mn >> 32), o);
+            const uint64_t v = ((uint64_t)hi << 32) | lo;
+            mn = v < mn ? v : mn;
+        }
+        if (sub == 0) {
+            const uint32_t* e = log + kSoloHeaderWords + (size_t)k * kSoloEntryWords;
+            bool ok = (e[4] & 0x7fffffffu) == mx;                    // lambda = ||c||_inf over all columns
+            if (e[1] & 1u) {
+                // off-support minimum over all columns, merged with the support's own candidate (logged)
+                float g = Lim<float>::max();
+                uint32_t idx = 0xffffffffu;
+                if (mn != ~0ull) { g = __uint_as_float((uint32_t)(mn >> 32)); idx = (uint32_t)mn; }
+                const float gs = __uint_as_float(e[6]);
+                const uint32_t is = e[7];
+                if (is != 0xffffffffu && better_min(gs, is, g, idx)) { g = gs; idx = is; }
+                ok = ok && __float_as_uint(g) == e[5] && idx == e[3];
+            }
+            if (!ok) atomicMin(&s_first, k);
+        }
+    }
+    __syncthreads();
+    const uint32_t first_bad = s_first;
+    if (sub == 0 && has_scan) {
+        atomicOr(&s_scan, 1u);
+        if (k < first_bad) atomicAdd(&s_good, 1u);
+    }
+    __syncthreads();
+    if (pending == 1u && first_bad < nlog) {
+        // a column outside the subset would have changed lambda or the pick at entry first_bad
+        if (tid == 0) {
+            st->solo_fails += 1u;
+            if (s_good == 0u) {
+                st->solo_off = 1;
+                __hip_atomic_store(&hflags[4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                st->solo_replay = s_good;
+            }
+            st->solo_pending = 0;
+            bump_seq(st, hflags);
+        }
+        return;
+    }
+
+    // ---- commit: the staged hand-over becomes the state (cf. the end of k_la_persist) -----------------
+    const uint32_t* sg = ca.stage;
+    constexpr uint32_t LP = kSoloListPitch;
+    const uint32_t code = sg[9];
+    const uint32_t K = sg[0];
+    const bool save = sg[1] != 0u;
+    if (code != 7u) {
+        const uint32_t kcap = ca.kcap;
+        const uint32_t cur = st->cur;
+        float* const Ig = cur ? ca.inv1 : ca.inv0;
+        uint32_t* const gam_cur = ca.gam2 + (size_t)cur * kcap;
+        uint32_t* const gam_alt = ca.gam2 + (size_t)(cur ^ 1u) * kcap;
+        const uint32_t K0 = st->K;
+        // the old support leaves the dense vectors and the membership flags ...
+        for (uint32_t j = tid; j < K0; j += kVfThreads) {
+            const uint32_t cl = gam_cur[j];
+            ca.x[cl] = 0.f; ca.d[cl] = 0.f; ca.insup[cl] = 0;
+        }
+        __syncthreads();
+        // ... the new one enters
+        for (uint32_t e = tid; e < K * K; e += kVfThreads) {
+            const uint32_t a = e / K, b = e - a * K;
+            Ig[(size_t)a * kcap + b] = __uint_as_float(sg[kSoloStageHead + 4 * LP + 1 + e]);
+        }
+        for (uint32_t j = tid; j < K; j += kVfThreads) {
+            const uint32_t cl = sg[kSoloStageHead + j];
+            gam_cur[j] = cl;
+            ca.x[cl] = __uint_as_float(sg[kSoloStageHead + LP + j]);
+            ca.d[cl] = __uint_as_float(sg[kSoloStageHead + 2 * LP + j]);
+            ca.insup[cl] = 1;
+        }
+        if (save)
+            for (uint32_t j = tid; j < K + 1u; j += kVfThreads) gam_alt[j] = sg[kSoloStageHead + 3 * LP + j];
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    if (code != 7u) {
+        if (save) ca.insup[sg[5]] = 1;                 // the entering column whose inverse update is pending
+        ca.sy->tick = sg[8];
+        st->K = save ? K + 1u : K;
+        st->iter = sg[2];
+        st->c_inf = (double)__uint_as_float(sg[3]);
+        st->gamma = (double)__uint_as_float(sg[4]);
+        st->idx = sg[5];
+        st->rank = sg[6];
+        st->added = sg[7];
+    }
+    bool off = pending == 2u;                          // after a replay the resident form goes on
+    if (code == 1u) {
+        st->done_round = sg[10];
+        st->need_sweep = 0;
+        st->done = 1;
+        signal_done(hflags, nullptr, 1u, sg[10]);
+    } else if (code == 2u) {
+        st->need_sweep = 1;
+        const uint32_t nm = st->nmiss + 1u;
+        st->nmiss = nm;
+        __hip_atomic_store(&hflags[2], nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (code == 3u || code == 7u) {
+        __hip_atomic_store(&hflags[3], K + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        off = true;
+    } else if (code == 6u) {
+        off = true;
+    }
+    if (off) {
+        st->solo_off = 1;
+        __hip_atomic_store(&hflags[4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    st->solo_replay = 0;
+    if (pending == 1u && s_scan) st->cand_scan = 1;
+    st->solo_pending = 0;
+    bump_seq(st, hflags);
+}
+
+hipError_t launch_la_cand_init_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
+{
+    if (ws.cand_top == nullptr || ws.nvwg == 0) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_la_cand_init, dim3(ws.nvwg), dim3(kVfThreads), 0, ctx->stream, (const float*)ws.c0, (uint32_t)ctx->n,
+                       (const DevState*)ws.st, ws.cand_top);
+    return hipGetLastError();
+}
+
+// k_la_verify + k_la_vpublish behind a solo launch
+hipError_t launch_la_verify_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
+{
+    if (ws.solo_log == nullptr || ws.v_max == nullptr || ws.nvwg == 0) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_la_verify, dim3(ws.nvwg), dim3(kVfThreads), 0, ctx->stream, (uint32_t)ctx->n, ws.gram_is_full ? 1 : 0,
+                       (const float*)ws.gcache, ws.gpitch, (const int32_t*)ws.slot_of, (const float*)ws.c0,
+                       (const uint32_t*)ws.solo_log, (const uint8_t*)ws.sub_pos, (const DevState*)ws.st, ws.v_max, ws.v_min,
+                       ws.nvwg, ws.tcand, ws.cand_top, ctx->tie_guard, ws.gram_is_full ? ctx->n_pad : ws.gcap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    CommitArgs ca;
+    ca.stage = ws.solo_stage;
+    ca.x = ws.x; ca.d = ws.d; ca.insup = ws.insup; ca.gam2 = ws.gam; ca.inv0 = ws.inv[0]; ca.inv1 = ws.inv[1];
+    ca.kcap = ws.dims.kcap; ca.sy = ws.la_sync;
+    hipLaunchKernelGGL(k_la_vpublish, dim3(1), dim3(kVfThreads), 0, ctx->stream, (const uint32_t*)ws.solo_log, ws.st,
+                       (const uint32_t*)ws.v_max, (const uint64_t*)ws.v_min, ws.nvwg, ctx->dev_flags, ca);
+    return hipGetLastError();
+}
+
+}  // namespace sship

@@ -18,6 +18,13 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int kSmallThreads = 256;
 constexpr int kUpdThreads = 1024;
 
+// order-preserving map float -> u32 (smaller float, smaller key)
+__device__ __forceinline__ uint32_t ordered_key(float v)
+{
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
 // ---- block reductions --------------------------------------------------------------
 
 // "better" for the arg-max of |c| (ixamax): larger value, ties -> smaller index

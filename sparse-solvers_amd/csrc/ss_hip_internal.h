@@ -56,7 +56,18 @@ struct DevState {
     uint32_t seq;         // k_la_iter launches executed so far (mirrored to hflags[0])
     uint32_t nmiss;       // iterations that had to wait for a lookahead sweep (mirrored to hflags[2])
     uint32_t bar_rounds;  // k_la_iter launches that went through the grid barrier (bar_count = this * grid)
-    uint32_t pad0_[12];
+    // speculative ("solo") form of the resident kernel: one workgroup iterates on a column subset, its
+    // breakpoints are checked against all columns afterwards (solo.hip); the outcome of a solo launch is
+    // staged here and reaches the host flags only once it is verified
+    uint32_t solo_off;     // 1: the rest of this solve runs in the resident form (k_la_persist / k_la_iter)
+    uint32_t solo_pending; // 1: a solo launch has run and awaits k_la_verify + k_la_vpublish; 2: a replay (already verified) awaits its commit
+    uint32_t pub_kind;     // staged outcome: 0 none, 1 solve finished, 2 Gram column missing, 3 support outgrew the LDS tier
+    uint32_t pub_arg;      // done_round / miss count / K + 1
+    uint32_t solo_nlog;    // breakpoints the solo launch logged
+    uint32_t cand_scan;    // 1 once tcand / cand_top carry the candidates of a verified scan (before: |c0| ranks)
+    uint32_t solo_replay;  // > 0: the last solo launch failed its check after this many good iterations; the next one repeats exactly those
+    uint32_t solo_fails;   // solo launches of this solve that failed a check
+    uint32_t pad0_[4];
     // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
     uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
     uint32_t pad1_[31];
@@ -87,6 +98,25 @@ constexpr uint64_t kLaSlotNone = 0x7f7fffffffffffffull;       // posted: no step
 constexpr size_t kLaSyncBytes = 128 + 4 * 512 * 8;
 constexpr uint32_t kLaLdsSmall = 96;      // support sizes the resident kernel holds in LDS: first tier ...
 constexpr uint32_t kLaLdsLarge = 192;     // ... and the one that takes a whole CU's LDS
+// Breakpoint log of a solo launch: a header of 2 * kSoloWidth words — the subset's columns (0xffffffff =
+// unused position) and their Gram rows (cache slot; the column itself in full-G mode) — then the entries,
+// 8 words + four lists of kSoloListPitch words each:
+//   [0] K  [1] flags (bit 0: the entry carries a step-length scan)  [2] round  [3] idx picked
+//   [4] bits(lambda)  [5] bits(gamma)  [6] bits(best candidate on the support)  [7] its column
+//   gam[], subset position[], bits(x_S)[], bits(d_S)[] in sorted-support order
+constexpr uint32_t kSoloLogCap = 64;                          // entries per launch
+constexpr uint32_t kSoloListPitch = kLaLdsSmall;              // solo launches run in the first LDS tier only
+constexpr uint32_t kSoloEntryWords = 8 + 4 * kSoloListPitch;
+constexpr uint32_t kSoloHeaderWords = 512;
+// What a solo launch leaves behind is STAGED: the state of the solve (DevState, lists, inverse, x, d,
+// membership flags) is only touched by k_la_vpublish, after the log has been verified.  Staging area (words):
+//   [0] K  [1] 1 = pick made, inverse update pending (Gram column missing)  [2] iter  [3] bits(lambda)
+//   [4] bits(gamma)  [5] idx  [6] rank  [7] added  [8] tick  [9] exit code  [10] done_round
+//   then gam[P], bits(x_S)[P], bits(d_S)[P], gam_new[P + 1] (with [1]), inverse [K][K]
+constexpr uint32_t kSoloStageHead = 16;
+constexpr uint32_t kSoloStageWords = kSoloStageHead + 4 * kSoloListPitch + 1 + kSoloListPitch * kSoloListPitch;
+constexpr uint32_t kSoloChunk = 32;                           // breakpoints verified per pass over the Gram rows
+constexpr uint32_t kSoloWidth = 256;                          // columns of a solo launch / of a verify workgroup
 
 // optional per-iteration record of the homotopy path (ss_hip_get_trace)
 struct TraceEntry {
@@ -154,6 +184,15 @@ struct Workspace {
     uint32_t gpitch_own = 0;
     int32_t* slot_of_own = nullptr;
     int32_t* slot_identity = nullptr;   // [n_pad] 0, 1, 2, ...
+    // speculative form (solo.hip)
+    uint32_t* slot_col = nullptr; // [gcap] column held by each cache slot
+    uint32_t* solo_log = nullptr; // [kSoloHeaderWords] + [kSoloLogCap][kSoloEntryWords]
+    uint8_t* sub_pos = nullptr;   // [n_pad] subset position of a column in the last solo launch (valid iff the header agrees)
+    uint32_t* solo_stage = nullptr; // [kSoloStageWords] staged hand-over of a solo launch
+    uint32_t* v_max = nullptr;    // [kSoloLogCap][nvwg] per-workgroup max |c| (bits) of every logged breakpoint
+    uint64_t* v_min = nullptr;    // [kSoloLogCap][nvwg] per-workgroup best step-length candidate (bits << 32 | column)
+    uint64_t* cand_top = nullptr; // [nvwg][2] per-workgroup best entrant candidates (ordered key << 32 | column)
+    uint32_t nvwg = 0;            // workgroups of k_la_verify = ceil(n / kSoloWidth)
     uint64_t* la_dbg = nullptr;   // [1024][8] stage timestamps of k_la_iter (option "la_debug"), else null
     uint32_t la_nparts = 0;       // partial maxima written by the last k_la_cq launch
     uint32_t* tile_skip = nullptr; // [b_pad/128 + 1] compact list of GEMM row tiles with a running signal + count
@@ -201,7 +240,9 @@ struct ss_hip_ctx {
     long cache_mib = 2048;   // budget of the lookahead engine's Gram-column cache
     int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns) unless the tolerance is too tight for it, 2 = lookahead always, 0 = one fused sweep per iteration
     int sweep32_variant = 0; // lookahead sweep tiling: 0 = 256 columns x 512 threads (1 per CU), 1 / 2 = 128 columns x 256 threads (2 / 3 per CU)
-    int la_fused = 2;        // lookahead engine: 2 = resident kernel (k_la_persist), 1 = one kernel per iteration (k_la_iter), 0 = scan / update / cq kernels
+    int la_fused = 2;        // lookahead engine: 2 = resident kernel (k_la_persist), 3 = its speculative form (one workgroup + verification, solo.hip: correct but measured slower), 1 = one kernel per iteration (k_la_iter), 0 = scan / update / cq kernels
+    int solo_subset = 256;   // option (tests): columns a solo launch may hold (<= 256; small values provoke verification failures)
+    int solo_off_solves = 0; // solves left for which the speculative form stays off after repeated verification failures
     int batch_min = 192;     // batches of at least this many fp32 signals run in lock-step on the MFMA GEMM (below: one lookahead solve per signal, ~2.4 ms each at C2, is faster)
     int batch_chunk = 4096;  // signals processed together by the batched path
     int tracing = 0;
@@ -217,6 +258,7 @@ struct ss_hip_ctx {
     std::vector<hipEvent_t> prof_events;   // pairs (start, stop) for sweeps of the current solve
     std::vector<int> prof_kind;            // 2 = fused sweep, 1 = single-RHS sweep
     hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;
+    int solo_attr_set = -1;                // dynamic-LDS attribute of the solo kernel: -1 not tried, 0 refused, 1 set
     int persist_workers[2] = { -1, -1 };   // worker workgroups of k_la_persist per LDS tier (-1 = not queried, 0 = unusable)
 
     ss_hip_stats stats{};
@@ -282,6 +324,13 @@ hipError_t launch_la_omp_update(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol);
 // missing or the support outgrows `lds_cols`; returns hipErrorInvalidConfiguration if the device
 // cannot keep the whole grid resident for this n
 hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, uint32_t lds_cols);
+// speculative form: k_la_persist<solo> (one workgroup on a column subset), then k_la_verify and
+// k_la_vpublish (solo.hip), which check the logged breakpoints against all columns and release or
+// revoke the outcome; launch_la_cand_init seeds the subset ranking from |c0|
+hipError_t launch_la_solo_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter);
+hipError_t launch_la_verify_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
+hipError_t launch_la_cand_init_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
+bool la_solo_usable(ss_hip_ctx* ctx);
 // true if k_la_persist can serve this context (column count vs resident workgroups)
 bool la_persist_usable(ss_hip_ctx* ctx, uint32_t lds_cols);
 // per-slot partial (max |c|, first index) over chunks of the correlation rows (batched path)

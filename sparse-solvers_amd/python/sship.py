@@ -53,6 +53,8 @@ class Stats(ctypes.Structure):
         ("gram_fallbacks", ctypes.c_uint64),
         ("persist_fallbacks", ctypes.c_uint64),
         ("gram_full_builds", ctypes.c_uint64),
+        ("solo_solves", ctypes.c_uint64),
+        ("solo_retries", ctypes.c_uint64),
     ]
 
 

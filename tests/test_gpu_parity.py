@@ -586,7 +586,8 @@ def test_ragged_shapes_vs_oracle(sship, shape, dtype):
 # ---------------------------------------------------------------- the fp32 single-signal engines
 
 ENGINES = {"sweep": {"engine": 0}, "lookahead": {"engine": 1, "la_fused": 0},
-           "lookahead-fused": {"engine": 1, "la_fused": 1}, "lookahead-resident": {"engine": 1, "la_fused": 2}}
+           "lookahead-fused": {"engine": 1, "la_fused": 1}, "lookahead-resident": {"engine": 1, "la_fused": 2},
+           "lookahead-speculative": {"engine": 1, "la_fused": 3}}
 
 
 @pytest.mark.gpu
@@ -679,6 +680,61 @@ def test_resident_kernel_matches_launch_per_iteration(sship, shape):
     assert np.array_equal(x1, x2) and e1 == e2
     if it2 == k:       # recovered along a removal-free path
         assert np.array_equal(significant_support(x2, 1e-4), sup)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(96, 700, 8), (512, 4096, 40), (1024, 9000, 120), (1500, 6000, 230), (2048, 70000, 60)])
+def test_speculative_form_matches_resident(sship, shape):
+    """la_fused = 3: one workgroup iterates on a 256-column subset and k_la_verify re-derives every
+    breakpoint over all columns.  Same arithmetic in the same order as the resident kernel: identical
+    breakpoints, step lengths and coefficients, bit for bit — also when the support outgrows the solo
+    tier (96 columns) and the resident forms take over mid-solve"""
+    m, n, k = shape
+    A, y, x0, sup = make_gaussian_problem(5000 + m, m, n, k, np.float32)
+    res = {}
+    with sship.Homotopy(A) as h:
+        h.set_option("trace", 1)
+        for mode in (2, 3):
+            h.set_option("la_fused", mode)
+            h.reset_stats()
+            xg, itg, eg = h.solve(y, 1e-3, 2 * k + 8)
+            res[mode] = (xg.copy(), itg, eg, h.trace(), h.stats())
+    (x2, it2, e2, t2, s2), (x3, it3, e3, t3, s3) = res[2], res[3]
+    assert s2["solo_solves"] == 0 and s3["solo_solves"] == 1
+    assert it2 == it3 and it3 >= k
+    assert np.array_equal(t2["idx"], t3["idx"]) and np.array_equal(t2["added"], t3["added"])
+    assert np.array_equal(t2["gamma"], t3["gamma"]) and np.array_equal(t2["c_inf"], t3["c_inf"])
+    assert np.array_equal(x2, x3) and e2 == e3
+    if k <= 60:
+        assert s3["solo_retries"] == 0        # the candidates of a well-posed problem sit in the subset
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subset", [0, 2, 5, 12])
+def test_speculative_form_failed_verification(sship, subset):
+    """with few or no entrant candidates in the subset a solo launch sooner or later picks a column that
+    is not the true minimiser: the verification must catch it, nothing of that launch may reach the state
+    (the verified iterations are repeated, the resident form goes on) and the solve must come back
+    identical to the resident form's"""
+    m, n, k = 512, 4096, 24
+    A, y, x0, sup = make_gaussian_problem(777, m, n, k, np.float32)
+    with sship.Homotopy(A) as h:
+        h.set_option("trace", 1)
+        h.set_option("la_fused", 2)
+        x2, it2, e2 = h.solve(y, 1e-3, 4 * k)
+        t2 = h.trace()
+        h.set_option("la_fused", 3)
+        h.set_option("solo_subset", subset)
+        h.reset_stats()
+        x3, it3, e3 = h.solve(y, 1e-3, 4 * k)
+        t3 = h.trace()
+        s3 = h.stats()
+    assert s3["solo_solves"] == 1 and s3["solves"] == 1
+    if 0 < subset <= 5:
+        assert s3["solo_retries"] >= 1
+    assert it2 == it3 and np.array_equal(x2, x3) and e2 == e3
+    assert np.array_equal(t2["idx"], t3["idx"]) and np.array_equal(t2["gamma"], t3["gamma"])
+    assert np.array_equal(significant_support(x3, 1e-4), sup)
 
 
 @pytest.mark.gpu
@@ -794,7 +850,7 @@ def test_batch_gram_form_vs_oracle(sship, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("la_fused", [2, 1])
+@pytest.mark.parametrize("la_fused", [3, 2, 1])
 def test_full_gram_single_signal(sship, la_fused):
     """option gram_full_after = 1: G = A^T A is formed at the first solve and serves as the Gram-column
     cache — no lookahead sweep; Homotopy (resident kernel / one launch per iteration) and OMP vs the oracle"""

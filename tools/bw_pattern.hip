@@ -169,6 +169,66 @@ void k_g32(const float* __restrict__ At, float* __restrict__ out, uint32_t K, ui
     if (t == 12345.678f) out[tid] = t;
 }
 
+
+// variant: wave = (column group of 64, k half): 2 accumulators per wave, R operand read half as often
+template <int DEPTH>
+__global__ __launch_bounds__(512, 1)
+void k_g32w(const float* __restrict__ At, float* __restrict__ out, uint32_t K, uint32_t ldq, uint32_t ntiles)
+{
+    constexpr int HN = 256, LD = 36, RPP = 64, NJ = 4, KS = 32;
+    __shared__ __attribute__((aligned(16))) float sR[2][32][LD];
+    __shared__ __attribute__((aligned(16))) float sQ[2][HN][LD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t h = lane >> 5, l31 = lane & 31u;
+    const uint32_t cg = wave & 3u, kh = wave >> 2;
+    const uint32_t srow = tid >> 3, squad = tid & 7u;
+    const bool has_r = tid < 256;
+    const float* gR = At + (size_t)((srow & 31u) * 1000u) * ldq + squad * 4;
+    const uint32_t nk = K / KS;
+    v16f acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    for (uint32_t bn = blockIdx.x; bn < ntiles; bn += gridDim.x) {
+        const float* gQ = At + (size_t)(bn * HN + srow) * ldq + squad * 4;
+        v4f rR[DEPTH], rQ[DEPTH][NJ];
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) LOADS(s, (uint32_t)s)
+        __syncthreads();
+        STORES(0, 0)
+        if ((uint32_t)DEPTH < nk) LOADS(0, (uint32_t)DEPTH)
+        __syncthreads();
+        for (uint32_t kt = 0; kt < nk; kt += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                const uint32_t k = kt + u;
+                const int buf = u & 1;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const uint32_t kq = (2u * (2u * kh + g2) + h) * 4u;
+                    const v4f a = *reinterpret_cast<const v4f*>(&sR[buf][l31][kq]);
+                    const v4f b0 = *reinterpret_cast<const v4f*>(&sQ[buf][cg * 64 + l31][kq]);
+                    const v4f b1 = *reinterpret_cast<const v4f*>(&sQ[buf][cg * 64 + 32 + l31][kq]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b0[t], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b1[t], acc1, 0, 0, 0);
+                    }
+                }
+                if (k + 1 < nk) {
+                    const int set = (u + 1) % DEPTH;
+                    STORES(set, buf ^ 1)
+                    if (k + 1 + DEPTH < nk) LOADS(set, k + 1 + DEPTH)
+                }
+                __syncthreads();
+            }
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) t += acc0[e] + acc1[e];
+    if (t == 12345.678f) out[tid] = t;
+}
+
 __global__ void k_fill(float* A, size_t nel, int mode)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nel; i += (size_t)gridDim.x * blockDim.x) {
@@ -238,6 +298,13 @@ int main()
         float ms = time_it([&] { hipLaunchKernelGGL((k_g32<DEPTH, RT, MF>), dim3(cus), dim3(512), 0, 0, A, out, m, m, n / 256); }, reps); \
         printf("  %.0f GB/s\n", bytes / ms / 1e6);                                                      \
     }
+    { printf("g32w   DEPTH=4 (64 cols x k-half per wave):");
+      float ms = time_it([&] { hipLaunchKernelGGL((k_g32w<4>), dim3(cus), dim3(512), 0, 0, A, out, m, m, n / 256); }, reps);
+      printf("  %.0f GB/s\n", bytes / ms / 1e6); }
+    RUN_G32(4, true, 2)
+    { printf("g32w   DEPTH=4 (64 cols x k-half per wave):");
+      float ms = time_it([&] { hipLaunchKernelGGL((k_g32w<4>), dim3(cus), dim3(512), 0, 0, A, out, m, m, n / 256); }, reps);
+      printf("  %.0f GB/s\n", bytes / ms / 1e6); }
     RUN_G32(4, false, 0)
     RUN_G32(4, false, 1)
     RUN_G32(4, true, 1)
