@@ -97,6 +97,8 @@ def main():
                     help="signals of the extra configs[2]-style lock-step batch run reported under "
                          "'batched' (outside the timed region; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the OMP and fp64 (configs[4]) extras reported under 'extras' (single-GPU runs only)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     args = ap.parse_args()
 
@@ -189,6 +191,24 @@ def main():
     gather_ok = all(np.array_equal(ix, np.nonzero(Xh[s])[0]) for s, (ix, _) in enumerate(mine))
 
     st = h.stats()
+
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+        # OMP on the same matrix and signals (north_star names it; no reference implementation exists: unpinned)
+        XO = torch.zeros((args.steps, N), device=dev, dtype=torch.float32)
+        h.solve_omp(sigs[0][0], TOL, K_SPARSE, out=XO[0])
+        torch.cuda.synchronize()
+        to = time.perf_counter()
+        for s_ in range(args.steps):
+            h.solve_omp(sigs[args.warmup + s_][0], TOL, K_SPARSE, out=XO[s_])
+        torch.cuda.synchronize()
+        dto = time.perf_counter() - to
+        XOh = XO.cpu().numpy()
+        oko = sum(int(np.array_equal(np.nonzero(XOh[s_])[0], sigs[args.warmup + s_][1])) for s_ in range(args.steps))
+        del XO
+        extras["omp"] = {"workload": "OMP (ss::omp<float>), the same A and signals, %d picks" % K_SPARSE,
+                         "ms_per_solve": dto / args.steps * 1e3, "support_exact": oko, "signals": args.steps}
 
     # configs[2]-style extra (NOT part of `value`): a batch of signals sharing A, solved in
     # lock-step with the correlations on the MFMA units
@@ -327,6 +347,45 @@ def main():
         out["cpu_baseline"] = base
         out["parity_vs_oracle"] = parity
     h.close()
+    if extras is not None:
+        # configs[4]: fp64, A 16384 x 131072 (16 GiB), k = 128, tol 1e-9 — Homotopy (the reference has no OMP)
+        del A
+        torch.cuda.empty_cache()
+        m5, n5, k5 = 16384, 131072, 128
+        g5 = torch.Generator(device=dev).manual_seed(4321)
+        A5 = torch.randn((m5, n5), generator=g5, device=dev, dtype=torch.float64)
+        A5 /= np.sqrt(m5)
+        rng5 = np.random.default_rng(4322)
+        sup5 = np.sort(rng5.choice(n5, k5, replace=False))
+        coef5 = 1.0 + np.abs(rng5.standard_normal(k5))
+        y5 = (A5[:, torch.from_numpy(sup5).to(dev)] @ torch.from_numpy(coef5).to(dev)).contiguous()
+        h5 = sship.Homotopy(A5, device=local_rank)
+        del A5
+        torch.cuda.empty_cache()
+        x5 = torch.zeros(n5, device=dev, dtype=torch.float64)
+        h5.solve(y5, 1e-9, 512, out=x5)
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        for _ in range(3):
+            _, it5, _ = h5.solve(y5, 1e-9, 512, out=x5)
+        torch.cuda.synchronize()
+        dt5 = (time.perf_counter() - t5) / 3
+        x5h = x5.cpu().numpy()
+        ok5 = bool(np.array_equal(np.nonzero(x5h)[0], sup5))
+        err5 = float(np.abs(x5h[sup5] - coef5).max() / coef5.max())
+        st5 = h5.stats()
+        _, ms32 = h5.gram_cols(np.arange(0, 32000, 1000, dtype=np.uint32), 5)
+        _, ms1 = h5.gemv_t(y5, 3)
+        b32 = m5 * n5 * 8 + 32 * m5 * 8 + 32 * n5 * 8
+        b1 = m5 * n5 * 8 + m5 * 8 + n5 * 8
+        extras["fp64_configs4"] = {
+            "workload": "configs[4] shape: Homotopy fp64, A 16384x131072 (16 GiB), k=128, tol 1e-9, max_iter 512",
+            "ms_per_solve": dt5 * 1e3, "iterations": int(it5), "support_exact": ok5, "max_rel_coef_err": err5,
+            "lookahead_sweeps_per_solve": st5["lookahead_sweeps"] / max(1, st5["solves"]),
+            "lookahead_sweep_f64": {"ms": ms32, "GB/s": b32 / ms32 / 1e6, "frac_of_8TBs": b32 / ms32 / 1e6 / HBM_PEAK_GBS},
+            "atr_gemv_f64": {"ms": ms1, "GB/s": b1 / ms1 / 1e6, "frac_of_8TBs": b1 / ms1 / 1e6 / HBM_PEAK_GBS}}
+        h5.close()
+        out["extras"] = extras
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -224,7 +224,13 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    correlations: such a solve runs as 0; 2 = lookahead engine unconditionally;
  *                    0 = one fused 2-RHS sweep per iteration (residual form).
  *   "la_fused"       form of the lookahead engine's iterations: 2 (default) = one resident launch
- *                    (k_la_persist, fp32; fp64 runs as 1), 1 = one launch per iteration, 0 = separate kernels
+ *                    (k_la_persist, fp32; fp64 runs as 1), 1 = one launch per iteration, 0 = separate kernels,
+ *                    3 = speculative form of the resident launch: one workgroup iterates on a 256-column
+ *                    subset, every breakpoint is re-derived over all columns before anything is committed
+ *                    (same results bit for bit; measured slower than 2, kept as an option)
+ *   "solo_subset"    columns beyond the support a speculative launch may hold (default 256; tests use small
+ *                    values to provoke failed verifications)
+ *   "sweep32_variant" tiling of the 32-RHS lookahead sweep (0 default; 1-7 measured alternatives, same results)
  *   "cache_mib"      memory budget of the lookahead engine's Gram-column cache (default 2048)
  *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 192: below
  *                    that, one lookahead solve per signal is faster)

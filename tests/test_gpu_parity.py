@@ -738,6 +738,45 @@ def test_speculative_form_failed_verification(sship, subset):
 
 
 @pytest.mark.gpu
+def test_speculative_form_random_problems(sship):
+    """noisy, poorly sparse and under-determined problems (removals, long paths, failed checks, replays,
+    hand-overs to the resident form): whatever happens inside, the speculative form must return what the
+    resident form returns, bit for bit"""
+    rng = np.random.default_rng(20261004)
+    fails = solo = 0
+    for case in range(36):
+        m = int(rng.choice([24, 40, 64, 128, 300]))
+        n = int(rng.choice([96, 200, 700, 3000, 20000]))
+        k = int(rng.integers(2, max(3, m // 3)))
+        A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(np.float32)
+        x0 = np.zeros(n, np.float32)
+        x0[rng.choice(n, k, replace=False)] = (1 + np.abs(rng.standard_normal(k))) * rng.choice([-1.0, 1.0], k)
+        y = (A @ x0 + (0.0 if case % 3 == 0 else 0.02) * rng.standard_normal(m)).astype(np.float32)
+        tol = float(rng.choice([1e-3, 1e-2, 5e-2]))
+        max_iter = int(min(3 * m, 200))
+        subset = int(rng.choice([256, 256, 40, 8]))
+        with sship.Homotopy(A) as h:
+            h.set_option("engine", 2)                   # Gram form whatever the tolerance
+            h.set_option("trace", 1)
+            h.set_option("la_fused", 2)
+            x2, it2, e2 = h.solve(y, tol, max_iter)
+            t2 = h.trace()
+            h.set_option("la_fused", 3)
+            h.set_option("solo_subset", subset)
+            h.reset_stats()
+            x3, it3, e3 = h.solve(y, tol, max_iter)
+            t3 = h.trace()
+            s3 = h.stats()
+        solo += s3["solo_solves"]
+        fails += s3["solo_retries"]
+        assert it2 == it3, (case, m, n, k, tol, subset, it2, it3)
+        assert np.array_equal(t2["idx"], t3["idx"]) and np.array_equal(t2["added"], t3["added"]), (case, m, n, k)
+        assert np.array_equal(t2["gamma"], t3["gamma"]), (case, m, n, k)
+        assert np.array_equal(x2, x3, equal_nan=True) and (e2 == e3 or (np.isnan(e2) and np.isnan(e3))), (case, m, n, k)
+    assert solo == 36 and fails >= 3            # the failure path has been walked
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_gram_cols_vs_numpy(sship, dtype):
     """the lookahead sweep G[s] = A^T a_{cols[s]} (fp32: v_mfma_f32_32x32x2, fp64: v_mfma_f64_16x16x4)"""
