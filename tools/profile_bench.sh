@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/bench_trace.log" 2>&1 || echo "trace run failed rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --batch 0 > "$OUT/bench_pmc_fetch.log" 2>&1 || echo "pmc fetch run failed rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --batch 0 > "$OUT/bench_pmc_write.log" 2>&1 || echo "pmc write run failed rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/bench_trace.log" 2>&1 || echo "trace run failed rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras --batch 0 > "$OUT/bench_pmc_fetch.log" 2>&1 || echo "pmc fetch run failed rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras --batch 0 > "$OUT/bench_pmc_write.log" 2>&1 || echo "pmc write run failed rc=$?"
 find "$OUT" -name "*.csv" | head -50
