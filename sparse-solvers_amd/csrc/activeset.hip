@@ -704,6 +704,9 @@ void k_omp_select(uint32_t round, T tol, uint32_t max_iter,
 // ---- update_direction: online_column_inverse's bordering / deflation (online_inverse.h:224-248,
 // ---- 275-290) and the new direction (homotopy-cpu.cpp:257-267), run by ONE workgroup once u1 and
 // ---- st->dot are visible.
+constexpr int kMvRows = 8, kMvSlices = 2;   // rows x 64-element slices of a matrix-vector product a wave has in flight
+constexpr int kInvBatch = 8;      // elements of the new inverse a thread has in flight (global memory: latency-bound)
+
 template <typename T>
 __device__ __forceinline__ void update_direction(uint32_t cur, uint32_t K_new, uint32_t rank, bool added,
                                                  const uint32_t* __restrict__ gam_old, const uint32_t* __restrict__ gam_new,
@@ -723,12 +726,36 @@ __device__ __forceinline__ void update_direction(uint32_t cur, uint32_t K_new, u
 
     if (added) {
         const uint32_t nn = K_old;
-        // u2 = inv * u1 (online_inverse.h:224-225), one wave per row
-        for (uint32_t i = wave; i < nn; i += NW) {
-            T acc = T(0);
-            for (uint32_t j = lane; j < nn; j += 64) acc += Iold[i * P + j] * u1[j];
-            acc = wave_sum(acc);
-            if (lane == 0) u2[i] = acc;
+        // u2 = inv * u1 (online_inverse.h:224-225), one wave per row; four rows at a time so that their
+        // loads overlap (the inverse lives in global memory here: a row at a time is one memory round
+        // trip per row — 40 us of an fp64 iteration at K = 128).  Per row the sum is formed as before.
+        for (uint32_t i0 = wave; i0 < nn; i0 += kMvRows * NW) {
+            T acc[kMvRows];
+#pragma unroll
+            for (int r = 0; r < kMvRows; ++r) acc[r] = T(0);
+            for (uint32_t j0 = lane; j0 < nn; j0 += 64 * kMvSlices) {
+                T uj[kMvSlices], v[kMvRows][kMvSlices];
+#pragma unroll
+                for (int t = 0; t < kMvSlices; ++t) { const uint32_t j = j0 + 64u * (uint32_t)t; uj[t] = j < nn ? u1[j] : T(0); }
+#pragma unroll
+                for (int r = 0; r < kMvRows; ++r)
+#pragma unroll
+                    for (int t = 0; t < kMvSlices; ++t) {
+                        const uint32_t i = i0 + (uint32_t)r * NW, j = j0 + 64u * (uint32_t)t;
+                        v[r][t] = (i < nn && j < nn) ? Iold[i * P + j] : T(0);
+                    }
+#pragma unroll
+                for (int t = 0; t < kMvSlices; ++t)
+#pragma unroll
+                    for (int r = 0; r < kMvRows; ++r)
+                        if (j0 + 64u * (uint32_t)t < nn) acc[r] += v[r][t] * uj[t];      // per row: j ascending, as before
+            }
+#pragma unroll
+            for (int r = 0; r < kMvRows; ++r) {
+                const uint32_t i = i0 + (uint32_t)r * NW;
+                const T a = wave_sum(acc[r]);
+                if (lane == 0 && i < nn) u2[i] = a;
+            }
         }
         __syncthreads();
         // d = 1 / (dot - u1.u2) (online_inverse.h:228)
@@ -750,20 +777,30 @@ __device__ __forceinline__ void update_direction(uint32_t cur, uint32_t K_new, u
         // new inverse in sorted order: [inv + d u2 u2^T, -d u2; -d u2^T, d] with the new
         // row/column at position `rank` (online_inverse.h:229-248)
         const uint32_t tot = K_new * K_new;
-        for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
-            const uint32_t a = e / K_new, b = e - a * K_new;
-            T v;
-            if (a == rank && b == rank) {
-                v = dv;
-            } else if (a == rank) {
-                v = -dv * u2[b - (b > rank ? 1u : 0u)];
-            } else if (b == rank) {
-                v = -dv * u2[a - (a > rank ? 1u : 0u)];
-            } else {
-                const uint32_t oa = a - (a > rank ? 1u : 0u), ob = b - (b > rank ? 1u : 0u);
-                v = Iold[oa * P + ob] + (dv * u2[oa]) * u2[ob];
+        for (uint32_t e0 = threadIdx.x; e0 < tot; e0 += kInvBatch * blockDim.x) {
+            T v[kInvBatch];
+#pragma unroll
+            for (int r = 0; r < kInvBatch; ++r) {                     // independent elements per thread and step
+                const uint32_t e = e0 + (uint32_t)r * blockDim.x;
+                v[r] = T(0);
+                if (e >= tot) continue;
+                const uint32_t a = e / K_new, b = e - a * K_new;
+                if (a == rank && b == rank) {
+                    v[r] = dv;
+                } else if (a == rank) {
+                    v[r] = -dv * u2[b - (b > rank ? 1u : 0u)];
+                } else if (b == rank) {
+                    v[r] = -dv * u2[a - (a > rank ? 1u : 0u)];
+                } else {
+                    const uint32_t oa = a - (a > rank ? 1u : 0u), ob = b - (b > rank ? 1u : 0u);
+                    v[r] = Iold[oa * P + ob] + (dv * u2[oa]) * u2[ob];
+                }
             }
-            Inew[a * P + b] = v;
+#pragma unroll
+            for (int r = 0; r < kInvBatch; ++r) {
+                const uint32_t e = e0 + (uint32_t)r * blockDim.x;
+                if (e < tot) { const uint32_t a = e / K_new, b = e - a * K_new; Inew[a * P + b] = v[r]; }
+            }
         }
     } else {
         // remove row/column `rank` (online_inverse.h:275-290)
@@ -773,10 +810,22 @@ __device__ __forceinline__ void update_direction(uint32_t cur, uint32_t K_new, u
         for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) u2[i] = Iold[i * P + rank] * sc;
         __syncthreads();
         const uint32_t tot = K_new * K_new;
-        for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
-            const uint32_t a = e / K_new, b = e - a * K_new;
-            const uint32_t oa = a + (a >= rank ? 1u : 0u), ob = b + (b >= rank ? 1u : 0u);
-            Inew[a * P + b] = Iold[oa * P + ob] + (-dd * u2[oa]) * u2[ob];
+        for (uint32_t e0 = threadIdx.x; e0 < tot; e0 += kInvBatch * blockDim.x) {
+            T v[kInvBatch];
+#pragma unroll
+            for (int r = 0; r < kInvBatch; ++r) {
+                const uint32_t e = e0 + (uint32_t)r * blockDim.x;
+                v[r] = T(0);
+                if (e >= tot) continue;
+                const uint32_t a = e / K_new, b = e - a * K_new;
+                const uint32_t oa = a + (a >= rank ? 1u : 0u), ob = b + (b >= rank ? 1u : 0u);
+                v[r] = Iold[oa * P + ob] + (-dd * u2[oa]) * u2[ob];
+            }
+#pragma unroll
+            for (int r = 0; r < kInvBatch; ++r) {
+                const uint32_t e = e0 + (uint32_t)r * blockDim.x;
+                if (e < tot) { const uint32_t a = e / K_new, b = e - a * K_new; Inew[a * P + b] = v[r]; }
+            }
         }
     }
 
@@ -810,12 +859,34 @@ __device__ __forceinline__ void update_direction(uint32_t cur, uint32_t K_new, u
     // clear the old direction
     for (uint32_t j = threadIdx.x; j < K_old; j += blockDim.x) d[gam_old[j]] = T(0);
     __syncthreads();
-    // direction = inv * sign (homotopy-cpu.cpp:263), scattered to its columns (:266)
-    for (uint32_t a = wave; a < K_new; a += NW) {
-        T acc = T(0);
-        for (uint32_t b = lane; b < K_new; b += 64) acc += Inew[a * P + b] * sgn[b];
-        acc = wave_sum(acc);
-        if (lane == 0) d[gam_new[a]] = acc;
+    // direction = inv * sign (homotopy-cpu.cpp:263), scattered to its columns (:266); four rows at a time
+    for (uint32_t a0 = wave; a0 < K_new; a0 += kMvRows * NW) {
+        T acc[kMvRows];
+#pragma unroll
+        for (int r = 0; r < kMvRows; ++r) acc[r] = T(0);
+        for (uint32_t b0 = lane; b0 < K_new; b0 += 64 * kMvSlices) {
+            T sb[kMvSlices], v[kMvRows][kMvSlices];
+#pragma unroll
+            for (int t = 0; t < kMvSlices; ++t) { const uint32_t b = b0 + 64u * (uint32_t)t; sb[t] = b < K_new ? sgn[b] : T(0); }
+#pragma unroll
+            for (int r = 0; r < kMvRows; ++r)
+#pragma unroll
+                for (int t = 0; t < kMvSlices; ++t) {
+                    const uint32_t a = a0 + (uint32_t)r * NW, b = b0 + 64u * (uint32_t)t;
+                    v[r][t] = (a < K_new && b < K_new) ? Inew[a * P + b] : T(0);
+                }
+#pragma unroll
+            for (int t = 0; t < kMvSlices; ++t)
+#pragma unroll
+                for (int r = 0; r < kMvRows; ++r)
+                    if (b0 + 64u * (uint32_t)t < K_new) acc[r] += v[r][t] * sb[t];
+        }
+#pragma unroll
+        for (int r = 0; r < kMvRows; ++r) {
+            const uint32_t a = a0 + (uint32_t)r * NW;
+            const T sa = wave_sum(acc[r]);
+            if (lane == 0 && a < K_new) d[gam_new[a]] = sa;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) st->cur = cur ^ 1u;
