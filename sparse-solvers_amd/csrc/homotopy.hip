@@ -409,7 +409,7 @@ template <typename T> struct Lookahead {
     // solo: the speculative form (one workgroup + verification) while the device has not switched it off
     static void iterate(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter, uint32_t lds_cols, bool solo = false)
     {
-        if (solo && lds_cols != 0) HIPCHK(launch_solo_group(ctx, ws, tol, max_iter));
+        if (solo) HIPCHK(launch_solo_group(ctx, ws, tol, max_iter));
         else if (lds_cols != 0) HIPCHK(launch_persist(ctx, ws, tol, max_iter, lds_cols));
         else HIPCHK(launch_la_iter<T>(ctx, ws, tol, max_iter));
     }
@@ -587,10 +587,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
-            // speculative form: fp32, exact zeros on removal (like the resident kernel), first LDS tier usable
-            solo = ctx->la_fused >= 3 && !no_solo && ctx->solo_off_solves == 0 && ctx->zero_on_removal && sizeof(T) == 4 &&
-                   la_persist_usable(ctx, std::min<uint32_t>((ws.dims.kcap + 15u) & ~15u, kLaLdsSmall)) && la_solo_usable(ctx);
-            if (ctx->la_fused >= 3 && !solo && ctx->solo_off_solves > 0 && !no_solo) ctx->solo_off_solves -= 1;
+            // Speculative form (fp32, exact zeros on removal like the resident kernel): on request only
+            // (la_fused = 3).  It also runs where the resident kernel cannot (dictionaries too wide for one
+            // launch to own every column); measured at n = 2^20 it does not pay there yet — its verification
+            // pass repeats a per-workgroup prologue 4096 times.
+            const bool solo_wanted = ctx->la_fused >= 3;
+            solo = solo_wanted && !no_solo && ctx->solo_off_solves == 0 && ctx->zero_on_removal && sizeof(T) == 4 && la_solo_usable(ctx);
+            if (solo_wanted && !solo && ctx->solo_off_solves > 0 && !no_solo) ctx->solo_off_solves -= 1;
             solo_started = solo;
             Lookahead<T>::init(ctx, ws, nb1, tol, solo);
         } else if (!omp) {
@@ -651,7 +654,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     lds_cols = (hf[3] <= big && big > lds_cols && la_persist_usable(ctx, big)) ? big : 0u;
                 }
                 if (enq >= max_launch) { stuck = true; break; }
-                if (solo && (hf[4] != 0 || lds_cols != std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsSmall))) solo = false;   // the device handed over to the resident form
+                if (solo && hf[4] != 0) solo = false;   // the device handed over to the resident / launch-per-iteration form
                 if (la_omp) HIPCHK(launch_la_omp<T>(ctx, ws, tol, max_iter));
                 else Lookahead<T>::iterate(ctx, ws, tol, max_iter, lds_cols, solo);
                 ++enq;

@@ -48,6 +48,7 @@ constexpr uint32_t kPsWidth = 256;              // columns a workgroup owns per 
 constexpr uint32_t kPsLdsBudget = 160 * 1024 - 1024;   // dynamic LDS a workgroup may take (static scratch aside)
 constexpr int kPsCols = 2;                      // columns a thread owns at most
 constexpr uint32_t kPsSpinLimit = 1u << 20;     // polls (~1 us each) before a wait gives up
+constexpr uint32_t kPsGroup = 8;                // rows a Gram-form pass handles per step (the lists are zero-padded to whole groups)
 
 // ---- L2-bypassing accessors for words that cross workgroups inside the launch ----------------
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t* p)
@@ -369,7 +370,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         S.xs[tid] = x[cl];
         S.ds[tid] = d[cl];
     } else if (tid < P) {
-        S.xs[tid] = 0.f;                             // padding of the Gram-form loops (whole groups of 16)
+        S.xs[tid] = 0.f;                             // padding of the Gram-form loops (whole groups of kPsGroup rows)
         S.ds[tid] = 0.f;
     }
     __syncthreads();
@@ -434,14 +435,14 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     // Each lane fetches one cache slot of the lists; the loop takes them out of the lanes as scalars.
     // Rows below gl_used come from the LDS slice (first column set), the others by buffer loads
     // whose row offset is a scalar register.  Entries Kc .. roundup16(Kc)-1 are padding (coef = 0
-    // on a valid row: exact zeros), so the loop runs in whole groups of sixteen without branches.
+    // on a valid row: exact zeros), so the loop runs in whole groups of kPsGroup rows without branches.
     auto gram_pass = [&](const float* coef, uint32_t Kc, float (&out)[kPsCols]) {
 #pragma unroll
         for (int k = 0; k < kPsCols; ++k) {
             out[k] = 0.f;
             if (__ballot(in[k]) == 0ull) continue;            // whole waves only (lanes exchange entries)
             const uint32_t cofs4 = (in[k] ? col[k] : 0u) * 4u;
-            const uint32_t K16 = (Kc + 15u) & ~15u;
+            const uint32_t K16 = (Kc + (kPsGroup - 1u)) & ~(kPsGroup - 1u);
             const uint32_t tcol = tid & (kPsWidth - 1u);
             float acc = 0.f;
             for (uint32_t j0 = 0; j0 < K16; j0 += 64) {
@@ -451,26 +452,26 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 const uint32_t cnt = K16 - j0 < 64u ? K16 - j0 : 64u;
                 const float* cf = coef + j0;
                 const uint64_t out_of_lds = __ballot(vl == kNoLdsRow);    // lanes whose row must come from L2
-                for (uint32_t u = 0; u < cnt; u += 16) {
-                    float gv[16];
-                    if (((out_of_lds >> u) & 0xffffull) == 0ull) {
+                for (uint32_t u = 0; u < cnt; u += kPsGroup) {
+                    float gv[kPsGroup];
+                    if (((out_of_lds >> u) & ((1ull << kPsGroup) - 1ull)) == 0ull) {
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) gv[t] = Glds[__builtin_amdgcn_readlane(vl, u + t) * kPsWidth + tcol];
+                        for (int t = 0; t < (int)kPsGroup; ++t) gv[t] = Glds[__builtin_amdgcn_readlane(vl, u + t) * kPsWidth + tcol];
                     } else {
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) {
+                        for (int t = 0; t < (int)kPsGroup; ++t) {
                             const uint32_t lr = __builtin_amdgcn_readlane(vl, u + t);
                             gv[t] = 0.f;
                             if (lr == kNoLdsRow) gv[t] = grow_global(__builtin_amdgcn_readlane(vs, u + t), cofs4);
                         }
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) {
+                        for (int t = 0; t < (int)kPsGroup; ++t) {
                             const uint32_t lr = __builtin_amdgcn_readlane(vl, u + t);
                             if (lr != kNoLdsRow) gv[t] = Glds[lr * kPsWidth + tcol];
                         }
                     }
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) acc += cf[u + t] * gv[t];
+                    for (int t = 0; t < (int)kPsGroup; ++t) acc += cf[u + t] * gv[t];
                 }
             }
             out[k] = acc;
