@@ -1043,8 +1043,11 @@ __device__ __forceinline__ bool grid_barrier_relaxed(uint32_t* counter, uint32_t
     return *s_flag != 0u;
 }
 
-template <typename T>
-__global__ __launch_bounds__(kItThreads)
+// THREADS x COLS columns per workgroup and pass: 256 x 2 in fp32; 1024 x 1 in fp64, where the serial part of the
+// last workgroup (inverse, direction: all in global memory) is a chain of memory round trips and four times
+// the threads keep four times the loads in flight
+template <typename T, int THREADS, int COLS>
+__global__ __launch_bounds__(THREADS)
 void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
                const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, const T* __restrict__ c0,
                uint32_t gpitch, T* c, T* q, T* x, T* d, uint8_t* insup,
@@ -1080,11 +1083,11 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
     // ---- phase 1: Gram-form correlations --------------------------------------------------
     T bv = T(-1);
     uint32_t bi = 0xffffffffu;
-    for (uint32_t base = blockIdx.x * kItChunk; base < n; base += gridDim.x * kItChunk) {
+    for (uint32_t base = blockIdx.x * (uint32_t)(THREADS * COLS); base < n; base += gridDim.x * (uint32_t)(THREADS * COLS)) {
         const T* gbase = gcache + base + tid;            // gpitch % 1024 == 0: rows never run out
-        T ax[kItCols], ad[kItCols];
+        T ax[COLS], ad[COLS];
 #pragma unroll
-        for (int k = 0; k < kItCols; ++k) { ax[k] = T(0); ad[k] = T(0); }
+        for (int k = 0; k < COLS; ++k) { ax[k] = T(0); ad[k] = T(0); }
         for (uint32_t j0 = 0; j0 < nt; j0 += kCqTile) {
             const uint32_t cnt = (nt - j0 < kCqTile) ? (nt - j0) : kCqTile;
             __syncthreads();
@@ -1095,32 +1098,29 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
                 s_dv[tid] = d[col];
             }
             __syncthreads();
-            uint32_t j = 0;
-            for (; j + 8 <= cnt; j += 8) {
-                T gv[8][kItCols];
+            // whole groups of UNR rows with all their loads in flight; a short last group is padded with
+            // zero coefficients on a valid row (exact zeros) — a row at a time would be a memory round trip each
+            constexpr int UNR = 8;
+            for (uint32_t j = 0; j < cnt; j += UNR) {
+                T gv[UNR][COLS];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const T* g = gbase + (size_t)s_slot[j + u] * gpitch;
+                for (int u = 0; u < UNR; ++u) {
+                    const T* g = gbase + (size_t)s_slot[j + u < cnt ? j + u : j] * gpitch;
 #pragma unroll
-                    for (int k = 0; k < kItCols; ++k) gv[u][k] = g[k * kItThreads];
+                    for (int k = 0; k < COLS; ++k) gv[u][k] = g[k * THREADS];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const T xj = s_x[j + u], dj = s_dv[j + u];
+                for (int u = 0; u < UNR; ++u) {
+                    const bool live = j + u < cnt;
+                    const T xj = live ? s_x[j + u] : T(0), dj = live ? s_dv[j + u] : T(0);
 #pragma unroll
-                    for (int k = 0; k < kItCols; ++k) { ax[k] += xj * gv[u][k]; ad[k] += dj * gv[u][k]; }
+                    for (int k = 0; k < COLS; ++k) { ax[k] += xj * gv[u][k]; ad[k] += dj * gv[u][k]; }
                 }
-            }
-            for (; j < cnt; ++j) {
-                const T* g = gbase + (size_t)s_slot[j] * gpitch;
-                const T xj = s_x[j], dj = s_dv[j];
-#pragma unroll
-                for (int k = 0; k < kItCols; ++k) { const T gvv = g[k * kItThreads]; ax[k] += xj * gvv; ad[k] += dj * gvv; }
             }
         }
 #pragma unroll
-        for (int k = 0; k < kItCols; ++k) {
-            const uint32_t i = base + k * kItThreads + tid;
+        for (int k = 0; k < COLS; ++k) {
+            const uint32_t i = base + k * THREADS + tid;
             if (i < n) {
                 const T cv = c0[i] - ax[k];
                 // (everything that crosses workgroups in this launch moves with L2-bypassing stores and
@@ -1173,10 +1173,10 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
     // ---- phase 2: step-length scan (same expressions as k_scansel) ---------------------------
     T best = Lim<T>::max();
     uint32_t best_i = 0xffffffffu;
-    for (uint32_t base = blockIdx.x * kItChunk; base < n; base += gridDim.x * kItChunk)
+    for (uint32_t base = blockIdx.x * (uint32_t)(THREADS * COLS); base < n; base += gridDim.x * (uint32_t)(THREADS * COLS))
 #pragma unroll
-    for (int k = 0; k < kItCols; ++k) {
-        const uint32_t i = base + k * kItThreads + tid;
+    for (int k = 0; k < COLS; ++k) {
+        const uint32_t i = base + k * THREADS + tid;
         if (i < n) {
             T m = Lim<T>::max();
             const bool act = insup[i] != 0;
@@ -1618,12 +1618,14 @@ template <typename T>
 hipError_t launch_la_iter(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter)
 {
     const uint32_t n = (uint32_t)ctx->n;
-    uint32_t nb = (n + kItChunk - 1) / kItChunk;
+    constexpr int TH = sizeof(T) == 8 ? 1024 : kItThreads, CL = sizeof(T) == 8 ? 1 : kItCols;
+    constexpr uint32_t chunk = (uint32_t)(TH * CL);
+    uint32_t nb = (n + chunk - 1) / chunk;
     const uint32_t cap = std::min<uint32_t>(std::min<uint32_t>(kItMaxBlocks, (uint32_t)ctx->num_cus),
                                             std::min<uint32_t>(ws.dims.pmax_stride, ws.dims.pmin_stride));
     if (nb > cap) nb = cap;                              // the kernel grid-strides; the grid must be resident
     if (nb == 0) nb = 1;
-    hipLaunchKernelGGL((k_la_iter<T>), dim3(nb), dim3(kItThreads), 0, ctx->stream, tol, max_iter, n,
+    hipLaunchKernelGGL((k_la_iter<T, TH, CL>), dim3(nb), dim3(TH), 0, ctx->stream, tol, max_iter, n,
                        (const T*)ws.gcache, (const int32_t*)ws.slot_of, (const T*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx, ws.pmin_val, ws.pmin_idx,
                        ws.gam, ws.touched, ws.inv[0], ws.inv[1], ws.u1, ws.u2, ws.sgn, ws.tcand, ws.dims, ws.st,
