@@ -281,15 +281,21 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             const uint32_t used = st->cache_used;
             const uint32_t quota = cap > cnt + 32u ? cap - cnt - 32u : 0u;       // room kept for candidates
             const uint32_t s0 = used > kPsThreads ? used - kPsThreads : 0u;
-            if (s0 + tid < used) {
-                const uint32_t cl = sa.slot_col[used - 1u - tid];
-                if (cl < n && !insup[cl]) {
-                    const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
-                    if (pos < quota) s_sub[cnt + pos] = cl;
-                }
-            }
+            // thread t looks at slot used-1-t; positions by an exclusive prefix count over the threads
+            // (ballot per wave, wave totals through LDS): the same subset on every run
+            uint32_t cl = 0xffffffffu;
+            if (s0 + tid < used) cl = sa.slot_col[used - 1u - tid];
+            const bool take = cl < n && !insup[cl];
+            const uint64_t bal = __ballot(take);
+            const uint32_t lane_ = tid & 63u, wave_ = tid >> 6;
+            if (lane_ == 0) si[wave_] = (uint32_t)__popcll(bal);
             __syncthreads();
-            cnt += s_cnt[0] < quota ? s_cnt[0] : quota;
+            uint32_t before = 0, total = 0;
+            for (uint32_t w2 = 0; w2 < kPsThreads / 64; ++w2) { const uint32_t c2 = si[w2]; if (w2 < wave_) before += c2; total += c2; }
+            const uint32_t pos = before + (uint32_t)__popcll(bal & ((1ull << lane_) - 1ull));
+            if (take && pos < quota) s_sub[cnt + pos] = cl;
+            __syncthreads();
+            cnt += total < quota ? total : quota;
         }
         // candidates: every thread offers the best of its strided share, the offers are ranked by counting
         uint64_t offer = ~0ull;
