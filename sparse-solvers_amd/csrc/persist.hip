@@ -383,7 +383,9 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     // the Gram-column cache as a buffer: row offsets go in the scalar offset of the loads (cache mode;
     // with the full Gram matrix as "cache" rows lie up to n * pitch * 4 B apart: 64-bit addressing there)
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gcache), 0, -1, 0x00020000);
-    auto grow_global = [&](uint32_t row, uint32_t cofs4) -> float {
+    // (every lambda below is forced inline: a closure that survives keeps its captures — K, the list
+    // pointers, ... — in scratch memory, which made each stage of the solo instantiation ~1.5x slower)
+    auto grow_global = [&](uint32_t row, uint32_t cofs4) __attribute__((always_inline)) -> float {
         if (full_g) return gcache[(size_t)row * gpitch + (cofs4 >> 2)];
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, cofs4, row * (gpitch * 4u), 0));
     };
@@ -442,7 +444,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     // Rows below gl_used come from the LDS slice (first column set), the others by buffer loads
     // whose row offset is a scalar register.  Entries Kc .. roundup16(Kc)-1 are padding (coef = 0
     // on a valid row: exact zeros), so the loop runs in whole groups of kPsGroup rows without branches.
-    auto gram_pass = [&](const float* coef, uint32_t Kc, float (&out)[kPsCols]) {
+    auto gram_pass = [&](const float* coef, uint32_t Kc, float (&out)[kPsCols]) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < kPsCols; ++k) {
             out[k] = 0.f;
@@ -489,7 +491,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     // partial maximum of |c|, and this workgroup's word of the lambda exchange of a new tick
     float cmax_v = -1.f;
     uint32_t cmax_i = 0xffffffffu;
-    auto c_pass = [&]() {
+    auto c_pass = [&]() __attribute__((always_inline)) {
         float ax[kPsCols];
         gram_pass(S.xs, K, ax);
         float bv = -1.f;
@@ -506,16 +508,16 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         cmax_v = bv;
         cmax_i = bi;
     };
-    auto post_lambda = [&]() {
+    auto post_lambda = [&]() __attribute__((always_inline)) {
         ++tick;
         if (!SOLO && tid == 0)
             st_u64(&smax[(tick & 1u) * kLaSlotStride + w],
                    cmax_i != 0xffffffffu ? (((uint64_t)__float_as_uint(cmax_v) << 32) | (uint64_t)(0xffffffffu - cmax_i)) : 0ull);
     };
-    auto c_pass_and_post = [&]() { c_pass(); post_lambda(); };
+    auto c_pass_and_post = [&]() __attribute__((always_inline)) { c_pass(); post_lambda(); };
     // read everybody's word of the lambda exchange of the current tick (false: a wait expired)
     // `early`: what this thread read from slot `tid` before the q pass (usually the word is there by then)
-    auto poll_lambda = [&](float& lam, uint64_t early = kLaSlotEmpty) -> bool {
+    auto poll_lambda = [&](float& lam, uint64_t early = kLaSlotEmpty) __attribute__((always_inline)) -> bool {
         if (SOLO) { lam = cmax_v; return true; }             // the subset's maximum (uniform after the block reduction)
         const uint32_t par = (tick & 1u) * kLaSlotStride;
         float mv = -1.f;
@@ -549,7 +551,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
 
     // solo: one log entry per decision taken from the subset alone (lists as they stand: K entries)
     uint32_t nlog = 0, nscan = 0;
-    auto log_entry = [&](uint32_t flags, uint32_t round_, float lam, float g_, uint32_t idx_, float gs_, uint32_t is_) {
+    auto log_entry = [&](uint32_t flags, uint32_t round_, float lam, float g_, uint32_t idx_, float gs_, uint32_t is_) __attribute__((always_inline)) {
         if (!SOLO) return;
         uint32_t* e = sa.log + kSoloHeaderWords + (size_t)nlog * kSoloEntryWords;
         if (tid == 0) {

@@ -34,7 +34,7 @@ namespace sship {
 
 constexpr int kVfThreads = 256;
 constexpr uint32_t kVfUnion = 128;           // support columns a chunk of breakpoints can involve (96 + 32)
-constexpr uint32_t kVfRedPitch = kVfThreads + 8;
+constexpr uint32_t kVfRedPitch = kSoloWidth + 16;    // row pitch of the reduction buffer (16 readers per row: conflict-free)
 
 // the two best (smallest key, then smallest column) of the block's offers -> out[0], out[1]
 __device__ __forceinline__ void block_top2(float key, uint32_t colv, uint64_t* out, float* sv, uint32_t* si)
@@ -70,19 +70,27 @@ void k_la_cand_init(const float* __restrict__ c0, uint32_t n, const DevState* __
     block_top2(key, cl, cand_top + 2 * (size_t)blockIdx.x, sv, si);
 }
 
-__global__ __launch_bounds__(kVfThreads)
+// Two threads per column: thread (half h, column t) carries the 16 breakpoints 16h .. 16h+15 of a chunk
+// (32 accumulators instead of 64: two waves per SIMD can be resident and hide each other's LDS latency).
+constexpr int kVfyThreads = 2 * (int)kSoloWidth;
+constexpr uint32_t kVfHalf = kSoloChunk / 2;
+
+__global__ __launch_bounds__(kVfyThreads)
 void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint32_t gpitch,
                  const int32_t* __restrict__ slot_of, const float* __restrict__ c0,
                  const uint32_t* __restrict__ log, const uint8_t* __restrict__ sub_pos,
                  const DevState* __restrict__ st, uint32_t* __restrict__ v_max, uint64_t* __restrict__ v_min,
-                 uint32_t nvwg, float* __restrict__ tcand, uint64_t* __restrict__ cand_top, int tie_guard, uint32_t nrows)
+                 uint32_t nvwg, float* __restrict__ tcand, uint64_t* __restrict__ cand_top, int tie_guard, uint32_t nrows,
+                 uint64_t* dbg)
 {
+    uint64_t tsv[8];
+    tsv[0] = wall_clock64();
     __shared__ float sX[kVfUnion][kSoloChunk];          // x_S of union column r at breakpoint k (0 when absent)
     __shared__ float sD[kVfUnion][kSoloChunk];
     __shared__ uint64_t sRed[kSoloChunk * kVfRedPitch]; // reductions: one row per breakpoint
-    __shared__ uint32_t s_sub[kSoloWidth];              // header: columns of the subset
+    __shared__ __attribute__((aligned(16))) uint32_t s_sub[kSoloWidth];   // header: columns of the subset
     __shared__ uint32_t s_row[kSoloWidth];              // header: their Gram rows
-    __shared__ uint32_t s_pres[kSoloWidth];             // bit k: position is in the support at breakpoint k
+    __shared__ __attribute__((aligned(16))) uint32_t s_pres[kSoloWidth];  // bit k: position is in the support at breakpoint k
     __shared__ uint32_t s_rank[kSoloWidth];             // position -> index in the union (sorted by column)
     __shared__ uint32_t s_urow[kVfUnion];               // union index -> Gram row
     __shared__ uint32_t s_hdr[kSoloChunk][8];
@@ -94,12 +102,15 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
     const uint32_t nlog = st->solo_nlog;
     if (nlog == 0u) return;
     const uint32_t tid = threadIdx.x, wg = blockIdx.x;
-    const uint32_t i = wg * kVfThreads + tid;
+    const uint32_t tcol = tid & (kSoloWidth - 1u), half = tid / kSoloWidth;
+    const uint32_t i = wg * kSoloWidth + tcol;
     const bool valid = i < n;
     const float c0v = valid ? c0[i] : 0.f;
     const bool cached = valid && slot_of[i] >= 0;
-    s_sub[tid] = log[tid];
-    s_row[tid] = log[kSoloWidth + tid];
+    if (tid < kSoloWidth) {
+        s_sub[tid] = log[tid];
+        s_row[tid] = log[kSoloWidth + tid];
+    }
     __syncthreads();
     // this thread's column in the subset?  (sub_pos is only trusted if the header agrees)
     uint32_t mypos = 0xffffffffu;
@@ -108,7 +119,7 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
         if (s_sub[p] == i) mypos = p;
     }
     // the last entry that carries a scan: its candidates feed tcand and the next subset
-    // (one parallel load of the flag words; s_hdr is free until the first chunk)
+    // (one parallel load of the flag words; s_U is free until the first chunk)
     if (tid < kSoloLogCap) {
         const uint32_t fl = tid < nlog ? (log[kSoloHeaderWords + (size_t)tid * kSoloEntryWords + 1] & 1u) : 0u;
         const uint64_t b = __ballot(fl != 0u);
@@ -118,45 +129,51 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
     const uint32_t last_scan = s_U;
 
     const uint32_t* entries = log + kSoloHeaderWords;
+    tsv[1] = wall_clock64();
     for (uint32_t k0 = 0; k0 < nlog; k0 += kSoloChunk) {
         const uint32_t J = nlog - k0 < kSoloChunk ? nlog - k0 : kSoloChunk;
         __syncthreads();
         // ---- the chunk's union of support columns, sorted by column; coefficient tables ---------------
-        s_pres[tid] = 0u;
-        for (uint32_t e = tid; e < kVfUnion * kSoloChunk; e += kVfThreads) {
-            (&sX[0][0])[e] = 0.f;
-            (&sD[0][0])[e] = 0.f;
-        }
+        if (tid < kSoloWidth) s_pres[tid] = 0u;
         // the chunk's entries, one bulk copy into LDS (the reduction buffer is free here): everything below
         // reads them from there — loads from the log issued entry by entry cost a memory round trip each
         uint32_t* const sE = reinterpret_cast<uint32_t*>(sRed);
         {
             const uint32_t* src = entries + (size_t)k0 * kSoloEntryWords;
             const uint32_t tot = J * kSoloEntryWords;
-            for (uint32_t e0 = 0; e0 < tot; e0 += 8 * kVfThreads) {
+            for (uint32_t e0 = 0; e0 < tot; e0 += 8 * kVfyThreads) {
                 uint32_t v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const uint32_t e = e0 + (uint32_t)u * kVfThreads + tid; v[u] = e < tot ? src[e] : 0u; }
+                for (int u = 0; u < 8; ++u) { const uint32_t e = e0 + (uint32_t)u * kVfyThreads + tid; v[u] = e < tot ? src[e] : 0u; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const uint32_t e = e0 + (uint32_t)u * kVfThreads + tid; if (e < tot) sE[e] = v[u]; }
+                for (int u = 0; u < 8; ++u) { const uint32_t e = e0 + (uint32_t)u * kVfyThreads + tid; if (e < tot) sE[e] = v[u]; }
             }
         }
         if (tid == 0) s_U = 0u;
         __syncthreads();
+        if (k0 == 0) tsv[2] = wall_clock64();
         if (tid < J * 8u) s_hdr[tid >> 3][tid & 7u] = sE[(tid >> 3) * kSoloEntryWords + (tid & 7u)];
-        for (uint32_t pr = tid; pr < J * kSoloListPitch; pr += kVfThreads) {
+        for (uint32_t pr = tid; pr < J * kSoloListPitch; pr += kVfyThreads) {
             const uint32_t k = pr / kSoloListPitch, j = pr - k * kSoloListPitch;
             const uint32_t* e = sE + k * kSoloEntryWords;
             if (j < e[0]) atomicOr(&s_pres[e[8 + kSoloListPitch + j] & (kSoloWidth - 1u)], 1u << k);
         }
         __syncthreads();
-        {
+        if (tid < kSoloWidth) {
             const bool part = s_pres[tid] != 0u;
             const uint32_t mycol = s_sub[tid];
             uint32_t r = 0;
             if (part) {
-#pragma unroll 16
-                for (uint32_t u = 0; u < kSoloWidth; ++u) r += (s_pres[u] != 0u && s_sub[u] < mycol) ? 1u : 0u;
+                const uint4* p4 = reinterpret_cast<const uint4*>(s_pres);
+                const uint4* c4 = reinterpret_cast<const uint4*>(s_sub);
+#pragma unroll 8
+                for (uint32_t u = 0; u < kSoloWidth / 4; ++u) {
+                    const uint4 pp = p4[u], cc = c4[u];
+                    r += (pp.x != 0u && cc.x < mycol) ? 1u : 0u;
+                    r += (pp.y != 0u && cc.y < mycol) ? 1u : 0u;
+                    r += (pp.z != 0u && cc.z < mycol) ? 1u : 0u;
+                    r += (pp.w != 0u && cc.w < mycol) ? 1u : 0u;
+                }
             }
             s_rank[tid] = part ? r : 0xffffffffu;
             if (part) {
@@ -166,7 +183,12 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
         }
         __syncthreads();
         const uint32_t U = s_U < kVfUnion ? s_U : kVfUnion;      // (U <= 96 + 32 by construction)
-        for (uint32_t pr = tid; pr < J * kSoloListPitch; pr += kVfThreads) {
+        for (uint32_t e = tid; e < U * kSoloChunk; e += kVfyThreads) {       // absent columns contribute exact zeros
+            (&sX[0][0])[e] = 0.f;
+            (&sD[0][0])[e] = 0.f;
+        }
+        __syncthreads();
+        for (uint32_t pr = tid; pr < J * kSoloListPitch; pr += kVfyThreads) {
             const uint32_t k = pr / kSoloListPitch, j = pr - k * kSoloListPitch;
             const uint32_t* e = sE + k * kSoloEntryWords;
             if (j < e[0]) {
@@ -179,67 +201,78 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
         }
         __syncthreads();
 
-        // ---- one pass over the union's Gram rows: 2 x 32 sums per column, sorted-support order -------
-        float ax[kSoloChunk], ad[kSoloChunk];
+        if (k0 == 0) tsv[3] = wall_clock64();
+        // ---- one pass over the union's Gram rows: 2 x 16 sums per thread, sorted-support order ---------
+        const uint32_t kb = half * kVfHalf;                // this thread's breakpoints: kb .. kb + 15 of the chunk
+        float ax[kVfHalf], ad[kVfHalf];
 #pragma unroll
-        for (int k = 0; k < (int)kSoloChunk; ++k) { ax[k] = 0.f; ad[k] = 0.f; }
+        for (int k = 0; k < (int)kVfHalf; ++k) { ax[k] = 0.f; ad[k] = 0.f; }
         const size_t ci = valid ? i : 0u;
-        for (uint32_t r0 = 0; r0 < U; r0 += 4) {
-            float gv[4];
+        constexpr int RB = 8;                              // Gram rows in flight per thread (each a trip to L2 / HBM)
+        if (kb < J) {
+            for (uint32_t r0 = 0; r0 < U; r0 += RB) {
+                float gv[RB];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t r = r0 + (uint32_t)t < U ? r0 + (uint32_t)t : r0;
-                gv[t] = gcache[(size_t)s_urow[r] * gpitch + ci];
-            }
+                for (int t = 0; t < RB; ++t) {
+                    const uint32_t r = r0 + (uint32_t)t < U ? r0 + (uint32_t)t : r0;
+                    gv[t] = gcache[(size_t)s_urow[r] * gpitch + ci];
+                }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (r0 + (uint32_t)t >= U) break;
-                const float g = gv[t];
-                const float* xr = sX[r0 + t];
-                const float* dr = sD[r0 + t];
+                for (int t = 0; t < RB; ++t) {
+                    if (r0 + (uint32_t)t >= U) break;
+                    const float g = gv[t];
+                    const float* xr = sX[r0 + t] + kb;
+                    const float* dr = sD[r0 + t] + kb;
 #pragma unroll
-                for (int k = 0; k < (int)kSoloChunk; ++k) {
-                    ax[k] += xr[k] * g;
-                    ad[k] += dr[k] * g;
+                    for (int kg = 0; kg < (int)kVfHalf; kg += 8) {
+                        if (kb + (uint32_t)kg >= J) break;             // (uniform per wave: whole groups of 8 breakpoints)
+#pragma unroll
+                        for (int k = kg; k < kg + 8; ++k) {
+                            ax[k] += xr[k] * g;
+                            ad[k] += dr[k] * g;
+                        }
+                    }
                 }
             }
         }
 
+        if (k0 == 0) tsv[4] = wall_clock64();
         // ---- max |c| per breakpoint ---------------------------------------------------------------------
         uint32_t* red32 = reinterpret_cast<uint32_t*>(sRed);
 #pragma unroll
-        for (int k = 0; k < (int)kSoloChunk; ++k) {
+        for (int k = 0; k < (int)kVfHalf; ++k) {
             const float cv = c0v - ax[k];
             const float a = cv < 0.f ? -cv : cv;
-            red32[k * kVfRedPitch + tid] = (valid && (uint32_t)k < J) ? (__float_as_uint(a) & 0x7fffffffu) : 0u;
+            red32[(kb + k) * kVfRedPitch + tcol] = (valid && kb + (uint32_t)k < J) ? (__float_as_uint(a) & 0x7fffffffu) : 0u;
         }
         __syncthreads();
         {
-            const uint32_t k = tid >> 3, sub = tid & 7u;
+            const uint32_t k = tid >> 4, sub = tid & 15u;
             uint32_t m = 0u;
-            for (uint32_t j = 0; j < kVfThreads / 8; ++j) {
-                const uint32_t v = red32[k * kVfRedPitch + j * 8u + sub];
+            for (uint32_t j = 0; j < kSoloWidth / 16; ++j) {
+                const uint32_t v = red32[k * kVfRedPitch + j * 16u + sub];
                 m = v > m ? v : m;                      // (|c| >= 0: the bit patterns order like the values; NaN wins)
             }
-            m = max(m, (uint32_t)__shfl_xor((int)m, 1));
-            m = max(m, (uint32_t)__shfl_xor((int)m, 2));
-            m = max(m, (uint32_t)__shfl_xor((int)m, 4));
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
             if (sub == 0 && k < J) v_max[(size_t)(k0 + k) * nvwg + wg] = m;
         }
         __syncthreads();
 
+        if (k0 == 0) tsv[5] = wall_clock64();
         // ---- step-length candidates per breakpoint (find_max_gamma's off-support part, :137-159) --------
         const uint32_t pres = mypos != 0xffffffffu ? s_pres[mypos] : 0u;
         float m_last = Lim<float>::max();
-        bool act_last = false;
+        bool act_last = false, own_last = false;
 #pragma unroll
-        for (int k = 0; k < (int)kSoloChunk; ++k) {
+        for (int k = 0; k < (int)kVfHalf; ++k) {
+            const uint32_t kk = kb + (uint32_t)k;
             uint64_t pk = ~0ull;
-            if (valid && (uint32_t)k < J && (s_hdr[k][1] & 1u)) {
-                const bool act = (pres >> k) & 1u;
+            if (valid && kk < J && (s_hdr[kk][1] & 1u)) {
+                const bool act = (pres >> kk) & 1u;
                 float m = Lim<float>::max();
                 if (!act) {
-                    const float c_inf = __uint_as_float(s_hdr[k][4]);
+                    const float c_inf = __uint_as_float(s_hdr[kk][4]);
                     const float ci2 = c0v - ax[k], qi = ad[k];
                     const float dl = 1.f - qi, dr = 1.f + qi;
                     if (dl != 0.f) {
@@ -254,35 +287,40 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
                     }
                 }
                 if (m < Lim<float>::max()) pk = ((uint64_t)__float_as_uint(m) << 32) | i;
-                if (k0 + (uint32_t)k == last_scan) { m_last = m; act_last = act; }
+                if (k0 + kk == last_scan) { m_last = m; act_last = act; own_last = true; }
             }
-            sRed[k * kVfRedPitch + tid] = pk;
+            sRed[kk * kVfRedPitch + tcol] = pk;
         }
         __syncthreads();
         {
-            const uint32_t k = tid >> 3, sub = tid & 7u;
+            const uint32_t k = tid >> 4, sub = tid & 15u;
             uint64_t m = ~0ull;
-            for (uint32_t j = 0; j < kVfThreads / 8; ++j) {
-                const uint64_t v = sRed[k * kVfRedPitch + j * 8u + sub];
+            for (uint32_t j = 0; j < kSoloWidth / 16; ++j) {
+                const uint64_t v = sRed[k * kVfRedPitch + j * 16u + sub];
                 m = v < m ? v : m;                      // positive floats order like their bits; ties -> left-most column
             }
 #pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
+            for (int o = 1; o < 16; o <<= 1) {
                 const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)m, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(m >> 32), o);
                 const uint64_t v = ((uint64_t)hi << 32) | lo;
                 m = v < m ? v : m;
             }
             if (sub == 0 && k < J) v_min[(size_t)(k0 + k) * nvwg + wg] = m;
         }
-        // ---- what the next steps rank by (from the last scan of the log) ----------------------------------
+        if (k0 == 0) tsv[6] = wall_clock64();
+        // ---- what the next steps rank by (from the last scan of the log; the thread that carries it) -------
         if (last_scan >= k0 && last_scan < k0 + J) {
             __syncthreads();
             // (full-G mode: every column is "cached" and k_la_top never runs; tcand then only ranks subsets)
-            if (valid) tcand[i] = (act_last || (cached && !full_g)) ? Lim<float>::max() : m_last;
+            if (own_last) tcand[i] = (act_last || (cached && !full_g)) ? Lim<float>::max() : m_last;
             // next subset: cached columns come in through their slots (cache mode), the support through its lists
-            const bool offer = valid && !act_last && (full_g || !cached) && m_last < Lim<float>::max();
+            const bool offer = own_last && !act_last && (full_g || !cached) && m_last < Lim<float>::max();
             block_top2(offer ? m_last : Lim<float>::max(), offer ? i : 0xffffffffu, cand_top + 2 * (size_t)wg, sv, si);
         }
+    }
+    if (dbg != nullptr && wg == 0 && tid == 0) {       // developer aid: stage timestamps of workgroup 0 (row 1600 + entries)
+        tsv[7] = wall_clock64();
+        for (int q2 = 0; q2 < 8; ++q2) dbg[(size_t)(1600 + nlog) * 8 + q2] = tsv[q2];
     }
 }
 
@@ -467,10 +505,10 @@ hipError_t launch_la_cand_init_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
 hipError_t launch_la_verify_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
 {
     if (ws.solo_log == nullptr || ws.v_max == nullptr || ws.nvwg == 0) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(k_la_verify, dim3(ws.nvwg), dim3(kVfThreads), 0, ctx->stream, (uint32_t)ctx->n, ws.gram_is_full ? 1 : 0,
+    hipLaunchKernelGGL(k_la_verify, dim3(ws.nvwg), dim3(kVfyThreads), 0, ctx->stream, (uint32_t)ctx->n, ws.gram_is_full ? 1 : 0,
                        (const float*)ws.gcache, ws.gpitch, (const int32_t*)ws.slot_of, (const float*)ws.c0,
                        (const uint32_t*)ws.solo_log, (const uint8_t*)ws.sub_pos, (const DevState*)ws.st, ws.v_max, ws.v_min,
-                       ws.nvwg, ws.tcand, ws.cand_top, ctx->tie_guard, ws.gram_is_full ? ctx->n_pad : ws.gcap);
+                       ws.nvwg, ws.tcand, ws.cand_top, ctx->tie_guard, ws.gram_is_full ? ctx->n_pad : ws.gcap, ws.la_dbg);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     CommitArgs ca;

@@ -7,6 +7,10 @@ rows = [r for r in range(1, 1024) if a[r, 0] != 0 and a[r, 6] > a[r, 0]]
 names = ["q pass + stores", "lambda poll", "scan + step exchange", "pick, x, c pass, post", "u2, d, lists", "sign + direction"]
 d = np.array([[(int(a[r, k + 1]) - int(a[r, k])) / 100.0 for k in range(6)] for r in rows])
 print("launch info (last): lds rows used %d, workgroups %d, lds rows %d, K at entry %d" % tuple(int(v) for v in a[0, :4]))
+for r in range(1600, 1700):
+    if a[r, 7] > a[r, 0]:
+        t = [(int(a[r, q + 1]) - int(a[r, q])) / 100.0 for q in range(7)]
+        print("k_la_verify with %d entries (workgroup 0, first chunk): entry %.1f  bulk copy %.1f  tables %.1f  rows %.1f  max %.1f  scan+min %.1f  rest/2nd chunk %.1f us" % tuple([r - 1600] + t))
 print("iterations recorded:", len(rows))
 for k, nme in enumerate(names):
     print("  %-22s mean %6.2f us   min %6.2f   max %6.2f" % (nme, d[:, k].mean(), d[:, k].min(), d[:, k].max()))
