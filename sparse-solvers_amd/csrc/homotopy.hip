@@ -333,6 +333,8 @@ inline hipError_t launch_solo_group(ss_hip_ctx* ctx, Workspace<float>& ws, float
 inline hipError_t launch_solo_group(ss_hip_ctx*, Workspace<double>&, double, uint32_t) { return hipErrorInvalidConfiguration; }
 inline hipError_t launch_cand_init(ss_hip_ctx* ctx, Workspace<float>& ws) { return launch_la_cand_init_f32(ctx, ws); }
 inline hipError_t launch_cand_init(ss_hip_ctx*, Workspace<double>&) { return hipErrorInvalidConfiguration; }
+inline hipError_t launch_top_cand(ss_hip_ctx* ctx, Workspace<float>& ws) { return launch_la_top_cand_f32(ctx, ws); }
+inline hipError_t launch_top_cand(ss_hip_ctx*, Workspace<double>&) { return hipErrorInvalidConfiguration; }
 
 template <typename T> struct Lookahead {
     static constexpr bool supported = true;
@@ -392,12 +394,13 @@ template <typename T> struct Lookahead {
         if (ws.la_dbg) HIPCHK(hipMemsetAsync(ws.la_dbg, 0, 2048 * 8 * sizeof(uint64_t), st));
         HIPCHK(hipMemcpyAsync(ws.c, ws.c0, (size_t)ctx->n_pad * sizeof(T), hipMemcpyDeviceToDevice, st));
         HIPCHK(launch_la_init_pick<T>(ctx, ws, nparts, tol, full));
+        if (solo) HIPCHK(launch_cand_init(ctx, ws));           // per-block tops of |c0|: ranking of the first sweep and subset
         if (!full) {
-            HIPCHK(launch_la_top<T>(ctx, ws, 1));
+            if (solo && ctx->n > 32u * 512u) HIPCHK(launch_top_cand(ctx, ws));
+            else HIPCHK(launch_la_top<T>(ctx, ws, 1));
             HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
         }
         HIPCHK(launch_la_update<T>(ctx, ws, 0, tol));
-        if (solo) HIPCHK(launch_cand_init(ctx, ws));           // ranking of the first subset: largest |c0|
         if (ctx->la_fused) return;                 // k_la_iter forms c and q itself
         uint32_t np2 = 0;
         HIPCHK(launch_la_cq<T>(ctx, ws, &np2));
@@ -415,9 +418,12 @@ template <typename T> struct Lookahead {
     }
     // ... and, when the device reports an entering column without cached Gram column, the sweep
     // that fetches it (plus 31 likely successors) and the inverse update that was waiting for it
-    static void fetch(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+    // from_cand: the speculative form is running — its verification has left the per-block candidate tops of
+    // the scan that missed (wide dictionaries only: with few blocks the tops are too few to rank from)
+    static void fetch(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool from_cand = false)
     {
-        HIPCHK(launch_la_top<T>(ctx, ws, 0));
+        if (from_cand && ctx->n > 32u * 512u) HIPCHK(launch_top_cand(ctx, ws));
+        else HIPCHK(launch_la_top<T>(ctx, ws, 0));
         if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
         HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
         if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
@@ -647,7 +653,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     hipEvent_t e0 = nullptr, e1 = nullptr;
                     if (timed_la) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
                     if (la_omp) Lookahead<T>::fetch_omp(ctx, ws, tol, e0, e1);
-                    else Lookahead<T>::fetch(ctx, ws, tol, e0, e1);
+                    else Lookahead<T>::fetch(ctx, ws, tol, e0, e1, solo);
                     if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
                     ++handled;
                 }

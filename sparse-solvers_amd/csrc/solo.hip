@@ -493,6 +493,77 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
     bump_seq(st, hflags);
 }
 
+// The columns of the next lookahead sweep, from the per-block candidate tops instead of a scan of all n
+// step-length candidates (k_la_top, one workgroup over n values: 31 us at n = 65536): the entering column
+// first, then the best-ranked offers that are neither active nor cached.  Same outputs as k_la_top.
+constexpr int kTcThreads = 512;
+constexpr int kTcS = 32;                      // columns per sweep (k_la_top's kTopS)
+
+__global__ __launch_bounds__(kTcThreads)
+void k_la_top_cand(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32_t n,
+                   const uint8_t* __restrict__ insup, int32_t* __restrict__ slot_of, uint32_t gcap,
+                   uint32_t* __restrict__ sw_list, DevState* st, uint32_t* hflags, uint32_t* __restrict__ slot_col)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t s_of[kTcThreads];
+    if (st->done || !st->need_sweep) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t idx = st->idx;
+    const uint32_t used = st->cache_used;                                 // (read before the barrier: thread 0 updates it at the end)
+    // one offer per thread (more candidates than threads: the best of a strided share), ranked by counting
+    uint64_t o1 = ~0ull;
+    for (uint32_t e = tid; e < ncand; e += kTcThreads) {
+        const uint64_t pk = cand_top[e];
+        const uint32_t cl = (uint32_t)pk;
+        if (pk == ~0ull || cl >= n || cl == idx || insup[cl] || slot_of[cl] >= 0) continue;
+        if (pk < o1) o1 = pk;
+    }
+    s_of[tid] = o1;
+    const uint32_t total = (uint32_t)__syncthreads_count(o1 != ~0ull);
+    uint32_t r1 = 0;
+    if (o1 != ~0ull) {
+        const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(s_of);
+#pragma unroll 8
+        for (uint32_t u = 0; u < kTcThreads / 2; ++u) {
+            const ulonglong2 v = p2[u];
+            r1 += v.x < o1 ? 1u : 0u;
+            r1 += v.y < o1 ? 1u : 0u;
+        }
+    }
+    const uint32_t room = gcap > used ? gcap - used : 0u;                 // slots left (the entering column takes the first)
+    uint32_t count = total < (uint32_t)kTcS - 1u ? total : (uint32_t)kTcS - 1u;
+    if (room == 0u) count = 0u; else if (count + 1u > room) count = room - 1u;
+    if (o1 != ~0ull && r1 < count) {
+        const uint32_t cl = (uint32_t)o1, sl = used + 1u + r1;
+        sw_list[1 + r1] = cl; sw_list[kTcS + 1 + r1] = sl; slot_of[cl] = (int32_t)sl;
+        if (slot_col != nullptr) slot_col[sl] = cl;
+    }
+    if (tid >= 1u + count && tid < (uint32_t)kTcS) { sw_list[tid] = 0xffffffffu; sw_list[kTcS + tid] = 0xffffffffu; }
+    if (tid == 0) {
+        if (room > 0u) {
+            sw_list[0] = idx; sw_list[kTcS] = used; slot_of[idx] = (int32_t)used;
+            if (slot_col != nullptr) slot_col[used] = idx;
+            st->cache_used = used + 1u + count;
+            st->nsweeps += 1;
+        } else {
+            // cache budget exhausted: the host re-runs the solve in residual form (as k_la_top does)
+            sw_list[0] = 0xffffffffu; sw_list[kTcS] = 0xffffffffu;
+            st->status = kStatusRetryResidual;
+            st->need_sweep = 0;
+            st->done = 1;
+            signal_done(hflags, nullptr, 1u, st->iter);
+        }
+    }
+}
+
+hipError_t launch_la_top_cand_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
+{
+    if (ws.cand_top == nullptr || ws.nvwg == 0) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_la_top_cand, dim3(1), dim3(kTcThreads), 0, ctx->stream, (const uint64_t*)ws.cand_top, 2 * ws.nvwg,
+                       (uint32_t)ctx->n, (const uint8_t*)ws.insup, ws.slot_of, ws.gcap, ws.sw_list, ws.st, ctx->dev_flags,
+                       ws.gram_is_full ? (uint32_t*)nullptr : ws.slot_col);
+    return hipGetLastError();
+}
+
 hipError_t launch_la_cand_init_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
 {
     if (ws.cand_top == nullptr || ws.nvwg == 0) return hipErrorInvalidConfiguration;

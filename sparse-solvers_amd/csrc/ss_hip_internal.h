@@ -330,6 +330,8 @@ hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float to
 hipError_t launch_la_solo_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter);
 hipError_t launch_la_verify_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
 hipError_t launch_la_cand_init_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
+// the columns of the next lookahead sweep from the per-block candidate tops (instead of k_la_top's scan)
+hipError_t launch_la_top_cand_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
 bool la_solo_usable(ss_hip_ctx* ctx);
 // true if k_la_persist can serve this context (column count vs resident workgroups)
 bool la_persist_usable(ss_hip_ctx* ctx, uint32_t lds_cols);
