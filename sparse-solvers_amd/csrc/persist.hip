@@ -508,6 +508,58 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         cmax_v = bv;
         cmax_i = bi;
     };
+    // solo: c and q in ONE pass over the rows (no exchange has to be posted in between, and each Gram
+    // value is read once).  Per column the two sums are formed exactly as by the separate passes.
+    auto cq_pass = [&]() __attribute__((always_inline)) {
+        float ax = 0.f, ad = 0.f;
+        if (__ballot(in[0]) != 0ull) {
+            const uint32_t cofs4 = (in[0] ? col[0] : 0u) * 4u;
+            const uint32_t K16 = (K + (kPsGroup - 1u)) & ~(kPsGroup - 1u);
+            const uint32_t tcol = tid & (kPsWidth - 1u);
+            for (uint32_t j0 = 0; j0 < K16; j0 += 64) {
+                const uint32_t jl = j0 + (uint32_t)lane;
+                const uint32_t vs = S.slt[jl < K ? jl : 0u];
+                const uint32_t vl = S.lrw[jl < K ? jl : 0u];
+                const uint32_t cnt = K16 - j0 < 64u ? K16 - j0 : 64u;
+                const float* cx = S.xs + j0;
+                const float* cd = S.ds + j0;
+                const uint64_t out_of_lds = __ballot(vl == kNoLdsRow);
+                for (uint32_t u = 0; u < cnt; u += kPsGroup) {
+                    float gv[kPsGroup];
+                    if (((out_of_lds >> u) & ((1ull << kPsGroup) - 1ull)) == 0ull) {
+#pragma unroll
+                        for (int t = 0; t < (int)kPsGroup; ++t) gv[t] = Glds[__builtin_amdgcn_readlane(vl, u + t) * kPsWidth + tcol];
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < (int)kPsGroup; ++t) {
+                            const uint32_t lr = __builtin_amdgcn_readlane(vl, u + t);
+                            gv[t] = 0.f;
+                            if (lr == kNoLdsRow) gv[t] = grow_global(__builtin_amdgcn_readlane(vs, u + t), cofs4);
+                        }
+#pragma unroll
+                        for (int t = 0; t < (int)kPsGroup; ++t) {
+                            const uint32_t lr = __builtin_amdgcn_readlane(vl, u + t);
+                            if (lr != kNoLdsRow) gv[t] = Glds[lr * kPsWidth + tcol];
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < (int)kPsGroup; ++t) { ax += cx[u + t] * gv[t]; ad += cd[u + t] * gv[t]; }
+                }
+            }
+        }
+        float bv = -1.f;
+        uint32_t bi = 0xffffffffu;
+        cv[0] = 0.f; qv[0] = 0.f; cv[1] = 0.f; qv[1] = 0.f;
+        if (in[0]) {
+            cv[0] = c0v[0] - ax;
+            qv[0] = ad;
+            const float a = cv[0] < 0.f ? -cv[0] : cv[0];
+            if (better_max(a, col[0], bv, bi)) { bv = a; bi = col[0]; }
+        }
+        block_reduce_pair<float, true>(bv, bi, sv, si);
+        cmax_v = bv;
+        cmax_i = bi;
+    };
     auto post_lambda = [&]() __attribute__((always_inline)) {
         ++tick;
         if (!SOLO && tid == 0)
@@ -573,6 +625,9 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     // hide its latency; the step-length exchange hides the in-place store pass of the inverse.
     if (K + 1u > P && P < kcap) {
         exit_code = 3;                               // (also caught at entry; kept for clarity)
+    } else if (SOLO) {
+        cq_pass();
+        post_lambda();
     } else {
         c_pass_and_post();
     }
@@ -594,7 +649,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         float* const qbuf = (tick & 1u) ? q_alt : q;
         // (the lambda words were posted before the inverse update: read this thread's slot now, use it below)
         const uint64_t early = (!SOLO && tid < nb) ? ld_u64(&smax[par + tid]) : kLaSlotEmpty;
-        gram_pass(S.ds, K, qv);
+        if (!SOLO) gram_pass(S.ds, K, qv);                    // (solo: q came with c, in cq_pass)
         if (SOLO) {
             // (scattered columns: 512 single-line stores per iteration would hold up every later barrier)
             if (tid < kSoloWidth) { s_cq[tid] = cv[0]; s_cq[kSoloWidth + tid] = qv[0]; }
@@ -785,8 +840,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         // The next iteration's c only needs the x just updated (a column that entered carries x = 0, one
         // that left carries an exact 0 in its old list entry): form it (the loads above are still in
         // flight) and start its lambda exchange now.
-        c_pass();
         const bool miss = added && slot < 0;
+        if (!SOLO || miss) c_pass();                          // (solo: after the new direction, together with q)
         const bool grow_next = !miss && (K_new + 1u > P) && (P < kcap);
         if (!grow_next) post_lambda();
 
@@ -938,6 +993,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         __syncthreads();
         pend = true; pend_added = added; pend_rk = rank; pend_dv = dv; pend_K = K_new;
         K = K_new;
+        if (SOLO) cq_pass();                                  // c and q of the next iteration (x updated, new direction)
         if (dbg != nullptr && lead && tid == 0 && round < 1024u) {
             ts[6] = wall_clock64();
             ts[7] = K;

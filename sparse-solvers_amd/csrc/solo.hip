@@ -336,7 +336,9 @@ struct CommitArgs {
     float* x; float* d; uint8_t* insup; uint32_t* gam2; float* inv0; float* inv1; uint32_t kcap; LaSync* sy;
 };
 
-__global__ __launch_bounds__(kVfThreads)
+constexpr int kPubThreads = 1024;            // 16 threads per log entry; the commit copies with all of them
+
+__global__ __launch_bounds__(kPubThreads)
 void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_t* __restrict__ v_max,
                    const uint64_t* __restrict__ v_min, uint32_t nvwg, uint32_t* hflags, CommitArgs ca)
 {
@@ -350,16 +352,16 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
     const uint32_t nlog = st->solo_nlog;
     if (tid == 0) { s_first = nlog; s_good = 0u; s_scan = 0u; }
     __syncthreads();
-    // four threads per entry
-    const uint32_t k = tid >> 2, sub = tid & 3u;
+    // sixteen threads per entry
+    const uint32_t k = tid >> 4, sub = tid & 15u;
     const bool has_scan = k < nlog && (log[kSoloHeaderWords + (size_t)k * kSoloEntryWords + 1] & 1u);
     if (pending == 1u && k < nlog) {
         uint32_t mx = 0u;
         uint64_t mn = ~0ull;
         const uint32_t* pm = v_max + (size_t)k * nvwg;
         const uint64_t* pn = v_min + (size_t)k * nvwg;
-        // this thread's quarter of the partials, sixteen independent loads at a time
-        const uint32_t per = (nvwg + 3u) / 4u;
+        // this thread's sixteenth of the partials, sixteen independent loads at a time
+        const uint32_t per = (nvwg + 15u) / 16u;
         const uint32_t b_lo = sub * per, b_hi = (b_lo + per < nvwg) ? b_lo + per : nvwg;
         for (uint32_t b0 = b_lo; b0 < b_hi; b0 += 16) {
             uint32_t a[16];
@@ -374,7 +376,7 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
             for (int t = 0; t < 16; ++t) { mx = a[t] > mx ? a[t] : mx; mn = c[t] < mn ? c[t] : mn; }
         }
 #pragma unroll
-        for (int o = 1; o < 4; o <<= 1) {
+        for (int o = 1; o < 16; o <<= 1) {
             mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
             const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mn, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mn >> 32), o);
             const uint64_t v = ((uint64_t)hi << 32) | lo;
@@ -433,17 +435,23 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
         uint32_t* const gam_alt = ca.gam2 + (size_t)(cur ^ 1u) * kcap;
         const uint32_t K0 = st->K;
         // the old support leaves the dense vectors and the membership flags ...
-        for (uint32_t j = tid; j < K0; j += kVfThreads) {
+        for (uint32_t j = tid; j < K0; j += kPubThreads) {
             const uint32_t cl = gam_cur[j];
             ca.x[cl] = 0.f; ca.d[cl] = 0.f; ca.insup[cl] = 0;
         }
         __syncthreads();
-        // ... the new one enters
-        for (uint32_t e = tid; e < K * K; e += kVfThreads) {
-            const uint32_t a = e / K, b = e - a * K;
-            Ig[(size_t)a * kcap + b] = __uint_as_float(sg[kSoloStageHead + 4 * LP + 1 + e]);
+        // ... the new one enters (the inverse: four independent elements per thread and step)
+        for (uint32_t e0 = tid; e0 < K * K; e0 += 4 * kPubThreads) {
+            uint32_t v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const uint32_t e = e0 + (uint32_t)t * kPubThreads; v[t] = e < K * K ? sg[kSoloStageHead + 4 * LP + 1 + e] : 0u; }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t e = e0 + (uint32_t)t * kPubThreads;
+                if (e < K * K) { const uint32_t a = e / K, b = e - a * K; Ig[(size_t)a * kcap + b] = __uint_as_float(v[t]); }
+            }
         }
-        for (uint32_t j = tid; j < K; j += kVfThreads) {
+        for (uint32_t j = tid; j < K; j += kPubThreads) {
             const uint32_t cl = sg[kSoloStageHead + j];
             gam_cur[j] = cl;
             ca.x[cl] = __uint_as_float(sg[kSoloStageHead + LP + j]);
@@ -451,7 +459,7 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
             ca.insup[cl] = 1;
         }
         if (save)
-            for (uint32_t j = tid; j < K + 1u; j += kVfThreads) gam_alt[j] = sg[kSoloStageHead + 3 * LP + j];
+            for (uint32_t j = tid; j < K + 1u; j += kPubThreads) gam_alt[j] = sg[kSoloStageHead + 3 * LP + j];
     }
     __syncthreads();
     if (tid != 0) return;
@@ -586,7 +594,7 @@ hipError_t launch_la_verify_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
     ca.stage = ws.solo_stage;
     ca.x = ws.x; ca.d = ws.d; ca.insup = ws.insup; ca.gam2 = ws.gam; ca.inv0 = ws.inv[0]; ca.inv1 = ws.inv[1];
     ca.kcap = ws.dims.kcap; ca.sy = ws.la_sync;
-    hipLaunchKernelGGL(k_la_vpublish, dim3(1), dim3(kVfThreads), 0, ctx->stream, (const uint32_t*)ws.solo_log, ws.st,
+    hipLaunchKernelGGL(k_la_vpublish, dim3(1), dim3(kPubThreads), 0, ctx->stream, (const uint32_t*)ws.solo_log, ws.st,
                        (const uint32_t*)ws.v_max, (const uint64_t*)ws.v_min, ws.nvwg, ctx->dev_flags, ca);
     return hipGetLastError();
 }
