@@ -337,7 +337,7 @@ def main():
             "batched": batched,
             "single_signal_with_gram_matrix": with_gram,
             "iterations_mean": float(iters.mean()),
-            "engine": "lookahead (cached Gram columns), resident iteration kernel" if engine >= 1 else "one fused sweep per iteration",
+            "engine": ("lookahead (cached Gram columns), speculative resident iterations (one workgroup + verification of every breakpoint)" if h.get_option("la_fused") >= 3 else "lookahead (cached Gram columns), resident iteration kernel") if engine >= 1 else "one fused sweep per iteration",
             "recovered": {"signals": world * args.steps, "support_exact": recovered_total,
                           "max_rel_coef_err_rank0": coef_err, "gathered_records_ok": bool(gather_ok)},
         }

@@ -223,11 +223,11 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    is below 2^-14 (fp32) / 2^-42 (fp64) * ||A^T y||_inf, too tight for Gram-form
  *                    correlations: such a solve runs as 0; 2 = lookahead engine unconditionally;
  *                    0 = one fused 2-RHS sweep per iteration (residual form).
- *   "la_fused"       form of the lookahead engine's iterations: 2 (default) = one resident launch
- *                    (k_la_persist, fp32; fp64 runs as 1), 1 = one launch per iteration, 0 = separate kernels,
- *                    3 = speculative form of the resident launch: one workgroup iterates on a 256-column
- *                    subset, every breakpoint is re-derived over all columns before anything is committed
- *                    (same results bit for bit; measured slower than 2, kept as an option)
+ *   "la_fused"       form of the lookahead engine's iterations: 3 (default, fp32) = speculative resident form:
+ *                    one workgroup iterates on a 256-column subset and every breakpoint is re-derived over
+ *                    all columns, bit for bit, before anything is committed; 2 = one resident launch on all
+ *                    CUs (k_la_persist, fp32; same results as 3; fp64 runs as 1), 1 = one launch per
+ *                    iteration, 0 = separate kernels
  *   "solo_subset"    columns beyond the support a speculative launch may hold (default 256; tests use small
  *                    values to provoke failed verifications)
  *   "sweep32_variant" tiling of the 32-RHS lookahead sweep (0 default; 1-7 measured alternatives, same results)

@@ -593,12 +593,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
-            // Speculative form (fp32, exact zeros on removal like the resident kernel): on request only
+            // Speculative form (fp32, exact zeros on removal like the resident kernel): the default
             // (la_fused = 3).  It also runs where the resident kernel cannot (dictionaries too wide for one
-            // launch to own every column); measured at n = 2^20 it does not pay there yet — its verification
-            // pass repeats a per-workgroup prologue 4096 times.
+            // launch to own every column).
             const bool solo_wanted = ctx->la_fused >= 3;
-            solo = solo_wanted && !no_solo && ctx->solo_off_solves == 0 && ctx->zero_on_removal && sizeof(T) == 4 && la_solo_usable(ctx);
+            // (not with the full Gram matrix as the cache: there every entering column's row slice is a gather of
+            // 256 scattered entries of a 256-KiB row in the iteration's chain — 1.81 ms per C2 solve against 1.55 ms)
+            solo = solo_wanted && !no_solo && ctx->solo_off_solves == 0 && ctx->zero_on_removal && sizeof(T) == 4 &&
+                   (!ws.gram_is_full || ctx->solo_full_gram) && la_solo_usable(ctx);
             if (solo_wanted && !solo && ctx->solo_off_solves > 0 && !no_solo) ctx->solo_off_solves -= 1;
             solo_started = solo;
             Lookahead<T>::init(ctx, ws, nb1, tol, solo);
@@ -1428,6 +1430,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(7, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_subset"))   { ctx->solo_subset = (int)std::max<long>(0, std::min<long>(256, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "solo_full_gram")) { ctx->solo_full_gram = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { ctx->cache_mib = std::max<long>(16, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_gram_min")) { ctx->batch_gram_min = (int)std::max<long>(0, value); return SS_HIP_OK; }

@@ -240,8 +240,9 @@ struct ss_hip_ctx {
     long cache_mib = 2048;   // budget of the lookahead engine's Gram-column cache
     int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns) unless the tolerance is too tight for it, 2 = lookahead always, 0 = one fused sweep per iteration
     int sweep32_variant = 0; // lookahead sweep tiling: 0 = 256 columns x 512 threads (1 per CU), 1 / 2 = 128 columns x 256 threads (2 / 3 per CU)
-    int la_fused = 2;        // lookahead engine: 2 = resident kernel (k_la_persist), 3 = its speculative form (one workgroup + verification, solo.hip: correct but measured slower), 1 = one kernel per iteration (k_la_iter), 0 = scan / update / cq kernels
+    int la_fused = 3;        // lookahead engine: 3 = speculative form of the resident kernel (one workgroup + verification of every breakpoint, solo.hip), 2 = resident kernel (k_la_persist), 1 = one kernel per iteration (k_la_iter), 0 = scan / update / cq kernels
     int solo_subset = 256;   // option (tests): columns a solo launch may hold (<= 256; small values provoke verification failures)
+    int solo_full_gram = 0;  // option (tests): let the speculative form run with the full Gram matrix as the cache too
     int solo_off_solves = 0; // solves left for which the speculative form stays off after repeated verification failures
     int batch_min = 192;     // batches of at least this many fp32 signals run in lock-step on the MFMA GEMM (below: one lookahead solve per signal, ~2.4 ms each at C2, is faster)
     int batch_chunk = 4096;  // signals processed together by the batched path

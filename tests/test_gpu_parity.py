@@ -899,6 +899,7 @@ def test_full_gram_single_signal(sship, la_fused):
     with sship.Homotopy(A) as h:
         h.set_option("gram_full_after", 1)
         h.set_option("la_fused", la_fused)
+        h.set_option("solo_full_gram", 1)       # (the speculative form stays off in this mode by default: slower there)
         h.set_option("trace", 1)
         for rep in range(2):
             xg, itg, eg = h.solve(y, 1e-3, 4 * k)
