@@ -217,6 +217,9 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     __shared__ uint64_t s_off[SOLO ? kPsThreads : 1];          // solo: candidate offers while the subset is built
     __shared__ uint32_t s_sps[SOLO ? kSoloListPitch : 1];      // solo: subset position of each support column
     __shared__ uint32_t s_ipos;                                // solo: subset position of the entering column
+    __shared__ float s_sgv[SOLO ? kPsThreads / 64 : 1];        // solo: per-wave best step-length candidate on the support ...
+    __shared__ uint32_t s_sgi[SOLO ? kPsThreads / 64 : 1];     // ... and its column
+    __shared__ float s_c0[SOLO ? kSoloWidth : 1];              // solo: c0 of the subset's columns
     __shared__ float s_cq[SOLO ? 2 * kSoloWidth : 1];          // solo: c, q of the subset (the resident form hands them through global memory)
 
     const uint32_t tid = threadIdx.x;
@@ -355,6 +358,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             if (cl < n) sa.sub_pos[cl] = (uint8_t)tid;
         }
         if (tid < kSoloListPitch) s_sps[tid] = tid;             // the support leads the subset, in order
+        if (tid < kSoloWidth) s_c0[tid] = s_sub[tid] < n ? c0[s_sub[tid]] : 0.f;
     }
     // ---- replica of the active set ---------------------------------------------------------------------
     const uint32_t cur = st->cur;
@@ -511,48 +515,55 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     // solo: c and q in ONE pass over the rows (no exchange has to be posted in between, and each Gram
     // value is read once).  Per column the two sums are formed exactly as by the separate passes.
     auto cq_pass = [&]() __attribute__((always_inline)) {
-        float ax = 0.f, ad = 0.f;
-        if (__ballot(in[0]) != 0ull) {
-            const uint32_t cofs4 = (in[0] ? col[0] : 0u) * 4u;
+        // all eight waves: wave w, lanes 0..31 form sum_j x_j g_j and lanes 32..63 sum_j d_j g_j of the 32
+        // columns 32w .. 32w+31 of the subset (one sum per lane; a packed two-column variant measured the same:
+        // the pass is bound by the latency of its LDS reads, not by instruction issue)
+        {
+            const uint32_t t = (uint32_t)wave * 32u + ((uint32_t)lane & 31u);       // subset position
+            const bool dsum = lane >= 32;
+            const uint32_t ccol = s_sub[t];
+            const uint32_t cofs4 = (ccol < n ? ccol : 0u) * 4u;
+            const float* coef = dsum ? S.ds : S.xs;
             const uint32_t K16 = (K + (kPsGroup - 1u)) & ~(kPsGroup - 1u);
-            const uint32_t tcol = tid & (kPsWidth - 1u);
+            float acc = 0.f;
             for (uint32_t j0 = 0; j0 < K16; j0 += 64) {
                 const uint32_t jl = j0 + (uint32_t)lane;
                 const uint32_t vs = S.slt[jl < K ? jl : 0u];
                 const uint32_t vl = S.lrw[jl < K ? jl : 0u];
                 const uint32_t cnt = K16 - j0 < 64u ? K16 - j0 : 64u;
-                const float* cx = S.xs + j0;
-                const float* cd = S.ds + j0;
+                const float* cf = coef + j0;
                 const uint64_t out_of_lds = __ballot(vl == kNoLdsRow);
                 for (uint32_t u = 0; u < cnt; u += kPsGroup) {
                     float gv[kPsGroup];
                     if (((out_of_lds >> u) & ((1ull << kPsGroup) - 1ull)) == 0ull) {
 #pragma unroll
-                        for (int t = 0; t < (int)kPsGroup; ++t) gv[t] = Glds[__builtin_amdgcn_readlane(vl, u + t) * kPsWidth + tcol];
+                        for (int q2 = 0; q2 < (int)kPsGroup; ++q2) gv[q2] = Glds[__builtin_amdgcn_readlane(vl, u + q2) * kPsWidth + t];
                     } else {
 #pragma unroll
-                        for (int t = 0; t < (int)kPsGroup; ++t) {
-                            const uint32_t lr = __builtin_amdgcn_readlane(vl, u + t);
-                            gv[t] = 0.f;
-                            if (lr == kNoLdsRow) gv[t] = grow_global(__builtin_amdgcn_readlane(vs, u + t), cofs4);
+                        for (int q2 = 0; q2 < (int)kPsGroup; ++q2) {
+                            const uint32_t lr = __builtin_amdgcn_readlane(vl, u + q2);
+                            gv[q2] = 0.f;
+                            if (lr == kNoLdsRow) gv[q2] = grow_global(__builtin_amdgcn_readlane(vs, u + q2), cofs4);
                         }
 #pragma unroll
-                        for (int t = 0; t < (int)kPsGroup; ++t) {
-                            const uint32_t lr = __builtin_amdgcn_readlane(vl, u + t);
-                            if (lr != kNoLdsRow) gv[t] = Glds[lr * kPsWidth + tcol];
+                        for (int q2 = 0; q2 < (int)kPsGroup; ++q2) {
+                            const uint32_t lr = __builtin_amdgcn_readlane(vl, u + q2);
+                            if (lr != kNoLdsRow) gv[q2] = Glds[lr * kPsWidth + t];
                         }
                     }
 #pragma unroll
-                    for (int t = 0; t < (int)kPsGroup; ++t) { ax += cx[u + t] * gv[t]; ad += cd[u + t] * gv[t]; }
+                    for (int q2 = 0; q2 < (int)kPsGroup; ++q2) acc += cf[u + q2] * gv[q2];
                 }
             }
+            s_cq[(dsum ? kSoloWidth : 0u) + t] = dsum ? acc : s_c0[t] - acc;
         }
+        __syncthreads();
         float bv = -1.f;
         uint32_t bi = 0xffffffffu;
         cv[0] = 0.f; qv[0] = 0.f; cv[1] = 0.f; qv[1] = 0.f;
         if (in[0]) {
-            cv[0] = c0v[0] - ax;
-            qv[0] = ad;
+            cv[0] = s_cq[tid];
+            qv[0] = s_cq[kSoloWidth + tid];
             const float a = cv[0] < 0.f ? -cv[0] : cv[0];
             if (better_max(a, col[0], bv, bi)) { bv = a; bi = col[0]; }
         }
@@ -702,7 +713,20 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             mk[k] = m;
             if (m < Lim<float>::max() && better_min(m, col[k], best, best_i)) { best = m; best_i = col[k]; }
         }
-        drain_vmem();                                      // this wave's c, q stores are performed
+        if (SOLO) {
+            // the support's own candidates, -x_j / d_j (homotopy-cpu.cpp:128-135): reduced per wave here, the
+            // per-wave results ride on the barriers of the block reduction below
+            float gw = Lim<float>::max();
+            uint32_t iw = 0xffffffffu;
+            if (tid < K) {
+                const float t = -S.xs[tid] / S.ds[tid];
+                if (t > 0.f && t < Lim<float>::max()) { gw = t; iw = S.gam[tid]; }
+            }
+            wave_reduce_pair<float, false>(gw, iw);
+            if (lane == 0) { s_sgv[wave] = gw; s_sgi[wave] = iw; }
+        } else {
+            drain_vmem();                                  // this wave's c, q stores are performed
+        }
         block_reduce_pair<float, false>(best, best_i, sv, si);
         if (!SOLO && tid == 0)
             st_u64(&smin[par + w], best_i != 0xffffffffu ? (((uint64_t)__float_as_uint(best) << 32) | (uint64_t)best_i) : kLaSlotNone);
@@ -716,7 +740,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         // ... and the active columns, -x_j / d_j (homotopy-cpu.cpp:128-135), from the replica
         float g = Lim<float>::max();
         uint32_t idx = 0xffffffffu;
-        if (tid < K) {
+        if (!SOLO && tid < K) {
             const float t = -S.xs[tid] / S.ds[tid];
             if (t > 0.f && t < Lim<float>::max()) { g = t; idx = S.gam[tid]; }
         }
@@ -725,7 +749,9 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         if (SOLO) {
             // support candidates alone (logged: the verification merges them with ITS candidates), then
             // merged with the subset's best
-            block_reduce_pair<float, false>(g, idx, sv, si);
+#pragma unroll
+            for (int w2 = 0; w2 < kPsThreads / 64; ++w2)
+                if (better_min(s_sgv[w2], s_sgi[w2], g, idx)) { g = s_sgv[w2]; idx = s_sgi[w2]; }
             gs_log = g; is_log = idx;
             if (best_i != 0xffffffffu && better_min(best, best_i, g, idx)) { g = best; idx = best_i; }
         } else {
@@ -993,10 +1019,10 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         __syncthreads();
         pend = true; pend_added = added; pend_rk = rank; pend_dv = dv; pend_K = K_new;
         K = K_new;
+        ts[6] = wall_clock64();
         if (SOLO) cq_pass();                                  // c and q of the next iteration (x updated, new direction)
         if (dbg != nullptr && lead && tid == 0 && round < 1024u) {
-            ts[6] = wall_clock64();
-            ts[7] = K;
+            ts[7] = wall_clock64();
             for (int k2 = 0; k2 < 8; ++k2) dbg[(size_t)round * 8 + k2] = ts[k2];
         }
         if (grow_next) {
@@ -1156,12 +1182,20 @@ hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float to
 }
 
 // ---- speculative form: one workgroup, first LDS tier ---------------------------------------------------
+// (its static LDS — subset, offers, position tables, c0 / c / q of the subset — takes ~9 KiB of the 160 KiB:
+// the Gram slice gets 96 rows instead of 112; a launch that does not fit is refused, never silently shrunk)
+constexpr uint32_t kSoloGlRows = 96;
+static size_t solo_lds_bytes()
+{
+    return ps_lds_words(persist_tier_cols(kLaLdsSmall)) * sizeof(float) + (size_t)kSoloGlRows * kPsWidth * sizeof(float);
+}
+
 bool la_solo_usable(ss_hip_ctx* ctx)
 {
     if (ctx->n >= (1u << 30)) return false;
     if (ctx->solo_attr_set < 0) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_la_persist<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(kLaLdsSmall));
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)solo_lds_bytes());
         if (e != hipSuccess) (void)hipGetLastError();
         ctx->solo_attr_set = e == hipSuccess ? 1 : 0;
     }
@@ -1172,7 +1206,7 @@ hipError_t launch_la_solo_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
 {
     const uint32_t P = kLaLdsSmall;
     if (!la_solo_usable(ctx) || ws.cq_alt == nullptr || ws.solo_log == nullptr || ws.solo_stage == nullptr) return hipErrorInvalidConfiguration;
-    const size_t lds = persist_lds_bytes(P);
+    const size_t lds = solo_lds_bytes();
     uint64_t* smax = reinterpret_cast<uint64_t*>(ws.la_sync + 1);
     uint64_t* smin = smax + 2 * kLaSlotStride;
     SoloArgs sa;
@@ -1183,7 +1217,7 @@ hipError_t launch_la_solo_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     sa.log = ws.solo_log;
     sa.sub_pos = ws.sub_pos;
     sa.stage = ws.solo_stage;
-    hipLaunchKernelGGL(k_la_persist<true>, dim3(1), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, persist_gl_rows(P), ws.gram_is_full ? 1 : 0,
+    hipLaunchKernelGGL(k_la_persist<true>, dim3(1), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, kSoloGlRows, ws.gram_is_full ? 1 : 0,
                        (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
                        ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg, sa);

@@ -3,9 +3,9 @@
 import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(2048, 8)
-rows = [r for r in range(1, 1024) if a[r, 0] != 0 and a[r, 6] > a[r, 0]]
-names = ["q pass + stores", "lambda poll", "scan + step exchange", "pick, x, c pass, post", "u2, d, lists", "sign + direction"]
-d = np.array([[(int(a[r, k + 1]) - int(a[r, k])) / 100.0 for k in range(6)] for r in rows])
+rows = [r for r in range(1, 1024) if a[r, 0] != 0 and a[r, 6] > a[r, 0] and a[r, 7] >= a[r, 6]]
+names = ["q pass + stores", "lambda poll", "scan + step exchange", "pick, x, c pass, post", "u2, d, lists", "sign + direction", "c/q pass (solo)"]
+d = np.array([[(int(a[r, k + 1]) - int(a[r, k])) / 100.0 for k in range(7)] for r in rows])
 print("launch info (last): lds rows used %d, workgroups %d, lds rows %d, K at entry %d" % tuple(int(v) for v in a[0, :4]))
 for r in range(1600, 1700):
     if a[r, 7] > a[r, 0]:
@@ -20,4 +20,4 @@ if gaps:
     print("  iteration to iteration mean %6.2f us (end of one to start of the next)" % np.mean(gaps))
 if len(sys.argv) > 2:
     for r, row in zip(rows, d):
-        print(r, " ".join("%6.2f" % v for v in row), "K", int(a[r, 7]))
+        print(r, " ".join("%6.2f" % v for v in row))
