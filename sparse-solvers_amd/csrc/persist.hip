@@ -998,7 +998,10 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         // The new inverse is not stored yet: its elements are formed on the fly, by the same
         // expressions the store pass uses; the store pass runs during the next step-length exchange.
         if (tid < K_new) S.sg[tid] = sign_tol(S.cn[tid], tol);
-        __syncthreads();
+        // (solo: no exchange to hide the store pass behind — the inverse is stored first and read back plainly;
+        // the stored elements are the values the on-the-fly expressions give)
+        if (SOLO) store_new_inverse(S.I, Pp, S.u2, added, rank, dv, K_new);
+        else __syncthreads();
         for (uint32_t a0 = wave; a0 < K_new; a0 += 4 * NW) {
             float acc[4];
 #pragma unroll
@@ -1007,7 +1010,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 acc[r] = 0.f;
                 if (a < K_new)
                     for (uint32_t b = lane; b < K_new; b += 64)
-                        acc[r] += new_inverse_elem(S.I, Pp, S.u2, added, rank, dv, a, b) * S.sg[b];
+                        acc[r] += (SOLO ? S.I[a * Pp + b] : new_inverse_elem(S.I, Pp, S.u2, added, rank, dv, a, b)) * S.sg[b];
             }
             wave_sum4(acc);
 #pragma unroll
@@ -1017,7 +1020,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             }
         }
         __syncthreads();
-        pend = true; pend_added = added; pend_rk = rank; pend_dv = dv; pend_K = K_new;
+        pend = !SOLO; pend_added = added; pend_rk = rank; pend_dv = dv; pend_K = K_new;
         K = K_new;
         ts[6] = wall_clock64();
         if (SOLO) cq_pass();                                  // c and q of the next iteration (x updated, new direction)
@@ -1026,7 +1029,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             for (int k2 = 0; k2 < 8; ++k2) dbg[(size_t)round * 8 + k2] = ts[k2];
         }
         if (grow_next) {
-            store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K);
+            if (pend) store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K);
             pend = false;
             exit_code = 3;
         }
