@@ -33,7 +33,7 @@
 namespace sship {
 
 constexpr int kVfThreads = 256;
-constexpr uint32_t kVfUnion = 128;           // support columns a chunk of breakpoints can involve (96 + 32)
+constexpr uint32_t kVfUnion = 144;           // support columns a chunk of breakpoints can involve (96 + 40, rounded up)
 constexpr uint32_t kVfRedPitch = kSoloWidth + 16;    // row pitch of the reduction buffer (16 readers per row: conflict-free)
 
 // the two best (smallest key, then smallest column) of the block's offers -> out[0], out[1]
@@ -70,8 +70,8 @@ void k_la_cand_init(const float* __restrict__ c0, uint32_t n, const DevState* __
     block_top2(key, cl, cand_top + 2 * (size_t)blockIdx.x, sv, si);
 }
 
-// Two threads per column: thread (half h, column t) carries the 16 breakpoints 16h .. 16h+15 of a chunk
-// (32 accumulators instead of 64: two waves per SIMD can be resident and hide each other's LDS latency).
+// Two threads per column: thread (half h, column t) carries the breakpoints 20h .. 20h+19 of a chunk
+// (40 accumulators: two waves per SIMD can be resident and hide each other's LDS latency).
 constexpr int kVfyThreads = 2 * (int)kSoloWidth;
 constexpr uint32_t kVfHalf = kSoloChunk / 2;
 
@@ -90,7 +90,9 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
     __shared__ uint64_t sRed[kSoloChunk * kVfRedPitch]; // reductions: one row per breakpoint
     __shared__ __attribute__((aligned(16))) uint32_t s_sub[kSoloWidth];   // header: columns of the subset
     __shared__ uint32_t s_row[kSoloWidth];              // header: their Gram rows
-    __shared__ __attribute__((aligned(16))) uint32_t s_pres[kSoloWidth];  // bit k: position is in the support at breakpoint k
+    __shared__ uint32_t s_pres[kSoloWidth];             // bit k: position is in the support at breakpoint k (k < 32) ...
+    __shared__ uint32_t s_preh[kSoloWidth];             // ... and at breakpoint 32 + k
+    __shared__ __attribute__((aligned(16))) uint32_t s_part[kSoloWidth];  // != 0: position is in the support at some breakpoint of the chunk
     __shared__ uint32_t s_rank[kSoloWidth];             // position -> index in the union (sorted by column)
     __shared__ uint32_t s_urow[kVfUnion];               // union index -> Gram row
     __shared__ uint32_t s_hdr[kSoloChunk][8];
@@ -134,7 +136,7 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
         const uint32_t J = nlog - k0 < kSoloChunk ? nlog - k0 : kSoloChunk;
         __syncthreads();
         // ---- the chunk's union of support columns, sorted by column; coefficient tables ---------------
-        if (tid < kSoloWidth) s_pres[tid] = 0u;
+        if (tid < kSoloWidth) { s_pres[tid] = 0u; s_preh[tid] = 0u; }
         // the chunk's entries, one bulk copy into LDS (the reduction buffer is free here): everything below
         // reads them from there — loads from the log issued entry by entry cost a memory round trip each
         uint32_t* const sE = reinterpret_cast<uint32_t*>(sRed);
@@ -156,15 +158,20 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
         for (uint32_t pr = tid; pr < J * kSoloListPitch; pr += kVfyThreads) {
             const uint32_t k = pr / kSoloListPitch, j = pr - k * kSoloListPitch;
             const uint32_t* e = sE + k * kSoloEntryWords;
-            if (j < e[0]) atomicOr(&s_pres[e[8 + kSoloListPitch + j] & (kSoloWidth - 1u)], 1u << k);
+            if (j < e[0]) {
+                const uint32_t pos = e[8 + kSoloListPitch + j] & (kSoloWidth - 1u);
+                if (k < 32u) atomicOr(&s_pres[pos], 1u << k); else atomicOr(&s_preh[pos], 1u << (k - 32u));
+            }
         }
         __syncthreads();
+        if (tid < kSoloWidth) s_part[tid] = s_pres[tid] | s_preh[tid];
+        __syncthreads();
         if (tid < kSoloWidth) {
-            const bool part = s_pres[tid] != 0u;
+            const bool part = s_part[tid] != 0u;
             const uint32_t mycol = s_sub[tid];
             uint32_t r = 0;
             if (part) {
-                const uint4* p4 = reinterpret_cast<const uint4*>(s_pres);
+                const uint4* p4 = reinterpret_cast<const uint4*>(s_part);
                 const uint4* c4 = reinterpret_cast<const uint4*>(s_sub);
 #pragma unroll 8
                 for (uint32_t u = 0; u < kSoloWidth / 4; ++u) {
@@ -224,10 +231,10 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
                     const float* xr = sX[r0 + t] + kb;
                     const float* dr = sD[r0 + t] + kb;
 #pragma unroll
-                    for (int kg = 0; kg < (int)kVfHalf; kg += 8) {
-                        if (kb + (uint32_t)kg >= J) break;             // (uniform per wave: whole groups of 8 breakpoints)
+                    for (int kg = 0; kg < (int)kVfHalf; kg += 4) {
+                        if (kb + (uint32_t)kg >= J) break;             // (uniform per wave: whole groups of 4 breakpoints)
 #pragma unroll
-                        for (int k = kg; k < kg + 8; ++k) {
+                        for (int k = kg; k < kg + 4; ++k) {
                             ax[k] += xr[k] * g;
                             ad[k] += dr[k] * g;
                         }
@@ -246,8 +253,8 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
             red32[(kb + k) * kVfRedPitch + tcol] = (valid && kb + (uint32_t)k < J) ? (__float_as_uint(a) & 0x7fffffffu) : 0u;
         }
         __syncthreads();
-        {
-            const uint32_t k = tid >> 4, sub = tid & 15u;
+        for (uint32_t k = tid >> 4; k < kSoloChunk; k += kVfyThreads / 16) {
+            const uint32_t sub = tid & 15u;
             uint32_t m = 0u;
             for (uint32_t j = 0; j < kSoloWidth / 16; ++j) {
                 const uint32_t v = red32[k * kVfRedPitch + j * 16u + sub];
@@ -262,6 +269,7 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
         if (k0 == 0) tsv[5] = wall_clock64();
         // ---- step-length candidates per breakpoint (find_max_gamma's off-support part, :137-159) --------
         const uint32_t pres = mypos != 0xffffffffu ? s_pres[mypos] : 0u;
+        const uint32_t preh = mypos != 0xffffffffu ? s_preh[mypos] : 0u;
         float m_last = Lim<float>::max();
         bool act_last = false, own_last = false;
 #pragma unroll
@@ -269,7 +277,7 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
             const uint32_t kk = kb + (uint32_t)k;
             uint64_t pk = ~0ull;
             if (valid && kk < J && (s_hdr[kk][1] & 1u)) {
-                const bool act = (pres >> kk) & 1u;
+                const bool act = kk < 32u ? ((pres >> kk) & 1u) : ((preh >> (kk - 32u)) & 1u);
                 float m = Lim<float>::max();
                 if (!act) {
                     const float c_inf = __uint_as_float(s_hdr[kk][4]);
@@ -292,8 +300,8 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
             sRed[kk * kVfRedPitch + tcol] = pk;
         }
         __syncthreads();
-        {
-            const uint32_t k = tid >> 4, sub = tid & 15u;
+        for (uint32_t k = tid >> 4; k < kSoloChunk; k += kVfyThreads / 16) {
+            const uint32_t sub = tid & 15u;
             uint64_t m = ~0ull;
             for (uint32_t j = 0; j < kSoloWidth / 16; ++j) {
                 const uint64_t v = sRed[k * kVfRedPitch + j * 16u + sub];

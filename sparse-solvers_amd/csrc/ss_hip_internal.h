@@ -115,7 +115,7 @@ constexpr uint32_t kSoloHeaderWords = 512;
 //   then gam[P], bits(x_S)[P], bits(d_S)[P], gam_new[P + 1] (with [1]), inverse [K][K]
 constexpr uint32_t kSoloStageHead = 16;
 constexpr uint32_t kSoloStageWords = kSoloStageHead + 4 * kSoloListPitch + 1 + kSoloListPitch * kSoloListPitch;
-constexpr uint32_t kSoloChunk = 32;                           // breakpoints verified per pass over the Gram rows
+constexpr uint32_t kSoloChunk = 40;                           // breakpoints verified per pass over the Gram rows (a phase of ~33 entries fits one)
 constexpr uint32_t kSoloWidth = 256;                          // columns of a solo launch / of a verify workgroup
 
 // optional per-iteration record of the homotopy path (ss_hip_get_trace)
