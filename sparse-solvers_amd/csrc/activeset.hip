@@ -1592,12 +1592,47 @@ hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode)
     return hipGetLastError();
 }
 
+// ---- k_la_reset: everything a lookahead solve clears before its first sweep, in ONE launch (ten small
+// ---- memsets / copies on the stream cost ~4 us each): x, d, membership flags, the slot map (-1), the
+// ---- exchange area of the resident kernel, DevState, and r = y for the A^T y sweep
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_la_reset(T* __restrict__ x, T* __restrict__ d, uint8_t* __restrict__ insup, int32_t* __restrict__ slot_of,
+                uint32_t n_pad, uint32_t* __restrict__ la_sync, uint32_t sync_head_words, uint32_t sync_words,
+                uint32_t* __restrict__ st_words, uint32_t st_nwords, uint32_t* __restrict__ ndone,
+                const T* __restrict__ y, T* __restrict__ rhs, uint32_t ldm)
+{
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    for (uint32_t i = gtid; i < n_pad; i += gsz) {
+        x[i] = T(0); d[i] = T(0); insup[i] = 0;
+        if (slot_of != nullptr) slot_of[i] = -1;
+    }
+    for (uint32_t i = gtid; i < ldm; i += gsz) rhs[i] = y[i];
+    for (uint32_t i = gtid; i < sync_words; i += gsz) la_sync[i] = i < sync_head_words ? 0u : 0xffffffffu;
+    for (uint32_t i = gtid; i < st_nwords; i += gsz) st_words[i] = 0u;
+    if (gtid == 0) *ndone = 0u;
+}
+
+template <typename T>
+hipError_t launch_la_reset(const ss_hip_ctx* ctx, Workspace<T>& ws, bool clear_slots)
+{
+    const uint32_t grid = std::min<uint32_t>((ctx->n_pad + kSmallThreads - 1) / kSmallThreads, 256u);
+    hipLaunchKernelGGL((k_la_reset<T>), dim3(grid), dim3(kSmallThreads), 0, ctx->stream, ws.x, ws.d, ws.insup,
+                       clear_slots ? ws.slot_of : (int32_t*)nullptr, ctx->n_pad, reinterpret_cast<uint32_t*>(ws.la_sync),
+                       (uint32_t)(sizeof(LaSync) / 4), (uint32_t)(kLaSyncBytes / 4), reinterpret_cast<uint32_t*>(ws.st),
+                       (uint32_t)(sizeof(DevState) / 4), ws.ndone, (const T*)ws.y, ws.rhs, ctx->ldm);
+    return hipGetLastError();
+}
+template hipError_t launch_la_reset<float>(const ss_hip_ctx*, Workspace<float>&, bool);
+template hipError_t launch_la_reset<double>(const ss_hip_ctx*, Workspace<double>&, bool);
+
 template <typename T>
 hipError_t launch_la_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol)
 {
+    // (round 0: the first sign is taken from c0 = A^T y itself)
     hipLaunchKernelGGL((k_gramupd<T>), dim3(1, 1), dim3(kUpdThreads), 0, ctx->stream,
                        static_cast<const T*>(ctx->At), ws.dims, ws.gam, ws.inv[0], ws.inv[1],
-                       ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 0, (const T*)nullptr, (T*)nullptr,
+                       ws.u1, ws.u2, ws.sgn, round == 0 ? (const T*)ws.c0 : (const T*)ws.c, ws.q, ws.d, tol, ws.st, 0, (const T*)nullptr, (T*)nullptr,
                        (const T*)ws.gcache, (const int32_t*)ws.slot_of, ws.gpitch, round == 0 ? 1 : 0, ctx->strict_sign);
     return hipGetLastError();
 }

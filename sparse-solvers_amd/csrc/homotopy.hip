@@ -385,14 +385,9 @@ template <typename T> struct Lookahead {
     {
         hipStream_t st = ctx->stream;
         const bool full = ws.gram_is_full;                      // every column is "cached": no sweep, ever
-        if (!full) HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // -1
-        {   // hand-off area of the resident kernel: header and triples zero, offer slots "empty"
-            const size_t head = sizeof(LaSync);
-            HIPCHK(hipMemsetAsync(ws.la_sync, 0, head, st));
-            HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(ws.la_sync) + head, 0xff, kLaSyncBytes - head, st));
-        }
+        // (the slot map, the hand-off area of the resident kernel and the dense vectors were cleared by
+        // k_la_reset before the sweep; the first sign is read from c0 itself)
         if (ws.la_dbg) HIPCHK(hipMemsetAsync(ws.la_dbg, 0, 2048 * 8 * sizeof(uint64_t), st));
-        HIPCHK(hipMemcpyAsync(ws.c, ws.c0, (size_t)ctx->n_pad * sizeof(T), hipMemcpyDeviceToDevice, st));
         HIPCHK(launch_la_init_pick<T>(ctx, ws, nparts, tol, full));
         if (solo) HIPCHK(launch_cand_init(ctx, ws));           // per-block tops of |c0|: ranking of the first sweep and subset
         if (!full) {
@@ -541,12 +536,15 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         ctx->host_flags[4] = 0;
         if (prof) HIPCHK(hipEventRecord(ctx->ev_solve0, st));
         copy_in<T>(ctx, ws.y, y, incy, m);
-        HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)ctx->n_pad * sizeof(T), st));
-        HIPCHK(hipMemsetAsync(ws.d, 0, (size_t)ctx->n_pad * sizeof(T), st));
-        HIPCHK(hipMemsetAsync(ws.insup, 0, (size_t)ctx->n_pad, st));
-        HIPCHK(hipMemsetAsync(ws.st, 0, sizeof(DevState), st));
-        HIPCHK(hipMemsetAsync(ws.ndone, 0, sizeof(uint32_t), st));
-        HIPCHK(hipMemcpyAsync(ws.rhs, ws.y, (size_t)ctx->ldm * sizeof(T), hipMemcpyDeviceToDevice, st));
+        const bool la_path = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual;
+        if (!la_path) {
+            HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)ctx->n_pad * sizeof(T), st));
+            HIPCHK(hipMemsetAsync(ws.d, 0, (size_t)ctx->n_pad * sizeof(T), st));
+            HIPCHK(hipMemsetAsync(ws.insup, 0, (size_t)ctx->n_pad, st));
+            HIPCHK(hipMemsetAsync(ws.st, 0, sizeof(DevState), st));
+            HIPCHK(hipMemsetAsync(ws.ndone, 0, sizeof(uint32_t), st));
+        }
+        if (!la_path) HIPCHK(hipMemcpyAsync(ws.rhs, ws.y, (size_t)ctx->ldm * sizeof(T), hipMemcpyDeviceToDevice, st));
         const size_t rhs_stride = (size_t)ws.dims.b_pad * ctx->ldm;   // r-block -> p-block
 
         const bool la = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual;
@@ -589,6 +587,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         } else if (la) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             enter_full_gram();
+            HIPCHK(launch_la_reset<T>(ctx, ws, !ws.gram_is_full));     // x, d, flags, slot map, exchange area, DevState, r = y
             uint32_t nb1 = 0;
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));

@@ -299,6 +299,9 @@ template <typename T>
 hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode);
 template <typename T>
 hipError_t launch_la_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol);
+// one launch for everything a lookahead solve clears before its first sweep (and r = y)
+template <typename T>
+hipError_t launch_la_reset(const ss_hip_ctx* ctx, Workspace<T>& ws, bool clear_slots);
 template <typename T>
 hipError_t launch_la_cq(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t* nparts_out);
 // fused iteration of the lookahead engine (c, q from the cache; scan; select; update)
