@@ -637,9 +637,10 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             bool stuck = false;
             for (;;) {
                 uint32_t spins = 0;
-                // (a solo group runs until the host has to act — fetch, hand-over, end — so two groups in
-                // flight are enough; every further one is three launches that find nothing to do)
-                const uint32_t depth = solo ? std::min<uint32_t>(L, 2u) : L;
+                // (a solo group runs until the host has to act — fetch, hand-over, end — so one group in
+                // flight is enough: every further one is three launches that find nothing to do; after
+                // the hand-over, near the end of the path, two resident launches)
+                const uint32_t depth = solo ? 1u : (solo_started ? std::min<uint32_t>(L, 2u) : L);
                 while (hf[1] == 0 && hf[2] == handled && enq >= (uint64_t)hf[0] + depth) {
                     if ((++spins & 0x3ffu) == 0) {
                         const hipError_t qs = hipStreamQuery(st);
