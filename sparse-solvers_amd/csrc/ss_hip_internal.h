@@ -57,17 +57,15 @@ struct DevState {
     uint32_t nmiss;       // iterations that had to wait for a lookahead sweep (mirrored to hflags[2])
     uint32_t bar_rounds;  // k_la_iter launches that went through the grid barrier (bar_count = this * grid)
     // speculative ("solo") form of the resident kernel: one workgroup iterates on a column subset, its
-    // breakpoints are checked against all columns afterwards (solo.hip); the outcome of a solo launch is
-    // staged here and reaches the host flags only once it is verified
+    // breakpoints are checked against all columns afterwards (solo.hip); what a solo launch leaves behind is
+    // staged (Workspace::solo_stage) and becomes the state of the solve only once it is verified
     uint32_t solo_off;     // 1: the rest of this solve runs in the resident form (k_la_persist / k_la_iter)
     uint32_t solo_pending; // 1: a solo launch has run and awaits k_la_verify + k_la_vpublish; 2: a replay (already verified) awaits its commit
-    uint32_t pub_kind;     // staged outcome: 0 none, 1 solve finished, 2 Gram column missing, 3 support outgrew the LDS tier
-    uint32_t pub_arg;      // done_round / miss count / K + 1
     uint32_t solo_nlog;    // breakpoints the solo launch logged
     uint32_t cand_scan;    // 1 once tcand / cand_top carry the candidates of a verified scan (before: |c0| ranks)
     uint32_t solo_replay;  // > 0: the last solo launch failed its check after this many good iterations; the next one repeats exactly those
     uint32_t solo_fails;   // solo launches of this solve that failed a check
-    uint32_t pad0_[4];
+    uint32_t pad0_[6];
     // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
     uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
     uint32_t pad1_[31];
