@@ -36,6 +36,14 @@
 // accumulation over j, the same reductions), so the two produce identical paths, bit for bit.
 // Requires option zero_on_removal = 1 (columns that left the support carry exact zeros).
 // Compiled with -ffp-contract=off like activeset.hip.
+//
+// k_la_persist<true> is the SPECULATIVE ("solo") form, the default for fp32: ONE workgroup runs the same
+// iterations on a subset of 256 columns (support, cached columns, best-ranked entrant candidates) with no
+// exchange at all — c, q of the subset stay in LDS and come from one fused pass, the inverse is stored
+// before the direction is formed — logs every breakpoint and STAGES the state it ends with; k_la_verify /
+// k_la_vpublish (solo.hip) re-derive every logged decision over all n columns, bit for bit, before that
+// state is committed.  The last step of a path (every column ties within rounding) and the rare endings
+// are left to the resident form above.  10 us per iteration instead of 16.
 #include "ss_hip_internal.h"
 #include "ss_hip_device.h"
 
