@@ -258,7 +258,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         if (st->done || st->need_sweep || st->solo_off) return;
         if (grow0) {
             // the support does not fit the solo tier: the resident form takes over (nothing staged: exit code 0)
-            if (tid == 0) { sa.stage[9] = 7u; sa.stage[0] = K0; st->solo_nlog = 0; st->solo_pending = 2; }    // exit code 7: nothing ran
+            if (tid == 0) { sa.stage[9] = kPsExitNothing; sa.stage[0] = K0; st->solo_nlog = 0; st->solo_pending = 2; }
             return;
         }
     } else if (st->done || st->need_sweep || grow0) {
@@ -442,7 +442,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     uint32_t last_idx = st->idx, last_rank = st->rank, last_added = st->added;
     uint32_t done_round = 0u, status = 0u;
     // 1 = solve finished, 2 = Gram column missing, 3 = support outgrew the LDS tier, 4 = wait expired
-    int exit_code = 0;
+    uint32_t exit_code = kPsExitNone;
     bool report_empty = false;               // the support became empty (DevState::K = 0)
     bool save_lists_for_update = false;      // exit 2: the pick is made, the inverse update is pending
     uint32_t pend_rank = 0, pend_idx = 0;
@@ -643,21 +643,21 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     // (right after the previous pick) and read only after the inverse update and the q pass, which
     // hide its latency; the step-length exchange hides the in-place store pass of the inverse.
     if (K + 1u > P && P < kcap) {
-        exit_code = 3;                               // (also caught at entry; kept for clarity)
+        exit_code = kPsExitGrow;                               // (also caught at entry; kept for clarity)
     } else if (SOLO) {
         cq_pass();
         post_lambda();
     } else {
         c_pass_and_post();
     }
-    while (exit_code == 0) {
+    while (exit_code == kPsExitNone) {
         const uint32_t round = iter + 1u;
         const uint32_t par = (tick & 1u) * kLaSlotStride;
         ts[0] = wall_clock64();
         if (SOLO && (nlog + 2u > kSoloLogCap || (replay != 0u && nscan >= replay))) {
             // the log is full: end the launch at this iteration boundary (the next one goes on)
             if (pend) { store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K); pend = false; }
-            exit_code = 5;
+            exit_code = kPsExitLogFull;
             break;
         }
 
@@ -681,7 +681,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
 
         // ---- lambda (posted before the inverse update) ---------------------------------------------------
         float c_inf;
-        if (!poll_lambda(c_inf, early)) { exit_code = 4; break; }
+        if (!poll_lambda(c_inf, early)) { exit_code = kPsExitWait; break; }
         ts[2] = wall_clock64();
 
         // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
@@ -691,7 +691,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             c_inf_rep = c_inf;
             iter = round - 1u;
             done_round = round;
-            exit_code = 1;
+            exit_code = kPsExitDone;
             break;
         }
 
@@ -781,7 +781,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                     }
                 }
             }
-            if (__syncthreads_or(ok ? 0 : 1)) { exit_code = 4; break; }
+            if (__syncthreads_or(ok ? 0 : 1)) { exit_code = kPsExitWait; break; }
             // final (gamma, idx): smallest positive candidate, left-most index (:123-124)
             block_reduce_pair<float, false>(g, idx, sv, si);
         }
@@ -810,7 +810,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 // endings (no step, empty support, workspace full) and the LAST step of a path — it takes
                 // lambda to ~0, where every column's candidate ties within rounding and no subset can know
                 // the winner.
-                exit_code = 6;
+                exit_code = kPsExitHandOver;
                 break;
             }
             log_entry(1u, round, c_inf, g, idx, gs_log, is_log);
@@ -834,7 +834,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             }
             c_inf_rep = c_inf;
             done_round = round;
-            exit_code = 1;
+            exit_code = kPsExitDone;
             break;
         }
 
@@ -884,20 +884,20 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             // needs lambda = ||A^T(y - A x)||_inf for the x just updated — the exchange just started.
             // If the solve ends here (homotopy-cpu.cpp:272) the pending inverse update is never used.
             float lam;
-            if (!poll_lambda(lam)) { exit_code = 4; break; }
+            if (!poll_lambda(lam)) { exit_code = kPsExitWait; break; }
             // this tick has no step-length exchange of its own: an (empty-handed) one keeps the slot
             // discipline — it proves every workgroup has read the maxima
             if (!SOLO) {
                 const uint32_t par2 = (tick & 1u) * kLaSlotStride;
                 const bool ok = exchange_all(smin + par2, nb, w, kLaSlotNone, [&](uint64_t) {});
-                if (!ok) { exit_code = 4; break; }
+                if (!ok) { exit_code = kPsExitWait; break; }
                 if (tid == 0) st_u64(&smax[par2 + w], kLaSlotEmpty);
             }
             log_entry(0u, round + 1u, lam, 0.f, 0u, 0.f, 0u);      // lambda after the step (x updated, K old entries)
             if (!(lam > tol) || round + 1u > max_iter) {
                 c_inf_rep = lam;                         // iter = round already
                 done_round = round + 1u;
-                exit_code = 1;
+                exit_code = kPsExitDone;
                 break;
             }
             // the path goes on: hand the pending inverse update to k_gramupd, which reads the
@@ -908,7 +908,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             save_lists_for_update = true;
             pend_rank = rank;
             pend_idx = idx;
-            exit_code = 2;
+            exit_code = kPsExitMiss;
             break;
         }
         ts[4] = wall_clock64();
@@ -1039,7 +1039,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         if (grow_next) {
             if (pend) store_new_inverse(S.I, Pp, S.u2, pend_added, pend_rk, pend_dv, pend_K);
             pend = false;
-            exit_code = 3;
+            exit_code = kPsExitGrow;
         }
     }
 
@@ -1065,7 +1065,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         if (tid == 0) {
             sg[0] = K; sg[1] = save_lists_for_update ? 1u : 0u; sg[2] = iter;
             sg[3] = __float_as_uint(c_inf_rep); sg[4] = __float_as_uint(gamma_last);
-            sg[5] = last_idx; sg[6] = last_rank; sg[7] = last_added; sg[8] = tick; sg[9] = (uint32_t)exit_code; sg[10] = done_round;
+            sg[5] = last_idx; sg[6] = last_rank; sg[7] = last_added; sg[8] = tick; sg[9] = exit_code; sg[10] = done_round;
             st->solo_nlog = nlog;
             st->solo_pending = replay != 0u ? 2u : 1u;
         }
@@ -1100,14 +1100,14 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         st->idx = last_idx;
         st->rank = last_rank;
         st->added = last_added;
-        if (exit_code == 4) { status = SS_HIP_ERUNTIME; done_round = iter + 1u; }
+        if (exit_code == kPsExitWait) { status = SS_HIP_ERUNTIME; done_round = iter + 1u; }
         if (status != 0u) st->status = status;
-        if (exit_code == 1 || exit_code == 4) {
+        if (exit_code == kPsExitDone || exit_code == kPsExitWait) {
             st->done_round = done_round;
             st->need_sweep = 0;
             st->done = 1;
             signal_done(hflags, nullptr, 1u, done_round);
-        } else if (exit_code == 2) {
+        } else if (exit_code == kPsExitMiss) {
             st->need_sweep = 1;
             const uint32_t nm = st->nmiss + 1u;
             st->nmiss = nm;

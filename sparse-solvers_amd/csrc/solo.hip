@@ -435,7 +435,7 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
     const uint32_t code = sg[9];
     const uint32_t K = sg[0];
     const bool save = sg[1] != 0u;
-    if (code != 7u) {
+    if (code != kPsExitNothing) {
         const uint32_t kcap = ca.kcap;
         const uint32_t cur = st->cur;
         float* const Ig = cur ? ca.inv1 : ca.inv0;
@@ -471,7 +471,7 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
     }
     __syncthreads();
     if (tid != 0) return;
-    if (code != 7u) {
+    if (code != kPsExitNothing) {
         if (save) ca.insup[sg[5]] = 1;                 // the entering column whose inverse update is pending
         ca.sy->tick = sg[8];
         st->K = save ? K + 1u : K;
@@ -483,20 +483,20 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
         st->added = sg[7];
     }
     bool off = pending == 2u;                          // after a replay the resident form goes on
-    if (code == 1u) {
+    if (code == kPsExitDone) {
         st->done_round = sg[10];
         st->need_sweep = 0;
         st->done = 1;
         signal_done(hflags, nullptr, 1u, sg[10]);
-    } else if (code == 2u) {
+    } else if (code == kPsExitMiss) {
         st->need_sweep = 1;
         const uint32_t nm = st->nmiss + 1u;
         st->nmiss = nm;
         __hip_atomic_store(&hflags[2], nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else if (code == 3u || code == 7u) {
+    } else if (code == kPsExitGrow || code == kPsExitNothing) {
         __hip_atomic_store(&hflags[3], K + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         off = true;
-    } else if (code == 6u) {
+    } else if (code == kPsExitHandOver) {
         off = true;
     }
     if (off) {

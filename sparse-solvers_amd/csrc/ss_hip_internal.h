@@ -111,6 +111,17 @@ constexpr uint32_t kSoloHeaderWords = 512;
 //   [0] K  [1] 1 = pick made, inverse update pending (Gram column missing)  [2] iter  [3] bits(lambda)
 //   [4] bits(gamma)  [5] idx  [6] rank  [7] added  [8] tick  [9] exit code  [10] done_round
 //   then gam[P], bits(x_S)[P], bits(d_S)[P], gam_new[P + 1] (with [1]), inverse [K][K]
+// why a launch of k_la_persist ended (staging word [9] of a solo launch)
+enum : uint32_t {
+    kPsExitNone = 0,       // still iterating
+    kPsExitDone = 1,       // the solve terminated
+    kPsExitMiss = 2,       // the entering column has no cached Gram column: lookahead sweep needed
+    kPsExitGrow = 3,       // the support outgrew the LDS tier of the launch
+    kPsExitWait = 4,       // a bounded wait expired (resident form only)
+    kPsExitLogFull = 5,    // solo: log full or replay finished — the next launch goes on
+    kPsExitHandOver = 6,   // solo: last step of a path / rare ending — the resident form goes on
+    kPsExitNothing = 7,    // solo: the launch could not start (support beyond its tier) — nothing staged
+};
 constexpr uint32_t kSoloStageHead = 16;
 constexpr uint32_t kSoloStageWords = kSoloStageHead + 4 * kSoloListPitch + 1 + kSoloListPitch * kSoloListPitch;
 constexpr uint32_t kSoloChunk = 40;                           // breakpoints verified per pass over the Gram rows (a phase of ~33 entries fits one)
