@@ -441,7 +441,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     float gamma_last = (float)st->gamma;
     uint32_t last_idx = st->idx, last_rank = st->rank, last_added = st->added;
     uint32_t done_round = 0u, status = 0u;
-    // 1 = solve finished, 2 = Gram column missing, 3 = support outgrew the LDS tier, 4 = wait expired
+    // why the launch ends (kPsExit*, ss_hip_internal.h)
     uint32_t exit_code = kPsExitNone;
     bool report_empty = false;               // the support became empty (DevState::K = 0)
     bool save_lists_for_update = false;      // exit 2: the pick is made, the inverse update is pending
