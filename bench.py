@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: signals recovered per second by the MI355X Homotopy path on
-BASELINE.json configs[1] (single signal per solve, A 8192 x 65536 fp32 Gaussian, k = 64),
-plus the achieved HBM bandwidth of the dominant kernel (the fused correlation sweep
-[c, q] = A^T [r, p]) against the chip's roofline and a CPU baseline timed on the same box.
+"""Benchmark of the MI355X Homotopy path on BASELINE.json's configurations.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  The sensing matrix is replicated (each rank builds the same seeded A
-in its own HBM); signals are sharded across ranks with no data-path collective; the
-recovered supports are collected with one RCCL all_gather of fixed-size records at the
-end of the timed region.  A "step" is one Homotopy solve of one signal, inputs already
-resident in HBM.  Prints ONE JSON line on rank 0.
+N = 1 — configs[1], the configuration the metric is quoted on: a step is ONE Homotopy solve of one signal
+(A 8192 x 65536 fp32, k = 64) with inputs resident in HBM; `value` = signals/s; `roofline` = the dominant HBM
+kernel (the 32-column lookahead sweep), timed live with HIP events on the solver's stream; `atr_gemv` = the
+plain A^T y sweep.  Outside the timed region the same run reports: configs[2] (a batch of 4096 signals
+sharing A, with the MFMA roofline of the G = A^T A build and the HBM roofline of the Gram-form pass),
+the drop-in surface timed with host arrays, OMP, configs[4] in fp64, and the CPU baseline (the reference's
+algorithm on the host cores, with a dlopen'd CBLAS and with the oracle's own loops) with full-solve parity.
+
+N > 1 — configs[3], the batched configuration north_star scales: signals are independent given A, so every
+rank holds A (replicated, 2 GiB) and solves its own contiguous block of 4096 signals per step in lock-step
+through ss_hip_homotopy_solve_batch_compact_f32 (records {K, iter, err, idx[96], val[96]} packed on the
+device); the only exchange is ONE RCCL all_gather of those records per step.  No data-path collective:
+weak scaling, `value` = N * 4096 * K / elapsed.  (The N = 1 line carries the same workload's single-GPU
+rate under `batched`: that, not the single-signal `value`, is the base of a scaling ratio.)
+
+One process per GPU; prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -28,6 +36,15 @@ M, N, K_SPARSE = 8192, 65536, 64
 TOL, MAX_ITER = 1e-3, 256
 KMAX_RECORD = 96                     # support record size of the gather
 HBM_PEAK_GBS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFS = 157.3            # dense fp32 MFMA peak (MI355X_MICROARCH.md)
+
+
+def survey_matrix():
+    """SURVEY §8d C2 recipe, exactly: default_rng(1234).standard_normal((8192, 65536), float32) / sqrt(8192),
+    C-contiguous row-major on the host (the same matrix on every rank)."""
+    A = np.random.default_rng(1234).standard_normal((M, N), dtype=np.float32)
+    A /= np.float32(np.sqrt(M))
+    return A
 
 
 def make_signal(A, seed, k, torch):
@@ -41,47 +58,96 @@ def make_signal(A, seed, k, torch):
     return y, sup, coef
 
 
-def cpu_baseline(A_dev, y_dev, h, iters_full, budget_s):
-    """Times the CPU oracle (reference-faithful: four dense GEMV sweeps per iteration,
-    homotopy-cpu.cpp:96,97,116,120) on this host and checks GPU parity on the same input."""
+def make_batch(A, seed, B, k, torch):
+    """B signals of the same recipe, built on the device -> (Y (B, m) device, supports (B, k), coefficients)"""
+    dev = A.device
+    rng = np.random.default_rng(seed)
+    sups = np.stack([np.sort(rng.choice(A.shape[1], k, replace=False)) for _ in range(B)])
+    coefs = 1.0 + np.abs(rng.standard_normal((B, k)))
+    Y = torch.empty((B, A.shape[0]), device=dev, dtype=A.dtype)
+    At = A.t()
+    for b0 in range(0, B, 128):
+        b1 = min(B, b0 + 128)
+        cols = At[torch.from_numpy(sups[b0:b1]).to(dev).reshape(-1)].reshape(b1 - b0, k, A.shape[0]).double()
+        Y[b0:b1] = torch.einsum("bkm,bk->bm", cols, torch.from_numpy(coefs[b0:b1]).to(dev)).to(A.dtype)
+    return Y, sups, coefs
+
+
+def check_records(rec_bytes, sups, coefs, max_iter):
+    """decode compact records (numpy uint8 (B, rb)) -> (signals with exactly the planted support, signals that
+    ran out of iterations, max relative coefficient error over the recovered ones, iterations array)"""
+    import sharding
+    recs = sharding.unpack_records(rec_bytes, KMAX_RECORD, np.float32)
+    ok = stuck = 0
+    cerr = 0.0
+    iters = np.zeros(len(recs), np.int64)
+    for b, r in enumerate(recs):
+        iters[b] = r["iter"]
+        if r["iter"] >= max_iter:
+            stuck += 1
+        if r["K"] == len(sups[b]) and np.array_equal(r["idx"], sups[b]):
+            ok += 1
+            cerr = max(cerr, float(np.abs(r["val"] - coefs[b]).max() / coefs[b].max()))
+    return ok, stuck, cerr, iters
+
+
+def cpu_baseline(A, y, h, y_dev, iters_full, budget_s):
+    """Times the reference's algorithm (four dense GEMV sweeps per iteration, homotopy-cpu.cpp:96,97,116,120)
+    on this host's cores — once with the GEMVs in a dlopen'd CBLAS like the reference's own loader
+    (blas_wrapper.cpp:33-66), once with the oracle's fixed-order loops — on a bounded sample of one
+    configs[1] solve, and checks the GPU against the oracle on the same input (full solve)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
-    A = A_dev.cpu().numpy()
-    y = y_dev.cpu().numpy()
     threads = oracle.num_threads()
-    # calibrate with two sweeps to size the sample
-    oracle.gemv_t(A, y)
-    t0 = time.perf_counter()
-    oracle.gemv_t(A, y)
-    t_sweep = time.perf_counter() - t0
     sweeps_full = 2 + 4 * iters_full
-    T = iters_full
-    if t_sweep * sweeps_full > budget_s:
-        T = max(2, int((budget_s / t_sweep - 2) / 4))
-    t0 = time.perf_counter()
-    xo, ito, eo = oracle.homotopy(A, y, TOL, T, flags=0)
-    dt = time.perf_counter() - t0
-    sweeps_sample = 2 + 4 * ito
-    est_full = dt * sweeps_full / sweeps_sample
-    xg, itg, eg = h.solve(y_dev, TOL, T)
-    scale = float(np.abs(xo).max())
-    parity = {
-        "iters_equal": bool(itg == ito),
+
+    def timed(flags, budget):
+        oracle.homotopy(A, y, TOL, 1, flags=flags)                 # first touch / BLAS thread start-up
+        t0 = time.perf_counter()
+        oracle.homotopy(A, y, TOL, 1, flags=flags)                 # 6 sweeps
+        t_sweep = (time.perf_counter() - t0) / 6
+        T = iters_full
+        if t_sweep * sweeps_full > budget:
+            T = max(2, int((budget / t_sweep - 2) / 4))
+        t0 = time.perf_counter()
+        xo, ito, eo = oracle.homotopy(A, y, TOL, T, flags=flags)
+        dt = time.perf_counter() - t0
+        sw = 2 + 4 * ito
+        return dt * sweeps_full / sw, ito, sw, dt
+
+    blas = oracle.load_cblas(threads)
+    out = {}
+    if blas is not None:
+        est, ito, sw, dt = timed(oracle.CBLAS, budget_s * 0.5)
+        out["cpu_baseline"] = {
+            "value": 1.0 / est, "unit": "signals/s", "cores": int(threads), "kind": "port",
+            "sample": ("reference algorithm, GEMVs in a dlopen'd CBLAS (%s, %d threads): %d of %d iterations of one "
+                       "configs[1] solve (%d of %d dense sweeps of A, %.1f s), scaled by sweep count; %.1f GB/s implied"
+                       % (blas, threads, ito, iters_full, sw, sweeps_full, dt, sw * A.nbytes / dt / 1e9))}
+    est, ito, sw, dt = timed(0, budget_s * (0.5 if blas is not None else 1.0))
+    own = {"value": 1.0 / est, "unit": "signals/s", "cores": int(threads), "kind": "port",
+           "sample": ("reference algorithm, the oracle's own fixed-order GEMV loops (OpenMP, %d threads): %d of %d iterations "
+                      "(%d of %d dense sweeps, %.1f s), scaled by sweep count; %.1f GB/s implied"
+                      % (threads, ito, iters_full, sw, sweeps_full, dt, sw * A.nbytes / dt / 1e9))}
+    if "cpu_baseline" in out:
+        out["cpu_baseline_own_loops"] = own
+    else:
+        out["cpu_baseline"] = own
+    # full-solve parity of the GPU against the oracle (sparse A x / A d: bit-identical to the dense form, faster)
+    xo, ito, eo, tro = oracle.homotopy(A, y, TOL, MAX_ITER, trace=True)
+    h.set_option("trace", 1)
+    xg, itg, eg = h.solve(y_dev, TOL, MAX_ITER)
+    trg = h.trace()
+    h.set_option("trace", 0)
+    nb = min(len(trg["idx"]), len(tro["idx"])) - 1
+    out["parity_vs_oracle"] = {
+        "iters_equal": bool(itg == ito), "iters": int(ito),
         "support_exact": bool(np.array_equal(np.nonzero(xg)[0], np.nonzero(xo)[0])),
-        "max_rel_coef_err": float(np.abs(xg.astype(np.float64) - xo).max() / scale),
-        "iters": int(ito),
+        "max_rel_coef_err": float(np.abs(xg.astype(np.float64) - xo).max() / np.abs(xo).max()),
+        "breakpoints_equal": bool(nb > 0 and np.array_equal(trg["idx"][:nb], tro["idx"][:nb])
+                                  and np.array_equal(trg["added"][:nb], tro["added"][:nb])),
     }
-    base = {
-        "value": 1.0 / est_full,
-        "unit": "signals/s",
-        "cores": int(threads),
-        "kind": "port",
-        "sample": ("%d of %d homotopy iterations of one configs[1] solve (%d of %d dense GEMV "
-                   "sweeps of A, %.1f s), scaled by sweep count; %.1f GB/s implied host bandwidth"
-                   % (ito, iters_full, sweeps_sample, sweeps_full, dt,
-                      sweeps_sample * A.nbytes / dt / 1e9)),
-    }
-    return base, parity
+    return out
 
 
 def main():
@@ -89,17 +155,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["auto", "single", "batched"], default="auto",
+                    help="auto: configs[1] (one signal per step) on one GPU, configs[3] (4096 signals per rank and "
+                         "step, lock-step batch) on several")
     ap.add_argument("--variant", type=int, default=None, help="sweep kernel variant (tuning)")
     ap.add_argument("--engine", type=int, default=None, help="0 = one fused sweep per iteration, 1 = lookahead")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="time every k-th fused sweep of the timed solves with HIP events")
-    ap.add_argument("--batch", type=int, default=1024,
-                    help="signals of the extra configs[2]-style lock-step batch run reported under "
-                         "'batched' (outside the timed region; 0 = skip)")
+    ap.add_argument("--batch", type=int, default=4096,
+                    help="signals per rank of the batched workload (configs[2] / configs[3]; 0 = skip the N = 1 extra)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the OMP and fp64 (configs[4]) extras reported under 'extras' (single-GPU runs only)")
-    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+                    help="skip the drop-in, OMP and fp64 (configs[4]) extras (single-GPU runs only)")
+    ap.add_argument("--cpu-budget-s", type=float, default=24.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,16 +192,126 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    workload = args.workload
+    if workload == "auto":
+        workload = "single" if world == 1 else "batched"
 
     # the same seeded sensing matrix on every rank (replicated, 2 GiB of the 288 GB HBM)
-    g = torch.Generator(device=dev).manual_seed(1234)
-    A = torch.randn((M, N), generator=g, device=dev, dtype=torch.float32) / np.sqrt(M)
+    A_host = survey_matrix()
+    A = torch.from_numpy(A_host).to(dev)
+    if not (rank == 0 and world == 1 and workload == "single" and not args.no_cpu_baseline):
+        A_host = None
     h = sship.Homotopy(A, device=local_rank)
     if args.variant is not None:
         h.set_option("sweep_variant", args.variant)
     if args.engine is not None:
         h.set_option("engine", args.engine)
 
+    if workload == "batched":
+        out = run_batched(args, h, A, dev, rank, world, use_dist, torch, dist, sharding)
+    else:
+        out = run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch, dist, sship)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def run_batched(args, h, A, dev, rank, world, use_dist, torch, dist, sharding):
+    """configs[3]: every rank solves its own block of `--batch` signals per step in lock-step (compact records on
+    the device), one all_gather of the records per step; nothing else crosses GPUs."""
+    B = max(4, args.batch)
+    rb = h.record_bytes(KMAX_RECORD)
+    # two distinct blocks per rank, alternating by step (inputs resident in HBM before the timed region)
+    blocks = [make_batch(A, 777000 + rank * 1000 + j, B, K_SPARSE, torch) for j in range(2)]
+    rec = torch.zeros((B, rb), dtype=torch.uint8, device=dev)
+    allrec = None
+
+    def step(s):
+        Y = blocks[s & 1][0]
+        h.solve_batch_compact(Y, TOL, MAX_ITER, kmax=KMAX_RECORD, out=rec)
+        return sharding.gather_records(rec, world, collective=use_dist)
+
+    for s in range(max(1, args.warmup)):           # (the first batch forms G = A^T A on this rank: 17 GiB, once)
+        allrec = step(s)
+    h.set_profiling(True)
+    h.reset_stats()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        allrec = step(max(1, args.warmup) + s)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    h.set_profiling(False)
+    if use_dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # the last step's block, decoded from the GATHERED records of this rank: exact planted supports
+    last = (max(1, args.warmup) + args.steps - 1) & 1
+    ok, stuck, cerr, iters = check_records(allrec[rank].cpu().numpy(), blocks[last][1], blocks[last][2], MAX_ITER)
+    agg = torch.tensor([ok, stuck], device=dev, dtype=torch.int64)
+    if use_dist:
+        dist.all_reduce(agg)
+    st = h.stats()
+    h.close()
+    if rank != 0:
+        return None
+    cq_ms = st["cq_ms"] / max(1, st["cq_launches"])
+    cq_gbs = st["cq_bytes"] / (st["cq_ms"] * 1e-3) / 1e9 if st["cq_ms"] > 0 else 0.0
+    return {
+        "metric": "signals recovered/sec (Homotopy l1, m=8192 n=65536 k=64 fp32)",
+        "value": world * B * args.steps / elapsed,
+        "unit": "signals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": max(1, args.warmup),
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[3]: batch of %d x %d signals sharing A 8192x65536 fp32 (k=64 positive coefficients, "
+                        "tol 1e-3, max_iter 256), %d per rank and step in lock-step (Gram form: correlations from rows "
+                        "of G = A^T A, formed once per rank in the warm-up), compact records, one RCCL all_gather per step"
+                        % (world, B, B),
+            "m": M, "n": N, "k": K_SPARSE, "signals_per_step_per_gpu": B,
+            "sharding": "signals across ranks (contiguous blocks), A replicated, no data-path collective; one all_gather "
+                        "of {K, iter, err, idx[96], val[96]} records (%d B each) per step" % rb,
+            "scaling_base": "the single-GPU rate of this same workload is `batched.signals_per_s` of the --gpus 1 line "
+                            "(whose `value` is the single-signal configs[1] rate)",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_la_cq (batched Gram form): c = c0 - sum_j x_j G[j], q = sum_j d_j G[j] for every live signal, "
+                      "K rows of G per signal and round",
+            "achieved": cq_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cq_gbs / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_launch": st["cq_bytes"] / max(1, st["cq_launches"]), "avg_launch_ms": cq_ms,
+            "launches_timed": st["cq_launches"],
+            "note": "bytes = sum over live signals of (K + 3) * n * 4 (K rows of G, c0, c, q); G rows shared by signals "
+                    "of one launch are re-served from L2 / Infinity Cache, so HBM traffic is below this figure",
+        },
+        "batch_rounds_per_step": st["batch_rounds"] / max(1, args.steps),
+        "recovered": {"signals_checked": world * B, "support_exact": int(agg[0].item()),
+                      "ran_to_max_iter": int(agg[1].item()), "max_rel_coef_err_rank0": cerr,
+                      "note": "checked on the records every rank received from the all_gather (last step); a signal "
+                              "that meets an exact tie runs to max_iter like the reference's (homotopy-cpu.cpp:143-153)"},
+        "iterations_mean": float(iters.mean()),
+    }
+
+
+def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch, dist, sship):
+    """configs[1]: one signal per solve; the N = 1 headline (and, with --workload single, replicas on N GPUs)"""
     total = args.warmup + args.steps
     sigs = [make_signal(A, 1235 + rank * 100003 + s, K_SPARSE, torch) for s in range(total)]
     X = torch.zeros((args.steps, N), device=dev, dtype=torch.float32)
@@ -143,8 +321,6 @@ def main():
 
     for s in range(args.warmup):
         h.solve(sigs[s][0], TOL, MAX_ITER, out=xw)
-    # warm up the record packing / gather too (first use of a torch kernel loads its code object)
-    sharding.gather_records(sharding.pack_records(xw.unsqueeze(0).expand(args.steps, N).contiguous(), KMAX_RECORD), world, collective=use_dist)
 
     h.set_profiling(True)
     h.set_option("profile_every", args.profile_every)
@@ -158,9 +334,6 @@ def main():
         _, it, e = h.solve(sigs[args.warmup + s][0], TOL, MAX_ITER, out=X[s])
         iters[s] = it
         errs[s] = e
-    # fixed-size support records {idx[KMAX], val[KMAX]} per signal; one gather over xGMI
-    rec = sharding.pack_records(X, KMAX_RECORD)
-    allrec = sharding.gather_records(rec, world, collective=use_dist)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -186,15 +359,32 @@ def main():
     if use_dist:
         dist.all_reduce(rc)
     recovered_total = int(rc.item())
-    # the gathered records of this rank's own block decode back to its solutions
-    mine = sharding.unpack_records(allrec[rank].cpu().numpy(), KMAX_RECORD, N)
-    gather_ok = all(np.array_equal(ix, np.nonzero(Xh[s])[0]) for s, (ix, _) in enumerate(mine))
-
     st = h.stats()
+    single_value = world * args.steps / elapsed
 
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
+        # the drop-in surface with HOST arrays: sparsesolvers.Homotopy(A).solve(y) — A uploaded and re-laid-out at
+        # construction (row-major numpy), per solve y up (32 KiB) and x down (256 KiB) over PCIe
+        import sparsesolvers
+        Ah = A_host if A_host is not None else A.cpu().numpy()
+        tc = time.perf_counter()
+        solver = sparsesolvers.Homotopy(Ah)
+        t_create = time.perf_counter() - tc
+        ys = [sigs[args.warmup + s_][0].cpu().numpy() for s_ in range(args.steps)]
+        solver.solve(ys[0], tolerance=TOL, max_iterations=MAX_ITER)
+        td = time.perf_counter()
+        same = 0
+        for s_ in range(args.steps):
+            xd, info = solver.solve(ys[s_], tolerance=TOL, max_iterations=MAX_ITER)
+            same += int(np.array_equal(xd, Xh[s_]) and info.iter == iters[s_])
+        dtd = time.perf_counter() - td
+        del solver
+        extras["drop_in_host_arrays"] = {
+            "workload": "the timed solves through sparsesolvers.Homotopy(A).solve(numpy y) -> (numpy x, HomotopyReport)",
+            "ms_per_solve": dtd / args.steps * 1e3, "signals_per_s": args.steps / dtd,
+            "construct_s": t_create, "bit_identical_to_timed_solves": same, "signals": args.steps}
         # OMP on the same matrix and signals (north_star names it; no reference implementation exists: unpinned)
         XO = torch.zeros((args.steps, N), device=dev, dtype=torch.float32)
         h.solve_omp(sigs[0][0], TOL, K_SPARSE, out=XO[0])
@@ -207,50 +397,62 @@ def main():
         XOh = XO.cpu().numpy()
         oko = sum(int(np.array_equal(np.nonzero(XOh[s_])[0], sigs[args.warmup + s_][1])) for s_ in range(args.steps))
         del XO
-        extras["omp"] = {"workload": "OMP (ss::omp<float>), the same A and signals, %d picks" % K_SPARSE,
+        extras["omp"] = {"workload": "OMP (ss::omp<float>, parity unpinned: the reference has no OMP), the same A and signals, %d picks" % K_SPARSE,
                          "ms_per_solve": dto / args.steps * 1e3, "support_exact": oko, "signals": args.steps}
 
-    # configs[2]-style extra (NOT part of `value`): a batch of signals sharing A, solved in
-    # lock-step with the correlations on the MFMA units
+    # configs[2] (NOT part of `value`): a batch of signals sharing A, solved in lock-step; compact records
     batched = None
-    if args.batch > 0:
+    if args.batch > 0 and world == 1:
         Bx = args.batch
-        rngb = np.random.default_rng(4242 + rank)
-        supb = np.stack([np.sort(rngb.choice(N, K_SPARSE, replace=False)) for _ in range(Bx)])
-        coefb = 1.0 + np.abs(rngb.standard_normal((Bx, K_SPARSE)))
-        Yb = torch.empty((Bx, M), device=dev, dtype=torch.float32)
-        for b0 in range(0, Bx, 128):
-            b1 = min(Bx, b0 + 128)
-            cols = A.t()[torch.from_numpy(supb[b0:b1]).to(dev).reshape(-1)].reshape(b1 - b0, K_SPARSE, M).double()
-            Yb[b0:b1] = torch.einsum("bkm,bk->bm", cols, torch.from_numpy(coefb[b0:b1]).to(dev)).float()
-        Xb = torch.zeros((Bx, N), device=dev, dtype=torch.float32)
-        h.solve_batch(Yb[:8].contiguous(), TOL, MAX_ITER, out=Xb[:8])          # warm-up / allocation
+        rb = h.record_bytes(KMAX_RECORD)
+        Yb, supb, coefb = make_batch(A, 4242 + rank, Bx, K_SPARSE, torch)
+        rec = torch.zeros((Bx, rb), dtype=torch.uint8, device=dev)
+        h.solve_batch_compact(Yb[:8].contiguous(), TOL, MAX_ITER, kmax=KMAX_RECORD, out=rec[:8])   # workspace of a small batch
         torch.cuda.synchronize()
         runs = []
-        for label in ("first batch (forms G = A^T A)", "next batch (G kept)"):
+        for label in ("first batch (allocates the batch workspace, forms G = A^T A)", "next batch (G kept)", "next batch, profiled"):
             h.reset_stats()
+            h.set_profiling(label.endswith("profiled"))
             tb = time.perf_counter()
-            _, itb, _ = h.solve_batch(Yb, TOL, MAX_ITER, out=Xb)
+            h.solve_batch_compact(Yb, TOL, MAX_ITER, kmax=KMAX_RECORD, out=rec)
             torch.cuda.synchronize()
             dtb = time.perf_counter() - tb
             stb = h.stats()
             runs.append({"which": label, "signals_per_s": Bx / dtb, "seconds": dtb, "rounds": int(stb["batch_rounds"]),
-                         "gram_matrix_built": int(stb["gram_full_builds"])})
-        Xbh = Xb.cpu().numpy()
-        okb = sum(int(np.array_equal(np.nonzero(Xbh[b])[0], supb[b])) for b in range(Bx))
-        batched = {"workload": "configs[2]-style: %d signals sharing A, lock-step; Gram form (correlations from rows of "
-                               "G = A^T A, formed once on the MFMA units) when the batch is >= 512 signals, else two "
-                               "MFMA GEMMs per round" % Bx,
-                   "signals": Bx, "signals_per_s": runs[-1]["signals_per_s"], "runs": runs,
-                   "support_exact": okb, "iterations_max": int(itb.max())}
-        del Xb, Yb
+                         "gram_matrix_built": int(stb["gram_full_builds"]),
+                         "gram_build_ms": stb["gram_build_ms"], "gram_alloc_ms": stb["gram_alloc_ms"]})
+        h.set_profiling(False)
+        okb, stuckb, cerrb, itb = check_records(rec.cpu().numpy(), supb, coefb, MAX_ITER)
+        n_pad = (N + 255) // 256 * 256
+        g_ms = runs[0]["gram_build_ms"]
+        t128 = n_pad // 128
+        gflops_full = 2.0 * M * n_pad * n_pad
+        gflops_exec = h.get_option("gram_symmetric") and 2.0 * M * 128 * 128 * (t128 * (t128 + 1) // 2) or gflops_full
+        cq_gbs = stb["cq_bytes"] / (stb["cq_ms"] * 1e-3) / 1e9 if stb["cq_ms"] > 0 else 0.0
+        batched = {
+            "workload": "configs[2]: %d signals sharing A (k=64, tol 1e-3, max_iter 256), lock-step, Gram form: correlations "
+                        "from rows of G = A^T A (formed once on the MFMA units, kept in the context), compact records "
+                        "{K, iter, err, idx[96], val[96]}" % Bx,
+            "signals": Bx, "signals_per_s": runs[1]["signals_per_s"],
+            "signals_per_s_first_batch_incl_G": runs[0]["signals_per_s"], "runs": runs,
+            "support_exact": okb, "ran_to_max_iter": stuckb, "max_rel_coef_err": cerrb, "iterations_max": int(itb.max()),
+            "roofline_gram_build": {
+                "bound": "mfma", "kernel": "k_gemm_tn_f32: G = A^T A (v_mfma_f32_32x32x2_f32, 128x128x32 tiles%s)"
+                                           % (", tiles on and above the diagonal + mirrored store" if h.get_option("gram_symmetric") else ""),
+                "achieved": gflops_exec / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0, "peak": MFMA_F32_PEAK_TFS,
+                "unit": "TFLOP/s", "frac": (gflops_exec / (g_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS) if g_ms > 0 else 0.0,
+                "traffic": None, "flops_per_launch": gflops_exec, "flops_full_product": gflops_full, "avg_launch_ms": g_ms},
+            "roofline_gram_pass": {
+                "bound": "hbm", "kernel": "k_la_cq (batched Gram form): K rows of G per live signal and round",
+                "achieved": cq_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cq_gbs / HBM_PEAK_GBS, "traffic": None,
+                "bytes_total": stb["cq_bytes"], "ms_total": stb["cq_ms"], "launches_timed": stb["cq_launches"]},
+        }
+        del rec, Yb
 
-    # extra (NOT `value`): once G = A^T A sits in HBM (the batch above formed it; a context also forms it
-    # by itself after 512 single-signal solves) a single-signal solve needs no pass over A beyond A^T y
+    # extra (NOT `value`): with G = A^T A in HBM (the batch above formed it) a single-signal solve needs no pass
+    # over A beyond A^T y
     with_gram = None
-    if h.stats()["gram_full_builds"] > 0 or args.batch >= 512:
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
+    if batched is not None:
         h.solve(sigs[0][0], TOL, MAX_ITER, out=xw)                # (first solve in this mode fills the identity map)
         torch.cuda.synchronize()
         tg = time.perf_counter()
@@ -289,24 +491,26 @@ def main():
         s1_ms = st["sweep1_ms"] / max(1, st["sweep1_launches"])
         s1_gbs = st["sweep1_bytes"] / (s1_ms * 1e-3) / 1e9 if s1_ms > 0 else 0.0
         ms_per_step = elapsed / args.steps * 1e3
+        la_ms = avg_ms * st["lookahead_sweeps"] / max(1, st["solves"]) if engine >= 1 else None
         out = {
             "metric": "signals recovered/sec (Homotopy l1, m=8192 n=65536 k=64 fp32)",
-            "value": world * args.steps / elapsed,
+            "value": single_value,
             "unit": "signals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: one signal per solve, A 8192x65536 fp32 Gaussian/sqrt(m), "
-                            "k=64 positive coefficients, tol 1e-3, max_iter 256",
+                "workload": "configs[1]: one signal per solve, A 8192x65536 fp32 = default_rng(1234).standard_normal/sqrt(m) "
+                            "(SURVEY 8d recipe), k=64 positive coefficients, tol 1e-3, max_iter 256; shipped defaults "
+                            "(reference behaviour: tie_guard 0, zero_on_removal 0)",
                 "m": M, "n": N, "k": K_SPARSE, "signals_per_step_per_gpu": 1,
-                "sharding": "signals across ranks, A replicated, one all_gather of support records",
+                "sharding": "one GPU (with --gpus N --workload single: independent replicas, one signal per rank and step)",
                 "sweep_variant": h.get_option("sweep_variant"), "engine": engine,
             },
             "roofline": {
@@ -327,25 +531,24 @@ def main():
                          "avg_launch_ms": s1_ms, "launches_timed": st["sweep1_launches"]},
             "sweeps_per_solve": {"lookahead_32rhs": st["lookahead_sweeps"] / max(1, st["solves"]),
                                  "atr_1rhs": 1, "reference_gemv_per_iteration": 4},
-            # where a solve's time goes (event-timed sweeps; the rest is the resident iteration kernel
-            # k_la_persist, which is latency-bound: two all-to-all exchanges per iteration)
+            # where a solve's time goes (event-timed sweeps; the rest is the iteration kernels, latency-bound)
             "ms_per_solve": {"total": ms_per_step,
                              "atr_1rhs_sweep": s1_ms,
-                             "lookahead_sweeps": avg_ms * st["lookahead_sweeps"] / max(1, st["solves"]) if engine >= 1 else None,
-                             "iterations_and_rest": (ms_per_step - s1_ms - avg_ms * st["lookahead_sweeps"] / max(1, st["solves"])) if engine >= 1 else None,
-                             "us_per_iteration": (1e3 * (ms_per_step - s1_ms - avg_ms * st["lookahead_sweeps"] / max(1, st["solves"])) / max(1.0, st["iterations"] / max(1, st["solves"]))) if engine >= 1 else None},
+                             "lookahead_sweeps": la_ms,
+                             "iterations_and_rest": (ms_per_step - s1_ms - la_ms) if engine >= 1 else None,
+                             "us_per_iteration": (1e3 * (ms_per_step - s1_ms - la_ms) / max(1.0, st["iterations"] / max(1, st["solves"]))) if engine >= 1 else None},
             "batched": batched,
             "single_signal_with_gram_matrix": with_gram,
             "iterations_mean": float(iters.mean()),
             "engine": ("lookahead (cached Gram columns), speculative resident iterations (one workgroup + verification of every breakpoint)" if h.get_option("la_fused") >= 3 else "lookahead (cached Gram columns), resident iteration kernel") if engine >= 1 else "one fused sweep per iteration",
             "recovered": {"signals": world * args.steps, "support_exact": recovered_total,
-                          "max_rel_coef_err_rank0": coef_err, "gathered_records_ok": bool(gather_ok)},
+                          "max_rel_coef_err_rank0": coef_err},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, parity = cpu_baseline(A, sigs[args.warmup][0], h, int(round(iters.mean())),
-                                    args.cpu_budget_s)
-        out["cpu_baseline"] = base
-        out["parity_vs_oracle"] = parity
+        if batched is not None:
+            h.set_option("gram_single", 0)              # parity run of the headline path: Gram-column cache, not G
+        out.update(cpu_baseline(A_host if A_host is not None else A.cpu().numpy(), sigs[args.warmup][0].cpu().numpy(), h,
+                                sigs[args.warmup][0], int(round(iters.mean())), args.cpu_budget_s))
     h.close()
     if extras is not None:
         # configs[4]: fp64, A 16384 x 131072 (16 GiB), k = 128, tol 1e-9 — Homotopy (the reference has no OMP)
@@ -379,18 +582,14 @@ def main():
         b32 = m5 * n5 * 8 + 32 * m5 * 8 + 32 * n5 * 8
         b1 = m5 * n5 * 8 + m5 * 8 + n5 * 8
         extras["fp64_configs4"] = {
-            "workload": "configs[4] shape: Homotopy fp64, A 16384x131072 (16 GiB), k=128, tol 1e-9, max_iter 512",
+            "workload": "configs[4] shape: Homotopy fp64, A 16384x131072 (16 GiB, torch.randn seed 4321 / sqrt(m)), k=128, tol 1e-9, max_iter 512",
             "ms_per_solve": dt5 * 1e3, "iterations": int(it5), "support_exact": ok5, "max_rel_coef_err": err5,
             "lookahead_sweeps_per_solve": st5["lookahead_sweeps"] / max(1, st5["solves"]),
             "lookahead_sweep_f64": {"ms": ms32, "GB/s": b32 / ms32 / 1e6, "frac_of_8TBs": b32 / ms32 / 1e6 / HBM_PEAK_GBS},
             "atr_gemv_f64": {"ms": ms1, "GB/s": b1 / ms1 / 1e6, "frac_of_8TBs": b1 / ms1 / 1e6 / HBM_PEAK_GBS}}
         h5.close()
         out["extras"] = extras
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_HIP_ABI_VERSION 1
+#define SS_HIP_ABI_VERSION 2
 
 typedef struct ss_hip_ctx ss_hip_ctx;
 
@@ -121,6 +121,31 @@ int ss_hip_homotopy_solve_batch_f64(ss_hip_ctx* ctx, const double* Y, size_t B,
                                     char* err, size_t errlen);
 
 /*
+ * The same batch with COMPACT output: one fixed-size record per signal instead of a dense row of n
+ * coefficients (4096 signals x 65536 columns are 1 GiB dense, 3 MiB compact) — what a batched caller such
+ * as the reference's benchmark driver (src/solvers/homotopy_bench.cpp:39-48) keeps of a solve, and the unit
+ * the multi-GPU path gathers (one RCCL all_gather of records, no dense X anywhere).  Record b starts at
+ * records + b * ss_hip_record_bytes(kmax, is_f64) and holds, packed on the device from the solver's own
+ * support lists (no scan of x):
+ *     uint32 K          number of non-zero coefficients of x_b (may exceed kmax: then only the first kmax,
+ *                       by column index, are stored)
+ *     uint32 iter       homotopy_report::iter        (policies.h:25-32)
+ *     double err        homotopy_report::solution_error
+ *     uint32 idx[kmax]  their column indices, ascending; unused entries 0
+ *     T      val[kmax]  their values; unused entries 0
+ * `records` may be a host or a device pointer (B * record_bytes bytes, 8-byte aligned).
+ */
+size_t ss_hip_record_bytes(uint32_t kmax, int is_f64);
+int ss_hip_homotopy_solve_batch_compact_f32(ss_hip_ctx* ctx, const float* Y, size_t B,
+                                            ptrdiff_t y_stride, ptrdiff_t incy,
+                                            float tol, uint32_t max_iter, uint32_t kmax,
+                                            void* records, char* err, size_t errlen);
+int ss_hip_homotopy_solve_batch_compact_f64(ss_hip_ctx* ctx, const double* Y, size_t B,
+                                            ptrdiff_t y_stride, ptrdiff_t incy,
+                                            double tol, uint32_t max_iter, uint32_t kmax,
+                                            void* records, char* err, size_t errlen);
+
+/*
  * The correlation sweep on its own, c = A^T r — the blas::xgemv(CblasTrans, ...)
  * of residual_vector (homotopy-cpu.cpp:97).  Runs `repeats` launches (>= 1) and
  * reports the mean kernel time in milliseconds measured with HIP events on the
@@ -160,6 +185,18 @@ int ss_hip_gram_cols_f64(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, double
 int ss_hip_reconstruct_f32(ss_hip_ctx* ctx, const float* x, float* y, char* err, size_t errlen);
 int ss_hip_reconstruct_f64(ss_hip_ctx* ctx, const double* x, double* y, char* err, size_t errlen);
 
+/*
+ * ss::norm_l1 (src/linalg/norms.h:22-27, src/lib.cpp:106-112): every column of the m x n matrix is divided,
+ * IN PLACE, by its l1 norm sum_i |A(i, j)| (a zero column becomes NaN, like the reference's 0 / 0).  A may be
+ * a device buffer (normalised where it lives: a column reduction and a scale kernel) or a host matrix (streamed
+ * through the device in row panels); element (i, j) at A[i*stride_row + j*stride_col].  No context is needed:
+ * in the reference this runs before the solver is constructed (src/solvers/test_util.h:167).
+ */
+int ss_hip_norm_l1_f32(float* A, size_t m, size_t n, ptrdiff_t stride_row, ptrdiff_t stride_col,
+                       int device, char* err, size_t errlen);
+int ss_hip_norm_l1_f64(double* A, size_t m, size_t n, ptrdiff_t stride_row, ptrdiff_t stride_col,
+                       int device, char* err, size_t errlen);
+
 /* ---- measurement ---------------------------------------------------------- */
 
 typedef struct ss_hip_stats {
@@ -182,6 +219,13 @@ typedef struct ss_hip_stats {
     uint64_t gram_full_builds;     /* times the full Gram matrix A^T A was formed for the batched Gram form        */
     uint64_t solo_solves;          /* solves that ran in the speculative form (one workgroup + verification)        */
     uint64_t solo_retries;         /* speculative launches whose verification failed (the solve went on in the resident form) */
+    /* ABI version 2 */
+    double   gram_build_ms;        /* HIP-event time of the MFMA GEMM(s) that formed G = A^T A (2 m n^2 flops each; n padded to 256) */
+    double   gram_alloc_ms;        /* host wall time of allocating G (hipMalloc of n_pad^2 fp32)                                    */
+    uint64_t cq_launches;          /* batched Gram form, profiling on: timed launches of k_la_cq (c, q of every live signal)        */
+    double   cq_ms;                /* sum of their HIP-event durations                                                             */
+    uint64_t cq_bytes;             /* algorithmic bytes of those launches: per live signal and round (K + 3) n s — K rows of G read,
+                                      c0 read, c and q written                                                                     */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------
@@ -239,17 +283,24 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    takes every signal's correlations from rows of G instead of two GEMMs per round
  *                    (default 512; once G exists every lock-step batch uses it; 0 = never)
  *   "gram_full_gib"  largest G the Gram forms may allocate (default 64 GiB; 0 = never form G)
- *   "gram_full_after" single-signal solves (fp32) after which the context forms G for them as well: with G
- *                    in HBM every Gram column is at hand and a solve needs no pass over A beyond A^T y
- *                    (default 512 solves; 1 = from the first solve; 0 = only if a batch formed G)
+ *   "gram_full_after" opt-in (default 0 = never): single-signal solves (fp32) after which the context forms G
+ *                    for them as well: with G in HBM every Gram column is at hand and a solve needs no pass over
+ *                    A beyond A^T y — at the price of n^2 fp32 of HBM (17 GiB at 8192 x 65536) and one GEMM;
+ *                    1 = from the first solve
+ *   "gram_single"    1 (default) = once G exists (a large batch formed it, or gram_full_after) single-signal
+ *                    solves use it as their Gram-column cache; 0 = they keep their own 32-column sweeps
+ *   "gram_symmetric" 1 (default) = G is formed from the GEMM tiles on and above the diagonal, each stored to both
+ *                    sides (half the flops, G exactly symmetric); 0 = the full product
  *   "profile_every"  with profiling on, bracket only every k-th fused sweep with events
- *   "tie_guard"      1 (default) = an off-support column that attains max|c| exactly (it
- *                    tied with an inserted column within an ulp) enters by a zero-length step
- *                    instead of being skipped for good by the reference's strict `t > 0`
- *                    (homotopy-cpu.cpp:143-153); 0 = reference behaviour
- *   "zero_on_removal" 1 (default) = a coefficient whose column leaves the support is set
- *                    to exactly 0; 0 = keep the reference's x + gamma*d rounding residue
- *                    (homotopy-cpu.cpp:246-252), which can make a re-inserted column bounce
+ *   "tie_guard"      0 (default) = the reference's strict `t > 0` (homotopy-cpu.cpp:135,145,151): an
+ *                    off-support column that attains max|c| exactly (it tied with an inserted column
+ *                    within an ulp) is skipped for good and such a solve runs to max_iterations, as the
+ *                    reference's does; 1 = opt-in fix: that column enters by a zero-length step
+ *   "zero_on_removal" 0 (default) = a coefficient whose column leaves the support keeps the reference's
+ *                    x + gamma*d rounding residue (homotopy-cpu.cpp:246-252; 0 or an ulp, and a
+ *                    re-inserted column may bounce out again); 1 = opt-in fix: it is set to exactly 0.
+ *                    Both fixes are restated in the CPU oracle (SS_ORACLE_TIE_GUARD,
+ *                    SS_ORACLE_ZERO_ON_REMOVAL) so that the opt-in modes are checked too.
  */
 int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value);
 int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value);

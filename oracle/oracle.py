@@ -17,7 +17,9 @@ _LIB_PATH = os.path.join(_HERE, "libss_oracle.so")
 
 SPARSE_NOTRANS = 1
 STRICT_SIGN = 2
-ZERO_ON_REMOVAL = 4
+ZERO_ON_REMOVAL = 4   # opt-in, not the reference (restates the HIP option zero_on_removal = 1)
+TIE_GUARD = 8         # opt-in, not the reference (restates the HIP option tie_guard = 1)
+CBLAS = 16            # timing leg only: the GEMVs through a dlopen'd CBLAS (load_cblas)
 
 
 class _Report(ctypes.Structure):
@@ -132,6 +134,31 @@ def lib():
         L.ss_oracle_set_num_threads(usable_cpus())
         _lib = L
     return _lib
+
+
+def load_cblas(threads=None):
+    """dlopen a CBLAS for the CBLAS flag, like the reference's loader (blas_wrapper.cpp:33-66): scipy's bundled
+    OpenBLAS (LP64, symbols prefixed scipy_), else a system libopenblas / libblas.  Returns its description
+    or None if none is usable."""
+    import glob
+    L = lib()
+    L.ss_oracle_load_cblas.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    L.ss_oracle_load_cblas.restype = ctypes.c_int
+    L.ss_oracle_cblas_config.restype = ctypes.c_char_p
+    threads = usable_cpus() if threads is None else int(threads)
+    cands = []
+    try:
+        import scipy
+        d = os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs")
+        cands += [(p, b"scipy_") for p in sorted(glob.glob(os.path.join(d, "libscipy_openblas-*.so")))]
+    except Exception:
+        pass
+    cands += [(p, b"") for p in ("libopenblas.so.0", "libopenblas.so", "libcblas.so.3", "libblas.so.3")]
+    for path, prefix in cands:
+        if L.ss_oracle_load_cblas(path.encode(), prefix, threads) == 0:
+            cfg = L.ss_oracle_cblas_config()
+            return "%s (%s)" % (os.path.basename(path), cfg.decode().strip() if cfg else "cblas")
+    return None
 
 
 def _suffix(dtype):

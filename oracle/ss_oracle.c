@@ -15,10 +15,51 @@
 #include <omp.h>
 #endif
 
+
+/* ---- optional CBLAS for the four GEMV call sites (timing leg only) ----------------------------
+ * The reference does its GEMVs in an OpenBLAS it dlopen()s at first use (src/linalg/blas_wrapper.cpp:
+ * 33-66).  ss_oracle_load_cblas() does the same with whatever CBLAS the host has (bench.py passes
+ * scipy's bundled libscipy_openblas, symbols prefixed "scipy_"); with SS_ORACLE_CBLAS the homotopy
+ * driver then calls cblas_sgemv / cblas_dgemv at homotopy-cpu.cpp:96,97,116,120 instead of the
+ * fixed-order loops.  Parity tests never set the flag: a BLAS's summation order is its own. */
+#include <dlfcn.h>
+#include <stdio.h>
+typedef void (*ss_sgemv_fn)(int, int, int, int, float, const float*, int, const float*, int, float, float*, int);
+typedef void (*ss_dgemv_fn)(int, int, int, int, double, const double*, int, const double*, int, double, double*, int);
+static void* g_blas_handle = NULL;
+static ss_sgemv_fn g_sgemv = NULL;
+static ss_dgemv_fn g_dgemv = NULL;
+static char g_blas_config[256] = "";
+
+int ss_oracle_load_cblas(const char* path, const char* prefix, int threads)
+{
+    char name[128];
+    if (g_blas_handle) { dlclose(g_blas_handle); g_blas_handle = NULL; g_sgemv = NULL; g_dgemv = NULL; }
+    g_blas_handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!g_blas_handle) return -1;
+    if (!prefix) prefix = "";
+    snprintf(name, sizeof(name), "%scblas_sgemv", prefix);
+    g_sgemv = (ss_sgemv_fn)dlsym(g_blas_handle, name);
+    snprintf(name, sizeof(name), "%scblas_dgemv", prefix);
+    g_dgemv = (ss_dgemv_fn)dlsym(g_blas_handle, name);
+    if (!g_sgemv || !g_dgemv) { dlclose(g_blas_handle); g_blas_handle = NULL; g_sgemv = NULL; g_dgemv = NULL; return -2; }
+    snprintf(name, sizeof(name), "%sopenblas_set_num_threads", prefix);
+    void (*set_threads)(int) = (void (*)(int))dlsym(g_blas_handle, name);
+    if (set_threads && threads > 0) set_threads(threads);
+    snprintf(name, sizeof(name), "%sopenblas_get_config", prefix);
+    char* (*get_config)(void) = (char* (*)(void))dlsym(g_blas_handle, name);
+    snprintf(g_blas_config, sizeof(g_blas_config), "%s", get_config ? get_config() : "cblas");
+    return 0;
+}
+
+const char* ss_oracle_cblas_config(void) { return g_blas_handle ? g_blas_config : NULL; }
+
 #define T      float
 #define SUF    f32
 #define T_MAX  FLT_MAX
 #define T_EPS  FLT_EPSILON
+#define T_TINY FLT_MIN
+#define T_GEMV g_sgemv
 #define T_HYPOT hypotf
 #include "ss_oracle_impl.inc"
 #include "ss_oracle_irls.inc"
@@ -26,12 +67,16 @@
 #undef SUF
 #undef T_MAX
 #undef T_EPS
+#undef T_TINY
+#undef T_GEMV
 #undef T_HYPOT
 
 #define T      double
 #define SUF    f64
 #define T_MAX  DBL_MAX
 #define T_EPS  DBL_EPSILON
+#define T_TINY DBL_MIN
+#define T_GEMV g_dgemv
 #define T_HYPOT hypot
 #include "ss_oracle_impl.inc"
 #include "ss_oracle_irls.inc"
@@ -39,6 +84,8 @@
 #undef SUF
 #undef T_MAX
 #undef T_EPS
+#undef T_TINY
+#undef T_GEMV
 #undef T_HYPOT
 
 int ss_oracle_num_threads(void)

@@ -38,6 +38,7 @@ HIP_UNITS = [
     ("irls.hip", ["-ffp-contract=off"]),
     ("gemm.hip", []),
     ("homotopy.hip", []),
+    ("utils.hip", ["-ffp-contract=off"]),
 ]
 
 

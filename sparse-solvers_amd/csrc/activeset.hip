@@ -210,6 +210,9 @@ __device__ __forceinline__ bool select_toggle(uint32_t round, T c_inf, uint32_t 
     const uint32_t rank = s_cnt[0];
     const uint32_t trank = s_cnt[1];
     const uint32_t K_new = added ? K + 1 : K - 1;
+    // touched list: sorted union of every support so far (the lists hold kcap entries)
+    const bool seen = (trank < nt) && (tch[trank] == idx);
+    const uint32_t nt_new = (added && !seen) ? nt + 1 : nt;
 
     if (trace != nullptr && threadIdx.x == 0 && round < trace_cap) {
         trace[round].idx = idx;
@@ -218,10 +221,10 @@ __device__ __forceinline__ bool select_toggle(uint32_t round, T c_inf, uint32_t 
         trace[round].c_inf = (double)c_inf;
     }
 
-    if (K_new == 0 || K_new > kcap) {
+    if (K_new == 0 || K_new > kcap || nt_new > kcap) {
         // K_new == 0: homotopy-cpu.cpp:248-249, the support became empty -> break before x
         // is updated; the report carries the c_inf of the previous iteration's end.
-        // K_new > kcap: workspace exhausted.
+        // K_new > kcap (or more distinct columns touched than the lists hold): workspace exhausted.
         if (threadIdx.x == 0) {
             if (K_new == 0) {
                 insup[idx] = 0;
@@ -263,9 +266,6 @@ __device__ __forceinline__ bool select_toggle(uint32_t round, T c_inf, uint32_t 
         for (uint32_t j = threadIdx.x; j < K_new; j += blockDim.x)
             gam_new[j] = gam[j + (j >= rank ? 1u : 0u)];
     }
-    // touched list: sorted union of every support so far
-    const bool seen = (trank < nt) && (tch[trank] == idx);
-    const uint32_t nt_new = (added && !seen) ? nt + 1 : nt;
     if (added && !seen) {
         for (uint32_t j = threadIdx.x; j < nt_new; j += blockDim.x)
             tch_new[j] = (j < trank) ? tch[j] : (j == trank ? idx : tch[j - 1]);

@@ -30,6 +30,11 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int GM = 128, GN = 128, GK = 32, GPAD = 4;
 constexpr int GLD = GK + GPAD;                 // LDS row pitch in floats (144 B: conflict-free b128 reads)
 
+// SYM: the symmetric product G = At · At^T (R == Q, square): only the tiles on and above the diagonal are
+// computed (blockIdx enumerates the pairs bm <= bn, column panel by column panel) and every off-diagonal tile
+// is stored to both sides.  G[i][j] and G[j][i] are the same k-ordered fma chain of the same (commutative)
+// products, so the mirrored copy is bit for bit what the full product would have put there.
+template <bool SYM>
 __global__ __launch_bounds__(256, 2)
 void k_gemm_tn_f32(const float* __restrict__ R, const float* __restrict__ Q, float* __restrict__ D,
                    uint32_t mtiles, uint32_t K, uint32_t ldr, uint32_t ldq, uint32_t ldd,
@@ -41,7 +46,15 @@ void k_gemm_tn_f32(const float* __restrict__ R, const float* __restrict__ Q, flo
     // row tiles fastest: concurrently resident workgroups share the same panel of At.  With a
     // tile list only its `nact` tiles are computed, by the leading nact*ntiles workgroups.
     uint32_t bm, bn;
-    if (row_tile_skip != nullptr) {
+    if (SYM) {
+        // blockIdx.x = bn (bn + 1) / 2 + bm with bm <= bn
+        const uint32_t b = blockIdx.x;
+        uint32_t t = (uint32_t)((__fsqrt_rn(8.f * (float)b + 1.f) - 1.f) * 0.5f);
+        while ((uint64_t)t * (t + 1u) / 2u > b) --t;
+        while ((uint64_t)(t + 1u) * (t + 2u) / 2u <= b) ++t;
+        bn = t;
+        bm = b - (uint32_t)((uint64_t)t * (t + 1u) / 2u);
+    } else if (row_tile_skip != nullptr) {
         const uint32_t nact = row_tile_skip[mtiles];
         if (nact == 0 || blockIdx.x / nact >= gridDim.x / mtiles) return;
         bm = row_tile_skip[blockIdx.x % nact];
@@ -132,6 +145,16 @@ void k_gemm_tn_f32(const float* __restrict__ R, const float* __restrict__ Q, flo
             for (int e = 0; e < 16; ++e) {
                 const uint32_t row = bm * GM + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 D[(size_t)row * ldd + col] = acc[i][j][e];
+            }
+            if (SYM && bm != bn) {
+                // the mirrored tile: registers 4g .. 4g+3 are four consecutive rows, i.e. 16 contiguous bytes of
+                // row `col` of G; the two half-waves and the four groups fill one 128-byte line per column
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t row0 = bm * GM + wm * 64 + i * 32 + 8 * g + 4 * h;
+                    v4f v = { acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3] };
+                    *reinterpret_cast<v4f*>(&D[(size_t)col * ldd + row0]) = v;
+                }
             }
         }
 }
@@ -657,9 +680,22 @@ hipError_t launch_gemm_tn_f32(const ss_hip_ctx* ctx, const float* R, uint32_t Mg
 {
     if (Mg % GM != 0 || ctx->n_pad % GN != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
     const uint32_t mtiles = Mg / GM, ntiles = ctx->n_pad / GN;
-    hipLaunchKernelGGL(k_gemm_tn_f32, dim3(mtiles * ntiles), dim3(256), 0, ctx->stream, R,
+    hipLaunchKernelGGL(k_gemm_tn_f32<false>, dim3(mtiles * ntiles), dim3(256), 0, ctx->stream, R,
                        static_cast<const float*>(ctx->At), D, mtiles, ctx->ldm, ldr, ctx->ldm, ldd,
                        row_tile_skip);
+    return hipGetLastError();
+}
+
+// G[n_pad][ldd] = At · At^T from the tiles on and above the diagonal, each stored to both sides
+hipError_t launch_gemm_sym_f32(const ss_hip_ctx* ctx, float* G, uint32_t ldd)
+{
+    if (ctx->n_pad % GN != 0 || ctx->ldm % GK != 0 || ldd % 4 != 0) return hipErrorInvalidValue;
+    const uint64_t t = ctx->n_pad / GN;
+    const uint64_t blocks = t * (t + 1) / 2;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const float* At = static_cast<const float*>(ctx->At);
+    hipLaunchKernelGGL(k_gemm_tn_f32<true>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, At, At, G, (uint32_t)t,
+                       ctx->ldm, ctx->ldm, ctx->ldm, ldd, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 

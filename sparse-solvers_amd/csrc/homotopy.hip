@@ -18,6 +18,7 @@
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -153,6 +154,60 @@ void upload_matrix(ss_hip_ctx* ctx, const T* A, ptrdiff_t rs, ptrdiff_t cs)
         throw;
     }
     HIPCHK(hipFree(stage));
+}
+
+// ---- compact output: one fixed-size record per signal, packed from the solver's own lists ----------
+// Record layout (include/ss_hip.h): u32 K, u32 iter, f64 err, u32 idx[kmax], T val[kmax].
+// The non-zero coefficients of x live on the columns of the slot's `touched` list (every column that was
+// ever in the support: reference mode, where a leaving column may keep a rounding residue) or on its
+// support list (zero_on_removal = 1: leaving columns carry exact zeros) — both sorted by column, so a
+// stable compaction of the entries with x != 0 gives the record without scanning the n coefficients.
+inline size_t record_bytes(uint32_t kmax, size_t elem) { return (16 + (size_t)kmax * (4 + elem) + 7) & ~(size_t)7; }
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_pack_records(const T* __restrict__ x, const uint32_t* __restrict__ gam2, const uint32_t* __restrict__ touched2,
+                    const DevState* __restrict__ st, SlotDims L, int use_touched, uint32_t kmax,
+                    unsigned char* __restrict__ rec, size_t rec_bytes)
+{
+    const size_t s = blockIdx.x;
+    x += s * L.n_pad;
+    st += s;
+    const uint32_t cur = st->cur;
+    const uint32_t* list = (use_touched ? touched2 : gam2) + s * 2 * (size_t)L.kcap + (size_t)cur * L.kcap;
+    // (a solve that ended on an emptied support keeps the one column in its list: its x is handed back)
+    uint32_t cnt = use_touched ? st->ntouched : st->K;
+    if (cnt == 0u) cnt = 1u;
+    if (cnt > L.kcap) cnt = L.kcap;
+    unsigned char* r = rec + s * rec_bytes;
+    uint32_t* idx = reinterpret_cast<uint32_t*>(r + 16);
+    T* val = reinterpret_cast<T*>(r + 16 + (size_t)kmax * 4);
+    __shared__ uint32_t s_w[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t base = 0;
+    for (uint32_t j0 = 0; j0 < cnt; j0 += 256u) {
+        const uint32_t j = j0 + tid;
+        uint32_t col = 0;
+        T v = T(0);
+        if (j < cnt) { col = list[j]; v = x[col]; }
+        const bool nz = j < cnt && v != T(0);
+        const uint64_t bal = __ballot(nz);
+        __syncthreads();
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < 4u; ++w) { if (w < wave) before += s_w[w]; total += s_w[w]; }
+        const uint32_t pos = base + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (nz && pos < kmax) { idx[pos] = col; val[pos] = v; }
+        base += total;
+    }
+    for (uint32_t p = (base < kmax ? base : kmax) + tid; p < kmax; p += 256u) { idx[p] = 0u; val[p] = T(0); }
+    for (size_t p = 16 + (size_t)kmax * (4 + sizeof(T)) + tid; p < rec_bytes; p += 256u) r[p] = 0;     // alignment padding
+    if (tid == 0) {
+        reinterpret_cast<uint32_t*>(r)[0] = base;
+        reinterpret_cast<uint32_t*>(r)[1] = st->iter;
+        *reinterpret_cast<double*>(r + 8) = st->c_inf;
+    }
 }
 
 template <typename T>
@@ -366,11 +421,11 @@ template <typename T> struct Lookahead {
             HIPCHK(hipMalloc(&ws.solo_log, ((size_t)kSoloHeaderWords + (size_t)kSoloLogCap * kSoloEntryWords) * sizeof(uint32_t)));
             HIPCHK(hipMalloc(&ws.solo_stage, (size_t)kSoloStageWords * sizeof(uint32_t)));
             HIPCHK(hipMalloc(&ws.sub_pos, (size_t)ctx->n_pad));
-            HIPCHK(hipMemset(ws.sub_pos, 0, (size_t)ctx->n_pad));
+            HIPCHK(hipMemsetAsync(ws.sub_pos, 0, (size_t)ctx->n_pad, ctx->stream));
             HIPCHK(hipMalloc(&ws.v_max, (size_t)kSoloLogCap * ws.nvwg * sizeof(uint32_t)));
             HIPCHK(hipMalloc(&ws.v_min, (size_t)kSoloLogCap * ws.nvwg * sizeof(uint64_t)));
             HIPCHK(hipMalloc(&ws.cand_top, 2 * (size_t)ws.nvwg * sizeof(uint64_t)));
-            HIPCHK(hipMemset(ws.cand_top, 0xff, 2 * (size_t)ws.nvwg * sizeof(uint64_t)));
+            HIPCHK(hipMemsetAsync(ws.cand_top, 0xff, 2 * (size_t)ws.nvwg * sizeof(uint64_t), ctx->stream));
         }
         ws.gcap = (uint32_t)want;
         ws.gpitch = gpitch;
@@ -484,10 +539,31 @@ hipEvent_t prof_event(ss_hip_ctx* ctx, size_t i)
     return ctx->prof_events[i];
 }
 
+// compact output: pack the records of `nslots` finished slots into the context's staging buffer (device)
+template <typename T>
+unsigned char* pack_records(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t kmax)
+{
+    const size_t rb = record_bytes(kmax, sizeof(T));
+    const size_t need = rb * nslots;
+    if (ctx->rec_stage_bytes < need) {
+        if (ctx->rec_stage) HIPCHK(hipFree(ctx->rec_stage));
+        ctx->rec_stage = nullptr;
+        ctx->rec_stage_bytes = 0;
+        HIPCHK(hipMalloc(&ctx->rec_stage, need));
+        ctx->rec_stage_bytes = need;
+    }
+    hipLaunchKernelGGL((k_pack_records<T>), dim3(nslots), dim3(256), 0, ctx->stream, (const T*)ws.x, (const uint32_t*)ws.gam,
+                       (const uint32_t*)ws.touched, (const DevState*)ws.st, ws.dims, ctx->zero_on_removal ? 0 : 1, kmax,
+                       ctx->rec_stage, rb);
+    HIPCHK(hipGetLastError());
+    return ctx->rec_stage;
+}
+
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
                ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
-               bool omp = false, bool force_residual = false, bool no_solo = false)
+               bool omp = false, bool force_residual = false, bool no_solo = false,
+               void* rec_out = nullptr, uint32_t kmax = 0)
 {
     if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
     if (ctx->kind != 0) { set_err(err, errlen, "solve: this context was created for IRLS"); return SS_HIP_EINVAL; }
@@ -495,7 +571,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         set_err(err, errlen, "solve: element type of the call does not match the context");
         return SS_HIP_ETYPE;
     }
-    if (!y || !x) { set_err(err, errlen, "solve: y and x must not be null"); return SS_HIP_EINVAL; }
+    if (!y || (!x && !rec_out)) { set_err(err, errlen, "solve: y and x must not be null"); return SS_HIP_EINVAL; }
     // preconditions the reference asserts (homotopy-cpu.cpp:193-199)
     if (max_iter == 0) { set_err(err, errlen, "solve: max_iterations must be > 0"); return SS_HIP_EINVAL; }
     if (!(tol >= std::numeric_limits<T>::epsilon() && tol < T(1))) {
@@ -552,15 +628,15 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const bool la_omp = omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && ctx->la_fused >= 1;
         bool solo = false, solo_started = false;
         // full-G mode (fp32): G = A^T A of the context as the cache.  G exists once a large batch has run
-        // on the context, or is made here after `gram_full_after` single-signal solves (0.55 s and 17 GiB
-        // at C2 against ~1 ms saved per solve from then on).
+        // on the context, or — opt-in, option gram_full_after > 0 — is made here after that many single-signal
+        // solves (17 GiB and a few tenths of a second at C2 against ~0.6 ms saved per solve from then on).
         struct FullGramView {
             Workspace<T>& w; bool on = false;
             ~FullGramView() { if (on) { w.gcache = w.gcache_own; w.gpitch = w.gpitch_own; w.slot_of = w.slot_of_own; w.gram_is_full = false; } }
         } full_view{ ws };
         auto enter_full_gram = [&]() {
-            if (sizeof(T) != 4 || ctx->engine < 1 || ws.gram_is_full) return;     // (a retry runs inside the outer view)
-            if (!ctx->gram_full && ctx->gram_full_after > 0 && ctx->stats.solves + 1 >= (uint64_t)ctx->gram_full_after)
+            if (sizeof(T) != 4 || ctx->engine < 1 || ws.gram_is_full || !ctx->gram_single) return;     // (a retry runs inside the outer view)
+            if (!ctx->gram_full && ctx->gram_full_after > 0 && ctx->single_solves + 1 >= (uint64_t)ctx->gram_full_after)
                 (void)ensure_full_gram(ctx);
             if (!ctx->gram_full) return;
             if (!ws.slot_identity) {
@@ -592,13 +668,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
-            // Speculative form (fp32, exact zeros on removal like the resident kernel): the default
+            // Speculative form (fp32): the default
             // (la_fused = 3).  It also runs where the resident kernel cannot (dictionaries too wide for one
             // launch to own every column).
             const bool solo_wanted = ctx->la_fused >= 3;
             // (not with the full Gram matrix as the cache: there every entering column's row slice is a gather of
             // 256 scattered entries of a 256-KiB row in the iteration's chain — 1.81 ms per C2 solve against 1.55 ms)
-            solo = solo_wanted && !no_solo && ctx->solo_off_solves == 0 && ctx->zero_on_removal && sizeof(T) == 4 &&
+            solo = solo_wanted && !no_solo && ctx->solo_off_solves == 0 && sizeof(T) == 4 &&
                    (!ws.gram_is_full || ctx->solo_full_gram) && la_solo_usable(ctx);
             if (solo_wanted && !solo && ctx->solo_off_solves > 0 && !no_solo) ctx->solo_off_solves -= 1;
             solo_started = solo;
@@ -629,7 +705,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             // resident kernel: LDS tier (support columns it can hold); 0 = one launch per iteration
             uint32_t lds_cols = 0;
             const uint32_t kcap_ws = ws.dims.kcap;       // what the device checks K against (>= this solve's kcap)
-            if (la && ctx->la_fused >= 2 && ctx->zero_on_removal && sizeof(T) == 4) {
+            if (la && ctx->la_fused >= 2 && sizeof(T) == 4) {
                 lds_cols = std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsSmall);
                 if (!la_persist_usable(ctx, lds_cols)) lds_cols = 0;
             }
@@ -726,7 +802,12 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
 
         DevState hs;
         HIPCHK(hipMemcpyAsync(&hs, ws.st, sizeof(DevState), hipMemcpyDeviceToHost, st));
-        copy_out<T>(ctx, x, incx, ws.x, n);
+        if (x) copy_out<T>(ctx, x, incx, ws.x, n);
+        if (rec_out) {
+            // compact output (a record that is superseded by a retry below is simply overwritten)
+            const unsigned char* stage = pack_records<T>(ctx, ws, 1, kmax);
+            HIPCHK(hipMemcpyAsync(rec_out, stage, record_bytes(kmax, sizeof(T)), hipMemcpyDefault, st));
+        }
         if (prof) HIPCHK(hipEventRecord(ctx->ev_solve1, st));
         HIPCHK(hipStreamSynchronize(st));
 
@@ -737,7 +818,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         if ((la || la_omp) && hs.status == kStatusRetryResidual) {
             // tolerance too tight for Gram-form correlations (see k_la_init_pick): residual form
             ctx->stats.gram_fallbacks += 1;
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, true, no_solo);
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, true, no_solo, rec_out, kmax);
         }
         if (la && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 2 && (ctx->persist_workers[0] != 0 || ctx->persist_workers[1] != 0)) {
             // the resident kernel gave up on a wait (its grid was not fully resident): this context
@@ -745,14 +826,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             ctx->persist_workers[0] = 0;
             ctx->persist_workers[1] = 0;
             ctx->stats.persist_fallbacks += 1;
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo);
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax);
         }
         if ((la || la_omp) && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 1) {
             // k_la_iter's grid barrier expired as well (the GPU is shared with another resident grid):
             // from here on this context uses the form without in-kernel grid synchronisation
             ctx->la_fused = 0;
             ctx->stats.persist_fallbacks += 1;
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo);
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax);
         }
         if (hs.status != 0) {
             set_err(err, errlen, hs.status == SS_HIP_ECAPACITY
@@ -778,6 +859,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         }
 
         ctx->stats.solves += 1;
+        ctx->single_solves += 1;
         if (solo_started) {
             // Speculative launches that failed their check cost a replay and the rest of the solve in the
             // resident form; contexts whose problems do that on most solves stop speculating for a while.
@@ -856,9 +938,24 @@ bool ensure_full_gram(ss_hip_ctx* ctx)
         return false;
     }
     float* G = nullptr;
+    const auto t_alloc = std::chrono::steady_clock::now();
     if (hipMalloc(&G, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
-    const hipError_t e = launch_gemm_tn_f32(ctx, static_cast<const float*>(ctx->At), (uint32_t)np, ctx->ldm, G, pitch, nullptr);
+    ctx->stats.gram_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count();
+    hipEvent_t g0 = nullptr, g1 = nullptr;
+    if (hipEventCreate(&g0) != hipSuccess || hipEventCreate(&g1) != hipSuccess) { (void)hipGetLastError(); g0 = g1 = nullptr; }
+    if (g0) (void)hipEventRecord(g0, ctx->stream);
+    const hipError_t e = ctx->gram_symmetric
+        ? launch_gemm_sym_f32(ctx, G, pitch)
+        : launch_gemm_tn_f32(ctx, static_cast<const float*>(ctx->At), (uint32_t)np, ctx->ldm, G, pitch, nullptr);
+    if (g1) (void)hipEventRecord(g1, ctx->stream);
     if (e != hipSuccess) { (void)hipFree(G); throw HipFail{ e, "launch_gemm_tn_f32(full Gram)" }; }
+    if (g0 && g1 && hipEventSynchronize(g1) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g0, g1) == hipSuccess) ctx->stats.gram_build_ms += ms;
+    }
+    (void)hipGetLastError();
+    if (g0) (void)hipEventDestroy(g0);
+    if (g1) (void)hipEventDestroy(g1);
     ctx->gram_full = G;
     ctx->gram_pitch = pitch;
     ctx->stats.gram_full_builds += 1;
@@ -869,7 +966,8 @@ bool ensure_full_gram(ss_hip_ctx* ctx)
 // (c = c0 - sum_j x_j G[j], q = sum_j d_j G[j]) instead of two GEMMs per round
 int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy,
                          float tol, uint32_t max_iter, float* X, ptrdiff_t x_stride, ptrdiff_t incx,
-                         uint32_t* iter_out, double* err_out, char* err, size_t errlen, bool gram = false)
+                         uint32_t* iter_out, double* err_out, char* err, size_t errlen, bool gram = false,
+                         void* rec_out = nullptr, uint32_t kmax = 0)
 {
     using T = float;
     if (max_iter == 0) { set_err(err, errlen, "solve_batch: max_iterations must be > 0"); return SS_HIP_EINVAL; }
@@ -942,6 +1040,7 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             volatile uint32_t* hf = ctx->host_flags;
             const uint64_t last_round = (uint64_t)max_iter + 1;
             uint64_t rounds_run = 0;
+            size_t ncq = 0;                                  // timed k_la_cq launches of this chunk (profiling on)
             for (uint64_t round = 1; round <= last_round; ++round) {
                 if (round > L) {
                     const uint32_t need = (uint32_t)(round - L);
@@ -957,7 +1056,10 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                     if (hf[1] != 0) break;
                 }
                 if (gram_chunk) {
+                    const bool timed_cq = ctx->profiling != 0 && ncq < 4096;
+                    if (timed_cq) HIPCHK(hipEventRecord(prof_event(ctx, 2 * ncq), st));
                     HIPCHK(launch_cq_gram_batched<T>(ctx, ws, Bc, ctx->gram_full, ctx->gram_pitch, ctx->c0_batch, &nparts));
+                    if (timed_cq) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * ncq + 1), st)); ++ncq; }
                     HIPCHK(launch_tail_gram_batched<T>(ctx, ws, Bc, (uint32_t)round, nparts, tol, max_iter,
                                                        ctx->gram_full, ctx->gram_pitch));
                 } else {
@@ -971,8 +1073,14 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             }
             hs.resize(Bc);
             HIPCHK(hipMemcpyAsync(hs.data(), ws.st, (size_t)Bc * sizeof(DevState), hipMemcpyDeviceToHost, st));
-            float* Xc = X + (ptrdiff_t)b0 * x_stride;
-            if (incx == 1) {
+            if (rec_out) {
+                const size_t rb = record_bytes(kmax, sizeof(T));
+                const unsigned char* stage = pack_records<T>(ctx, ws, Bc, kmax);
+                HIPCHK(hipMemcpyAsync(static_cast<unsigned char*>(rec_out) + b0 * rb, stage, rb * Bc, hipMemcpyDefault, st));
+            }
+            float* Xc = X ? X + (ptrdiff_t)b0 * x_stride : nullptr;
+            if (!X) {
+            } else if (incx == 1) {
                 HIPCHK(hipMemcpy2DAsync(Xc, (size_t)x_stride * sizeof(T), ws.x, np * sizeof(T), n * sizeof(T), Bc,
                                         hipMemcpyDefault, st));
             } else {
@@ -988,6 +1096,26 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             }
             ctx->stats.solves += Bc;
             ctx->stats.batch_rounds += rounds_run;
+            if (ncq != 0) {
+                // rounds enqueued behind the end of the batch are no-ops (microseconds): only launches that
+                // belong to a round some signal was still running in are counted, with their bytes
+                uint32_t live_rounds = 0;
+                for (uint32_t b = 0; b < Bc; ++b) live_rounds = std::max(live_rounds, std::min<uint32_t>(hs[b].iter + 1u, max_iter));
+                for (size_t i = 0; i < ncq && i < live_rounds; ++i) {
+                    float ms = 0.f;
+                    HIPCHK(hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
+                    ctx->stats.cq_ms += ms;
+                    ctx->stats.cq_launches += 1;
+                }
+                // a signal with `it` iterations is live in rounds 1 .. it + 1 (the last one finds the end); in
+                // round r its list holds r columns (one per iteration; removals make this an upper bound)
+                uint64_t rows = 0;
+                for (uint32_t b = 0; b < Bc; ++b) {
+                    const uint64_t r = std::min<uint64_t>(std::min<uint32_t>(hs[b].iter + 1u, max_iter), ncq);
+                    rows += r * (r + 1) / 2 + 3 * r;
+                }
+                ctx->stats.cq_bytes += rows * (uint64_t)n * sizeof(T);
+            }
         }
     } catch (const HipFail& f) {
         set_err(err, errlen, hip_msg(f));
@@ -1002,13 +1130,15 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
 template <typename T>
 int solve_batch_seq(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, T tol,
                     uint32_t max_iter, T* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
-                    double* err_out, char* err, size_t errlen)
+                    double* err_out, char* err, size_t errlen, void* rec_out = nullptr, uint32_t kmax = 0)
 {
+    const size_t rb = record_bytes(kmax, sizeof(T));
     for (size_t b = 0; b < B; ++b) {
         uint32_t it = 0;
         double e = 0.0;
         const int rc = solve_impl<T>(ctx, Y + (ptrdiff_t)b * y_stride, incy, tol, max_iter,
-                                     X + (ptrdiff_t)b * x_stride, incx, &it, &e, err, errlen);
+                                     X ? X + (ptrdiff_t)b * x_stride : nullptr, incx, &it, &e, err, errlen, false, false, false,
+                                     rec_out ? static_cast<unsigned char*>(rec_out) + b * rb : nullptr, kmax);
         if (rc != SS_HIP_OK) return rc;
         if (iter_out) iter_out[b] = it;
         if (err_out) err_out[b] = e;
@@ -1018,7 +1148,7 @@ int solve_batch_seq(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, p
 
 int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, float tol,
                          uint32_t max_iter, float* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
-                         double* err_out, char* err, size_t errlen)
+                         double* err_out, char* err, size_t errlen, void* rec_out = nullptr, uint32_t kmax = 0)
 {
     // lock-step MFMA path once enough signals share the matrix (batch_min option, default 192)
     if (B >= (size_t)std::max(2, ctx->batch_min)) {
@@ -1034,30 +1164,35 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 return SS_HIP_ERUNTIME;
             }
         }
-        return solve_batch_gemm_f32(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, gram);
+        return solve_batch_gemm_f32(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, gram,
+                                    rec_out, kmax);
     }
-    return solve_batch_seq<float>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen);
+    return solve_batch_seq<float>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
 }
 
 int solve_batch_dispatch(ss_hip_ctx* ctx, const double* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, double tol,
                          uint32_t max_iter, double* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
-                         double* err_out, char* err, size_t errlen)
+                         double* err_out, char* err, size_t errlen, void* rec_out = nullptr, uint32_t kmax = 0)
 {
     // fp64: one signal at a time (memory-bound sweep path)
-    return solve_batch_seq<double>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen);
+    return solve_batch_seq<double>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
 }
 
 template <typename T>
 int solve_batch_impl(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, T tol,
                      uint32_t max_iter, T* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
-                     double* err_out, char* err, size_t errlen)
+                     double* err_out, char* err, size_t errlen, void* rec_out = nullptr, uint32_t kmax = 0)
 {
     if (!ctx) { set_err(err, errlen, "solve_batch: null context"); return SS_HIP_EINVAL; }
     if (ctx->kind != 0) { set_err(err, errlen, "solve_batch: this context was created for IRLS"); return SS_HIP_EINVAL; }
     if (ctx->is_f64 != (sizeof(T) == 8)) { set_err(err, errlen, "solve_batch: element type mismatch"); return SS_HIP_ETYPE; }
-    if (!Y || !X) { set_err(err, errlen, "solve_batch: Y and X must not be null"); return SS_HIP_EINVAL; }
+    if (!Y || (!X && !rec_out)) { set_err(err, errlen, "solve_batch: Y and the output must not be null"); return SS_HIP_EINVAL; }
+    if (rec_out && (kmax == 0 || kmax > kKcapLimit || (reinterpret_cast<uintptr_t>(rec_out) & 7u))) {
+        set_err(err, errlen, "solve_batch_compact: kmax must be 1..4096 and records 8-byte aligned");
+        return SS_HIP_EINVAL;
+    }
     if (B == 0) return SS_HIP_OK;
-    return solve_batch_dispatch(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen);
+    return solve_batch_dispatch(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
 }
 
 template <typename T>
@@ -1297,6 +1432,7 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     sship::irls_free(ctx);
     if (ctx->gram_full) (void)hipFree(ctx->gram_full);
     if (ctx->c0_batch) (void)hipFree(ctx->c0_batch);
+    if (ctx->rec_stage) (void)hipFree(ctx->rec_stage);
     if (ctx->At) (void)hipFree(ctx->At);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
@@ -1348,6 +1484,22 @@ int ss_hip_homotopy_solve_batch_f64(ss_hip_ctx* ctx, const double* Y, size_t B, 
 {
     return solve_batch_impl<double>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx,
                                     iter_out, err_out, err, errlen);
+}
+
+size_t ss_hip_record_bytes(uint32_t kmax, int is_f64) { return record_bytes(kmax, is_f64 ? 8 : 4); }
+
+int ss_hip_homotopy_solve_batch_compact_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy,
+                                            float tol, uint32_t max_iter, uint32_t kmax, void* records, char* err, size_t errlen)
+{
+    if (!records) { set_err(err, errlen, "solve_batch_compact: records must not be null"); return SS_HIP_EINVAL; }
+    return solve_batch_impl<float>(ctx, Y, B, y_stride, incy, tol, max_iter, nullptr, 0, 1, nullptr, nullptr, err, errlen, records, kmax);
+}
+
+int ss_hip_homotopy_solve_batch_compact_f64(ss_hip_ctx* ctx, const double* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy,
+                                            double tol, uint32_t max_iter, uint32_t kmax, void* records, char* err, size_t errlen)
+{
+    if (!records) { set_err(err, errlen, "solve_batch_compact: records must not be null"); return SS_HIP_EINVAL; }
+    return solve_batch_impl<double>(ctx, Y, B, y_stride, incy, tol, max_iter, nullptr, 0, 1, nullptr, nullptr, err, errlen, records, kmax);
 }
 
 int ss_hip_gemv_t_f32(ss_hip_ctx* ctx, const float* r, float* c, int repeats, float* ms_out,
@@ -1436,6 +1588,8 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "batch_gram_min")) { ctx->batch_gram_min = (int)std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_full_gib")) { ctx->gram_full_gib = std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_full_after")) { ctx->gram_full_after = std::max<long>(0, value); return SS_HIP_OK; }
+    if (!std::strcmp(key, "gram_single"))   { ctx->gram_single = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "gram_symmetric")) { ctx->gram_symmetric = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { ctx->batch_chunk = (int)std::max<long>(4, value); return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
@@ -1489,6 +1643,8 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "batch_gram_min")) { *value = ctx->batch_gram_min; return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_full_gib")) { *value = ctx->gram_full_gib; return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_full_after")) { *value = ctx->gram_full_after; return SS_HIP_OK; }
+    if (!std::strcmp(key, "gram_single"))   { *value = ctx->gram_single; return SS_HIP_OK; }
+    if (!std::strcmp(key, "gram_symmetric")) { *value = ctx->gram_symmetric; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { *value = ctx->batch_chunk; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }

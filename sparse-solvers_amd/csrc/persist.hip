@@ -34,7 +34,9 @@
 //
 // The arithmetic is the same, in the same order, as k_la_iter's (sorted support, sequential
 // accumulation over j, the same reductions), so the two produce identical paths, bit for bit.
-// Requires option zero_on_removal = 1 (columns that left the support carry exact zeros).
+// Columns that left the support must carry exact zeros here (the lists hold the support only): with option
+// zero_on_removal = 1 they always do; in reference mode (0, the default) a removal whose x + gamma*d is not
+// exactly 0 ends the launch and k_la_iter, which walks every column ever touched, goes on.
 // Compiled with -ffp-contract=off like activeset.hip.
 //
 // k_la_persist<true> is the SPECULATIVE ("solo") form, the default for fp32: ONE workgroup runs the same
@@ -214,7 +216,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                   float* c, float* q, float* c_alt, float* q_alt, float* x, float* d, uint8_t* insup,
                   uint32_t* gam2, float* inv0, float* inv1, float* __restrict__ tcand,
                   SlotDims L, DevState* st, LaSync* sy, uint64_t* smax, uint64_t* smin, uint32_t* hflags,
-                  TraceEntry* trace, uint32_t trace_cap, int tie_guard, uint64_t* dbg, SoloArgs sa)
+                  TraceEntry* trace, uint32_t trace_cap, int tie_guard, int zero_on_removal, uint32_t* touched2,
+                  uint64_t* dbg, SoloArgs sa)
 {
     extern __shared__ float smem[];
     __shared__ float sv[16];
@@ -804,8 +807,15 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         const uint32_t rank = s_cnt[0];
         const bool added = s_cnt[1] == 0u;
         const uint32_t K_new = added ? K + 1u : K - 1u;
+        // Reference behaviour (option zero_on_removal = 0, the default): the column that leaves keeps
+        // x + gamma*d (homotopy-cpu.cpp:252) — 0, or an ulp of residue that stays in x for good and goes on
+        // contributing to c.  This kernel's lists hold the support only: an exact 0 is handled here (it is what
+        // the lists assume), a residue ends the launch at this iteration boundary and the launch-per-iteration
+        // form (k_la_iter, which walks every column ever touched) repeats the iteration and goes on.
+        bool residue = false;
+        if (!zero_on_removal && !added && !no_candidate && K_new != 0u) residue = (S.xs[rank] + g * S.ds[rank]) != 0.f;
         if (SOLO) {
-            if (no_candidate || K_new == 0u || K_new > kcap || !(c_inf - g > tol)) {
+            if (no_candidate || K_new == 0u || K_new > kcap || !(c_inf - g > tol) || residue) {
                 // Left to the resident form (nothing of this iteration has been committed yet): the rare
                 // endings (no step, empty support, workspace full) and the LAST step of a path — it takes
                 // lambda to ~0, where every column's candidate ties within rounding and no subset can know
@@ -814,6 +824,9 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 break;
             }
             log_entry(1u, round, c_inf, g, idx, gs_log, is_log);
+        } else if (residue) {
+            exit_code = kPsExitResidue;                // (same decision in every workgroup: same inputs, same bits)
+            break;
         }
         if (lead && trace != nullptr && tid == 0 && round < trace_cap) {
             trace[round].idx = idx;
@@ -1091,6 +1104,18 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         x[cl] = S.xs[tid];
         d[cl] = S.ds[tid];
     }
+    if (!zero_on_removal) {
+        // reference mode: k_la_iter / k_la_cq walk the `touched` list (every column whose x may be non-zero).
+        // Columns that left the support inside this kernel carry exact zeros (a residue ends the launch), so
+        // the list that will be current — this support, or the pending one — is all of it.
+        uint32_t* const tch = touched2 + (size_t)(save_lists_for_update ? (cur ^ 1u) : cur) * kcap;
+        const uint32_t Kt = save_lists_for_update ? K + 1u : K;
+        if (tid < Kt) {
+            const uint32_t o = save_lists_for_update ? tid - (tid > pend_rank ? 1u : 0u) : tid;
+            tch[tid] = (save_lists_for_update && tid == pend_rank) ? pend_idx : S.gam[o];
+        }
+        if (tid == 0) st->ntouched = Kt;
+    }
     if (tid == 0) {
         sy->tick = tick;
         st->K = report_empty ? 0u : (save_lists_for_update ? K + 1u : K);
@@ -1113,7 +1138,9 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             st->nmiss = nm;
             __hip_atomic_store(&hflags[2], nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
-            __hip_atomic_store(&hflags[3], K + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // the support outgrew the tier (the host picks the next one), or a removal left a rounding residue in
+            // x: 0xffffffff = no tier will do, the launch-per-iteration form goes on
+            __hip_atomic_store(&hflags[3], exit_code == kPsExitResidue ? 0xffffffffu : K + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         bump_seq(st, hflags);
     }
@@ -1188,7 +1215,7 @@ hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float to
     hipLaunchKernelGGL(k_la_persist<false>, dim3(nw), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, persist_gl_rows(P), ws.gram_is_full ? 1 : 0,
                        (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
-                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg, SoloArgs{});
+                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ctx->zero_on_removal, ws.touched, ws.la_dbg, SoloArgs{});
     return hipGetLastError();
 }
 
@@ -1231,7 +1258,7 @@ hipError_t launch_la_solo_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     hipLaunchKernelGGL(k_la_persist<true>, dim3(1), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, kSoloGlRows, ws.gram_is_full ? 1 : 0,
                        (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
-                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ws.la_dbg, sa);
+                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ctx->zero_on_removal, ws.touched, ws.la_dbg, sa);
     return hipGetLastError();
 }
 

@@ -342,6 +342,7 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
 struct CommitArgs {
     const uint32_t* stage;
     float* x; float* d; uint8_t* insup; uint32_t* gam2; float* inv0; float* inv1; uint32_t kcap; LaSync* sy;
+    uint32_t* touched2; int zero_on_removal;
 };
 
 constexpr int kPubThreads = 1024;            // 16 threads per log entry; the commit copies with all of them
@@ -468,6 +469,14 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
         }
         if (save)
             for (uint32_t j = tid; j < K + 1u; j += kPubThreads) gam_alt[j] = sg[kSoloStageHead + 3 * LP + j];
+        if (!ca.zero_on_removal) {
+            // reference mode: the `touched` list k_la_iter / k_la_cq walk (columns whose x may be non-zero).  A solo
+            // launch never commits a removal that leaves a rounding residue (it hands over before), so the list
+            // that will be current — the staged support, or the pending one — is all of it.
+            uint32_t* const tch = ca.touched2 + (size_t)(save ? (cur ^ 1u) : cur) * kcap;
+            const uint32_t Kt = save ? K + 1u : K;
+            for (uint32_t j = tid; j < Kt; j += kPubThreads) tch[j] = sg[kSoloStageHead + (save ? 3u : 0u) * LP + j];
+        }
     }
     __syncthreads();
     if (tid != 0) return;
@@ -481,6 +490,7 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
         st->idx = sg[5];
         st->rank = sg[6];
         st->added = sg[7];
+        if (!ca.zero_on_removal) st->ntouched = save ? K + 1u : K;
     }
     bool off = pending == 2u;                          // after a replay the resident form goes on
     if (code == kPsExitDone) {
@@ -602,6 +612,7 @@ hipError_t launch_la_verify_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
     ca.stage = ws.solo_stage;
     ca.x = ws.x; ca.d = ws.d; ca.insup = ws.insup; ca.gam2 = ws.gam; ca.inv0 = ws.inv[0]; ca.inv1 = ws.inv[1];
     ca.kcap = ws.dims.kcap; ca.sy = ws.la_sync;
+    ca.touched2 = ws.touched; ca.zero_on_removal = ctx->zero_on_removal;
     hipLaunchKernelGGL(k_la_vpublish, dim3(1), dim3(kPubThreads), 0, ctx->stream, (const uint32_t*)ws.solo_log, ws.st,
                        (const uint32_t*)ws.v_max, (const uint64_t*)ws.v_min, ws.nvwg, ctx->dev_flags, ca);
     return hipGetLastError();

@@ -121,6 +121,7 @@ enum : uint32_t {
     kPsExitLogFull = 5,    // solo: log full or replay finished — the next launch goes on
     kPsExitHandOver = 6,   // solo: last step of a path / rare ending — the resident form goes on
     kPsExitNothing = 7,    // solo: the launch could not start (support beyond its tier) — nothing staged
+    kPsExitResidue = 8,    // resident form, reference mode: a leaving column keeps a rounding residue — k_la_iter goes on
 };
 constexpr uint32_t kSoloStageHead = 16;
 constexpr uint32_t kSoloStageWords = kSoloStageHead + 4 * kSoloListPitch + 1 + kSoloListPitch * kSoloListPitch;
@@ -222,9 +223,14 @@ struct ss_hip_ctx {
     uint32_t gram_pitch = 0;
     float* c0_batch = nullptr;
     size_t c0_batch_rows = 0;
+    unsigned char* rec_stage = nullptr;   // compact output: device staging of the records of one chunk
+    size_t rec_stage_bytes = 0;
     long gram_full_gib = 64;     // option: largest G the batched Gram form may allocate
     int batch_gram_min = 512;    // option: smallest batch that pays for making G (0 = never)
-    long gram_full_after = 512;  // option: single-signal solves on this context after which G is made for them too (0 = never)
+    long gram_full_after = 0;    // option: single-signal solves on this context after which G is made for them too (0 = never: opt-in — 17 GiB and 0.3-0.55 s at C2)
+    int gram_single = 1;         // option: 1 = single-signal solves use G as their Gram-column cache once it exists, 0 = never
+    int gram_symmetric = 1;      // option: 1 = G is formed from the tiles on and above the diagonal + mirrored store, 0 = full product
+    uint64_t single_solves = 0;  // single-signal solves since create (the trigger of gram_full_after; not a statistic)
     int kind = 0;            // 0 = Homotopy / OMP context, 1 = IRLS context
     void* irls = nullptr;    // sship::IrlsState<T>* of an IRLS context
     int device = 0;
@@ -242,8 +248,8 @@ struct ss_hip_ctx {
     long temporal_cols = 0;  // leading dictionary columns swept with cache-allocating loads (rest: nt)
     int lookahead = 4;
     int strict_sign = 0;
-    int zero_on_removal = 1;
-    int tie_guard = 1;
+    int zero_on_removal = 0; // 0 = the reference's x + gamma*d residue on a leaving column (homotopy-cpu.cpp:252); 1 = exact 0 (opt-in)
+    int tie_guard = 0;       // 0 = the reference's strict t > 0 (homotopy-cpu.cpp:135,145,151); 1 = zero-length step on an exact tie (opt-in)
     int profiling = 0;
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
     long cache_mib = 2048;   // budget of the lookahead engine's Gram-column cache
@@ -359,6 +365,9 @@ hipError_t launch_gemv_n(const ss_hip_ctx* ctx, const T* x_dev, T* y_dev);
 // null = all tiles): compact list of the row tiles to compute, count at tile_list[Mg/128].
 hipError_t launch_gemm_tn_f32(const ss_hip_ctx* ctx, const float* R, uint32_t Mg, uint32_t ldr,
                               float* D, uint32_t ldd, const uint32_t* tile_list);
+
+// G[n_pad][ldd] = At · At^T (the full Gram matrix) from the tiles on and above the diagonal + mirrored stores
+hipError_t launch_gemm_sym_f32(const ss_hip_ctx* ctx, float* G, uint32_t ldd);
 
 // D[drows[s]][:] = At · At[rcols[s]][:] for s < 32: 32 right-hand sides in one HBM-bound pass
 // (rcols / drows live on the device; 0xffffffff entries are skipped; with st != null the launch

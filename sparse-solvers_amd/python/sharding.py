@@ -2,9 +2,14 @@
 
 Signals are independent given the sensing matrix, so the batch is cut into contiguous
 blocks, one per rank (A is replicated, no data-path collective).  The only exchange is one
-all_gather of fixed-size support records at the end: for signal s the KMAX largest-|x|
-entries as (index, value) pairs, zero-padded — RCCL over xGMI with the `nccl` backend, gloo
-on CPU tensors in the tests.
+all_gather of fixed-size records at the end — RCCL over xGMI with the `nccl` backend, gloo on
+CPU tensors in the tests.  A record is what ss_hip_homotopy_solve_batch_compact_* writes on the
+device (include/ss_hip.h):
+
+    uint32 K | uint32 iter | float64 err | uint32 idx[kmax] | T val[kmax]      (padded to 8 bytes)
+
+so the multi-GPU path never materialises a dense B x n solution array: the solver packs the records
+from its own support lists and the collective moves them as bytes.
 """
 import numpy as np
 
@@ -18,44 +23,63 @@ def shard_range(total, rank, world):
     return lo, hi
 
 
-def pack_records(X, kmax):
-    """X: (S, n) solutions (torch tensor) -> (S, 2*kmax) float records [idx..., val...]."""
-    import torch
-    S, n = X.shape
-    k = min(int(kmax), n)
-    _, idx = torch.topk(X.abs(), k, dim=1)
-    idx, _ = torch.sort(idx, dim=1)
-    val = torch.gather(X, 1, idx)
-    # entries that are exactly zero carry index -1 (support smaller than kmax)
-    idxf = torch.where(val != 0, idx.to(X.dtype), torch.full_like(val, -1))
-    rec = torch.full((S, 2 * int(kmax)), -1, dtype=X.dtype, device=X.device)
-    rec[:, int(kmax):] = 0
-    rec[:, :k] = idxf
-    rec[:, int(kmax):int(kmax) + k] = val
-    return rec.contiguous()
+def record_bytes(kmax, dtype):
+    """size of one record (== ss_hip_record_bytes(kmax, dtype is float64))"""
+    item = np.dtype(dtype).itemsize
+    return (16 + int(kmax) * (4 + item) + 7) & ~7
 
 
-def unpack_records(rec, kmax, n):
-    """(S, 2*kmax) records -> list of (support indices int64 array, values array)"""
-    rec = np.asarray(rec)
+def record_dtype(kmax, dtype):
+    """numpy structured dtype that overlays a record buffer"""
+    kmax = int(kmax)
+    item = np.dtype(dtype).itemsize
+    return np.dtype({"names": ["K", "iter", "err", "idx", "val"],
+                     "formats": [np.uint32, np.uint32, np.float64, (np.uint32, (kmax,)), (np.dtype(dtype), (kmax,))],
+                     "offsets": [0, 4, 8, 16, 16 + 4 * kmax],
+                     "itemsize": record_bytes(kmax, dtype)})
+
+
+def pack_records_host(X, iters, errs, kmax):
+    """Host statement of the device packer (k_pack_records): dense solutions (S, n) -> (S, record_bytes)
+    uint8.  Used by the CPU tests of the N > 1 path and as the checker of the device records."""
+    X = np.asarray(X)
+    S = X.shape[0]
+    kmax = int(kmax)
+    rec = np.zeros(S, dtype=record_dtype(kmax, X.dtype))
+    for s in range(S):
+        nz = np.nonzero(X[s])[0]
+        rec["K"][s] = len(nz)
+        rec["iter"][s] = iters[s]
+        rec["err"][s] = errs[s]
+        keep = nz[:kmax]
+        rec["idx"][s, :len(keep)] = keep
+        rec["val"][s, :len(keep)] = X[s][keep]
+    return rec.view(np.uint8).reshape(S, -1)
+
+
+def unpack_records(buf, kmax, dtype):
+    """(S, record_bytes) uint8 (numpy, or anything np.asarray accepts) -> list of dicts
+    {K, iter, err, idx (int64), val} with the unused tail of idx / val cut off"""
+    buf = np.ascontiguousarray(np.asarray(buf, dtype=np.uint8))
+    rec = buf.reshape(-1).view(record_dtype(kmax, dtype))
     out = []
-    for row in rec:
-        idx = row[:kmax]
-        val = row[kmax:]
-        keep = idx >= 0
-        out.append((idx[keep].astype(np.int64), val[keep]))
+    for r in rec:
+        k = min(int(r["K"]), int(kmax))
+        out.append({"K": int(r["K"]), "iter": int(r["iter"]), "err": float(r["err"]),
+                    "idx": r["idx"][:k].astype(np.int64), "val": r["val"][:k].copy()})
     return out
 
 
 def gather_records(rec, world, max_rows=None, collective=None):
-    """all_gather of per-rank records.  Ranks may own different numbers of signals: rows are
-    padded to `max_rows` (default: this rank's row count, for equal shards).
-    Returns a (world, max_rows, width) tensor on every rank."""
+    """all_gather of per-rank record buffers (torch uint8 tensors (rows, record_bytes), CPU or device).
+    Ranks may own different numbers of signals: rows are zero-padded to `max_rows` (default: this rank's
+    row count, for equal shards; a padding record has K = 0, iter = 0).
+    Returns a (world, max_rows, record_bytes) tensor on every rank."""
     import torch
     import torch.distributed as dist
     rows = rec.shape[0] if max_rows is None else int(max_rows)
     if rec.shape[0] != rows:
-        pad = torch.full((rows - rec.shape[0], rec.shape[1]), -1, dtype=rec.dtype, device=rec.device)
+        pad = torch.zeros((rows - rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
         rec = torch.cat([rec, pad], dim=0)
     rec = rec.contiguous()
     if world == 1 and not collective:          # collective=True: run the all_gather even for one rank

@@ -25,8 +25,9 @@ SYMBOLS = [
     "ss_hip_homotopy_solve_f32", "ss_hip_homotopy_solve_f64",
     "ss_hip_omp_solve_f32", "ss_hip_omp_solve_f64",
     "ss_hip_homotopy_solve_batch_f32", "ss_hip_homotopy_solve_batch_f64",
+    "ss_hip_record_bytes", "ss_hip_homotopy_solve_batch_compact_f32", "ss_hip_homotopy_solve_batch_compact_f64",
     "ss_hip_gemv_t_f32", "ss_hip_gemv_t_f64", "ss_hip_gemm_t_f32", "ss_hip_gram_cols_f32", "ss_hip_gram_cols_f64",
-    "ss_hip_reconstruct_f32", "ss_hip_reconstruct_f64",
+    "ss_hip_reconstruct_f32", "ss_hip_reconstruct_f64", "ss_hip_norm_l1_f32", "ss_hip_norm_l1_f64",
     "ss_hip_set_profiling", "ss_hip_get_stats", "ss_hip_reset_stats",
     "ss_hip_set_option", "ss_hip_get_option", "ss_hip_get_trace", "ss_hip_ctx_info",
     "ss_hip_irls_create_f32", "ss_hip_irls_create_f64", "ss_hip_irls_solve_f32", "ss_hip_irls_solve_f64",
@@ -55,6 +56,11 @@ class Stats(ctypes.Structure):
         ("gram_full_builds", ctypes.c_uint64),
         ("solo_solves", ctypes.c_uint64),
         ("solo_retries", ctypes.c_uint64),
+        ("gram_build_ms", ctypes.c_double),
+        ("gram_alloc_ms", ctypes.c_double),
+        ("cq_launches", ctypes.c_uint64),
+        ("cq_ms", ctypes.c_double),
+        ("cq_bytes", ctypes.c_uint64),
     ]
 
 
@@ -90,12 +96,18 @@ def lib():
         f = getattr(L, "ss_hip_homotopy_solve_batch_" + suf)
         f.restype = ctypes.c_int
         f.argtypes = [vp, vp, sz, pd, pd, ct, u32, vp, pd, pd, vp, vp, cp, sz]
+        f = getattr(L, "ss_hip_homotopy_solve_batch_compact_" + suf)
+        f.restype = ctypes.c_int
+        f.argtypes = [vp, vp, sz, pd, pd, ct, u32, u32, vp, cp, sz]
         f = getattr(L, "ss_hip_gemv_t_" + suf)
         f.restype = ctypes.c_int
         f.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), cp, sz]
         f = getattr(L, "ss_hip_reconstruct_" + suf)
         f.restype = ctypes.c_int
         f.argtypes = [vp, vp, vp, cp, sz]
+        f = getattr(L, "ss_hip_norm_l1_" + suf)
+        f.restype = ctypes.c_int
+        f.argtypes = [vp, sz, sz, pd, pd, ctypes.c_int, cp, sz]
         f = getattr(L, "ss_hip_irls_create_" + suf)
         f.restype = vp
         f.argtypes = [vp, sz, sz, pd, pd, ctypes.c_int, cp, sz]
@@ -103,6 +115,8 @@ def lib():
         f.restype = ctypes.c_int
         f.argtypes = [vp, vp, pd, ct, u32, vp, pd, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_double),
                       ctypes.POINTER(ctypes.c_int), cp, sz]
+    L.ss_hip_record_bytes.restype = sz
+    L.ss_hip_record_bytes.argtypes = [u32, ctypes.c_int]
     L.ss_hip_gemm_t_f32.restype = ctypes.c_int
     L.ss_hip_gemm_t_f32.argtypes = [vp, vp, sz, pd, vp, pd, ctypes.c_int, ctypes.POINTER(ctypes.c_float), cp, sz]
     for nme in ("ss_hip_gram_cols_f32", "ss_hip_gram_cols_f64"):
@@ -132,6 +146,22 @@ def version():
     return lib().ss_hip_version().decode()
 
 
+def norm_l1(A, device=0):
+    """ss::norm_l1 on the device, in place: every column of A (numpy array or torch tensor, host or
+    device, any 2-D strides) divided by its l1 norm (src/linalg/norms.h:22-27)."""
+    ptr, shape, strides, dt, keep = _describe(A)
+    if len(shape) != 2:
+        raise ValueError("A must be 2-D")
+    suffix, _ = _suffix(dt)
+    _sync_producers(A)
+    err = ctypes.create_string_buffer(512)
+    rc = getattr(lib(), "ss_hip_norm_l1_" + suffix)(ptr, int(shape[0]), int(shape[1]), strides[0], strides[1], device,
+                                                     err, len(err))
+    if rc != 0:
+        raise SsHipError(rc, err.value.decode())
+    return A
+
+
 class SsHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("ss_hip error %d: %s" % (code, msg))
@@ -150,6 +180,17 @@ def _describe(a):
     raise TypeError("expected a numpy array or a torch tensor")
 
 
+def _sync_producers(*arrays):
+    """The library consumes device pointers on the context's own (non-blocking) stream, which is not
+    ordered against the stream that produced them: wait for the caller's current torch stream first
+    (INTEGRATION.md, 'streams')."""
+    for a in arrays:
+        if a is not None and hasattr(a, "data_ptr") and getattr(a, "is_cuda", False):
+            import torch
+            torch.cuda.current_stream(a.device).synchronize()
+            return
+
+
 def _suffix(dt):
     if dt == np.float32:
         return "f32", ctypes.c_float
@@ -165,6 +206,7 @@ class Homotopy:
         ptr, shape, strides, dt, keep = _describe(A)
         if len(shape) != 2:
             raise ValueError("A must be 2-D")
+        _sync_producers(A)
         self.suffix, self.ctype = _suffix(dt)
         self.dtype = dt
         self.m, self.n = int(shape[0]), int(shape[1])
@@ -217,6 +259,7 @@ class Homotopy:
         it = ctypes.c_uint32(0)
         e = ctypes.c_double(0.0)
         err = ctypes.create_string_buffer(512)
+        _sync_producers(y, out)
         fn = getattr(lib(), _entry + self.suffix)
         rc = fn(self._h, yp, ystr[0], self.ctype(tolerance), int(max_iterations), xp, xstr[0],
                 ctypes.byref(it), ctypes.byref(e), err, len(err))
@@ -238,11 +281,45 @@ class Homotopy:
         iters = np.zeros(B, dtype=np.uint32)
         errs = np.zeros(B, dtype=np.float64)
         err = ctypes.create_string_buffer(512)
+        _sync_producers(Y, X)
         fn = getattr(lib(), "ss_hip_homotopy_solve_batch_" + self.suffix)
         rc = fn(self._h, Yp, B, strides[0], strides[1], self.ctype(tolerance), int(max_iterations),
                 Xp, xstr[0], xstr[1], iters.ctypes.data, errs.ctypes.data, err, len(err))
         self._check(rc, err)
         return X, iters, errs
+
+    def record_bytes(self, kmax):
+        return int(lib().ss_hip_record_bytes(int(kmax), 1 if self.dtype == np.float64 else 0))
+
+    def solve_batch_compact(self, Y, tolerance=None, max_iterations=100, kmax=96, out=None):
+        """Y: (B, m) -> records (B, record_bytes) uint8: {u32 K, u32 iter, f64 err, u32 idx[kmax], T val[kmax]}
+        per signal (include/ss_hip.h), packed on the device.  `out`: a uint8 numpy array or torch tensor
+        (host or device) of that shape; default a numpy array.  Decode with sharding.unpack_records."""
+        Yp, shape, strides, dt, keep = _describe(Y)
+        if dt != self.dtype or len(shape) != 2 or shape[1] != self.m:
+            raise ValueError("Y must be (B, m) of the matrix dtype")
+        B = int(shape[0])
+        if tolerance is None:
+            tolerance = float(np.finfo(self.dtype).eps) * 10
+        rb = self.record_bytes(kmax)
+        if out is None:
+            out = np.empty((B, rb), dtype=np.uint8)
+        if isinstance(out, np.ndarray):
+            ok = out.dtype == np.uint8 and out.shape == (B, rb) and out.flags.c_contiguous
+            rp = out.ctypes.data
+        else:
+            import torch
+            ok = out.dtype == torch.uint8 and tuple(out.shape) == (B, rb) and out.is_contiguous()
+            rp = out.data_ptr()
+        if not ok:
+            raise ValueError("out must be a contiguous (B, %d) uint8 array" % rb)
+        err = ctypes.create_string_buffer(512)
+        _sync_producers(Y, out)
+        fn = getattr(lib(), "ss_hip_homotopy_solve_batch_compact_" + self.suffix)
+        rc = fn(self._h, Yp, B, strides[0], strides[1], self.ctype(tolerance), int(max_iterations), int(kmax),
+                rp, err, len(err))
+        self._check(rc, err)
+        return out
 
     def gemv_t(self, r, repeats=1):
         """c = A^T r on the device copy -> (c, mean kernel ms)"""
@@ -252,6 +329,7 @@ class Homotopy:
         c = np.empty(self.n, dtype=self.dtype)
         ms = ctypes.c_float(0.0)
         err = ctypes.create_string_buffer(512)
+        _sync_producers(r)
         fn = getattr(lib(), "ss_hip_gemv_t_" + self.suffix)
         self._check(fn(self._h, rp, c.ctypes.data, int(repeats), ctypes.byref(ms), err, len(err)), err)
         return c, float(ms.value)

@@ -8,8 +8,12 @@
 
 #include "ss_hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <mutex>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 namespace ss
@@ -84,6 +88,31 @@ namespace ss
         }
     }
 
+    /* Live solver states by the matrix view they were built from: reconstruct_signal(A, x, y) finds the
+       device copy of A there (the one a solver<T, P>(A) of the same view made) instead of touching the
+       host matrix. */
+    namespace
+    {
+        struct live_view
+        {
+            const void* data; size_t m, n; ptrdiff_t rs, cs; bool f64; ss_hip_ctx* ctx;
+        };
+        std::mutex& live_mutex() { static std::mutex mx; return mx; }
+        std::vector<live_view>& live_views() { static std::vector<live_view> v; return v; }
+
+        void register_view(const void* data, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, bool f64, ss_hip_ctx* ctx)
+        {
+            std::lock_guard<std::mutex> lock(live_mutex());
+            live_views().push_back(live_view{ data, m, n, rs, cs, f64, ctx });
+        }
+        void unregister_view(ss_hip_ctx* ctx)
+        {
+            std::lock_guard<std::mutex> lock(live_mutex());
+            auto& v = live_views();
+            v.erase(std::remove_if(v.begin(), v.end(), [ctx](const live_view& e) { return e.ctx == ctx; }), v.end());
+        }
+    }
+
     /* Homotopy solver ----------------------------------------------------- */
 
     template <typename T>
@@ -94,12 +123,16 @@ namespace ss
         _ctx = create(A.data(), _m, _n, (ptrdiff_t)A.strides()[0], (ptrdiff_t)A.strides()[1],
                       device, msg, sizeof(msg));
         if (!_ctx) _error = msg;
+        else register_view(A.data(), _m, _n, (ptrdiff_t)A.strides()[0], (ptrdiff_t)A.strides()[1], sizeof(T) == 8, _ctx);
     }
 
     template <typename T>
     homotopy_state<T>::~homotopy_state()
     {
-        if (_ctx) ss_hip_homotopy_destroy(_ctx);
+        if (_ctx) {
+            unregister_view(_ctx);
+            ss_hip_homotopy_destroy(_ctx);
+        }
     }
 
     template class homotopy_state<float>;
@@ -202,29 +235,67 @@ namespace ss
 
     namespace detail
     {
-        /* y = A x on the host: x is sparse in every use of the reference
-           (test_util.h:167,187), so only its non-zero columns are visited */
+        inline int hip_reconstruct(ss_hip_ctx* c, const float* x, float* y, char* e, size_t l) { return ss_hip_reconstruct_f32(c, x, y, e, l); }
+        inline int hip_reconstruct(ss_hip_ctx* c, const double* x, double* y, char* e, size_t l) { return ss_hip_reconstruct_f64(c, x, y, e, l); }
+        inline int hip_norm_l1(float* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, char* e, size_t l) { return ss_hip_norm_l1_f32(A, m, n, rs, cs, 0, e, l); }
+        inline int hip_norm_l1(double* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, char* e, size_t l) { return ss_hip_norm_l1_f64(A, m, n, rs, cs, 0, e, l); }
+
+        /* y = A x on the device (reference: one row-major xgemv, src/lib.cpp:78-92).
+           A solver built from the same view holds A in HBM already: its copy is used
+           (ss_hip_reconstruct_*).  Otherwise only the columns x actually uses travel: x is sparse
+           in every use of the reference (test_util.h:167,187), so those columns are gathered
+           into a compact matrix, uploaded and multiplied there.  No arithmetic on the host;
+           the reference's signature cannot report an error, so a failure (no usable GPU) throws. */
         template <typename T>
         void reconstruct_signal(const ndspan<T, 2> A, const ndspan<T> x, ndspan<T> y)
         {
             const size_t m = A.shape()[0], n = A.shape()[1];
-            for (size_t i = 0; i < m; i++) y[i] = T(0);
-            for (size_t j = 0; j < n; j++) {
-                const T xj = x[j];
-                if (xj == T(0)) continue;
-                for (size_t i = 0; i < m; i++) y[i] += A(i, j) * xj;
+            if (x.size() != n || y.size() != m)
+                throw std::invalid_argument("reconstruct_signal: vector lengths do not match the shape of A");
+            char msg[512] = { 0 };
+            std::vector<T> xs(n), ys(m);
+            for (size_t j = 0; j < n; j++) xs[j] = x[j];
+            ss_hip_ctx* held = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(live_mutex());
+                for (const live_view& e : live_views())
+                    if (e.data == (const void*)A.data() && e.m == m && e.n == n && e.f64 == (sizeof(T) == 8) &&
+                        e.rs == (ptrdiff_t)A.strides()[0] && e.cs == (ptrdiff_t)A.strides()[1]) { held = e.ctx; break; }
+                if (held && hip_reconstruct(held, xs.data(), ys.data(), msg, sizeof(msg)) != SS_HIP_OK)
+                    throw std::runtime_error(std::string("reconstruct_signal: ") + msg);
             }
+            if (!held) {
+                std::vector<size_t> nz;
+                for (size_t j = 0; j < n; j++) if (xs[j] != T(0)) nz.push_back(j);
+                if (nz.empty()) {
+                    for (size_t i = 0; i < m; i++) y[i] = T(0);
+                    return;
+                }
+                const size_t k = nz.size();
+                std::vector<T> cols(m * k), xk(k);
+                for (size_t c = 0; c < k; c++) {
+                    xk[c] = xs[nz[c]];
+                    for (size_t i = 0; i < m; i++) cols[c * m + i] = A(i, nz[c]);       // column-major, compact
+                }
+                ss_hip_ctx* tmp = create(cols.data(), m, k, (ptrdiff_t)1, (ptrdiff_t)m, 0, msg, sizeof(msg));
+                if (!tmp) throw std::runtime_error(std::string("reconstruct_signal: ") + msg);
+                const int rc = hip_reconstruct(tmp, xk.data(), ys.data(), msg, sizeof(msg));
+                ss_hip_homotopy_destroy(tmp);
+                if (rc != SS_HIP_OK) throw std::runtime_error(std::string("reconstruct_signal: ") + msg);
+            }
+            for (size_t i = 0; i < m; i++) y[i] = ys[i];
         }
 
+        /* every column of A divided by its l1 norm, in place, on the device (ss_hip_norm_l1_*:
+           reference src/linalg/norms.h:22-27); a failure (no usable GPU) throws */
         template <typename T>
         void norm_l1(ndspan<T, 2> A)
         {
-            const size_t m = A.shape()[0], n = A.shape()[1];
-            std::vector<T> sums(n, T(0));
-            for (size_t i = 0; i < m; i++)
-                for (size_t j = 0; j < n; j++) sums[j] += std::abs(A(i, j));
-            for (size_t i = 0; i < m; i++)
-                for (size_t j = 0; j < n; j++) A(i, j) /= sums[j];
+            char msg[512] = { 0 };
+            if (A.shape()[0] == 0 || A.shape()[1] == 0) return;
+            const int rc = hip_norm_l1(A.data(), A.shape()[0], A.shape()[1], (ptrdiff_t)A.strides()[0],
+                                       (ptrdiff_t)A.strides()[1], msg, sizeof(msg));
+            if (rc != SS_HIP_OK) throw std::runtime_error(std::string("norm_l1: ") + msg);
         }
     }
 

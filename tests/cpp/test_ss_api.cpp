@@ -6,6 +6,8 @@
 
 #include <cstdio>
 #include <cstring>
+#include <stdexcept>
+#include <cmath>
 #include <vector>
 
 static int failures = 0;
@@ -131,13 +133,42 @@ void irls_api()
 
 void utilities()
 {
-    // norm_l1 literal (reference: src/linalg/norms_test.cpp) and reconstruct_signal
+    // norm_l1 literal (reference: src/linalg/norms_test.cpp:10-26): columns divided by their l1 norms
+    {
+        std::vector<float> A = { 1, 2, 0,
+                                 3, 4, 1 };   // 2 x 3
+        ss::norm_l1(ss::as_span<2>(A.data(), { size_t(2), size_t(3) }));
+        const float expect[6] = { 0.25f, 0.3333f, 0.f, 0.75f, 0.6667f, 1.f };
+        for (int e = 0; e < 6; e++) CHECK(std::fabs(A[e] - expect[e]) <= 1e-4f);
+    }
+    // exact values, a strided (column-subset) view and a column-major view
     std::vector<double> A = { 1, 2, 3, 6 };   // 2 x 2
     ss::norm_l1(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }));
     CHECK(A[0] == 0.25 && A[1] == 0.25 && A[2] == 0.75 && A[3] == 0.75);
+    {
+        std::vector<double> W = { 9, 1, 2, 9,
+                                  9, 3, 6, 9 };   // columns 1..2 of a 2 x 4 buffer
+        ss::norm_l1(ss::as_span<2>(W.data() + 1, { size_t(2), size_t(2) }, { size_t(4), size_t(1) }));
+        CHECK(W[1] == 0.25 && W[2] == 0.25 && W[5] == 0.75 && W[6] == 0.75 && W[0] == 9 && W[3] == 9 && W[7] == 9);
+        std::vector<double> C = { 1, 3, 2, 6 };   // the same matrix, column-major
+        ss::norm_l1(ss::as_span<2>(C.data(), { size_t(2), size_t(2) }, { size_t(1), size_t(2) }));
+        CHECK(C[0] == 0.25 && C[1] == 0.75 && C[2] == 0.25 && C[3] == 0.75);
+    }
+    // reconstruct_signal: no solver holds A -> the used columns travel to the device
     std::vector<double> x = { 2, 0 }, y(2, -1);
     ss::reconstruct_signal(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }), ss::as_span(x), ss::as_span(y));
     CHECK(y[0] == 0.5 && y[1] == 1.5);
+    // ... and with a solver built from the same view: its device copy of A is used (test_util.h:167-190 order:
+    // normalise, construct, solve, reconstruct)
+    {
+        ss::homotopy<double> solver(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }));
+        std::vector<double> x2 = { 0, 4 }, y2(2, -1);
+        ss::reconstruct_signal(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }), ss::as_span(x2), ss::as_span(y2));
+        CHECK(y2[0] == 1.0 && y2[1] == 3.0);
+    }
+    std::vector<double> xz = { 0, 0 }, yz(2, -1);
+    ss::reconstruct_signal(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }), ss::as_span(xz), ss::as_span(yz));
+    CHECK(yz[0] == 0.0 && yz[1] == 0.0);
 }
 
 int no_device()
@@ -147,7 +178,13 @@ int no_device()
     auto r = s.solve(ss::as_span(y), 0.001f, 2, ss::as_span(x));
     CHECK(r.is<kernelpp::error>());
     if (r.is<kernelpp::error>()) std::printf("error (expected): %s\n", r.get<kernelpp::error>().data());
-    utilities();
+    // the utilities run on the device as well: without one they fail loudly (no host fallback)
+    bool threw = false;
+    try { ss::norm_l1(ss::as_span<2>(A.data(), { size_t(2), size_t(2) })); } catch (const std::runtime_error& e) { threw = true; std::printf("error (expected): %s\n", e.what()); }
+    CHECK(threw && A[0] == 1.f);
+    threw = false;
+    try { ss::reconstruct_signal(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }), ss::as_span(y), ss::as_span(x)); } catch (const std::runtime_error& e) { threw = true; }
+    CHECK(threw);
     return failures;
 }
 

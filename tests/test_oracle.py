@@ -100,6 +100,60 @@ def test_first_step_sign_quirk():
     assert not np.allclose(aq[0], -x0, atol=1e-3) or aq[1] > bq[1]
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_exact_tie_and_the_opt_in_guard(dtype):
+    """homotopy-cpu.cpp:143-153: an off-support column that attains lambda exactly has t = 0 and the strict
+    `t > 0` skips it for good.  A = I, y = e_0 + e_1 (+ 0.5 e_5) makes that tie in exact arithmetic: the
+    reference-faithful default wanders and runs out of iterations; TIE_GUARD (a restatement of the HIP
+    path's opt-in option, not of the reference) lets the tied column in by a zero-length step."""
+    n = 32
+    A = np.eye(n, dtype=dtype)
+    y = np.zeros(n, dtype=dtype)
+    y[0] = y[1] = 1.0
+    y[5] = 0.5
+    x, it, err, tr = oracle.homotopy(A, y, 1e-3, 6, trace=True)
+    assert it == 6 and err == 1.0 and x[1] == 0.0 and 1 not in tr["idx"]
+    x, it, err, tr = oracle.homotopy(A, y, 1e-3, 6, flags=oracle.SPARSE_NOTRANS | oracle.TIE_GUARD, trace=True)
+    assert it == 3 and err == 0.0 and np.array_equal(x, y)
+    assert tr["idx"][1] == 1 and tr["gamma"][1] == np.finfo(dtype).tiny
+    # the guard only acts on an exact tie: elsewhere the flag changes nothing
+    A2, y2, x0, sup = make_gaussian_problem(7, 64, 256, 5, dtype)
+    a = oracle.homotopy(A2, y2, 1e-6, 50)
+    b = oracle.homotopy(A2, y2, 1e-6, 50, flags=oracle.SPARSE_NOTRANS | oracle.TIE_GUARD)
+    assert a[1] == b[1] and np.array_equal(a[0], b[0])
+
+
+def test_zero_on_removal_flag_only_touches_leaving_columns(golden):
+    """ZERO_ON_REMOVAL restates the HIP path's opt-in option: the removal goldens of the reference's numpy
+    solver are met with and without it (the residue is below every tolerance), and on a removal-free path
+    the flag changes nothing"""
+    g = golden["removal_f64_24x64_seed1000"]
+    A, y, tol = g["A"], g["y"], float(g["tol"])
+    a = oracle.homotopy(A, y, tol, 4000)
+    b = oracle.homotopy(A, y, tol, 4000, flags=oracle.SPARSE_NOTRANS | oracle.ZERO_ON_REMOVAL)
+    assert a[1] == b[1] == int(g["iters"])
+    assert np.abs(a[0] - b[0]).max() <= 1e-12 * np.abs(a[0]).max()
+    A2, y2, x0, sup = make_gaussian_problem(7, 64, 256, 5, np.float64)
+    c = oracle.homotopy(A2, y2, 1e-8, 50)
+    d = oracle.homotopy(A2, y2, 1e-8, 50, flags=oracle.SPARSE_NOTRANS | oracle.ZERO_ON_REMOVAL)
+    assert c[1] == d[1] and np.array_equal(c[0], d[0])
+
+
+def test_cblas_timing_leg_agrees_with_the_fixed_order_loops():
+    """SS_ORACLE_CBLAS (bench.py's CPU baseline: the GEMVs through a dlopen'd CBLAS like the reference's
+    blas_wrapper.cpp:33-66) walks the same path as the fixed-order loops; the parity tests never use it"""
+    desc = oracle.load_cblas()
+    if desc is None:
+        pytest.skip("no CBLAS on this host")
+    for dtype, tol, rtol in ((np.float32, 1e-3, 1e-5), (np.float64, 1e-9, 1e-12)):
+        A, y, x0, sup = make_gaussian_problem(5, 256, 2048, 12, dtype)
+        for V in (A, np.asfortranarray(A)):
+            a = oracle.homotopy(V, y, tol, 60, flags=0)
+            b = oracle.homotopy(V, y, tol, 60, flags=oracle.CBLAS)
+            assert a[1] == b[1] and np.array_equal(np.nonzero(a[0])[0], np.nonzero(b[0])[0])
+            assert np.abs(a[0] - b[0]).max() <= rtol * np.abs(a[0]).max()
+
+
 def test_preconditions_are_errors():
     """asserts of homotopy-cpu.cpp:193-199 become error returns."""
     A = np.eye(4, dtype=np.float32)
