@@ -160,6 +160,7 @@ def main():
                          "step, lock-step batch) on several")
     ap.add_argument("--variant", type=int, default=None, help="sweep kernel variant (tuning)")
     ap.add_argument("--engine", type=int, default=None, help="0 = one fused sweep per iteration, 1 = lookahead")
+    ap.add_argument("--first-sweep-cols", type=int, default=None, help="32 / 64: columns of the first lookahead sweep (tuning)")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="time every k-th fused sweep of the timed solves with HIP events")
     ap.add_argument("--batch", type=int, default=4096,
@@ -206,6 +207,8 @@ def main():
         h.set_option("sweep_variant", args.variant)
     if args.engine is not None:
         h.set_option("engine", args.engine)
+    if args.first_sweep_cols is not None:
+        h.set_option("first_sweep_cols", args.first_sweep_cols)
 
     if workload == "batched":
         out = run_batched(args, h, A, dev, rank, world, use_dist, torch, dist, sharding)
@@ -477,8 +480,24 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                 tj = json.load(open(tpath))
             except Exception:
                 tj = {}
+        n_pad = (N + 255) // 256 * 256
+        roof = None
+        if engine >= 1 and st["sweep64_launches"] > 0:
+            # dominant kernel of the default engine: the first lookahead sweep, 64 Gram columns in one pass over A —
+            # 2*64*m*n flops on the fp32 MFMA units (16x the flops per byte of a GEMV: MFMA-bound, not HBM-bound)
+            launches, ms_sum, nbytes = st["sweep64_launches"], st["sweep64_ms"], st["sweep64_bytes"]
+            avg_ms = ms_sum / max(1, launches)
+            flops = 2.0 * 64 * M * n_pad
+            tfs = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            roof = {"bound": "mfma",
+                    "kernel": "k_gemm32_tn_f32<RH = 64>: first lookahead sweep, 64 Gram columns A^T a_j in one pass over A "
+                              "(v_mfma_f32_32x32x2_f32; 32.6 flop per byte of A: right of the fp32 ridge)",
+                    "achieved": tfs, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": tfs / MFMA_F32_PEAK_TFS,
+                    "traffic": tj.get("gemm64_hbm_bytes_per_launch"), "flops_per_launch": flops, "bytes_per_launch": nbytes,
+                    "hbm_GBs_of_the_same_launch": nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                    "avg_launch_ms": avg_ms, "launches_timed": launches}
         if engine >= 1:
-            # dominant HBM kernel of the lookahead engine: the 32-RHS sweep G = A^T [a_j1 .. a_j32]
+            # the 32-RHS sweep G = A^T [a_j1 .. a_j32] (HBM-bound): a solve that meets a column outside its first 64
             launches, ms_sum, nbytes = st["sweep32_launches"], st["sweep32_ms"], st["sweep32_bytes"]
             kname = "k_gemm32_tn_f32: lookahead sweep, 32 Gram columns A^T a_j per pass over A (fp32 MFMA, HBM-bound)"
             traffic = tj.get("gemm32_hbm_bytes_per_launch")
@@ -488,10 +507,18 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             traffic = tj.get("sweep2_hbm_bytes_per_launch")
         avg_ms = ms_sum / max(1, launches)
         achieved = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        hbm_roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": nbytes,
+                    "avg_launch_ms": avg_ms, "launches_timed": launches}
+        if roof is None:
+            roof = hbm_roof
         s1_ms = st["sweep1_ms"] / max(1, st["sweep1_launches"])
         s1_gbs = st["sweep1_bytes"] / (s1_ms * 1e-3) / 1e9 if s1_ms > 0 else 0.0
         ms_per_step = elapsed / args.steps * 1e3
-        la_ms = avg_ms * st["lookahead_sweeps"] / max(1, st["solves"]) if engine >= 1 else None
+        first_ms = st["sweep64_ms"] / max(1, st["sweep64_launches"]) if st["sweep64_launches"] else 0.0
+        # (device counter: sweeps of all widths; the first one of each solve is the 64-column pass when it ran)
+        n32 = st["lookahead_sweeps"] / max(1, st["solves"]) - (1.0 if st["sweep64_launches"] else 0.0)
+        la_ms = (first_ms + avg_ms * max(0.0, n32)) if engine >= 1 else None
         out = {
             "metric": "signals recovered/sec (Homotopy l1, m=8192 n=65536 k=64 fp32)",
             "value": single_value,
@@ -513,23 +540,15 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                 "sharding": "one GPU (with --gpus N --workload single: independent replicas, one signal per rank and step)",
                 "sweep_variant": h.get_option("sweep_variant"), "engine": engine,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kname,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "bytes_per_launch": nbytes,
-                "avg_launch_ms": avg_ms,
-                "launches_timed": launches,
-            },
+            "roofline": roof,
+            # the 32-column lookahead sweep (HBM-bound), when any of the timed solves needed one
+            "lookahead_sweep_32rhs": hbm_roof if roof is not hbm_roof else None,
             # the plain correlation GEMV c = A^T y (k_sweep, 1 right-hand side): one per solve
             "atr_gemv": {"kernel": "k_sweep<float,1 rhs> c = A^T y", "achieved": s1_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": s1_gbs / HBM_PEAK_GBS, "bytes_per_launch": st["sweep1_bytes"],
                          "avg_launch_ms": s1_ms, "launches_timed": st["sweep1_launches"]},
-            "sweeps_per_solve": {"lookahead_32rhs": st["lookahead_sweeps"] / max(1, st["solves"]),
+            "sweeps_per_solve": {"lookahead_64rhs_first": 1.0 if st["sweep64_launches"] else 0.0,
+                                 "lookahead_32rhs": max(0.0, n32) if engine >= 1 else 0.0,
                                  "atr_1rhs": 1, "reference_gemv_per_iteration": 4},
             # where a solve's time goes (event-timed sweeps; the rest is the iteration kernels, latency-bound)
             "ms_per_solve": {"total": ms_per_step,

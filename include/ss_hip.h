@@ -179,6 +179,15 @@ int ss_hip_gram_cols_f64(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, double
                          int repeats, float* ms_out, char* err, size_t errlen);
 
 /*
+ * Gs[i][j] = a_{cols[i]} . a_{cols[j]} for a subset of exactly 256 dictionary columns (host index list; entries
+ * >= n give zero rows / columns): the 256 x 256 Gram matrix the early speculative iterations of the single-signal
+ * engine run on while the full Gram columns are still being swept (csrc/subgram.hip).  Every entry is, bit for
+ * bit, the value ss_hip_gram_cols_f32 returns for the same pair of columns.  Gs: 256 * 256 floats, row-major.
+ */
+int ss_hip_subset_gram_f32(ss_hip_ctx* ctx, const uint32_t* cols, float* Gs, int repeats, float* ms_out,
+                           char* err, size_t errlen);
+
+/*
  * y = A x on the device copy — ss::reconstruct_signal (src/lib.cpp:78-104).
  * x: n elements, y: m elements.
  */
@@ -226,6 +235,11 @@ typedef struct ss_hip_stats {
     double   cq_ms;                /* sum of their HIP-event durations                                                             */
     uint64_t cq_bytes;             /* algorithmic bytes of those launches: per live signal and round (K + 3) n s — K rows of G read,
                                       c0 read, c and q written                                                                     */
+    uint64_t sweep64_launches;     /* first lookahead sweeps of fp32 solves that fetched 64 Gram columns in one pass (timed ones)   */
+    double   sweep64_ms;           /* sum of their HIP-event durations (profiling on)                                              */
+    uint64_t sweep64_flops;        /* algorithmic flops of ONE such pass: 2 * 64 * m * n (MFMA-bound: 16x the flops per byte of A
+                                      of a GEMV)                                                                                  */
+    uint64_t sweep64_bytes;        /* its algorithmic bytes: m*n*s + 64*m*s + 64*n*s                                               */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------
@@ -275,6 +289,9 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "solo_subset"    columns beyond the support a speculative launch may hold (default 256; tests use small
  *                    values to provoke failed verifications)
  *   "sweep32_variant" tiling of the 32-RHS lookahead sweep (0 default; 1-7 measured alternatives, same results)
+ *   "first_sweep_cols" 64 (default) = the first lookahead sweep of a fp32 solve fetches the entering column and the
+ *                    63 largest |A^T y| in ONE pass over A (2*64*m*n flops: MFMA-bound, ~0.45 ms at 8192 x 65536)
+ *                    instead of two 32-column HBM-bound passes with a round trip through the host in between; 32 = off
  *   "cache_mib"      memory budget of the lookahead engine's Gram-column cache (default 2048)
  *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 192: below
  *                    that, one lookahead solve per signal is faster)

@@ -39,6 +39,7 @@ HIP_UNITS = [
     ("gemm.hip", []),
     ("homotopy.hip", []),
     ("utils.hip", ["-ffp-contract=off"]),
+    ("subgram.hip", []),
 ]
 
 

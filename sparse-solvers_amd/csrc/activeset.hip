@@ -449,13 +449,15 @@ void k_la_init_pick(const T* __restrict__ pmax_val, const uint32_t* __restrict__
 // cached columns with small step-length candidates (init: large |c0|).  The ranking is a
 // prefetch heuristic, not part of the algorithm's decisions, so it is approximate on purpose:
 // every thread offers the best of its n/1024 strided columns and the 32 best offers win.
-constexpr int kTopS = 32;
+constexpr int kTopS = 32;                   // columns of a sweep (the first sweep of a fp32 solve may take 64: nsel)
+constexpr int kSwStride = 64;               // sw_list layout: rcols[kSwStride] then drows[kSwStride]
 
 template <typename T>
 __global__ __launch_bounds__(kUpdThreads)
 void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, int init_mode,
               const uint8_t* __restrict__ insup, int32_t* __restrict__ slot_of, uint32_t gcap,
-              uint32_t* __restrict__ sw_list, DevState* st, uint32_t* hflags, uint32_t* __restrict__ slot_col)
+              uint32_t* __restrict__ sw_list, DevState* st, uint32_t* hflags, uint32_t* __restrict__ slot_col,
+              uint32_t nsel)
 {
     if (st->done || !st->need_sweep) return;
     const uint32_t idx = st->idx;
@@ -486,8 +488,8 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
             else if (better_min(v, i, v2, i2)) { v2 = v; i2 = i; }
         }
     }
-    // stage 1: every wave extracts the 6 best of its 128 offers (wave-level reductions only)
-    constexpr int kPerWave = 6;
+    // stage 1: every wave extracts the 8 best of its 128 offers (wave-level reductions only)
+    constexpr int kPerWave = 8;
     constexpr int kNW = kUpdThreads / 64;
     __shared__ T s_cv[kNW * kPerWave];
     __shared__ uint32_t s_ci[kNW * kPerWave];
@@ -501,7 +503,7 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
     }
     __syncthreads();
     if (wave != 0) return;
-    // stage 2: one wave ranks the 96 finalists and hands out cache slots, best first
+    // stage 2: one wave ranks the 128 finalists and hands out cache slots, best first
     constexpr int kFinal = kNW * kPerWave;
     static_assert(kFinal <= 128, "two finalists per lane");
     T f1 = s_cv[lane];
@@ -512,7 +514,7 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
     if (better_min(f2, j2, f1, j1)) { const T tv = f1; f1 = f2; f2 = tv; const uint32_t ti = j1; j1 = j2; j2 = ti; }
     uint32_t used = st->cache_used;
     uint32_t count = 0;
-    for (int sidx = 0; sidx < kTopS; ++sidx) {
+    for (uint32_t sidx = 0; sidx < nsel; ++sidx) {
         T bv = f1;
         uint32_t bi = j1;
         wave_reduce_pair<T, false>(bv, bi);
@@ -520,7 +522,7 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
         if (bi == j1) { f1 = f2; j1 = j2; f2 = Lim<T>::max(); j2 = 0xffffffffu; }
         if (lane == 0) {
             sw_list[count] = bi;               // rcols: right-hand side = column bi of A
-            sw_list[kTopS + count] = used;     // drows: output row = cache slot
+            sw_list[kSwStride + count] = used; // drows: output row = cache slot
             slot_of[bi] = (int32_t)used;
             if (slot_col != nullptr) slot_col[used] = bi;      // (the speculative form lists the cached columns)
         }
@@ -528,7 +530,7 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
         ++count;
     }
     if (lane == 0) {
-        for (uint32_t s2 = count; s2 < (uint32_t)kTopS; ++s2) { sw_list[s2] = 0xffffffffu; sw_list[kTopS + s2] = 0xffffffffu; }
+        for (uint32_t s2 = count; s2 < (uint32_t)kSwStride; ++s2) { sw_list[s2] = 0xffffffffu; sw_list[kSwStride + s2] = 0xffffffffu; }
         st->cache_used = used;
         st->nsweeps += 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1583,12 +1585,12 @@ hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t
 }
 
 template <typename T>
-hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode)
+hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode, uint32_t nsel)
 {
     // init_mode 1: rank by |c0| (first batch of a Homotopy solve); 2: by the current |c| (OMP)
     hipLaunchKernelGGL((k_la_top<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, ws.tcand, init_mode == 2 ? ws.c : ws.c0,
                        (uint32_t)ctx->n, init_mode, ws.insup, ws.slot_of, ws.gcap, ws.sw_list, ws.st, ctx->dev_flags,
-                       ws.gram_is_full ? (uint32_t*)nullptr : ws.slot_col);
+                       ws.gram_is_full ? (uint32_t*)nullptr : ws.slot_col, nsel > (uint32_t)kSwStride ? (uint32_t)kSwStride : nsel);
     return hipGetLastError();
 }
 
@@ -1803,8 +1805,8 @@ template hipError_t launch_omp_tail<double>(const ss_hip_ctx*, Workspace<double>
                                             uint32_t, double, uint32_t);
 template hipError_t launch_la_init_pick<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float, bool);
 template hipError_t launch_la_init_pick<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double, bool);
-template hipError_t launch_la_top<float>(const ss_hip_ctx*, Workspace<float>&, int);
-template hipError_t launch_la_top<double>(const ss_hip_ctx*, Workspace<double>&, int);
+template hipError_t launch_la_top<float>(const ss_hip_ctx*, Workspace<float>&, int, uint32_t);
+template hipError_t launch_la_top<double>(const ss_hip_ctx*, Workspace<double>&, int, uint32_t);
 template hipError_t launch_la_update<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
 template hipError_t launch_la_update<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double);
 template hipError_t launch_la_cq<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t*);

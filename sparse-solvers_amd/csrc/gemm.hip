@@ -176,16 +176,22 @@ constexpr int HM = 32;
 // columns).  To keep enough HBM requests in flight from a single workgroup the global loads
 // run THREE K-steps ahead through a ring of register sets (3 x 36 KiB per workgroup), LDS is
 // double buffered, one barrier per K-step.
-template <int HN, int HT, int BPC, int KS = GK, bool DRY = false>
+// RH = 32 or 64 right-hand sides per pass.  With 64 the pass is no longer HBM-bound: 2 * 64 * m * n flops
+// (68.7 GFLOP at C2) take ~0.45 ms on the fp32 MFMA units against 0.27 ms for the bytes — but it replaces TWO
+// 32-column passes (2 x 0.37 ms) and one round trip through the host, which is why the first lookahead sweep
+// of a solve (the entering column + the 63 largest |c0|) uses it.
+template <int HN, int HT, int BPC, int KS = GK, bool DRY = false, int RH = HM>
 __global__ __launch_bounds__(HT, BPC)
 void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
                      const uint32_t* __restrict__ drows, float* __restrict__ D,
                      uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
                      const DevState* __restrict__ st)
 {
-    if (st != nullptr && (st->done != 0 || st->need_sweep == 0)) return;   // no sweep needed this round
+    if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
+    if (rcols[0] == 0xffffffffu) return;                        // an empty list (lists are filled from entry 0)
     constexpr int LD = KS + GPAD;                               // LDS row pitch in floats
-    __shared__ __attribute__((aligned(16))) float sR[2][HM][LD];
+    constexpr int RB = RH / 32;                                 // 32-row blocks of right-hand sides
+    __shared__ __attribute__((aligned(16))) float sR[2][RH][LD];
     __shared__ __attribute__((aligned(16))) float sQ[2][HN][LD];
 
     const uint32_t tid = threadIdx.x;
@@ -194,10 +200,11 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
     constexpr int TPR = KS / 4;                                 // threads per staged row (one k-quad each)
     constexpr int RPP = HT / TPR;                               // rows staged per pass
     constexpr int NJ = HN / RPP;                                // passes per column tile
+    static_assert(RH * TPR <= HT, "the R tile is staged in one pass");
     const uint32_t srow = tid / TPR, squad = tid % TPR;        // staging: rows srow + RPP*j, k-quad squad
-    const bool has_r = tid < 32 * TPR;                          // R tile: 32 rows x TPR quads
+    const bool has_r = tid < RH * TPR;                          // R tile: RH rows x TPR quads
 
-    const uint32_t rc = rcols[srow & 31u];
+    const uint32_t rc = rcols[srow % (uint32_t)RH];
     const bool rvalid = has_r && rc != 0xffffffffu;
     const float* gR = At + (size_t)(rvalid ? rc : 0u) * ldq + squad * 4;
     const v4f zero4 = { 0.f, 0.f, 0.f, 0.f };
@@ -205,9 +212,11 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
 
     for (uint32_t bn = blockIdx.x; bn < ntiles; bn += gridDim.x) {
         const float* gQ = At + (size_t)(bn * HN + srow) * ldq + squad * 4;
-        v16f acc;
+        v16f acc[RB];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
 
         v4f rR[3], rQ[3][NJ];
 #define G32_LOAD(SET, KT)                                                                      \
@@ -227,12 +236,15 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
 #define G32_COMPUTE(BUF)                                                                       \
     _Pragma("unroll") for (int g = 0; g < KS / 8; ++g) {                                       \
         const uint32_t kq_ = (2u * g + h) * 4u;                                                \
-        const v4f a_ = *reinterpret_cast<const v4f*>(&sR[BUF][l31][kq_]);                      \
+        v4f a_[RB];                                                                            \
+        _Pragma("unroll") for (int r = 0; r < RB; ++r)                                         \
+            a_[r] = *reinterpret_cast<const v4f*>(&sR[BUF][r * 32 + l31][kq_]);                \
         const v4f b_ = *reinterpret_cast<const v4f*>(&sQ[BUF][wave * 32 + l31][kq_]);          \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                        \
-            if (DRY) acc[t] += a_[t] + b_[t];    /* measurement aid: data movement without MFMA */ \
-            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], b_[t], acc, 0, 0, 0);       \
-        }                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                          \
+            _Pragma("unroll") for (int r = 0; r < RB; ++r) {                                   \
+                if (DRY) acc[r][t] += a_[r][t] + b_[t];    /* measurement aid: data movement without MFMA */ \
+                else acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[r][t], b_[t], acc[r], 0, 0, 0); \
+            }                                                                                  \
     }
 
         // prologue: tiles 0,1,2 in flight; tile 0 -> LDS[0]; tile 3 re-uses set 0
@@ -279,11 +291,13 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
 
         const uint32_t col = bn * HN + wave * 32 + l31;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const uint32_t row = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const uint32_t dr = drows[row];
-            if (dr != 0xffffffffu) D[(size_t)dr * ldd + col] = acc[e];
-        }
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t row = (uint32_t)r * 32u + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const uint32_t dr = drows[row];
+                if (dr != 0xffffffffu) D[(size_t)dr * ldd + col] = acc[r][e];
+            }
     }
 }
 
@@ -301,7 +315,7 @@ void k_gemm32r_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__
                       const DevState* __restrict__ st)
 {
     static_assert(RING % 2 == 0, "ring depth must be even");
-    if (st != nullptr && (st->done != 0 || st->need_sweep == 0)) return;   // no sweep needed this round
+    if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
     __shared__ __attribute__((aligned(16))) float sR[2][HM][GLD];
     __shared__ __attribute__((aligned(16))) float sQ[2][HN][GLD];
 
@@ -395,7 +409,8 @@ void k_gemm32w_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__
                       uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
                       const DevState* __restrict__ st)
 {
-    if (st != nullptr && (st->done != 0 || st->need_sweep == 0)) return;   // no sweep needed this round
+    if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
+    if (rcols[0] == 0xffffffffu) return;                                    // an empty list (lists are filled from entry 0)
     __shared__ __attribute__((aligned(16))) float sT[WAVES][2][32][GLD];    // per wave: R tile, Q tile
 
     const uint32_t tid = threadIdx.x;
@@ -477,6 +492,98 @@ void k_gemm32w_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__
     }
 }
 
+// ---- the early form's pass: barrier-free, one 32-column tile per single-wave workgroup, THREE waves per SIMD ----
+// Runs beside a solo launch that holds one CU (homotopy.hip, early form).  k_gemm32w_tn_f32 needs 210 VGPRs: two
+// waves per SIMD, i.e. exactly the 2048 wave slots of an empty chip for the 2048 tiles of C2 — with one CU taken
+// four tiles found no slot and ran alone afterwards, one latency-bound wave each (0.64 ms per pass instead of 0.42).
+// Here the register ring is two K-steps deep and the k-groups of a step are consumed in two halves: <= 168 VGPRs,
+// three waves per SIMD (12 per CU carry as many bytes in flight as 8 with the deeper ring), every tile resident
+// from the start.  Same k-order of the accumulation as every other tiling of the pass: bitwise identical output.
+__global__ __launch_bounds__(64, 3)
+void k_gemm32e_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
+                      const uint32_t* __restrict__ drows, float* __restrict__ D,
+                      uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
+                      const DevState* __restrict__ st)
+{
+    if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
+    if (rcols[0] == 0xffffffffu) return;                                    // an empty list (lists are filled from entry 0)
+    __shared__ __attribute__((aligned(16))) float sT[2][32][GLD];           // R tile, Q tile
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t h = lane >> 5, l31 = lane & 31u;
+    const uint32_t r8 = lane >> 3, quad = lane & 7u;            // staging: rows r8 + 8j, k-quad `quad`
+    float (*sR)[GLD] = sT[0];
+    float (*sQ)[GLD] = sT[1];
+    const v4f zero4 = { 0.f, 0.f, 0.f, 0.f };
+    const uint32_t nk = K / GK;
+
+    const float* gR[4];
+    bool rvalid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t rc = rcols[r8 + 8 * j];
+        rvalid[j] = rc != 0xffffffffu;
+        gR[j] = At + (size_t)(rvalid[j] ? rc : 0u) * ldq + quad * 4;
+    }
+
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const float* gQ = At + (size_t)(tile * 32 + r8) * ldq + quad * 4;
+        v16f acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        v4f rR[2][4], rQ[2][4];
+#define E32_LOAD(SET, KT)                                                                      \
+    {                                                                                          \
+        const uint32_t koff_ = (KT) * GK;                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
+            rR[SET][j] = rvalid[j] ? *reinterpret_cast<const v4f*>(gR[j] + koff_) : zero4;     \
+            rQ[SET][j] = __builtin_nontemporal_load(                                           \
+                reinterpret_cast<const v4f*>(gQ + (size_t)(8 * j) * ldq + koff_));             \
+        }                                                                                      \
+    }
+#define E32_STEP(SET)                                                                          \
+    {                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
+            *reinterpret_cast<v4f*>(&sR[r8 + 8 * j][quad * 4]) = rR[SET][j];                   \
+            *reinterpret_cast<v4f*>(&sQ[r8 + 8 * j][quad * 4]) = rQ[SET][j];                   \
+        }                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                       \
+        _Pragma("unroll") for (int gh = 0; gh < GK / 8; gh += 2) {                             \
+            v4f a_[2], b_[2];                                                                  \
+            _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                    \
+                const uint32_t kq_ = (2u * (gh + g) + h) * 4u;                                 \
+                a_[g] = *reinterpret_cast<const v4f*>(&sR[l31][kq_]);                          \
+                b_[g] = *reinterpret_cast<const v4f*>(&sQ[l31][kq_]);                          \
+            }                                                                                  \
+            _Pragma("unroll") for (int g = 0; g < 2; ++g)                                      \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t)                                  \
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[g][t], b_[g][t], acc, 0, 0, 0); \
+        }                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                       \
+    }
+        E32_LOAD(0, 0u)
+        if (nk > 1) E32_LOAD(1, 1u)
+        uint32_t kt = 0;
+        for (; kt + 2 <= nk; kt += 2) {
+            E32_STEP(0)
+            if (kt + 2 < nk) E32_LOAD(0, kt + 2)
+            E32_STEP(1)
+            if (kt + 3 < nk) E32_LOAD(1, kt + 3)
+        }
+        if (kt < nk) { E32_STEP(0) ++kt; }
+#undef E32_LOAD
+#undef E32_STEP
+
+        const uint32_t col = tile * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const uint32_t dr = drows[row];
+            if (dr != 0xffffffffu) D[(size_t)dr * ldd + col] = acc[e];
+        }
+    }
+}
+
 // ---- the same pass in fp64 (engine 1 for double): v_mfma_f64_16x16x4_f64 -------------------------
 // 32 right-hand sides x 256 columns per 512-thread workgroup, K-step 16 doubles (128 B per row, the
 // same bytes per step as the fp32 kernel): wave w owns 32 columns as 2 x 2 tiles of 16 x 16.  Per
@@ -497,7 +604,7 @@ void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__
                      uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
                      const DevState* __restrict__ st)
 {
-    if (st != nullptr && (st->done != 0 || st->need_sweep == 0)) return;   // no sweep needed this round
+    if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
     constexpr int HN = 256, HT = 512;
     __shared__ __attribute__((aligned(16))) double sR[2][HM][DLD];
     __shared__ __attribute__((aligned(16))) double sQ[2][HN][DLD];
@@ -644,6 +751,13 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
         if (ctx->ldm % 64 != 0) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1, 64>), dim3(grid), dim3(512), 0, ctx->stream,
                            At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+    } else if (ctx->sweep32_variant == 8 || ctx->sweep32_variant == 9) {
+        // measurement aid: the early form's pass (one 32-column tile per single-wave workgroup), or two-wave workgroups
+        const uint32_t ntiles = ctx->n_pad / 32;
+        if (ctx->sweep32_variant == 8)
+            hipLaunchKernelGGL((k_gemm32e_tn_f32), dim3(ntiles), dim3(64), 0, ctx->stream, At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+        else
+            hipLaunchKernelGGL((k_gemm32w_tn_f32<2>), dim3((ntiles + 1) / 2), dim3(128), 0, ctx->stream, At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
     } else if (ctx->sweep32_variant == 3) {
         // barrier-free: 32-column tiles, one per wave, 4 waves per workgroup, 2 workgroups per CU
         const uint32_t ntiles = ctx->n_pad / 32;
@@ -671,6 +785,30 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
             hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3>), dim3(grid), dim3(256), 0, ctx->stream,
                                At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
     }
+    return hipGetLastError();
+}
+
+// the barrier-free 32-column pass with one 32-column tile per single-wave workgroup, on a given stream, ungated
+// (early form of the speculative engine: it runs beside a solo launch that occupies one CU — 2048 small workgroups
+// spread evenly over whatever CUs are free, where 256 one-per-CU workgroups would leave one waiting for a CU)
+hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd)
+{
+    if (ctx->n_pad % 32 != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
+    const uint32_t ntiles = ctx->n_pad / 32;
+    hipLaunchKernelGGL((k_gemm32e_tn_f32), dim3(ntiles), dim3(64), 0, on, static_cast<const float*>(ctx->At),
+                       rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, (const DevState*)nullptr);
+    return hipGetLastError();
+}
+
+// the 64-column pass (first lookahead sweep of a solve): rcols / drows hold 64 entries each
+hipError_t launch_gemm64_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
+                                float* D, uint32_t ldd, const DevState* st)
+{
+    if (ctx->n_pad % 256 != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
+    const uint32_t ntiles = ctx->n_pad / 256;
+    const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
+    hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1, GK, false, 64>), dim3(grid), dim3(512), 0, ctx->stream,
+                       static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
     return hipGetLastError();
 }
 

@@ -217,7 +217,8 @@ void release_arrays(Workspace<T>* w)
                      w->pmin_val, w->pmin_idx, w->gam, w->touched, w->inv[0], w->u1,
                      w->u2, w->sgn, w->st, w->ndone, w->tile_skip, w->gcache, w->slot_of, w->c0,
                      w->tcand, w->sw_list, w->la_dbg, w->la_sync, w->cq_alt, w->slot_identity,
-                     w->slot_col, w->solo_log, w->sub_pos, w->v_max, w->v_min, w->cand_top, w->solo_stage };
+                     w->slot_col, w->solo_log, w->sub_pos, w->v_max, w->v_min, w->cand_top, w->solo_stage,
+                     w->sw_list2, w->sub_cols, w->subg };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     TraceEntry* tr = w->trace;
@@ -355,6 +356,8 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
         ctx->stats.sweep_bytes = (uint64_t)m * n * s + 2 * (uint64_t)m * s + 2 * (uint64_t)n * s;
         ctx->stats.sweep1_bytes = (uint64_t)m * n * s + (uint64_t)m * s + (uint64_t)n * s;
         ctx->stats.sweep32_bytes = (uint64_t)m * n * s + 32 * (uint64_t)m * s + 32 * (uint64_t)n * s;
+        ctx->stats.sweep64_bytes = (uint64_t)m * n * s + 64 * (uint64_t)m * s + 64 * (uint64_t)n * s;
+        ctx->stats.sweep64_flops = 2ull * 64ull * (uint64_t)m * n;
     } catch (const HipFail& f) {
         set_err(err, errlen, hip_msg(f));
         ss_hip_homotopy_destroy(ctx);
@@ -375,9 +378,9 @@ inline hipError_t launch_gemm32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
 { return launch_gemm32_tn_f32(ctx, rcols, drows, D, ldd, st); }
 inline hipError_t launch_gemm32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows, double* D, uint32_t ldd, const DevState* st)
 { return launch_gemm32_tn_f64(ctx, rcols, drows, D, ldd, st); }
-inline hipError_t launch_persist(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, uint32_t lds_cols)
-{ return launch_la_persist_f32(ctx, ws, tol, max_iter, lds_cols); }
-inline hipError_t launch_persist(ss_hip_ctx*, Workspace<double>&, double, uint32_t, uint32_t)
+inline hipError_t launch_persist(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, uint32_t lds_cols, bool after_solo = false)
+{ return launch_la_persist_f32(ctx, ws, tol, max_iter, lds_cols, after_solo); }
+inline hipError_t launch_persist(ss_hip_ctx*, Workspace<double>&, double, uint32_t, uint32_t, bool = false)
 { return hipErrorInvalidConfiguration; }
 // speculative form (fp32 only): solo launch + verification + publication; seeding of the subset ranking
 inline hipError_t launch_solo_group(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter)
@@ -388,8 +391,19 @@ inline hipError_t launch_solo_group(ss_hip_ctx* ctx, Workspace<float>& ws, float
 inline hipError_t launch_solo_group(ss_hip_ctx*, Workspace<double>&, double, uint32_t) { return hipErrorInvalidConfiguration; }
 inline hipError_t launch_cand_init(ss_hip_ctx* ctx, Workspace<float>& ws) { return launch_la_cand_init_f32(ctx, ws); }
 inline hipError_t launch_cand_init(ss_hip_ctx*, Workspace<double>&) { return hipErrorInvalidConfiguration; }
-inline hipError_t launch_top_cand(ss_hip_ctx* ctx, Workspace<float>& ws) { return launch_la_top_cand_f32(ctx, ws); }
-inline hipError_t launch_top_cand(ss_hip_ctx*, Workspace<double>&) { return hipErrorInvalidConfiguration; }
+inline hipError_t launch_top_cand(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nsel = 32) { return launch_la_top_cand_f32(ctx, ws, nsel); }
+inline hipError_t launch_top_cand(ss_hip_ctx*, Workspace<double>&, uint32_t = 32) { return hipErrorInvalidConfiguration; }
+// the first lookahead sweep of a fp32 solve may fetch 64 Gram columns in one (MFMA-bound) pass
+inline hipError_t launch_gemm_first(const ss_hip_ctx* ctx, uint32_t nsel, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd, const DevState* st)
+{ return nsel > 32 ? launch_gemm64_tn_f32(ctx, rcols, drows, D, ldd, st) : launch_gemm32_tn_f32(ctx, rcols, drows, D, ldd, st); }
+inline hipError_t launch_gemm_first(const ss_hip_ctx* ctx, uint32_t, const uint32_t* rcols, const uint32_t* drows, double* D, uint32_t ldd, const DevState* st)
+{ return launch_gemm32_tn_f64(ctx, rcols, drows, D, ldd, st); }
+
+// early form of the speculative engine (fp32): the first solo launch runs on the subset Gram matrix beside the passes over A
+inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nparts, float tol, uint32_t max_iter, uint32_t lds_cols,
+                           hipEvent_t pe0, hipEvent_t pe1);
+inline void early_prologue(ss_hip_ctx*, Workspace<double>&, uint32_t, double, uint32_t, uint32_t, hipEvent_t, hipEvent_t)
+{ throw HipFail{ hipErrorInvalidConfiguration, "early_prologue<double>" }; }
 
 template <typename T> struct Lookahead {
     static constexpr bool supported = true;
@@ -404,8 +418,10 @@ template <typename T> struct Lookahead {
         const uint64_t fit = std::max<uint64_t>(64, budget / ((uint64_t)gpitch * sizeof(T)));
         if (want > fit) want = fit;
         if (ws.gcache && ws.gcap >= want && ws.gpitch == gpitch) return;
-        void* olds[] = { ws.gcache, ws.slot_of, ws.c0, ws.tcand, ws.sw_list, ws.slot_col, ws.solo_log, ws.sub_pos, ws.v_max, ws.v_min, ws.cand_top, ws.solo_stage };
+        void* olds[] = { ws.gcache, ws.slot_of, ws.c0, ws.tcand, ws.sw_list, ws.slot_col, ws.solo_log, ws.sub_pos, ws.v_max, ws.v_min, ws.cand_top, ws.solo_stage,
+                         ws.sw_list2, ws.sub_cols, ws.subg };
         for (void* p : olds) if (p) HIPCHK(hipFree(p));
+        ws.sw_list2 = nullptr; ws.sub_cols = nullptr; ws.subg = nullptr;
         ws.gcache = nullptr; ws.slot_of = nullptr; ws.c0 = nullptr; ws.tcand = nullptr; ws.sw_list = nullptr;
         ws.solo_stage = nullptr; ws.slot_col = nullptr; ws.solo_log = nullptr; ws.sub_pos = nullptr; ws.v_max = nullptr; ws.v_min = nullptr; ws.cand_top = nullptr;
         ws.gcap = 0;
@@ -413,7 +429,7 @@ template <typename T> struct Lookahead {
         HIPCHK(hipMalloc(&ws.slot_of, (size_t)ctx->n_pad * sizeof(int32_t)));
         HIPCHK(hipMalloc(&ws.c0, (size_t)ctx->n_pad * sizeof(T)));
         HIPCHK(hipMalloc(&ws.tcand, (size_t)ctx->n_pad * sizeof(T)));
-        HIPCHK(hipMalloc(&ws.sw_list, 64 * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&ws.sw_list, 128 * sizeof(uint32_t)));
         if (sizeof(T) == 4) {
             // speculative form: slot -> column map, breakpoint log, verification partials, subset ranking
             ws.nvwg = (uint32_t)((ctx->n + kSoloWidth - 1) / kSoloWidth);
@@ -424,8 +440,11 @@ template <typename T> struct Lookahead {
             HIPCHK(hipMemsetAsync(ws.sub_pos, 0, (size_t)ctx->n_pad, ctx->stream));
             HIPCHK(hipMalloc(&ws.v_max, (size_t)kSoloLogCap * ws.nvwg * sizeof(uint32_t)));
             HIPCHK(hipMalloc(&ws.v_min, (size_t)kSoloLogCap * ws.nvwg * sizeof(uint64_t)));
-            HIPCHK(hipMalloc(&ws.cand_top, 2 * (size_t)ws.nvwg * sizeof(uint64_t)));
-            HIPCHK(hipMemsetAsync(ws.cand_top, 0xff, 2 * (size_t)ws.nvwg * sizeof(uint64_t), ctx->stream));
+            HIPCHK(hipMalloc(&ws.sw_list2, 128 * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(&ws.sub_cols, (size_t)kSoloWidth * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&ws.subg), (size_t)kSoloWidth * kSoloWidth * sizeof(float)));
+            HIPCHK(hipMalloc(&ws.cand_top, kCandPerBlock * (size_t)ws.nvwg * sizeof(uint64_t)));
+            HIPCHK(hipMemsetAsync(ws.cand_top, 0xff, kCandPerBlock * (size_t)ws.nvwg * sizeof(uint64_t), ctx->stream));
         }
         ws.gcap = (uint32_t)want;
         ws.gpitch = gpitch;
@@ -436,8 +455,11 @@ template <typename T> struct Lookahead {
     }
 
     // c0 = A^T y has been swept into ws.c0 (partials in pmax): first pick, first lookahead sweep
-    static void init(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, bool solo = false)
+    // returns the number of columns of the first sweep (0: none — full-G mode); ev0 / ev1: events around it
+    static uint32_t init(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, bool solo = false,
+                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
     {
+        uint32_t first_cols = 0;
         hipStream_t st = ctx->stream;
         const bool full = ws.gram_is_full;                      // every column is "cached": no sweep, ever
         // (the slot map, the hand-off area of the resident kernel and the dense vectors were cleared by
@@ -446,15 +468,22 @@ template <typename T> struct Lookahead {
         HIPCHK(launch_la_init_pick<T>(ctx, ws, nparts, tol, full));
         if (solo) HIPCHK(launch_cand_init(ctx, ws));           // per-block tops of |c0|: ranking of the first sweep and subset
         if (!full) {
-            if (solo && ctx->n > 32u * 512u) HIPCHK(launch_top_cand(ctx, ws));
-            else HIPCHK(launch_la_top<T>(ctx, ws, 1));
-            HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+            // the first sweep: the entering column and the largest |c0| — 64 columns in one pass (fp32; MFMA-bound,
+            // ~0.45 ms at C2) instead of two 32-column passes and a round trip through the host in between
+            const uint32_t nsel = (sizeof(T) == 4 && ctx->first_sweep_cols > 32 && ctx->sweep32_variant == 0 && ws.gcap >= 128) ? 64u : 32u;
+            if (solo && ctx->n > 32u * 512u) HIPCHK(launch_top_cand(ctx, ws, nsel));
+            else HIPCHK(launch_la_top<T>(ctx, ws, 1, nsel));
+            if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
+            HIPCHK(launch_gemm_first(ctx, nsel, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, ws.st));
+            if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
+            first_cols = nsel;
         }
         HIPCHK(launch_la_update<T>(ctx, ws, 0, tol));
-        if (ctx->la_fused) return;                 // k_la_iter forms c and q itself
+        if (ctx->la_fused) return first_cols;      // k_la_iter forms c and q itself
         uint32_t np2 = 0;
         HIPCHK(launch_la_cq<T>(ctx, ws, &np2));
         ws.la_nparts = np2;
+        return first_cols;
     }
 
     // fused form: one launch per iteration ...
@@ -475,7 +504,7 @@ template <typename T> struct Lookahead {
         if (from_cand && ctx->n > 32u * 512u) HIPCHK(launch_top_cand(ctx, ws));
         else HIPCHK(launch_la_top<T>(ctx, ws, 0));
         if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
-        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, ws.st));
         if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
         HIPCHK(launch_la_update<T>(ctx, ws, 1, tol));
     }
@@ -484,7 +513,7 @@ template <typename T> struct Lookahead {
     {
         HIPCHK(launch_la_top<T>(ctx, ws, 2));
         if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
-        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, ws.st));
         if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
         HIPCHK(launch_la_omp_update<T>(ctx, ws, tol));
     }
@@ -497,7 +526,7 @@ template <typename T> struct Lookahead {
         HIPCHK(launch_la_scansel<T>(ctx, ws, rnd, ws.la_nparts, tol, max_iter));
         HIPCHK(launch_la_top<T>(ctx, ws, 0));
         if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
-        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 32, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, ws.st));
         if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
         HIPCHK(launch_la_update<T>(ctx, ws, rnd, tol));
         uint32_t np2 = 0;
@@ -505,6 +534,67 @@ template <typename T> struct Lookahead {
         ws.la_nparts = np2;
     }
 };
+
+// ---- early form (fp32, option early_solo): everything of a typical solve in ONE enqueue ---------------------------------
+// After c0 = A^T y the columns that matter are ranked once (|c0| tops).  The best 256 become the subset of the
+// first solo launch, whose Gram values all come from Gs = A_S^T A_S (subgram.hip: bit for bit the sweep's values,
+// 8 MiB of A instead of two passes over it); the best 64 get cache slots and their full Gram columns are swept on a
+// SECOND stream while the solo workgroup iterates (the barrier-free pass: 2048 single-wave workgroups that share
+// the chip with it; a gate kernel holds them back until the solo workgroup is resident).  Afterwards, on the main
+// stream again: slots + up to two passes for the columns the launch used beyond those 64, then the verification of
+// every breakpoint over all n columns (from the swept rows, exactly as in the plain form), the commit, and the
+// resident form for the last step of the path.  A solve that does not fit this mould (a pick outside the subset,
+// a miss, a failed check) simply continues in the plain pump below.
+inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nparts, float tol, uint32_t max_iter, uint32_t lds_cols,
+                           hipEvent_t pe0, hipEvent_t pe1)
+{
+    hipStream_t st = ctx->stream;
+    if (!ctx->stream2) {
+        // A stream of another priority class: HIP keeps a pool of hardware queues per class, so this one never
+        // shares a queue with the main stream (two streams on ONE hardware queue execute in submission order, and
+        // the gate kernel below would then sit in front of the very launch it waits for).
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        }
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    const int probe = ctx->early_probe;              // developer aid: 1 = no overlap (the passes first, then the solo launch)
+    if (ws.la_dbg) HIPCHK(hipMemsetAsync(ws.la_dbg, 0, 2048 * 8 * sizeof(uint64_t), st));
+    HIPCHK(launch_la_init_pick<float>(ctx, ws, nparts, tol, false));
+    HIPCHK(launch_la_cand_init_f32(ctx, ws));
+    HIPCHK(launch_subset_pick_f32(ctx, ws));                        // subset of 256, slots 0..63, the two sweep lists
+    // Gs, and a_idx . a_idx seeded into the first pick's cache row for the first inverse update
+    HIPCHK(launch_subset_gram_f32(ctx, ws.sub_cols, ws.subg, ws.st, ws.gcache, ws.slot_of, ws.gpitch));
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    // second stream: the two 32-column passes, held back until the solo workgroup is resident.  (Enqueued AFTER the
+    // solo launch: should the two streams ever share a hardware queue after all, the gate then follows the launch it
+    // waits for and everything merely runs one after the other.)
+    auto enqueue_passes = [&]() {
+        HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        if (!probe) HIPCHK(launch_wait_started(ctx, ws, ctx->stream2));
+        if (pe0) HIPCHK(hipEventRecord(pe0, ctx->stream2));
+        HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch));
+        if (pe1) HIPCHK(hipEventRecord(pe1, ctx->stream2));
+        HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch));
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+    };
+    if (probe == 1) { enqueue_passes(); HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0)); }
+    // main stream: first inverse + direction (k_gramupd, round 0: reads only the seeded entry), then the solo launch
+    HIPCHK(launch_la_update<float>(ctx, ws, 0, tol));
+    HIPCHK(launch_la_solo_f32(ctx, ws, tol, max_iter));
+    if (probe != 1) enqueue_passes();
+    // ... which the passes have to be complete for from here on
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    HIPCHK(launch_missing_cols_f32(ctx, ws));
+    HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list2, ws.sw_list2 + 64, ws.gcache, ws.gpitch, nullptr));
+    HIPCHK(launch_gemm32_tn_f32(ctx, ws.sw_list2 + 32, ws.sw_list2 + 96, ws.gcache, ws.gpitch, nullptr));
+    HIPCHK(launch_la_verify_f32(ctx, ws));                          // verification + publication
+    if (lds_cols != 0) HIPCHK(launch_la_persist_f32(ctx, ws, tol, max_iter, lds_cols, true));
+}
 
 // copies a strided vector (host or device) into a contiguous device buffer
 template <typename T>
@@ -626,7 +716,8 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const bool la = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual;
         // orthogonal matching pursuit in Gram form (k_la_omp): same cache, same sweeps
         const bool la_omp = omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && ctx->la_fused >= 1;
-        bool solo = false, solo_started = false;
+        bool solo = false, solo_started = false, early = false;
+        uint32_t early_lds_cols = 0;
         // full-G mode (fp32): G = A^T A of the context as the cache.  G exists once a large batch has run
         // on the context, or — opt-in, option gram_full_after > 0 — is made here after that many single-signal
         // solves (17 GiB and a few tenths of a second at C2 against ~0.6 ms saved per solve from then on).
@@ -678,7 +769,24 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                    (!ws.gram_is_full || ctx->solo_full_gram) && la_solo_usable(ctx);
             if (solo_wanted && !solo && ctx->solo_off_solves > 0 && !no_solo) ctx->solo_off_solves -= 1;
             solo_started = solo;
-            Lookahead<T>::init(ctx, ws, nb1, tol, solo);
+            early = solo && ctx->early_solo && sizeof(T) == 4 && !ws.gram_is_full && ctx->n > 32u * 512u && ws.gcap >= 160 &&
+                    ctx->sweep32_variant == 0 && ws.subg != nullptr && !ws.la_dbg;
+            if (early) {
+                // resident tier of the launch queued behind the solo group (the last step of the path)
+                uint32_t lc = std::min<uint32_t>((ws.dims.kcap + 15u) & ~15u, kLaLdsSmall);
+                if (ctx->la_fused < 2 || !la_persist_usable(ctx, lc)) lc = 0;
+                early_lds_cols = lc;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (prof) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
+                early_prologue(ctx, ws, nb1, tol, max_iter, lc, e0, e1);
+                if (prof) { ctx->prof_kind.push_back(3); ++nprof; }
+            } else {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (prof) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
+                const uint32_t fc = Lookahead<T>::init(ctx, ws, nb1, tol, solo, e0, e1);
+                // (events were recorded only if a sweep was launched; 4 = the 64-column first sweep, 3 = a 32-column one)
+                if (prof && fc != 0) { ctx->prof_kind.push_back(fc > 32 ? 4 : 3); ++nprof; }
+            }
         } else if (!omp) {
             // c = A^T y  (residual_vector with x = 0, homotopy-cpu.cpp:215)
             uint32_t nb1 = 0;
@@ -700,7 +808,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             // Fused lookahead engine: every launch of k_la_iter performs the next iteration, or
             // nothing while the device waits for a Gram column (hf[2] counts those waits).  The
             // host keeps L launches queued ahead and answers each wait with one fetch.
-            uint64_t enq = 0;
+            uint64_t enq = early ? (early_lds_cols != 0 ? 2u : 1u) : 0u;   // (early form: a solo group and the resident launch behind it are queued)
             uint32_t handled = 0, timed_fetches = 0;
             // resident kernel: LDS tier (support columns it can hold); 0 = one launch per iteration
             uint32_t lds_cols = 0;
@@ -745,6 +853,12 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 if (la_omp) HIPCHK(launch_la_omp<T>(ctx, ws, tol, max_iter));
                 else Lookahead<T>::iterate(ctx, ws, tol, max_iter, lds_cols, solo);
                 ++enq;
+                if (solo && lds_cols != 0) {
+                    // the resident form queued right behind the speculative group: a no-op unless that group hands
+                    // over (the last step of a path), which then costs no trip through the host
+                    HIPCHK(launch_persist(ctx, ws, tol, max_iter, lds_cols, true));
+                    ++enq;
+                }
             }
             if (stuck) {
                 HIPCHK(hipStreamSynchronize(st));
@@ -814,6 +928,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         if (!hs.done) {
             set_err(err, errlen, "solve: internal error, device loop did not terminate");
             return SS_HIP_ERUNTIME;
+        }
+        if (la && hs.status == kStatusRetryPlain) {
+            // the early form's first launch used too many columns beyond the prefetched ones: plain form for this solve
+            const int keep = ctx->early_solo;
+            ctx->early_solo = 0;
+            const int rc2 = solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax);
+            ctx->early_solo = keep;
+            return rc2;
         }
         if ((la || la_omp) && hs.status == kStatusRetryResidual) {
             // tolerance too tight for Gram-form correlations (see k_la_init_pick): residual form
@@ -897,6 +1019,11 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 if (ctx->prof_kind[i] == 1) {
                     ctx->stats.sweep1_launches += 1;
                     ctx->stats.sweep1_ms += ms;
+                } else if (ctx->prof_kind[i] == 4) {
+                    if (ms > 0.02f) {                          // (a launch of a solve that ended at the first pick is a no-op)
+                        ctx->stats.sweep64_launches += 1;
+                        ctx->stats.sweep64_ms += ms;
+                    }
                 } else if (ctx->prof_kind[i] == 3) {
                     // lookahead sweep: a launch that found nothing to do returns in microseconds
                     if ((double)ctx->stats.sweep32_bytes / (ms * 1e-3) < 50e12) {   // < 50 TB/s: it streamed A
@@ -1309,6 +1436,38 @@ int gram_cols_impl(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, T* G, ptrdif
     return rc;
 }
 
+int subset_gram_impl(ss_hip_ctx* ctx, const uint32_t* cols, float* Gs, int repeats, float* ms_out, char* err, size_t errlen)
+{
+    if (ctx && ctx->kind != 0) { set_err(err, errlen, "this entry point needs a Homotopy context (an IRLS context holds the factorised matrix)"); return SS_HIP_EINVAL; }
+    if (!ctx || !cols || !Gs) { set_err(err, errlen, "subset_gram: null argument"); return SS_HIP_EINVAL; }
+    if (ctx->is_f64) { set_err(err, errlen, "subset_gram: fp32 contexts only"); return SS_HIP_ETYPE; }
+    if (repeats < 1) repeats = 1;
+    uint32_t* dcols = nullptr;
+    float* dG = nullptr;
+    int rc = SS_HIP_OK;
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        HIPCHK(hipMalloc(&dcols, kSoloWidth * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&dG, (size_t)kSoloWidth * kSoloWidth * sizeof(float)));
+        HIPCHK(hipMemcpyAsync(dcols, cols, kSoloWidth * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev_solve0, ctx->stream));
+        for (int i = 0; i < repeats; ++i)
+            HIPCHK(launch_subset_gram_f32(ctx, dcols, dG, nullptr, nullptr, nullptr, 0));
+        HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
+        HIPCHK(hipMemcpyAsync(Gs, dG, (size_t)kSoloWidth * kSoloWidth * sizeof(float), hipMemcpyDefault, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
+        if (ms_out) *ms_out = ms / (float)repeats;
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        rc = SS_HIP_ERUNTIME;
+    }
+    if (dcols) (void)hipFree(dcols);
+    if (dG) (void)hipFree(dG);
+    return rc;
+}
+
 template <typename T>
 int reconstruct_impl(ss_hip_ctx* ctx, const T* x, T* y, char* err, size_t errlen)
 {
@@ -1424,6 +1583,7 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) {
         if (ctx->is_f64) free_ws(static_cast<Workspace<double>*>(ctx->ws));
@@ -1438,6 +1598,9 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_solve0) (void)hipEventDestroy(ctx->ev_solve0);
     if (ctx->ev_solve1) (void)hipEventDestroy(ctx->ev_solve1);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1532,6 +1695,11 @@ int ss_hip_gram_cols_f64(ss_hip_ctx* ctx, const uint32_t* cols, size_t S, double
     return gram_cols_impl<double>(ctx, cols, S, G, ldG, repeats, ms_out, err, errlen);
 }
 
+int ss_hip_subset_gram_f32(ss_hip_ctx* ctx, const uint32_t* cols, float* Gs, int repeats, float* ms_out, char* err, size_t errlen)
+{
+    return subset_gram_impl(ctx, cols, Gs, repeats, ms_out, err, errlen);
+}
+
 int ss_hip_reconstruct_f32(ss_hip_ctx* ctx, const float* x, float* y, char* err, size_t errlen)
 {
     return reconstruct_impl<float>(ctx, x, y, err, errlen);
@@ -1560,10 +1728,13 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx)
 {
     if (!ctx) return SS_HIP_EINVAL;
     const uint64_t b2 = ctx->stats.sweep_bytes, b1 = ctx->stats.sweep1_bytes, b32 = ctx->stats.sweep32_bytes;
+    const uint64_t b64 = ctx->stats.sweep64_bytes, f64 = ctx->stats.sweep64_flops;
     ctx->stats = ss_hip_stats{};
     ctx->stats.sweep_bytes = b2;
     ctx->stats.sweep1_bytes = b1;
     ctx->stats.sweep32_bytes = b32;
+    ctx->stats.sweep64_bytes = b64;
+    ctx->stats.sweep64_flops = f64;
     return SS_HIP_OK;
 }
 
@@ -1579,7 +1750,10 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
-    if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(7, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(9, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "first_sweep_cols")) { ctx->first_sweep_cols = value > 32 ? 64 : 32; return SS_HIP_OK; }
+    if (!std::strcmp(key, "early_solo"))    { ctx->early_solo = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "early_probe"))   { ctx->early_probe = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_subset"))   { ctx->solo_subset = (int)std::max<long>(0, std::min<long>(256, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_full_gram")) { ctx->solo_full_gram = value ? 1 : 0; return SS_HIP_OK; }
@@ -1638,6 +1812,8 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "la_fused"))      { *value = ctx->la_fused; return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_subset"))   { *value = ctx->solo_subset; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep32_variant")) { *value = ctx->sweep32_variant; return SS_HIP_OK; }
+    if (!std::strcmp(key, "first_sweep_cols")) { *value = ctx->first_sweep_cols; return SS_HIP_OK; }
+    if (!std::strcmp(key, "early_solo"))    { *value = ctx->early_solo; return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { *value = ctx->cache_mib; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_gram_min")) { *value = ctx->batch_gram_min; return SS_HIP_OK; }

@@ -206,6 +206,10 @@ struct SoloArgs {
     uint32_t* log;              // header + [kSoloLogCap][kSoloEntryWords] (ss_hip_internal.h)
     uint8_t* sub_pos;           // [n_pad] subset position of each of this launch's columns
     uint32_t* stage;            // [kSoloStageWords] staged hand-over (committed by k_la_vpublish)
+    // early form (DevState::subg_active): the launch runs on the subset Gram matrix Gs = A_S^T A_S of the given
+    // columns (subgram.hip) instead of cache rows — Gram "row" and "column" are subset positions there
+    const float* subg;          // [kSoloWidth][kSoloWidth], null = never
+    const uint32_t* sub_cols;   // [kSoloWidth] the columns of that subset (position 0 = the first pick)
 };
 
 template <bool SOLO>
@@ -217,7 +221,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                   uint32_t* gam2, float* inv0, float* inv1, float* __restrict__ tcand,
                   SlotDims L, DevState* st, LaSync* sy, uint64_t* smax, uint64_t* smin, uint32_t* hflags,
                   TraceEntry* trace, uint32_t trace_cap, int tie_guard, int zero_on_removal, uint32_t* touched2,
-                  uint64_t* dbg, SoloArgs sa)
+                  int after_solo, uint64_t* dbg, SoloArgs sa)
 {
     extern __shared__ float smem[];
     __shared__ float sv[16];
@@ -257,6 +261,8 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     const uint32_t K0 = st->K;
     const bool grow0 = (K0 + 1u > P) && (P < kcap);
     if (SOLO) {
+        // early form: the passes over A on the second stream are held back until this workgroup is resident
+        if (tid == 0) __hip_atomic_store(&st->solo_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (k_la_vpublish counts the launch for the host pump, whether it worked or not)
         if (st->done || st->need_sweep || st->solo_off) return;
         if (grow0) {
@@ -264,6 +270,11 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             if (tid == 0) { sa.stage[9] = kPsExitNothing; sa.stage[0] = K0; st->solo_nlog = 0; st->solo_pending = 2; }
             return;
         }
+    } else if (after_solo && !st->solo_off) {
+        // queued right behind a speculative group so that its hand-over (the last step of a path) needs no trip
+        // through the host: nothing to do unless that group has handed over
+        if (lead && tid == 0) bump_seq(st, hflags);
+        return;
     } else if (st->done || st->need_sweep || grow0) {
         if (lead && tid == 0) {
             if (!st->done && !st->need_sweep)
@@ -273,10 +284,17 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         return;
     }
     uint32_t tick = sy->tick;
+    // early form: Gram values come from Gs, indexed by subset positions (rows are handed out in LDS as columns
+    // enter, like the full-G mode does it)
+    const bool subg = SOLO && sa.subg != nullptr && st->subg_active != 0u;
+    const bool by_entry = full_g || subg;                      // LDS rows follow the order of entry, not the cache slots
 
     // ---- this workgroup's columns -------------------------------------------------------------------
     const uint32_t replay = SOLO ? st->solo_replay : 0u;       // > 0: repeat exactly this many (verified) iterations
-    if (SOLO && replay != 0u) {
+    if (SOLO && subg && replay == 0u) {
+        if (tid < kSoloWidth) s_sub[tid] = sa.sub_cols[tid];     // chosen before the launch (k_subset_pick)
+        __syncthreads();
+    } else if (SOLO && replay != 0u) {
         // the same columns as the launch that is being repeated (its header is still in the log)
         if (tid < kSoloWidth) s_sub[tid] = sa.log[tid];
         __syncthreads();
@@ -365,7 +383,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         if (tid < kSoloWidth) {
             const uint32_t cl = s_sub[tid];
             sa.log[tid] = cl;
-            sa.log[kSoloWidth + tid] = cl < n ? (full_g ? cl : (uint32_t)slot_of[cl]) : 0xffffffffu;
+            sa.log[kSoloWidth + tid] = cl < n ? (full_g ? cl : (uint32_t)slot_of[cl]) : 0xffffffffu;   // (informational: k_la_verify looks the rows up itself)
             if (cl < n) sa.sub_pos[cl] = (uint8_t)tid;
         }
         if (tid < kSoloListPitch) s_sps[tid] = tid;             // the support leads the subset, in order
@@ -387,7 +405,12 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     if (tid < K) {
         const uint32_t cl = gam_cur[tid];
         S.gam[tid] = cl;
-        S.slt[tid] = (uint32_t)slot_of[cl];
+        uint32_t sl = (uint32_t)slot_of[cl];
+        if (subg) {                                  // the Gram row of a column is its subset position
+            sl = 0u;
+            for (uint32_t p2 = 0; p2 < kSoloWidth; ++p2) if (s_sub[p2] == cl) sl = p2;
+        }
+        S.slt[tid] = sl;
         S.xs[tid] = x[cl];
         S.ds[tid] = d[cl];
     } else if (tid < P) {
@@ -401,6 +424,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     // (every lambda below is forced inline: a closure that survives keeps its captures — K, the list
     // pointers, ... — in scratch memory, which made each stage of the solo instantiation ~1.5x slower)
     auto grow_global = [&](uint32_t row, uint32_t cofs4) __attribute__((always_inline)) -> float {
+        if (subg) return sa.subg[(size_t)row * kSoloWidth + (cofs4 >> 2)];       // (row, column: subset positions)
         if (full_g) return gcache[(size_t)row * gpitch + (cofs4 >> 2)];
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, cofs4, row * (gpitch * 4u), 0));
     };
@@ -409,17 +433,17 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     //   cache mode : LDS row r = cache slot r, for the first gl_rows slots handed out;
     //   full-G mode: LDS rows are handed out as columns enter (the support at entry takes rows 0..K0-1),
     //                each workgroup fetching its 1 KiB of row idx of G at that moment.
-    const uint32_t gl_used = full_g ? (K0 < gl_rows ? K0 : gl_rows) : (st->cache_used < gl_rows ? st->cache_used : gl_rows);
+    const uint32_t gl_used = by_entry ? (K0 < gl_rows ? K0 : gl_rows) : (st->cache_used < gl_rows ? st->cache_used : gl_rows);
     uint32_t lds_rows_used = gl_used;                  // full-G mode: next free LDS row (same in every workgroup)
     if (tid < P) {
         uint32_t lr = kNoLdsRow;
-        if (tid < K0) lr = full_g ? (tid < gl_rows ? tid : kNoLdsRow) : (S.slt[tid] < gl_used ? S.slt[tid] : kNoLdsRow);
+        if (tid < K0) lr = by_entry ? (tid < gl_rows ? tid : kNoLdsRow) : (S.slt[tid] < gl_used ? S.slt[tid] : kNoLdsRow);
         S.lrw[tid] = lr;
     }
     {
         const uint32_t tcol = tid & (kPsWidth - 1u), half = tid / kPsWidth;          // two rows per pass
         const uint32_t cg = SOLO ? s_sub[tcol] : w * kPsWidth + tcol;
-        const uint32_t cofs4 = (cg < n ? cg : 0u) * 4u;
+        const uint32_t cofs4 = subg ? tcol * 4u : (cg < n ? cg : 0u) * 4u;
         constexpr uint32_t rpp = kPsThreads / kPsWidth;      // rows per pass
         for (uint32_t r0 = 0; r0 < gl_used; r0 += 8 * rpp) {
             float gv[8];
@@ -427,7 +451,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             for (int t = 0; t < 8; ++t) {
                 const uint32_t r = r0 + rpp * t + half;
                 gv[t] = 0.f;
-                if (r < gl_used) gv[t] = grow_global(full_g ? S.slt[r] : r, cofs4);
+                if (r < gl_used) gv[t] = grow_global(by_entry ? S.slt[r] : r, cofs4);
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -533,7 +557,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             const uint32_t t = (uint32_t)wave * 32u + ((uint32_t)lane & 31u);       // subset position
             const bool dsum = lane >= 32;
             const uint32_t ccol = s_sub[t];
-            const uint32_t cofs4 = (ccol < n ? ccol : 0u) * 4u;
+            const uint32_t cofs4 = subg ? t * 4u : (ccol < n ? ccol : 0u) * 4u;
             const float* coef = dsum ? S.ds : S.xs;
             const uint32_t K16 = (K + (kPsGroup - 1u)) & ~(kPsGroup - 1u);
             float acc = 0.f;
@@ -859,14 +883,20 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
         } else if (tid < K) { cj = ld_f32(&cbuf[S.gam[tid]]); qj = ld_f32(&qbuf[S.gam[tid]]); }
         else if (tid == K && added) { cj = ld_f32(&cbuf[idx]); qj = ld_f32(&qbuf[idx]); }
         int32_t slot = 0;
-        if (added) slot = slot_of[idx];
+        if (added) slot = subg ? (int32_t)s_ipos : slot_of[idx];
         // u1 = A_S^T a_idx, dot = a_idx.a_idx from the Gram column of idx (online_inverse.h:209-218): issued
         // here (the slot permitting), consumed in the inverse update after the c pass
         float u1v = 0.f;
         if (added && slot >= 0) {
-            const float* gi = gcache + (size_t)slot * gpitch;
-            if (tid < K) u1v = gi[S.gam[tid]];
-            else if (tid == K) u1v = gi[idx];
+            if (subg) {
+                const float* gi = sa.subg + (size_t)slot * kSoloWidth;
+                if (tid < K) u1v = gi[s_sps[tid]];
+                else if (tid == K) u1v = gi[slot];
+            } else {
+                const float* gi = gcache + (size_t)slot * gpitch;
+                if (tid < K) u1v = gi[S.gam[tid]];
+                else if (tid == K) u1v = gi[idx];
+            }
         }
 
         // x += gamma * direction over the OLD support (:252); the leaving column lands on exactly 0
@@ -963,12 +993,13 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             // full-G mode: the entering column gets the next LDS row; this workgroup fetches its slice of row
             // idx of G (used first by the q pass below, after several barriers)
             uint32_t new_lrow = kNoLdsRow;
-            if (full_g) {
+            if (by_entry) {
                 if (lds_rows_used < gl_rows) {
                     new_lrow = lds_rows_used++;
                     if (tid < kPsWidth) {
                         const uint32_t cg = SOLO ? s_sub[tid] : w * kPsWidth + tid;
-                        Glds[new_lrow * kPsWidth + tid] = gcache[(size_t)idx * gpitch + (cg < n ? cg : 0u)];
+                        Glds[new_lrow * kPsWidth + tid] = subg ? sa.subg[(size_t)slot * kSoloWidth + tid]
+                                                               : gcache[(size_t)idx * gpitch + (cg < n ? cg : 0u)];
                     }
                 }
             } else if ((uint32_t)slot < gl_used) {
@@ -1203,7 +1234,7 @@ bool la_persist_usable(ss_hip_ctx* ctx, uint32_t lds_cols)
     return persist_grid_workers(ctx, lds_cols) != 0;
 }
 
-hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, uint32_t lds_cols)
+hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, uint32_t lds_cols, bool after_solo)
 {
     const uint32_t P = lds_cols;
     const uint32_t nw = persist_grid_workers(ctx, P);
@@ -1215,7 +1246,7 @@ hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float to
     hipLaunchKernelGGL(k_la_persist<false>, dim3(nw), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, persist_gl_rows(P), ws.gram_is_full ? 1 : 0,
                        (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
-                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ctx->zero_on_removal, ws.touched, ws.la_dbg, SoloArgs{});
+                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ctx->zero_on_removal, ws.touched, after_solo ? 1 : 0, ws.la_dbg, SoloArgs{});
     return hipGetLastError();
 }
 
@@ -1250,15 +1281,17 @@ hipError_t launch_la_solo_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     SoloArgs sa;
     sa.slot_col = ws.slot_col;
     sa.cand_top = ws.cand_top;
-    sa.ncand = 2 * ws.nvwg;
+    sa.ncand = kCandPerBlock * ws.nvwg;
     sa.subset_cap = (uint32_t)std::max(0, std::min(ctx->solo_subset, (int)kSoloWidth));
     sa.log = ws.solo_log;
     sa.sub_pos = ws.sub_pos;
     sa.stage = ws.solo_stage;
+    sa.subg = ws.subg;
+    sa.sub_cols = ws.sub_cols;
     hipLaunchKernelGGL(k_la_persist<true>, dim3(1), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, kSoloGlRows, ws.gram_is_full ? 1 : 0,
                        (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,
-                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ctx->zero_on_removal, ws.touched, ws.la_dbg, sa);
+                       ws.la_sync, smax, smin, ctx->dev_flags, ws.trace, ws.trace_cap, ctx->tie_guard, ctx->zero_on_removal, ws.touched, 0, ws.la_dbg, sa);
     return hipGetLastError();
 }
 

@@ -30,25 +30,27 @@
 #include "ss_hip_internal.h"
 #include "ss_hip_device.h"
 
+#include <algorithm>
+
 namespace sship {
 
 constexpr int kVfThreads = 256;
 constexpr uint32_t kVfUnion = 144;           // support columns a chunk of breakpoints can involve (96 + 40, rounded up)
 constexpr uint32_t kVfRedPitch = kSoloWidth + 16;    // row pitch of the reduction buffer (16 readers per row: conflict-free)
 
-// the two best (smallest key, then smallest column) of the block's offers -> out[0], out[1]
-__device__ __forceinline__ void block_top2(float key, uint32_t colv, uint64_t* out, float* sv, uint32_t* si)
+// the kCandPerBlock best (smallest key, then smallest column) of the block's offers -> out[0 .. kCandPerBlock)
+// (two per 256-column block were too few: with 64 support columns spread over 256 blocks four solves in ten
+// have a block that holds three of them, and the third was then never ranked)
+__device__ __forceinline__ void block_topn(float key, uint32_t colv, uint64_t* out, float* sv, uint32_t* si)
 {
-    float k1 = key;
-    uint32_t c1 = colv;
-    block_reduce_pair<float, false>(k1, c1, sv, si);
-    __syncthreads();
-    float k2 = (colv == c1) ? Lim<float>::max() : key;
-    uint32_t c2 = (colv == c1) ? 0xffffffffu : colv;
-    block_reduce_pair<float, false>(k2, c2, sv, si);
-    if (threadIdx.x == 0) {
-        out[0] = c1 != 0xffffffffu ? (((uint64_t)ordered_key(k1) << 32) | c1) : ~0ull;
-        out[1] = c2 != 0xffffffffu ? (((uint64_t)ordered_key(k2) << 32) | c2) : ~0ull;
+#pragma unroll
+    for (uint32_t r = 0; r < kCandPerBlock; ++r) {
+        float k1 = key;
+        uint32_t c1 = colv;
+        block_reduce_pair<float, false>(k1, c1, sv, si);
+        if (threadIdx.x == 0) out[r] = c1 != 0xffffffffu ? (((uint64_t)ordered_key(k1) << 32) | c1) : ~0ull;
+        if (colv == c1) { key = Lim<float>::max(); colv = 0xffffffffu; }     // taken
+        __syncthreads();
     }
 }
 
@@ -67,7 +69,7 @@ void k_la_cand_init(const float* __restrict__ c0, uint32_t n, const DevState* __
         key = v < 0.f ? v : -v;
         cl = i;
     }
-    block_top2(key, cl, cand_top + 2 * (size_t)blockIdx.x, sv, si);
+    block_topn(key, cl, cand_top + kCandPerBlock * (size_t)blockIdx.x, sv, si);
 }
 
 // Two threads per column: thread (half h, column t) carries the breakpoints 20h .. 20h+19 of a chunk
@@ -110,9 +112,13 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
     const float c0v = valid ? c0[i] : 0.f;
     const bool cached = valid && slot_of[i] >= 0;
     if (tid < kSoloWidth) {
-        s_sub[tid] = log[tid];
-        s_row[tid] = log[kSoloWidth + tid];
+        // (the Gram row of a subset column is looked up NOW, not taken from the header: in the early form the
+        // solo launch ran before its columns had rows, which the passes over A have filled in since)
+        const uint32_t cl = log[tid];
+        s_sub[tid] = cl;
+        s_row[tid] = cl < n ? (full_g ? cl : (uint32_t)slot_of[cl]) : 0xffffffffu;
     }
+    if (tid == 0) s_U = 0u;                              // (free until the first chunk: 1 + index of the last scan entry)
     __syncthreads();
     // this thread's column in the subset?  (sub_pos is only trusted if the header agrees)
     uint32_t mypos = 0xffffffffu;
@@ -122,13 +128,14 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
     }
     // the last entry that carries a scan: its candidates feed tcand and the next subset
     // (one parallel load of the flag words; s_U is free until the first chunk)
+    static_assert(kSoloLogCap <= (uint32_t)kVfyThreads && kSoloLogCap % 64u == 0u, "whole waves look at the flag words");
     if (tid < kSoloLogCap) {
         const uint32_t fl = tid < nlog ? (log[kSoloHeaderWords + (size_t)tid * kSoloEntryWords + 1] & 1u) : 0u;
         const uint64_t b = __ballot(fl != 0u);
-        if (tid == 0) s_U = b ? 63u - (uint32_t)__builtin_clzll(b) : 0xffffffffu;
+        if ((tid & 63u) == 0u && b) atomicMax(&s_U, (tid & ~63u) + 64u - (uint32_t)__builtin_clzll(b));
     }
     __syncthreads();
-    const uint32_t last_scan = s_U;
+    const uint32_t last_scan = s_U ? s_U - 1u : 0xffffffffu;
 
     const uint32_t* entries = log + kSoloHeaderWords;
     tsv[1] = wall_clock64();
@@ -323,7 +330,7 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
             if (own_last) tcand[i] = (act_last || (cached && !full_g)) ? Lim<float>::max() : m_last;
             // next subset: cached columns come in through their slots (cache mode), the support through its lists
             const bool offer = own_last && !act_last && (full_g || !cached) && m_last < Lim<float>::max();
-            block_top2(offer ? m_last : Lim<float>::max(), offer ? i : 0xffffffffu, cand_top + 2 * (size_t)wg, sv, si);
+            block_topn(offer ? m_last : Lim<float>::max(), offer ? i : 0xffffffffu, cand_top + kCandPerBlock * (size_t)wg, sv, si);
         }
     }
     if (dbg != nullptr && wg == 0 && tid == 0) {       // developer aid: stage timestamps of workgroup 0 (row 1600 + entries)
@@ -345,7 +352,7 @@ struct CommitArgs {
     uint32_t* touched2; int zero_on_removal;
 };
 
-constexpr int kPubThreads = 1024;            // 16 threads per log entry; the commit copies with all of them
+constexpr int kPubThreads = 1024;            // 8 threads per log entry; the commit copies with all of them
 
 __global__ __launch_bounds__(kPubThreads)
 void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_t* __restrict__ v_max,
@@ -361,16 +368,17 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
     const uint32_t nlog = st->solo_nlog;
     if (tid == 0) { s_first = nlog; s_good = 0u; s_scan = 0u; }
     __syncthreads();
-    // sixteen threads per entry
-    const uint32_t k = tid >> 4, sub = tid & 15u;
+    // eight threads per entry
+    static_assert(kSoloLogCap * 8u <= (uint32_t)kPubThreads, "eight threads per log entry");
+    const uint32_t k = tid >> 3, sub = tid & 7u;
     const bool has_scan = k < nlog && (log[kSoloHeaderWords + (size_t)k * kSoloEntryWords + 1] & 1u);
     if (pending == 1u && k < nlog) {
         uint32_t mx = 0u;
         uint64_t mn = ~0ull;
         const uint32_t* pm = v_max + (size_t)k * nvwg;
         const uint64_t* pn = v_min + (size_t)k * nvwg;
-        // this thread's sixteenth of the partials, sixteen independent loads at a time
-        const uint32_t per = (nvwg + 15u) / 16u;
+        // this thread's eighth of the partials, sixteen independent loads at a time
+        const uint32_t per = (nvwg + 7u) / 8u;
         const uint32_t b_lo = sub * per, b_hi = (b_lo + per < nvwg) ? b_lo + per : nvwg;
         for (uint32_t b0 = b_lo; b0 < b_hi; b0 += 16) {
             uint32_t a[16];
@@ -385,7 +393,7 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
             for (int t = 0; t < 16; ++t) { mx = a[t] > mx ? a[t] : mx; mn = c[t] < mn ? c[t] : mn; }
         }
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
+        for (int o = 1; o < 8; o <<= 1) {
             mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
             const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mn, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mn >> 32), o);
             const uint64_t v = ((uint64_t)hi << 32) | lo;
@@ -491,6 +499,7 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
         st->rank = sg[6];
         st->added = sg[7];
         if (!ca.zero_on_removal) st->ntouched = save ? K + 1u : K;
+        st->subg_active = 0;                           // later solo launches pick a new subset: Gram-column cache
     }
     bool off = pending == 2u;                          // after a replay the resident form goes on
     if (code == kPsExitDone) {
@@ -522,13 +531,14 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
 // The columns of the next lookahead sweep, from the per-block candidate tops instead of a scan of all n
 // step-length candidates (k_la_top, one workgroup over n values: 31 us at n = 65536): the entering column
 // first, then the best-ranked offers that are neither active nor cached.  Same outputs as k_la_top.
-constexpr int kTcThreads = 512;
-constexpr int kTcS = 32;                      // columns per sweep (k_la_top's kTopS)
+constexpr int kTcThreads = 1024;             // one offer per thread up to 1024 candidates (4 per block at n = 65536)
+constexpr int kTcStride = 64;                 // sw_list layout: rcols[64] then drows[64] (k_la_top's kSwStride)
 
 __global__ __launch_bounds__(kTcThreads)
 void k_la_top_cand(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32_t n,
                    const uint8_t* __restrict__ insup, int32_t* __restrict__ slot_of, uint32_t gcap,
-                   uint32_t* __restrict__ sw_list, DevState* st, uint32_t* hflags, uint32_t* __restrict__ slot_col)
+                   uint32_t* __restrict__ sw_list, DevState* st, uint32_t* hflags, uint32_t* __restrict__ slot_col,
+                   uint32_t nsel /* columns of this sweep: 32, or 64 for the first one of a solve */)
 {
     __shared__ __attribute__((aligned(16))) uint64_t s_of[kTcThreads];
     if (st->done || !st->need_sweep) return;
@@ -556,23 +566,23 @@ void k_la_top_cand(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32
         }
     }
     const uint32_t room = gcap > used ? gcap - used : 0u;                 // slots left (the entering column takes the first)
-    uint32_t count = total < (uint32_t)kTcS - 1u ? total : (uint32_t)kTcS - 1u;
+    uint32_t count = total < nsel - 1u ? total : nsel - 1u;
     if (room == 0u) count = 0u; else if (count + 1u > room) count = room - 1u;
     if (o1 != ~0ull && r1 < count) {
         const uint32_t cl = (uint32_t)o1, sl = used + 1u + r1;
-        sw_list[1 + r1] = cl; sw_list[kTcS + 1 + r1] = sl; slot_of[cl] = (int32_t)sl;
+        sw_list[1 + r1] = cl; sw_list[kTcStride + 1 + r1] = sl; slot_of[cl] = (int32_t)sl;
         if (slot_col != nullptr) slot_col[sl] = cl;
     }
-    if (tid >= 1u + count && tid < (uint32_t)kTcS) { sw_list[tid] = 0xffffffffu; sw_list[kTcS + tid] = 0xffffffffu; }
+    if (tid >= 1u + count && tid < (uint32_t)kTcStride) { sw_list[tid] = 0xffffffffu; sw_list[kTcStride + tid] = 0xffffffffu; }
     if (tid == 0) {
         if (room > 0u) {
-            sw_list[0] = idx; sw_list[kTcS] = used; slot_of[idx] = (int32_t)used;
+            sw_list[0] = idx; sw_list[kTcStride] = used; slot_of[idx] = (int32_t)used;
             if (slot_col != nullptr) slot_col[used] = idx;
             st->cache_used = used + 1u + count;
             st->nsweeps += 1;
         } else {
             // cache budget exhausted: the host re-runs the solve in residual form (as k_la_top does)
-            sw_list[0] = 0xffffffffu; sw_list[kTcS] = 0xffffffffu;
+            sw_list[0] = 0xffffffffu; sw_list[kTcStride] = 0xffffffffu;
             st->status = kStatusRetryResidual;
             st->need_sweep = 0;
             st->done = 1;
@@ -581,12 +591,164 @@ void k_la_top_cand(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32
     }
 }
 
-hipError_t launch_la_top_cand_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
+// ===== early form: the iterations start on the subset Gram matrix while A is still being swept ================
+// (homotopy.hip, Lookahead::init_early; csrc/subgram.hip)
+
+// The subset of the first solo launch and the slots of the first 64 Gram columns, from one ranking of the
+// per-block candidate tops by |c0|: position 0 / slot 0 = the first pick, positions 1..255 = the best-ranked
+// candidates, the first 63 of which also get cache slots 1..63 (two 32-column passes: sw_list[0..31] / [64..95]
+// and sw_list[32..63] / [96..127]).
+__global__ __launch_bounds__(kTcThreads)
+void k_subset_pick(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32_t n, int32_t* __restrict__ slot_of,
+                   uint32_t* __restrict__ sw_list, uint32_t* __restrict__ sub_cols, DevState* st,
+                   uint32_t* __restrict__ slot_col, uint32_t subset_cap /* option solo_subset: columns beyond the support */)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t s_of[kTcThreads];
+    if (st->done) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t idx = st->idx;
+    uint64_t o1 = ~0ull;
+    for (uint32_t e = tid; e < ncand; e += kTcThreads) {
+        const uint64_t pk = cand_top[e];
+        const uint32_t cl = (uint32_t)pk;
+        if (pk == ~0ull || cl >= n || cl == idx) continue;
+        if (pk < o1) o1 = pk;
+    }
+    s_of[tid] = o1;
+    const uint32_t total = (uint32_t)__syncthreads_count(o1 != ~0ull);
+    uint32_t r1 = 0;
+    if (o1 != ~0ull) {
+        const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(s_of);
+#pragma unroll 8
+        for (uint32_t u = 0; u < kTcThreads / 2; ++u) {
+            const ulonglong2 v = p2[u];
+            r1 += v.x < o1 ? 1u : 0u;
+            r1 += v.y < o1 ? 1u : 0u;
+        }
+    }
+    uint32_t nsub = total < kSoloWidth - 1u ? total : kSoloWidth - 1u;             // subset positions 1 .. nsub
+    if (nsub > subset_cap) nsub = subset_cap;
+    const uint32_t nslot = total < 63u ? total : 63u;                              // cache slots 1 .. nslot
+    if (o1 != ~0ull && r1 < nsub) {
+        const uint32_t cl = (uint32_t)o1;
+        sub_cols[1u + r1] = cl;
+        if (r1 < nslot) {
+            sw_list[1u + r1] = cl; sw_list[kTcStride + 1u + r1] = 1u + r1; slot_of[cl] = (int32_t)(1u + r1);
+            if (slot_col != nullptr) slot_col[1u + r1] = cl;
+        }
+    }
+    if (tid >= 1u + nsub && tid < kSoloWidth) sub_cols[tid] = 0xffffffffu;
+    if (tid >= 1u + nslot && tid < (uint32_t)kTcStride) { sw_list[tid] = 0xffffffffu; sw_list[kTcStride + tid] = 0xffffffffu; }
+    if (tid == 0) {
+        sub_cols[0] = idx;
+        sw_list[0] = idx; sw_list[kTcStride] = 0u; slot_of[idx] = 0;
+        if (slot_col != nullptr) slot_col[0] = idx;
+        st->cache_used = 1u + nslot;
+        st->nsweeps += nslot >= 32u ? 2u : 1u;
+        st->subg_active = 1;
+    }
+}
+
+// second stream: hold the passes over A back until the solo workgroup is resident (it needs a whole CU's LDS; once
+// the barrier-free pass has spread its single-wave workgroups over every CU there is no room for it until they
+// finish).  Bounded: a solo launch that never starts only costs the overlap.
+__global__ void k_wait_started(const DevState* st)
+{
+    if (threadIdx.x != 0) return;
+    for (uint32_t spin = 0; spin < 4000u; ++spin) {
+        if (__hip_atomic_load(&st->solo_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        if (__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// After the first solo launch of the early form: every column that was in the support at any of its breakpoints
+// (or was its last pick) needs its full Gram row before the verification can re-derive the breakpoints over all n
+// columns.  The first 64 ranked columns have theirs (the two passes that ran beside the launch); the others get
+// slots here and up to two more passes fetch them (sw_list2, same layout as sw_list).  More than 64 of them, or a
+// full cache: the host re-runs the solve in the plain form (kStatusRetryPlain).
+__global__ __launch_bounds__(kSoloWidth)
+void k_missing_cols(const uint32_t* __restrict__ log, const uint8_t* __restrict__ sub_pos, uint32_t n, uint32_t gcap,
+                    int32_t* __restrict__ slot_of, uint32_t* __restrict__ slot_col, uint32_t* __restrict__ sw_list2,
+                    DevState* st, uint32_t* hflags)
+{
+    __shared__ uint32_t s_need[kSoloWidth];
+    __shared__ uint32_t s_w[kSoloWidth / 64];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 2u * (uint32_t)kTcStride) sw_list2[tid] = 0xffffffffu;                // (kSoloWidth >= 128 threads)
+    if (st->done || st->solo_pending != 1u || !st->subg_active) return;
+    const uint32_t nlog = st->solo_nlog;
+    s_need[tid] = 0u;
+    __syncthreads();
+    const uint32_t* entries = log + kSoloHeaderWords;
+    for (uint32_t pr = tid; pr < nlog * kSoloListPitch; pr += kSoloWidth) {
+        const uint32_t k = pr / kSoloListPitch, j = pr - k * kSoloListPitch;
+        const uint32_t* e = entries + (size_t)k * kSoloEntryWords;
+        if (j < e[0]) s_need[e[8 + kSoloListPitch + j] & (kSoloWidth - 1u)] = 1u;   // subset position of a support column
+        if (j == 0 && (e[1] & 1u)) {
+            const uint32_t cl = e[3];                                                // the pick of a scan entry
+            if (cl < n) { const uint32_t p = sub_pos[cl]; if (log[p] == cl) s_need[p] = 1u; }
+        }
+    }
+    __syncthreads();
+    const uint32_t cl = log[tid];                                                    // header: column of position tid
+    const bool miss = s_need[tid] != 0u && cl < n && slot_of[cl] < 0;
+    const uint64_t bal = __ballot(miss);
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < kSoloWidth / 64; ++w) { if (w < wave) before += s_w[w]; total += s_w[w]; }
+    const uint32_t used = st->cache_used;
+    if (total > 64u || used + total > gcap) {
+        if (tid == 0) {
+            st->status = kStatusRetryPlain;
+            st->need_sweep = 0;
+            st->done = 1;
+            signal_done(hflags, nullptr, 1u, st->iter);
+        }
+        return;
+    }
+    if (miss) {
+        const uint32_t r = before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        const uint32_t sl = used + r;
+        // list 0: entries 0..31 / 64..95, list 1: entries 32..63 / 96..127
+        sw_list2[r] = cl; sw_list2[kTcStride + r] = sl; slot_of[cl] = (int32_t)sl;
+        if (slot_col != nullptr) slot_col[sl] = cl;
+    }
+    if (tid == 0 && total != 0u) { st->cache_used = used + total; st->nsweeps += total > 32u ? 2u : 1u; }
+}
+
+hipError_t launch_subset_pick_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
+{
+    if (ws.cand_top == nullptr || ws.nvwg == 0 || ws.sub_cols == nullptr) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_subset_pick, dim3(1), dim3(kTcThreads), 0, ctx->stream, (const uint64_t*)ws.cand_top, kCandPerBlock * ws.nvwg,
+                       (uint32_t)ctx->n, ws.slot_of, ws.sw_list, ws.sub_cols, ws.st, ws.slot_col,
+                       (uint32_t)std::max(0, std::min(ctx->solo_subset, (int)kSoloWidth)));
+    return hipGetLastError();
+}
+
+hipError_t launch_wait_started(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on)
+{
+    (void)ctx;
+    hipLaunchKernelGGL(k_wait_started, dim3(1), dim3(64), 0, on, (const DevState*)ws.st);
+    return hipGetLastError();
+}
+
+hipError_t launch_missing_cols_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
+{
+    if (ws.solo_log == nullptr || ws.sw_list2 == nullptr) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_missing_cols, dim3(1), dim3(kSoloWidth), 0, ctx->stream, (const uint32_t*)ws.solo_log, (const uint8_t*)ws.sub_pos,
+                       (uint32_t)ctx->n, ws.gcap, ws.slot_of, ws.slot_col, ws.sw_list2, ws.st, ctx->dev_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_la_top_cand_f32(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nsel)
 {
     if (ws.cand_top == nullptr || ws.nvwg == 0) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(k_la_top_cand, dim3(1), dim3(kTcThreads), 0, ctx->stream, (const uint64_t*)ws.cand_top, 2 * ws.nvwg,
+    hipLaunchKernelGGL(k_la_top_cand, dim3(1), dim3(kTcThreads), 0, ctx->stream, (const uint64_t*)ws.cand_top, kCandPerBlock * ws.nvwg,
                        (uint32_t)ctx->n, (const uint8_t*)ws.insup, ws.slot_of, ws.gcap, ws.sw_list, ws.st, ctx->dev_flags,
-                       ws.gram_is_full ? (uint32_t*)nullptr : ws.slot_col);
+                       ws.gram_is_full ? (uint32_t*)nullptr : ws.slot_col, nsel > 64u ? 64u : (nsel < 2u ? 2u : nsel));
     return hipGetLastError();
 }
 

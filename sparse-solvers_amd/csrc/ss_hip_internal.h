@@ -23,6 +23,9 @@ constexpr uint32_t kColPad = 256;
 // DevState::status raised by the lookahead engine when the tolerance is too tight for Gram-form
 // correlations (never leaves the library: the host re-runs the solve in residual form).
 constexpr uint32_t kStatusRetryResidual = 100;
+// DevState::status raised by the early form of the speculative engine when its first launch used more columns
+// outside the prefetched ones than two fill-in passes fetch (the host re-runs the solve in the plain form).
+constexpr uint32_t kStatusRetryPlain = 101;
 // Gram form is used while tolerance >= guard * ||A^T y||_inf: 2^-14 in fp32, 2^-42 in fp64 (eps x ~1000)
 constexpr double kGramGuard = 1.0 / 16384.0;
 constexpr double kGramGuard64 = 1.0 / 4398046511104.0;
@@ -65,7 +68,9 @@ struct DevState {
     uint32_t cand_scan;    // 1 once tcand / cand_top carry the candidates of a verified scan (before: |c0| ranks)
     uint32_t solo_replay;  // > 0: the last solo launch failed its check after this many good iterations; the next one repeats exactly those
     uint32_t solo_fails;   // solo launches of this solve that failed a check
-    uint32_t pad0_[6];
+    uint32_t solo_started; // early form: set by the solo launch when it begins (the passes over A on the second stream wait for it)
+    uint32_t subg_active;  // early form: 1 while the solo launches of this solve run on the subset Gram matrix Gs (until their first commit)
+    uint32_t pad0_[4];
     // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
     uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
     uint32_t pad1_[31];
@@ -102,7 +107,7 @@ constexpr uint32_t kLaLdsLarge = 192;     // ... and the one that takes a whole 
 //   [0] K  [1] flags (bit 0: the entry carries a step-length scan)  [2] round  [3] idx picked
 //   [4] bits(lambda)  [5] bits(gamma)  [6] bits(best candidate on the support)  [7] its column
 //   gam[], subset position[], bits(x_S)[], bits(d_S)[] in sorted-support order
-constexpr uint32_t kSoloLogCap = 64;                          // entries per launch
+constexpr uint32_t kSoloLogCap = 128;                         // entries per launch (a C2 path of 64 iterations fits one launch)
 constexpr uint32_t kSoloListPitch = kLaLdsSmall;              // solo launches run in the first LDS tier only
 constexpr uint32_t kSoloEntryWords = 8 + 4 * kSoloListPitch;
 constexpr uint32_t kSoloHeaderWords = 512;
@@ -127,6 +132,7 @@ constexpr uint32_t kSoloStageHead = 16;
 constexpr uint32_t kSoloStageWords = kSoloStageHead + 4 * kSoloListPitch + 1 + kSoloListPitch * kSoloListPitch;
 constexpr uint32_t kSoloChunk = 40;                           // breakpoints verified per pass over the Gram rows (a phase of ~33 entries fits one)
 constexpr uint32_t kSoloWidth = 256;                          // columns of a solo launch / of a verify workgroup
+constexpr uint32_t kCandPerBlock = 4;                         // entrant candidates kept per 256-column block (cand_top)
 
 // optional per-iteration record of the homotopy path (ss_hip_get_trace)
 struct TraceEntry {
@@ -182,7 +188,10 @@ struct Workspace {
     int32_t* slot_of = nullptr;   // [n_pad] cache slot of a column, -1 = not cached
     T* c0 = nullptr;              // [n_pad] A^T y
     T* tcand = nullptr;           // [n_pad] per-column step-length candidate of the last scan
-    uint32_t* sw_list = nullptr;  // [64] rcols[32] then drows[32] of the next lookahead sweep
+    uint32_t* sw_list = nullptr;  // [128] rcols[64] then drows[64] of the next lookahead sweep (32 or 64 columns)
+    uint32_t* sw_list2 = nullptr; // [128] the same for the fill-in sweeps of the early form (columns a solo launch used beyond the first 64)
+    uint32_t* sub_cols = nullptr; // [kSoloWidth] early form: the columns of the first solo launch (position 0 = the first pick)
+    float* subg = nullptr;        // [kSoloWidth][kSoloWidth] early form: Gs = A_S^T A_S of those columns (subgram.hip)
     LaSync* la_sync = nullptr;    // hand-off area of k_la_persist, followed by the offer slots
     T* cq_alt = nullptr;          // [2][n_pad] second (c, q) pair: k_la_persist alternates by tick parity
     // full-G mode of the single-signal engine (fp32): the context's G = A^T A serves as the cache — every
@@ -201,7 +210,7 @@ struct Workspace {
     uint32_t* solo_stage = nullptr; // [kSoloStageWords] staged hand-over of a solo launch
     uint32_t* v_max = nullptr;    // [kSoloLogCap][nvwg] per-workgroup max |c| (bits) of every logged breakpoint
     uint64_t* v_min = nullptr;    // [kSoloLogCap][nvwg] per-workgroup best step-length candidate (bits << 32 | column)
-    uint64_t* cand_top = nullptr; // [nvwg][2] per-workgroup best entrant candidates (ordered key << 32 | column)
+    uint64_t* cand_top = nullptr; // [nvwg][kCandPerBlock] per-workgroup best entrant candidates (ordered key << 32 | column)
     uint32_t nvwg = 0;            // workgroups of k_la_verify = ceil(n / kSoloWidth)
     uint64_t* la_dbg = nullptr;   // [1024][8] stage timestamps of k_la_iter (option "la_debug"), else null
     uint32_t la_nparts = 0;       // partial maxima written by the last k_la_cq launch
@@ -240,6 +249,8 @@ struct ss_hip_ctx {
     uint32_t n_pad = 0;      // padded column count (multiple of kColPad)
     void* At = nullptr;      // [n_pad][ldm] column-contiguous device copy of A
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // early form: the passes over A that run beside the solo launch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int num_cus = 256;
     size_t lds_per_block = 65536;
 
@@ -254,6 +265,9 @@ struct ss_hip_ctx {
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
     long cache_mib = 2048;   // budget of the lookahead engine's Gram-column cache
     int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns) unless the tolerance is too tight for it, 2 = lookahead always, 0 = one fused sweep per iteration
+    int early_solo = 1;        // option: 1 = early form of the speculative engine (iterations on the subset Gram matrix beside the passes over A)
+    int early_probe = 0;       // developer aid (option): 1 = early form without overlap (passes first, then the solo launch)
+    int first_sweep_cols = 32; // option: columns of the first lookahead sweep of a fp32 solve (64: one MFMA-bound pass instead of two HBM-bound ones; 32)
     int sweep32_variant = 0; // lookahead sweep tiling: 0 = 256 columns x 512 threads (1 per CU), 1 / 2 = 128 columns x 256 threads (2 / 3 per CU)
     int la_fused = 3;        // lookahead engine: 3 = speculative form of the resident kernel (one workgroup + verification of every breakpoint, solo.hip), 2 = resident kernel (k_la_persist), 1 = one kernel per iteration (k_la_iter), 0 = scan / update / cq kernels
     int solo_subset = 256;   // option (tests): columns a solo launch may hold (<= 256; small values provoke verification failures)
@@ -311,7 +325,7 @@ hipError_t launch_omp_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nsl
 template <typename T>
 hipError_t launch_la_init_pick(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, bool full_gram = false);
 template <typename T>
-hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode);
+hipError_t launch_la_top(const ss_hip_ctx* ctx, Workspace<T>& ws, int init_mode, uint32_t nsel = 32);
 template <typename T>
 hipError_t launch_la_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol);
 // one launch for everything a lookahead solve clears before its first sweep (and r = y)
@@ -342,7 +356,14 @@ hipError_t launch_la_omp_update(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol);
 // resident form (persist.hip): one launch runs iterations until the solve ends, a Gram column is
 // missing or the support outgrows `lds_cols`; returns hipErrorInvalidConfiguration if the device
 // cannot keep the whole grid resident for this n
-hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, uint32_t lds_cols);
+hipError_t launch_la_persist_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, uint32_t lds_cols, bool after_solo = false);
+// early form (solo.hip / subgram.hip): the subset of the first solo launch + the slots of the first 64 Gram columns;
+// the gate of the second stream; the slots of the columns the launch used beyond those 64
+hipError_t launch_subset_pick_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
+hipError_t launch_wait_started(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on);
+hipError_t launch_missing_cols_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
+// the barrier-free 32-column pass (one 32-column tile per single-wave workgroup) on a given stream, ungated
+hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd);
 // speculative form: k_la_persist<solo> (one workgroup on a column subset), then k_la_verify and
 // k_la_vpublish (solo.hip), which check the logged breakpoints against all columns and release or
 // revoke the outcome; launch_la_cand_init seeds the subset ranking from |c0|
@@ -350,7 +371,7 @@ hipError_t launch_la_solo_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
 hipError_t launch_la_verify_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
 hipError_t launch_la_cand_init_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
 // the columns of the next lookahead sweep from the per-block candidate tops (instead of k_la_top's scan)
-hipError_t launch_la_top_cand_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
+hipError_t launch_la_top_cand_f32(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nsel = 32);
 bool la_solo_usable(ss_hip_ctx* ctx);
 // true if k_la_persist can serve this context (column count vs resident workgroups)
 bool la_persist_usable(ss_hip_ctx* ctx, uint32_t lds_cols);
@@ -374,6 +395,14 @@ hipError_t launch_gemm_sym_f32(const ss_hip_ctx* ctx, float* G, uint32_t ldd);
 // is a no-op unless st->need_sweep is set and the solve is still running)
 hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
                                 float* D, uint32_t ldd, const DevState* st);
+
+// the same pass with 64 right-hand sides (rcols / drows hold 64 entries): the first lookahead sweep of a solve
+hipError_t launch_gemm64_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
+                                float* D, uint32_t ldd, const DevState* st);
+
+// ---- subgram.hip: Gs[256][256] = A_S^T A_S of a 256-column subset, bit for bit the lookahead sweep's values
+hipError_t launch_subset_gram_f32(const ss_hip_ctx* ctx, const uint32_t* cols_dev, float* Gs, const DevState* st,
+                                  float* seed_base, const int32_t* slot_of, uint32_t gpitch);
 
 // ---- IRLS (irls.hip) ---------------------------------------------------------------------
 struct IrlsResult {

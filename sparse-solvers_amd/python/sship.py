@@ -27,6 +27,7 @@ SYMBOLS = [
     "ss_hip_homotopy_solve_batch_f32", "ss_hip_homotopy_solve_batch_f64",
     "ss_hip_record_bytes", "ss_hip_homotopy_solve_batch_compact_f32", "ss_hip_homotopy_solve_batch_compact_f64",
     "ss_hip_gemv_t_f32", "ss_hip_gemv_t_f64", "ss_hip_gemm_t_f32", "ss_hip_gram_cols_f32", "ss_hip_gram_cols_f64",
+    "ss_hip_subset_gram_f32",
     "ss_hip_reconstruct_f32", "ss_hip_reconstruct_f64", "ss_hip_norm_l1_f32", "ss_hip_norm_l1_f64",
     "ss_hip_set_profiling", "ss_hip_get_stats", "ss_hip_reset_stats",
     "ss_hip_set_option", "ss_hip_get_option", "ss_hip_get_trace", "ss_hip_ctx_info",
@@ -61,6 +62,10 @@ class Stats(ctypes.Structure):
         ("cq_launches", ctypes.c_uint64),
         ("cq_ms", ctypes.c_double),
         ("cq_bytes", ctypes.c_uint64),
+        ("sweep64_launches", ctypes.c_uint64),
+        ("sweep64_ms", ctypes.c_double),
+        ("sweep64_flops", ctypes.c_uint64),
+        ("sweep64_bytes", ctypes.c_uint64),
     ]
 
 
@@ -115,6 +120,8 @@ def lib():
         f.restype = ctypes.c_int
         f.argtypes = [vp, vp, pd, ct, u32, vp, pd, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_double),
                       ctypes.POINTER(ctypes.c_int), cp, sz]
+    L.ss_hip_subset_gram_f32.restype = ctypes.c_int
+    L.ss_hip_subset_gram_f32.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), cp, sz]
     L.ss_hip_record_bytes.restype = sz
     L.ss_hip_record_bytes.argtypes = [u32, ctypes.c_int]
     L.ss_hip_gemm_t_f32.restype = ctypes.c_int
@@ -359,6 +366,17 @@ class Homotopy:
         err = ctypes.create_string_buffer(512)
         self._check(getattr(lib(), "ss_hip_gram_cols_" + self.suffix)(self._h, cols.ctypes.data, len(cols), G.ctypes.data, self.n,
                                                int(repeats), ctypes.byref(ms), err, len(err)), err)
+        return G, float(ms.value)
+
+    def subset_gram(self, cols, repeats=1):
+        """Gs = A_S^T A_S for exactly 256 columns (csrc/subgram.hip) -> (Gs (256, 256) float32, mean kernel ms)"""
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        if cols.shape != (256,):
+            raise ValueError("cols must hold 256 column indices")
+        G = np.empty((256, 256), dtype=np.float32)
+        ms = ctypes.c_float(0.0)
+        err = ctypes.create_string_buffer(512)
+        self._check(lib().ss_hip_subset_gram_f32(self._h, cols.ctypes.data, G.ctypes.data, int(repeats), ctypes.byref(ms), err, len(err)), err)
         return G, float(ms.value)
 
     def reconstruct(self, x):

@@ -99,3 +99,18 @@ def test_python_surface(built):
             h.solve(np.ones(3, dtype=np.float32))   # dtype of b != dtype of A
         with pytest.raises(TypeError):
             h.solve([1.0, 1.0, 1.0])                # b is noconvert
+
+
+def test_no_null_stream_memset_in_the_device_sources():
+    """Regression guard for the round-1 'iter = 1, err = 0, gamma = FLT_MIN' flake (faults): a
+    blocking-API hipMemset runs on the NULL stream, which is not ordered against the context's
+    hipStreamNonBlocking stream — a late memset zeroed y after its upload.  Every memset in the C sources
+    must be hipMemsetAsync on the context's stream."""
+    import re
+    csrc = os.path.join(ROOT, "sparse-solvers_amd", "csrc")
+    bad = []
+    for name in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r"\bhipMemset(2D|3D)?\s*\(", text):
+            bad.append("%s:%d" % (name, text.count("\n", 0, m.start()) + 1))
+    assert not bad, "blocking hipMemset on the null stream: %s" % ", ".join(bad)
