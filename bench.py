@@ -499,7 +499,11 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         if engine >= 1:
             # the 32-RHS sweep G = A^T [a_j1 .. a_j32] (HBM-bound): a solve that meets a column outside its first 64
             launches, ms_sum, nbytes = st["sweep32_launches"], st["sweep32_ms"], st["sweep32_bytes"]
-            kname = "k_gemm32_tn_f32: lookahead sweep, 32 Gram columns A^T a_j per pass over A (fp32 MFMA, HBM-bound)"
+            if h.get_option("early_solo") and h.get_option("la_fused") >= 3:
+                kname = ("k_gemm32e_tn_f32: lookahead sweep, 32 Gram columns A^T a_j per pass over A (fp32 MFMA, HBM-bound), "
+                         "timed on the second stream where it runs BESIDE the speculative iterations (one CU taken)")
+            else:
+                kname = "k_gemm32_tn_f32: lookahead sweep, 32 Gram columns A^T a_j per pass over A (fp32 MFMA, HBM-bound)"
             traffic = tj.get("gemm32_hbm_bytes_per_launch")
         else:
             launches, ms_sum, nbytes = st["sweep_launches"], st["sweep_ms"], st["sweep_bytes"]
@@ -559,7 +563,10 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             "batched": batched,
             "single_signal_with_gram_matrix": with_gram,
             "iterations_mean": float(iters.mean()),
-            "engine": ("lookahead (cached Gram columns), speculative resident iterations (one workgroup + verification of every breakpoint)" if h.get_option("la_fused") >= 3 else "lookahead (cached Gram columns), resident iteration kernel") if engine >= 1 else "one fused sweep per iteration",
+            "engine": (("lookahead (cached Gram columns), speculative iterations on the subset Gram matrix beside the passes over A "
+                        "(early form; every breakpoint verified over all columns)" if h.get_option("early_solo") else
+                        "lookahead (cached Gram columns), speculative resident iterations (one workgroup + verification of every breakpoint)")
+                       if h.get_option("la_fused") >= 3 else "lookahead (cached Gram columns), resident iteration kernel") if engine >= 1 else "one fused sweep per iteration",
             "recovered": {"signals": world * args.steps, "support_exact": recovered_total,
                           "max_rel_coef_err_rank0": coef_err},
         }

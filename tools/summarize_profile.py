@@ -23,7 +23,7 @@ def short(name):
     return name.split("(")[0]
 
 
-KERNEL_KEY = "k_gemm32_tn_f32"      # dominant kernel whose traffic is priced (argv[2] overrides)
+KERNEL_KEY = "k_gemm32e_tn_f32"     # dominant kernel whose traffic is priced (argv[2] overrides): the early form's 32-column pass
 
 
 def main():
@@ -36,7 +36,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     out = {"tag": tag}
     lines = ["# rocprofv3 summary `%s`" % tag, "",
-             "command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`", ""]
+             "command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras`", ""]
 
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     if stats:
