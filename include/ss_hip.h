@@ -289,9 +289,17 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "solo_subset"    columns beyond the support a speculative launch may hold (default 256; tests use small
  *                    values to provoke failed verifications)
  *   "sweep32_variant" tiling of the 32-RHS lookahead sweep (0 default; 1-7 measured alternatives, same results)
- *   "first_sweep_cols" 64 (default) = the first lookahead sweep of a fp32 solve fetches the entering column and the
- *                    63 largest |A^T y| in ONE pass over A (2*64*m*n flops: MFMA-bound, ~0.45 ms at 8192 x 65536)
- *                    instead of two 32-column HBM-bound passes with a round trip through the host in between; 32 = off
+ *   "first_sweep_cols" 32 (default) / 64: 64 = the first lookahead pass of a fp32 solve (plain speculative form)
+ *                    fetches the entering column and the 63 largest |A^T y| in ONE pass over A (2*64*m*n flops:
+ *                    MFMA-bound, 0.61 ms at 8192 x 65536) instead of 32; measured no faster end to end
+ *   "early_solo"     1 (default) = early form of the speculative engine (fp32, n > 16384): the first speculative
+ *                    launch iterates on the 256 x 256 Gram matrix of its column subset (csrc/subgram.hip, the
+ *                    pass's own arithmetic) while two 32-column passes over A run beside it on a second stream;
+ *                    the passes' columns are what the verification then needs.  Same results, bit for bit, as 0
+ *                    (= the passes first, then the launch)
+ *   "sweep_cols_f64" 64 (default) / 32: right-hand sides of one fp64 lookahead pass (k_gemm32_tn_f64<RH>): fp64
+ *                    passes are MFMA-bound, so 64 columns cost 1.6 x the time of 32 and a solve needs fewer passes
+ *                    and fewer round trips through the host; same results as 32
  *   "cache_mib"      memory budget of the lookahead engine's Gram-column cache (default 2048)
  *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 192: below
  *                    that, one lookahead solve per signal is faster)

@@ -598,6 +598,11 @@ typedef double v4d_t __attribute__((ext_vector_type(4)));
 constexpr int DK = 16;                       // doubles per K-step
 constexpr int DLD = DK + 2;                  // LDS row pitch in doubles (144 B, as in the fp32 kernel)
 
+// RH = 32 or 64 right-hand sides.  In double precision the 32-column pass is already close to both roofs (137
+// GFLOP against 78.6 TFLOP/s = 1.75 ms of matrix-core time inside a 3.4 ms pass); 64 columns double the flops
+// (MFMA-bound: ~3.5 ms at the peak) but not the bytes, so one wide pass costs little more than one narrow pass and
+// replaces two of them.
+template <int RH>
 __global__ __launch_bounds__(512, 1)
 void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__ rcols,
                      const uint32_t* __restrict__ drows, double* __restrict__ D,
@@ -606,7 +611,8 @@ void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__
 {
     if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
     constexpr int HN = 256, HT = 512;
-    __shared__ __attribute__((aligned(16))) double sR[2][HM][DLD];
+    constexpr int RB = RH / 16;                                 // 16-row blocks of right-hand sides (2 or 4)
+    __shared__ __attribute__((aligned(16))) double sR[2][RH][DLD];
     __shared__ __attribute__((aligned(16))) double sQ[2][HN][DLD];
 
     const uint32_t tid = threadIdx.x;
@@ -615,9 +621,9 @@ void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__
     constexpr int RPP = HT / 8;                                 // rows staged per pass (64)
     constexpr int NJ = HN / RPP;                                // passes per column tile (4)
     const uint32_t srow = tid >> 3, spair = tid & 7u;          // staging: rows srow + RPP*j, doubles 2*spair, 2*spair+1
-    const bool has_r = tid < 256;                               // R tile: 32 rows x 8 pairs
+    const bool has_r = tid < RH * 8;                            // R tile: RH rows x 8 pairs
 
-    const uint32_t rc = rcols[srow & 31u];
+    const uint32_t rc = rcols[srow % (uint32_t)RH];
     const bool rvalid = has_r && rc != 0xffffffffu;
     const double* gR = At + (size_t)(rvalid ? rc : 0u) * ldq + spair * 2;
     const v2d_t zero2 = { 0.0, 0.0 };
@@ -625,13 +631,13 @@ void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__
 
     for (uint32_t bn = blockIdx.x; bn < ntiles; bn += gridDim.x) {
         const double* gQ = At + (size_t)(bn * HN + srow) * ldq + spair * 2;
-        v4d_t acc[2][2];
+        v4d_t acc[RB][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = v4d_t{ 0.0, 0.0, 0.0, 0.0 };
 
-        v2d_t rR[3], rQ[3][NJ];
+        v2d_t rR[RH > 32 ? 2 : 3], rQ[RH > 32 ? 2 : 3][NJ];
 #define D32_LOAD(SET, KT)                                                                      \
     {                                                                                          \
         const uint32_t koff_ = (KT) * DK;                                                      \
@@ -649,14 +655,41 @@ void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__
 #define D32_COMPUTE(BUF)                                                                       \
     _Pragma("unroll") for (int g = 0; g < DK / 4; ++g) {                                       \
         const uint32_t k_ = 4u * g + kq;                                                       \
-        const double a0_ = sR[BUF][l15][k_], a1_ = sR[BUF][16 + l15][k_];                      \
         const double b0_ = sQ[BUF][wave * 32 + l15][k_], b1_ = sQ[BUF][wave * 32 + 16 + l15][k_]; \
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0_, b0_, acc[0][0], 0, 0, 0);        \
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0_, b1_, acc[0][1], 0, 0, 0);        \
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_, b0_, acc[1][0], 0, 0, 0);        \
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_, b1_, acc[1][1], 0, 0, 0);        \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                       \
+            const double a_ = sR[BUF][16 * i + l15][k_];                                       \
+            acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b0_, acc[i][0], 0, 0, 0);     \
+            acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b1_, acc[i][1], 0, 0, 0);     \
+        }                                                                                      \
     }
 
+        if (RH > 32) {
+            // 64 right-hand sides: eight accumulators of four doubles per lane leave room for a ring of TWO K-steps
+            // (three spilled 84 registers to scratch: 7.9 ms per pass)
+            D32_LOAD(0, 0u)
+            if (nk > 1) D32_LOAD(1, 1u)
+            __syncthreads();                                    // previous column tile fully consumed
+            D32_STORE(0, 0)
+            if (nk > 2) D32_LOAD(0, 2u)
+            __syncthreads();
+            uint32_t kt = 0;
+            for (; kt + 2 <= nk; kt += 2) {
+                D32_COMPUTE(0)
+                D32_STORE(1, 1)                                 // (kt + 1 < nk holds here)
+                if (kt + 3 < nk) D32_LOAD(1, kt + 3)
+                __syncthreads();
+                D32_COMPUTE(1)
+                if (kt + 2 < nk) {
+                    D32_STORE(0, 0)
+                    if (kt + 4 < nk) D32_LOAD(0, kt + 4)
+                }
+                __syncthreads();
+            }
+            if (kt < nk) {                                      // odd number of K-steps (not hit: ldm is a multiple of 256)
+                D32_COMPUTE(0)
+                __syncthreads();
+            }
+        } else {
         D32_LOAD(0, 0u)
         if (nk > 1) D32_LOAD(1, 1u)
         if (nk > 2) D32_LOAD(2, 2u)
@@ -691,12 +724,13 @@ void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__
             }
             __syncthreads();
         }
+        }
 #undef D32_LOAD
 #undef D32_STORE
 #undef D32_COMPUTE
 
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint32_t col = bn * HN + wave * 32 + 16 * j + l15;
@@ -716,7 +750,19 @@ hipError_t launch_gemm32_tn_f64(const ss_hip_ctx* ctx, const uint32_t* rcols, co
     if (ctx->n_pad % 256 != 0 || ctx->ldm % DK != 0) return hipErrorInvalidValue;
     const uint32_t ntiles = ctx->n_pad / 256;
     const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
-    hipLaunchKernelGGL(k_gemm32_tn_f64, dim3(grid), dim3(512), 0, ctx->stream, static_cast<const double*>(ctx->At),
+    hipLaunchKernelGGL(k_gemm32_tn_f64<32>, dim3(grid), dim3(512), 0, ctx->stream, static_cast<const double*>(ctx->At),
+                       rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+    return hipGetLastError();
+}
+
+// the 64-column pass in double precision (rcols / drows hold 64 entries each)
+hipError_t launch_gemm64_tn_f64(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
+                                double* D, uint32_t ldd, const DevState* st)
+{
+    if (ctx->n_pad % 256 != 0 || ctx->ldm % DK != 0) return hipErrorInvalidValue;
+    const uint32_t ntiles = ctx->n_pad / 256;
+    const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
+    hipLaunchKernelGGL(k_gemm32_tn_f64<64>, dim3(grid), dim3(512), 0, ctx->stream, static_cast<const double*>(ctx->At),
                        rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
     return hipGetLastError();
 }

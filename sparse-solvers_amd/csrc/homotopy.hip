@@ -396,8 +396,11 @@ inline hipError_t launch_top_cand(ss_hip_ctx*, Workspace<double>&, uint32_t = 32
 // the first lookahead sweep of a fp32 solve may fetch 64 Gram columns in one (MFMA-bound) pass
 inline hipError_t launch_gemm_first(const ss_hip_ctx* ctx, uint32_t nsel, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd, const DevState* st)
 { return nsel > 32 ? launch_gemm64_tn_f32(ctx, rcols, drows, D, ldd, st) : launch_gemm32_tn_f32(ctx, rcols, drows, D, ldd, st); }
-inline hipError_t launch_gemm_first(const ss_hip_ctx* ctx, uint32_t, const uint32_t* rcols, const uint32_t* drows, double* D, uint32_t ldd, const DevState* st)
-{ return launch_gemm32_tn_f64(ctx, rcols, drows, D, ldd, st); }
+inline hipError_t launch_gemm_first(const ss_hip_ctx* ctx, uint32_t nsel, const uint32_t* rcols, const uint32_t* drows, double* D, uint32_t ldd, const DevState* st)
+{ return nsel > 32 ? launch_gemm64_tn_f64(ctx, rcols, drows, D, ldd, st) : launch_gemm32_tn_f64(ctx, rcols, drows, D, ldd, st); }
+// columns of a miss sweep: 32 in fp32 (HBM-bound), option sweep_cols_f64 in double precision
+inline uint32_t miss_cols(const ss_hip_ctx*, const Workspace<float>&) { return 32u; }
+inline uint32_t miss_cols(const ss_hip_ctx* ctx, const Workspace<double>& ws) { return (ctx->sweep_cols_f64 > 32 && ws.gcap >= 192) ? 64u : 32u; }
 
 // early form of the speculative engine (fp32): the first solo launch runs on the subset Gram matrix beside the passes over A
 inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nparts, float tol, uint32_t max_iter, uint32_t lds_cols,
@@ -470,7 +473,8 @@ template <typename T> struct Lookahead {
         if (!full) {
             // the first sweep: the entering column and the largest |c0| — 64 columns in one pass (fp32; MFMA-bound,
             // ~0.45 ms at C2) instead of two 32-column passes and a round trip through the host in between
-            const uint32_t nsel = (sizeof(T) == 4 && ctx->first_sweep_cols > 32 && ctx->sweep32_variant == 0 && ws.gcap >= 128) ? 64u : 32u;
+            const uint32_t nsel = sizeof(T) == 8 ? miss_cols(ctx, ws)
+                                : ((ctx->first_sweep_cols > 32 && ctx->sweep32_variant == 0 && ws.gcap >= 128) ? 64u : 32u);
             if (solo && ctx->n > 32u * 512u) HIPCHK(launch_top_cand(ctx, ws, nsel));
             else HIPCHK(launch_la_top<T>(ctx, ws, 1, nsel));
             if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
@@ -501,19 +505,21 @@ template <typename T> struct Lookahead {
     // the scan that missed (wide dictionaries only: with few blocks the tops are too few to rank from)
     static void fetch(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool from_cand = false)
     {
+        const uint32_t nsel = miss_cols(ctx, ws);
         if (from_cand && ctx->n > 32u * 512u) HIPCHK(launch_top_cand(ctx, ws));
-        else HIPCHK(launch_la_top<T>(ctx, ws, 0));
+        else HIPCHK(launch_la_top<T>(ctx, ws, 0, nsel));
         if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
-        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_gemm_first(ctx, nsel, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, ws.st));
         if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
         HIPCHK(launch_la_update<T>(ctx, ws, 1, tol));
     }
     // OMP: the next picks are the largest correlations; the pending update is k_gramupd in OMP mode
     static void fetch_omp(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
     {
-        HIPCHK(launch_la_top<T>(ctx, ws, 2));
+        const uint32_t nsel = miss_cols(ctx, ws);
+        HIPCHK(launch_la_top<T>(ctx, ws, 2, nsel));
         if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
-        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_gemm_first(ctx, nsel, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, ws.st));
         if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
         HIPCHK(launch_la_omp_update<T>(ctx, ws, tol));
     }
@@ -524,9 +530,10 @@ template <typename T> struct Lookahead {
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
     {
         HIPCHK(launch_la_scansel<T>(ctx, ws, rnd, ws.la_nparts, tol, max_iter));
-        HIPCHK(launch_la_top<T>(ctx, ws, 0));
+        const uint32_t nsel = miss_cols(ctx, ws);
+        HIPCHK(launch_la_top<T>(ctx, ws, 0, nsel));
         if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
-        HIPCHK(launch_gemm32(ctx, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, ws.st));
+        HIPCHK(launch_gemm_first(ctx, nsel, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, ws.st));
         if (ev1) HIPCHK(hipEventRecord(ev1, ctx->stream));
         HIPCHK(launch_la_update<T>(ctx, ws, rnd, tol));
         uint32_t np2 = 0;
@@ -1753,6 +1760,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(9, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "first_sweep_cols")) { ctx->first_sweep_cols = value > 32 ? 64 : 32; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_solo"))    { ctx->early_solo = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "sweep_cols_f64")) { ctx->sweep_cols_f64 = value > 32 ? 64 : 32; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_probe"))   { ctx->early_probe = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_subset"))   { ctx->solo_subset = (int)std::max<long>(0, std::min<long>(256, value)); return SS_HIP_OK; }
@@ -1814,6 +1822,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "sweep32_variant")) { *value = ctx->sweep32_variant; return SS_HIP_OK; }
     if (!std::strcmp(key, "first_sweep_cols")) { *value = ctx->first_sweep_cols; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_solo"))    { *value = ctx->early_solo; return SS_HIP_OK; }
+    if (!std::strcmp(key, "sweep_cols_f64")) { *value = ctx->sweep_cols_f64; return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { *value = ctx->cache_mib; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_gram_min")) { *value = ctx->batch_gram_min; return SS_HIP_OK; }

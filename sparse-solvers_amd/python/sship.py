@@ -328,17 +328,20 @@ class Homotopy:
         self._check(rc, err)
         return out
 
-    def gemv_t(self, r, repeats=1):
-        """c = A^T r on the device copy -> (c, mean kernel ms)"""
+    def gemv_t(self, r, repeats=1, out=None):
+        """c = A^T r on the device copy -> (c, mean kernel ms); `out` (host array or device tensor, length n) receives c"""
         rp, shape, strides, dt, keep = _describe(r)
         if dt != self.dtype or len(shape) != 1 or shape[0] != self.m or strides[0] != 1:
             raise ValueError("r must be a contiguous length-m vector of the matrix dtype")
-        c = np.empty(self.n, dtype=self.dtype)
+        c = np.empty(self.n, dtype=self.dtype) if out is None else out
+        cp, cshape, cstrides, cdt, keepc = _describe(c)
+        if cdt != self.dtype or len(cshape) != 1 or cshape[0] != self.n or cstrides[0] != 1:
+            raise ValueError("out must be a contiguous length-n vector of the matrix dtype")
         ms = ctypes.c_float(0.0)
         err = ctypes.create_string_buffer(512)
-        _sync_producers(r)
+        _sync_producers(r, c)
         fn = getattr(lib(), "ss_hip_gemv_t_" + self.suffix)
-        self._check(fn(self._h, rp, c.ctypes.data, int(repeats), ctypes.byref(ms), err, len(err)), err)
+        self._check(fn(self._h, rp, cp, int(repeats), ctypes.byref(ms), err, len(err)), err)
         return c, float(ms.value)
 
     def gemm_t(self, R, repeats=1, out=None):
