@@ -403,6 +403,33 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         extras["omp"] = {"workload": "OMP (ss::omp<float>, parity unpinned: the reference has no OMP), the same A and signals, %d picks" % K_SPARSE,
                          "ms_per_solve": dto / args.steps * 1e3, "support_exact": oko, "signals": args.steps}
 
+    # extra (NOT `value`): a mid-size batch (64 signals sharing A, no G): lock-step in the column form — one pass
+    # over A per round forms the Gram columns of the 64 entering columns — against one solve per signal
+    if args.batch > 0 and extras is not None and h.get_option("engine") >= 1:
+        Bm = 64
+        rbm = h.record_bytes(KMAX_RECORD)
+        Ym, supm, coefm = make_batch(A, 5151 + rank, Bm, K_SPARSE, torch)
+        recm = torch.zeros((Bm, rbm), dtype=torch.uint8, device=dev)
+        mid = {}
+        keep_min = h.get_option("batch_cols_min")
+        for label, cmin in (("column_form", keep_min), ("one_solve_per_signal", 0)):
+            h.set_option("batch_cols_min", cmin)
+            h.solve_batch_compact(Ym, TOL, MAX_ITER, kmax=KMAX_RECORD, out=recm)          # allocations
+            torch.cuda.synchronize()
+            h.reset_stats()
+            tm = time.perf_counter()
+            h.solve_batch_compact(Ym, TOL, MAX_ITER, kmax=KMAX_RECORD, out=recm)
+            torch.cuda.synchronize()
+            dtm = time.perf_counter() - tm
+            okm, stuckm, cerrm, itm = check_records(recm.cpu().numpy(), supm, coefm, MAX_ITER)
+            mid[label] = {"signals_per_s": Bm / dtm, "ms": dtm * 1e3, "rounds": int(h.stats()["batch_col_rounds"]),
+                          "support_exact": okm, "max_rel_coef_err": cerrm, "iterations_max": int(itm.max())}
+        h.set_option("batch_cols_min", keep_min)
+        mid["workload"] = "64 signals sharing A (k=64, tol 1e-3, max_iter 256), compact records"
+        mid["speedup"] = mid["column_form"]["signals_per_s"] / mid["one_solve_per_signal"]["signals_per_s"]
+        extras["mid_size_batch"] = mid
+        del recm, Ym
+
     # configs[2] (NOT part of `value`): a batch of signals sharing A, solved in lock-step; compact records
     batched = None
     if args.batch > 0 and world == 1:

@@ -240,6 +240,8 @@ typedef struct ss_hip_stats {
     uint64_t sweep64_flops;        /* algorithmic flops of ONE such pass: 2 * 64 * m * n (MFMA-bound: 16x the flops per byte of A
                                       of a GEMV)                                                                                  */
     uint64_t sweep64_bytes;        /* its algorithmic bytes: m*n*s + 64*m*s + 64*n*s                                               */
+    uint64_t batch_col_rounds;     /* rounds of mid-size batches run in the column form (Gram columns of the entering columns
+                                      formed per round, 64 signals per pass over A)                                                */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------
@@ -307,7 +309,13 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "batch_gram_min" smallest lock-step batch that forms G = A^T A (n^2 fp32, 2 m n^2 flops once) and then
  *                    takes every signal's correlations from rows of G instead of two GEMMs per round
  *                    (default 512; once G exists every lock-step batch uses it; 0 = never)
- *   "gram_full_gib"  largest G the Gram forms may allocate (default 64 GiB; 0 = never form G)
+ *   "batch_cols_min" / "batch_cols_max"  fp32 batches of this many signals (default 24 .. 511) with no G at hand run
+ *                    in lock-step in the column form: per round ONE pass over A per 64 signals forms the Gram columns
+ *                    of the columns that enter (a single solve spends three passes on one signal), and correlations
+ *                    come from those cached columns as in the Gram form; smaller batches run one solve per signal;
+ *                    batch_cols_min = 0: never (batches below batch_min run one solve per signal, as in round 1)
+ *   "gram_full_gib"  largest G — and largest column cache of the column form — that may be allocated
+ *                    (default 64 GiB; 0 = never form G)
  *   "gram_full_after" opt-in (default 0 = never): single-signal solves (fp32) after which the context forms G
  *                    for them as well: with G in HBM every Gram column is at hand and a solve needs no pass over
  *                    A beyond A^T y — at the price of n^2 fp32 of HBM (17 GiB at 8192 x 65536) and one GEMM;

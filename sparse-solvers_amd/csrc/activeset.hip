@@ -554,9 +554,11 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
              uint32_t n, uint32_t gpitch, SlotDims L, T* __restrict__ c, T* __restrict__ q,
              T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx, const DevState* st)
 {
-    {   // slot = blockIdx.y (batched Gram form: one signal per slot, gcache = the full A^T A, slot_of = null)
+    {   // slot = blockIdx.y (batched Gram form: one signal per slot; gcache = the full A^T A and slot_of = null,
+        // or gcache = the batch's column cache and slot_of = one row table per slot)
         const size_t s = blockIdx.y;
         c0 += s * L.n_pad; x += s * L.n_pad; d += s * L.n_pad; c += s * L.n_pad; q += s * L.n_pad;
+        if (slot_of != nullptr) slot_of += s * L.n_pad;
         touched2 += s * 2 * L.kcap;
         pmax_val += s * L.pmax_stride; pmax_idx += s * L.pmax_stride;
         st += s;
@@ -916,6 +918,7 @@ void k_gramupd(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict_
         inv0 += s * 2 * (size_t)kcap * kcap; inv1 += s * 2 * (size_t)kcap * kcap;
         u1 += s * kcap; u2 += s * kcap; sgn += s * kcap;
         c += s * L.n_pad; q += s * L.n_pad; d += s * L.n_pad;
+        if (slot_of != nullptr) slot_of += s * L.n_pad;
         st += s;
     }
     if (st->done) return;
@@ -1718,24 +1721,67 @@ hipError_t launch_gram_guard_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, ui
 }
 
 // ---- batched Gram form: every signal slot against the full Gram matrix G = A^T A ------------------------
+// ---- column form of a mid-size batch: the entering columns of one round, compacted into the pass's lists ---------
+// One workgroup.  Slot b that is still running and has just INSERTED column idx gets a row of the batch's column
+// cache: row = row_base + b; rcols / drows are filled from entry 0 (the pass kernels skip a list whose first entry
+// is 0xffffffff, so groups of 64 beyond the live picks cost microseconds), and the slot's row table learns the row.
+constexpr uint32_t kBatchColsThreads = 512;
+__global__ __launch_bounds__(kBatchColsThreads)
+void k_batch_cols(const DevState* __restrict__ st, uint32_t nslots, uint32_t row_base, int first, uint32_t n_pad,
+                  int32_t* __restrict__ bslot, uint32_t* __restrict__ rcols, uint32_t* __restrict__ drows, uint32_t cap)
+{
+    __shared__ uint32_t s_wave[kBatchColsThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    bool live = false;
+    uint32_t idx = 0;
+    if (tid < nslots) {
+        const DevState& s = st[tid];
+        live = s.done == 0 && s.status == 0 && (first || s.added != 0);
+        idx = s.idx;
+    }
+    const uint64_t bal = __ballot(live);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+    for (uint32_t w = 0; w < kBatchColsThreads / 64; ++w) { if (w < wave) off += s_wave[w]; total += s_wave[w]; }
+    if (live) {
+        const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        rcols[pos] = idx;
+        drows[pos] = row_base + tid;
+        bslot[(size_t)tid * n_pad + idx] = (int32_t)(row_base + tid);
+    }
+    for (uint32_t i = total + tid; i < cap; i += kBatchColsThreads) { rcols[i] = 0xffffffffu; drows[i] = 0xffffffffu; }
+}
+
+hipError_t launch_batch_cols(const ss_hip_ctx* ctx, const DevState* st, uint32_t nslots, uint32_t row_base, bool first,
+                             int32_t* bslot, uint32_t* rcols, uint32_t* drows, uint32_t cap)
+{
+    if (nslots > kBatchColsThreads || cap < nslots) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_batch_cols, dim3(1), dim3(kBatchColsThreads), 0, ctx->stream, st, nslots, row_base, first ? 1 : 0,
+                       (uint32_t)ctx->n_pad, bslot, rcols, drows, cap);
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_cq_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, const T* G, uint32_t gpitch,
-                                  const T* c0b, uint32_t* nparts_out)
+                                  const T* c0b, uint32_t* nparts_out, const int32_t* bslot)
 {
     const uint32_t n = (uint32_t)ctx->n;
     const uint32_t nb = (n + kCqChunk - 1) / kCqChunk;
     if (nb > ws.dims.pmax_stride) return hipErrorInvalidValue;
     if (nparts_out) *nparts_out = nb;
-    hipLaunchKernelGGL((k_la_cq<T>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, (const int32_t*)nullptr,
+    hipLaunchKernelGGL((k_la_cq<T>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, bslot,
                        c0b, (const T*)ws.x, (const T*)ws.d, (const uint32_t*)ws.touched, n, gpitch, ws.dims, ws.c, ws.q,
                        ws.pmax_val, ws.pmax_idx, (const DevState*)ws.st);
     return hipGetLastError();
 }
 
-// scan + select, then the inverse update with u1 gathered from row idx of G, for all slots
+// scan + select, then the inverse update with u1 gathered from row idx of G, for all slots.  Column form
+// (cols != nullptr): between the two, the Gram columns of this round's entering columns are formed — one pass over
+// A per 64 live picks (launch_gemm64_tn_f32) into rows row_base + slot of the batch's column cache G.
 template <typename T>
 hipError_t launch_tail_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts,
-                                    T tol, uint32_t max_iter, const T* G, uint32_t gpitch)
+                                    T tol, uint32_t max_iter, const T* G, uint32_t gpitch, const BatchCols* cols)
 {
     const uint32_t n = (uint32_t)ctx->n;
     const uint32_t per_block = kSmallThreads * kScanPerThread;
@@ -1746,11 +1792,28 @@ hipError_t launch_tail_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uin
                        nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
                        ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,
                        (T*)nullptr, (const int32_t*)nullptr);
+    if (cols != nullptr) {
+        hipError_t e = launch_batch_cols(ctx, ws.st, nslots, cols->row_base, false, cols->bslot, cols->rcols, cols->drows, cols->cap);
+        if (e != hipSuccess) return e;
+        e = launch_batch_passes(ctx, cols, nslots);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((k_gramupd<T>), dim3(1, nslots), dim3(kUpdThreads), 0, ctx->stream,
                        static_cast<const T*>(ctx->At), ws.dims, ws.gam, ws.inv[0], ws.inv[1],
                        ws.u1, ws.u2, ws.sgn, ws.c, ws.q, ws.d, tol, ws.st, 0, (const T*)nullptr, (T*)nullptr,
-                       G, (const int32_t*)nullptr, gpitch, 0, ctx->strict_sign);
+                       G, cols != nullptr ? (const int32_t*)cols->bslot : (const int32_t*)nullptr, gpitch, 0, ctx->strict_sign);
     return hipGetLastError();
+}
+
+// the passes of one round of the column form: 64 picks per pass; a pass whose list is empty returns at once
+hipError_t launch_batch_passes(const ss_hip_ctx* ctx, const BatchCols* cols, uint32_t nslots)
+{
+    for (uint32_t g = 0; g * 64u < nslots; ++g) {
+        const hipError_t e = launch_gemm64_tn_f32(ctx, cols->rcols + g * 64u, cols->drows + g * 64u, cols->cache,
+                                                  (uint32_t)ctx->n_pad, nullptr);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 template <typename T>
@@ -1811,8 +1874,8 @@ template hipError_t launch_la_update<float>(const ss_hip_ctx*, Workspace<float>&
 template hipError_t launch_la_update<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double);
 template hipError_t launch_la_cq<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t*);
 template hipError_t launch_gram_guard_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
-template hipError_t launch_cq_gram_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, const float*, uint32_t, const float*, uint32_t*);
-template hipError_t launch_tail_gram_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, uint32_t, float, uint32_t, const float*, uint32_t);
+template hipError_t launch_cq_gram_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, const float*, uint32_t, const float*, uint32_t*, const int32_t*);
+template hipError_t launch_tail_gram_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, uint32_t, float, uint32_t, const float*, uint32_t, const BatchCols*);
 template hipError_t launch_la_cq<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t*);
 template hipError_t launch_la_iter<float>(const ss_hip_ctx*, Workspace<float>&, float, uint32_t);
 template hipError_t launch_la_omp<float>(const ss_hip_ctx*, Workspace<float>&, float, uint32_t);

@@ -1100,10 +1100,13 @@ bool ensure_full_gram(ss_hip_ctx* ctx)
 // (c = c0 - sum_j x_j G[j], q = sum_j d_j G[j]) instead of two GEMMs per round
 int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy,
                          float tol, uint32_t max_iter, float* X, ptrdiff_t x_stride, ptrdiff_t incx,
-                         uint32_t* iter_out, double* err_out, char* err, size_t errlen, bool gram = false,
+                         uint32_t* iter_out, double* err_out, char* err, size_t errlen, int form = 0,
                          void* rec_out = nullptr, uint32_t kmax = 0)
 {
+    // form: 0 = two GEMMs per round (residual form), 1 = Gram form on the full G = A^T A, 2 = column form: Gram form
+    // on a cache of the entering columns' Gram columns, formed round by round (mid-size batches, no G)
     using T = float;
+    const bool gram = form != 0, cols_form = form == 2;
     if (max_iter == 0) { set_err(err, errlen, "solve_batch: max_iterations must be > 0"); return SS_HIP_EINVAL; }
     if (!(tol >= std::numeric_limits<T>::epsilon() && tol < T(1))) {
         set_err(err, errlen, "solve_batch: tolerance must satisfy eps <= tolerance < 1");
@@ -1169,6 +1172,39 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             } else {
                 HIPCHK(launch_rp<T>(ctx, ws, Bc));
             }
+            BatchCols bc;
+            const bool cols_chunk = gram_chunk && cols_form;
+            if (cols_chunk) {
+                // one cache row per slot and round (round 0 = the first pick), a row table per slot, the pass lists
+                const size_t rows_needed = ((size_t)max_iter + 2) * Bc;
+                if (ctx->bcol_cache_rows < rows_needed) {
+                    if (ctx->bcol_cache) HIPCHK(hipFree(ctx->bcol_cache));
+                    ctx->bcol_cache = nullptr;
+                    ctx->bcol_cache_rows = 0;
+                    HIPCHK(hipMalloc(&ctx->bcol_cache, rows_needed * np * sizeof(T)));
+                    ctx->bcol_cache_rows = rows_needed;
+                }
+                if (ctx->bcol_slot_rows < Bc) {
+                    if (ctx->bcol_slot) HIPCHK(hipFree(ctx->bcol_slot));
+                    ctx->bcol_slot = nullptr;
+                    ctx->bcol_slot_rows = 0;
+                    HIPCHK(hipMalloc(&ctx->bcol_slot, (size_t)Bc * np * sizeof(int32_t)));
+                    ctx->bcol_slot_rows = Bc;
+                }
+                if (!ctx->bcol_lists) HIPCHK(hipMalloc(&ctx->bcol_lists, 2 * 1024 * sizeof(uint32_t)));
+                HIPCHK(hipMemsetAsync(ctx->bcol_slot, 0xff, (size_t)Bc * np * sizeof(int32_t), st));
+                bc.cache = ctx->bcol_cache;
+                bc.bslot = ctx->bcol_slot;
+                bc.rcols = ctx->bcol_lists;
+                bc.drows = ctx->bcol_lists + 1024;
+                bc.cap = (Bc + 63u) / 64u * 64u;
+                bc.row_base = 0;
+                HIPCHK(launch_batch_cols(ctx, ws.st, Bc, 0, true, bc.bslot, bc.rcols, bc.drows, bc.cap));
+                HIPCHK(launch_batch_passes(ctx, &bc, Bc));
+                ctx->stats.batch_col_rounds += 1;
+            }
+            const T* const Gsrc = cols_chunk ? bc.cache : ctx->gram_full;
+            const uint32_t Gpitch = cols_chunk ? (uint32_t)np : ctx->gram_pitch;
 
             const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
             volatile uint32_t* hf = ctx->host_flags;
@@ -1192,10 +1228,12 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 if (gram_chunk) {
                     const bool timed_cq = ctx->profiling != 0 && ncq < 4096;
                     if (timed_cq) HIPCHK(hipEventRecord(prof_event(ctx, 2 * ncq), st));
-                    HIPCHK(launch_cq_gram_batched<T>(ctx, ws, Bc, ctx->gram_full, ctx->gram_pitch, ctx->c0_batch, &nparts));
+                    HIPCHK(launch_cq_gram_batched<T>(ctx, ws, Bc, Gsrc, Gpitch, ctx->c0_batch, &nparts, cols_chunk ? bc.bslot : nullptr));
                     if (timed_cq) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * ncq + 1), st)); ++ncq; }
+                    bc.row_base = (uint32_t)(round * Bc);
                     HIPCHK(launch_tail_gram_batched<T>(ctx, ws, Bc, (uint32_t)round, nparts, tol, max_iter,
-                                                       ctx->gram_full, ctx->gram_pitch));
+                                                       Gsrc, Gpitch, cols_chunk ? &bc : nullptr));
+                    if (cols_chunk) ctx->stats.batch_col_rounds += 1;
                 } else {
                     HIPCHK(launch_tile_list(ctx, ws.st, Bc, rows, ws.tile_skip));
                     HIPCHK(launch_gemm_tn_f32(ctx, Rblk, rows, (uint32_t)ldm, ws.c, (uint32_t)np, ws.tile_skip));
@@ -1285,22 +1323,31 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                          double* err_out, char* err, size_t errlen, void* rec_out = nullptr, uint32_t kmax = 0)
 {
     // lock-step MFMA path once enough signals share the matrix (batch_min option, default 192)
-    if (B >= (size_t)std::max(2, ctx->batch_min)) {
-        // Gram form when G = A^T A is at hand, or the batch is large enough to pay for making it
-        // (2 m n^2 flops once, against 4 m n flops per signal and round); same tolerance guard as engine 1
-        bool gram = false;
-        if (ctx->engine >= 1 && ctx->batch_gram_min > 0 && (ctx->gram_full || B >= (size_t)ctx->batch_gram_min)) {
-            try {
-                HIPCHK(hipSetDevice(ctx->device));
-                gram = ensure_full_gram(ctx);
-            } catch (const HipFail& f) {
-                set_err(err, errlen, hip_msg(f));
-                return SS_HIP_ERUNTIME;
-            }
+    const bool lockstep = B >= (size_t)std::max(2, ctx->batch_min);
+    int form = 0;
+    // Gram form when G = A^T A is at hand, or the batch is large enough to pay for making it
+    // (2 m n^2 flops once, against 4 m n flops per signal and round); same tolerance guard as engine 1
+    if (lockstep && ctx->engine >= 1 && ctx->batch_gram_min > 0 && (ctx->gram_full || B >= (size_t)ctx->batch_gram_min)) {
+        try {
+            HIPCHK(hipSetDevice(ctx->device));
+            if (ensure_full_gram(ctx)) form = 1;
+        } catch (const HipFail& f) {
+            set_err(err, errlen, hip_msg(f));
+            return SS_HIP_ERUNTIME;
         }
-        return solve_batch_gemm_f32(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, gram,
-                                    rec_out, kmax);
     }
+    // column form for the batches in between (batch_cols_min .. batch_cols_max signals, no G): in lock-step, one pass
+    // over A per round and 64 signals forms the Gram columns of the entering columns (half the flops of the two GEMMs
+    // of form 0, and one pass serves 64 signals where a single solve spends three on one).  The cache holds one row
+    // per slot and round; a budget (option gram_full_gib) it does not fit sends the batch the old way.
+    if (form == 0 && !ctx->gram_full && ctx->engine >= 1 && ctx->batch_cols_min > 0 && B >= (size_t)std::max(2, ctx->batch_cols_min) &&
+        B <= (size_t)std::min(511, ctx->batch_cols_max) && ctx->n_pad % 256 == 0) {
+        const double bytes = ((double)max_iter + 2.0) * (double)B * (double)ctx->n_pad * 4.0;
+        if (bytes <= (double)ctx->gram_full_gib * 1073741824.0) form = 2;
+    }
+    if (lockstep || form == 2)
+        return solve_batch_gemm_f32(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, form,
+                                    rec_out, kmax);
     return solve_batch_seq<float>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
 }
 
@@ -1599,6 +1646,9 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     sship::irls_free(ctx);
     if (ctx->gram_full) (void)hipFree(ctx->gram_full);
     if (ctx->c0_batch) (void)hipFree(ctx->c0_batch);
+    if (ctx->bcol_cache) (void)hipFree(ctx->bcol_cache);
+    if (ctx->bcol_slot) (void)hipFree(ctx->bcol_slot);
+    if (ctx->bcol_lists) (void)hipFree(ctx->bcol_lists);
     if (ctx->rec_stage) (void)hipFree(ctx->rec_stage);
     if (ctx->At) (void)hipFree(ctx->At);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
@@ -1768,6 +1818,8 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "cache_mib"))     { ctx->cache_mib = std::max<long>(16, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_gram_min")) { ctx->batch_gram_min = (int)std::max<long>(0, value); return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_cols_min")) { ctx->batch_cols_min = (int)std::max<long>(0, value); return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_cols_max")) { ctx->batch_cols_max = (int)std::max<long>(0, std::min<long>(511, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_full_gib")) { ctx->gram_full_gib = std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_full_after")) { ctx->gram_full_after = std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_single"))   { ctx->gram_single = value ? 1 : 0; return SS_HIP_OK; }
@@ -1826,6 +1878,8 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "cache_mib"))     { *value = ctx->cache_mib; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_gram_min")) { *value = ctx->batch_gram_min; return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_cols_min")) { *value = ctx->batch_cols_min; return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_cols_max")) { *value = ctx->batch_cols_max; return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_full_gib")) { *value = ctx->gram_full_gib; return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_full_after")) { *value = ctx->gram_full_after; return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_single"))   { *value = ctx->gram_single; return SS_HIP_OK; }

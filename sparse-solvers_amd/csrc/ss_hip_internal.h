@@ -232,6 +232,14 @@ struct ss_hip_ctx {
     uint32_t gram_pitch = 0;
     float* c0_batch = nullptr;
     size_t c0_batch_rows = 0;
+    // column form of mid-size batches: cache of Gram columns, row tables, pass lists (grown on demand)
+    float* bcol_cache = nullptr;
+    size_t bcol_cache_rows = 0;
+    int32_t* bcol_slot = nullptr;
+    size_t bcol_slot_rows = 0;
+    uint32_t* bcol_lists = nullptr;   // rcols[1024] then drows[1024]
+    int batch_cols_min = 24;          // option: smallest fp32 batch that runs in lock-step in the column form (0 = never)
+    int batch_cols_max = 511;         // largest one (beyond: GEMM form, or G once batch_gram_min is reached)
     unsigned char* rec_stage = nullptr;   // compact output: device staging of the records of one chunk
     size_t rec_stage_bytes = 0;
     long gram_full_gib = 64;     // option: largest G the batched Gram form may allocate
@@ -343,12 +351,25 @@ hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t r
 // batched Gram form (activeset.hip): c, q of every slot from rows of the full G = A^T A; scan + inverse update
 template <typename T>
 hipError_t launch_gram_guard_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, T tol);
+// column form of a mid-size batch (no G): the Gram columns of the entering columns are formed round by round,
+// 64 per pass over A, into rows of a cache the batch owns (row = round * nslots + slot, pitch n_pad)
+struct BatchCols {
+    float* cache = nullptr;        // [rounds][nslots][n_pad]
+    int32_t* bslot = nullptr;      // [nslots][n_pad]: column -> cache row of that slot (-1 = not cached)
+    uint32_t* rcols = nullptr;     // [cap] entering columns of the round, compacted (0xffffffff = none)
+    uint32_t* drows = nullptr;     // [cap] their cache rows
+    uint32_t cap = 0;              // nslots rounded up to 64
+    uint32_t row_base = 0;         // round * nslots
+};
+hipError_t launch_batch_cols(const ss_hip_ctx* ctx, const DevState* st, uint32_t nslots, uint32_t row_base, bool first,
+                             int32_t* bslot, uint32_t* rcols, uint32_t* drows, uint32_t cap);
+hipError_t launch_batch_passes(const ss_hip_ctx* ctx, const BatchCols* cols, uint32_t nslots);
 template <typename T>
 hipError_t launch_cq_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, const T* G, uint32_t gpitch,
-                                  const T* c0b, uint32_t* nparts_out);
+                                  const T* c0b, uint32_t* nparts_out, const int32_t* bslot = nullptr);
 template <typename T>
 hipError_t launch_tail_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts,
-                                    T tol, uint32_t max_iter, const T* G, uint32_t gpitch);
+                                    T tol, uint32_t max_iter, const T* G, uint32_t gpitch, const BatchCols* cols = nullptr);
 // orthogonal matching pursuit in Gram form: one launch per iteration, and the pending update after a fetch
 template <typename T>
 hipError_t launch_la_omp(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter);

@@ -66,6 +66,7 @@ class Stats(ctypes.Structure):
         ("sweep64_ms", ctypes.c_double),
         ("sweep64_flops", ctypes.c_uint64),
         ("sweep64_bytes", ctypes.c_uint64),
+        ("batch_col_rounds", ctypes.c_uint64),
     ]
 
 

@@ -355,9 +355,10 @@ def test_batch_vs_oracle(sship, B):
     A, Y, sups = _batch_problem(500 + B, 256, 640, B, 3, 9, np.float32)   # m >> k log(n/k): well-posed recovery
     with sship.Homotopy(A) as h:
         h.set_option("batch_min", 4)
+        h.set_option("batch_cols_min", 0)            # (the column form has its own test)
         X, iters, errs = h.solve_batch(Y, 1e-3, 40)
         if B >= 4:
-            assert h.stats()["batch_rounds"] > 0
+            assert h.stats()["batch_rounds"] > 0 and h.stats()["batch_col_rounds"] == 0
         for b in range(B):
             xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 40)
             assert_parity(X[b], int(iters[b]), float(errs[b]), xo, ito, eo, np.float32)
@@ -1251,6 +1252,63 @@ def test_small_batches_run_signal_by_signal(sship):
             x1, it1, e1 = h.solve(Y[b], 1e-3, 40)
             assert it1 == iters[b] and np.array_equal(x1, X[b])
             assert np.array_equal(significant_support(X[b], 1e-3), sups[b])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("B", [24, 64, 65, 191, 300])
+def test_mid_size_batches_column_form(sship, B, mode):
+    """24 .. 511 signals with no G at hand run in lock-step in the column form: per round one 64-column pass over A
+    per 64 live picks forms the Gram columns of the entering columns, correlations come from those cached columns.
+    Against the oracle signal by signal (signals of different sparsity end in different rounds; 65 and 300 leave a
+    ragged last group), and against the one-signal path; the cache budget falls back, not fails."""
+    A, Y, sups = _batch_problem(3100 + B, 256, 1000, B, 3, 12, np.float32)
+    with sship.Homotopy(A) as h:
+        set_mode(h, mode)
+        X, iters, errs = h.solve_batch(Y, 1e-3, 48)
+        st = h.stats()
+        assert st["batch_col_rounds"] > 0 and st["gram_full_builds"] == 0
+        for b in range(0, B, max(1, B // 40)):
+            xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 48, flags=MODES[mode][1])
+            assert_parity(X[b], int(iters[b]), float(errs[b]), xo, ito, eo, np.float32)
+            assert np.array_equal(significant_support(X[b], 1e-3), sups[b])
+        x1, it1, e1 = h.solve(Y[B // 2], 1e-3, 48)
+        assert it1 == iters[B // 2] and np.abs(x1 - X[B // 2]).max() <= 1e-5 * np.abs(x1).max()
+        # same batch again, and a sub-batch: the cache rows are reused, nothing is left over from the last batch
+        sub = max(24, B // 2 + 1)
+        X2, iters2, _ = h.solve_batch(Y[:sub], 1e-3, 48)
+        assert np.array_equal(X2, X[:sub]) and np.array_equal(iters2, iters[:sub])
+        # a budget the cache does not fit: the batch runs the old way (one solve per signal below batch_min,
+        # two GEMMs per round from batch_min on), same answers to rounding
+        h.set_option("gram_full_gib", 0)
+        h.reset_stats()
+        X3, iters3, _ = h.solve_batch(Y[:24], 1e-3, 48)
+        assert h.stats()["batch_col_rounds"] == 0
+        assert np.array_equal(iters3, iters[:24]) and np.abs(X3 - X[:24]).max() <= 1e-5 * np.abs(X).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", list(MODES))
+def test_column_form_removal_paths(sship, mode):
+    """under-determined problems whose paths drop columns again (and, in reference mode, keep the residue of the
+    leaving column and may re-insert it: its cached Gram column is formed anew, the row table points at the new
+    row) — column form against the oracle"""
+    A, Y, sups = _batch_problem(77, 96, 400, 48, 6, 14, np.float32)
+    removed = 0
+    with sship.Homotopy(A) as h:
+        set_mode(h, mode)
+        X, iters, errs = h.solve_batch(Y, 1e-3, 60)
+        assert h.stats()["batch_col_rounds"] > 0
+    agree = 0
+    for b in range(48):
+        xo, ito, eo, tro = oracle.homotopy(A, Y[b], 1e-3, 60, flags=MODES[mode][1], trace=True)
+        removed += int((tro["added"][: ito + 1] == 0).sum())
+        if int(iters[b]) == ito:
+            agree += 1
+            assert np.array_equal(significant_support(X[b], 1e-3), significant_support(xo, 1e-3))
+            assert np.abs(X[b] - xo).max() <= 2e-4 * max(1.0, np.abs(xo).max())
+    assert removed >= 20
+    assert agree >= 46          # ill-conditioned fp32 paths with re-insertions may part ways on rounding (DESIGN.md §4)
 
 
 @pytest.mark.gpu
