@@ -349,6 +349,8 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
         else ensure_workspace<T>(ctx, 1, 64);
         HIPCHK(hipHostMalloc(&ctx->host_flags, 64 * sizeof(uint32_t), hipHostMallocMapped));
         std::memset(ctx->host_flags, 0, 64 * sizeof(uint32_t));
+        HIPCHK(hipHostMalloc(&ctx->hs_pinned, sizeof(DevState), hipHostMallocDefault));
+        std::memset(ctx->hs_pinned, 0, sizeof(DevState));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->dev_flags), ctx->host_flags, 0));
         HIPCHK(hipEventCreate(&ctx->ev_solve0));
         HIPCHK(hipEventCreate(&ctx->ev_solve1));
@@ -725,6 +727,18 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const bool la_omp = omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && ctx->la_fused >= 1;
         bool solo = false, solo_started = false, early = false;
         uint32_t early_lds_cols = 0;
+        // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
+        bool spec_epilogue = false, pump_enqueued = false;
+        auto enqueue_epilogue = [&]() {
+            HIPCHK(hipMemcpyAsync(ctx->hs_pinned, ws.st, sizeof(DevState), hipMemcpyDeviceToHost, st));
+            if (x) copy_out<T>(ctx, x, incx, ws.x, n);
+            if (rec_out) {
+                // compact output (a record that is superseded by a retry below is simply overwritten)
+                const unsigned char* stage = pack_records<T>(ctx, ws, 1, kmax);
+                HIPCHK(hipMemcpyAsync(rec_out, stage, record_bytes(kmax, sizeof(T)), hipMemcpyDefault, st));
+            }
+            if (prof) HIPCHK(hipEventRecord(ctx->ev_solve1, st));
+        };
         // full-G mode (fp32): G = A^T A of the context as the cache.  G exists once a large batch has run
         // on the context, or — opt-in, option gram_full_after > 0 — is made here after that many single-signal
         // solves (17 GiB and a few tenths of a second at C2 against ~0.6 ms saved per solve from then on).
@@ -787,6 +801,11 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 if (prof) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
                 early_prologue(ctx, ws, nb1, tol, max_iter, lc, e0, e1);
                 if (prof) { ctx->prof_kind.push_back(3); ++nprof; }
+                // The typical solve is complete with what is queued now: its epilogue (state, x, record) goes right
+                // behind instead of after a trip through the host (host notices `done`, three enqueues: ~70 us).
+                // Should the pump below have to queue more work, the epilogue is simply issued again at the end.
+                enqueue_epilogue();
+                spec_epilogue = true;
             } else {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (prof) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
@@ -841,6 +860,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     std::this_thread::yield();
                 }
                 if (hf[1] != 0) break;
+                pump_enqueued = true;
                 if (hf[2] != handled) {
                     const bool timed_la = prof && (timed_fetches++ % (uint32_t)std::max(1, ctx->profile_every) == 0);
                     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -921,16 +941,9 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             HIPCHK(launch_iteration_tail<T>(ctx, ws, 1, (uint32_t)round, nb, tol, max_iter));
         }
 
-        DevState hs;
-        HIPCHK(hipMemcpyAsync(&hs, ws.st, sizeof(DevState), hipMemcpyDeviceToHost, st));
-        if (x) copy_out<T>(ctx, x, incx, ws.x, n);
-        if (rec_out) {
-            // compact output (a record that is superseded by a retry below is simply overwritten)
-            const unsigned char* stage = pack_records<T>(ctx, ws, 1, kmax);
-            HIPCHK(hipMemcpyAsync(rec_out, stage, record_bytes(kmax, sizeof(T)), hipMemcpyDefault, st));
-        }
-        if (prof) HIPCHK(hipEventRecord(ctx->ev_solve1, st));
+        if (!(spec_epilogue && !pump_enqueued)) enqueue_epilogue();
         HIPCHK(hipStreamSynchronize(st));
+        const DevState hs = *static_cast<const DevState*>(ctx->hs_pinned);
 
         if (!hs.done) {
             set_err(err, errlen, "solve: internal error, device loop did not terminate");
@@ -1652,6 +1665,7 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     if (ctx->rec_stage) (void)hipFree(ctx->rec_stage);
     if (ctx->At) (void)hipFree(ctx->At);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
+    if (ctx->hs_pinned) (void)hipHostFree(ctx->hs_pinned);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_solve0) (void)hipEventDestroy(ctx->ev_solve0);
     if (ctx->ev_solve1) (void)hipEventDestroy(ctx->ev_solve1);

@@ -293,6 +293,7 @@ struct ss_hip_ctx {
     // launches executed), [1] = done, [2] = iterations waiting for a lookahead sweep so far.
     // Written by the device with system-scope stores, polled by the host loop (no copies in the stream).
     uint32_t* host_flags = nullptr;
+    void* hs_pinned = nullptr;        // pinned landing place of the end-of-solve DevState copy (sizeof(DevState))
     uint32_t* dev_flags = nullptr;    // device address of host_flags
     std::vector<hipEvent_t> prof_events;   // pairs (start, stop) for sweeps of the current solve
     std::vector<int> prof_kind;            // 2 = fused sweep, 1 = single-RHS sweep
