@@ -309,11 +309,13 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "batch_gram_min" smallest lock-step batch that forms G = A^T A (n^2 fp32, 2 m n^2 flops once) and then
  *                    takes every signal's correlations from rows of G instead of two GEMMs per round
  *                    (default 512; once G exists every lock-step batch uses it; 0 = never)
- *   "batch_cols_min" / "batch_cols_max"  fp32 batches of this many signals (default 24 .. 511) with no G at hand run
- *                    in lock-step in the column form: per round ONE pass over A per 64 signals forms the Gram columns
+ *   "batch_cols_min" / "batch_cols_max"  fp32 batches of at least batch_cols_min signals (default 24; max 0 = no upper
+ *                    limit) with no G at hand — below batch_gram_min, or G switched off or too large — run in
+ *                    lock-step in the column form: per round ONE pass over A per 64 signals forms the Gram columns
  *                    of the columns that enter (a single solve spends three passes on one signal), and correlations
- *                    come from those cached columns as in the Gram form; smaller batches run one solve per signal;
- *                    batch_cols_min = 0: never (batches below batch_min run one solve per signal, as in round 1)
+ *                    come from those cached columns as in the Gram form; chunks of at most 448 signals; smaller
+ *                    batches run one solve per signal; batch_cols_min = 0: never (round-1 behaviour: one solve per
+ *                    signal below batch_min, two GEMMs per round from there on)
  *   "gram_full_gib"  largest G — and largest column cache of the column form — that may be allocated
  *                    (default 64 GiB; 0 = never form G)
  *   "gram_full_after" opt-in (default 0 = never): single-signal solves (fp32) after which the context forms G

@@ -1130,7 +1130,8 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
         HIPCHK(hipSetDevice(ctx->device));
         const size_t m = ctx->m, n = ctx->n, ldm = ctx->ldm, np = ctx->n_pad;
         const uint32_t kcap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n, (uint64_t)max_iter + 1), kKcapLimit);
-        const size_t chunk = (size_t)std::max(4, ctx->batch_chunk);
+        // (column form: chunks of at most 448 signals = 7 full passes per round, fewer if the cache budget says so)
+        const size_t chunk = cols_form ? (size_t)std::max(1, ctx->bcol_chunk) : (size_t)std::max(4, ctx->batch_chunk);
         hipStream_t st = ctx->stream;
         std::vector<DevState> hs;
         for (size_t b0 = 0; b0 < B; b0 += chunk) {
@@ -1354,9 +1355,13 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
     // of form 0, and one pass serves 64 signals where a single solve spends three on one).  The cache holds one row
     // per slot and round; a budget (option gram_full_gib) it does not fit sends the batch the old way.
     if (form == 0 && !ctx->gram_full && ctx->engine >= 1 && ctx->batch_cols_min > 0 && B >= (size_t)std::max(2, ctx->batch_cols_min) &&
-        B <= (size_t)std::min(511, ctx->batch_cols_max) && ctx->n_pad % 256 == 0) {
-        const double bytes = ((double)max_iter + 2.0) * (double)B * (double)ctx->n_pad * 4.0;
-        if (bytes <= (double)ctx->gram_full_gib * 1073741824.0) form = 2;
+        (ctx->batch_cols_max <= 0 || B <= (size_t)ctx->batch_cols_max) && ctx->n_pad % 256 == 0) {
+        // signals per chunk: at most 448 (7 full passes per round), at most what the cache budget holds, whole passes
+        const double row_bytes = ((double)max_iter + 2.0) * (double)ctx->n_pad * 4.0;
+        const double fit = (double)ctx->gram_full_gib * 1073741824.0 / row_bytes;
+        size_t per = (size_t)std::min<double>(448.0, std::max(0.0, fit));
+        if (per >= B) per = B; else per = per / 64 * 64;
+        if (per >= 64 || (per == B && per > 0)) { form = 2; ctx->bcol_chunk = (int)std::max<size_t>(per, 1); }
     }
     if (lockstep || form == 2)
         return solve_batch_gemm_f32(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, form,
@@ -1833,7 +1838,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "batch_min"))     { ctx->batch_min = (int)std::max<long>(2, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_gram_min")) { ctx->batch_gram_min = (int)std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_cols_min")) { ctx->batch_cols_min = (int)std::max<long>(0, value); return SS_HIP_OK; }
-    if (!std::strcmp(key, "batch_cols_max")) { ctx->batch_cols_max = (int)std::max<long>(0, std::min<long>(511, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_cols_max")) { ctx->batch_cols_max = (int)std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_full_gib")) { ctx->gram_full_gib = std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_full_after")) { ctx->gram_full_after = std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_single"))   { ctx->gram_single = value ? 1 : 0; return SS_HIP_OK; }

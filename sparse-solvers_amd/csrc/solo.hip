@@ -667,7 +667,8 @@ __global__ void k_wait_started(const DevState* st)
 // columns.  The first 64 ranked columns have theirs (the two passes that ran beside the launch); the others get
 // slots here and up to two more passes fetch them (sw_list2, same layout as sw_list).  More than 64 of them, or a
 // full cache: the host re-runs the solve in the plain form (kStatusRetryPlain).
-__global__ __launch_bounds__(kSoloWidth)
+constexpr uint32_t kMissThreads = 1024;        // the walk over the log's support lists is what takes the time: 1024 threads on it
+__global__ __launch_bounds__(kMissThreads)
 void k_missing_cols(const uint32_t* __restrict__ log, const uint8_t* __restrict__ sub_pos, uint32_t n, uint32_t gcap,
                     int32_t* __restrict__ slot_of, uint32_t* __restrict__ slot_col, uint32_t* __restrict__ sw_list2,
                     DevState* st, uint32_t* hflags)
@@ -675,13 +676,14 @@ void k_missing_cols(const uint32_t* __restrict__ log, const uint8_t* __restrict_
     __shared__ uint32_t s_need[kSoloWidth];
     __shared__ uint32_t s_w[kSoloWidth / 64];
     const uint32_t tid = threadIdx.x;
-    if (tid < 2u * (uint32_t)kTcStride) sw_list2[tid] = 0xffffffffu;                // (kSoloWidth >= 128 threads)
+    const bool pos_thread = tid < kSoloWidth;                                        // threads that stand for a subset position
+    if (tid < 2u * (uint32_t)kTcStride) sw_list2[tid] = 0xffffffffu;
     if (st->done || st->solo_pending != 1u || !st->subg_active) return;
     const uint32_t nlog = st->solo_nlog;
-    s_need[tid] = 0u;
+    if (pos_thread) s_need[tid] = 0u;
     __syncthreads();
     const uint32_t* entries = log + kSoloHeaderWords;
-    for (uint32_t pr = tid; pr < nlog * kSoloListPitch; pr += kSoloWidth) {
+    for (uint32_t pr = tid; pr < nlog * kSoloListPitch; pr += kMissThreads) {
         const uint32_t k = pr / kSoloListPitch, j = pr - k * kSoloListPitch;
         const uint32_t* e = entries + (size_t)k * kSoloEntryWords;
         if (j < e[0]) s_need[e[8 + kSoloListPitch + j] & (kSoloWidth - 1u)] = 1u;   // subset position of a support column
@@ -691,11 +693,11 @@ void k_missing_cols(const uint32_t* __restrict__ log, const uint8_t* __restrict_
         }
     }
     __syncthreads();
-    const uint32_t cl = log[tid];                                                    // header: column of position tid
-    const bool miss = s_need[tid] != 0u && cl < n && slot_of[cl] < 0;
+    const uint32_t cl = pos_thread ? log[tid] : 0xffffffffu;                         // header: column of position tid
+    const bool miss = pos_thread && s_need[tid] != 0u && cl < n && slot_of[cl] < 0;
     const uint64_t bal = __ballot(miss);
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    if (lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
+    if (pos_thread && lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
     __syncthreads();
     uint32_t before = 0, total = 0;
     for (uint32_t w = 0; w < kSoloWidth / 64; ++w) { if (w < wave) before += s_w[w]; total += s_w[w]; }
@@ -738,7 +740,7 @@ hipError_t launch_wait_started(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_
 hipError_t launch_missing_cols_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
 {
     if (ws.solo_log == nullptr || ws.sw_list2 == nullptr) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(k_missing_cols, dim3(1), dim3(kSoloWidth), 0, ctx->stream, (const uint32_t*)ws.solo_log, (const uint8_t*)ws.sub_pos,
+    hipLaunchKernelGGL(k_missing_cols, dim3(1), dim3(kMissThreads), 0, ctx->stream, (const uint32_t*)ws.solo_log, (const uint8_t*)ws.sub_pos,
                        (uint32_t)ctx->n, ws.gcap, ws.slot_of, ws.slot_col, ws.sw_list2, ws.st, ctx->dev_flags);
     return hipGetLastError();
 }

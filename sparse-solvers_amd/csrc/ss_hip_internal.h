@@ -239,7 +239,9 @@ struct ss_hip_ctx {
     size_t bcol_slot_rows = 0;
     uint32_t* bcol_lists = nullptr;   // rcols[1024] then drows[1024]
     int batch_cols_min = 24;          // option: smallest fp32 batch that runs in lock-step in the column form (0 = never)
-    int batch_cols_max = 511;         // largest one (beyond: GEMM form, or G once batch_gram_min is reached)
+    int batch_cols_max = 0;           // largest one (0 = no limit: larger batches run in chunks of <= 448 signals); batches of
+                                      // batch_gram_min signals or more form G instead when that is allowed
+    int bcol_chunk = 448;             // signals per chunk of the batch being dispatched (set by the dispatcher)
     unsigned char* rec_stage = nullptr;   // compact output: device staging of the records of one chunk
     size_t rec_stage_bytes = 0;
     long gram_full_gib = 64;     // option: largest G the batched Gram form may allocate

@@ -1256,15 +1256,18 @@ def test_small_batches_run_signal_by_signal(sship):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", list(MODES))
-@pytest.mark.parametrize("B", [24, 64, 65, 191, 300])
+@pytest.mark.parametrize("B", [24, 64, 65, 191, 300, 600])
 def test_mid_size_batches_column_form(sship, B, mode):
-    """24 .. 511 signals with no G at hand run in lock-step in the column form: per round one 64-column pass over A
+    """24 signals or more with no G at hand run in lock-step in the column form: per round one 64-column pass over A
     per 64 live picks forms the Gram columns of the entering columns, correlations come from those cached columns.
     Against the oracle signal by signal (signals of different sparsity end in different rounds; 65 and 300 leave a
-    ragged last group), and against the one-signal path; the cache budget falls back, not fails."""
+    ragged last group; 600 runs as chunks of 448 + 152), and against the one-signal path; the cache budget falls
+    back, not fails."""
     A, Y, sups = _batch_problem(3100 + B, 256, 1000, B, 3, 12, np.float32)
     with sship.Homotopy(A) as h:
         set_mode(h, mode)
+        if B >= 512:
+            h.set_option("batch_gram_min", 0)       # no G (as for a dictionary whose G does not fit): chunks of 448 signals
         X, iters, errs = h.solve_batch(Y, 1e-3, 48)
         st = h.stats()
         assert st["batch_col_rounds"] > 0 and st["gram_full_builds"] == 0
