@@ -61,6 +61,31 @@ def main():
                                                             len(work), kern[n]["mean_us_working"]))
         out["kernels"] = kern
         lines.append("")
+        # timeline of one timed solve (kernel trace timestamps, us from the start of its A^T y sweep): the second
+        # hardware queue carries the passes that run beside the speculative launch
+        starts = [i for i, r in enumerate(rows) if "k_sweep" in r["Kernel_Name"]]
+        if len(starts) >= 4:
+            a = starts[len(starts) // 2]
+            t0 = int(rows[a]["Start_Timestamp"])
+            lines += ["## Timeline of one solve (us from the start of `k_sweep`; queue = hardware queue id)", "",
+                      "| start | end | queue | kernel |", "|---|---|---|---|"]
+            i = a
+            tl = []
+            while i < len(rows) and (i == a or "k_sweep" not in rows[i]["Kernel_Name"]):
+                r = rows[i]
+                tl.append(((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3, r["Queue_Id"],
+                           short(r["Kernel_Name"]).replace("sship::", "")))
+                i += 1
+            for t in sorted(tl):
+                lines.append("| %.1f | %.1f | %s | `%s` |" % t)
+            solo = [t for t in tl if "k_la_persist<true>" in t[3]]
+            pas = [t for t in tl if "k_gemm32e" in t[3]]
+            if solo and pas:
+                ov = sum(max(0.0, min(solo[0][1], q[1]) - max(solo[0][0], q[0])) for q in pas)
+                lines += ["", "The speculative launch `k_la_persist<true>` runs %.0f..%.0f us; the passes `k_gemm32e_tn_f32` on the other "
+                          "queue overlap it for %.0f us of their %.0f us." % (solo[0][0], solo[0][1], ov, sum(q[1] - q[0] for q in pas))]
+                out["overlap_us"] = ov
+            lines.append("")
 
     traffic = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
