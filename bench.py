@@ -527,7 +527,9 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             # the 32-RHS sweep G = A^T [a_j1 .. a_j32] (HBM-bound): a solve that meets a column outside its first 64
             launches, ms_sum, nbytes = st["sweep32_launches"], st["sweep32_ms"], st["sweep32_bytes"]
             if h.get_option("early_solo") and h.get_option("la_fused") >= 3:
-                kname = ("k_gemm32e_tn_f32: lookahead sweep, 32 Gram columns A^T a_j per pass over A (fp32 MFMA, HBM-bound), "
+                tiling = ("k_gemm32_tn_f32<128, 256, 3> (128-column LDS tiles, three workgroups per CU)"
+                          if h.get_option("early_pass") == 2 else "k_gemm32e_tn_f32 (one 32-column tile per single-wave workgroup)")
+                kname = (tiling + ": lookahead sweep, 32 Gram columns A^T a_j per pass over A (fp32 MFMA, HBM-bound), "
                          "timed on the second stream where it runs BESIDE the speculative iterations (one CU taken)")
             else:
                 kname = "k_gemm32_tn_f32: lookahead sweep, 32 Gram columns A^T a_j per pass over A (fp32 MFMA, HBM-bound)"

@@ -299,6 +299,10 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    pass's own arithmetic) while two 32-column passes over A run beside it on a second stream;
  *                    the passes' columns are what the verification then needs.  Same results, bit for bit, as 0
  *                    (= the passes first, then the launch)
+ *   "early_pass"     tiling of the early form's two passes: 2 (default) = 128-column LDS-staged tiles, three 256-thread
+ *                    workgroups per CU (all 512 tiles of 8192 x 65536 resident on the 255 CUs the speculative launch
+ *                    leaves: 0.49 ms per pass beside it); 0 = one 32-column tile per single-wave workgroup (0.52 ms).
+ *                    Same results bit for bit
  *   "sweep_cols_f64" 64 (default) / 32: right-hand sides of one fp64 lookahead pass (k_gemm32_tn_f64<RH>): fp64
  *                    passes are MFMA-bound, so 64 columns cost 1.6 x the time of 32 and a solve needs fewer passes
  *                    and fewer round trips through the host; same results as 32

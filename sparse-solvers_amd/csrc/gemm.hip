@@ -840,6 +840,15 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
 hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd)
 {
     if (ctx->n_pad % 32 != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
+    if (ctx->early_pass == 2 && ctx->n_pad % 128 == 0) {
+        // LDS-staged tiling with 128-column tiles, three 256-thread workgroups per CU (46 KB LDS each): 765 slots on the
+        // 255 CUs the solo launch leaves, every one of the 512 tiles of C2 resident from the start
+        const uint32_t nt = ctx->n_pad / 128;
+        const uint32_t cap = 3u * (uint32_t)ctx->num_cus;
+        hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3>), dim3(nt < cap ? nt : cap), dim3(256), 0, on, static_cast<const float*>(ctx->At),
+                           rcols, drows, D, ctx->ldm, ctx->ldm, ldd, nt, (const DevState*)nullptr);
+        return hipGetLastError();
+    }
     const uint32_t ntiles = ctx->n_pad / 32;
     hipLaunchKernelGGL((k_gemm32e_tn_f32), dim3(ntiles), dim3(64), 0, on, static_cast<const float*>(ctx->At),
                        rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, (const DevState*)nullptr);

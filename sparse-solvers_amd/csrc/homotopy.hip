@@ -446,7 +446,7 @@ template <typename T> struct Lookahead {
             HIPCHK(hipMalloc(&ws.v_max, (size_t)kSoloLogCap * ws.nvwg * sizeof(uint32_t)));
             HIPCHK(hipMalloc(&ws.v_min, (size_t)kSoloLogCap * ws.nvwg * sizeof(uint64_t)));
             HIPCHK(hipMalloc(&ws.sw_list2, 128 * sizeof(uint32_t)));
-            HIPCHK(hipMalloc(&ws.sub_cols, (size_t)kSoloWidth * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(&ws.sub_cols, 2 * (size_t)kSoloWidth * sizeof(uint32_t)));     // columns, then the progress hints (float)
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&ws.subg), (size_t)kSoloWidth * kSoloWidth * sizeof(float)));
             HIPCHK(hipMalloc(&ws.cand_top, kCandPerBlock * (size_t)ws.nvwg * sizeof(uint64_t)));
             HIPCHK(hipMemsetAsync(ws.cand_top, 0xff, kCandPerBlock * (size_t)ws.nvwg * sizeof(uint64_t), ctx->stream));
@@ -588,6 +588,9 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
         if (pe0) HIPCHK(hipEventRecord(pe0, ctx->stream2));
         HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch));
         if (pe1) HIPCHK(hipEventRecord(pe1, ctx->stream2));
+        // the second pass's 32 columns are chosen now, half a millisecond into the solo launch: what has entered
+        // its support without a Gram row so far, then the columns closest to entering (k_pick_pass_b)
+        HIPCHK(launch_pick_pass_b_f32(ctx, ws, ctx->stream2));
         HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch));
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     };
@@ -1831,6 +1834,8 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "early_solo"))    { ctx->early_solo = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep_cols_f64")) { ctx->sweep_cols_f64 = value > 32 ? 64 : 32; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_probe"))   { ctx->early_probe = (int)value; return SS_HIP_OK; }
+    if (!std::strcmp(key, "early_pass"))    { ctx->early_pass = (int)value; return SS_HIP_OK; }
+    if (!std::strcmp(key, "early_adapt"))   { ctx->early_adapt = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_subset"))   { ctx->solo_subset = (int)std::max<long>(0, std::min<long>(256, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_full_gram")) { ctx->solo_full_gram = value ? 1 : 0; return SS_HIP_OK; }
@@ -1893,6 +1898,8 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "sweep32_variant")) { *value = ctx->sweep32_variant; return SS_HIP_OK; }
     if (!std::strcmp(key, "first_sweep_cols")) { *value = ctx->first_sweep_cols; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_solo"))    { *value = ctx->early_solo; return SS_HIP_OK; }
+    if (!std::strcmp(key, "early_pass"))    { *value = ctx->early_pass; return SS_HIP_OK; }
+    if (!std::strcmp(key, "early_adapt"))   { *value = ctx->early_adapt; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep_cols_f64")) { *value = ctx->sweep_cols_f64; return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { *value = ctx->cache_mib; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }

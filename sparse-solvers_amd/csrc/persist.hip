@@ -210,6 +210,8 @@ struct SoloArgs {
     // columns (subgram.hip) instead of cache rows — Gram "row" and "column" are subset positions there
     const float* subg;          // [kSoloWidth][kSoloWidth], null = never
     const uint32_t* sub_cols;   // [kSoloWidth] the columns of that subset (position 0 = the first pick)
+    float* prog;                // [kSoloWidth] progress for k_pick_pass_b: per subset position, -1 = in the support,
+                                // else this breakpoint's step-length candidate (how soon the column would enter)
 };
 
 template <bool SOLO>
@@ -748,6 +750,11 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
             mk[k] = m;
             if (m < Lim<float>::max() && better_min(m, col[k], best, best_i)) { best = m; best_i = col[k]; }
         }
+        if (SOLO && subg && sa.prog != nullptr && tid < kSoloWidth && in[0])
+            // early form: the second pass over A picks its columns while this launch runs (k_pick_pass_b, another
+            // stream): columns that have entered, then those closest to entering.  A hint, not a hand-over: plain
+            // write-through stores, no ordering, nothing in this launch depends on them
+            __hip_atomic_store(&sa.prog[tid], act[0] ? -1.f : mk[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (SOLO) {
             // the support's own candidates, -x_j / d_j (homotopy-cpu.cpp:128-135): reduced per wave here, the
             // per-wave results ride on the barriers of the block reduction below
@@ -1288,6 +1295,7 @@ hipError_t launch_la_solo_f32(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     sa.stage = ws.solo_stage;
     sa.subg = ws.subg;
     sa.sub_cols = ws.sub_cols;
+    sa.prog = (ws.sub_cols != nullptr && ctx->early_adapt) ? reinterpret_cast<float*>(ws.sub_cols + kSoloWidth) : nullptr;
     hipLaunchKernelGGL(k_la_persist<true>, dim3(1), dim3(kPsThreads), lds, ctx->stream, tol, max_iter, (uint32_t)ctx->n, P, kSoloGlRows, ws.gram_is_full ? 1 : 0,
                        (const float*)ws.gcache, (const int32_t*)ws.slot_of, (const float*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.cq_alt, ws.cq_alt + ctx->n_pad, ws.x, ws.d, ws.insup, ws.gam, ws.inv[0], ws.inv[1], ws.tcand, ws.dims, ws.st,

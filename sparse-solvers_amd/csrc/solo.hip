@@ -603,6 +603,8 @@ void k_subset_pick(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32
                    uint32_t* __restrict__ sw_list, uint32_t* __restrict__ sub_cols, DevState* st,
                    uint32_t* __restrict__ slot_col, uint32_t subset_cap /* option solo_subset: columns beyond the support */)
 {
+    // (the progress hints of the solo launch that follows, one per subset position: nothing known yet)
+    if (threadIdx.x < kSoloWidth) reinterpret_cast<float*>(sub_cols + kSoloWidth)[threadIdx.x] = Lim<float>::max();
     __shared__ __attribute__((aligned(16))) uint64_t s_of[kTcThreads];
     if (st->done) return;
     const uint32_t tid = threadIdx.x;
@@ -628,17 +630,18 @@ void k_subset_pick(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32
     }
     uint32_t nsub = total < kSoloWidth - 1u ? total : kSoloWidth - 1u;             // subset positions 1 .. nsub
     if (nsub > subset_cap) nsub = subset_cap;
-    const uint32_t nslot = total < 63u ? total : 63u;                              // cache slots 1 .. nslot
-    if (o1 != ~0ull && r1 < nsub) {
+    const uint32_t nslot = total < 63u ? total : 63u;                              // cache slots 1 .. nslot are set aside:
+    const uint32_t nfirst = nslot < 31u ? nslot : 31u;                             // 1 .. nfirst for the first pass (given here),
+    if (o1 != ~0ull && r1 < nsub) {                                                // 32 .. nslot for the second (k_pick_pass_b)
         const uint32_t cl = (uint32_t)o1;
         sub_cols[1u + r1] = cl;
-        if (r1 < nslot) {
+        if (r1 < nfirst) {
             sw_list[1u + r1] = cl; sw_list[kTcStride + 1u + r1] = 1u + r1; slot_of[cl] = (int32_t)(1u + r1);
             if (slot_col != nullptr) slot_col[1u + r1] = cl;
         }
     }
     if (tid >= 1u + nsub && tid < kSoloWidth) sub_cols[tid] = 0xffffffffu;
-    if (tid >= 1u + nslot && tid < (uint32_t)kTcStride) { sw_list[tid] = 0xffffffffu; sw_list[kTcStride + tid] = 0xffffffffu; }
+    if (tid >= 1u + nfirst && tid < (uint32_t)kTcStride) { sw_list[tid] = 0xffffffffu; sw_list[kTcStride + tid] = 0xffffffffu; }
     if (tid == 0) {
         sub_cols[0] = idx;
         sw_list[0] = idx; sw_list[kTcStride] = 0u; slot_of[idx] = 0;
@@ -646,6 +649,47 @@ void k_subset_pick(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32
         st->cache_used = 1u + nslot;
         st->nsweeps += nslot >= 32u ? 2u : 1u;
         st->subg_active = 1;
+    }
+}
+
+// The second pass's columns (second stream, between the two passes; the solo launch is half a millisecond old):
+// of the subset's columns that have no Gram row yet, first those that ENTERED the launch's support so far — the
+// verification will need their rows whatever happens — then the ones closest to entering by the launch's latest
+// step-length candidates, then by |c0| rank (= subset position).  The hints are read while the launch writes them:
+// a stale or torn view only changes which columns are fetched, never a result — whatever is still missing afterwards
+// is found by k_missing_cols.  adapt = 0: by |c0| rank alone (positions 32..63, the round-2 first version).
+__global__ __launch_bounds__(kSoloWidth)
+void k_pick_pass_b(const uint32_t* __restrict__ sub_cols, uint32_t n, int32_t* __restrict__ slot_of,
+                   uint32_t* __restrict__ slot_col, uint32_t* __restrict__ sw_list, const DevState* __restrict__ st, int adapt)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t s_key[kSoloWidth];
+    if (st->done) return;                                   // (the lists' second halves are empty since k_subset_pick)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cl = sub_cols[tid];
+    const float* prog = reinterpret_cast<const float*>(sub_cols + kSoloWidth);
+    uint64_t key = ~0ull;
+    if (cl < n && slot_of[cl] < 0) {
+        float p = adapt ? __hip_atomic_load(&prog[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : Lim<float>::max();
+        if (!(p == p) || p > Lim<float>::max()) p = Lim<float>::max();
+        const float k = p < 0.f ? 0.f : p;                  // entered: first of all
+        key = ((uint64_t)__float_as_uint(k) << 32) | (uint64_t)tid;
+    }
+    s_key[tid] = key;
+    __syncthreads();
+    uint32_t r = 0;
+    if (key != ~0ull) {
+        const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(s_key);
+#pragma unroll 8
+        for (uint32_t u = 0; u < kSoloWidth / 2; ++u) {
+            const ulonglong2 v = p2[u];
+            r += v.x < key ? 1u : 0u;
+            r += v.y < key ? 1u : 0u;
+        }
+        if (r < 32u) {
+            const uint32_t sl = 32u + r;                    // slots 32..63 were set aside by k_subset_pick
+            sw_list[32u + r] = cl; sw_list[kTcStride + 32u + r] = sl; slot_of[cl] = (int32_t)sl;
+            if (slot_col != nullptr) slot_col[sl] = cl;
+        }
     }
 }
 
@@ -727,6 +771,14 @@ hipError_t launch_subset_pick_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
     hipLaunchKernelGGL(k_subset_pick, dim3(1), dim3(kTcThreads), 0, ctx->stream, (const uint64_t*)ws.cand_top, kCandPerBlock * ws.nvwg,
                        (uint32_t)ctx->n, ws.slot_of, ws.sw_list, ws.sub_cols, ws.st, ws.slot_col,
                        (uint32_t)std::max(0, std::min(ctx->solo_subset, (int)kSoloWidth)));
+    return hipGetLastError();
+}
+
+hipError_t launch_pick_pass_b_f32(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on)
+{
+    if (ws.sub_cols == nullptr || ws.sw_list == nullptr) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_pick_pass_b, dim3(1), dim3(kSoloWidth), 0, on, (const uint32_t*)ws.sub_cols, (uint32_t)ctx->n, ws.slot_of,
+                       ws.slot_col, ws.sw_list, (const DevState*)ws.st, ctx->early_adapt);
     return hipGetLastError();
 }
 

@@ -238,6 +238,8 @@ struct ss_hip_ctx {
     int32_t* bcol_slot = nullptr;
     size_t bcol_slot_rows = 0;
     uint32_t* bcol_lists = nullptr;   // rcols[1024] then drows[1024]
+    int early_pass = 2;               // option: tiling of the early form's passes (2 = 128-column LDS tiles, 3 workgroups per CU; 0 = k_gemm32e)
+    int early_adapt = 1;              // option: the early form's second pass takes its columns from the solo launch's progress (0 = from |c0|)
     int batch_cols_min = 24;          // option: smallest fp32 batch that runs in lock-step in the column form (0 = never)
     int batch_cols_max = 0;           // largest one (0 = no limit: larger batches run in chunks of <= 448 signals); batches of
                                       // batch_gram_min signals or more form G instead when that is allowed
@@ -388,6 +390,7 @@ hipError_t launch_subset_pick_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
 hipError_t launch_wait_started(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on);
 hipError_t launch_missing_cols_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
 // the barrier-free 32-column pass (one 32-column tile per single-wave workgroup) on a given stream, ungated
+hipError_t launch_pick_pass_b_f32(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on);
 hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd);
 // speculative form: k_la_persist<solo> (one workgroup on a column subset), then k_la_verify and
 // k_la_vpublish (solo.hip), which check the logged breakpoints against all columns and release or

@@ -11,7 +11,7 @@ A = np.random.default_rng(1234).standard_normal((M, N), dtype=np.float32)
 A /= np.float32(np.sqrt(M))
 Ad = torch.from_numpy(A).to("cuda:0")
 sigs = []
-for s in range(12):
+for s in range(42):
     rng = np.random.default_rng(1235 + s)
     sup = np.sort(rng.choice(N, K, replace=False))
     coef = 1.0 + np.abs(rng.standard_normal(K))
@@ -19,8 +19,11 @@ for s in range(12):
     sigs.append(y)
 x = torch.zeros(N, device="cuda:0")
 with sship.Homotopy(Ad) as h:
-    for name, opts in (("plain", {"early_solo": 0}), ("early", {"early_solo": 1, "early_probe": 0}),
-                       ("early, no overlap", {"early_solo": 1, "early_probe": 1})):
+    for name, opts in (("plain", {"early_solo": 0}),
+                       ("early e-kernel |c0|", {"early_solo": 1, "early_probe": 0, "early_pass": 0, "early_adapt": 0}),
+                       ("early LDSx3 |c0|", {"early_solo": 1, "early_probe": 0, "early_pass": 2, "early_adapt": 0}),
+                       ("early LDSx3 adaptive", {"early_solo": 1, "early_probe": 0, "early_pass": 2, "early_adapt": 1}),
+                       ("early, no overlap", {"early_solo": 1, "early_probe": 1, "early_pass": 2, "early_adapt": 1})):
         for k_, v_ in opts.items():
             h.set_option(k_, v_)
         for prof in (0, 1):
@@ -34,6 +37,6 @@ with sship.Homotopy(Ad) as h:
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / len(sigs[2:])
             st = h.stats()
-            print("%-18s profiling %d: %.3f ms/solve, sweeps/solve %.2f, timed 32-col pass %.3f ms (%d), A^T y %.3f ms, solo retries %d" % (
+            print("%-20s profiling %d: %.3f ms/solve, sweeps/solve %.2f, timed 32-col pass %.3f ms (%d), A^T y %.3f ms, solo retries %d" % (
                 name, prof, dt * 1e3, st["lookahead_sweeps"] / st["solves"], st["sweep32_ms"] / max(1, st["sweep32_launches"]),
                 st["sweep32_launches"], st["sweep1_ms"] / max(1, st["sweep1_launches"]), st["solo_retries"]))

@@ -23,7 +23,7 @@ def short(name):
     return name.split("(")[0]
 
 
-KERNEL_KEY = "k_gemm32e_tn_f32"     # dominant kernel whose traffic is priced (argv[2] overrides): the early form's 32-column pass
+KERNEL_KEY = "k_gemm32_tn_f32<128, 256, 3"     # dominant kernel whose traffic is priced (argv[2] overrides): the early form's 32-column pass
 
 
 def main():
@@ -79,10 +79,10 @@ def main():
             for t in sorted(tl):
                 lines.append("| %.1f | %.1f | %s | `%s` |" % t)
             solo = [t for t in tl if "k_la_persist<true>" in t[3]]
-            pas = [t for t in tl if "k_gemm32e" in t[3]]
+            pas = [t for t in tl if "k_gemm32" in t[3] and solo and t[2] != solo[0][2]]
             if solo and pas:
                 ov = sum(max(0.0, min(solo[0][1], q[1]) - max(solo[0][0], q[0])) for q in pas)
-                lines += ["", "The speculative launch `k_la_persist<true>` runs %.0f..%.0f us; the passes `k_gemm32e_tn_f32` on the other "
+                lines += ["", "The speculative launch `k_la_persist<true>` runs %.0f..%.0f us; the 32-column passes on the other "
                           "queue overlap it for %.0f us of their %.0f us." % (solo[0][0], solo[0][1], ov, sum(q[1] - q[0] for q in pas))]
                 out["overlap_us"] = ov
             lines.append("")
