@@ -303,6 +303,10 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    workgroups per CU (all 512 tiles of 8192 x 65536 resident on the 255 CUs the speculative launch
  *                    leaves: 0.49 ms per pass beside it); 0 = one 32-column tile per single-wave workgroup (0.52 ms).
  *                    Same results bit for bit
+ *   "early_adapt"    1 (default) = the early form's second pass takes its 32 columns from the speculative launch's
+ *                    progress when the first pass has finished (columns that have entered its support, then those
+ *                    closest to entering); 0 = from the |c0| ranking.  Decides which Gram columns are fetched when,
+ *                    never a result
  *   "sweep_cols_f64" 64 (default) / 32: right-hand sides of one fp64 lookahead pass (k_gemm32_tn_f64<RH>): fp64
  *                    passes are MFMA-bound, so 64 columns cost 1.6 x the time of 32 and a solve needs fewer passes
  *                    and fewer round trips through the host; same results as 32

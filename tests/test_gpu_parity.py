@@ -1136,6 +1136,23 @@ def test_early_form_matches_plain_form(sship, shape):
         assert ita == itb and ea == eb and np.array_equal(xa, xb)
         assert np.array_equal(ta["idx"], tb["idx"]) and np.array_equal(ta["added"], tb["added"])
         assert np.array_equal(ta["gamma"], tb["gamma"]) and np.array_equal(ta["c_inf"], tb["c_inf"])
+        # the switches of the early form — tiling of the two passes (128-column LDS tiles / single-wave tiles), second
+        # pass chosen from the launch's progress or from |c0| — decide which Gram columns are fetched when, never a bit
+        # of the result; the adaptive choice must not cost passes
+        h.set_option("early_solo", 1)
+        sweeps = {}
+        for early_pass, adapt in ((2, 1), (0, 1), (2, 0), (0, 0)):
+            h.set_option("early_pass", early_pass)
+            h.set_option("early_adapt", adapt)
+            h.reset_stats()
+            x, it, e = h.solve(y, 1e-3, 2 * k + 8)
+            assert it == ita and e == ea and np.array_equal(x, xa), (early_pass, adapt)
+            tr = h.trace()
+            assert np.array_equal(tr["gamma"], ta["gamma"]) and np.array_equal(tr["idx"], ta["idx"])
+            sweeps[(early_pass, adapt)] = h.stats()["lookahead_sweeps"]
+        assert sweeps[(2, 1)] <= sweeps[(2, 0)] and sweeps[(0, 1)] <= sweeps[(0, 0)]
+        h.set_option("early_pass", 2)
+        h.set_option("early_adapt", 1)
         # subsets too small to hold the path: failed checks, replays and the resident form — same answer
         for subset in (12, 3):
             h.set_option("solo_subset", subset)
