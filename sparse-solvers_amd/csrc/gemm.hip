@@ -602,15 +602,18 @@ constexpr int DLD = DK + 2;                  // LDS row pitch in doubles (144 B,
 // GFLOP against 78.6 TFLOP/s = 1.75 ms of matrix-core time inside a 3.4 ms pass); 64 columns double the flops
 // (MFMA-bound: ~3.5 ms at the peak) but not the bytes, so one wide pass costs little more than one narrow pass and
 // replaces two of them.
-template <int RH>
-__global__ __launch_bounds__(512, 1)
+// HN / HT / BPC: 256 columns per 512-thread workgroup, one per CU (default), or 128 columns per 256-thread workgroup,
+// two or three per CU — one workgroup's barrier waits are then another's MFMAs (SQ counters, DESIGN.md §3.9: with one
+// workgroup per CU a third of the wave cycles of the 32-column pass are parked at the barrier).
+template <int RH, int HN = 256, int HT = 512, int BPC = 1>
+__global__ __launch_bounds__(HT, BPC)
 void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__ rcols,
                      const uint32_t* __restrict__ drows, double* __restrict__ D,
                      uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
                      const DevState* __restrict__ st)
 {
     if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
-    constexpr int HN = 256, HT = 512;
+    static_assert(HN / 32 == HT / 64 && RH * 8 <= HT, "one 32-column block per wave; the R tile is staged in one pass");
     constexpr int RB = RH / 16;                                 // 16-row blocks of right-hand sides (2 or 4)
     __shared__ __attribute__((aligned(16))) double sR[2][RH][DLD];
     __shared__ __attribute__((aligned(16))) double sQ[2][HN][DLD];
@@ -748,6 +751,19 @@ hipError_t launch_gemm32_tn_f64(const ss_hip_ctx* ctx, const uint32_t* rcols, co
                                 double* D, uint32_t ldd, const DevState* st)
 {
     if (ctx->n_pad % 256 != 0 || ctx->ldm % DK != 0) return hipErrorInvalidValue;
+    if (ctx->sweep_f64_variant == 1 || ctx->sweep_f64_variant == 2) {
+        // 128-column tiles, 256 threads, two or three workgroups per CU
+        const uint32_t nt = ctx->n_pad / 128;
+        const uint32_t cap = (ctx->sweep_f64_variant == 1 ? 2u : 3u) * (uint32_t)ctx->num_cus;
+        const uint32_t g = nt < cap ? nt : cap;
+        if (ctx->sweep_f64_variant == 1)
+            hipLaunchKernelGGL((k_gemm32_tn_f64<32, 128, 256, 2>), dim3(g), dim3(256), 0, ctx->stream, static_cast<const double*>(ctx->At),
+                               rcols, drows, D, ctx->ldm, ctx->ldm, ldd, nt, st);
+        else
+            hipLaunchKernelGGL((k_gemm32_tn_f64<32, 128, 256, 3>), dim3(g), dim3(256), 0, ctx->stream, static_cast<const double*>(ctx->At),
+                               rcols, drows, D, ctx->ldm, ctx->ldm, ldd, nt, st);
+        return hipGetLastError();
+    }
     const uint32_t ntiles = ctx->n_pad / 256;
     const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
     hipLaunchKernelGGL(k_gemm32_tn_f64<32>, dim3(grid), dim3(512), 0, ctx->stream, static_cast<const double*>(ctx->At),

@@ -1836,6 +1836,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "early_probe"))   { ctx->early_probe = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_pass"))    { ctx->early_pass = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_adapt"))   { ctx->early_adapt = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "sweep_f64_variant")) { ctx->sweep_f64_variant = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_subset"))   { ctx->solo_subset = (int)std::max<long>(0, std::min<long>(256, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_full_gram")) { ctx->solo_full_gram = value ? 1 : 0; return SS_HIP_OK; }

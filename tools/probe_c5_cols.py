@@ -16,8 +16,10 @@ del A5
 torch.cuda.empty_cache()
 x = torch.zeros(n5, device="cuda:0", dtype=torch.float64)
 res = {}
-for cols in (32, 64):
+for cols, variant in ((32, 0), (32, 1), (32, 2), (64, 0)):
     h.set_option("sweep_cols_f64", cols)
+    h.set_option("sweep_f64_variant", variant)
+    h.set_profiling(True)
     h.solve(y, 1e-9, 512, out=x)
     h.reset_stats()
     torch.cuda.synchronize()
@@ -28,7 +30,7 @@ for cols in (32, 64):
     dt = (time.perf_counter() - t) / 3
     st = h.stats()
     xs = x.cpu().numpy()
-    res[cols] = xs.copy()
-    print("sweep cols", cols, "ms/solve %.2f" % (dt * 1e3), "iters", it, "sweeps/solve", st["lookahead_sweeps"] / st["solves"],
+    res[(cols, variant)] = xs.copy()
+    print("sweep cols", cols, "variant", variant, "pass ms %.3f" % (st["sweep32_ms"] / max(1, st["sweep32_launches"])), "ms/solve %.2f" % (dt * 1e3), "iters", it, "sweeps/solve", st["lookahead_sweeps"] / st["solves"],
           "support ok", np.array_equal(np.nonzero(xs)[0], sup), "coef err", np.abs(xs[sup] - coef).max() / coef.max())
-print("bitwise equal 32 vs 64:", np.array_equal(res[32], res[64]))
+print("bitwise equal across tilings:", all(np.array_equal(res[(32, 0)], v) for v in res.values()))
