@@ -1010,7 +1010,10 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             // resident form; contexts whose problems do that on most solves stop speculating for a while.
             ctx->stats.solo_solves += 1;
             ctx->stats.solo_retries += hs.solo_fails;
-            if (ctx->stats.solo_solves >= 8 && 2 * ctx->stats.solo_retries > ctx->stats.solo_solves) ctx->solo_off_solves = 64;
+            // (private counters: the decision must not depend on whether the caller reset the statistics)
+            ctx->solo_seen += 1;
+            ctx->solo_failed += hs.solo_fails;
+            if (ctx->solo_seen >= 8 && 2 * ctx->solo_failed > ctx->solo_seen) ctx->solo_off_solves = 64;
             const char* path = hs.solo_fails ? std::getenv("SS_HIP_SOLO_DEBUG") : nullptr;
             if (path != nullptr) {
                 // developer aid: the log and the verification partials of the last solo launch

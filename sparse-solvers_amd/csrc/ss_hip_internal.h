@@ -240,6 +240,7 @@ struct ss_hip_ctx {
     uint32_t* bcol_lists = nullptr;   // rcols[1024] then drows[1024]
     int early_pass = 2;               // option: tiling of the early form's passes (2 = 128-column LDS tiles, 3 workgroups per CU; 0 = k_gemm32e)
     int sweep_f64_variant = 0;        // option: tiling of the 32-column fp64 pass (0 = 256 columns / 512 threads / 1 per CU; 1, 2 = 128 / 256 / 2, 3 per CU)
+    uint64_t solo_seen = 0, solo_failed = 0;   // speculative solves / failed checks since the form was last switched off (private: not the statistics)
     int early_adapt = 1;              // option: the early form's second pass takes its columns from the solo launch's progress (0 = from |c0|)
     int batch_cols_min = 24;          // option: smallest fp32 batch that runs in lock-step in the column form (0 = never)
     int batch_cols_max = 0;           // largest one (0 = no limit: larger batches run in chunks of <= 448 signals); batches of

@@ -11,7 +11,7 @@ bad = fails = solo = 0
 t0 = time.time()
 for case in range(ncase):
     m = int(rng.choice([16, 40, 64, 128, 300, 700, 1500]))
-    n = int(rng.choice([64, 200, 700, 3000, 20000, 70000]))
+    n = int(rng.choice([64, 700, 3000, 20000, 20000, 33000, 70000, 70000]))
     k = int(rng.integers(1, max(2, min(m // 2, 90))))
     A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(np.float32)
     x0 = np.zeros(n, np.float32)
@@ -26,6 +26,10 @@ for case in range(ncase):
         x2, it2, e2 = h.solve(y, tol, max_iter); t2 = h.trace()
         h.set_option("la_fused", 3)
         h.set_option("solo_subset", int(rng.choice([256, 256, 256, 60, 10])))
+        # (n > 16384: the early form; its switches decide which Gram columns are fetched when, never a result)
+        h.set_option("early_solo", int(rng.choice([1, 1, 1, 0])))
+        h.set_option("early_pass", int(rng.choice([2, 2, 0])))
+        h.set_option("early_adapt", int(rng.choice([1, 1, 0])))
         h.reset_stats()
         x3, it3, e3 = h.solve(y, tol, max_iter); t3 = h.trace()
         x3b, it3b, e3b = h.solve(y, tol, max_iter)           # and again on the same context
