@@ -594,7 +594,8 @@ def test_full_size_vs_oracle(sship, c2_host_matrix):
 
 def test_batch_full_size(sship, c2_host_matrix):
     """configs[2] at full size: B = 4096 signals sharing the 8192 x 65536 fp32 matrix, lock-step, in Gram
-    form (rows of G = A^T A) and in GEMM form (two MFMA GEMMs per round).  Every signal's support must be
+    form (rows of G = A^T A) and in GEMM form (two MFMA GEMMs per round); before that, 128 of them as a mid-size
+    batch in the column form (two signals against the oracle).  Every signal's support must be
     the planted one (the property check); 16 sampled signals are compared with the oracle (iterations,
     support, coefficients within 1e-5).  With the shipped defaults a signal that hits an exact tie runs to
     max_iter like the reference's would (homotopy-cpu.cpp:143-153: strict t > 0) — at most a handful of 4096,
@@ -622,6 +623,23 @@ def test_batch_full_size(sship, c2_host_matrix):
         del Ad
         torch.cuda.empty_cache()
         results = {}
+        # before G exists: the first 128 signals as a mid-size batch — lock-step in the column form
+        Bc = 128
+        _, itc, erc = h.solve_batch(Y[:Bc], 1e-3, 256, out=X[:Bc])
+        torch.cuda.synchronize()
+        stc = h.stats()
+        assert stc["batch_col_rounds"] > 0 and stc["gram_full_builds"] == 0
+        nzc = (X[:Bc] != 0)
+        supc = torch.from_numpy(sups[:Bc]).to("cuda:0")
+        goodc = (torch.gather(nzc, 1, supc).all(1) & (nzc.sum(1) == k)).cpu().numpy()
+        stuckc = itc >= 256
+        assert goodc[~stuckc].all() and stuckc.sum() <= 2
+        valsc = torch.gather(X[:Bc], 1, supc).cpu().numpy()
+        assert (np.abs(valsc - coefs[:Bc]).max(1) / coefs[:Bc].max(1))[~stuckc].max() <= 1e-4
+        for b in (3, 77):
+            if not stuckc[b]:
+                xo, ito, eo = oracle.homotopy(A, Yh[b], 1e-3, 256)
+                assert_parity(X[b].cpu().numpy(), int(itc[b]), float(erc[b]), xo, ito, eo, np.float32)
         for form in ("gram", "gemm", "gram+tie_guard"):
             if form == "gemm":
                 h.set_option("batch_gram_min", 0)
