@@ -310,6 +310,9 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "sweep_cols_f64" 64 (default) / 32: right-hand sides of one fp64 lookahead pass (k_gemm32_tn_f64<RH>): fp64
  *                    passes are MFMA-bound, so 64 columns cost 1.6 x the time of 32 and a solve needs fewer passes
  *                    and fewer round trips through the host; same results as 32
+ *   "sweep_cols_f64_late" 32 (default) / 64: the same for the third and later passes of a solve — misses that late on
+ *                    the path are sparse (16384 x 131072, k = 128: the third pass serves the last ~8 iterations), a
+ *                    narrow pass (3.4 ms against 5.4) covers them; same results
  *   "cache_mib"      memory budget of the lookahead engine's Gram-column cache (default 2048)
  *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 192: below
  *                    that, one lookahead solve per signal is faster)

@@ -401,8 +401,14 @@ inline hipError_t launch_gemm_first(const ss_hip_ctx* ctx, uint32_t nsel, const 
 inline hipError_t launch_gemm_first(const ss_hip_ctx* ctx, uint32_t nsel, const uint32_t* rcols, const uint32_t* drows, double* D, uint32_t ldd, const DevState* st)
 { return nsel > 32 ? launch_gemm64_tn_f64(ctx, rcols, drows, D, ldd, st) : launch_gemm32_tn_f64(ctx, rcols, drows, D, ldd, st); }
 // columns of a miss sweep: 32 in fp32 (HBM-bound), option sweep_cols_f64 in double precision
-inline uint32_t miss_cols(const ss_hip_ctx*, const Workspace<float>&) { return 32u; }
-inline uint32_t miss_cols(const ss_hip_ctx* ctx, const Workspace<double>& ws) { return (ctx->sweep_cols_f64 > 32 && ws.gcap >= 192) ? 64u : 32u; }
+// (fetch = how many passes this solve has fetched after its first: in double precision the first two passes are wide;
+// later misses come late on the path — at configs[4] the third pass serves the last ~8 of 128 iterations — and take 32)
+inline uint32_t miss_cols(const ss_hip_ctx*, const Workspace<float>&, uint32_t = 0) { return 32u; }
+inline uint32_t miss_cols(const ss_hip_ctx* ctx, const Workspace<double>& ws, uint32_t fetch = 0)
+{
+    if (!(ctx->sweep_cols_f64 > 32 && ws.gcap >= 192)) return 32u;
+    return (fetch >= 1 && ctx->sweep_cols_f64_late <= 32) ? 32u : 64u;
+}
 
 // early form of the speculative engine (fp32): the first solo launch runs on the subset Gram matrix beside the passes over A
 inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nparts, float tol, uint32_t max_iter, uint32_t lds_cols,
@@ -505,9 +511,10 @@ template <typename T> struct Lookahead {
     // that fetches it (plus 31 likely successors) and the inverse update that was waiting for it
     // from_cand: the speculative form is running — its verification has left the per-block candidate tops of
     // the scan that missed (wide dictionaries only: with few blocks the tops are too few to rank from)
-    static void fetch(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool from_cand = false)
+    static void fetch(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool from_cand = false,
+                      uint32_t fetch_index = 0)
     {
-        const uint32_t nsel = miss_cols(ctx, ws);
+        const uint32_t nsel = miss_cols(ctx, ws, fetch_index);
         if (from_cand && ctx->n > 32u * 512u) HIPCHK(launch_top_cand(ctx, ws));
         else HIPCHK(launch_la_top<T>(ctx, ws, 0, nsel));
         if (ev0) HIPCHK(hipEventRecord(ev0, ctx->stream));
@@ -869,7 +876,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     hipEvent_t e0 = nullptr, e1 = nullptr;
                     if (timed_la) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
                     if (la_omp) Lookahead<T>::fetch_omp(ctx, ws, tol, e0, e1);
-                    else Lookahead<T>::fetch(ctx, ws, tol, e0, e1, solo);
+                    else Lookahead<T>::fetch(ctx, ws, tol, e0, e1, solo, handled);
                     if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
                     ++handled;
                 }
@@ -1836,6 +1843,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "first_sweep_cols")) { ctx->first_sweep_cols = value > 32 ? 64 : 32; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_solo"))    { ctx->early_solo = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep_cols_f64")) { ctx->sweep_cols_f64 = value > 32 ? 64 : 32; return SS_HIP_OK; }
+    if (!std::strcmp(key, "sweep_cols_f64_late")) { ctx->sweep_cols_f64_late = value > 32 ? 64 : 32; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_probe"))   { ctx->early_probe = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_pass"))    { ctx->early_pass = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_adapt"))   { ctx->early_adapt = value ? 1 : 0; return SS_HIP_OK; }
@@ -1905,6 +1913,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "early_pass"))    { *value = ctx->early_pass; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_adapt"))   { *value = ctx->early_adapt; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep_cols_f64")) { *value = ctx->sweep_cols_f64; return SS_HIP_OK; }
+    if (!std::strcmp(key, "sweep_cols_f64_late")) { *value = ctx->sweep_cols_f64_late; return SS_HIP_OK; }
     if (!std::strcmp(key, "cache_mib"))     { *value = ctx->cache_mib; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_min"))     { *value = ctx->batch_min; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_gram_min")) { *value = ctx->batch_gram_min; return SS_HIP_OK; }

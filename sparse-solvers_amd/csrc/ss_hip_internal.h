@@ -281,6 +281,7 @@ struct ss_hip_ctx {
     int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns) unless the tolerance is too tight for it, 2 = lookahead always, 0 = one fused sweep per iteration
     int early_solo = 1;        // option: 1 = early form of the speculative engine (iterations on the subset Gram matrix beside the passes over A)
     int sweep_cols_f64 = 64;   // option: columns per lookahead sweep in double precision (64: the pass is MFMA-bound either way; 32)
+    int sweep_cols_f64_late = 32;     // option: ... of the third and later passes of a solve (late misses are sparse)
     int early_probe = 0;       // developer aid (option): 1 = early form without overlap (passes first, then the solo launch)
     int first_sweep_cols = 32; // option: columns of the first lookahead sweep of a fp32 solve (64: one MFMA-bound pass instead of two HBM-bound ones; 32)
     int sweep32_variant = 0; // lookahead sweep tiling: 0 = 256 columns x 512 threads (1 per CU), 1 / 2 = 128 columns x 256 threads (2 / 3 per CU)
