@@ -103,9 +103,12 @@ int ss_hip_omp_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy,
  * Batch of B signals sharing the context's sensing matrix: signal b is
  * Y[b*y_stride + i*incy], its solution X[b*x_stride + j*incx].
  * iter_out[B], err_out[B] receive the per-signal reports.
- * fp32 batches of >= "batch_min" (default 192) signals advance in lock-step: the 2B
- * correlation GEMVs of a round become MFMA GEMMs over the shared matrix.  Smaller batches
- * and fp64 run one signal at a time (the single-signal engine, see option "engine").
+ * fp32 batches advance in lock-step on the MFMA units — from "batch_cols_min" (default 24) signals in the column
+ * form (per round one pass over the matrix forms the Gram columns of the entering columns), from "batch_gram_min"
+ * (default 512) in the Gram form on G = A^T A; where neither applies, from "batch_min" (default 192) the 2B
+ * correlation GEMVs of a round become two GEMMs over the shared matrix.  Smaller batches and fp64 run one signal at a
+ * time (the single-signal engine, see option "engine").  The lock-step forms agree with the single-signal engine
+ * to rounding (same supports and iteration counts), not bit for bit.
  */
 int ss_hip_homotopy_solve_batch_f32(ss_hip_ctx* ctx, const float* Y, size_t B,
                                     ptrdiff_t y_stride, ptrdiff_t incy,
