@@ -856,7 +856,9 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
 hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd)
 {
     if (ctx->n_pad % 32 != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
-    if (ctx->early_pass == 2 && ctx->n_pad % 128 == 0) {
+    // (fewer 128-column tiles than CUs: the single-wave tiling below spreads the same columns over four times as many
+    // workgroups and keeps every CU loading)
+    if (ctx->early_pass == 2 && ctx->n_pad % 128 == 0 && ctx->n_pad / 128 >= (size_t)ctx->num_cus) {
         // LDS-staged tiling with 128-column tiles, three 256-thread workgroups per CU (46 KB LDS each): 765 slots on the
         // 255 CUs the solo launch leaves, every one of the 512 tiles of C2 resident from the start
         const uint32_t nt = ctx->n_pad / 128;
