@@ -16,6 +16,10 @@ x0 = np.zeros(n); sup = np.sort(rng.choice(n, k, replace=False)); x0[sup] = 1.0 
 y = (A.astype(np.float64) @ x0).astype(np.float32)
 with sship.Homotopy(A) as h:
     h.set_option("la_fused", 3)
+    if os.environ.get("SOLO_DEBUG_FULLG"):
+        h.set_option("gram_full_after", 1)
+        h.set_option("solo_full_gram", 1)
+        h.solve(y, 1e-3, 2 * k + 8)
     h.reset_stats()
     x, it, e = h.solve(y, 1e-3, 2 * k + 8)
     print("iter", it, "stats", {k_: v for k_, v in h.stats().items() if "solo" in k_})
@@ -24,10 +28,10 @@ if not os.path.exists(path):
 raw = open(path, "rb").read()
 nlog, nvwg, ew, hw = struct.unpack("4I", raw[:16])
 off = 16
-lw = hw + 64 * ew
+lw = hw + 128 * ew
 lg = np.frombuffer(raw, np.uint32, lw, off); off += 4 * lw
-vm = np.frombuffer(raw, np.uint32, 64 * nvwg, off).reshape(64, nvwg); off += 4 * 64 * nvwg
-vn = np.frombuffer(raw, np.uint64, 64 * nvwg, off).reshape(64, nvwg)
+vm = np.frombuffer(raw, np.uint32, 128 * nvwg, off).reshape(128, nvwg); off += 4 * 128 * nvwg
+vn = np.frombuffer(raw, np.uint64, 128 * nvwg, off).reshape(128, nvwg)
 print("nlog", nlog, "nvwg", nvwg)
 sub = lg[:256]; rows = lg[256:512]
 print("subset size", (sub != 0xffffffff).sum(), "first", sub[:12], "rows", rows[:12].astype(np.int32))
