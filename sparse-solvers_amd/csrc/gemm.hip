@@ -180,6 +180,10 @@ constexpr int HM = 32;
 // (68.7 GFLOP at C2) take ~0.45 ms on the fp32 MFMA units against 0.27 ms for the bytes — but it replaces TWO
 // 32-column passes (2 x 0.37 ms) and one round trip through the host, which is why the first lookahead sweep
 // of a solve (the entering column + the 63 largest |c0|) uses it.
+// developer aid (option pass_dbg_ptr): where and when every workgroup of the lookahead passes ran — entry e of the
+// buffer: {start, end (100 MHz ticks), XCC_ID << 16 | HW_ID, blockIdx.x | tiles << 32}; word 0 counts the entries
+__device__ uint64_t* g_pass_dbg = nullptr;
+
 template <int HN, int HT, int BPC, int KS = GK, bool DRY = false, int RH = HM>
 __global__ __launch_bounds__(HT, BPC)
 void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
@@ -189,6 +193,8 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
 {
     if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
     if (rcols[0] == 0xffffffffu) return;                        // an empty list (lists are filled from entry 0)
+    uint64_t* const pdbg = g_pass_dbg;
+    const uint64_t t_dbg0 = pdbg != nullptr ? wall_clock64() : 0ull;
     constexpr int LD = KS + GPAD;                               // LDS row pitch in floats
     constexpr int RB = RH / 32;                                 // 32-row blocks of right-hand sides
     __shared__ __attribute__((aligned(16))) float sR[2][RH][LD];
@@ -298,6 +304,17 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
                 const uint32_t dr = drows[row];
                 if (dr != 0xffffffffu) D[(size_t)dr * ldd + col] = acc[r][e];
             }
+    }
+    if (pdbg != nullptr && tid == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const uint64_t e = atomicAdd(reinterpret_cast<unsigned long long*>(pdbg), 1ull);
+        if (e < 4096ull) {
+            uint64_t* o = pdbg + 1 + 4 * e;
+            o[0] = t_dbg0; o[1] = wall_clock64(); o[2] = ((uint64_t)(xcc & 0xfu) << 16) | (hw & 0xffffu);
+            o[3] = (uint64_t)blockIdx.x | ((uint64_t)ntiles << 32);
+        }
     }
 }
 
@@ -782,6 +799,8 @@ hipError_t launch_gemm64_tn_f64(const ss_hip_ctx* ctx, const uint32_t* rcols, co
                        rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
     return hipGetLastError();
 }
+
+hipError_t set_pass_debug(uint64_t* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_pass_dbg), &buf, sizeof(buf)); }
 
 // D[drows[s]][:] = At · At[rcols[s]][:] for s < 32 (entries 0xffffffff are skipped)
 hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,

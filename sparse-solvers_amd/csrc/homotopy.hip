@@ -1847,6 +1847,10 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "early_probe"))   { ctx->early_probe = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_pass"))    { ctx->early_pass = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_adapt"))   { ctx->early_adapt = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "pass_dbg_ptr"))  {   // developer aid: device buffer of 1 + 4 * 4096 u64 (0 = off), tools/probe_pass_trace.py
+        (void)hipSetDevice(ctx->device);
+        return sship::set_pass_debug(reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(value))) == hipSuccess ? SS_HIP_OK : SS_HIP_ERUNTIME;
+    }
     if (!std::strcmp(key, "sweep_f64_variant")) { ctx->sweep_f64_variant = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { ctx->la_fused = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_subset"))   { ctx->solo_subset = (int)std::max<long>(0, std::min<long>(256, value)); return SS_HIP_OK; }

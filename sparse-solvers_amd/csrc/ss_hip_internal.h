@@ -393,6 +393,7 @@ hipError_t launch_subset_pick_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
 hipError_t launch_wait_started(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on);
 hipError_t launch_missing_cols_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
 // the barrier-free 32-column pass (one 32-column tile per single-wave workgroup) on a given stream, ungated
+hipError_t set_pass_debug(uint64_t* buf);      // developer aid: per-workgroup trace of the fp32 lookahead passes (gemm.hip)
 hipError_t launch_pick_pass_b_f32(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on);
 hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd);
 // speculative form: k_la_persist<solo> (one workgroup on a column subset), then k_la_verify and
