@@ -177,3 +177,47 @@ def test_column_sharded_on_device_with_hip_sweeps(tmp_path):
         assert np.array_equal(p["added"][:cmp], tro["added"][:cmp])
     assert np.array_equal(np.abs(x) > 1e-4, np.abs(xo) > 1e-4)
     assert np.allclose(x, xo, rtol=2e-4, atol=2e-5)
+
+
+def _nccl_worker(rank, world, port, tmpdir):
+    import torch
+    import torch.distributed as dist
+    import sship
+    from colshard import ColumnShardedHomotopy
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    A, y = _gpu_problem()
+    shard = torch.from_numpy(A).to("cuda:0")
+    h = sship.Homotopy(A)
+    out = torch.empty(A.shape[1], dtype=shard.dtype, device="cuda:0")
+
+    def sweep_t(v):
+        h.gemv_t(v.contiguous(), out=out)
+        return out.clone()
+
+    solver = ColumnShardedHomotopy(shard, 0, A.shape[1], sweep_t=sweep_t)
+    assert solver.comm_dev.type == "cuda"                 # RCCL moves device buffers: every collective ran on the GPU
+    x, it, err, tr = solver.solve(torch.from_numpy(y).to("cuda:0"), 1e-5, 40, trace=True)
+    np.savez(os.path.join(tmpdir, "nccl.npz"), x=x.cpu().numpy(), it=it, err=err, **tr)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_column_sharded_over_rccl_one_rank(tmp_path):
+    """the driver with the `nccl` (= RCCL) backend: collectives on device buffers.  One rank only — a box with one GPU
+    cannot host two RCCL ranks — so this walks the device-side code path (all_reduce, all_gather, broadcast of
+    device tensors), not an exchange; the two-rank exchange is the gloo test above."""
+    import oracle
+    import torch.multiprocessing as mp
+    port = 33900 + (os.getpid() % 1000)
+    mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    A, y = _gpu_problem()
+    xo, ito, erro, tro = oracle.homotopy(A, y, 1e-5, 40, trace=True)
+    p = np.load(tmp_path / "nccl.npz")
+    assert int(p["it"]) == ito
+    cmp = ito if erro <= 1e-5 else ito + 1
+    assert np.array_equal(p["idx"][:cmp], tro["idx"][:cmp])
+    assert np.allclose(p["x"], xo, rtol=2e-4, atol=2e-5)
