@@ -526,9 +526,15 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         if engine >= 1:
             # the 32-RHS sweep G = A^T [a_j1 .. a_j32] (HBM-bound): a solve that meets a column outside its first 64
             launches, ms_sum, nbytes = st["sweep32_launches"], st["sweep32_ms"], st["sweep32_bytes"]
+            cols_timed = int(st["sweep32_timed_cols"])
             if h.get_option("early_solo") and h.get_option("la_fused") >= 3:
-                tiling = ("k_gemm32_tn_f32<128, 256, 3> (128-column LDS tiles, three workgroups per CU)"
+                tiling = ("k_gemm32_tn_f32<128, 256, 3> (128-column LDS tiles)"
                           if h.get_option("early_pass") == 2 else "k_gemm32e_tn_f32 (one 32-column tile per single-wave workgroup)")
+                if 0 < cols_timed < N:
+                    # the pass is dealt out by shader engine: the timed launch is the main one (14 tiles per SE); the
+                    # other tiles run beside it on a third stream.  Its own algorithmic bytes:
+                    nbytes = M * cols_timed * 4 + 32 * M * 4 + 32 * cols_timed * 4
+                    tiling += ", main launch of the pass: %d of %d columns, the others beside it by shader engine" % (cols_timed, N)
                 kname = (tiling + ": lookahead sweep, 32 Gram columns A^T a_j per pass over A (fp32 MFMA, HBM-bound), "
                          "timed on the second stream where it runs BESIDE the speculative iterations (one CU taken)")
             else:

@@ -245,6 +245,10 @@ typedef struct ss_hip_stats {
     uint64_t sweep64_bytes;        /* its algorithmic bytes: m*n*s + 64*m*s + 64*n*s                                               */
     uint64_t batch_col_rounds;     /* rounds of mid-size batches run in the column form (Gram columns of the entering columns
                                       formed per round, 64 signals per pass over A)                                                */
+    uint64_t sweep32_timed_cols;   /* dictionary columns covered by ONE timed lookahead launch: n, or — early form with the pass
+                                      dealt out by shader engine (option early_se) — the main launch's share of them (57344 of
+                                      65536: the rest runs beside it on another stream); its algorithmic bytes are
+                                      m*cols*s + 32*m*s + 32*cols*s                                                                 */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------
@@ -306,6 +310,13 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    workgroups per CU (all 512 tiles of 8192 x 65536 resident on the 255 CUs the speculative launch
  *                    leaves: 0.49 ms per pass beside it); 0 = one 32-column tile per single-wave workgroup (0.52 ms).
  *                    Same results bit for bit
+ *   "early_se"       1 (default) = the early form's two passes are dealt out around the speculative workgroup: the
+ *                    hardware gives every shader engine the same number of workgroups of a grid, and the SE of that
+ *                    workgroup has 7 CUs for its share — so the main launch takes 14 tiles per SE, a second launch puts
+ *                    two more workgroups on every SE, which pick their tile by where they run and leave at once on that
+ *                    SE, and the last two tiles are formed by a VALU kernel: every other CU carries exactly two tiles
+ *                    (0.37-0.38 ms per pass instead of 0.47-0.49; 256-CU parts, 57345..65536 columns); 0 = one launch
+ *                    per pass.  Same results bit for bit
  *   "early_adapt"    1 (default) = the early form's second pass takes its 32 columns from the speculative launch's
  *                    progress when the first pass has finished (columns that have entered its support, then those
  *                    closest to entering); 0 = from the |c0| ranking.  Decides which Gram columns are fetched when,

@@ -184,15 +184,47 @@ constexpr int HM = 32;
 // buffer: {start, end (100 MHz ticks), XCC_ID << 16 | HW_ID, blockIdx.x | tiles << 32}; word 0 counts the entries
 __device__ uint64_t* g_pass_dbg = nullptr;
 
-template <int HN, int HT, int BPC, int KS = GK, bool DRY = false, int RH = HM>
+// BYSE (early form, the tiles the main launch leaves: homotopy.hip): the workgroup's tile follows from WHERE it runs.
+// The hardware deals a grid out statically — every shader engine of every XCD gets the same number of workgroups,
+// whatever its CUs hold — so a launch of 2 * kSeCount workgroups puts two on every SE; a workgroup reads its (XCC, SE)
+// from the hardware registers, leaves at once if that is the solo workgroup's SE (st->solo_where: its 7 other CUs have
+// their two tiles from the main launch), and otherwise takes tile first + 2 * ord + slot, ord = its SE's rank among
+// the others, slot = arrival order on that SE (se_count).  Every CU but the solo workgroup's then carries two tiles.
+template <int HN, int HT, int BPC, int KS = GK, bool DRY = false, int RH = HM, bool BYSE = false>
 __global__ __launch_bounds__(HT, BPC)
 void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
                      const uint32_t* __restrict__ drows, float* __restrict__ D,
                      uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
-                     const DevState* __restrict__ st)
+                     const DevState* __restrict__ st, uint32_t first, uint32_t* se_count)
 {
-    if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
+    if (!BYSE && st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
+    // (BYSE: arrivals, for the main launch of the same pass — it is held back until all of these hold their CUs: a
+    // workgroup of THIS launch that finds its SE full would hold up every workgroup behind it in the grid)
+    if (BYSE && threadIdx.x == 0) __hip_atomic_fetch_add(&se_count[kSeCount], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (rcols[0] == 0xffffffffu) return;                        // an empty list (lists are filled from entry 0)
+    uint32_t my_tile = 0;
+    if (BYSE) {
+        __shared__ uint32_t s_tile;
+        if (threadIdx.x == 0) {
+            uint32_t hw_, xcc_;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+            const uint32_t se = ((xcc_ & 7u) << 2) | ((hw_ >> 13) & 3u);
+            const uint32_t where = __hip_atomic_load(&st->solo_where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t solo_se = 0xffffffffu;
+            if (where != 0u) solo_se = ((((where - 1u) >> 16) & 7u) << 2) | (((where - 1u) >> 13) & 3u);
+            uint32_t t = 0xffffffffu;
+            if (se != solo_se) {
+                const uint32_t slot = __hip_atomic_fetch_add(&se_count[se], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t ord = se - ((solo_se != 0xffffffffu && se > solo_se) ? 1u : 0u);
+                if (slot < 2u) t = first + 2u * ord + slot;
+            }
+            s_tile = t;
+        }
+        __syncthreads();
+        my_tile = s_tile;
+        if (my_tile >= ntiles) return;
+    }
     uint64_t* const pdbg = g_pass_dbg;
     const uint64_t t_dbg0 = pdbg != nullptr ? wall_clock64() : 0ull;
     constexpr int LD = KS + GPAD;                               // LDS row pitch in floats
@@ -216,7 +248,7 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
     const v4f zero4 = { 0.f, 0.f, 0.f, 0.f };
     const uint32_t nk = K / KS;
 
-    for (uint32_t bn = blockIdx.x; bn < ntiles; bn += gridDim.x) {
+    for (uint32_t bn = BYSE ? my_tile : blockIdx.x; bn < ntiles; bn += BYSE ? ntiles : gridDim.x) {
         const float* gQ = At + (size_t)(bn * HN + srow) * ldq + squad * 4;
         v16f acc[RB];
 #pragma unroll
@@ -824,14 +856,14 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
         const uint32_t ntiles = ctx->n_pad / 256;
         const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
         hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1, GK, true>), dim3(grid), dim3(512), 0, ctx->stream,
-                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
     } else if (ctx->sweep32_variant == 4) {
         // K-step 64: 256 contiguous bytes per row and step (fewer, larger DRAM bursts per stream)
         const uint32_t ntiles = ctx->n_pad / 256;
         const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
         if (ctx->ldm % 64 != 0) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1, 64>), dim3(grid), dim3(512), 0, ctx->stream,
-                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
     } else if (ctx->sweep32_variant == 8 || ctx->sweep32_variant == 9) {
         // measurement aid: the early form's pass (one 32-column tile per single-wave workgroup), or two-wave workgroups
         const uint32_t ntiles = ctx->n_pad / 32;
@@ -851,7 +883,7 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
         const uint32_t ntiles = ctx->n_pad / 256;
         const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
         hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1>), dim3(grid), dim3(512), 0, ctx->stream,
-                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
     } else {
         // 128-column tiles, 256 threads, several workgroups per CU: one's barrier waits are
         // another's compute
@@ -861,10 +893,10 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
         const uint32_t grid = ntiles < cap ? ntiles : cap;
         if (ctx->sweep32_variant == 1)
             hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 2>), dim3(grid), dim3(256), 0, ctx->stream,
-                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
         else
             hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3>), dim3(grid), dim3(256), 0, ctx->stream,
-                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
     }
     return hipGetLastError();
 }
@@ -872,9 +904,29 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
 // the barrier-free 32-column pass with one 32-column tile per single-wave workgroup, on a given stream, ungated
 // (early form of the speculative engine: it runs beside a solo launch that occupies one CU — 2048 small workgroups
 // spread evenly over whatever CUs are free, where 256 one-per-CU workgroups would leave one waiting for a CU)
-hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd)
+// (10 KB of unused dynamic LDS on top of the kernel's 46 KB: at most TWO of these workgroups fit a CU, which is what
+// makes the placement below the hardware's only choice)
+constexpr uint32_t kSePad = 10240;
+
+hipError_t launch_gemm32se_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
+                              uint32_t first, uint32_t ntiles, const DevState* st, uint32_t* se_count)
+{
+    if (ctx->n_pad % 128 != 0 || ctx->ldm % GK != 0 || st == nullptr || se_count == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3, GK, false, HM, true>), dim3(2u * kSeCount), dim3(256), kSePad, on,
+                       static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, first, se_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
+                             uint32_t tiles128)
 {
     if (ctx->n_pad % 32 != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
+    if (tiles128 != 0) {
+        // the first tiles128 tiles only, at most two workgroups per CU (the caller covers the other columns: early_prologue)
+        hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3>), dim3(tiles128), dim3(256), kSePad, on, static_cast<const float*>(ctx->At),
+                           rcols, drows, D, ctx->ldm, ctx->ldm, ldd, tiles128, (const DevState*)nullptr, 0u, nullptr);
+        return hipGetLastError();
+    }
     // (fewer 128-column tiles than CUs: the single-wave tiling below spreads the same columns over four times as many
     // workgroups and keeps every CU loading)
     if (ctx->early_pass == 2 && ctx->n_pad % 128 == 0 && ctx->n_pad / 128 >= (size_t)ctx->num_cus) {
@@ -883,7 +935,7 @@ hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32
         const uint32_t nt = ctx->n_pad / 128;
         const uint32_t cap = 3u * (uint32_t)ctx->num_cus;
         hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3>), dim3(nt < cap ? nt : cap), dim3(256), 0, on, static_cast<const float*>(ctx->At),
-                           rcols, drows, D, ctx->ldm, ctx->ldm, ldd, nt, (const DevState*)nullptr);
+                           rcols, drows, D, ctx->ldm, ctx->ldm, ldd, nt, (const DevState*)nullptr, 0u, nullptr);
         return hipGetLastError();
     }
     const uint32_t ntiles = ctx->n_pad / 32;
@@ -900,7 +952,7 @@ hipError_t launch_gemm64_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
     const uint32_t ntiles = ctx->n_pad / 256;
     const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
     hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1, GK, false, 64>), dim3(grid), dim3(512), 0, ctx->stream,
-                       static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st);
+                       static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
     return hipGetLastError();
 }
 

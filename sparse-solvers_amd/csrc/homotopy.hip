@@ -358,6 +358,7 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
         ctx->stats.sweep_bytes = (uint64_t)m * n * s + 2 * (uint64_t)m * s + 2 * (uint64_t)n * s;
         ctx->stats.sweep1_bytes = (uint64_t)m * n * s + (uint64_t)m * s + (uint64_t)n * s;
         ctx->stats.sweep32_bytes = (uint64_t)m * n * s + 32 * (uint64_t)m * s + 32 * (uint64_t)n * s;
+        ctx->stats.sweep32_timed_cols = n;
         ctx->stats.sweep64_bytes = (uint64_t)m * n * s + 64 * (uint64_t)m * s + 64 * (uint64_t)n * s;
         ctx->stats.sweep64_flops = 2ull * 64ull * (uint64_t)m * n;
     } catch (const HipFail& f) {
@@ -565,6 +566,7 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
                            hipEvent_t pe0, hipEvent_t pe1)
 {
     hipStream_t st = ctx->stream;
+    const int probe = ctx->early_probe;              // developer aid: 1 = no overlap (the passes first, then the solo launch)
     if (!ctx->stream2) {
         // A stream of another priority class: HIP keeps a pool of hardware queues per class, so this one never
         // shares a queue with the main stream (two streams on ONE hardware queue execute in submission order, and
@@ -577,14 +579,46 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
         }
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        // a third stream (lowest priority class: again its own hardware queue) for the tiles dealt out by shader engine
+        if (hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->stream3 = nullptr;
+        }
+        if (ctx->stream3) {
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_b0, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming));
+            HIPCHK(hipMalloc(&ctx->se_count, 2 * (kSeCount + 1) * sizeof(uint32_t)));
+        }
     }
-    const int probe = ctx->early_probe;              // developer aid: 1 = no overlap (the passes first, then the solo launch)
+    // Dealing the passes out around the solo workgroup (option early_se).  The hardware distributes a grid statically:
+    // every shader engine of every XCD gets the same number of workgroups, whatever its CUs hold (per-workgroup trace of
+    // the real pass, tools/probe_pass_trace.py).  The solo workgroup owns one CU of one SE; 512 tiles put 16 on the 7
+    // other CUs of that SE, two of them run a third tile, and a pass — bound by what ONE CU can load — ends at 0.49 ms
+    // instead of 0.37.  So: the main launch takes 14 tiles per SE (two per CU on the solo SE, room for exactly two
+    // workgroups per CU: LDS padding), a second launch on a third stream puts two more workgroups on every SE, which
+    // pick their tile by where they run and leave at once on the solo workgroup's SE (k_gemm32_tn_f32<BYSE>), and the
+    // two tiles that are left of 512 are formed by the VALU chain (k_cols_gram) on the main stream once the solo launch
+    // is done.  Every CU but one then carries exactly two tiles.
+    uint32_t main_tiles = 0, se_last = 0, tail_c0 = 0, tail_cols = 0;
+    if (ctx->early_se && ctx->early_pass == 2 && !probe && ctx->stream3 && ctx->num_cus == 8 * (int)kSeCount &&
+        ctx->n_pad % 128 == 0 && ctx->ldm % 256 == 0) {
+        const uint32_t nt = (uint32_t)(ctx->n_pad / 128);
+        if (nt > 14u * kSeCount && nt <= 16u * kSeCount) {
+            main_tiles = 14u * kSeCount;                                        // 448
+            se_last = std::min<uint32_t>(nt, main_tiles + 2u * (kSeCount - 1u)); // tiles [448, 510) by shader engine
+            tail_c0 = se_last * 128u;
+            tail_cols = (nt - se_last) * 128u;                                  // the last 256 columns at 8192 x 65536
+        }
+    }
+    ctx->stats.sweep32_timed_cols = main_tiles ? (uint64_t)main_tiles * 128u : (uint64_t)ctx->n;
     if (ws.la_dbg) HIPCHK(hipMemsetAsync(ws.la_dbg, 0, 2048 * 8 * sizeof(uint64_t), st));
     HIPCHK(launch_la_init_pick<float>(ctx, ws, nparts, tol, false));
     HIPCHK(launch_la_cand_init_f32(ctx, ws));
     HIPCHK(launch_subset_pick_f32(ctx, ws));                        // subset of 256, slots 0..63, the two sweep lists
     // Gs, and a_idx . a_idx seeded into the first pick's cache row for the first inverse update
     HIPCHK(launch_subset_gram_f32(ctx, ws.sub_cols, ws.subg, ws.st, ws.gcache, ws.slot_of, ws.gpitch));
+    if (main_tiles) HIPCHK(hipMemsetAsync(ctx->se_count, 0, 2 * (kSeCount + 1) * sizeof(uint32_t), st));
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     // second stream: the two 32-column passes, held back until the solo workgroup is resident.  (Enqueued AFTER the
     // solo launch: should the two streams ever share a hardware queue after all, the gate then follows the launch it
@@ -592,13 +626,33 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
     auto enqueue_passes = [&]() {
         HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         if (!probe) HIPCHK(launch_wait_started(ctx, ws, ctx->stream2));
+        if (main_tiles) {
+            // third stream: the tiles dealt out by shader engine.  Its workgroups must hold their CUs BEFORE the main launch
+            // of the pass arrives (a workgroup that finds its SE full holds up every workgroup behind it in its grid; the
+            // two that land on the solo workgroup's SE leave at once when they get there first): the main launch waits for
+            // their arrival count
+            HIPCHK(hipEventRecord(ctx->ev_gate, ctx->stream2));                     // (behind the gate: the solo workgroup is resident)
+            HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_gate, 0));
+            HIPCHK(launch_gemm32se_on(ctx, ctx->stream3, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, main_tiles, se_last, ws.st,
+                                      ctx->se_count));
+            HIPCHK(launch_wait_count(ctx->stream2, ctx->se_count + kSeCount, 2u * kSeCount, ws.st));
+        }
         if (pe0) HIPCHK(hipEventRecord(pe0, ctx->stream2));
-        HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch));
+        HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, main_tiles));
         if (pe1) HIPCHK(hipEventRecord(pe1, ctx->stream2));
         // the second pass's 32 columns are chosen now, half a millisecond into the solo launch: what has entered
         // its support without a Gram row so far, then the columns closest to entering (k_pick_pass_b)
         HIPCHK(launch_pick_pass_b_f32(ctx, ws, ctx->stream2));
-        HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch));
+        if (main_tiles) {
+            HIPCHK(hipEventRecord(ctx->ev_b0, ctx->stream2));                       // (the second list exists, the first pass is complete)
+            HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_b0, 0));
+            HIPCHK(launch_gemm32se_on(ctx, ctx->stream3, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch, main_tiles, se_last, ws.st,
+                                      ctx->se_count + (kSeCount + 1)));
+            HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
+            HIPCHK(launch_wait_count(ctx->stream2, ctx->se_count + (kSeCount + 1) + kSeCount, 2u * kSeCount, ws.st));
+        }
+        HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch, main_tiles));
+        if (main_tiles) HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_join3, 0));
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     };
     if (probe == 1) { enqueue_passes(); HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0)); }
@@ -606,6 +660,13 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
     HIPCHK(launch_la_update<float>(ctx, ws, 0, tol));
     HIPCHK(launch_la_solo_f32(ctx, ws, tol, max_iter));
     if (probe != 1) enqueue_passes();
+    if (tail_cols) {
+        // the last columns of both passes by the VALU chain, on this stream behind the solo launch (which ends well before
+        // the second pass does); the second list exists once ev_b0 has fired
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_b0, 0));
+        HIPCHK(launch_cols_gram_on(ctx, st, tail_c0, tail_cols, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch));
+        HIPCHK(launch_cols_gram_on(ctx, st, tail_c0, tail_cols, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch));
+    }
     // ... which the passes have to be complete for from here on
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     HIPCHK(launch_missing_cols_f32(ctx, ws));
@@ -1668,6 +1729,7 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) {
@@ -1689,6 +1751,11 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     if (ctx->ev_solve1) (void)hipEventDestroy(ctx->ev_solve1);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->se_count) (void)hipFree(ctx->se_count);
+    if (ctx->ev_gate) (void)hipEventDestroy(ctx->ev_gate);
+    if (ctx->ev_b0) (void)hipEventDestroy(ctx->ev_b0);
+    if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1817,11 +1884,13 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx)
 {
     if (!ctx) return SS_HIP_EINVAL;
     const uint64_t b2 = ctx->stats.sweep_bytes, b1 = ctx->stats.sweep1_bytes, b32 = ctx->stats.sweep32_bytes;
+    const uint64_t tc32 = ctx->stats.sweep32_timed_cols;
     const uint64_t b64 = ctx->stats.sweep64_bytes, f64 = ctx->stats.sweep64_flops;
     ctx->stats = ss_hip_stats{};
     ctx->stats.sweep_bytes = b2;
     ctx->stats.sweep1_bytes = b1;
     ctx->stats.sweep32_bytes = b32;
+    ctx->stats.sweep32_timed_cols = tc32;
     ctx->stats.sweep64_bytes = b64;
     ctx->stats.sweep64_flops = f64;
     return SS_HIP_OK;
@@ -1847,6 +1916,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "early_probe"))   { ctx->early_probe = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_pass"))    { ctx->early_pass = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_adapt"))   { ctx->early_adapt = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "early_se"))      { ctx->early_se = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "pass_dbg_ptr"))  {   // developer aid: device buffer of 1 + 4 * 4096 u64 (0 = off), tools/probe_pass_trace.py
         (void)hipSetDevice(ctx->device);
         return sship::set_pass_debug(reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(value))) == hipSuccess ? SS_HIP_OK : SS_HIP_ERUNTIME;

@@ -264,7 +264,14 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     const bool grow0 = (K0 + 1u > P) && (P < kcap);
     if (SOLO) {
         // early form: the passes over A on the second stream are held back until this workgroup is resident
-        if (tid == 0) __hip_atomic_store(&st->solo_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            // where this workgroup runs, for the passes that share the chip with it (they keep off its shader engine)
+            uint32_t hw_, xcc_;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+            __hip_atomic_store(&st->solo_where, (((xcc_ & 0xfu) << 16) | (hw_ & 0xffffu)) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->solo_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // (k_la_vpublish counts the launch for the host pump, whether it worked or not)
         if (st->done || st->need_sweep || st->solo_off) return;
         if (grow0) {

@@ -782,6 +782,23 @@ hipError_t launch_pick_pass_b_f32(ss_hip_ctx* ctx, Workspace<float>& ws, hipStre
     return hipGetLastError();
 }
 
+// hold a pass's main launch back until every workgroup of the launch that goes first holds its CU (bounded, like the gate)
+__global__ void k_wait_count(const uint32_t* counter, uint32_t target, const DevState* st)
+{
+    if (threadIdx.x != 0) return;
+    for (uint32_t spin = 0; spin < 2000u; ++spin) {
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+        if (__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+hipError_t launch_wait_count(hipStream_t on, const uint32_t* counter, uint32_t target, const DevState* st)
+{
+    hipLaunchKernelGGL(k_wait_count, dim3(1), dim3(64), 0, on, counter, target, st);
+    return hipGetLastError();
+}
+
 hipError_t launch_wait_started(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on)
 {
     (void)ctx;

@@ -70,7 +70,8 @@ struct DevState {
     uint32_t solo_fails;   // solo launches of this solve that failed a check
     uint32_t solo_started; // early form: set by the solo launch when it begins (the passes over A on the second stream wait for it)
     uint32_t subg_active;  // early form: 1 while the solo launches of this solve run on the subset Gram matrix Gs (until their first commit)
-    uint32_t pad0_[4];
+    uint32_t solo_where;   // early form: (XCC_ID << 16 | HW_ID) of the solo workgroup + 1 (0 = none): the passes keep off its shader engine
+    uint32_t pad0_[3];
     // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
     uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
     uint32_t pad1_[31];
@@ -81,6 +82,8 @@ struct DevState {
     uint32_t bar_count;   // grid barrier of k_la_iter: arrivals so far in this solve (monotonic)
     uint32_t pad4_[31];
 };
+// shader engines of the chip as the early form's passes count them: 8 XCDs x 4
+constexpr uint32_t kSeCount = 32;
 static_assert(sizeof(DevState) == 640, "DevState layout");
 
 // Hand-off area of the resident lookahead kernel (k_la_persist).  Everything that crosses
@@ -239,6 +242,10 @@ struct ss_hip_ctx {
     size_t bcol_slot_rows = 0;
     uint32_t* bcol_lists = nullptr;   // rcols[1024] then drows[1024]
     int early_pass = 2;               // option: tiling of the early form's passes (2 = 128-column LDS tiles, 3 workgroups per CU; 0 = k_gemm32e)
+    int early_se = 1;                 // option: the early form's passes are dealt out by shader engine around the solo workgroup
+    hipStream_t stream3 = nullptr;    // ... third stream (the tiles of the other shader engines), its events, the per-SE counters
+    hipEvent_t ev_gate = nullptr, ev_b0 = nullptr, ev_join3 = nullptr;
+    uint32_t* se_count = nullptr;     // [2][kSeCount + 1] device counters, one set per pass: arrivals per SE, then arrivals in all
     int sweep_f64_variant = 0;        // option: tiling of the 32-column fp64 pass (0 = 256 columns / 512 threads / 1 per CU; 1, 2 = 128 / 256 / 2, 3 per CU)
     uint64_t solo_seen = 0, solo_failed = 0;   // speculative solves / failed checks since the form was last switched off (private: not the statistics)
     int early_adapt = 1;              // option: the early form's second pass takes its columns from the solo launch's progress (0 = from |c0|)
@@ -395,7 +402,14 @@ hipError_t launch_missing_cols_f32(ss_hip_ctx* ctx, Workspace<float>& ws);
 // the barrier-free 32-column pass (one 32-column tile per single-wave workgroup) on a given stream, ungated
 hipError_t set_pass_debug(uint64_t* buf);      // developer aid: per-workgroup trace of the fp32 lookahead passes (gemm.hip)
 hipError_t launch_pick_pass_b_f32(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on);
-hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd);
+hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
+                             uint32_t tiles128 = 0);
+// tiles first .. ntiles-1 of the same pass, two per shader engine except the solo workgroup's (early form)
+hipError_t launch_gemm32se_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
+                              uint32_t first, uint32_t ntiles, const DevState* st, uint32_t* se_count);
+hipError_t launch_wait_count(hipStream_t on, const uint32_t* counter, uint32_t target, const DevState* st);
+hipError_t launch_cols_gram_on(const ss_hip_ctx* ctx, hipStream_t on, uint32_t c0, uint32_t ncols, const uint32_t* rcols,
+                               const uint32_t* drows, float* D, uint32_t ldd);
 // speculative form: k_la_persist<solo> (one workgroup on a column subset), then k_la_verify and
 // k_la_vpublish (solo.hip), which check the logged breakpoints against all columns and release or
 // revoke the outcome; launch_la_cand_init seeds the subset ranking from |c0|

@@ -97,6 +97,82 @@ void k_subset_gram(const float* __restrict__ At, uint32_t ldm, uint32_t n, const
     }
 }
 
+// The pass's outputs for a RANGE of dictionary columns, by the same VALU chain: D[drows[s]][c] = a_c . a_{rcols[s]}
+// for c0 <= c < c0 + 16 * (gridDim.x / 2), s < 32 (entries 0xffffffff of the lists are skipped; an empty list —
+// first entry 0xffffffff — returns at once, like the pass).  One workgroup per 16 x 16 outputs, 8.7 KB of LDS.  Used by
+// the early form for the last two tiles of each pass (homotopy.hip, early_prologue): with one CU held by the solo
+// workgroup 510 tiles of 128 columns are what the other 255 can carry two each.
+constexpr uint32_t kCgRows = 64;             // rows of A staged per step
+constexpr uint32_t kCgPitch = kCgRows + 4;
+__global__ __launch_bounds__(256)
+void k_cols_gram(const float* __restrict__ At, uint32_t ldm, uint32_t c0, const uint32_t* __restrict__ rcols,
+                 const uint32_t* __restrict__ drows, float* __restrict__ D, uint32_t ldd)
+{
+    if (rcols[0] == 0xffffffffu) return;
+    __shared__ __attribute__((aligned(16))) float sA[kSgTile][kCgPitch];
+    __shared__ __attribute__((aligned(16))) float sB[kSgTile][kCgPitch];
+    const uint32_t bi = blockIdx.x & 1u, bj = blockIdx.x >> 1;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ii = tid >> 4, jj = tid & 15u;
+    const uint32_t sc = tid >> 4, sq = tid & 15u;            // staging: column sc of the 16, float4 sq of the 16 per step
+    const uint32_t ca = rcols[bi * kSgTile + sc];
+    const bool va_ok = ca != 0xffffffffu;
+    const float* ga = At + (size_t)(va_ok ? ca : 0u) * ldm + 4u * sq;
+    const float* gb = At + (size_t)(c0 + bj * kSgTile + sc) * ldm + 4u * sq;
+    const sg_v4f zero4 = { 0.f, 0.f, 0.f, 0.f };
+    float acc = 0.f;
+    // register ring three steps deep (a step is 4 KiB per operand and 64 fmas of chain: the loads need the lead)
+    sg_v4f va[3], vb[3];
+#define CG_LOAD(SET, R0)                                                                        \
+    {                                                                                           \
+        va[SET] = va_ok ? *reinterpret_cast<const sg_v4f*>(ga + (R0)) : zero4;                  \
+        vb[SET] = __builtin_nontemporal_load(reinterpret_cast<const sg_v4f*>(gb + (R0)));       \
+    }
+#define CG_STEP(SET, R0)                                                                        \
+    {                                                                                           \
+        __syncthreads();                                                                        \
+        *reinterpret_cast<sg_v4f*>(&sA[sc][4u * sq]) = va[SET];                                 \
+        *reinterpret_cast<sg_v4f*>(&sB[sc][4u * sq]) = vb[SET];                                 \
+        __syncthreads();                                                                        \
+        if ((R0) + 3u * kCgRows < ldm) CG_LOAD(SET, (R0) + 3u * kCgRows)                         \
+        /* the pass's chain (a = right-hand side s, b = dictionary column c, as in the MFMA) */ \
+        _Pragma("unroll") for (uint32_t k8 = 0; k8 < kCgRows; k8 += 8) {                        \
+            const sg_v4f a0 = *reinterpret_cast<const sg_v4f*>(&sA[ii][k8]), a1 = *reinterpret_cast<const sg_v4f*>(&sA[ii][k8 + 4]); \
+            const sg_v4f b0 = *reinterpret_cast<const sg_v4f*>(&sB[jj][k8]), b1 = *reinterpret_cast<const sg_v4f*>(&sB[jj][k8 + 4]); \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
+                acc = __builtin_fmaf(a0[e], b0[e], acc);                                        \
+                acc = __builtin_fmaf(a1[e], b1[e], acc);                                        \
+            }                                                                                   \
+        }                                                                                       \
+    }
+    CG_LOAD(0, 0u)
+    if (kCgRows < ldm) CG_LOAD(1, kCgRows)
+    if (2u * kCgRows < ldm) CG_LOAD(2, 2u * kCgRows)
+    uint32_t r0 = 0;
+    for (; r0 + 3u * kCgRows <= ldm; r0 += 3u * kCgRows) {
+        CG_STEP(0, r0)
+        CG_STEP(1, r0 + kCgRows)
+        CG_STEP(2, r0 + 2u * kCgRows)
+    }
+    if (r0 < ldm) { CG_STEP(0, r0) r0 += kCgRows; }
+    if (r0 < ldm) { CG_STEP(1, r0) r0 += kCgRows; }
+#undef CG_LOAD
+#undef CG_STEP
+    const uint32_t dr = drows[bi * kSgTile + ii];
+    if (dr != 0xffffffffu) D[(size_t)dr * ldd + c0 + bj * kSgTile + jj] = acc;
+}
+
+// columns c0 .. c0 + ncols - 1 (both multiples of 16) of the 32 Gram columns of a pass, on the given stream
+hipError_t launch_cols_gram_on(const ss_hip_ctx* ctx, hipStream_t on, uint32_t c0, uint32_t ncols, const uint32_t* rcols,
+                               const uint32_t* drows, float* D, uint32_t ldd)
+{
+    if (ctx->ldm % kCgRows != 0 || c0 % kSgTile != 0 || ncols % kSgTile != 0 || c0 + ncols > ctx->n_pad) return hipErrorInvalidValue;
+    if (ncols == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cols_gram, dim3(2u * (ncols / kSgTile)), dim3(256), 0, on, static_cast<const float*>(ctx->At), ctx->ldm, c0,
+                       rcols, drows, D, ldd);
+    return hipGetLastError();
+}
+
 hipError_t launch_subset_gram_f32(const ss_hip_ctx* ctx, const uint32_t* cols_dev, float* Gs, const DevState* st,
                                   float* seed_base, const int32_t* slot_of, uint32_t gpitch)
 {

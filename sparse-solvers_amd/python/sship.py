@@ -67,6 +67,7 @@ class Stats(ctypes.Structure):
         ("sweep64_flops", ctypes.c_uint64),
         ("sweep64_bytes", ctypes.c_uint64),
         ("batch_col_rounds", ctypes.c_uint64),
+        ("sweep32_timed_cols", ctypes.c_uint64),
     ]
 
 

@@ -21,8 +21,9 @@ x = torch.zeros(N, device="cuda:0")
 with sship.Homotopy(Ad) as h:
     for name, opts in (("plain", {"early_solo": 0}),
                        ("early e-kernel |c0|", {"early_solo": 1, "early_probe": 0, "early_pass": 0, "early_adapt": 0}),
-                       ("early LDSx3 |c0|", {"early_solo": 1, "early_probe": 0, "early_pass": 2, "early_adapt": 0}),
-                       ("early LDSx3 adaptive", {"early_solo": 1, "early_probe": 0, "early_pass": 2, "early_adapt": 1}),
+                       ("early LDSx3 |c0|", {"early_solo": 1, "early_probe": 0, "early_pass": 2, "early_adapt": 0, "early_se": 0}),
+                       ("early LDSx3 adaptive", {"early_solo": 1, "early_probe": 0, "early_pass": 2, "early_adapt": 1, "early_se": 0}),
+                       ("early by SE adaptive", {"early_solo": 1, "early_probe": 0, "early_pass": 2, "early_adapt": 1, "early_se": 1}),
                        ("early, no overlap", {"early_solo": 1, "early_probe": 1, "early_pass": 2, "early_adapt": 1})):
         for k_, v_ in opts.items():
             h.set_option(k_, v_)

@@ -46,6 +46,15 @@ def report(tag):
         for v in counts.values():
             hist[v] = hist.get(v, 0) + 1
         print("    CUs used %d; workgroups per CU: %s" % (len(counts), " ".join("%dx%d" % (hist[k], k) for k in sorted(hist))))
+        se = (hw >> 13) & 7
+        sh = (hw >> 12) & 1
+        per_se = {}
+        for a, b_, c_ in zip(xcc, se, sh):
+            per_se[(a, b_, c_)] = per_se.get((a, b_, c_), 0) + 1
+        cus_se = {}
+        for a, b_, c_, d_ in zip(xcc, se, sh, cu):
+            cus_se.setdefault((a, b_, c_), set()).add(d_)
+        print("    workgroups / CUs per (XCC, SE, SH): " + "  ".join("%d.%d.%d: %d/%d" % (k[0], k[1], k[2], v, len(cus_se[k])) for k, v in sorted(per_se.items())))
         for xc in range(8):
             m_ = xcc == xc
             if m_.any():

@@ -110,6 +110,16 @@ def main():
         out["pmc_raw"] = traffic
         nrhs = 32 if key == "gemm32" else 2
         alg = 8192 * 65536 * 4 + nrhs * 8192 * 4 + nrhs * 65536 * 4
+        # (the bench line of the traced run knows the timed launch's own algorithmic bytes — the main launch of a pass that
+        # is dealt out by shader engine covers 57344 of the 65536 columns)
+        blog = os.path.join(src, "bench_trace.log")
+        if os.path.exists(blog):
+            for ln in open(blog):
+                if ln.startswith("{"):
+                    try:
+                        alg = int(json.loads(ln)["roofline"]["bytes_per_launch"])
+                    except Exception:
+                        pass
         lines += ["## HBM traffic of `%s` (PMC, separate passes)" % KERNEL_KEY, "",
                   "- FETCH_SIZE mean %.1f KiB x 1024 x 2 (gfx950 correction) = %.0f B read" % (
                       traffic.get("FETCH_SIZE", {}).get("mean_raw_KiB", 0.0), rd),
