@@ -589,6 +589,8 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
             HIPCHK(hipEventCreateWithFlags(&ctx->ev_b0, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming));
             HIPCHK(hipMalloc(&ctx->se_count, 2 * (kSeCount + 1) * sizeof(uint32_t)));
+            if (hipStreamCreateWithPriority(&ctx->stream4, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); ctx->stream4 = nullptr; }
+            if (ctx->stream4) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join4, hipEventDisableTiming));
         }
     }
     // Dealing the passes out around the solo workgroup (option early_se).  The hardware distributes a grid statically:
@@ -661,11 +663,18 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
     HIPCHK(launch_la_solo_f32(ctx, ws, tol, max_iter));
     if (probe != 1) enqueue_passes();
     if (tail_cols) {
-        // the last columns of both passes by the VALU chain, on this stream behind the solo launch (which ends well before
-        // the second pass does); the second list exists once ev_b0 has fired
-        HIPCHK(hipStreamWaitEvent(st, ctx->ev_b0, 0));
-        HIPCHK(launch_cols_gram_on(ctx, st, tail_c0, tail_cols, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch));
-        HIPCHK(launch_cols_gram_on(ctx, st, tail_c0, tail_cols, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch));
+        // the last columns of both passes by the VALU chain (32 small workgroups each, ~70 us): on a fourth stream beside the
+        // passes when there is one, else on this stream behind the solo launch
+        hipStream_t ts = ctx->stream4 ? ctx->stream4 : st;
+        if (ctx->stream4) HIPCHK(hipStreamWaitEvent(ts, ctx->ev_gate, 0));
+        else HIPCHK(hipStreamWaitEvent(ts, ctx->ev_b0, 0));
+        HIPCHK(launch_cols_gram_on(ctx, ts, tail_c0, tail_cols, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch));
+        if (ctx->stream4) HIPCHK(hipStreamWaitEvent(ts, ctx->ev_b0, 0));
+        HIPCHK(launch_cols_gram_on(ctx, ts, tail_c0, tail_cols, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch));
+        if (ctx->stream4) {
+            HIPCHK(hipEventRecord(ctx->ev_join4, ts));
+            HIPCHK(hipStreamWaitEvent(st, ctx->ev_join4, 0));
+        }
     }
     // ... which the passes have to be complete for from here on
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -1729,6 +1738,7 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream4) (void)hipStreamSynchronize(ctx->stream4);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -1755,6 +1765,8 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     if (ctx->ev_gate) (void)hipEventDestroy(ctx->ev_gate);
     if (ctx->ev_b0) (void)hipEventDestroy(ctx->ev_b0);
     if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
+    if (ctx->ev_join4) (void)hipEventDestroy(ctx->ev_join4);
+    if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

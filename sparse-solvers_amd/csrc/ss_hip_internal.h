@@ -244,6 +244,8 @@ struct ss_hip_ctx {
     int early_pass = 2;               // option: tiling of the early form's passes (2 = 128-column LDS tiles, 3 workgroups per CU; 0 = k_gemm32e)
     int early_se = 1;                 // option: the early form's passes are dealt out by shader engine around the solo workgroup
     hipStream_t stream3 = nullptr;    // ... third stream (the tiles of the other shader engines), its events, the per-SE counters
+    hipStream_t stream4 = nullptr;    // ... and a fourth for the two left-over tiles of each pass (VALU)
+    hipEvent_t ev_join4 = nullptr;
     hipEvent_t ev_gate = nullptr, ev_b0 = nullptr, ev_join3 = nullptr;
     uint32_t* se_count = nullptr;     // [2][kSeCount + 1] device counters, one set per pass: arrivals per SE, then arrivals in all
     int sweep_f64_variant = 0;        // option: tiling of the 32-column fp64 pass (0 = 256 columns / 512 threads / 1 per CU; 1, 2 = 128 / 256 / 2, 3 per CU)
