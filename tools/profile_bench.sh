@@ -5,6 +5,7 @@ set -u
 TAG=${1:-r01}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/bench_trace.log" 2>&1 || echo "trace run failed rc=$?"
