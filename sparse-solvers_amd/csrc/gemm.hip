@@ -188,9 +188,11 @@ __device__ uint64_t* g_pass_dbg = nullptr;
 // The hardware deals a grid out statically — every shader engine of every XCD gets the same number of workgroups,
 // whatever its CUs hold — so a launch of 2 * kSeCount workgroups puts two on every SE; a workgroup reads its (XCC, SE)
 // from the hardware registers, leaves at once if that is the solo workgroup's SE (st->solo_where: its 7 other CUs have
-// their two tiles from the main launch), and otherwise takes tile first + 2 * ord + slot, ord = its SE's rank among
-// the others, slot = arrival order on that SE (se_count).  Every CU but the solo workgroup's then carries two tiles.
-template <int HN, int HT, int BPC, int KS = GK, bool DRY = false, int RH = HM, bool BYSE = false>
+// their two tiles from the main launch), and otherwise — if it is the first or second of this launch on its SE
+// (se_count) — takes the next tile from `first` on.  Every CU but the solo workgroup's then carries two tiles.
+// FIXUP: a third launch in the same stream covers whatever tiles that left undone (none, as long as the dealing-out is
+// what was measured; the RESULT must not depend on it).
+template <int HN, int HT, int BPC, int KS = GK, bool DRY = false, int RH = HM, bool BYSE = false, bool FIXUP = false>
 __global__ __launch_bounds__(HT, BPC)
 void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
                      const uint32_t* __restrict__ drows, float* __restrict__ D,
@@ -200,7 +202,7 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
     if (!BYSE && st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
     // (BYSE: arrivals, for the main launch of the same pass — it is held back until all of these hold their CUs: a
     // workgroup of THIS launch that finds its SE full would hold up every workgroup behind it in the grid)
-    if (BYSE && threadIdx.x == 0) __hip_atomic_fetch_add(&se_count[kSeCount], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (BYSE && !FIXUP && threadIdx.x == 0) __hip_atomic_fetch_add(&se_count[kSeCount], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (rcols[0] == 0xffffffffu) return;                        // an empty list (lists are filled from entry 0)
     uint32_t my_tile = 0;
     if (BYSE) {
@@ -214,10 +216,14 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
             uint32_t solo_se = 0xffffffffu;
             if (where != 0u) solo_se = ((((where - 1u) >> 16) & 7u) << 2) | (((where - 1u) >> 13) & 3u);
             uint32_t t = 0xffffffffu;
-            if (se != solo_se) {
+            if (FIXUP) {
+                // third launch of the pass (same stream, afterwards): whatever the second left undone — nothing, unless
+                // the hardware dealt its workgroups out differently than assumed; coverage must not depend on that
+                t = first + __hip_atomic_load(&se_count[kSeCount + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + blockIdx.x;
+            } else if (se != solo_se) {
                 const uint32_t slot = __hip_atomic_fetch_add(&se_count[se], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t ord = se - ((solo_se != 0xffffffffu && se > solo_se) ? 1u : 0u);
-                if (slot < 2u) t = first + 2u * ord + slot;
+                // two per shader engine take the next tile each
+                if (slot < 2u) t = first + __hip_atomic_fetch_add(&se_count[kSeCount + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             s_tile = t;
         }
@@ -912,8 +918,13 @@ hipError_t launch_gemm32se_on(const ss_hip_ctx* ctx, hipStream_t on, const uint3
                               uint32_t first, uint32_t ntiles, const DevState* st, uint32_t* se_count)
 {
     if (ctx->n_pad % 128 != 0 || ctx->ldm % GK != 0 || st == nullptr || se_count == nullptr) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3, GK, false, HM, true>), dim3(2u * kSeCount), dim3(256), kSePad, on,
+    // (option early_se = 2, tests: ONE workgroup per SE, so that half the tiles are left to the fix-up launch)
+    hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3, GK, false, HM, true>), dim3(early_se_wgs(ctx)), dim3(256), kSePad, on,
                        static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, first, se_count);
+    // ... and whatever that left undone (nothing if the workgroups were dealt out as assumed: these then leave at once)
+    if (ntiles > first)
+        hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3, GK, false, HM, true, true>), dim3(ntiles - first), dim3(256), 0, on,
+                           static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, first, se_count);
     return hipGetLastError();
 }
 

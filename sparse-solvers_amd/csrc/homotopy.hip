@@ -588,7 +588,7 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
             HIPCHK(hipEventCreateWithFlags(&ctx->ev_gate, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&ctx->ev_b0, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming));
-            HIPCHK(hipMalloc(&ctx->se_count, 2 * (kSeCount + 1) * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(&ctx->se_count, 2 * (kSeCount + 2) * sizeof(uint32_t)));
             if (hipStreamCreateWithPriority(&ctx->stream4, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); ctx->stream4 = nullptr; }
             if (ctx->stream4) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join4, hipEventDisableTiming));
         }
@@ -620,7 +620,7 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
     HIPCHK(launch_subset_pick_f32(ctx, ws));                        // subset of 256, slots 0..63, the two sweep lists
     // Gs, and a_idx . a_idx seeded into the first pick's cache row for the first inverse update
     HIPCHK(launch_subset_gram_f32(ctx, ws.sub_cols, ws.subg, ws.st, ws.gcache, ws.slot_of, ws.gpitch));
-    if (main_tiles) HIPCHK(hipMemsetAsync(ctx->se_count, 0, 2 * (kSeCount + 1) * sizeof(uint32_t), st));
+    if (main_tiles) HIPCHK(hipMemsetAsync(ctx->se_count, 0, 2 * (kSeCount + 2) * sizeof(uint32_t), st));
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     // second stream: the two 32-column passes, held back until the solo workgroup is resident.  (Enqueued AFTER the
     // solo launch: should the two streams ever share a hardware queue after all, the gate then follows the launch it
@@ -637,7 +637,7 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
             HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_gate, 0));
             HIPCHK(launch_gemm32se_on(ctx, ctx->stream3, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, main_tiles, se_last, ws.st,
                                       ctx->se_count));
-            HIPCHK(launch_wait_count(ctx->stream2, ctx->se_count + kSeCount, 2u * kSeCount, ws.st));
+            HIPCHK(launch_wait_count(ctx->stream2, ctx->se_count + kSeCount, early_se_wgs(ctx), ws.st));
         }
         if (pe0) HIPCHK(hipEventRecord(pe0, ctx->stream2));
         HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, main_tiles));
@@ -649,9 +649,9 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
             HIPCHK(hipEventRecord(ctx->ev_b0, ctx->stream2));                       // (the second list exists, the first pass is complete)
             HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_b0, 0));
             HIPCHK(launch_gemm32se_on(ctx, ctx->stream3, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch, main_tiles, se_last, ws.st,
-                                      ctx->se_count + (kSeCount + 1)));
+                                      ctx->se_count + (kSeCount + 2)));
             HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
-            HIPCHK(launch_wait_count(ctx->stream2, ctx->se_count + (kSeCount + 1) + kSeCount, 2u * kSeCount, ws.st));
+            HIPCHK(launch_wait_count(ctx->stream2, ctx->se_count + (kSeCount + 2) + kSeCount, early_se_wgs(ctx), ws.st));
         }
         HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch, main_tiles));
         if (main_tiles) HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_join3, 0));
@@ -1928,7 +1928,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "early_probe"))   { ctx->early_probe = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_pass"))    { ctx->early_pass = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_adapt"))   { ctx->early_adapt = value ? 1 : 0; return SS_HIP_OK; }
-    if (!std::strcmp(key, "early_se"))      { ctx->early_se = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "early_se"))      { ctx->early_se = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "pass_dbg_ptr"))  {   // developer aid: device buffer of 1 + 4 * 4096 u64 (0 = off), tools/probe_pass_trace.py
         (void)hipSetDevice(ctx->device);
         return sship::set_pass_debug(reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(value))) == hipSuccess ? SS_HIP_OK : SS_HIP_ERUNTIME;

@@ -247,7 +247,7 @@ struct ss_hip_ctx {
     hipStream_t stream4 = nullptr;    // ... and a fourth for the two left-over tiles of each pass (VALU)
     hipEvent_t ev_join4 = nullptr;
     hipEvent_t ev_gate = nullptr, ev_b0 = nullptr, ev_join3 = nullptr;
-    uint32_t* se_count = nullptr;     // [2][kSeCount + 1] device counters, one set per pass: arrivals per SE, then arrivals in all
+    uint32_t* se_count = nullptr;     // [2][kSeCount + 2] device counters, one set per pass: arrivals per SE, arrivals in all, tiles taken
     int sweep_f64_variant = 0;        // option: tiling of the 32-column fp64 pass (0 = 256 columns / 512 threads / 1 per CU; 1, 2 = 128 / 256 / 2, 3 per CU)
     uint64_t solo_seen = 0, solo_failed = 0;   // speculative solves / failed checks since the form was last switched off (private: not the statistics)
     int early_adapt = 1;              // option: the early form's second pass takes its columns from the solo launch's progress (0 = from |c0|)
@@ -406,6 +406,7 @@ hipError_t set_pass_debug(uint64_t* buf);      // developer aid: per-workgroup t
 hipError_t launch_pick_pass_b_f32(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on);
 hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
                              uint32_t tiles128 = 0);
+inline uint32_t early_se_wgs(const ss_hip_ctx* ctx) { return ctx->early_se == 2 ? kSeCount : 2u * kSeCount; }
 // tiles first .. ntiles-1 of the same pass, two per shader engine except the solo workgroup's (early form)
 hipError_t launch_gemm32se_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
                               uint32_t first, uint32_t ntiles, const DevState* st, uint32_t* se_count);
