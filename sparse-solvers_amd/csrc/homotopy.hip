@@ -620,7 +620,7 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
     HIPCHK(launch_subset_pick_f32(ctx, ws));                        // subset of 256, slots 0..63, the two sweep lists
     // Gs, and a_idx . a_idx seeded into the first pick's cache row for the first inverse update
     HIPCHK(launch_subset_gram_f32(ctx, ws.sub_cols, ws.subg, ws.st, ws.gcache, ws.slot_of, ws.gpitch));
-    if (main_tiles) HIPCHK(hipMemsetAsync(ctx->se_count, 0, 2 * (kSeCount + 2) * sizeof(uint32_t), st));
+    // (the counters of the dealing-out were zeroed by k_subset_pick)
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     // second stream: the two 32-column passes, held back until the solo workgroup is resident.  (Enqueued AFTER the
     // solo launch: should the two streams ever share a hardware queue after all, the gate then follows the launch it

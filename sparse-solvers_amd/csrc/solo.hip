@@ -601,8 +601,10 @@ void k_la_top_cand(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32
 __global__ __launch_bounds__(kTcThreads)
 void k_subset_pick(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32_t n, int32_t* __restrict__ slot_of,
                    uint32_t* __restrict__ sw_list, uint32_t* __restrict__ sub_cols, DevState* st,
-                   uint32_t* __restrict__ slot_col, uint32_t subset_cap /* option solo_subset: columns beyond the support */)
+                   uint32_t* __restrict__ slot_col, uint32_t subset_cap /* option solo_subset: columns beyond the support */,
+                   uint32_t* __restrict__ se_count /* counters of the passes dealt out by shader engine, or null */)
 {
+    if (se_count != nullptr && threadIdx.x < 2u * (kSeCount + 2u)) se_count[threadIdx.x] = 0u;
     // (the progress hints of the solo launch that follows, one per subset position: nothing known yet)
     if (threadIdx.x < kSoloWidth) reinterpret_cast<float*>(sub_cols + kSoloWidth)[threadIdx.x] = Lim<float>::max();
     __shared__ __attribute__((aligned(16))) uint64_t s_of[kTcThreads];
@@ -770,7 +772,7 @@ hipError_t launch_subset_pick_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
     if (ws.cand_top == nullptr || ws.nvwg == 0 || ws.sub_cols == nullptr) return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL(k_subset_pick, dim3(1), dim3(kTcThreads), 0, ctx->stream, (const uint64_t*)ws.cand_top, kCandPerBlock * ws.nvwg,
                        (uint32_t)ctx->n, ws.slot_of, ws.sw_list, ws.sub_cols, ws.st, ws.slot_col,
-                       (uint32_t)std::max(0, std::min(ctx->solo_subset, (int)kSoloWidth)));
+                       (uint32_t)std::max(0, std::min(ctx->solo_subset, (int)kSoloWidth)), ctx->se_count);
     return hipGetLastError();
 }
 
