@@ -1,4 +1,5 @@
-"""Developer probe: the early form's two pass tilings (early_pass 2 / 0) at dictionary widths between 20 000 and 131 072."""
+"""Developer probe: the early form with / without the passes dealt out by shader engine (early_se 1 / 0) at dictionary widths
+between 24 000 and 131 072."""
 import os, sys, time
 import numpy as np
 import torch
@@ -19,8 +20,8 @@ for N in (24000, 32768, 49152, 65536, 98304, 131072):
     with sship.Homotopy(Ad) as h:
         del Ad
         out = []
-        for ep in (2, 0, 2, 0):
-            h.set_option("early_pass", ep)
+        for ep in (1, 0, 1, 0):
+            h.set_option("early_se", ep)
             h.solve(sigs[0], 1e-3, 256, out=x)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -28,5 +29,5 @@ for N in (24000, 32768, 49152, 65536, 98304, 131072):
                 h.solve(y, 1e-3, 256, out=x)
             torch.cuda.synchronize()
             out.append("%d: %.3f" % (ep, (time.perf_counter() - t0) / len(sigs[2:]) * 1e3))
-        print("n = %6d  ms/solve by early_pass  %s" % (N, "  ".join(out)), flush=True)
+        print("n = %6d  ms/solve by early_se  %s" % (N, "  ".join(out)), flush=True)
     torch.cuda.empty_cache()
