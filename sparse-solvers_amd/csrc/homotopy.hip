@@ -600,8 +600,8 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
     // instead of 0.37.  So: the main launch takes 14 tiles per SE (two per CU on the solo SE, room for exactly two
     // workgroups per CU: LDS padding), a second launch on a third stream puts two more workgroups on every SE, which
     // pick their tile by where they run and leave at once on the solo workgroup's SE (k_gemm32_tn_f32<BYSE>), and the
-    // two tiles that are left of 512 are formed by the VALU chain (k_cols_gram) on the main stream once the solo launch
-    // is done.  Every CU but one then carries exactly two tiles.
+    // two tiles that are left of 512 are formed by the VALU chain (k_cols_gram) on a fourth stream.  Every CU but one
+    // then carries exactly two tiles.
     uint32_t main_tiles = 0, se_last = 0, tail_c0 = 0, tail_cols = 0;
     if (ctx->early_se && ctx->early_pass == 2 && !probe && ctx->stream3 && ctx->num_cus == 8 * (int)kSeCount &&
         ctx->n_pad % 128 == 0 && ctx->ldm % 256 == 0) {
