@@ -327,6 +327,9 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
 
     h.set_profiling(True)
     h.set_option("profile_every", args.profile_every)
+    # the roofline's launch durations come from HIP events inside the timed region: on every 4th solve (each event costs
+    # stream time; `launches_timed` says how many launches the average is over)
+    h.set_option("profile_solve_every", 4 if args.steps >= 8 else 1)
     h.reset_stats()
     torch.cuda.synchronize()
     if use_dist:
@@ -343,6 +346,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     h.set_profiling(False)
+    h.set_option("profile_solve_every", 1)
 
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)

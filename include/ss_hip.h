@@ -352,6 +352,7 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "gram_symmetric" 1 (default) = G is formed from the GEMM tiles on and above the diagonal, each stored to both
  *                    sides (half the flops, G exactly symmetric); 0 = the full product
  *   "profile_every"  with profiling on, bracket only every k-th fused sweep with events
+ *   "profile_solve_every" with profiling on, only every k-th solve carries events at all (each event costs stream time)
  *   "tie_guard"      0 (default) = the reference's strict `t > 0` (homotopy-cpu.cpp:135,145,151): an
  *                    off-support column that attains max|c| exactly (it tied with an inserted column
  *                    within an ulp) is skipped for good and such a solve runs to max_iterations, as the

@@ -780,7 +780,9 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         TraceEntry* const trace_keep = ws.trace;
         if (!ctx->tracing) ws.trace = nullptr;          // kernels skip the stores
         struct Restore { Workspace<T>& w; TraceEntry* p; ~Restore() { w.trace = p; } } restore{ ws, trace_keep };
-        const bool prof = ctx->profiling != 0;
+        // (option profile_solve_every = k: with profiling on, only every k-th solve carries the HIP events — each costs
+        // stream time, ~0.07 ms per solve in all at 8192 x 65536)
+        const bool prof = ctx->profiling != 0 && (ctx->profile_solve_every <= 1 || (ctx->prof_solve_tick++ % (uint64_t)ctx->profile_solve_every) == 0);
         size_t nprof = 0;
         ctx->prof_kind.clear();
 
@@ -1919,6 +1921,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "zero_on_removal")) { ctx->zero_on_removal = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
+    if (!std::strcmp(key, "profile_solve_every")) { ctx->profile_solve_every = (int)std::max<long>(1, value); ctx->prof_solve_tick = 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(9, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "first_sweep_cols")) { ctx->first_sweep_cols = value > 32 ? 64 : 32; return SS_HIP_OK; }

@@ -286,6 +286,8 @@ struct ss_hip_ctx {
     int tie_guard = 0;       // 0 = the reference's strict t > 0 (homotopy-cpu.cpp:135,145,151); 1 = zero-length step on an exact tie (opt-in)
     int profiling = 0;
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
+    int profile_solve_every = 1;   // ... and only every k-th solve at all
+    uint64_t prof_solve_tick = 0;
     long cache_mib = 2048;   // budget of the lookahead engine's Gram-column cache
     int engine = 1;          // fp32 single-signal Homotopy: 1 = lookahead (cached Gram columns) unless the tolerance is too tight for it, 2 = lookahead always, 0 = one fused sweep per iteration
     int early_solo = 1;        // option: 1 = early form of the speculative engine (iterations on the subset Gram matrix beside the passes over A)
