@@ -1810,7 +1810,7 @@ hipError_t launch_batch_passes(const ss_hip_ctx* ctx, const BatchCols* cols, uin
 {
     for (uint32_t g = 0; g * 64u < nslots; ++g) {
         const hipError_t e = launch_gemm64_tn_f32(ctx, cols->rcols + g * 64u, cols->drows + g * 64u, cols->cache,
-                                                  (uint32_t)ctx->n_pad, nullptr);
+                                                  cols->pitch, nullptr);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -1276,13 +1276,15 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             if (cols_chunk) {
                 // one cache row per slot and round (round 0 = the first pick), a row table per slot, the pass lists
                 const size_t rows_needed = ((size_t)max_iter + 2) * Bc;
+                const size_t pitchc = (np + 1023) / 1024 * 1024;          // (k_la_cq reads whole 1024-column chunks of a row)
                 if (ctx->bcol_cache_rows < rows_needed) {
                     if (ctx->bcol_cache) HIPCHK(hipFree(ctx->bcol_cache));
                     ctx->bcol_cache = nullptr;
                     ctx->bcol_cache_rows = 0;
-                    HIPCHK(hipMalloc(&ctx->bcol_cache, rows_needed * np * sizeof(T)));
+                    HIPCHK(hipMalloc(&ctx->bcol_cache, rows_needed * pitchc * sizeof(T)));
                     ctx->bcol_cache_rows = rows_needed;
                 }
+                bc.pitch = (uint32_t)pitchc;
                 if (ctx->bcol_slot_rows < Bc) {
                     if (ctx->bcol_slot) HIPCHK(hipFree(ctx->bcol_slot));
                     ctx->bcol_slot = nullptr;
@@ -1303,7 +1305,7 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 ctx->stats.batch_col_rounds += 1;
             }
             const T* const Gsrc = cols_chunk ? bc.cache : ctx->gram_full;
-            const uint32_t Gpitch = cols_chunk ? (uint32_t)np : ctx->gram_pitch;
+            const uint32_t Gpitch = cols_chunk ? bc.pitch : ctx->gram_pitch;
 
             const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
             volatile uint32_t* hf = ctx->host_flags;
@@ -1442,7 +1444,7 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
     if (form == 0 && !ctx->gram_full && ctx->engine >= 1 && ctx->batch_cols_min > 0 && B >= (size_t)std::max(2, ctx->batch_cols_min) &&
         (ctx->batch_cols_max <= 0 || B <= (size_t)ctx->batch_cols_max) && ctx->n_pad % 256 == 0) {
         // signals per chunk: at most 448 (7 full passes per round), at most what the cache budget holds, whole passes
-        const double row_bytes = ((double)max_iter + 2.0) * (double)ctx->n_pad * 4.0;
+        const double row_bytes = ((double)max_iter + 2.0) * (double)((ctx->n_pad + 1023) / 1024 * 1024) * 4.0;
         const double fit = (double)ctx->gram_full_gib * 1073741824.0 / row_bytes;
         size_t per = (size_t)std::min<double>(448.0, std::max(0.0, fit));
         if (per >= B) per = B; else per = per / 64 * 64;

@@ -373,7 +373,8 @@ hipError_t launch_gram_guard_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, ui
 // column form of a mid-size batch (no G): the Gram columns of the entering columns are formed round by round,
 // 64 per pass over A, into rows of a cache the batch owns (row = round * nslots + slot, pitch n_pad)
 struct BatchCols {
-    float* cache = nullptr;        // [rounds][nslots][n_pad]
+    float* cache = nullptr;        // [rounds][nslots][pitch]
+    uint32_t pitch = 0;            // row pitch in floats: n_pad rounded up to 1024 (k_la_cq reads whole 1024-column chunks of a row)
     int32_t* bslot = nullptr;      // [nslots][n_pad]: column -> cache row of that slot (-1 = not cached)
     uint32_t* rcols = nullptr;     // [cap] entering columns of the round, compacted (0xffffffff = none)
     uint32_t* drows = nullptr;     // [cap] their cache rows
