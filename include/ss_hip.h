@@ -341,6 +341,9 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    come from those cached columns as in the Gram form; chunks of at most 448 signals; smaller
  *                    batches run one solve per signal; batch_cols_min = 0: never (round-1 behaviour: one solve per
  *                    signal below batch_min, two GEMMs per round from there on)
+ *   "scan_blocks"    workgroups per signal of the step-length scan in the lock-step Gram forms with 64 signals or more
+ *                    (default 8: a launch of 4096 signals x 64 workgroups spends its time on reductions and tickets,
+ *                    not on its 9 bytes per column; same results); 0 = one per 1024 columns
  *   "gram_full_gib"  largest G — and largest column cache of the column form — that may be allocated
  *                    (default 64 GiB; 0 = never form G)
  *   "gram_full_after" opt-in (default 0 = never): single-signal solves (fp32) after which the context forms G

@@ -1787,6 +1787,9 @@ hipError_t launch_tail_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uin
     const uint32_t per_block = kSmallThreads * kScanPerThread;
     uint32_t ns = (n + per_block - 1) / per_block;
     if (ns > ws.dims.pmin_stride) ns = ws.dims.pmin_stride;
+    // (many slots: fewer, longer workgroups per slot — the kernel grid-strides; with 64 per slot a launch of 4096 slots is
+    // 262 144 workgroups whose reductions and tickets, not their 9 bytes per column, set its time; option scan_blocks)
+    if (nslots >= 64u && ctx->scan_blocks > 0 && ns > (uint32_t)ctx->scan_blocks) ns = (uint32_t)ctx->scan_blocks;
     hipLaunchKernelGGL((k_scansel<T>), dim3(ns, nslots), dim3(kSmallThreads), 0, ctx->stream, round, tol,
                        max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
                        nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,

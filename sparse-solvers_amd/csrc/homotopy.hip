@@ -1933,6 +1933,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "early_probe"))   { ctx->early_probe = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_pass"))    { ctx->early_pass = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_adapt"))   { ctx->early_adapt = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "scan_blocks"))   { ctx->scan_blocks = (int)std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "early_se"))      { ctx->early_se = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "pass_dbg_ptr"))  {   // developer aid: device buffer of 1 + 4 * 4096 u64 (0 = off), tools/probe_pass_trace.py
         (void)hipSetDevice(ctx->device);

@@ -248,6 +248,7 @@ struct ss_hip_ctx {
     hipEvent_t ev_join4 = nullptr;
     hipEvent_t ev_gate = nullptr, ev_b0 = nullptr, ev_join3 = nullptr;
     uint32_t* se_count = nullptr;     // [2][kSeCount + 2] device counters, one set per pass: arrivals per SE, arrivals in all, tiles taken
+    int scan_blocks = 8;              // option: workgroups per slot of the batched Gram form's scan (0 = one per 1024 columns)
     int sweep_f64_variant = 0;        // option: tiling of the 32-column fp64 pass (0 = 256 columns / 512 threads / 1 per CU; 1, 2 = 128 / 256 / 2, 3 per CU)
     uint64_t solo_seen = 0, solo_failed = 0;   // speculative solves / failed checks since the form was last switched off (private: not the statistics)
     int early_adapt = 1;              // option: the early form's second pass takes its columns from the solo launch's progress (0 = from |c0|)
