@@ -39,6 +39,10 @@ namespace ss
       public:
         /* uploads (and re-lays-out) the m x n view A to HIP device `device` */
         explicit homotopy_state(const ndspan<T, 2> A, int device = 0);
+        /* the same with an explicit compute mode for this solver (kernelpp/kernel.h): AUTO and HIP upload;
+           a mode this library is not built with (CPU, AVX) uploads nothing and every solve returns
+           error_code::COMPUTE_MODE_DISABLED */
+        homotopy_state(const ndspan<T, 2> A, kernelpp::compute_mode mode, int device = 0);
         ~homotopy_state();
 
         homotopy_state(const homotopy_state&) = delete;
@@ -49,11 +53,15 @@ namespace ss
         size_t cols() const { return _n; }
         /* non-empty when construction failed (no device, out of memory, ...) */
         const std::string& error() const { return _error; }
+        /* the compute mode asked for at construction (AUTO: the process-wide request decides at solve time) */
+        kernelpp::compute_mode mode() const { return _mode; }
 
       private:
+        void init(const ndspan<T, 2> A, int device);
         ss_hip_ctx* _ctx;
         size_t      _m, _n;
         std::string _error;
+        kernelpp::compute_mode _mode;
     };
 
     /* Orthogonal matching pursuit ------------------------------------------ */
@@ -107,6 +115,7 @@ namespace ss
     {
       public:
         explicit irls_device_state(const ndspan<T, 2> A, int device = 0);
+        irls_device_state(const ndspan<T, 2> A, kernelpp::compute_mode mode, int device = 0);
         ~irls_device_state();
 
         irls_device_state(const irls_device_state&) = delete;
@@ -116,11 +125,14 @@ namespace ss
         size_t rows() const { return _m; }
         size_t cols() const { return _n; }
         const std::string& error() const { return _error; }
+        kernelpp::compute_mode mode() const { return _mode; }
 
       private:
+        void init(const ndspan<T, 2> A, int device);
         ss_hip_ctx* _ctx;
         size_t      _m, _n;
         std::string _error;
+        kernelpp::compute_mode _mode;
     };
 
     /* A solver policy which implements the Iteratively Reweighted Least Squares method

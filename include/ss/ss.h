@@ -47,6 +47,13 @@ namespace ss
            copied to the device here; the caller's buffer is not referenced afterwards. */
         solver(const ndspan<T, 2> A) : m(new state_type(A)) {}
 
+        /* The same with an explicit compute mode for this solver (the reference picks the mode inside
+           kernelpp::run, src/lib.cpp:36; here it can also be pinned per solver).  AUTO = the process-wide
+           request (environment variable SS_COMPUTE_MODE, else the best mode available); a mode this library
+           is not built with — it has a HIP back-end only — makes every solve return
+           kernelpp::error_code::COMPUTE_MODE_DISABLED.  For policies whose state takes a mode. */
+        solver(const ndspan<T, 2> A, kernelpp::compute_mode mode) : m(new state_type(A, mode)) {}
+
         solver(solver&& other) : m(std::move(other.m)) {}
 
         ~solver() = default;

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_HIP_ABI_VERSION 2
+#define SS_HIP_ABI_VERSION 3
 
 typedef struct ss_hip_ctx ss_hip_ctx;
 
@@ -249,6 +249,10 @@ typedef struct ss_hip_stats {
                                       dealt out by shader engine (option early_se) — the main launch's share of them (57344 of
                                       65536: the rest runs beside it on another stream); its algorithmic bytes are
                                       m*cols*s + 32*m*s + 32*cols*s                                                                 */
+    /* ABI version 3 */
+    uint64_t tie_reruns;           /* signals solved again in the reference-order engine because a step-length scan met an exact tie
+                                      (option "tie_rerun"): an off-support column attained max|c|, the reference's strict t > 0
+                                      (homotopy-cpu.cpp:143-153) skips it for good, and which rounding hits that is luck                 */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------
@@ -289,7 +293,13 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    sides per pass) only when an uncached column enters — unless the tolerance
  *                    is below 2^-14 (fp32) / 2^-42 (fp64) * ||A^T y||_inf, too tight for Gram-form
  *                    correlations: such a solve runs as 0; 2 = lookahead engine unconditionally;
- *                    0 = one fused 2-RHS sweep per iteration (residual form).
+ *                    0 = one fused 2-RHS sweep per iteration (residual form);
+ *                    3 = reference-order engine (csrc/reforder.hip): the reference's iteration statement for statement
+ *                    — c = A^T(y - A x) re-computed before the direction is formed, two passes over A per iteration —
+ *                    with every reduction in ONE documented order (8 partial sums, term r to partial r & 7, combined
+ *                    ((0+1)+(2+3))+((4+5)+(6+7)), products and sums separately rounded): the path is reproducible bit
+ *                    for bit by any implementation that states the same order.  Slower (2 x 2 GiB per iteration at
+ *                    8192 x 65536); the arbiter of "tie_rerun".
  *   "la_fused"       form of the lookahead engine's iterations: 3 (default, fp32) = speculative resident form:
  *                    one workgroup iterates on a 256-column subset and every breakpoint is re-derived over
  *                    all columns, bit for bit, before anything is committed; 2 = one resident launch on all
@@ -360,6 +370,12 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    off-support column that attains max|c| exactly (it tied with an inserted column
  *                    within an ulp) is skipped for good and such a solve runs to max_iterations, as the
  *                    reference's does; 1 = opt-in fix: that column enters by a zero-length step
+ *   "tie_rerun"      1 (default) = a solve (or a signal of a batch) whose step-length scan met an EXACT tie — an
+ *                    off-support column that attains max|c|, candidate t == 0 — is solved again in the
+ *                    reference-order engine (engine 3) and that result is returned: after such a tie the reference's
+ *                    strict t > 0 decides by rounding whether the path derails, so the fast engines (other summation
+ *                    orders) do not guess; ss_hip_stats::tie_reruns counts them.  0 = keep the fast engine's path
+ *                    (with "tie_guard" = 1 the tie is resolved by the guard and nothing is re-run)
  *   "zero_on_removal" 0 (default) = a coefficient whose column leaves the support keeps the reference's
  *                    x + gamma*d rounding residue (homotopy-cpu.cpp:246-252; 0 or an ulp, and a
  *                    re-inserted column may bounce out again); 1 = opt-in fix: it is set to exactly 0.

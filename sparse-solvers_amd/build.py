@@ -40,6 +40,8 @@ HIP_UNITS = [
     ("homotopy.hip", []),
     ("utils.hip", ["-ffp-contract=off"]),
     ("subgram.hip", []),
+    # reference-order engine: separately rounded products and sums in a fixed order
+    ("reforder.hip", ["-ffp-contract=off"]),
 ]
 
 
@@ -92,14 +94,21 @@ def build_hip(verbose=False):
 
 
 def build_host(verbose=False):
-    """C++14 host library (ss::solver & co.) on top of the C-ABI."""
+    """C++14 host library (ss::solver & co.) on top of the C-ABI: src/lib.cpp + src/solvers/*-hip.cpp
+    (the op<compute_mode::HIP, T> specialisations behind the compute-mode seam)."""
     os.makedirs(LIB, exist_ok=True)
     src = os.path.join(SRC, "lib.cpp")
     if not os.path.exists(src):
         return None
+    srcs = [src]
+    sdir = os.path.join(SRC, "solvers")
+    if os.path.isdir(sdir):
+        srcs += sorted(os.path.join(sdir, f) for f in os.listdir(sdir) if f.endswith(".cpp"))
     so = os.path.join(LIB, "libsparsesolvers.so")
-    if _newer(so, [src] + _headers()):
-        cmd = [CXX, "-std=c++14", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, src,
+    extra_hdrs = [os.path.join(sdir, f) for f in os.listdir(sdir) if f.endswith(".h")] if os.path.isdir(sdir) else []
+    extra_hdrs += [os.path.join(INCLUDE, "kernelpp", f) for f in os.listdir(os.path.join(INCLUDE, "kernelpp"))]
+    if _newer(so, srcs + _headers() + extra_hdrs):
+        cmd = [CXX, "-std=c++14", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, "-I", SRC] + srcs + [
                "-o", so, "-L", LIB, "-lss_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

@@ -307,7 +307,7 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
                uint32_t* __restrict__ gam2, uint32_t* __restrict__ touched2, SlotDims L,
                DevState* st, uint32_t* hflags, TraceEntry* trace, uint32_t trace_cap,
                int zero_on_removal, int tie_guard, uint32_t* ndone, uint32_t nslots,
-               T* __restrict__ tcand, const int32_t* __restrict__ slot_of)
+               T* __restrict__ tcand, const int32_t* __restrict__ slot_of, int tie_exit)
 {
     const uint32_t kcap = L.kcap;
     {   // slot = blockIdx.y
@@ -347,6 +347,7 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
 
     T best = Lim<T>::max();
     uint32_t best_i = 0xffffffffu;
+    bool tie = false;      // an off-support candidate that is exactly 0 (see DevState::tie_stall)
     for (uint32_t base = blockIdx.x * (kSmallThreads * kScanPerThread); base < n;
          base += gridDim.x * (kSmallThreads * kScanPerThread))
 #pragma unroll
@@ -368,11 +369,13 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
                 if (dl != T(0)) {
                     T t = (c_inf - ci) / dl;
                     if (tie_guard && t == T(0) && dl > T(0)) t = Lim<T>::tiny();
+                    if (t == T(0)) tie = true;
                     if (t > T(0) && t < m) m = t;
                 }
                 if (dr != T(0)) {
                     T t = (c_inf + ci) / dr;
                     if (tie_guard && t == T(0) && dr > T(0)) t = Lim<T>::tiny();
+                    if (t == T(0)) tie = true;
                     if (t > T(0) && t < m) m = t;
                 }
             }
@@ -381,6 +384,7 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
             if (better_min(m, i, best, best_i)) { best = m; best_i = i; }
         }
     }
+    if (tie) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     block_reduce_pair<T, false>(best, best_i, sv, si);
     if (threadIdx.x == 0) {
         // the partials are the only data that crosses workgroups in this launch (x, d, insup and the
@@ -390,6 +394,20 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
     }
     if (!arrive_last_relaxed(&st->ticket_scan, gridDim.x, &s_flag)) return;
 
+    // tie stall (the flag moved with L2-bypassing stores before the tickets): the host re-runs this signal in the
+    // reference-order engine — no point in following a path the reference's own rounding may not take
+    if (tie_exit && __hip_atomic_load(&st->tie_stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        if (threadIdx.x == 0) {
+            st->status = kStatusTieRerun;
+            st->c_inf = (double)c_inf;
+            st->iter = round - 1;
+            st->done_round = round;
+            st->need_sweep = 0;
+            st->done = 1;
+            signal_done(hflags, ndone, nslots, round);
+        }
+        return;
+    }
     select_toggle<T>(round, c_inf, gridDim.x, pmin_val, pmin_idx, x, d, insup, gam2, touched2, kcap, st, hflags,
                      true, trace, trace_cap, zero_on_removal, ndone, nslots, slot_of, sv, si, s_cnt);
 }
@@ -1195,11 +1213,13 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
                 if (dl != T(0)) {
                     T t = (c_inf - ci) / dl;
                     if (tie_guard && t == T(0) && dl > T(0)) t = Lim<T>::tiny();
+                    if (t == T(0)) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see DevState::tie_stall)
                     if (t > T(0) && t < m) m = t;
                 }
                 if (dr != T(0)) {
                     T t = (c_inf + ci) / dr;
                     if (tie_guard && t == T(0) && dr > T(0)) t = Lim<T>::tiny();
+                    if (t == T(0)) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (t > T(0) && t < m) m = t;
                 }
             }
@@ -1544,7 +1564,7 @@ hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32
                        max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
                        nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
                        ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,
-                       (T*)nullptr, (const int32_t*)nullptr);
+                       (T*)nullptr, (const int32_t*)nullptr, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0);
     uint32_t gb = round + 1;
     if (gb > ws.kcap) gb = ws.kcap;
     hipLaunchKernelGGL((k_gramupd<T>), dim3(gb, nslots), dim3(kUpdThreads), 0, ctx->stream,
@@ -1794,7 +1814,7 @@ hipError_t launch_tail_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uin
                        max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
                        nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
                        ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,
-                       (T*)nullptr, (const int32_t*)nullptr);
+                       (T*)nullptr, (const int32_t*)nullptr, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0);
     if (cols != nullptr) {
         hipError_t e = launch_batch_cols(ctx, ws.st, nslots, cols->row_base, false, cols->bslot, cols->rcols, cols->drows, cols->cap);
         if (e != hipSuccess) return e;
@@ -1831,7 +1851,24 @@ hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t r
                        max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
                        nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
                        ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, 1u,
-                       ws.tcand, (const int32_t*)ws.slot_of);
+                       ws.tcand, (const int32_t*)ws.slot_of, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0);
+    return hipGetLastError();
+}
+
+// the same launch without the lookahead ranking and without the early exit: the reference-order engine
+// follows the path wherever its own rounding takes it
+template <typename T>
+hipError_t launch_scansel_plain(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol, uint32_t max_iter)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    const uint32_t per_block = kSmallThreads * kScanPerThread;
+    uint32_t ns = (n + per_block - 1) / per_block;
+    if (ns > ws.dims.pmin_stride) ns = ws.dims.pmin_stride;
+    hipLaunchKernelGGL((k_scansel<T>), dim3(ns, 1), dim3(kSmallThreads), 0, ctx->stream, round, tol,
+                       max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
+                       nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
+                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, 1u,
+                       (T*)nullptr, (const int32_t*)nullptr, 0);
     return hipGetLastError();
 }
 
@@ -1886,6 +1923,8 @@ template hipError_t launch_la_omp<double>(const ss_hip_ctx*, Workspace<double>&,
 template hipError_t launch_la_omp_update<float>(const ss_hip_ctx*, Workspace<float>&, float);
 template hipError_t launch_la_omp_update<double>(const ss_hip_ctx*, Workspace<double>&, double);
 template hipError_t launch_la_iter<double>(const ss_hip_ctx*, Workspace<double>&, double, uint32_t);
+template hipError_t launch_scansel_plain<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, float, uint32_t);
+template hipError_t launch_scansel_plain<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t, double, uint32_t);
 template hipError_t launch_la_scansel<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, float, uint32_t);
 template hipError_t launch_la_scansel<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t, double, uint32_t);
 template hipError_t launch_absmax<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t*);

@@ -742,7 +742,7 @@ template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
                ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
                bool omp = false, bool force_residual = false, bool no_solo = false,
-               void* rec_out = nullptr, uint32_t kmax = 0)
+               void* rec_out = nullptr, uint32_t kmax = 0, bool force_ro = false)
 {
     if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
     if (ctx->kind != 0) { set_err(err, errlen, "solve: this context was created for IRLS"); return SS_HIP_EINVAL; }
@@ -793,7 +793,10 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         ctx->host_flags[4] = 0;
         if (prof) HIPCHK(hipEventRecord(ctx->ev_solve0, st));
         copy_in<T>(ctx, ws.y, y, incy, m);
-        const bool la_path = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual;
+        // reference-order engine (reforder.hip; option engine = 3, and the arbiter of tie stalls): the reference's
+        // iteration with every reduction in the documented 8-partial order, two passes over A per iteration
+        const bool ro = !omp && (force_ro || ctx->engine == 3);
+        const bool la_path = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && !ro;
         if (!la_path) {
             HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)ctx->n_pad * sizeof(T), st));
             HIPCHK(hipMemsetAsync(ws.d, 0, (size_t)ctx->n_pad * sizeof(T), st));
@@ -804,11 +807,11 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         if (!la_path) HIPCHK(hipMemcpyAsync(ws.rhs, ws.y, (size_t)ctx->ldm * sizeof(T), hipMemcpyDeviceToDevice, st));
         const size_t rhs_stride = (size_t)ws.dims.b_pad * ctx->ldm;   // r-block -> p-block
 
-        const bool la = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual;
+        const bool la = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && !ro;
         // orthogonal matching pursuit in Gram form (k_la_omp): same cache, same sweeps
         const bool la_omp = omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && ctx->la_fused >= 1;
         bool solo = false, solo_started = false, early = false;
-        uint32_t early_lds_cols = 0;
+        uint32_t early_lds_cols = 0, ro_parts = 0;
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
         bool spec_epilogue = false, pump_enqueued = false;
         auto enqueue_epilogue = [&]() {
@@ -895,6 +898,10 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 // (events were recorded only if a sweep was launched; 4 = the 64-column first sweep, 3 = a 32-column one)
                 if (prof && fc != 0) { ctx->prof_kind.push_back(fc > 32 ? 4 : 3); ++nprof; }
             }
+        } else if (ro) {
+            // c = A^T y in reference order, first pick with the column norm as a chain dot product
+            HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, ws.c, ws.pmax_val, ws.pmax_idx, &ro_parts, ws.st));
+            HIPCHK(launch_ro_init<T>(ctx, ws, ro_parts, tol));
         } else if (!omp) {
             // c = A^T y  (residual_vector with x = 0, homotopy-cpu.cpp:215)
             uint32_t nb1 = 0;
@@ -1001,6 +1008,18 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
                 continue;
             }
+            if (ro) {
+                // homotopy-cpu.cpp:236-272 in its own order: p = A d, q = A^T p, scan + toggle + x update, inverse
+                // update, r = y - A x, c = A^T r, then lambda, the while-test, sign(c_Gamma) and the new direction
+                HIPCHK(launch_ro_mv<T>(ctx, ws, 1));
+                HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs + rhs_stride, ws.q, (T*)nullptr, (uint32_t*)nullptr, nullptr, ws.st));
+                HIPCHK(launch_scansel_plain<T>(ctx, ws, (uint32_t)round, ro_parts, tol, max_iter));
+                HIPCHK(launch_ro_update<T>(ctx, ws, (uint32_t)round));
+                HIPCHK(launch_ro_mv<T>(ctx, ws, 0));
+                HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, ws.c, ws.pmax_val, ws.pmax_idx, nullptr, ws.st));
+                HIPCHK(launch_ro_dir<T>(ctx, ws, ro_parts, tol, max_iter));
+                continue;
+            }
             if (omp) {
                 // orthogonal matching pursuit round: c = A^T r (one right-hand side), pick,
                 // bordered inverse + least squares on the support, new residual
@@ -1030,6 +1049,12 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         if (!hs.done) {
             set_err(err, errlen, "solve: internal error, device loop did not terminate");
             return SS_HIP_ERUNTIME;
+        }
+        if (!ro && !omp && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun)) {
+            // a step-length scan met an exact tie (DevState::tie_stall): whether the strict t > 0 of the reference then
+            // derails the path is decided by rounding — the reference-order engine is the arbiter
+            ctx->stats.tie_reruns += 1;
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, false, false, no_solo, rec_out, kmax, true);
         }
         if (la && hs.status == kStatusRetryPlain) {
             // the early form's first launch used too many columns beyond the prefetched ones: plain form for this solve
@@ -1360,14 +1385,19 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 for (uint32_t b = 0; b < Bc; ++b) copy_out<T>(ctx, Xc + (ptrdiff_t)b * x_stride, incx, ws.x + (size_t)b * np, n);
             }
             HIPCHK(hipStreamSynchronize(st));
+            std::vector<uint32_t> ties;                      // slots whose scan met a tie stall (DevState::tie_stall)
             for (uint32_t b = 0; b < Bc; ++b) {
                 if (!hs[b].done) { set_err(err, errlen, "solve_batch: internal error, a signal did not terminate"); return SS_HIP_ERUNTIME; }
+                if (ctx->tie_rerun && !ctx->tie_guard && (hs[b].status == kStatusTieRerun || (hs[b].status == 0 && hs[b].tie_stall != 0))) {
+                    ties.push_back(b);
+                    continue;
+                }
                 if (hs[b].status != 0) { set_err(err, errlen, "solve_batch: active set outgrew the workspace capacity"); return (int)hs[b].status; }
                 if (iter_out) iter_out[b0 + b] = hs[b].iter;
                 if (err_out) err_out[b0 + b] = hs[b].c_inf;
                 ctx->stats.iterations += hs[b].iter;
             }
-            ctx->stats.solves += Bc;
+            ctx->stats.solves += Bc - (uint32_t)ties.size();
             ctx->stats.batch_rounds += rounds_run;
             if (ncq != 0) {
                 // rounds enqueued behind the end of the batch are no-ops (microseconds): only launches that
@@ -1388,6 +1418,22 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                     rows += r * (r + 1) / 2 + 3 * r;
                 }
                 ctx->stats.cq_bytes += rows * (uint64_t)n * sizeof(T);
+            }
+            // Tie stalls: which implementation's rounding derails on an exact tie is luck (homotopy-cpu.cpp:143-153), so
+            // these signals are solved again, one by one, in the reference-order engine — the chunk's results are out,
+            // its workspace is free.  (A handful per 4096 signals at 8192 x 65536.)
+            for (uint32_t b : ties) {
+                const size_t g = b0 + b;
+                uint32_t it = 0;
+                double e = 0.0;
+                ctx->stats.tie_reruns += 1;
+                const int rc = solve_impl<T>(ctx, Y + (ptrdiff_t)g * y_stride, incy, tol, max_iter,
+                                             X ? X + (ptrdiff_t)g * x_stride : nullptr, incx, &it, &e, err, errlen, false, false, false,
+                                             rec_out ? static_cast<unsigned char*>(rec_out) + g * record_bytes(kmax, sizeof(T)) : nullptr,
+                                             kmax, true);
+                if (rc != SS_HIP_OK) return rc;
+                if (iter_out) iter_out[g] = it;
+                if (err_out) err_out[g] = e;
             }
         }
     } catch (const HipFail& f) {
@@ -1423,6 +1469,9 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                          uint32_t max_iter, float* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
                          double* err_out, char* err, size_t errlen, void* rec_out = nullptr, uint32_t kmax = 0)
 {
+    // reference-order engine: one solve per signal (it is the arbiter, not a throughput path)
+    if (ctx->engine == 3)
+        return solve_batch_seq<float>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
     // lock-step MFMA path once enough signals share the matrix (batch_min option, default 192)
     const bool lockstep = B >= (size_t)std::max(2, ctx->batch_min);
     int form = 0;
@@ -1497,8 +1546,11 @@ int gemv_t_impl(ss_hip_ctx* ctx, const T* r, T* c, int repeats, float* ms_out, c
             HIPCHK(hipMemsetAsync(ws.rhs + ctx->m, 0, (ctx->ldm - ctx->m) * sizeof(T), st));
         uint32_t nb = 0;
         HIPCHK(hipEventRecord(ctx->ev_solve0, st));
-        for (int i = 0; i < repeats; ++i)
-            HIPCHK(launch_sweep<T>(ctx, ws.rhs, 0, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
+        for (int i = 0; i < repeats; ++i) {
+            // (option engine = 3: the reference-order sweep, reforder.hip)
+            if (ctx->engine == 3) HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, ws.c, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
+            else HIPCHK(launch_sweep<T>(ctx, ws.rhs, 0, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
+        }
         HIPCHK(hipEventRecord(ctx->ev_solve1, st));
         copy_out<T>(ctx, c, 1, ws.c, ctx->n);
         HIPCHK(hipStreamSynchronize(st));
@@ -1924,7 +1976,8 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_every")) { ctx->profile_every = (int)std::max<long>(1, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "profile_solve_every")) { ctx->profile_solve_every = (int)std::max<long>(1, value); ctx->prof_solve_tick = 0; return SS_HIP_OK; }
-    if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "tie_rerun"))     { ctx->tie_rerun = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(9, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "first_sweep_cols")) { ctx->first_sweep_cols = value > 32 ? 64 : 32; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_solo"))    { ctx->early_solo = value ? 1 : 0; return SS_HIP_OK; }
@@ -1997,6 +2050,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
         return SS_HIP_OK;
     }
     if (!std::strcmp(key, "engine"))        { *value = ctx->engine; return SS_HIP_OK; }
+    if (!std::strcmp(key, "tie_rerun"))     { *value = ctx->tie_rerun; return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { *value = ctx->la_fused; return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_subset"))   { *value = ctx->solo_subset; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep32_variant")) { *value = ctx->sweep32_variant; return SS_HIP_OK; }

@@ -746,11 +746,13 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 if (dl != 0.f) {
                     float t = (c_inf - ci) / dl;
                     if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
+                    if (t == 0.f) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see DevState::tie_stall)
                     if (t > 0.f && t < m) m = t;
                 }
                 if (dr != 0.f) {
                     float t = (c_inf + ci) / dr;
                     if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
+                    if (t == 0.f) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (t > 0.f && t < m) m = t;
                 }
             }

@@ -1,0 +1,438 @@
+// reforder.hip — the "reference-order" engine (option "engine" = 3): the reference's iteration statement for
+// statement (two transposed sweeps per iteration, the direction formed from the RE-COMPUTED correlations),
+// with every floating-point reduction carried out in one documented, layout-independent order:
+//
+//   * a dot product / GEMV output keeps EIGHT partial sums; term number r (the row index of a transposed sweep,
+//     the column index of  A x  and  A d, the position in the support of the K x K products) goes to partial
+//     r & 7 in ascending r; the partials are combined ((0+1)+(2+3))+((4+5)+(6+7));
+//   * products and sums are separately rounded (this file is compiled with -ffp-contract=off).
+//
+// That is the arithmetic a plain (non-FMA, 8-way unrolled) CPU GEMV performs, and it does not depend on grid
+// size, tiling or thread count: the whole homotopy path — every pick, every step length, every coefficient —
+// is reproducible bit for bit on any implementation that states the same order.  The fast engines (one fused
+// sweep per iteration; Gram form) sum in other orders and agree with it to rounding; where rounding DECIDES
+// (two columns reach the boundary within an ulp: homotopy-cpu.cpp:143-153 then skips the later one for good)
+// they hand the signal to this engine (DevState::tie_stall, homotopy.hip).
+//
+// Reference (paths under /root/reference):
+//   residual_vector            src/solvers/homotopy-cpu.cpp:87-98     -> k_ro_mv (A x), k_ro_sweep (A^T r)
+//   find_max_gamma  p, q       src/solvers/homotopy-cpu.cpp:114-120   -> k_ro_mv (A d), k_ro_sweep (A^T p)
+//   find_max_gamma  scan       src/solvers/homotopy-cpu.cpp:122-163   -> k_scansel (activeset.hip: element-wise)
+//   online_column_inverse      src/linalg/online_inverse.h:183-293    -> k_ro_update
+//   sign / direction / loop    src/solvers/homotopy-cpu.cpp:257-272   -> k_ro_dir
+//   first pick                 src/solvers/homotopy-cpu.cpp:215-229   -> k_ro_init
+//
+// Roofline: HBM (two passes over A per iteration: 2 x m n s bytes).  This engine is the arbiter, not the
+// headline path; its sweep streams 32-byte runs per column (two lanes per column, four partial sums each).
+#include "ss_hip_internal.h"
+#include "ss_hip_device.h"
+
+#include <algorithm>
+
+namespace sship {
+
+template <typename T> struct RoVec;
+template <> struct RoVec<float>  { using V = v4f; static constexpr int VN = 4; static constexpr int LPC = 2; };
+template <> struct RoVec<double> { using V = v2d; static constexpr int VN = 2; static constexpr int LPC = 4; };
+
+constexpr int kRoThreads = 256;
+constexpr int kRoUnroll = 8;            // 8-row groups a lane has in flight (8 x 16 B per lane)
+constexpr uint32_t kRoChunk = 4096;     // rows of the two columns a chain dot product stages in LDS at a time
+
+template <typename T>
+__device__ __forceinline__ T combine8(const T (&s)[8])
+{
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+// the partial sums of one column are spread over LPC neighbouring lanes (VN partials each, classes h*VN ..):
+// every lane of the group receives the combined sum
+template <typename T>
+__device__ __forceinline__ T combine_lanes(const T (&acc)[RoVec<T>::VN])
+{
+    if (RoVec<T>::VN == 4) {
+        T s = (acc[0] + acc[1]) + (acc[2] + acc[RoVec<T>::VN - 1]);
+        s = s + __shfl_xor(s, 1, 64);                 // (0..3) + (4..7)
+        return s;
+    } else {
+        T s = acc[0] + acc[1];                        // 2h, 2h + 1
+        s = s + __shfl_xor(s, 1, 64);                 // (0+1)+(2+3) | (4+5)+(6+7)
+        s = s + __shfl_xor(s, 2, 64);
+        return s;
+    }
+}
+
+// ---- k_ro_sweep: out = A^T v, 8 partial sums per column by row & 7 --------------------------------------
+// LPC lanes per column: lane h of a column reads rows 8 t + h*VN .. + VN - 1 (one 16-byte load) for ascending
+// t and keeps VN partial sums; v sits in LDS.  Per workgroup: max |out| and its first index (inf_norm).
+template <typename T>
+__global__ __launch_bounds__(kRoThreads)
+void k_ro_sweep(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngroups, uint32_t mc,
+                const T* __restrict__ v, T* __restrict__ out, T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx,
+                const DevState* st)
+{
+    using V = typename RoVec<T>::V;
+    constexpr int VN = RoVec<T>::VN, LPC = RoVec<T>::LPC, CPB = kRoThreads / LPC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* lds = reinterpret_cast<T*>(smem);
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    if (st != nullptr && st->done != 0) return;
+    const uint32_t h = threadIdx.x % LPC, cl = threadIdx.x / LPC;
+    const uint32_t nchunks = (ldm + mc - 1) / mc;
+    T best = T(-1);
+    uint32_t best_idx = 0xffffffffu;
+    bool lds_valid = false;
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint32_t col = g * CPB + cl;
+        T acc[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] = T(0);
+        for (uint32_t ch = 0; ch < nchunks; ++ch) {
+            const uint32_t r0 = ch * mc;
+            const uint32_t rows = (ldm - r0 < mc) ? (ldm - r0) : mc;
+            if (nchunks > 1 || !lds_valid) {
+                if (lds_valid) __syncthreads();
+                for (uint32_t i = threadIdx.x * VN; i < rows; i += kRoThreads * VN)
+                    *reinterpret_cast<V*>(&lds[i]) = *reinterpret_cast<const V*>(&v[r0 + i]);
+                __syncthreads();
+                lds_valid = true;
+            }
+            const V* cp = reinterpret_cast<const V*>(At + (size_t)col * ldm + r0) + h;
+            const V* vp = reinterpret_cast<const V*>(lds) + h;
+            const uint32_t nsteps = rows / 8u;                        // rows is a multiple of 256
+            for (uint32_t t = 0; t < nsteps; t += kRoUnroll) {
+                V a[kRoUnroll];
+#pragma unroll
+                for (int u = 0; u < kRoUnroll; ++u) a[u] = __builtin_nontemporal_load(cp + (size_t)(t + u) * LPC);
+#pragma unroll
+                for (int u = 0; u < kRoUnroll; ++u) {
+                    const V b = vp[(t + u) * LPC];
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) acc[e] = acc[e] + a[u][e] * b[e];
+                }
+            }
+        }
+        const T s = combine_lanes<T>(acc);
+        if (h == 0 && col < n) {
+            out[col] = s;
+            const T a = s < T(0) ? -s : s;
+            if (a > best) { best = a; best_idx = col; }               // ascending columns: first maximum kept
+        }
+    }
+    if (pmax_val == nullptr) return;
+    block_reduce_pair<T, true>(best, best_idx, sv, si);
+    if (threadIdx.x == 0) { pmax_val[blockIdx.x] = best; pmax_idx[blockIdx.x] = best_idx; }
+}
+
+// ---- k_ro_mv: r = y - A x over the touched columns (mode 0), p = A d over the support (mode 1) ----------
+// One thread per row; term `col` goes to partial col & 7, columns ascending (the lists are sorted).
+template <typename T>
+__global__ __launch_bounds__(kRoThreads)
+void k_ro_mv(const T* __restrict__ At, SlotDims L, const T* __restrict__ y, const T* __restrict__ coef,
+             const uint32_t* __restrict__ list2, int mode, T* __restrict__ out, const DevState* st)
+{
+    if (st->done) return;
+    const uint32_t i = blockIdx.x * kRoThreads + threadIdx.x;
+    if (i >= L.ldm) return;
+    const uint32_t cnt = mode == 0 ? st->ntouched : st->K;
+    const uint32_t* list = list2 + (size_t)st->cur * L.kcap;
+    T s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = T(0);
+    for (uint32_t j = 0; j < cnt; ++j) {
+        const uint32_t col = list[j];
+        const T prod = At[(size_t)col * L.ldm + i] * coef[col];
+        switch (col & 7u) {                                           // uniform over the launch
+            case 0: s[0] = s[0] + prod; break;
+            case 1: s[1] = s[1] + prod; break;
+            case 2: s[2] = s[2] + prod; break;
+            case 3: s[3] = s[3] + prod; break;
+            case 4: s[4] = s[4] + prod; break;
+            case 5: s[5] = s[5] + prod; break;
+            case 6: s[6] = s[6] + prod; break;
+            default: s[7] = s[7] + prod; break;
+        }
+    }
+    const T sum = combine8<T>(s);
+    // (padding rows stay exactly zero even if x or d went non-finite)
+    out[i] = (i < L.m) ? (mode == 0 ? (y[i] - sum) : sum) : T(0);
+}
+
+// ---- chain dot product of two device columns by one workgroup: both are staged through LDS in chunks, the
+// ---- first LPC lanes walk the 8 partial sums in ascending row order.  The result is valid in thread 0.
+template <typename T>
+__device__ __forceinline__ T ro_chain_dot(const T* __restrict__ a, const T* __restrict__ b, uint32_t ldm, T* lds)
+{
+    using V = typename RoVec<T>::V;
+    constexpr int VN = RoVec<T>::VN, LPC = RoVec<T>::LPC;
+    T acc[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[e] = T(0);
+    for (uint32_t r0 = 0; r0 < ldm; r0 += kRoChunk) {
+        const uint32_t rows = (ldm - r0 < kRoChunk) ? (ldm - r0) : kRoChunk;
+        __syncthreads();                                              // the previous chunk is consumed
+        for (uint32_t i = threadIdx.x * VN; i < rows; i += blockDim.x * VN) {
+            *reinterpret_cast<V*>(&lds[i]) = *reinterpret_cast<const V*>(&a[r0 + i]);
+            *reinterpret_cast<V*>(&lds[kRoChunk + i]) = *reinterpret_cast<const V*>(&b[r0 + i]);
+        }
+        __syncthreads();
+        if (threadIdx.x < (uint32_t)LPC) {
+            const V* ap = reinterpret_cast<const V*>(lds) + threadIdx.x;
+            const V* bp = reinterpret_cast<const V*>(lds + kRoChunk) + threadIdx.x;
+            const uint32_t nsteps = rows / 8u;
+#pragma unroll 8
+            for (uint32_t t = 0; t < nsteps; ++t) {
+                const V x = ap[t * LPC], w = bp[t * LPC];
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[e] = acc[e] + x[e] * w[e];
+            }
+        }
+    }
+    return combine_lanes<T>(acc);                                     // (lanes >= LPC carry zeros; thread 0 reads lanes 0..LPC-1)
+}
+
+// ---- k_ro_init: first pick (homotopy-cpu.cpp:217-229), inv = [1 / ||col||^2] through the norm --------------
+template <typename T>
+__global__ __launch_bounds__(kRoThreads)
+void k_ro_init(const T* __restrict__ At, SlotDims L, const T* __restrict__ c,
+               const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
+               T* __restrict__ d, uint8_t* __restrict__ insup, uint32_t* __restrict__ gam,
+               uint32_t* __restrict__ touched, T* __restrict__ inv0, T tol, int strict_sign,
+               DevState* st, TraceEntry* trace)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* lds = reinterpret_cast<T*>(smem);
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    T c_inf;
+    uint32_t idx;
+    reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, idx, sv, si);
+    const T* col = At + (size_t)idx * L.ldm;
+    const T dot = ro_chain_dot<T>(col, col, L.ldm, lds);
+    if (threadIdx.x == 0) {
+        const T nrm = sqrt(dot);                                      // online_inverse.h:193-201 (xnrm2)
+        const T inv00 = T(1) / (nrm * nrm);
+        const T seed = strict_sign ? c[idx] : c_inf;                  // first-step quirk (homotopy-cpu.cpp:223-227)
+        d[idx] = sign_tol(seed, tol) * inv00;
+        insup[idx] = 1;
+        gam[0] = idx;
+        touched[0] = idx;
+        inv0[0] = inv00;
+        st->done = 0; st->status = 0; st->iter = 0;
+        st->K = 1; st->ntouched = 1; st->idx = idx; st->rank = 0; st->added = 1; st->cur = 0;
+        st->done_round = 0;
+        st->c_inf = (double)c_inf;
+        st->gamma = 0.0;
+        st->dot = (double)dot;
+        if (trace != nullptr) { trace[0].idx = idx; trace[0].added = 1; trace[0].gamma = 0.0; trace[0].c_inf = (double)c_inf; }
+    }
+}
+
+// ---- k_ro_update: online_column_inverse::insert / remove (online_inverse.h:183-293) ------------------------
+// insert: workgroup b < K_new forms u1[.] = a_{Gamma_b} . a_idx (b == rank: a_idx . a_idx) as a chain dot
+// product; the last to arrive forms u2 = inv u1 (8 partials by position & 7), d = 1 / (dot - u1 . u2) and the
+// bordered inverse, element by element, directly in sorted-support order.  remove: the deflated inverse.
+template <typename T>
+__global__ __launch_bounds__(kRoThreads)
+void k_ro_update(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict__ gam2,
+                 T* inv0, T* inv1, T* u1, T* u2, DevState* st)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* lds = reinterpret_cast<T*>(smem);
+    __shared__ T s_d;
+    __shared__ uint32_t s_flag;
+    if (st->done) return;
+    const uint32_t ldm = L.ldm, kcap = L.kcap;
+    const uint32_t cur = st->cur;
+    const uint32_t K_new = st->K;
+    const uint32_t rank = st->rank;
+    const bool added = st->added != 0;
+    const uint32_t* gam_new = gam2 + (size_t)(cur ^ 1u) * kcap;
+    if (added && blockIdx.x < K_new) {
+        const uint32_t b = blockIdx.x;
+        const T v = ro_chain_dot<T>(At + (size_t)gam_new[b] * ldm, At + (size_t)st->idx * ldm, ldm, lds);
+        if (threadIdx.x == 0) {
+            if (b == rank) st->dot = (double)v;
+            else u1[b - (b > rank ? 1u : 0u)] = v;
+        }
+    }
+    if (!arrive_last(&st->ticket_gram, gridDim.x, &s_flag)) return;
+
+    const T* Iold = cur ? inv1 : inv0;
+    T* Inew = cur ? inv0 : inv1;
+    const size_t P = kcap;
+    const uint32_t K_old = added ? K_new - 1 : K_new + 1;
+    if (added) {
+        const uint32_t nn = K_old;
+        for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) {     // u2 = inv * u1 (online_inverse.h:224-225)
+            T s[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] = T(0);
+            for (uint32_t j0 = 0; j0 < nn; j0 += 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (j0 + (uint32_t)k < nn) s[k] = s[k] + Iold[i * P + j0 + k] * u1[j0 + k];
+            }
+            u2[i] = combine8<T>(s);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            T s[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] = T(0);
+            for (uint32_t j0 = 0; j0 < nn; j0 += 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (j0 + (uint32_t)k < nn) s[k] = s[k] + u1[j0 + k] * u2[j0 + k];
+            }
+            const T dotv = (T)load_handoff(&st->dot);
+            s_d = T(1) / (dotv - combine8<T>(s));                     // online_inverse.h:228
+        }
+        __syncthreads();
+        const T dv = s_d;
+        const uint32_t tot = K_new * K_new;
+        for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {    // online_inverse.h:229-248
+            const uint32_t a = e / K_new, b = e - a * K_new;
+            T v;
+            if (a == rank && b == rank) v = dv;
+            else if (a == rank) v = -dv * u2[b - (b > rank ? 1u : 0u)];
+            else if (b == rank) v = -dv * u2[a - (a > rank ? 1u : 0u)];
+            else {
+                const uint32_t oa = a - (a > rank ? 1u : 0u), ob = b - (b > rank ? 1u : 0u);
+                v = Iold[oa * P + ob] + (dv * u2[oa]) * u2[ob];
+            }
+            Inew[a * P + b] = v;
+        }
+    } else {
+        const uint32_t nn = K_old;                                    // online_inverse.h:275-290
+        const T dd = Iold[rank * P + rank];
+        const T sc = -(T(1) / dd);
+        for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) u2[i] = Iold[i * P + rank] * sc;
+        __syncthreads();
+        const uint32_t tot = K_new * K_new;
+        for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
+            const uint32_t a = e / K_new, b = e - a * K_new;
+            const uint32_t oa = a + (a >= rank ? 1u : 0u), ob = b + (b >= rank ? 1u : 0u);
+            Inew[a * P + b] = Iold[oa * P + ob] + (-dd * u2[oa]) * u2[ob];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st->cur = cur ^ 1u;
+}
+
+// ---- k_ro_dir: lambda = ||c||_inf of the correlations just re-computed, the loop's while-test
+// ---- (homotopy-cpu.cpp:270-272), sign(c_Gamma) with the dead zone and direction = inv * sign (:257-267) -----
+template <typename T>
+__global__ __launch_bounds__(kUpdThreads)
+void k_ro_dir(const T* __restrict__ c, const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
+              T* __restrict__ d, const uint32_t* __restrict__ gam2, const T* inv0, const T* inv1, T* sgn, SlotDims L,
+              T tol, uint32_t max_iter, DevState* st, uint32_t* hflags, uint32_t* ndone)
+{
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    if (st->done) return;
+    T c_inf;
+    uint32_t imax;
+    reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, imax, sv, si);
+    const uint32_t iter = st->iter;
+    if (!(iter < max_iter && c_inf > tol)) {
+        if (threadIdx.x == 0) {
+            st->c_inf = (double)c_inf;
+            st->done_round = iter + 1u;
+            st->done = 1;
+            signal_done(hflags, ndone, 1u, iter + 1u);
+        }
+        return;
+    }
+    const uint32_t kcap = L.kcap;
+    const uint32_t cur = st->cur;                                     // (k_ro_update has flipped it)
+    const uint32_t K = st->K;
+    const uint32_t K_old = st->added ? K - 1u : K + 1u;
+    const uint32_t* gam = gam2 + (size_t)cur * kcap;
+    const uint32_t* gam_old = gam2 + (size_t)(cur ^ 1u) * kcap;
+    const T* I = cur ? inv1 : inv0;
+    const size_t P = kcap;
+    for (uint32_t a = threadIdx.x; a < K; a += blockDim.x) sgn[a] = sign_tol(c[gam[a]], tol);
+    for (uint32_t j = threadIdx.x; j < K_old; j += blockDim.x) d[gam_old[j]] = T(0);
+    __syncthreads();
+    for (uint32_t a = threadIdx.x; a < K; a += blockDim.x) {
+        T s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = T(0);
+        for (uint32_t b0 = 0; b0 < K; b0 += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (b0 + (uint32_t)k < K) s[k] = s[k] + I[a * P + b0 + k] * sgn[b0 + k];
+        }
+        d[gam[a]] = combine8<T>(s);
+    }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------
+template <typename T>
+hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, T* out, T* pmax_val, uint32_t* pmax_idx, uint32_t* nblocks_out,
+                           const DevState* st)
+{
+    constexpr uint32_t CPB = kRoThreads / RoVec<T>::LPC;
+    const uint32_t ngroups = ctx->n_pad / CPB;                        // n_pad is a multiple of 256
+    uint32_t mc = (uint32_t)(65536 / sizeof(T));
+    if (mc > ctx->ldm) mc = ctx->ldm;
+    uint32_t grid = std::min<uint32_t>(ngroups, kMaxSweepBlocks);
+    if (nblocks_out) *nblocks_out = grid;
+    hipLaunchKernelGGL((k_ro_sweep<T>), dim3(grid), dim3(kRoThreads), (size_t)mc * sizeof(T), ctx->stream,
+                       static_cast<const T*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, ngroups, mc, v, out, pmax_val, pmax_idx, st);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_ro_mv(const ss_hip_ctx* ctx, Workspace<T>& ws, int mode)
+{
+    const uint32_t blocks = (ctx->ldm + kRoThreads - 1) / kRoThreads;
+    T* out = mode == 0 ? ws.rhs : ws.rhs + (size_t)ws.dims.b_pad * ctx->ldm;
+    hipLaunchKernelGGL((k_ro_mv<T>), dim3(blocks), dim3(kRoThreads), 0, ctx->stream, static_cast<const T*>(ctx->At), ws.dims,
+                       (const T*)ws.y, mode == 0 ? (const T*)ws.x : (const T*)ws.d,
+                       mode == 0 ? (const uint32_t*)ws.touched : (const uint32_t*)ws.gam, mode, out, (const DevState*)ws.st);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_ro_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol)
+{
+    hipLaunchKernelGGL((k_ro_init<T>), dim3(1), dim3(kRoThreads), 2 * (size_t)kRoChunk * sizeof(T), ctx->stream,
+                       static_cast<const T*>(ctx->At), ws.dims, (const T*)ws.c, (const T*)ws.pmax_val,
+                       (const uint32_t*)ws.pmax_idx, nparts, ws.d, ws.insup, ws.gam, ws.touched, ws.inv[0], tol,
+                       ctx->strict_sign, ws.st, ws.trace);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_ro_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round)
+{
+    uint32_t gb = round + 1;                                          // support size after this round is <= round + 1
+    if (gb > ws.kcap) gb = ws.kcap;
+    hipLaunchKernelGGL((k_ro_update<T>), dim3(gb), dim3(kRoThreads), 2 * (size_t)kRoChunk * sizeof(T), ctx->stream,
+                       static_cast<const T*>(ctx->At), ws.dims, (const uint32_t*)ws.gam, ws.inv[0], ws.inv[1], ws.u1, ws.u2, ws.st);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_ro_dir(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, uint32_t max_iter)
+{
+    hipLaunchKernelGGL((k_ro_dir<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, (const T*)ws.c, (const T*)ws.pmax_val,
+                       (const uint32_t*)ws.pmax_idx, nparts, ws.d, (const uint32_t*)ws.gam, (const T*)ws.inv[0], (const T*)ws.inv[1],
+                       ws.sgn, ws.dims, tol, max_iter, ws.st, ctx->dev_flags, ws.ndone);
+    return hipGetLastError();
+}
+
+#define SS_RO_INST(T)                                                                                                          \
+    template hipError_t launch_ro_sweep<T>(const ss_hip_ctx*, const T*, T*, T*, uint32_t*, uint32_t*, const DevState*);       \
+    template hipError_t launch_ro_mv<T>(const ss_hip_ctx*, Workspace<T>&, int);                                               \
+    template hipError_t launch_ro_init<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, T);                                     \
+    template hipError_t launch_ro_update<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t);                                      \
+    template hipError_t launch_ro_dir<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, T, uint32_t);
+SS_RO_INST(float)
+SS_RO_INST(double)
+#undef SS_RO_INST
+
+}  // namespace sship

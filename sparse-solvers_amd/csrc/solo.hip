@@ -83,7 +83,7 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
                  const uint32_t* __restrict__ log, const uint8_t* __restrict__ sub_pos,
                  const DevState* __restrict__ st, uint32_t* __restrict__ v_max, uint64_t* __restrict__ v_min,
                  uint32_t nvwg, float* __restrict__ tcand, uint64_t* __restrict__ cand_top, int tie_guard, uint32_t nrows,
-                 uint64_t* dbg)
+                 uint64_t* dbg, uint32_t* tie_flag)
 {
     uint64_t tsv[8];
     tsv[0] = wall_clock64();
@@ -293,11 +293,13 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
                     if (dl != 0.f) {
                         float t = (c_inf - ci2) / dl;
                         if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
+                        if (t == 0.f) __hip_atomic_store(tie_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see DevState::tie_stall)
                         if (t > 0.f && t < m) m = t;
                     }
                     if (dr != 0.f) {
                         float t = (c_inf + ci2) / dr;
                         if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
+                        if (t == 0.f) __hip_atomic_store(tie_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (t > 0.f && t < m) m = t;
                     }
                 }
@@ -840,7 +842,7 @@ hipError_t launch_la_verify_f32(ss_hip_ctx* ctx, Workspace<float>& ws)
     hipLaunchKernelGGL(k_la_verify, dim3(ws.nvwg), dim3(kVfyThreads), 0, ctx->stream, (uint32_t)ctx->n, ws.gram_is_full ? 1 : 0,
                        (const float*)ws.gcache, ws.gpitch, (const int32_t*)ws.slot_of, (const float*)ws.c0,
                        (const uint32_t*)ws.solo_log, (const uint8_t*)ws.sub_pos, (const DevState*)ws.st, ws.v_max, ws.v_min,
-                       ws.nvwg, ws.tcand, ws.cand_top, ctx->tie_guard, ws.gram_is_full ? ctx->n_pad : ws.gcap, ws.la_dbg);
+                       ws.nvwg, ws.tcand, ws.cand_top, ctx->tie_guard, ws.gram_is_full ? ctx->n_pad : ws.gcap, ws.la_dbg, &ws.st->tie_stall);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     CommitArgs ca;

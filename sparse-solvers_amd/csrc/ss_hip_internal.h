@@ -26,6 +26,9 @@ constexpr uint32_t kStatusRetryResidual = 100;
 // DevState::status raised by the early form of the speculative engine when its first launch used more columns
 // outside the prefetched ones than two fill-in passes fetch (the host re-runs the solve in the plain form).
 constexpr uint32_t kStatusRetryPlain = 101;
+// DevState::status raised by a step-length scan that met a tie stall (DevState::tie_stall) when the host asked for an early
+// exit: the signal is re-run in the reference-order engine (never leaves the library).
+constexpr uint32_t kStatusTieRerun = 102;
 // Gram form is used while tolerance >= guard * ||A^T y||_inf: 2^-14 in fp32, 2^-42 in fp64 (eps x ~1000)
 constexpr double kGramGuard = 1.0 / 16384.0;
 constexpr double kGramGuard64 = 1.0 / 4398046511104.0;
@@ -71,7 +74,10 @@ struct DevState {
     uint32_t solo_started; // early form: set by the solo launch when it begins (the passes over A on the second stream wait for it)
     uint32_t subg_active;  // early form: 1 while the solo launches of this solve run on the subset Gram matrix Gs (until their first commit)
     uint32_t solo_where;   // early form: (XCC_ID << 16 | HW_ID) of the solo workgroup + 1 (0 = none): the passes keep off its shader engine
-    uint32_t pad0_[3];
+    uint32_t tie_stall;    // a step-length scan met an off-support column whose candidate is exactly 0: it attains max|c| (a tie within
+                           // rounding) and the reference's strict t > 0 (homotopy-cpu.cpp:143-153) skips it for good.  Which implementation
+                           // hits that is rounding luck: the host re-runs such a signal in the reference-order engine (reforder.hip)
+    uint32_t pad0_[2];
     // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
     uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
     uint32_t pad1_[31];
@@ -285,6 +291,7 @@ struct ss_hip_ctx {
     int strict_sign = 0;
     int zero_on_removal = 0; // 0 = the reference's x + gamma*d residue on a leaving column (homotopy-cpu.cpp:252); 1 = exact 0 (opt-in)
     int tie_guard = 0;       // 0 = the reference's strict t > 0 (homotopy-cpu.cpp:135,145,151); 1 = zero-length step on an exact tie (opt-in)
+    int tie_rerun = 1;       // 1 = a solve whose scan met a tie stall (DevState::tie_stall) is re-run in the reference-order engine
     int profiling = 0;
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
     int profile_solve_every = 1;   // ... and only every k-th solve at all
@@ -344,6 +351,17 @@ hipError_t launch_rp(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots);
 template <typename T>
 hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round,
                                  uint32_t nparts, T tol, uint32_t max_iter);
+// the scan + select + toggle + x update of one iteration on its own (reference-order engine)
+template <typename T>
+hipError_t launch_scansel_plain(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol, uint32_t max_iter);
+// ---- reference-order engine (reforder.hip): every reduction in the documented 8-partial order ------------
+template <typename T>
+hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, T* out, T* pmax_val, uint32_t* pmax_idx, uint32_t* nblocks_out,
+                           const DevState* st);
+template <typename T> hipError_t launch_ro_mv(const ss_hip_ctx* ctx, Workspace<T>& ws, int mode);     // 0: r = y - A x, 1: p = A d
+template <typename T> hipError_t launch_ro_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol);
+template <typename T> hipError_t launch_ro_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round);
+template <typename T> hipError_t launch_ro_dir(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, uint32_t max_iter);
 // list[0..count) = 128-row tiles that still hold a running signal, list[rows/128] = count
 hipError_t launch_tile_list(const ss_hip_ctx* ctx, const DevState* st, uint32_t nslots, uint32_t rows,
                             uint32_t* list);

@@ -68,6 +68,7 @@ class Stats(ctypes.Structure):
         ("sweep64_bytes", ctypes.c_uint64),
         ("batch_col_rounds", ctypes.c_uint64),
         ("sweep32_timed_cols", ctypes.c_uint64),
+        ("tie_reruns", ctypes.c_uint64),
     ]
 
 

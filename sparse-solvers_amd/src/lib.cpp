@@ -1,12 +1,19 @@
 /*
  * lib.cpp — C++14 host library behind include/ss/*.h.  The counterpart of the reference's
- * src/lib.cpp:28-46 (policy -> kernel glue): homotopy_policy::run forwards to the HIP
- * implementation through the C-ABI of include/ss_hip.h.  There is no CPU path here: if no
- * MI355X is usable the result is the error alternative, never a silent fallback.
+ * src/lib.cpp:28-46 (policy -> kernel glue): homotopy_policy::run goes through the compute-mode
+ * dispatcher (kernelpp/kernel.h) to solve_homotopy::op<compute_mode::HIP, T> (solvers/homotopy-hip.cpp),
+ * which calls the C-ABI of include/ss_hip.h.  HIP is the only mode built: there is no CPU path here — a
+ * request for one yields error_code::COMPUTE_MODE_DISABLED, a missing MI355X the error alternative,
+ * never a silent fallback.
  */
 #include <ss/ss.h>
+#include <kernelpp/kernel.h>
 
+#include "solvers/homotopy.h"
 #include "ss_hip.h"
+
+#include <cctype>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -15,6 +22,65 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+namespace kernelpp
+{
+    /* ---- the compute-mode request (kernelpp/kernel.h) ------------------------------------------------ */
+    namespace
+    {
+        std::mutex& mode_mutex() { static std::mutex mx; return mx; }
+        bool g_mode_set = false;
+        compute_mode g_mode = compute_mode::AUTO;
+    }
+
+    const char* to_string(compute_mode m)
+    {
+        switch (m) {
+            case compute_mode::AUTO: return "AUTO";
+            case compute_mode::CPU:  return "CPU";
+            case compute_mode::AVX:  return "AVX";
+            case compute_mode::HIP:  return "HIP";
+        }
+        return "?";
+    }
+
+    bool parse_mode(const char* text, compute_mode& out)
+    {
+        if (!text) return false;
+        std::string t(text);
+        for (char& ch : t) ch = (char)std::toupper((unsigned char)ch);
+        if (t == "AUTO" || t.empty()) { out = compute_mode::AUTO; return true; }
+        if (t == "HIP" || t == "GPU") { out = compute_mode::HIP; return true; }
+        if (t == "CPU") { out = compute_mode::CPU; return true; }
+        if (t == "AVX") { out = compute_mode::AVX; return true; }
+        return false;
+    }
+
+    compute_mode requested_mode()
+    {
+        std::lock_guard<std::mutex> lock(mode_mutex());
+        if (!g_mode_set) {
+            compute_mode m = compute_mode::AUTO;
+            if (!parse_mode(std::getenv("SS_COMPUTE_MODE"), m)) m = compute_mode::AUTO;
+            g_mode = m;
+            g_mode_set = true;
+        }
+        return g_mode;
+    }
+
+    void set_requested_mode(compute_mode m)
+    {
+        std::lock_guard<std::mutex> lock(mode_mutex());
+        g_mode = m;
+        g_mode_set = true;
+    }
+
+    /* HIP: a device is visible to this process.  CPU / AVX: this library has no such implementation. */
+    bool mode_available(compute_mode m)
+    {
+        return m == compute_mode::HIP && ss_hip_device_count() > 0;
+    }
+}
 
 namespace ss
 {
@@ -28,186 +94,115 @@ namespace ss
                                   int dev, char* err, size_t len)
         { return ss_hip_homotopy_create_f64(A, m, n, rs, cs, dev, err, len); }
 
-        inline int solve(ss_hip_ctx* c, const float* y, ptrdiff_t incy, float tol, uint32_t it,
-                         float* x, ptrdiff_t incx, uint32_t* io, double* eo, char* err, size_t len)
-        { return ss_hip_homotopy_solve_f32(c, y, incy, tol, it, x, incx, io, eo, err, len); }
+        inline ss_hip_ctx* create_irls(const float* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, int dev, char* err, size_t len)
+        { return ss_hip_irls_create_f32(A, m, n, rs, cs, dev, err, len); }
+        inline ss_hip_ctx* create_irls(const double* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, int dev, char* err, size_t len)
+        { return ss_hip_irls_create_f64(A, m, n, rs, cs, dev, err, len); }
 
-        inline int solve(ss_hip_ctx* c, const double* y, ptrdiff_t incy, double tol, uint32_t it,
-                         double* x, ptrdiff_t incx, uint32_t* io, double* eo, char* err, size_t len)
-        { return ss_hip_homotopy_solve_f64(c, y, incy, tol, it, x, incx, io, eo, err, len); }
-
-        inline int solve_omp(ss_hip_ctx* c, const float* y, ptrdiff_t incy, float tol, uint32_t it,
-                             float* x, ptrdiff_t incx, uint32_t* io, double* eo, char* err, size_t len)
-        { return ss_hip_omp_solve_f32(c, y, incy, tol, it, x, incx, io, eo, err, len); }
-
-        inline int solve_omp(ss_hip_ctx* c, const double* y, ptrdiff_t incy, double tol, uint32_t it,
-                             double* x, ptrdiff_t incx, uint32_t* io, double* eo, char* err, size_t len)
-        { return ss_hip_omp_solve_f64(c, y, incy, tol, it, x, incx, io, eo, err, len); }
-
-        template <typename T>
-        kernelpp::maybe<omp_report> run_hip_omp(
-            homotopy_state<T>& st, const ndspan<T> y, T tol, uint32_t maxiter, ndspan<T> x)
+        /* the mode a state built with `mode` will run in: its own, else the process-wide request */
+        inline kernelpp::compute_mode effective(kernelpp::compute_mode mode)
         {
-            if (!st.ctx())
-                return kernelpp::error(st.error().empty() ? "omp: no device context" : st.error());
-            if (y.size() != st.rows() || x.size() != st.cols())
-                return kernelpp::error("omp: vector lengths do not match the shape of A",
-                                       kernelpp::error_code::INVALID_ARGUMENT);
-            char msg[512] = { 0 };
-            omp_report rep{ 0u, 0.0 };
-            const int rc = solve_omp(st.ctx(), y.data(), (ptrdiff_t)y.strides()[0], tol, maxiter,
-                                     x.data(), (ptrdiff_t)x.strides()[0], &rep.iter, &rep.solution_error,
-                                     msg, sizeof(msg));
-            if (rc != SS_HIP_OK)
-                return kernelpp::error(msg, rc == SS_HIP_EINVAL ? kernelpp::error_code::INVALID_ARGUMENT
-                                                                : kernelpp::error_code::KERNEL_FAILED);
-            return rep;
+            return mode != kernelpp::compute_mode::AUTO ? mode : kernelpp::requested_mode();
         }
-
-        template <typename T>
-        kernelpp::maybe<homotopy_report> run_hip(
-            homotopy_state<T>& st, const ndspan<T> y, T tol, uint32_t maxiter, ndspan<T> x)
+        inline bool wants_device(kernelpp::compute_mode mode)
         {
-            if (!st.ctx())
-                return kernelpp::error(st.error().empty() ? "homotopy: no device context" : st.error());
-            if (y.size() != st.rows())
-                return kernelpp::error("homotopy: length of y does not match the rows of A",
-                                       kernelpp::error_code::INVALID_ARGUMENT);
-            if (x.size() != st.cols())
-                return kernelpp::error("homotopy: length of x does not match the columns of A",
-                                       kernelpp::error_code::INVALID_ARGUMENT);
-            char msg[512] = { 0 };
-            homotopy_report rep{ 0u, 0.0 };
-            const int rc = solve(st.ctx(), y.data(), (ptrdiff_t)y.strides()[0], tol, maxiter,
-                                 x.data(), (ptrdiff_t)x.strides()[0], &rep.iter, &rep.solution_error,
-                                 msg, sizeof(msg));
-            if (rc != SS_HIP_OK)
-                return kernelpp::error(msg, rc == SS_HIP_EINVAL ? kernelpp::error_code::INVALID_ARGUMENT
-                                                                : kernelpp::error_code::KERNEL_FAILED);
-            return rep;
-        }
-    }
-
-    /* Live solver states by the matrix view they were built from: reconstruct_signal(A, x, y) finds the
-       device copy of A there (the one a solver<T, P>(A) of the same view made) instead of touching the
-       host matrix. */
-    namespace
-    {
-        struct live_view
-        {
-            const void* data; size_t m, n; ptrdiff_t rs, cs; bool f64; ss_hip_ctx* ctx;
-        };
-        std::mutex& live_mutex() { static std::mutex mx; return mx; }
-        std::vector<live_view>& live_views() { static std::vector<live_view> v; return v; }
-
-        void register_view(const void* data, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, bool f64, ss_hip_ctx* ctx)
-        {
-            std::lock_guard<std::mutex> lock(live_mutex());
-            live_views().push_back(live_view{ data, m, n, rs, cs, f64, ctx });
-        }
-        void unregister_view(ss_hip_ctx* ctx)
-        {
-            std::lock_guard<std::mutex> lock(live_mutex());
-            auto& v = live_views();
-            v.erase(std::remove_if(v.begin(), v.end(), [ctx](const live_view& e) { return e.ctx == ctx; }), v.end());
+            const kernelpp::compute_mode e = effective(mode);
+            return e == kernelpp::compute_mode::AUTO || e == kernelpp::compute_mode::HIP;
         }
     }
 
     /* Homotopy solver ----------------------------------------------------- */
 
     template <typename T>
-    homotopy_state<T>::homotopy_state(const ndspan<T, 2> A, int device)
-        : _ctx(nullptr), _m(A.shape()[0]), _n(A.shape()[1])
+    void homotopy_state<T>::init(const ndspan<T, 2> A, int device)
     {
+        if (!wants_device(_mode)) {
+            /* a mode that is not built: nothing is uploaded; solve() reports COMPUTE_MODE_DISABLED */
+            _error = std::string("compute mode ") + kernelpp::to_string(effective(_mode)) + " is not built into this library";
+            return;
+        }
         char msg[512] = { 0 };
         _ctx = create(A.data(), _m, _n, (ptrdiff_t)A.strides()[0], (ptrdiff_t)A.strides()[1],
                       device, msg, sizeof(msg));
         if (!_ctx) _error = msg;
-        else register_view(A.data(), _m, _n, (ptrdiff_t)A.strides()[0], (ptrdiff_t)A.strides()[1], sizeof(T) == 8, _ctx);
+    }
+
+    template <typename T>
+    homotopy_state<T>::homotopy_state(const ndspan<T, 2> A, int device)
+        : _ctx(nullptr), _m(A.shape()[0]), _n(A.shape()[1]), _mode(kernelpp::compute_mode::AUTO)
+    {
+        init(A, device);
+    }
+
+    template <typename T>
+    homotopy_state<T>::homotopy_state(const ndspan<T, 2> A, kernelpp::compute_mode mode, int device)
+        : _ctx(nullptr), _m(A.shape()[0]), _n(A.shape()[1]), _mode(mode)
+    {
+        init(A, device);
     }
 
     template <typename T>
     homotopy_state<T>::~homotopy_state()
     {
-        if (_ctx) {
-            unregister_view(_ctx);
-            ss_hip_homotopy_destroy(_ctx);
-        }
+        if (_ctx) ss_hip_homotopy_destroy(_ctx);
     }
 
     template class homotopy_state<float>;
     template class homotopy_state<double>;
 
+    /* policy -> kernel glue (reference: src/lib.cpp:30-46, kernelpp::run<solve_homotopy>(...)): the mode is the
+       solver's own if it was built with one, else the process-wide request */
     kernelpp::maybe<homotopy_report> homotopy_policy::run(
         homotopy_state<float>& st, const ndspan<float> y, float tol, uint32_t maxiter, ndspan<float> x)
     {
-        return run_hip<float>(st, y, tol, maxiter, x);
+        return kernelpp::run_with<solve_homotopy, kernelpp::maybe<homotopy_report>>(effective(st.mode()), st, y, tol, maxiter, x);
     }
 
     kernelpp::maybe<homotopy_report> homotopy_policy::run(
         homotopy_state<double>& st, const ndspan<double> y, double tol, uint32_t maxiter, ndspan<double> x)
     {
-        return run_hip<double>(st, y, tol, maxiter, x);
+        return kernelpp::run_with<solve_homotopy, kernelpp::maybe<homotopy_report>>(effective(st.mode()), st, y, tol, maxiter, x);
     }
 
     kernelpp::maybe<omp_report> omp_policy::run(
         homotopy_state<float>& st, const ndspan<float> y, float tol, uint32_t maxiter, ndspan<float> x)
     {
-        return run_hip_omp<float>(st, y, tol, maxiter, x);
+        return kernelpp::run_with<solve_omp, kernelpp::maybe<omp_report>>(effective(st.mode()), st, y, tol, maxiter, x);
     }
 
     kernelpp::maybe<omp_report> omp_policy::run(
         homotopy_state<double>& st, const ndspan<double> y, double tol, uint32_t maxiter, ndspan<double> x)
     {
-        return run_hip_omp<double>(st, y, tol, maxiter, x);
+        return kernelpp::run_with<solve_omp, kernelpp::maybe<omp_report>>(effective(st.mode()), st, y, tol, maxiter, x);
     }
 
     /* IRLS ---------------------------------------------------------------- */
 
-    namespace
-    {
-        inline ss_hip_ctx* create_irls(const float* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, int dev, char* err, size_t len)
-        { return ss_hip_irls_create_f32(A, m, n, rs, cs, dev, err, len); }
-        inline ss_hip_ctx* create_irls(const double* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, int dev, char* err, size_t len)
-        { return ss_hip_irls_create_f64(A, m, n, rs, cs, dev, err, len); }
-        inline int solve_irls(ss_hip_ctx* c, const float* y, ptrdiff_t incy, float tol, uint32_t it, float* x, ptrdiff_t incx,
-                              uint32_t* io, double* eo, int* spd, char* err, size_t len)
-        { return ss_hip_irls_solve_f32(c, y, incy, tol, it, x, incx, io, eo, spd, err, len); }
-        inline int solve_irls(ss_hip_ctx* c, const double* y, ptrdiff_t incy, double tol, uint32_t it, double* x, ptrdiff_t incx,
-                              uint32_t* io, double* eo, int* spd, char* err, size_t len)
-        { return ss_hip_irls_solve_f64(c, y, incy, tol, it, x, incx, io, eo, spd, err, len); }
-
-        template <typename T>
-        kernelpp::maybe<irls_report> run_hip_irls(
-            irls_device_state<T>& st, const ndspan<T> y, T tol, uint32_t maxiter, ndspan<T> x)
-        {
-            if (!st.ctx())
-                return kernelpp::error(st.error().empty() ? "irls: no device context" : st.error());
-            if (y.size() != st.rows() || x.size() != st.cols())
-                return kernelpp::error("irls: vector lengths do not match the shape of A",
-                                       kernelpp::error_code::INVALID_ARGUMENT);
-            char msg[512] = { 0 };
-            irls_report rep{ 0u, 0.0, false };
-            int spd = 0;
-            const int rc = solve_irls(st.ctx(), y.data(), (ptrdiff_t)y.strides()[0], tol, maxiter,
-                                      x.data(), (ptrdiff_t)x.strides()[0], &rep.iter, &rep.solution_error, &spd,
-                                      msg, sizeof(msg));
-            if (rc != SS_HIP_OK)
-                return kernelpp::error(msg, rc == SS_HIP_EINVAL ? kernelpp::error_code::INVALID_ARGUMENT
-                                                                : kernelpp::error_code::KERNEL_FAILED);
-            rep.spd_failure = spd != 0;
-            return rep;
-        }
-    }
-
     template <typename T>
-    irls_device_state<T>::irls_device_state(const ndspan<T, 2> A, int device)
-        : _ctx(nullptr), _m(A.shape()[0]), _n(A.shape()[1])
+    void irls_device_state<T>::init(const ndspan<T, 2> A, int device)
     {
+        if (!wants_device(_mode)) {
+            _error = std::string("compute mode ") + kernelpp::to_string(effective(_mode)) + " is not built into this library";
+            return;
+        }
         char msg[512] = { 0 };
         _ctx = create_irls(A.data(), _m, _n, (ptrdiff_t)A.strides()[0], (ptrdiff_t)A.strides()[1],
                            device, msg, sizeof(msg));
         if (!_ctx) _error = msg;
+    }
+
+    template <typename T>
+    irls_device_state<T>::irls_device_state(const ndspan<T, 2> A, int device)
+        : _ctx(nullptr), _m(A.shape()[0]), _n(A.shape()[1]), _mode(kernelpp::compute_mode::AUTO)
+    {
+        init(A, device);
+    }
+
+    template <typename T>
+    irls_device_state<T>::irls_device_state(const ndspan<T, 2> A, kernelpp::compute_mode mode, int device)
+        : _ctx(nullptr), _m(A.shape()[0]), _n(A.shape()[1]), _mode(mode)
+    {
+        init(A, device);
     }
 
     template <typename T>
@@ -222,13 +217,13 @@ namespace ss
     kernelpp::maybe<irls_report> irls_policy::run(
         irls_device_state<float>& st, const ndspan<float> y, float tol, uint32_t maxiter, ndspan<float> x)
     {
-        return run_hip_irls<float>(st, y, tol, maxiter, x);
+        return kernelpp::run_with<solve_irls, kernelpp::maybe<irls_report>>(effective(st.mode()), st, y, tol, maxiter, x);
     }
 
     kernelpp::maybe<irls_report> irls_policy::run(
         irls_device_state<double>& st, const ndspan<double> y, double tol, uint32_t maxiter, ndspan<double> x)
     {
-        return run_hip_irls<double>(st, y, tol, maxiter, x);
+        return kernelpp::run_with<solve_irls, kernelpp::maybe<irls_report>>(effective(st.mode()), st, y, tol, maxiter, x);
     }
 
     /* Utils --------------------------------------------------------------- */
@@ -240,12 +235,12 @@ namespace ss
         inline int hip_norm_l1(float* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, char* e, size_t l) { return ss_hip_norm_l1_f32(A, m, n, rs, cs, 0, e, l); }
         inline int hip_norm_l1(double* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, char* e, size_t l) { return ss_hip_norm_l1_f64(A, m, n, rs, cs, 0, e, l); }
 
-        /* y = A x on the device (reference: one row-major xgemv, src/lib.cpp:78-92).
-           A solver built from the same view holds A in HBM already: its copy is used
-           (ss_hip_reconstruct_*).  Otherwise only the columns x actually uses travel: x is sparse
-           in every use of the reference (test_util.h:167,187), so those columns are gathered
-           into a compact matrix, uploaded and multiplied there.  No arithmetic on the host;
-           the reference's signature cannot report an error, so a failure (no usable GPU) throws. */
+        /* y = A x on the device (reference: one row-major xgemv, src/lib.cpp:78-92).  Stateless like the
+           reference's: the CURRENT contents of the host view are used (no look-up of a solver's device copy —
+           a caller may have changed A in place since, e.g. norm_l1(A)).  Only the columns x actually uses
+           travel: x is sparse in every use of the reference (test_util.h:167,187), so those columns are
+           gathered into a compact matrix, uploaded and multiplied there (ss_hip_reconstruct_*).  No arithmetic
+           on the host; the reference's signature cannot report an error, so a failure (no usable GPU) throws. */
         template <typename T>
         void reconstruct_signal(const ndspan<T, 2> A, const ndspan<T> x, ndspan<T> y)
         {
@@ -253,36 +248,23 @@ namespace ss
             if (x.size() != n || y.size() != m)
                 throw std::invalid_argument("reconstruct_signal: vector lengths do not match the shape of A");
             char msg[512] = { 0 };
-            std::vector<T> xs(n), ys(m);
-            for (size_t j = 0; j < n; j++) xs[j] = x[j];
-            ss_hip_ctx* held = nullptr;
-            {
-                std::lock_guard<std::mutex> lock(live_mutex());
-                for (const live_view& e : live_views())
-                    if (e.data == (const void*)A.data() && e.m == m && e.n == n && e.f64 == (sizeof(T) == 8) &&
-                        e.rs == (ptrdiff_t)A.strides()[0] && e.cs == (ptrdiff_t)A.strides()[1]) { held = e.ctx; break; }
-                if (held && hip_reconstruct(held, xs.data(), ys.data(), msg, sizeof(msg)) != SS_HIP_OK)
-                    throw std::runtime_error(std::string("reconstruct_signal: ") + msg);
+            std::vector<size_t> nz;
+            for (size_t j = 0; j < n; j++) if (x[j] != T(0)) nz.push_back(j);
+            if (nz.empty()) {
+                for (size_t i = 0; i < m; i++) y[i] = T(0);
+                return;
             }
-            if (!held) {
-                std::vector<size_t> nz;
-                for (size_t j = 0; j < n; j++) if (xs[j] != T(0)) nz.push_back(j);
-                if (nz.empty()) {
-                    for (size_t i = 0; i < m; i++) y[i] = T(0);
-                    return;
-                }
-                const size_t k = nz.size();
-                std::vector<T> cols(m * k), xk(k);
-                for (size_t c = 0; c < k; c++) {
-                    xk[c] = xs[nz[c]];
-                    for (size_t i = 0; i < m; i++) cols[c * m + i] = A(i, nz[c]);       // column-major, compact
-                }
-                ss_hip_ctx* tmp = create(cols.data(), m, k, (ptrdiff_t)1, (ptrdiff_t)m, 0, msg, sizeof(msg));
-                if (!tmp) throw std::runtime_error(std::string("reconstruct_signal: ") + msg);
-                const int rc = hip_reconstruct(tmp, xk.data(), ys.data(), msg, sizeof(msg));
-                ss_hip_homotopy_destroy(tmp);
-                if (rc != SS_HIP_OK) throw std::runtime_error(std::string("reconstruct_signal: ") + msg);
+            const size_t k = nz.size();
+            std::vector<T> cols(m * k), xk(k), ys(m);
+            for (size_t c = 0; c < k; c++) {
+                xk[c] = x[nz[c]];
+                for (size_t i = 0; i < m; i++) cols[c * m + i] = A(i, nz[c]);       // column-major, compact
             }
+            ss_hip_ctx* tmp = create(cols.data(), m, k, (ptrdiff_t)1, (ptrdiff_t)m, 0, msg, sizeof(msg));
+            if (!tmp) throw std::runtime_error(std::string("reconstruct_signal: ") + msg);
+            const int rc = hip_reconstruct(tmp, xk.data(), ys.data(), msg, sizeof(msg));
+            ss_hip_homotopy_destroy(tmp);
+            if (rc != SS_HIP_OK) throw std::runtime_error(std::string("reconstruct_signal: ") + msg);
             for (size_t i = 0; i < m; i++) y[i] = ys[i];
         }
 

@@ -3,8 +3,10 @@
 //   test_ss_api                 -> needs an MI355X; exit code 0 when every check passes
 //   test_ss_api --no-device     -> checks the error convention when no GPU is usable
 #include <ss/ss.h>
+#include <kernelpp/kernel.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <cmath>
@@ -158,17 +160,71 @@ void utilities()
     std::vector<double> x = { 2, 0 }, y(2, -1);
     ss::reconstruct_signal(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }), ss::as_span(x), ss::as_span(y));
     CHECK(y[0] == 0.5 && y[1] == 1.5);
-    // ... and with a solver built from the same view: its device copy of A is used (test_util.h:167-190 order:
-    // normalise, construct, solve, reconstruct)
+    // ... stateless like the reference's: with a solver alive on the same view, a later in-place change of the host
+    // matrix IS seen (the solver keeps its own device copy; reconstruct_signal reads the caller's current A)
     {
-        ss::homotopy<double> solver(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }));
+        std::vector<double> B = A;
+        ss::homotopy<double> solver(ss::as_span<2>(B.data(), { size_t(2), size_t(2) }));
         std::vector<double> x2 = { 0, 4 }, y2(2, -1);
-        ss::reconstruct_signal(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }), ss::as_span(x2), ss::as_span(y2));
+        ss::reconstruct_signal(ss::as_span<2>(B.data(), { size_t(2), size_t(2) }), ss::as_span(x2), ss::as_span(y2));
         CHECK(y2[0] == 1.0 && y2[1] == 3.0);
+        B[1] = 0.5;                                                   // A(0, 1): 0.25 -> 0.5
+        ss::reconstruct_signal(ss::as_span<2>(B.data(), { size_t(2), size_t(2) }), ss::as_span(x2), ss::as_span(y2));
+        CHECK(y2[0] == 2.0 && y2[1] == 3.0);
     }
     std::vector<double> xz = { 0, 0 }, yz(2, -1);
     ss::reconstruct_signal(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }), ss::as_span(xz), ss::as_span(yz));
     CHECK(yz[0] == 0.0 && yz[1] == 0.0);
+}
+
+// The compute-mode seam (kernelpp/kernel.h; reference: src/solvers/homotopy.h:27-38 KERNEL_DECL + op<mode, T>,
+// src/lib.cpp:36 kernelpp::run): this library is built with the HIP mode only.  A solver pinned to a mode that
+// is not built, or a process-wide request for one, reports error_code::COMPUTE_MODE_DISABLED — with or without a GPU.
+void compute_mode_seam(bool have_device)
+{
+    using kernelpp::compute_mode;
+    using kernelpp::error_code;
+    std::vector<float> A = { 1, 0, 0, 1 }, y = { 1, 0 }, x(2);
+    const auto Av = ss::as_span<2>(A.data(), { size_t(2), size_t(2) });
+    compute_mode parsed = compute_mode::AUTO;
+    CHECK(kernelpp::parse_mode("hip", parsed) && parsed == compute_mode::HIP);
+    CHECK(kernelpp::parse_mode("CPU", parsed) && parsed == compute_mode::CPU);
+    CHECK(!kernelpp::parse_mode("tpu", parsed));
+    CHECK(kernelpp::mode_available(compute_mode::HIP) == have_device);
+    CHECK(!kernelpp::mode_available(compute_mode::CPU) && !kernelpp::mode_available(compute_mode::AVX));
+    for (compute_mode m : { compute_mode::CPU, compute_mode::AVX }) {
+        ss::homotopy<float> pinned(Av, m);
+        auto r = pinned.solve(ss::as_span(y), 0.001f, 2, ss::as_span(x));
+        CHECK(r.is<kernelpp::error>());
+        if (r.is<kernelpp::error>()) CHECK(r.get<kernelpp::error>().code() == error_code::COMPUTE_MODE_DISABLED);
+        ss::omp<float> pinned_omp(Av, m);
+        auto ro = pinned_omp.solve(ss::as_span(y), 0.001f, 2, ss::as_span(x));
+        CHECK(ro.is<kernelpp::error>() && ro.get<kernelpp::error>().code() == error_code::COMPUTE_MODE_DISABLED);
+        ss::irls<float> pinned_irls(Av, m);
+        auto ri = pinned_irls.solve(ss::as_span(y), 0.001f, 2, ss::as_span(x));
+        CHECK(ri.is<kernelpp::error>() && ri.get<kernelpp::error>().code() == error_code::COMPUTE_MODE_DISABLED);
+    }
+    // the process-wide request (what SS_COMPUTE_MODE sets at first use)
+    const compute_mode before = kernelpp::requested_mode();
+    kernelpp::set_requested_mode(compute_mode::CPU);
+    {
+        ss::homotopy<float> s(Av);
+        auto r = s.solve(ss::as_span(y), 0.001f, 2, ss::as_span(x));
+        CHECK(r.is<kernelpp::error>() && r.get<kernelpp::error>().code() == error_code::COMPUTE_MODE_DISABLED);
+        // a solver pinned to HIP is not affected by the process-wide request
+        ss::homotopy<float> hip(Av, compute_mode::HIP);
+        auto rh = hip.solve(ss::as_span(y), 0.001f, 2, ss::as_span(x));
+        if (have_device) { CHECK(rh.is<ss::homotopy_report>()); CHECK(x == y); }
+        else { CHECK(rh.is<kernelpp::error>() && rh.get<kernelpp::error>().code() != error_code::COMPUTE_MODE_DISABLED); }
+    }
+    kernelpp::set_requested_mode(compute_mode::HIP);
+    {
+        ss::homotopy<float> s(Av);
+        auto r = s.solve(ss::as_span(y), 0.001f, 2, ss::as_span(x));
+        if (have_device) CHECK(r.is<ss::homotopy_report>());
+        else CHECK(r.is<kernelpp::error>() && r.get<kernelpp::error>().code() == error_code::KERNEL_FAILED);
+    }
+    kernelpp::set_requested_mode(before);
 }
 
 int no_device()
@@ -185,6 +241,7 @@ int no_device()
     threw = false;
     try { ss::reconstruct_signal(ss::as_span<2>(A.data(), { size_t(2), size_t(2) }), ss::as_span(y), ss::as_span(x)); } catch (const std::runtime_error& e) { threw = true; }
     CHECK(threw);
+    compute_mode_seam(false);
     return failures;
 }
 
@@ -203,6 +260,7 @@ int main(int argc, char** argv)
     omp_api();
     irls_api();
     utilities();
+    compute_mode_seam(true);
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;
 }
