@@ -250,6 +250,8 @@ typedef struct ss_hip_stats {
                                       65536: the rest runs beside it on another stream); its algorithmic bytes are
                                       m*cols*s + 32*m*s + 32*cols*s                                                                 */
     /* ABI version 3 */
+    uint64_t sweep32_bytes_timed;  /* algorithmic bytes of the timed lookahead launches, summed launch by launch (a plain pass covers all
+                                      n columns, the early form's main launch its share): sweep32_bytes_timed / sweep32_ms is the rate  */
     uint64_t tie_reruns;           /* signals solved again in the reference-order engine because a step-length scan met an exact tie
                                       (option "tie_rerun"): an off-support column attained max|c|, the reference's strict t > 0
                                       (homotopy-cpu.cpp:143-153) skips it for good, and which rounding hits that is luck                 */
@@ -275,6 +277,42 @@ int ss_hip_irls_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy, doub
                           double* x, ptrdiff_t incx, uint32_t* iter_out, double* solution_error_out,
                           int* spd_failure_out, char* err, size_t errlen);
 void ss_hip_irls_destroy(ss_hip_ctx* ctx);
+
+/* ---- one signal over a COLUMN-SHARDED dictionary (csrc/colshard.hip) -------------------------------
+ *
+ * For dictionaries beyond one GPU's memory (or n >> 10^6): every rank — one process per GPU — owns the columns
+ * [col_lo, col_lo + n_local) of the m x n_total sensing matrix; the reference's iteration (homotopy-cpu.cpp:236-272)
+ * runs with the O(m n) work local to the shard (the correlation sweep of the shard's own context) and its reductions
+ * over all columns as device-side collectives: one (value, index) all-reduce for lambda = ||A^T r||_inf and the
+ * left-most arg-max (homotopy-cpu.cpp:32-37), one for the smallest step length and its left-most column (:122-163),
+ * and one all-reduce of m + kcap floats that carries the entering column from its owner to everyone.  The active
+ * set (support, (A_S^T A_S)^-1, x_S, the active columns) is replicated: every rank performs the same update.
+ * Results equal the single-GPU residual form (option "engine" = 0) to rounding; sharded and unsharded runs of THIS
+ * entry point agree bit for bit.
+ *
+ * Transport: RCCL (librccl.so is opened at run time) — rank 0 calls ss_hip_comm_unique_id, distributes the 128 bytes
+ * out of band (MPI, torch.distributed, a file) and every rank passes them to create, which calls ncclCommInitRank —
+ * or, with comm_id == NULL, a table of HOST collectives (in-place all-reduces on host memory, called by every rank in
+ * the same order; tests and other transports).  world == 1 needs neither.
+ * x_local receives the shard's n_local coefficients; iter_out / err_out as ss_hip_homotopy_solve_f32.  Options
+ * "strict_sign", "tie_guard", "zero_on_removal", "trace" apply; destroy with ss_hip_homotopy_destroy. */
+#define SS_HIP_COMM_ID_BYTES 128
+typedef struct ss_hip_collectives {
+    void* user;
+    int (*allreduce_max_u64)(void* user, uint64_t* buf, size_t count);   /* 0 on success */
+    int (*allreduce_min_u64)(void* user, uint64_t* buf, size_t count);
+    int (*allreduce_sum_f32)(void* user, float* buf, size_t count);
+} ss_hip_collectives;
+int ss_hip_comm_unique_id(unsigned char* id /* SS_HIP_COMM_ID_BYTES */, char* err, size_t errlen);
+ss_hip_ctx* ss_hip_homotopy_colshard_create_f32(const float* A_local, size_t m, size_t n_local,
+                                                ptrdiff_t stride_row, ptrdiff_t stride_col,
+                                                size_t col_lo, size_t n_total, int device,
+                                                const unsigned char* comm_id, int rank, int world,
+                                                const ss_hip_collectives* host_collectives,
+                                                char* err, size_t errlen);
+int ss_hip_homotopy_colshard_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_t incy, float tol, uint32_t max_iter,
+                                       float* x_local, ptrdiff_t incx, uint32_t* iter_out, double* err_out,
+                                       char* err, size_t errlen);
 
 /* profiling != 0: bracket every sweep launch with HIP events on the context's stream. */
 int ss_hip_set_profiling(ss_hip_ctx* ctx, int profiling);

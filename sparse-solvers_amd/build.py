@@ -42,6 +42,8 @@ HIP_UNITS = [
     ("subgram.hip", []),
     # reference-order engine: separately rounded products and sums in a fixed order
     ("reforder.hip", ["-ffp-contract=off"]),
+    # column-sharded single-signal solve: replicated active-set arithmetic (separately rounded like activeset.hip)
+    ("colshard.hip", ["-ffp-contract=off"]),
 ]
 
 

@@ -80,6 +80,7 @@ void k_init(const T* __restrict__ At, SlotDims L, const T* __restrict__ c,
         st->done_round = 0;
         st->c_inf = (double)c_inf;
         st->gamma = 0.0;
+        st->lambda0 = (float)c_inf;
         st->dot = (double)dot;
         if (trace != nullptr) {
             trace[0].idx = idx;
@@ -348,6 +349,10 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
     T best = Lim<T>::max();
     uint32_t best_i = 0xffffffffu;
     bool tie = false;      // an off-support candidate that is exactly 0 (see DevState::tie_stall)
+    // (the column that LEFT the support in the previous iteration still sits on the boundary, |c| = lambda: its t = 0
+    // is the rule, not a tie — the strict t > 0 exists to keep it out)
+    const uint32_t just_removed = (round > 1 && st->added == 0u) ? st->idx : 0xffffffffu;
+    const bool in_band = tie_band<T>(c_inf, (T)st->c_inf, (T)st->gamma, (T)st->lambda0);
     for (uint32_t base = blockIdx.x * (kSmallThreads * kScanPerThread); base < n;
          base += gridDim.x * (kSmallThreads * kScanPerThread))
 #pragma unroll
@@ -369,13 +374,13 @@ void k_scansel(uint32_t round, T tol, uint32_t max_iter, uint32_t n,
                 if (dl != T(0)) {
                     T t = (c_inf - ci) / dl;
                     if (tie_guard && t == T(0) && dl > T(0)) t = Lim<T>::tiny();
-                    if (t == T(0)) tie = true;
+                    if (t == T(0) && i != just_removed && in_band) tie = true;
                     if (t > T(0) && t < m) m = t;
                 }
                 if (dr != T(0)) {
                     T t = (c_inf + ci) / dr;
                     if (tie_guard && t == T(0) && dr > T(0)) t = Lim<T>::tiny();
-                    if (t == T(0)) tie = true;
+                    if (t == T(0) && i != just_removed && in_band) tie = true;
                     if (t > T(0) && t < m) m = t;
                 }
             }
@@ -457,6 +462,7 @@ void k_la_init_pick(const T* __restrict__ pmax_val, const uint32_t* __restrict__
         st->done_round = 0;
         st->c_inf = (double)c_inf;
         st->gamma = 0.0;
+        st->lambda0 = (float)c_inf;
         // (full_rows != 0: the full Gram matrix is the cache — every column is there already)
         st->need_sweep = full_rows ? 0u : 1u; st->cache_used = full_rows; st->nsweeps = 0;
         if (trace != nullptr) { trace[0].idx = idx; trace[0].added = 1; trace[0].gamma = 0.0; trace[0].c_inf = (double)c_inf; }
@@ -640,6 +646,210 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
     }
     block_reduce_pair<T, true>(bv, bi, sv, si);
     if (threadIdx.x == 0) { pmax_val[blockIdx.x] = bv; pmax_idx[blockIdx.x] = bi; }
+}
+
+// ---- k_la_cqs: k_la_cq and k_scansel in ONE launch (batched Gram forms, option batch_fused_scan) ----------
+// k_scansel re-reads, per signal and round, the c and q that k_la_cq wrote microseconds earlier (9 bytes per
+// column: 2.4 GB per round for 4096 signals of 65536 columns — at 2 TB/s the HBM kernel furthest below its
+// roof).  Here a workgroup keeps c and q of its 1024 columns in REGISTERS across the one thing the scan has to
+// wait for — lambda = ||c||_inf over all columns of the signal: the workgroups of a signal meet at a per-signal
+// counter (DevState::bar_count, monotonic over the rounds of the batch; target = round * gridDim.x), read each
+// other's partial maxima (L2-bypassing), and go on to find_max_gamma's scan (homotopy-cpu.cpp:122-163) with the
+// same expressions and predicates as k_scansel.  The last one to arrive picks, toggles and updates x
+// (select_toggle) as before.  c and q are written only where someone still reads them: on the support and for
+// each workgroup's best candidate (the entering column is one of those; k_gramupd takes its sign from there).
+// Same bits as the two-kernel form (tested).
+// Residency: the workgroups of a signal are 64 consecutive block ids, dispatched in order, so the oldest unfinished
+// signal always has all of its workgroups resident; the wait is bounded all the same (kCqsSpinLimit): on expiry the
+// slot ends with SS_HIP_ERUNTIME instead of hanging the queue.
+constexpr uint32_t kCqsSpinLimit = 1u << 22;
+
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads)
+void k_la_cqs(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, const T* __restrict__ c0,
+              T* __restrict__ x, const T* __restrict__ d, uint32_t* __restrict__ touched2, uint32_t* __restrict__ gam2,
+              uint32_t n, uint32_t gpitch, SlotDims L, T* __restrict__ c, T* __restrict__ q,
+              T* pmax_val, uint32_t* pmax_idx, T* pmin_val, uint32_t* pmin_idx, uint8_t* __restrict__ insup,
+              DevState* st, uint32_t round, T tol, uint32_t max_iter, uint32_t* hflags, TraceEntry* trace, uint32_t trace_cap,
+              int zero_on_removal, int tie_guard, uint32_t* ndone, uint32_t nslots, int tie_exit)
+{
+    const uint32_t kcap = L.kcap;
+    const int32_t* slot_tab = slot_of;
+    {
+        const size_t s = blockIdx.y;
+        c0 += s * L.n_pad; x += s * L.n_pad; d += s * L.n_pad; c += s * L.n_pad; q += s * L.n_pad; insup += s * L.n_pad;
+        if (slot_tab != nullptr) slot_tab += s * L.n_pad;
+        touched2 += s * 2 * kcap; gam2 += s * 2 * kcap;
+        pmax_val += s * L.pmax_stride; pmax_idx += s * L.pmax_stride;
+        pmin_val += s * L.pmin_stride; pmin_idx += s * L.pmin_stride;
+        st += s;
+        if (s != 0) trace = nullptr;
+    }
+    if (st->done) return;
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_flag;
+    __shared__ uint32_t s_slot[kCqTile];
+    __shared__ T s_x[kCqTile];
+    __shared__ T s_d[kCqTile];
+    const uint32_t nt = st->ntouched;
+    const uint32_t* touched = touched2 + (size_t)st->cur * kcap;
+    const uint32_t base = blockIdx.x * kCqChunk;
+    const T* gbase = gcache + base + threadIdx.x;
+    T ax[4] = { T(0), T(0), T(0), T(0) }, ad[4] = { T(0), T(0), T(0), T(0) };
+    for (uint32_t j0 = 0; j0 < nt; j0 += kCqTile) {                  // (the loop of k_la_cq, statement for statement)
+        const uint32_t cnt = (nt - j0 < kCqTile) ? (nt - j0) : kCqTile;
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const uint32_t col = touched[j0 + threadIdx.x];
+            s_slot[threadIdx.x] = slot_tab != nullptr ? (uint32_t)slot_tab[col] : col;
+            s_x[threadIdx.x] = x[col];
+            s_d[threadIdx.x] = d[col];
+        }
+        __syncthreads();
+        uint32_t j = 0;
+        for (; j + 4 <= cnt; j += 4) {
+            T gv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T* g = gbase + (size_t)s_slot[j + u] * gpitch;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gv[u][k] = g[k * kSmallThreads];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T xj = s_x[j + u], dj = s_d[j + u];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ax[k] += xj * gv[u][k]; ad[k] += dj * gv[u][k]; }
+            }
+        }
+        for (; j < cnt; ++j) {
+            const T* g = gbase + (size_t)s_slot[j] * gpitch;
+            const T xj = s_x[j], dj = s_d[j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const T gvv = g[k * kSmallThreads]; ax[k] += xj * gvv; ad[k] += dj * gvv; }
+        }
+    }
+    T cv[4], qv[4];
+    uint8_t act[4];
+    T bv = T(-1);
+    uint32_t bi = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = base + k * kSmallThreads + threadIdx.x;
+        cv[k] = T(0); qv[k] = T(0); act[k] = 0;
+        if (i < n) {
+            cv[k] = c0[i] - ax[k];
+            qv[k] = ad[k];
+            act[k] = insup[i];
+            const T a = cv[k] < T(0) ? -cv[k] : cv[k];
+            if (better_max(a, i, bv, bi)) { bv = a; bi = i; }
+        }
+    }
+    block_reduce_pair<T, true>(bv, bi, sv, si);
+    // ---- the meeting: every workgroup of the signal posts its maximum, then reads all of them ------------------
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&pmax_val[blockIdx.x], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pmax_idx[blockIdx.x], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&st->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t target = round * gridDim.x;
+        uint32_t ok = 0;
+        for (uint32_t spin = 0; spin < kCqsSpinLimit; ++spin) {
+            if (__hip_atomic_load(&st->bar_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        s_flag = ok;
+    }
+    __syncthreads();
+    if (s_flag == 0u) {
+        // the signal's workgroups were not resident together: give up on this slot rather than hang
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&st->status, (uint32_t)SS_HIP_ERUNTIME, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) { st->done_round = round; st->need_sweep = 0; st->done = 1; signal_done(hflags, ndone, nslots, round); }
+        }
+        return;
+    }
+    T c_inf;
+    uint32_t imax;
+    reduce_partials_agent(pmax_val, pmax_idx, gridDim.x, c_inf, imax, sv, si);
+    // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272; as in k_scansel)
+    if ((round > 1 && !(c_inf > tol)) || round > max_iter) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->c_inf = (double)c_inf;
+            st->iter = round - 1;
+            st->done_round = round;
+            st->need_sweep = 0;
+            st->done = 1;
+            signal_done(hflags, ndone, nslots, round);
+        }
+        return;
+    }
+    // ---- find_max_gamma's scan over the columns in registers (k_scansel's expressions) ---------------------------
+    const uint32_t just_removed = (round > 1 && st->added == 0u) ? st->idx : 0xffffffffu;
+    const bool in_band = tie_band<T>(c_inf, (T)st->c_inf, (T)st->gamma, (T)st->lambda0);
+    T best = Lim<T>::max();
+    uint32_t best_i = 0xffffffffu;
+    T best_c = T(0), best_q = T(0);
+    bool tie = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = base + k * kSmallThreads + threadIdx.x;
+        if (i < n) {
+            T m = Lim<T>::max();
+            if (act[k]) {
+                const T t = -x[i] / d[i];
+                if (t > T(0) && t < m) m = t;
+                c[i] = cv[k];                        // the support's correlations: k_gramupd forms sign(c - gamma q) from them
+                q[i] = qv[k];
+            } else {
+                const T qi = qv[k], ci = cv[k];
+                const T dl = T(1) - qi, dr = T(1) + qi;
+                if (dl != T(0)) {
+                    T t = (c_inf - ci) / dl;
+                    if (tie_guard && t == T(0) && dl > T(0)) t = Lim<T>::tiny();
+                    if (t == T(0) && i != just_removed && in_band) tie = true;
+                    if (t > T(0) && t < m) m = t;
+                }
+                if (dr != T(0)) {
+                    T t = (c_inf + ci) / dr;
+                    if (tie_guard && t == T(0) && dr > T(0)) t = Lim<T>::tiny();
+                    if (t == T(0) && i != just_removed && in_band) tie = true;
+                    if (t > T(0) && t < m) m = t;
+                }
+            }
+            if (better_min(m, i, best, best_i)) { best = m; best_i = i; best_c = cv[k]; best_q = qv[k]; }
+        }
+    }
+    if (tie) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        // the workgroup's best candidate, with its c and q: the thread that owns it stores them (the entering column of
+        // the signal is the best of some workgroup)
+        const T mine = best;
+        const uint32_t mine_i = best_i;
+        block_reduce_pair<T, false>(best, best_i, sv, si);
+        if (mine_i == best_i && mine == best && best_i != 0xffffffffu) { c[best_i] = best_c; q[best_i] = best_q; }
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&pmin_val[blockIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pmin_idx[blockIdx.x], best_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!arrive_last_relaxed(&st->ticket_scan, gridDim.x, &s_flag)) return;
+    if (tie_exit && __hip_atomic_load(&st->tie_stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        if (threadIdx.x == 0) {
+            st->status = kStatusTieRerun;
+            st->c_inf = (double)c_inf;
+            st->iter = round - 1;
+            st->done_round = round;
+            st->need_sweep = 0;
+            st->done = 1;
+            signal_done(hflags, ndone, nslots, round);
+        }
+        return;
+    }
+    select_toggle<T>(round, c_inf, gridDim.x, pmin_val, pmin_idx, x, d, insup, gam2, touched2, kcap, st, hflags,
+                     true, trace, trace_cap, zero_on_removal, ndone, nslots, (const int32_t*)nullptr, sv, si, s_cnt);
 }
 
 // ---- k_omp_select: orthogonal matching pursuit's pick (one workgroup per slot) -------------
@@ -1196,6 +1406,8 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
     // ---- phase 2: step-length scan (same expressions as k_scansel) ---------------------------
     T best = Lim<T>::max();
     uint32_t best_i = 0xffffffffu;
+    const uint32_t just_removed = (st->iter >= 1u && st->added == 0u) ? st->idx : 0xffffffffu;   // (see k_scansel)
+    const bool in_band = tie_band<T>(c_inf, (T)st->c_inf, (T)st->gamma, (T)st->lambda0);
     for (uint32_t base = blockIdx.x * (uint32_t)(THREADS * COLS); base < n; base += gridDim.x * (uint32_t)(THREADS * COLS))
 #pragma unroll
     for (int k = 0; k < COLS; ++k) {
@@ -1213,13 +1425,13 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
                 if (dl != T(0)) {
                     T t = (c_inf - ci) / dl;
                     if (tie_guard && t == T(0) && dl > T(0)) t = Lim<T>::tiny();
-                    if (t == T(0)) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see DevState::tie_stall)
+                    if (t == T(0) && i != just_removed && in_band) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see DevState::tie_stall)
                     if (t > T(0) && t < m) m = t;
                 }
                 if (dr != T(0)) {
                     T t = (c_inf + ci) / dr;
                     if (tie_guard && t == T(0) && dr > T(0)) t = Lim<T>::tiny();
-                    if (t == T(0)) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t == T(0) && i != just_removed && in_band) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (t > T(0) && t < m) m = t;
                 }
             }
@@ -1782,14 +1994,31 @@ hipError_t launch_batch_cols(const ss_hip_ctx* ctx, const DevState* st, uint32_t
     return hipGetLastError();
 }
 
+// fused form (round != 0): k_la_cqs — the Gram-form pass, lambda, the scan and the pick of `round` in one launch
+// (launch_tail_gram_batched is then told to skip its k_scansel)
+bool cqs_usable(const ss_hip_ctx* ctx, uint32_t pmin_stride)
+{
+    const uint32_t nb = ((uint32_t)ctx->n + kCqChunk - 1) / kCqChunk;
+    return ctx->batch_fused_scan != 0 && nb <= pmin_stride && nb <= 2048u;
+}
+
 template <typename T>
 hipError_t launch_cq_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, const T* G, uint32_t gpitch,
-                                  const T* c0b, uint32_t* nparts_out, const int32_t* bslot)
+                                  const T* c0b, uint32_t* nparts_out, const int32_t* bslot, uint32_t round, T tol, uint32_t max_iter)
 {
     const uint32_t n = (uint32_t)ctx->n;
     const uint32_t nb = (n + kCqChunk - 1) / kCqChunk;
     if (nb > ws.dims.pmax_stride) return hipErrorInvalidValue;
     if (nparts_out) *nparts_out = nb;
+    if (round != 0) {
+        if (nb > ws.dims.pmin_stride) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_la_cqs<T>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, bslot,
+                           c0b, ws.x, (const T*)ws.d, ws.touched, ws.gam, n, gpitch, ws.dims, ws.c, ws.q,
+                           ws.pmax_val, ws.pmax_idx, ws.pmin_val, ws.pmin_idx, ws.insup, ws.st, round, tol, max_iter,
+                           ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,
+                           (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((k_la_cq<T>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, bslot,
                        c0b, (const T*)ws.x, (const T*)ws.d, (const uint32_t*)ws.touched, n, gpitch, ws.dims, ws.c, ws.q,
                        ws.pmax_val, ws.pmax_idx, (const DevState*)ws.st);
@@ -1801,7 +2030,7 @@ hipError_t launch_cq_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint3
 // A per 64 live picks (launch_gemm64_tn_f32) into rows row_base + slot of the batch's column cache G.
 template <typename T>
 hipError_t launch_tail_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts,
-                                    T tol, uint32_t max_iter, const T* G, uint32_t gpitch, const BatchCols* cols)
+                                    T tol, uint32_t max_iter, const T* G, uint32_t gpitch, const BatchCols* cols, bool scan_done)
 {
     const uint32_t n = (uint32_t)ctx->n;
     const uint32_t per_block = kSmallThreads * kScanPerThread;
@@ -1810,6 +2039,7 @@ hipError_t launch_tail_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uin
     // (many slots: fewer, longer workgroups per slot — the kernel grid-strides; with 64 per slot a launch of 4096 slots is
     // 262 144 workgroups whose reductions and tickets, not their 9 bytes per column, set its time; option scan_blocks)
     if (nslots >= 64u && ctx->scan_blocks > 0 && ns > (uint32_t)ctx->scan_blocks) ns = (uint32_t)ctx->scan_blocks;
+    if (!scan_done)          // (fused form: k_la_cqs has scanned and picked already)
     hipLaunchKernelGGL((k_scansel<T>), dim3(ns, nslots), dim3(kSmallThreads), 0, ctx->stream, round, tol,
                        max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
                        nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
@@ -1914,8 +2144,8 @@ template hipError_t launch_la_update<float>(const ss_hip_ctx*, Workspace<float>&
 template hipError_t launch_la_update<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, double);
 template hipError_t launch_la_cq<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t*);
 template hipError_t launch_gram_guard_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, float);
-template hipError_t launch_cq_gram_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, const float*, uint32_t, const float*, uint32_t*, const int32_t*);
-template hipError_t launch_tail_gram_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, uint32_t, float, uint32_t, const float*, uint32_t, const BatchCols*);
+template hipError_t launch_cq_gram_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, const float*, uint32_t, const float*, uint32_t*, const int32_t*, uint32_t, float, uint32_t);
+template hipError_t launch_tail_gram_batched<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, uint32_t, float, uint32_t, const float*, uint32_t, const BatchCols*, bool);
 template hipError_t launch_la_cq<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t*);
 template hipError_t launch_la_iter<float>(const ss_hip_ctx*, Workspace<float>&, float, uint32_t);
 template hipError_t launch_la_omp<float>(const ss_hip_ctx*, Workspace<float>&, float, uint32_t);

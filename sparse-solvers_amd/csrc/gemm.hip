@@ -34,7 +34,13 @@ constexpr int GLD = GK + GPAD;                 // LDS row pitch in floats (144 B
 // computed (blockIdx enumerates the pairs bm <= bn, column panel by column panel) and every off-diagonal tile
 // is stored to both sides.  G[i][j] and G[j][i] are the same k-ordered fma chain of the same (commutative)
 // products, so the mirrored copy is bit for bit what the full product would have put there.
-template <bool SYM>
+// BLK (the correlations of a batch, c = A^T y and the two GEMMs of a GEMM-form round): an output that is ONE fma
+// chain over all m rows carries a rounding error that grows like sqrt(m) * eps * |partial sums| — five times what the
+// single-signal sweep's 64 per-lane sums + tree leave in c0 = A^T y (measured on the step lengths of small steps:
+// tools/dbg_colform.py) — and that error stays in every c = c0 - sum_j x_j g_j of the path.  With BLK
+// every K-step (32 rows) runs its own chain from zero and the 32-row sums are added up in a second accumulator:
+// chains of 32 + m / 32 instead of m.  Not for SYM: G's entries have to be the mirrored-tile chains.
+template <bool SYM, bool BLK = false>
 __global__ __launch_bounds__(256, 2)
 void k_gemm_tn_f32(const float* __restrict__ R, const float* __restrict__ Q, float* __restrict__ D,
                    uint32_t mtiles, uint32_t K, uint32_t ldr, uint32_t ldq, uint32_t ldd,
@@ -75,12 +81,17 @@ void k_gemm_tn_f32(const float* __restrict__ R, const float* __restrict__ Q, flo
     const float* gQ = Q + (size_t)(bn * GN + srow) * ldq + squad * 4;
 
     v16f acc[2][2];
+    v16f tot[BLK ? 2 : 1][BLK ? 2 : 1];                     // BLK: the sum of the 32-row chains so far
+    v16f zero16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int j = 0; j < 2; ++j) {
+            acc[i][j] = zero16;
+            if (BLK) tot[i][j] = zero16;
+        }
 
     v4f stR[4], stQ[4];
 #pragma unroll
@@ -122,7 +133,15 @@ void k_gemm_tn_f32(const float* __restrict__ R, const float* __restrict__ Q, flo
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], (BLK && g == 0 && t == 0) ? zero16 : acc[i][j], 0, 0, 0);
+        }
+        if (BLK) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) tot[i][j][e] += acc[i][j][e];
         }
         if (more) {
 #pragma unroll
@@ -144,7 +163,7 @@ void k_gemm_tn_f32(const float* __restrict__ R, const float* __restrict__ Q, flo
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const uint32_t row = bm * GM + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                D[(size_t)row * ldd + col] = acc[i][j][e];
+                D[(size_t)row * ldd + col] = BLK ? tot[i][j][e] : acc[i][j][e];
             }
             if (SYM && bm != bn) {
                 // the mirrored tile: registers 4g .. 4g+3 are four consecutive rows, i.e. 16 contiguous bytes of
@@ -968,14 +987,19 @@ hipError_t launch_gemm64_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
 }
 
 // D[Mg][ldd] = R[Mg][ldr] * At^T ; Mg % 128 == 0, ctx->n_pad % 128 == 0, ldm % 32 == 0
+// blocked: 32-row chains summed in a second accumulator (the correlations of a batch); false: one chain per output
+// (the full product G = A^T A of option gram_symmetric = 0: the symmetric build's chains)
 hipError_t launch_gemm_tn_f32(const ss_hip_ctx* ctx, const float* R, uint32_t Mg, uint32_t ldr,
-                              float* D, uint32_t ldd, const uint32_t* row_tile_skip)
+                              float* D, uint32_t ldd, const uint32_t* row_tile_skip, bool blocked)
 {
     if (Mg % GM != 0 || ctx->n_pad % GN != 0 || ctx->ldm % GK != 0) return hipErrorInvalidValue;
     const uint32_t mtiles = Mg / GM, ntiles = ctx->n_pad / GN;
-    hipLaunchKernelGGL(k_gemm_tn_f32<false>, dim3(mtiles * ntiles), dim3(256), 0, ctx->stream, R,
-                       static_cast<const float*>(ctx->At), D, mtiles, ctx->ldm, ldr, ctx->ldm, ldd,
-                       row_tile_skip);
+    if (blocked)
+        hipLaunchKernelGGL((k_gemm_tn_f32<false, true>), dim3(mtiles * ntiles), dim3(256), 0, ctx->stream, R,
+                           static_cast<const float*>(ctx->At), D, mtiles, ctx->ldm, ldr, ctx->ldm, ldd, row_tile_skip);
+    else
+        hipLaunchKernelGGL((k_gemm_tn_f32<false, false>), dim3(mtiles * ntiles), dim3(256), 0, ctx->stream, R,
+                           static_cast<const float*>(ctx->At), D, mtiles, ctx->ldm, ldr, ctx->ldm, ldd, row_tile_skip);
     return hipGetLastError();
 }
 
@@ -987,7 +1011,7 @@ hipError_t launch_gemm_sym_f32(const ss_hip_ctx* ctx, float* G, uint32_t ldd)
     const uint64_t blocks = t * (t + 1) / 2;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const float* At = static_cast<const float*>(ctx->At);
-    hipLaunchKernelGGL(k_gemm_tn_f32<true>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, At, At, G, (uint32_t)t,
+    hipLaunchKernelGGL((k_gemm_tn_f32<true, false>), dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, At, At, G, (uint32_t)t,
                        ctx->ldm, ctx->ldm, ctx->ldm, ldd, (const uint32_t*)nullptr);
     return hipGetLastError();
 }

@@ -210,6 +210,21 @@ void k_pack_records(const T* __restrict__ x, const uint32_t* __restrict__ gam2, 
     }
 }
 
+// ---- end of a solve in ONE launch: the device state to pinned (device-mapped) host memory and, when the caller's x
+// ---- lives on the device, the n coefficients to it — instead of two or three copy commands with 10-20 us between them
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_epilogue(const uint32_t* __restrict__ st_words, uint32_t* __restrict__ hs_mapped, uint32_t st_nwords,
+                const T* __restrict__ x_src, T* __restrict__ x_dst, long long incx, uint32_t n)
+{
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    if (x_dst != nullptr)
+        for (uint32_t i = gtid; i < n; i += gsz) x_dst[(long long)i * incx] = x_src[i];
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < st_nwords; i += blockDim.x)
+            __hip_atomic_store(&hs_mapped[i], st_words[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <typename T>
 void release_arrays(Workspace<T>* w)
 {
@@ -295,6 +310,25 @@ void ensure_workspace(ss_hip_ctx* ctx, uint32_t nslots, uint32_t kcap)
     HIPCHK(hipMemsetAsync(w->ndone, 0, 64, ctx->stream));
 }
 
+}  // namespace
+
+namespace sship {
+int colshard_workspace(ss_hip_ctx* ctx, uint32_t kcap)
+{
+    try {
+        ensure_workspace<float>(ctx, 1, kcap);
+    } catch (const HipFail&) {
+        (void)hipGetLastError();
+        return SS_HIP_ENOMEM;
+    } catch (const std::bad_alloc&) {
+        return SS_HIP_ENOMEM;
+    }
+    return SS_HIP_OK;
+}
+}  // namespace sship
+
+namespace {
+
 template <typename T>
 ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t cs, int device,
                         char* err, size_t errlen, int kind = 0)
@@ -349,8 +383,9 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
         else ensure_workspace<T>(ctx, 1, 64);
         HIPCHK(hipHostMalloc(&ctx->host_flags, 64 * sizeof(uint32_t), hipHostMallocMapped));
         std::memset(ctx->host_flags, 0, 64 * sizeof(uint32_t));
-        HIPCHK(hipHostMalloc(&ctx->hs_pinned, sizeof(DevState), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&ctx->hs_pinned, sizeof(DevState), hipHostMallocMapped));
         std::memset(ctx->hs_pinned, 0, sizeof(DevState));
+        if (hipHostGetDevicePointer(&ctx->hs_mapped, ctx->hs_pinned, 0) != hipSuccess) { (void)hipGetLastError(); ctx->hs_mapped = nullptr; }
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->dev_flags), ctx->host_flags, 0));
         HIPCHK(hipEventCreate(&ctx->ev_solve0));
         HIPCHK(hipEventCreate(&ctx->ev_solve1));
@@ -442,6 +477,8 @@ template <typename T> struct Lookahead {
         HIPCHK(hipMalloc(&ws.c0, (size_t)ctx->n_pad * sizeof(T)));
         HIPCHK(hipMalloc(&ws.tcand, (size_t)ctx->n_pad * sizeof(T)));
         HIPCHK(hipMalloc(&ws.sw_list, 128 * sizeof(uint32_t)));
+        // (0xffffffff = "no column": k_subset_pick with a small subset writes only the entries it uses)
+        HIPCHK(hipMemsetAsync(ws.sw_list, 0xff, 128 * sizeof(uint32_t), ctx->stream));
         if (sizeof(T) == 4) {
             // speculative form: slot -> column map, breakpoint log, verification partials, subset ranking
             ws.nvwg = (uint32_t)((ctx->n + kSoloWidth - 1) / kSoloWidth);
@@ -453,6 +490,7 @@ template <typename T> struct Lookahead {
             HIPCHK(hipMalloc(&ws.v_max, (size_t)kSoloLogCap * ws.nvwg * sizeof(uint32_t)));
             HIPCHK(hipMalloc(&ws.v_min, (size_t)kSoloLogCap * ws.nvwg * sizeof(uint64_t)));
             HIPCHK(hipMalloc(&ws.sw_list2, 128 * sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(ws.sw_list2, 0xff, 128 * sizeof(uint32_t), ctx->stream));
             HIPCHK(hipMalloc(&ws.sub_cols, 2 * (size_t)kSoloWidth * sizeof(uint32_t)));     // columns, then the progress hints (float)
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&ws.subg), (size_t)kSoloWidth * kSoloWidth * sizeof(float)));
             HIPCHK(hipMalloc(&ws.cand_top, kCandPerBlock * (size_t)ws.nvwg * sizeof(uint64_t)));
@@ -613,7 +651,7 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
             tail_cols = (nt - se_last) * 128u;                                  // the last 256 columns at 8192 x 65536
         }
     }
-    ctx->stats.sweep32_timed_cols = main_tiles ? (uint64_t)main_tiles * 128u : (uint64_t)ctx->n;
+    ctx->stats.sweep32_timed_cols = main_tiles ? (uint64_t)main_tiles * 128u : (uint64_t)ctx->n;   // (of THIS form's timed launch: kind 5 below)
     if (ws.la_dbg) HIPCHK(hipMemsetAsync(ws.la_dbg, 0, 2048 * 8 * sizeof(uint64_t), st));
     HIPCHK(launch_la_init_pick<float>(ctx, ws, nparts, tol, false));
     HIPCHK(launch_la_cand_init_f32(ctx, ws));
@@ -814,9 +852,20 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         uint32_t early_lds_cols = 0, ro_parts = 0;
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
         bool spec_epilogue = false, pump_enqueued = false;
+        const bool x_on_device = x != nullptr && is_device_pointer(x);
         auto enqueue_epilogue = [&]() {
-            HIPCHK(hipMemcpyAsync(ctx->hs_pinned, ws.st, sizeof(DevState), hipMemcpyDeviceToHost, st));
-            if (x) copy_out<T>(ctx, x, incx, ws.x, n);
+            if (ctx->hs_mapped != nullptr) {
+                // one launch: state -> pinned memory, x -> the caller's device buffer (a host x still takes a copy command)
+                const uint32_t grid = x_on_device ? std::min<uint32_t>(((uint32_t)n + 1023u) / 1024u, 256u) : 1u;
+                hipLaunchKernelGGL((k_epilogue<T>), dim3(std::max(1u, grid)), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ws.st),
+                                   static_cast<uint32_t*>(ctx->hs_mapped), (uint32_t)(sizeof(DevState) / 4), (const T*)ws.x,
+                                   x_on_device ? x : (T*)nullptr, (long long)incx, (uint32_t)n);
+                HIPCHK(hipGetLastError());
+                if (x && !x_on_device) copy_out<T>(ctx, x, incx, ws.x, n);
+            } else {
+                HIPCHK(hipMemcpyAsync(ctx->hs_pinned, ws.st, sizeof(DevState), hipMemcpyDeviceToHost, st));
+                if (x) copy_out<T>(ctx, x, incx, ws.x, n);
+            }
             if (rec_out) {
                 // compact output (a record that is superseded by a retry below is simply overwritten)
                 const unsigned char* stage = pack_records<T>(ctx, ws, 1, kmax);
@@ -885,7 +934,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (prof) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
                 early_prologue(ctx, ws, nb1, tol, max_iter, lc, e0, e1);
-                if (prof) { ctx->prof_kind.push_back(3); ++nprof; }
+                if (prof) { ctx->prof_kind.push_back(5); ++nprof; }       // 5 = the main launch of an early-form pass (its share of the columns)
                 // The typical solve is complete with what is queued now: its epilogue (state, x, record) goes right
                 // behind instead of after a trip through the host (host notices `done`, three enqueues: ~70 us).
                 // Should the pump below have to queue more work, the epilogue is simply issued again at the end.
@@ -1154,11 +1203,16 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                         ctx->stats.sweep64_launches += 1;
                         ctx->stats.sweep64_ms += ms;
                     }
-                } else if (ctx->prof_kind[i] == 3) {
-                    // lookahead sweep: a launch that found nothing to do returns in microseconds
-                    if ((double)ctx->stats.sweep32_bytes / (ms * 1e-3) < 50e12) {   // < 50 TB/s: it streamed A
+                } else if (ctx->prof_kind[i] == 3 || ctx->prof_kind[i] == 5) {
+                    // lookahead sweep: a launch that found nothing to do returns in microseconds.  Bytes per EVENT: a
+                    // plain pass (3) covers all n columns, the early form's main launch (5) its share of them
+                    const uint64_t sz = sizeof(T);
+                    const uint64_t cols = ctx->prof_kind[i] == 5 ? ctx->stats.sweep32_timed_cols : (uint64_t)ctx->n;
+                    const uint64_t bytes = (uint64_t)ctx->m * cols * sz + 32ull * ctx->m * sz + 32ull * cols * sz;
+                    if ((double)bytes / (ms * 1e-3) < 50e12) {   // < 50 TB/s: it streamed A
                         ctx->stats.sweep32_launches += 1;
                         ctx->stats.sweep32_ms += ms;
+                        ctx->stats.sweep32_bytes_timed += bytes;
                     }
                 } else if ((uint32_t)(ctx->prof_kind[i] - 16) <= hs.done_round) {
                     ctx->stats.sweep_launches += 1;
@@ -1203,7 +1257,7 @@ bool ensure_full_gram(ss_hip_ctx* ctx)
     if (g0) (void)hipEventRecord(g0, ctx->stream);
     const hipError_t e = ctx->gram_symmetric
         ? launch_gemm_sym_f32(ctx, G, pitch)
-        : launch_gemm_tn_f32(ctx, static_cast<const float*>(ctx->At), (uint32_t)np, ctx->ldm, G, pitch, nullptr);
+        : launch_gemm_tn_f32(ctx, static_cast<const float*>(ctx->At), (uint32_t)np, ctx->ldm, G, pitch, nullptr, false);
     if (g1) (void)hipEventRecord(g1, ctx->stream);
     if (e != hipSuccess) { (void)hipFree(G); throw HipFail{ e, "launch_gemm_tn_f32(full Gram)" }; }
     if (g0 && g1 && hipEventSynchronize(g1) == hipSuccess) {
@@ -1216,6 +1270,44 @@ bool ensure_full_gram(ss_hip_ctx* ctx)
     ctx->gram_full = G;
     ctx->gram_pitch = pitch;
     ctx->stats.gram_full_builds += 1;
+    return true;
+}
+
+// Column form of mid-size batches: makes sure the context holds the Gram-column cache ((max_iter + 2) * per rows of
+// n_pad fp32, rounded up to 1024 columns), the row tables and the pass lists for chunks of `per` signals.  Returns
+// false — nothing thrown, the sticky error cleared — when that does not fit the budget (option gram_full_gib) or the
+// free HBM, or an allocation fails: the dispatcher then runs the batch another way.  Sizes only grow; the buffers are
+// released with the context.
+bool ensure_bcol(ss_hip_ctx* ctx, size_t per, uint32_t max_iter)
+{
+    const size_t np = ctx->n_pad;
+    const size_t pitchc = (np + 1023) / 1024 * 1024;
+    const size_t rows_needed = ((size_t)max_iter + 2) * per;
+    auto try_malloc = [](void** p, size_t bytes) {
+        if (hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+        return true;
+    };
+    if (ctx->bcol_cache_rows < rows_needed) {
+        const size_t bytes = rows_needed * pitchc * sizeof(float);
+        const size_t held = ctx->bcol_cache_rows * pitchc * sizeof(float);
+        if (ctx->gram_full_gib <= 0 || bytes > ((size_t)ctx->gram_full_gib << 30)) return false;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (bytes + ((size_t)4 << 30) > free_b + held) return false;          // keep 4 GiB for everything else
+        if (ctx->bcol_cache) (void)hipFree(ctx->bcol_cache);
+        ctx->bcol_cache = nullptr;
+        ctx->bcol_cache_rows = 0;
+        if (!try_malloc(reinterpret_cast<void**>(&ctx->bcol_cache), bytes)) return false;
+        ctx->bcol_cache_rows = rows_needed;
+    }
+    if (ctx->bcol_slot_rows < per) {
+        if (ctx->bcol_slot) (void)hipFree(ctx->bcol_slot);
+        ctx->bcol_slot = nullptr;
+        ctx->bcol_slot_rows = 0;
+        if (!try_malloc(reinterpret_cast<void**>(&ctx->bcol_slot), per * np * sizeof(int32_t))) return false;
+        ctx->bcol_slot_rows = per;
+    }
+    if (!ctx->bcol_lists && !try_malloc(reinterpret_cast<void**>(&ctx->bcol_lists), 2 * 1024 * sizeof(uint32_t))) return false;
     return true;
 }
 
@@ -1248,6 +1340,18 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             const uint32_t Bc = (uint32_t)std::min(chunk, B - b0);
             ensure_workspace<T>(ctx, Bc, kcap);
             Workspace<T>& ws = *ws_of<T>(ctx);
+            // option "trace": the path of the batch's FIRST signal (slot 0 of the first chunk) is recorded like a single solve's
+            const uint32_t want_trace = (ctx->tracing && b0 == 0) ? (uint32_t)std::min<uint64_t>((uint64_t)max_iter + 2, 1u << 20) : 0u;
+            if (want_trace > ws.trace_cap) {
+                if (ws.trace) HIPCHK(hipFree(ws.trace));
+                ws.trace = nullptr;
+                ws.trace_cap = 0;
+                HIPCHK(hipMalloc(&ws.trace, (size_t)want_trace * sizeof(TraceEntry)));
+                ws.trace_cap = want_trace;
+            }
+            TraceEntry* const trace_keep = ws.trace;
+            if (want_trace == 0u) ws.trace = nullptr;
+            struct RestoreTrace { Workspace<T>& w; TraceEntry* p; ~RestoreTrace() { w.trace = p; } } restore_trace{ ws, trace_keep };
             const uint32_t rows = (Bc + 127u) / 128u * 128u;          // GEMM rows of each block
             const size_t bp = ws.dims.b_pad;
             T* const Rblk = ws.rhs;
@@ -1299,25 +1403,13 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             BatchCols bc;
             const bool cols_chunk = gram_chunk && cols_form;
             if (cols_chunk) {
-                // one cache row per slot and round (round 0 = the first pick), a row table per slot, the pass lists
+                // one cache row per slot and round (round 0 = the first pick), a row table per slot, the pass lists:
+                // sized by the dispatcher (ensure_bcol), which sends the batch another way when they do not fit
                 const size_t rows_needed = ((size_t)max_iter + 2) * Bc;
                 const size_t pitchc = (np + 1023) / 1024 * 1024;          // (k_la_cq reads whole 1024-column chunks of a row)
-                if (ctx->bcol_cache_rows < rows_needed) {
-                    if (ctx->bcol_cache) HIPCHK(hipFree(ctx->bcol_cache));
-                    ctx->bcol_cache = nullptr;
-                    ctx->bcol_cache_rows = 0;
-                    HIPCHK(hipMalloc(&ctx->bcol_cache, rows_needed * pitchc * sizeof(T)));
-                    ctx->bcol_cache_rows = rows_needed;
-                }
+                if (ctx->bcol_cache_rows < rows_needed || ctx->bcol_slot_rows < Bc || !ctx->bcol_lists)
+                    throw HipFail{ hipErrorOutOfMemory, "column form: cache not sized for this chunk" };
                 bc.pitch = (uint32_t)pitchc;
-                if (ctx->bcol_slot_rows < Bc) {
-                    if (ctx->bcol_slot) HIPCHK(hipFree(ctx->bcol_slot));
-                    ctx->bcol_slot = nullptr;
-                    ctx->bcol_slot_rows = 0;
-                    HIPCHK(hipMalloc(&ctx->bcol_slot, (size_t)Bc * np * sizeof(int32_t)));
-                    ctx->bcol_slot_rows = Bc;
-                }
-                if (!ctx->bcol_lists) HIPCHK(hipMalloc(&ctx->bcol_lists, 2 * 1024 * sizeof(uint32_t)));
                 HIPCHK(hipMemsetAsync(ctx->bcol_slot, 0xff, (size_t)Bc * np * sizeof(int32_t), st));
                 bc.cache = ctx->bcol_cache;
                 bc.bslot = ctx->bcol_slot;
@@ -1354,11 +1446,14 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 if (gram_chunk) {
                     const bool timed_cq = ctx->profiling != 0 && ncq < 4096;
                     if (timed_cq) HIPCHK(hipEventRecord(prof_event(ctx, 2 * ncq), st));
-                    HIPCHK(launch_cq_gram_batched<T>(ctx, ws, Bc, Gsrc, Gpitch, ctx->c0_batch, &nparts, cols_chunk ? bc.bslot : nullptr));
+                    // (fused form: the scan and the pick of this round happen inside the Gram-form pass, k_la_cqs)
+                    const bool fused = cqs_usable(ctx, ws.dims.pmin_stride);
+                    HIPCHK(launch_cq_gram_batched<T>(ctx, ws, Bc, Gsrc, Gpitch, ctx->c0_batch, &nparts, cols_chunk ? bc.bslot : nullptr,
+                                                     fused ? (uint32_t)round : 0u, tol, max_iter));
                     if (timed_cq) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * ncq + 1), st)); ++ncq; }
                     bc.row_base = (uint32_t)(round * Bc);
                     HIPCHK(launch_tail_gram_batched<T>(ctx, ws, Bc, (uint32_t)round, nparts, tol, max_iter,
-                                                       Gsrc, Gpitch, cols_chunk ? &bc : nullptr));
+                                                       Gsrc, Gpitch, cols_chunk ? &bc : nullptr, fused));
                     if (cols_chunk) ctx->stats.batch_col_rounds += 1;
                 } else {
                     HIPCHK(launch_tile_list(ctx, ws.st, Bc, rows, ws.tile_skip));
@@ -1385,6 +1480,11 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 for (uint32_t b = 0; b < Bc; ++b) copy_out<T>(ctx, Xc + (ptrdiff_t)b * x_stride, incx, ws.x + (size_t)b * np, n);
             }
             HIPCHK(hipStreamSynchronize(st));
+            if (want_trace != 0u && ws.trace) {
+                const size_t cnt = std::min<size_t>((size_t)hs[0].iter + 1, ws.trace_cap);
+                ctx->last_trace.resize(cnt);
+                HIPCHK(hipMemcpy(ctx->last_trace.data(), ws.trace, cnt * sizeof(TraceEntry), hipMemcpyDeviceToHost));
+            }
             std::vector<uint32_t> ties;                      // slots whose scan met a tie stall (DevState::tie_stall)
             for (uint32_t b = 0; b < Bc; ++b) {
                 if (!hs[b].done) { set_err(err, errlen, "solve_batch: internal error, a signal did not terminate"); return SS_HIP_ERUNTIME; }
@@ -1492,12 +1592,20 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
     // per slot and round; a budget (option gram_full_gib) it does not fit sends the batch the old way.
     if (form == 0 && !ctx->gram_full && ctx->engine >= 1 && ctx->batch_cols_min > 0 && B >= (size_t)std::max(2, ctx->batch_cols_min) &&
         (ctx->batch_cols_max <= 0 || B <= (size_t)ctx->batch_cols_max) && ctx->n_pad % 256 == 0) {
-        // signals per chunk: at most 448 (7 full passes per round), at most what the cache budget holds, whole passes
+        // signals per chunk: at most 448 (7 full passes per round), at most what the cache budget AND the free HBM hold
+        // (the cache is (max_iter + 2) rows per signal: a large max_iter with many signals does not fit — such a batch
+        // goes the old way instead of failing), whole passes
         const double row_bytes = ((double)max_iter + 2.0) * (double)((ctx->n_pad + 1023) / 1024 * 1024) * 4.0;
-        const double fit = (double)ctx->gram_full_gib * 1073741824.0 / row_bytes;
+        double budget = (double)ctx->gram_full_gib * 1073741824.0;
+        size_t free_b = 0, total_b = 0;
+        if (hipSetDevice(ctx->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double held = (double)ctx->bcol_cache_rows * (double)((ctx->n_pad + 1023) / 1024 * 1024) * 4.0;
+            budget = std::min(budget, std::max(0.0, (double)free_b + held - 4.0 * 1073741824.0));
+        } else (void)hipGetLastError();
+        const double fit = budget / row_bytes;
         size_t per = (size_t)std::min<double>(448.0, std::max(0.0, fit));
         if (per >= B) per = B; else per = per / 64 * 64;
-        if (per >= 64 || (per == B && per > 0)) { form = 2; ctx->bcol_chunk = (int)std::max<size_t>(per, 1); }
+        if ((per >= 64 || (per == B && per > 0)) && ensure_bcol(ctx, per, max_iter)) { form = 2; ctx->bcol_chunk = (int)std::max<size_t>(per, 1); }
     }
     if (lockstep || form == 2)
         return solve_batch_gemm_f32(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, form,
@@ -1803,6 +1911,7 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
         else free_ws(static_cast<Workspace<float>*>(ctx->ws));
     }
     sship::irls_free(ctx);
+    sship::colshard_destroy(ctx);
     if (ctx->gram_full) (void)hipFree(ctx->gram_full);
     if (ctx->c0_batch) (void)hipFree(ctx->c0_batch);
     if (ctx->bcol_cache) (void)hipFree(ctx->bcol_cache);
@@ -1978,6 +2087,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "profile_solve_every")) { ctx->profile_solve_every = (int)std::max<long>(1, value); ctx->prof_solve_tick = 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_rerun"))     { ctx->tie_rerun = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_fused_scan")) { ctx->batch_fused_scan = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(9, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "first_sweep_cols")) { ctx->first_sweep_cols = value > 32 ? 64 : 32; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_solo"))    { ctx->early_solo = value ? 1 : 0; return SS_HIP_OK; }
@@ -2051,6 +2161,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     }
     if (!std::strcmp(key, "engine"))        { *value = ctx->engine; return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_rerun"))     { *value = ctx->tie_rerun; return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_fused_scan")) { *value = ctx->batch_fused_scan; return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { *value = ctx->la_fused; return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_subset"))   { *value = ctx->solo_subset; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep32_variant")) { *value = ctx->sweep32_variant; return SS_HIP_OK; }

@@ -475,6 +475,7 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
     uint32_t iter = st->iter;
     float c_inf_rep = (float)st->c_inf;      // what the report will carry
     float gamma_last = (float)st->gamma;
+    const float lambda0 = st->lambda0;       // scale of the tie band (ss_hip_device.h)
     uint32_t last_idx = st->idx, last_rank = st->rank, last_added = st->added;
     uint32_t done_round = 0u, status = 0u;
     // why the launch ends (kPsExit*, ss_hip_internal.h)
@@ -746,13 +747,14 @@ void k_la_persist(float tol, uint32_t max_iter, uint32_t n, uint32_t P, uint32_t
                 if (dl != 0.f) {
                     float t = (c_inf - ci) / dl;
                     if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
-                    if (t == 0.f) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see DevState::tie_stall)
+                    // (see DevState::tie_stall; the column that left the support in the previous iteration sits on the boundary by rule)
+                    if (t == 0.f && !(last_added == 0u && col[k] == last_idx) && tie_band<float>(c_inf, c_inf_rep, gamma_last, lambda0)) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (t > 0.f && t < m) m = t;
                 }
                 if (dr != 0.f) {
                     float t = (c_inf + ci) / dr;
                     if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
-                    if (t == 0.f) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t == 0.f && !(last_added == 0u && col[k] == last_idx) && tie_band<float>(c_inf, c_inf_rep, gamma_last, lambda0)) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (t > 0.f && t < m) m = t;
                 }
             }

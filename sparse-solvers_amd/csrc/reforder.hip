@@ -224,6 +224,7 @@ void k_ro_init(const T* __restrict__ At, SlotDims L, const T* __restrict__ c,
         st->done_round = 0;
         st->c_inf = (double)c_inf;
         st->gamma = 0.0;
+        st->lambda0 = (float)c_inf;
         st->dot = (double)dot;
         if (trace != nullptr) { trace[0].idx = idx; trace[0].added = 1; trace[0].gamma = 0.0; trace[0].c_inf = (double)c_inf; }
     }

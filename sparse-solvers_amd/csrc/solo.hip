@@ -87,6 +87,8 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
 {
     uint64_t tsv[8];
     tsv[0] = wall_clock64();
+    __shared__ uint32_t s_tieok[kSoloChunk];            // breakpoint k: lambda is where the previous step left it (tie_band) ...
+    __shared__ uint32_t s_tiejr[kSoloChunk];            // ... and the column that left the support in the step before (or none)
     __shared__ float sX[kVfUnion][kSoloChunk];          // x_S of union column r at breakpoint k (0 when absent)
     __shared__ float sD[kVfUnion][kSoloChunk];
     __shared__ uint64_t sRed[kSoloChunk * kVfRedPitch]; // reductions: one row per breakpoint
@@ -162,6 +164,25 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
         __syncthreads();
         if (k0 == 0) tsv[2] = wall_clock64();
         if (tid < J * 8u) s_hdr[tid >> 3][tid & 7u] = sE[(tid >> 3) * kSoloEntryWords + (tid & 7u)];
+        if (tid < J) {
+            // tie stalls (DevState::tie_stall): an exact-zero candidate counts only while lambda is where the previous
+            // step left it, and never for the column that has just left the support — the rules of k_scansel, from the
+            // log: the previous entry (the state the launch started from for the first one) has lambda, gamma and the pick
+            const uint32_t g = k0 + tid;
+            const uint32_t* cur = sE + tid * kSoloEntryWords;
+            float lam_prev, gam_prev;
+            uint32_t jr = 0xffffffffu;
+            if (g == 0u) {
+                lam_prev = (float)st->c_inf; gam_prev = (float)st->gamma;
+                if (st->iter >= 1u && st->added == 0u) jr = st->idx;
+            } else {
+                const uint32_t* pe = entries + (size_t)(g - 1u) * kSoloEntryWords;
+                lam_prev = __uint_as_float(pe[4]); gam_prev = __uint_as_float(pe[5]);
+                if (cur[0] + 1u == pe[0]) jr = pe[3];                     // the support shrank: that pick was a removal
+            }
+            s_tieok[tid] = tie_band<float>(__uint_as_float(cur[4]), lam_prev, gam_prev, st->lambda0) ? 1u : 0u;
+            s_tiejr[tid] = jr;
+        }
         for (uint32_t pr = tid; pr < J * kSoloListPitch; pr += kVfyThreads) {
             const uint32_t k = pr / kSoloListPitch, j = pr - k * kSoloListPitch;
             const uint32_t* e = sE + k * kSoloEntryWords;
@@ -293,13 +314,13 @@ void k_la_verify(uint32_t n, int full_g, const float* __restrict__ gcache, uint3
                     if (dl != 0.f) {
                         float t = (c_inf - ci2) / dl;
                         if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
-                        if (t == 0.f) __hip_atomic_store(tie_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see DevState::tie_stall)
+                        if (t == 0.f && s_tieok[kk] && i != s_tiejr[kk]) __hip_atomic_store(tie_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (t > 0.f && t < m) m = t;
                     }
                     if (dr != 0.f) {
                         float t = (c_inf + ci2) / dr;
                         if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
-                        if (t == 0.f) __hip_atomic_store(tie_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (t == 0.f && s_tieok[kk] && i != s_tiejr[kk]) __hip_atomic_store(tie_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (t > 0.f && t < m) m = t;
                     }
                 }

@@ -191,6 +191,18 @@ __device__ __forceinline__ T sign_tol(T v, T tol)   // homotopy-cpu.cpp:59-67
     return T(0);
 }
 
+// Is lambda = ||c||_inf where the previous step left it?  In exact arithmetic lambda_now = lambda_prev - gamma_prev; a
+// candidate that is exactly 0 while that holds within rounding (256 eps of the solve's first lambda: the absolute
+// error of a Gram-form correlation is ~eps * ||A^T y||_inf * sqrt(K)) is a TIE decided by rounding.  When lambda jumped
+// instead, an off-support column dominates by a margin — every summation order sees that, nothing to arbitrate.
+template <typename T>
+__device__ __forceinline__ bool tie_band(T c_inf_now, T lambda_prev, T gamma_prev, T lambda0)
+{
+    const T expect = lambda_prev - gamma_prev;
+    const T diff = c_inf_now > expect ? c_inf_now - expect : expect - c_inf_now;
+    return diff <= T(256) * Lim<T>::eps() * lambda0;
+}
+
 // dot product of two contiguous device rows of length len (multiple of 256) by one block
 template <typename T>
 __device__ __forceinline__ T block_dot(const T* a, const T* b, uint32_t len, T* sv)

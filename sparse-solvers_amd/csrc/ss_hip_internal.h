@@ -74,10 +74,14 @@ struct DevState {
     uint32_t solo_started; // early form: set by the solo launch when it begins (the passes over A on the second stream wait for it)
     uint32_t subg_active;  // early form: 1 while the solo launches of this solve run on the subset Gram matrix Gs (until their first commit)
     uint32_t solo_where;   // early form: (XCC_ID << 16 | HW_ID) of the solo workgroup + 1 (0 = none): the passes keep off its shader engine
-    uint32_t tie_stall;    // a step-length scan met an off-support column whose candidate is exactly 0: it attains max|c| (a tie within
-                           // rounding) and the reference's strict t > 0 (homotopy-cpu.cpp:143-153) skips it for good.  Which implementation
-                           // hits that is rounding luck: the host re-runs such a signal in the reference-order engine (reforder.hip)
-    uint32_t pad0_[2];
+    uint32_t tie_stall;    // a step-length scan met an off-support column whose candidate is exactly 0 while lambda is where the previous
+                           // step left it (tie_band): two columns reached the boundary within rounding, this one attains max|c| and the
+                           // reference's strict t > 0 (homotopy-cpu.cpp:143-153) skips it for good.  Which implementation hits that is
+                           // rounding luck: the host re-runs such a signal in the reference-order engine (reforder.hip).  Not raised for
+                           // the column that has just LEFT the support (it sits on the boundary by rule), nor when an off-support column
+                           // dominates by a margin (a path already derailed, e.g. by the first-step sign quirk: every rounding agrees)
+    float    lambda0;      // ||A^T y||_inf, the first lambda of the solve (the scale of the tie band, ss_hip_device.h: tie_band)
+    uint32_t pad0_[1];
     // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
     uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
     uint32_t pad1_[31];
@@ -254,6 +258,7 @@ struct ss_hip_ctx {
     hipEvent_t ev_join4 = nullptr;
     hipEvent_t ev_gate = nullptr, ev_b0 = nullptr, ev_join3 = nullptr;
     uint32_t* se_count = nullptr;     // [2][kSeCount + 2] device counters, one set per pass: arrivals per SE, arrivals in all, tiles taken
+    int batch_fused_scan = 1;         // option: the batched Gram forms scan inside the Gram-form pass (k_la_cqs: c, q stay in registers)
     int scan_blocks = 8;              // option: workgroups per slot of the batched Gram form's scan (0 = one per 1024 columns)
     int sweep_f64_variant = 0;        // option: tiling of the 32-column fp64 pass (0 = 256 columns / 512 threads / 1 per CU; 1, 2 = 128 / 256 / 2, 3 per CU)
     uint64_t solo_seen = 0, solo_failed = 0;   // speculative solves / failed checks since the form was last switched off (private: not the statistics)
@@ -270,6 +275,7 @@ struct ss_hip_ctx {
     int gram_single = 1;         // option: 1 = single-signal solves use G as their Gram-column cache once it exists, 0 = never
     int gram_symmetric = 1;      // option: 1 = G is formed from the tiles on and above the diagonal + mirrored store, 0 = full product
     uint64_t single_solves = 0;  // single-signal solves since create (the trigger of gram_full_after; not a statistic)
+    void* colshard = nullptr;    // sship::ColShard* of a column-sharded context (colshard.hip): shard description, communicator, replicated active set
     int kind = 0;            // 0 = Homotopy / OMP context, 1 = IRLS context
     void* irls = nullptr;    // sship::IrlsState<T>* of an IRLS context
     int device = 0;
@@ -320,6 +326,7 @@ struct ss_hip_ctx {
     // Written by the device with system-scope stores, polled by the host loop (no copies in the stream).
     uint32_t* host_flags = nullptr;
     void* hs_pinned = nullptr;        // pinned landing place of the end-of-solve DevState copy (sizeof(DevState))
+    void* hs_mapped = nullptr;        // its device address (k_epilogue writes the state there)
     uint32_t* dev_flags = nullptr;    // device address of host_flags
     std::vector<hipEvent_t> prof_events;   // pairs (start, stop) for sweeps of the current solve
     std::vector<int> prof_kind;            // 2 = fused sweep, 1 = single-RHS sweep
@@ -403,12 +410,17 @@ struct BatchCols {
 hipError_t launch_batch_cols(const ss_hip_ctx* ctx, const DevState* st, uint32_t nslots, uint32_t row_base, bool first,
                              int32_t* bslot, uint32_t* rcols, uint32_t* drows, uint32_t cap);
 hipError_t launch_batch_passes(const ss_hip_ctx* ctx, const BatchCols* cols, uint32_t nslots);
+// round != 0: the fused form (k_la_cqs: Gram-form pass + lambda + scan + pick of that round in one launch; the tail
+// is then called with scan_done = true)
+bool cqs_usable(const ss_hip_ctx* ctx, uint32_t pmin_stride);
 template <typename T>
 hipError_t launch_cq_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, const T* G, uint32_t gpitch,
-                                  const T* c0b, uint32_t* nparts_out, const int32_t* bslot = nullptr);
+                                  const T* c0b, uint32_t* nparts_out, const int32_t* bslot = nullptr,
+                                  uint32_t round = 0, T tol = T(0), uint32_t max_iter = 0);
 template <typename T>
 hipError_t launch_tail_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts,
-                                    T tol, uint32_t max_iter, const T* G, uint32_t gpitch, const BatchCols* cols = nullptr);
+                                    T tol, uint32_t max_iter, const T* G, uint32_t gpitch, const BatchCols* cols = nullptr,
+                                    bool scan_done = false);
 // orthogonal matching pursuit in Gram form: one launch per iteration, and the pending update after a fetch
 template <typename T>
 hipError_t launch_la_omp(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter);
@@ -456,7 +468,7 @@ hipError_t launch_gemv_n(const ss_hip_ctx* ctx, const T* x_dev, T* y_dev);
 // D[Mg][ldd] = R[Mg][ldr] * At^T on the MFMA units (fp32).  Mg % 128 == 0.  tile_list (may be
 // null = all tiles): compact list of the row tiles to compute, count at tile_list[Mg/128].
 hipError_t launch_gemm_tn_f32(const ss_hip_ctx* ctx, const float* R, uint32_t Mg, uint32_t ldr,
-                              float* D, uint32_t ldd, const uint32_t* tile_list);
+                              float* D, uint32_t ldd, const uint32_t* tile_list, bool blocked = true);
 
 // G[n_pad][ldd] = At · At^T (the full Gram matrix) from the tiles on and above the diagonal + mirrored stores
 hipError_t launch_gemm_sym_f32(const ss_hip_ctx* ctx, float* G, uint32_t ldd);
@@ -497,5 +509,9 @@ hipError_t launch_gemm64_tn_f64(const ss_hip_ctx* ctx, const uint32_t* rcols, co
 
 // ---- helpers implemented in homotopy.hip ---------------------------------------
 void set_err(char* err, size_t errlen, const std::string& msg);
+// the one-slot fp32 workspace of a context with an active-set capacity of at least kcap (0 / ss_hip_status)
+int colshard_workspace(ss_hip_ctx* ctx, uint32_t kcap);
+// ---- colshard.hip: releases the column-sharded state of a context (communicator, replicated active set)
+void colshard_destroy(ss_hip_ctx* ctx);
 
 }  // namespace sship

@@ -33,7 +33,19 @@ SYMBOLS = [
     "ss_hip_set_option", "ss_hip_get_option", "ss_hip_get_trace", "ss_hip_ctx_info",
     "ss_hip_irls_create_f32", "ss_hip_irls_create_f64", "ss_hip_irls_solve_f32", "ss_hip_irls_solve_f64",
     "ss_hip_irls_destroy",
+    "ss_hip_comm_unique_id", "ss_hip_homotopy_colshard_create_f32", "ss_hip_homotopy_colshard_solve_f32",
 ]
+
+
+COMM_ID_BYTES = 128
+_CB_U64 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t)
+_CB_F32 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t)
+
+
+class Collectives(ctypes.Structure):
+    """struct ss_hip_collectives (include/ss_hip.h): host-side in-place all-reduces"""
+    _fields_ = [("user", ctypes.c_void_p), ("allreduce_max_u64", _CB_U64), ("allreduce_min_u64", _CB_U64),
+                ("allreduce_sum_f32", _CB_F32)]
 
 
 class Stats(ctypes.Structure):
@@ -68,6 +80,7 @@ class Stats(ctypes.Structure):
         ("sweep64_bytes", ctypes.c_uint64),
         ("batch_col_rounds", ctypes.c_uint64),
         ("sweep32_timed_cols", ctypes.c_uint64),
+        ("sweep32_bytes_timed", ctypes.c_uint64),
         ("tie_reruns", ctypes.c_uint64),
     ]
 
@@ -144,6 +157,14 @@ def lib():
     L.ss_hip_get_trace.argtypes = [vp, u32, vp, vp, vp, vp, ctypes.POINTER(u32)]
     L.ss_hip_ctx_info.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(sz),
                                   ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.ss_hip_comm_unique_id.restype = ctypes.c_int
+    L.ss_hip_comm_unique_id.argtypes = [vp, cp, sz]
+    L.ss_hip_homotopy_colshard_create_f32.restype = vp
+    L.ss_hip_homotopy_colshard_create_f32.argtypes = [vp, sz, sz, pd, pd, sz, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.POINTER(Collectives), cp, sz]
+    L.ss_hip_homotopy_colshard_solve_f32.restype = ctypes.c_int
+    L.ss_hip_homotopy_colshard_solve_f32.argtypes = [vp, vp, pd, ctypes.c_float, u32, vp, pd, ctypes.POINTER(u32),
+                                                     ctypes.POINTER(ctypes.c_double), cp, sz]
     _lib = L
     return L
 
@@ -432,6 +453,84 @@ class Homotopy:
         if rc != 0:
             raise SsHipError(rc, "unknown option %r" % key)
         return int(v.value)
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0 calls it and distributes the 128 bytes) -> bytes"""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    err = ctypes.create_string_buffer(512)
+    rc = lib().ss_hip_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p), err, len(err))
+    if rc != 0:
+        raise SsHipError(rc, err.value.decode())
+    return buf.raw
+
+
+class ColumnSharded(Homotopy):
+    """ONE signal over a column-sharded dictionary (ss_hip_homotopy_colshard_*_f32): this rank owns the columns
+    [col_lo, col_lo + A_local.shape[1]) of the m x n_total matrix.  Transport: `comm_id` (128 bytes from
+    comm_unique_id(), the same on every rank: RCCL) or `allreduce` = a callable (numpy array, op) -> None that
+    all-reduces the array IN PLACE over the ranks, op in {"max", "min", "sum"} (host collectives: tests, other
+    transports); world == 1 needs neither."""
+
+    def __init__(self, A_local, col_lo, n_total, rank=0, world=1, comm_id=None, allreduce=None, device=0):
+        ptr, shape, strides, dt, keep = _describe(A_local)
+        if len(shape) != 2 or dt != np.float32:
+            raise ValueError("A_local must be a 2-D float32 matrix")
+        _sync_producers(A_local)
+        self.suffix, self.ctype = _suffix(dt)
+        self.dtype = dt
+        self.m, self.n = int(shape[0]), int(shape[1])
+        self.col_lo, self.n_total = int(col_lo), int(n_total)
+        self._coll = None
+        coll_p = None
+        if comm_id is None and allreduce is not None:
+            def wrap(op, ctype_np):
+                def cb(user, buf, count):
+                    try:
+                        allreduce(np.ctypeslib.as_array(buf, shape=(int(count),)), op)
+                        return 0
+                    except Exception:                     # an exception must not cross the C boundary
+                        import traceback
+                        traceback.print_exc()
+                        return 1
+                return cb
+            self._cbs = (_CB_U64(wrap("max", np.uint64)), _CB_U64(wrap("min", np.uint64)), _CB_F32(wrap("sum", np.float32)))
+            self._coll = Collectives(None, *self._cbs)
+            coll_p = ctypes.byref(self._coll)
+        idbuf = None
+        if comm_id is not None:
+            if len(comm_id) != COMM_ID_BYTES:
+                raise ValueError("comm_id must be %d bytes" % COMM_ID_BYTES)
+            idbuf = ctypes.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        err = ctypes.create_string_buffer(512)
+        # (an empty shard has no data pointer worth passing)
+        self._h = lib().ss_hip_homotopy_colshard_create_f32(
+            ptr if self.n else None, self.m, self.n, strides[0], strides[1], self.col_lo, self.n_total, device,
+            ctypes.cast(idbuf, ctypes.c_void_p) if idbuf is not None else None, int(rank), int(world), coll_p, err, len(err))
+        if not self._h:
+            raise SsHipError(-1, err.value.decode())
+
+    def solve(self, y, tolerance=None, max_iterations=100, out=None):
+        """-> (x_local, iter, solution_error): the shard's coefficients"""
+        yp, yshape, ystr, ydt, keep = _describe(y)
+        if ydt != self.dtype or len(yshape) != 1 or yshape[0] != self.m:
+            raise ValueError("y must be a float32 vector of length m = %d" % self.m)
+        if tolerance is None:
+            tolerance = float(np.finfo(self.dtype).eps) * 10
+        if out is None:
+            out = np.empty(self.n, dtype=self.dtype)
+        xp, xshape, xstr, xdt, keepx = _describe(out)
+        if xdt != self.dtype or len(xshape) != 1 or xshape[0] != self.n:
+            raise ValueError("out must be a float32 vector of the shard's width")
+        it = ctypes.c_uint32(0)
+        e = ctypes.c_double(0.0)
+        err = ctypes.create_string_buffer(512)
+        _sync_producers(y, out)
+        rc = lib().ss_hip_homotopy_colshard_solve_f32(self._h, yp, ystr[0], ctypes.c_float(tolerance), int(max_iterations),
+                                                      xp if self.n else None, xstr[0] if self.n else 1, ctypes.byref(it), ctypes.byref(e),
+                                                      err, len(err))
+        self._check(rc, err)
+        return out, int(it.value), float(e.value)
 
 
 class Irls:

@@ -111,3 +111,85 @@ def test_record_layout_and_truncation():
     # raw words: K, iter, err, idx[0]
     w = rec[0].view(np.uint32)
     assert w[0] == 4 and w[1] == 4 and w[4] == 3 and rec[0][8:16].view(np.float64)[0] == 1e-4
+
+
+# ---------------------------------------------------------------- the PRODUCT under world_size 2 (one MI355X)
+
+def _gpu_batch(B=64, m=256, n=2048, k=8):
+    rng = np.random.default_rng(505)
+    A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(np.float32)
+    Y = np.zeros((B, m), np.float32)
+    for b in range(B):
+        x0 = np.zeros(n)
+        x0[rng.choice(n, k, replace=False)] = 1 + np.abs(rng.standard_normal(k))
+        Y[b] = (A.astype(np.float64) @ x0).astype(np.float32)
+    return A, Y
+
+
+def _gpu_rank(rank, world, port, tmpdir, B):
+    """one rank of configs[3]'s code path: its shard_range block through ss_hip_homotopy_solve_batch_compact_f32
+    (device inputs, records packed on the device by k_pack_records), then the gather of the record bytes"""
+    import torch
+    import torch.distributed as dist
+    import sship
+    from sharding import gather_records, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, Y = _gpu_batch(B)
+    lo, hi = shard_range(len(Y), rank, world)
+    with sship.Homotopy(torch.from_numpy(A).to("cuda:0")) as h:
+        Yd = torch.from_numpy(Y[lo:hi]).to("cuda:0")
+        rec = torch.zeros((hi - lo, h.record_bytes(KMAX)), dtype=torch.uint8, device="cuda:0")
+        h.solve_batch_compact(Yd, 1e-3, 64, kmax=KMAX, out=rec)
+        torch.cuda.synchronize()
+        st = h.stats()
+    max_rows = max(shard_range(len(Y), r, world)[1] - shard_range(len(Y), r, world)[0] for r in range(world))
+    # (two ranks on ONE GPU cannot form an RCCL communicator: the bytes cross through gloo; on an 8-GPU node
+    # bench.py --gpus N gathers the same device buffers with the nccl backend)
+    allrec = gather_records(rec.cpu(), world, max_rows=max_rows)
+    np.savez(os.path.join(tmpdir, "rank%d.npz" % rank), rec=allrec.numpy(), col_rounds=st["batch_col_rounds"],
+             solves=st["solves"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [64, 51])
+def test_product_sharded_batch_two_ranks_one_gpu(tmp_path, B):
+    """The product under world_size 2: two gloo ranks share the one MI355X of the test box, each solves its
+    shard_range block with libss_hip.so (lock-step column form, compact records packed on the device) and the
+    records are gathered as bytes.  The gathered buffer must equal, byte for byte, what ONE process writes for the
+    whole batch (a signal's arithmetic does not depend on which other signals share its batch), and decode to the
+    oracle's supports.  B = 51: ragged shards (26 + 25 rows, zero-padded gather)."""
+    import oracle
+    import sship
+    import torch
+    import torch.multiprocessing as mp
+    from sharding import shard_range, unpack_records
+    world = 2
+    port = 31800 + (os.getpid() % 1000) + B
+    mp.spawn(_gpu_rank, args=(world, port, str(tmp_path), B), nprocs=world, join=True)
+    A, Y = _gpu_batch(B)
+    with sship.Homotopy(torch.from_numpy(A).to("cuda:0")) as h:
+        rec1 = torch.zeros((B, h.record_bytes(KMAX)), dtype=torch.uint8, device="cuda:0")
+        h.solve_batch_compact(torch.from_numpy(Y).to("cuda:0"), 1e-3, 64, kmax=KMAX, out=rec1)
+        torch.cuda.synchronize()
+    ref = rec1.cpu().numpy()
+    got0 = np.load(tmp_path / "rank0.npz")
+    got1 = np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(got0["rec"], got1["rec"])                    # every rank holds the whole result
+    assert int(got0["col_rounds"]) > 0 and int(got1["col_rounds"]) > 0     # the lock-step device path ran in both
+    rows = []
+    for r in range(world):
+        lo, hi = shard_range(B, r, world)
+        rows.append(got0["rec"][r, :hi - lo])
+        assert not got0["rec"][r, hi - lo:].any()                       # padding records are zero
+    got = np.concatenate(rows, axis=0)
+    assert np.array_equal(got, ref), "sharded records differ from the single-process records"
+    for b, r in enumerate(unpack_records(got, KMAX, np.float32)):
+        if b % 8:
+            continue
+        xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 64)
+        assert r["iter"] == ito and np.array_equal(r["idx"], np.nonzero(xo)[0])
+        assert np.abs(r["val"] - xo[r["idx"]]).max() <= 1e-5 * np.abs(xo).max()

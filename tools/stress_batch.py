@@ -9,6 +9,7 @@ import numpy as np, sship, oracle
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 tot = agree = agree_seq = bad = 0
+worst = 0.0
 t0 = time.time()
 for case in range(ncase):
     m = int(rng.choice([48, 96, 200, 400]))
@@ -35,6 +36,7 @@ for case in range(ncase):
         assert h.stats()["batch_col_rounds"] > 0
         h.set_option("batch_cols_min", 0)
         Xs, iters_s, errs_s = h.solve_batch(Y, tol, max_iter)
+    A64 = A.astype(np.float64)
     for b in range(0, B, 3):
         xo, ito, eo = oracle.homotopy(A, Y[b], tol, max_iter, flags=flags)
         tot += 1
@@ -44,14 +46,24 @@ for case in range(ncase):
             agree += 1
             if ito >= max_iter:
                 continue                         # (a path that ran to the budget: rounding-chaotic in fp32 on the CPU too)
-            scale = max(1.0, np.abs(xo).max())
-            dc = np.abs(X[b] - xo).max() / scale
-            ds = np.abs(Xs[b] - xo).max() / scale if int(iters_s[b]) == ito else 0.0
-            # the yardstick is what the one-solve-per-signal path (other summation order, same algorithm) deviates by
-            if dc > max(1e-3, 5.0 * ds):
+            # The yardstick is the reference algorithm itself in fp32 against fp64 on the same data: a device path must be
+            # as close to the double-precision answer as the fp32 oracle is.  (Distance to the fp32 ORACLE is not one: the
+            # last step of a noise-free path — every column ties at lambda -> 0 — lands where the largest rounding error
+            # among n candidates puts it, 0.5-1 % short of the fp64 step on every fp32 implementation, the oracle
+            # included; two of them agreeing there to 1e-5 is luck.  tools/dbg_colform.py)
+            xd, itd, ed = oracle.homotopy(A64, Y[b].astype(np.float64), tol, max_iter, flags=flags)
+            scale = max(1.0, np.abs(xd).max())
+            er = np.abs(xo - xd).max() / scale
+            dc = np.abs(X[b] - xd).max() / scale
+            ds = np.abs(Xs[b] - xd).max() / scale if int(iters_s[b]) == ito else 0.0
+            if ds > 0.0:
+                worst = max(worst, dc / max(ds, 1e-7))
+            # (floor 2e-4: Gram-form correlations carry an absolute error ~eps * ||c0||_inf * sqrt(K); on m <= 100 problems that
+            # is ~1e-4 on the coefficients' scale — for the one-solve path, also Gram form, alike: the ratio of the two is printed)
+            if dc > max(5.0 * er, 2e-4):
                 bad += 1
-                print("COEFFICIENTS case %d signal %d: m %d n %d B %d tol %g iters %d  column form %.3g  one solve %.3g" % (
-                    case, b, m, n, B, tol, ito, dc, ds), flush=True)
+                print("COEFFICIENTS case %d signal %d: m %d n %d B %d tol %g iters %d  |x - x_fp64|: fp32 oracle %.3g  column form %.3g  one solve %.3g" % (
+                    case, b, m, n, B, tol, ito, er, dc, ds), flush=True)
 print("%d cases, %d signals checked in %.1f s: column form agrees with the oracle's iteration count on %d (one solve per signal: %d), "
-      "%d coefficient mismatches among the agreeing" % (ncase, tot, time.time() - t0, agree, agree_seq, bad))
+      "%d signals further from the fp64 answer than max(5 x the fp32 oracle's distance, 2e-4) (worst column-form / one-solve distance ratio %.2f)" % (ncase, tot, time.time() - t0, agree, agree_seq, bad, worst))
 sys.exit(1 if bad or agree < 0.9 * tot else 0)
