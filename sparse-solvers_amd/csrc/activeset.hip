@@ -567,11 +567,41 @@ void k_la_top(const T* __restrict__ tcand, const T* __restrict__ c, uint32_t n, 
     }
 }
 
+// four consecutive elements with 16-byte loads (rows of the Gram cache, c0): a wave reads 1 KiB (fp32) per instruction
+// where four strided 4-byte loads per lane moved 256 bytes each
+__device__ __forceinline__ void load4(const float* __restrict__ p, float (&v)[4])
+{
+    const v4f t = *reinterpret_cast<const v4f*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+__device__ __forceinline__ void load4(const double* __restrict__ p, double (&v)[4])
+{
+    const v2d a = *reinterpret_cast<const v2d*>(p), b = *reinterpret_cast<const v2d*>(p + 2);
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+}
+
+// the four columns of a thread: VEC — consecutive (base + 4 tid .. + 3, one 16-byte load per row); else strided by the
+// workgroup (base + tid + 256 k, four 4-byte loads per row: each wave-instruction reads 256 contiguous bytes)
+template <bool VEC, typename T>
+__device__ __forceinline__ void load_cols(const T* __restrict__ p, T (&v)[4])
+{
+    if (VEC) load4(p, v);
+    else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = p[k * kSmallThreads];
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ uint32_t col_of(uint32_t base, uint32_t tid, int k)
+{
+    return VEC ? base + 4u * tid + (uint32_t)k : base + (uint32_t)k * kSmallThreads + tid;
+}
+
 // c = c0 - sum_j x_j g_j ; q = sum_j d_j g_j over the touched columns; partial max |c|
 constexpr uint32_t kCqChunk = 1024;
 constexpr uint32_t kCqTile = 256;        // touched columns staged in LDS per pass
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(kSmallThreads)
 void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, const T* __restrict__ c0,
              const T* __restrict__ x, const T* __restrict__ d, const uint32_t* __restrict__ touched2,
@@ -596,7 +626,7 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
     const uint32_t nt = st->ntouched;
     const uint32_t* touched = touched2 + (size_t)st->cur * L.kcap;
     const uint32_t base = blockIdx.x * kCqChunk;
-    const T* gbase = gcache + base + threadIdx.x;               // gpitch % 1024 == 0: rows never run out
+    const T* gbase = gcache + base + (VEC ? 4u : 1u) * threadIdx.x;               // gpitch % 1024 == 0: rows never run out
     T ax[4] = { T(0), T(0), T(0), T(0) }, ad[4] = { T(0), T(0), T(0), T(0) };
     for (uint32_t j0 = 0; j0 < nt; j0 += kCqTile) {
         const uint32_t cnt = (nt - j0 < kCqTile) ? (nt - j0) : kCqTile;
@@ -612,11 +642,7 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
         for (; j + 4 <= cnt; j += 4) {
             T gv[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const T* g = gbase + (size_t)s_slot[j + u] * gpitch;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) gv[u][k] = g[k * kSmallThreads];
-            }
+            for (int u = 0; u < 4; ++u) load_cols<VEC>(gbase + (size_t)s_slot[j + u] * gpitch, gv[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const T xj = s_x[j + u], dj = s_d[j + u];
@@ -625,19 +651,22 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
             }
         }
         for (; j < cnt; ++j) {
-            const T* g = gbase + (size_t)s_slot[j] * gpitch;
+            T gv1[4];
+            load_cols<VEC>(gbase + (size_t)s_slot[j] * gpitch, gv1);
             const T xj = s_x[j], dj = s_d[j];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const T gvv = g[k * kSmallThreads]; ax[k] += xj * gvv; ad[k] += dj * gvv; }
+            for (int k = 0; k < 4; ++k) { ax[k] += xj * gv1[k]; ad[k] += dj * gv1[k]; }
         }
     }
     T bv = T(-1);
     uint32_t bi = 0xffffffffu;
+    T c0v[4];
+    load_cols<VEC>(c0 + base + (VEC ? 4u : 1u) * threadIdx.x, c0v);     // (n_pad is a multiple of 256, gpitch of 1024: no tail)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t i = base + k * kSmallThreads + threadIdx.x;
+        const uint32_t i = col_of<VEC>(base, threadIdx.x, k);
         if (i < n) {
-            const T cv = c0[i] - ax[k];
+            const T cv = c0v[k] - ax[k];
             c[i] = cv;
             q[i] = ad[k];
             const T a = cv < T(0) ? -cv : cv;
@@ -664,7 +693,7 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
 // slot ends with SS_HIP_ERUNTIME instead of hanging the queue.
 constexpr uint32_t kCqsSpinLimit = 1u << 22;
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(kSmallThreads)
 void k_la_cqs(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, const T* __restrict__ c0,
               T* __restrict__ x, const T* __restrict__ d, uint32_t* __restrict__ touched2, uint32_t* __restrict__ gam2,
@@ -696,7 +725,7 @@ void k_la_cqs(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of,
     const uint32_t nt = st->ntouched;
     const uint32_t* touched = touched2 + (size_t)st->cur * kcap;
     const uint32_t base = blockIdx.x * kCqChunk;
-    const T* gbase = gcache + base + threadIdx.x;
+    const T* gbase = gcache + base + (VEC ? 4u : 1u) * threadIdx.x;
     T ax[4] = { T(0), T(0), T(0), T(0) }, ad[4] = { T(0), T(0), T(0), T(0) };
     for (uint32_t j0 = 0; j0 < nt; j0 += kCqTile) {                  // (the loop of k_la_cq, statement for statement)
         const uint32_t cnt = (nt - j0 < kCqTile) ? (nt - j0) : kCqTile;
@@ -712,11 +741,7 @@ void k_la_cqs(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of,
         for (; j + 4 <= cnt; j += 4) {
             T gv[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const T* g = gbase + (size_t)s_slot[j + u] * gpitch;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) gv[u][k] = g[k * kSmallThreads];
-            }
+            for (int u = 0; u < 4; ++u) load_cols<VEC>(gbase + (size_t)s_slot[j + u] * gpitch, gv[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const T xj = s_x[j + u], dj = s_d[j + u];
@@ -725,22 +750,25 @@ void k_la_cqs(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of,
             }
         }
         for (; j < cnt; ++j) {
-            const T* g = gbase + (size_t)s_slot[j] * gpitch;
+            T gv1[4];
+            load_cols<VEC>(gbase + (size_t)s_slot[j] * gpitch, gv1);
             const T xj = s_x[j], dj = s_d[j];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const T gvv = g[k * kSmallThreads]; ax[k] += xj * gvv; ad[k] += dj * gvv; }
+            for (int k = 0; k < 4; ++k) { ax[k] += xj * gv1[k]; ad[k] += dj * gv1[k]; }
         }
     }
     T cv[4], qv[4];
     uint8_t act[4];
     T bv = T(-1);
     uint32_t bi = 0xffffffffu;
+    T c0v[4];
+    load_cols<VEC>(c0 + base + (VEC ? 4u : 1u) * threadIdx.x, c0v);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t i = base + k * kSmallThreads + threadIdx.x;
+        const uint32_t i = col_of<VEC>(base, threadIdx.x, k);
         cv[k] = T(0); qv[k] = T(0); act[k] = 0;
         if (i < n) {
-            cv[k] = c0[i] - ax[k];
+            cv[k] = c0v[k] - ax[k];
             qv[k] = ad[k];
             act[k] = insup[i];
             const T a = cv[k] < T(0) ? -cv[k] : cv[k];
@@ -795,7 +823,7 @@ void k_la_cqs(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of,
     bool tie = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t i = base + k * kSmallThreads + threadIdx.x;
+        const uint32_t i = col_of<VEC>(base, threadIdx.x, k);
         if (i < n) {
             T m = Lim<T>::max();
             if (act[k]) {
@@ -1881,7 +1909,7 @@ hipError_t launch_la_cq(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t* npart
     const uint32_t nb = (n + kCqChunk - 1) / kCqChunk;
     if (nb > ws.dims.pmax_stride) return hipErrorInvalidValue;
     if (nparts_out) *nparts_out = nb;
-    hipLaunchKernelGGL((k_la_cq<T>), dim3(nb), dim3(kSmallThreads), 0, ctx->stream, ws.gcache, ws.slot_of,
+    hipLaunchKernelGGL((k_la_cq<T, false>), dim3(nb), dim3(kSmallThreads), 0, ctx->stream, ws.gcache, ws.slot_of,
                        ws.c0, ws.x, ws.d, ws.touched, n, ws.gpitch, ws.dims, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, ws.st);
     return hipGetLastError();
 }
@@ -2012,16 +2040,22 @@ hipError_t launch_cq_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint3
     if (nparts_out) *nparts_out = nb;
     if (round != 0) {
         if (nb > ws.dims.pmin_stride) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((k_la_cqs<T>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, bslot,
-                           c0b, ws.x, (const T*)ws.d, ws.touched, ws.gam, n, gpitch, ws.dims, ws.c, ws.q,
-                           ws.pmax_val, ws.pmax_idx, ws.pmin_val, ws.pmin_idx, ws.insup, ws.st, round, tol, max_iter,
-                           ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,
-                           (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0);
+#define SS_CQS_LAUNCH(VEC)                                                                                                   \
+        hipLaunchKernelGGL((k_la_cqs<T, VEC>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, bslot,                    \
+                           c0b, ws.x, (const T*)ws.d, ws.touched, ws.gam, n, gpitch, ws.dims, ws.c, ws.q,                           \
+                           ws.pmax_val, ws.pmax_idx, ws.pmin_val, ws.pmin_idx, ws.insup, ws.st, round, tol, max_iter,               \
+                           ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,          \
+                           (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0)
+        if (ctx->cq_vec4) SS_CQS_LAUNCH(true); else SS_CQS_LAUNCH(false);
+#undef SS_CQS_LAUNCH
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((k_la_cq<T>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, bslot,
-                       c0b, (const T*)ws.x, (const T*)ws.d, (const uint32_t*)ws.touched, n, gpitch, ws.dims, ws.c, ws.q,
-                       ws.pmax_val, ws.pmax_idx, (const DevState*)ws.st);
+#define SS_CQ_LAUNCH(VEC)                                                                                                    \
+    hipLaunchKernelGGL((k_la_cq<T, VEC>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, bslot,                         \
+                       c0b, (const T*)ws.x, (const T*)ws.d, (const uint32_t*)ws.touched, n, gpitch, ws.dims, ws.c, ws.q,            \
+                       ws.pmax_val, ws.pmax_idx, (const DevState*)ws.st)
+    if (ctx->cq_vec4) SS_CQ_LAUNCH(true); else SS_CQ_LAUNCH(false);
+#undef SS_CQ_LAUNCH
     return hipGetLastError();
 }
 

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(HT, BPC)
 void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ rcols,
                      const uint32_t* __restrict__ drows, float* __restrict__ D,
                      uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
-                     const DevState* __restrict__ st, uint32_t first, uint32_t* se_count)
+                     const DevState* __restrict__ st, uint32_t first, uint32_t* se_count, uint32_t quota)
 {
     if (!BYSE && st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
     // (BYSE: arrivals, for the main launch of the same pass — it is held back until all of these hold their CUs: a
@@ -224,8 +224,11 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
     if (BYSE && !FIXUP && threadIdx.x == 0) __hip_atomic_fetch_add(&se_count[kSeCount], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (rcols[0] == 0xffffffffu) return;                        // an empty list (lists are filled from entry 0)
     uint32_t my_tile = 0;
-    if (BYSE) {
-        __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_tile;
+    // BYSE: claims the workgroup's next tile (0xffffffff: none left for it).  `quota` tiles per shader engine in all —
+    // two at 8192 x 65536 (one per workgroup of the launch); wider dictionaries give every CU more tiles, and the
+    // workgroups of this launch then come back for more until their SE has had its share (round 3: any tile count)
+    auto claim = [&]() {
         if (threadIdx.x == 0) {
             uint32_t hw_, xcc_;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
@@ -235,19 +238,25 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
             uint32_t solo_se = 0xffffffffu;
             if (where != 0u) solo_se = ((((where - 1u) >> 16) & 7u) << 2) | (((where - 1u) >> 13) & 3u);
             uint32_t t = 0xffffffffu;
-            if (FIXUP) {
-                // third launch of the pass (same stream, afterwards): whatever the second left undone — nothing, unless
-                // the hardware dealt its workgroups out differently than assumed; coverage must not depend on that
-                t = first + __hip_atomic_load(&se_count[kSeCount + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + blockIdx.x;
-            } else if (se != solo_se) {
+            if (se != solo_se) {
                 const uint32_t slot = __hip_atomic_fetch_add(&se_count[se], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // two per shader engine take the next tile each
-                if (slot < 2u) t = first + __hip_atomic_fetch_add(&se_count[kSeCount + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < quota) t = first + __hip_atomic_fetch_add(&se_count[kSeCount + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             s_tile = t;
         }
         __syncthreads();
-        my_tile = s_tile;
+        const uint32_t t = s_tile;
+        __syncthreads();
+        return t;
+    };
+    if (BYSE) {
+        if (FIXUP) {
+            // third launch of the pass (same stream, afterwards): whatever the second left undone — nothing, unless
+            // the hardware dealt its workgroups out differently than assumed; coverage must not depend on that
+            my_tile = first + __hip_atomic_load(&se_count[kSeCount + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + blockIdx.x;
+        } else {
+            my_tile = claim();
+        }
         if (my_tile >= ntiles) return;
     }
     uint64_t* const pdbg = g_pass_dbg;
@@ -273,7 +282,8 @@ void k_gemm32_tn_f32(const float* __restrict__ At, const uint32_t* __restrict__ 
     const v4f zero4 = { 0.f, 0.f, 0.f, 0.f };
     const uint32_t nk = K / KS;
 
-    for (uint32_t bn = BYSE ? my_tile : blockIdx.x; bn < ntiles; bn += BYSE ? ntiles : gridDim.x) {
+    // (plain launches: tiles first + blockIdx.x, + gridDim.x, ...; BYSE: one claimed tile after the other)
+    for (uint32_t bn = BYSE ? my_tile : first + blockIdx.x; bn < ntiles; bn = BYSE ? ((FIXUP || quota <= 2u) ? ntiles : claim()) : bn + gridDim.x) {
         const float* gQ = At + (size_t)(bn * HN + srow) * ldq + squad * 4;
         v16f acc[RB];
 #pragma unroll
@@ -881,14 +891,14 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
         const uint32_t ntiles = ctx->n_pad / 256;
         const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
         hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1, GK, true>), dim3(grid), dim3(512), 0, ctx->stream,
-                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
+                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr, 2u);
     } else if (ctx->sweep32_variant == 4) {
         // K-step 64: 256 contiguous bytes per row and step (fewer, larger DRAM bursts per stream)
         const uint32_t ntiles = ctx->n_pad / 256;
         const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
         if (ctx->ldm % 64 != 0) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1, 64>), dim3(grid), dim3(512), 0, ctx->stream,
-                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
+                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr, 2u);
     } else if (ctx->sweep32_variant == 8 || ctx->sweep32_variant == 9) {
         // measurement aid: the early form's pass (one 32-column tile per single-wave workgroup), or two-wave workgroups
         const uint32_t ntiles = ctx->n_pad / 32;
@@ -908,7 +918,7 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
         const uint32_t ntiles = ctx->n_pad / 256;
         const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
         hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1>), dim3(grid), dim3(512), 0, ctx->stream,
-                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
+                           At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr, 2u);
     } else {
         // 128-column tiles, 256 threads, several workgroups per CU: one's barrier waits are
         // another's compute
@@ -918,10 +928,10 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
         const uint32_t grid = ntiles < cap ? ntiles : cap;
         if (ctx->sweep32_variant == 1)
             hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 2>), dim3(grid), dim3(256), 0, ctx->stream,
-                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
+                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr, 2u);
         else
             hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3>), dim3(grid), dim3(256), 0, ctx->stream,
-                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
+                               At, rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr, 2u);
     }
     return hipGetLastError();
 }
@@ -934,16 +944,27 @@ hipError_t launch_gemm32_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
 constexpr uint32_t kSePad = 10240;
 
 hipError_t launch_gemm32se_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
-                              uint32_t first, uint32_t ntiles, const DevState* st, uint32_t* se_count)
+                              uint32_t first, uint32_t ntiles, const DevState* st, uint32_t* se_count, uint32_t quota)
 {
     if (ctx->n_pad % 128 != 0 || ctx->ldm % GK != 0 || st == nullptr || se_count == nullptr) return hipErrorInvalidValue;
     // (option early_se = 2, tests: ONE workgroup per SE, so that half the tiles are left to the fix-up launch)
+    // quota: tiles per shader engine in all (2: one per workgroup of this launch; more: they come back for the next)
     hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3, GK, false, HM, true>), dim3(early_se_wgs(ctx)), dim3(256), kSePad, on,
-                       static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, first, se_count);
+                       static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, first, se_count, quota);
     // ... and whatever that left undone (nothing if the workgroups were dealt out as assumed: these then leave at once)
     if (ntiles > first)
         hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3, GK, false, HM, true, true>), dim3(ntiles - first), dim3(256), 0, on,
-                           static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, first, se_count);
+                           static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, first, se_count, quota);
+    return hipGetLastError();
+}
+
+// tiles [first, last) of a pass, one workgroup each, at most two per CU (the partial round a wide dictionary leaves)
+hipError_t launch_gemm32range_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
+                                 uint32_t first, uint32_t last)
+{
+    if (ctx->n_pad % 128 != 0 || ctx->ldm % GK != 0 || last <= first) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3>), dim3(last - first), dim3(256), kSePad, on, static_cast<const float*>(ctx->At),
+                       rcols, drows, D, ctx->ldm, ctx->ldm, ldd, last, (const DevState*)nullptr, first, nullptr, 2u);
     return hipGetLastError();
 }
 
@@ -954,7 +975,7 @@ hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32
     if (tiles128 != 0) {
         // the first tiles128 tiles only, at most two workgroups per CU (the caller covers the other columns: early_prologue)
         hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3>), dim3(tiles128), dim3(256), kSePad, on, static_cast<const float*>(ctx->At),
-                           rcols, drows, D, ctx->ldm, ctx->ldm, ldd, tiles128, (const DevState*)nullptr, 0u, nullptr);
+                           rcols, drows, D, ctx->ldm, ctx->ldm, ldd, tiles128, (const DevState*)nullptr, 0u, nullptr, 2u);
         return hipGetLastError();
     }
     // (also with fewer tiles than CUs: a single-wave workgroup of the tiling below streams its 32 columns at one wave's
@@ -965,7 +986,7 @@ hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32
         const uint32_t nt = ctx->n_pad / 128;
         const uint32_t cap = 3u * (uint32_t)ctx->num_cus;
         hipLaunchKernelGGL((k_gemm32_tn_f32<128, 256, 3>), dim3(nt < cap ? nt : cap), dim3(256), 0, on, static_cast<const float*>(ctx->At),
-                           rcols, drows, D, ctx->ldm, ctx->ldm, ldd, nt, (const DevState*)nullptr, 0u, nullptr);
+                           rcols, drows, D, ctx->ldm, ctx->ldm, ldd, nt, (const DevState*)nullptr, 0u, nullptr, 2u);
         return hipGetLastError();
     }
     const uint32_t ntiles = ctx->n_pad / 32;
@@ -982,7 +1003,7 @@ hipError_t launch_gemm64_tn_f32(const ss_hip_ctx* ctx, const uint32_t* rcols, co
     const uint32_t ntiles = ctx->n_pad / 256;
     const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
     hipLaunchKernelGGL((k_gemm32_tn_f32<256, 512, 1, GK, false, 64>), dim3(grid), dim3(512), 0, ctx->stream,
-                       static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr);
+                       static_cast<const float*>(ctx->At), rcols, drows, D, ctx->ldm, ctx->ldm, ldd, ntiles, st, 0u, nullptr, 2u);
     return hipGetLastError();
 }
 

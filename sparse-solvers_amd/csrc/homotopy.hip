@@ -640,7 +640,7 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
     // pick their tile by where they run and leave at once on the solo workgroup's SE (k_gemm32_tn_f32<BYSE>), and the
     // two tiles that are left of 512 are formed by the VALU chain (k_cols_gram) on a fourth stream.  Every CU but one
     // then carries exactly two tiles.
-    uint32_t main_tiles = 0, se_last = 0, tail_c0 = 0, tail_cols = 0;
+    uint32_t main_tiles = 0, se_last = 0, tail_c0 = 0, tail_cols = 0, se_quota = 2u, range_last = 0;
     if (ctx->early_se && ctx->early_pass == 2 && !probe && ctx->stream3 && ctx->num_cus == 8 * (int)kSeCount &&
         ctx->n_pad % 128 == 0 && ctx->ldm % 256 == 0) {
         const uint32_t nt = (uint32_t)(ctx->n_pad / 128);
@@ -649,6 +649,24 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
             se_last = std::min<uint32_t>(nt, main_tiles + 2u * (kSeCount - 1u)); // tiles [448, 510) by shader engine
             tail_c0 = se_last * 128u;
             tail_cols = (nt - se_last) * 128u;                                  // the last 256 columns at 8192 x 65536
+        } else if (nt > 16u * kSeCount && ctx->early_se == 3) {
+            // Wider dictionaries, opt-in (early_se = 3; measured no faster than one launch per pass: 2.43 against 2.21 ms per
+            // solve at 98304 columns, 2.79 against 2.78 at 131072 — with three or more tiles per CU the launch evens itself
+            // out as workgroups finish; the cliff round 2 saw beyond 65536 columns was the candidate ranking, solo.hip:
+            // rank_offers): a pass is bound by what ONE CU can load, so its time is the largest number of
+            // tiles any CU gets — u = nt / 255 per CU when the 255 CUs beside the solo workgroup share evenly: the main
+            // launch takes 7 u tiles per shader engine (u per CU on the solo workgroup's SE, which has 7), the workgroups
+            // dealt out by shader engine come back until their SE has had u more (u per CU there too), and the remainder
+            // (< 255 tiles) runs as a partial round behind the main launch — or, when it is at most 16 tiles, on the VALU
+            // chain beside the pass like the two left-over tiles at 65536 columns.
+            const uint32_t per = 8u * kSeCount - 1u;                            // 255 CUs take tiles
+            const uint32_t u = nt / per;
+            main_tiles = 7u * kSeCount * u;
+            se_quota = u;
+            se_last = main_tiles + (kSeCount - 1u) * u;                          // = 255 u
+            const uint32_t rest = nt - se_last;
+            if (rest <= 16u) { tail_c0 = se_last * 128u; tail_cols = rest * 128u; }
+            else range_last = nt;
         }
     }
     ctx->stats.sweep32_timed_cols = main_tiles ? (uint64_t)main_tiles * 128u : (uint64_t)ctx->n;   // (of THIS form's timed launch: kind 5 below)
@@ -674,12 +692,13 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
             HIPCHK(hipEventRecord(ctx->ev_gate, ctx->stream2));                     // (behind the gate: the solo workgroup is resident)
             HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_gate, 0));
             HIPCHK(launch_gemm32se_on(ctx, ctx->stream3, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, main_tiles, se_last, ws.st,
-                                      ctx->se_count));
+                                      ctx->se_count, se_quota));
             HIPCHK(launch_wait_count(ctx->stream2, ctx->se_count + kSeCount, early_se_wgs(ctx), ws.st));
         }
         if (pe0) HIPCHK(hipEventRecord(pe0, ctx->stream2));
         HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, main_tiles));
         if (pe1) HIPCHK(hipEventRecord(pe1, ctx->stream2));
+        if (range_last) HIPCHK(launch_gemm32range_on(ctx, ctx->stream2, ws.sw_list, ws.sw_list + 64, ws.gcache, ws.gpitch, se_last, range_last));
         // the second pass's 32 columns are chosen now, half a millisecond into the solo launch: what has entered
         // its support without a Gram row so far, then the columns closest to entering (k_pick_pass_b)
         HIPCHK(launch_pick_pass_b_f32(ctx, ws, ctx->stream2));
@@ -687,11 +706,12 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
             HIPCHK(hipEventRecord(ctx->ev_b0, ctx->stream2));                       // (the second list exists, the first pass is complete)
             HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_b0, 0));
             HIPCHK(launch_gemm32se_on(ctx, ctx->stream3, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch, main_tiles, se_last, ws.st,
-                                      ctx->se_count + (kSeCount + 2)));
+                                      ctx->se_count + (kSeCount + 2), se_quota));
             HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
             HIPCHK(launch_wait_count(ctx->stream2, ctx->se_count + (kSeCount + 2) + kSeCount, early_se_wgs(ctx), ws.st));
         }
         HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch, main_tiles));
+        if (range_last) HIPCHK(launch_gemm32range_on(ctx, ctx->stream2, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch, se_last, range_last));
         if (main_tiles) HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_join3, 0));
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     };
@@ -2088,6 +2108,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_rerun"))     { ctx->tie_rerun = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_fused_scan")) { ctx->batch_fused_scan = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "cq_vec4"))       { ctx->cq_vec4 = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep32_variant")) { ctx->sweep32_variant = (int)std::max<long>(0, std::min<long>(9, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "first_sweep_cols")) { ctx->first_sweep_cols = value > 32 ? 64 : 32; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_solo"))    { ctx->early_solo = value ? 1 : 0; return SS_HIP_OK; }
@@ -2097,7 +2118,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "early_pass"))    { ctx->early_pass = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "early_adapt"))   { ctx->early_adapt = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "scan_blocks"))   { ctx->scan_blocks = (int)std::max<long>(0, value); return SS_HIP_OK; }
-    if (!std::strcmp(key, "early_se"))      { ctx->early_se = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "early_se"))      { ctx->early_se = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "pass_dbg_ptr"))  {   // developer aid: device buffer of 1 + 4 * 4096 u64 (0 = off), tools/probe_pass_trace.py
         (void)hipSetDevice(ctx->device);
         return sship::set_pass_debug(reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(value))) == hipSuccess ? SS_HIP_OK : SS_HIP_ERUNTIME;
@@ -2162,6 +2183,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "engine"))        { *value = ctx->engine; return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_rerun"))     { *value = ctx->tie_rerun; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_fused_scan")) { *value = ctx->batch_fused_scan; return SS_HIP_OK; }
+    if (!std::strcmp(key, "cq_vec4"))       { *value = ctx->cq_vec4; return SS_HIP_OK; }
     if (!std::strcmp(key, "la_fused"))      { *value = ctx->la_fused; return SS_HIP_OK; }
     if (!std::strcmp(key, "solo_subset"))   { *value = ctx->solo_subset; return SS_HIP_OK; }
     if (!std::strcmp(key, "sweep32_variant")) { *value = ctx->sweep32_variant; return SS_HIP_OK; }

@@ -556,6 +556,49 @@ void k_la_vpublish(const uint32_t* __restrict__ log, DevState* st, const uint32_
 // first, then the best-ranked offers that are neither active nor cached.  Same outputs as k_la_top.
 constexpr int kTcThreads = 1024;             // one offer per thread up to 1024 candidates (4 per block at n = 65536)
 constexpr int kTcStride = 64;                 // sw_list layout: rcols[64] then drows[64] (k_la_top's kSwStride)
+// Wider dictionaries have more candidates than threads (4 per 256-column block: 1536 at n = 98304).  Round 2 let a thread
+// keep only the BEST of its strided share — and dropped, now and then, a column that was about to enter: the subset then
+// missed it, the first speculative launch failed its check on nearly every solve beyond 65536 columns, and after eight
+// solves the context stopped speculating (3.5 ms per solve at 98304 columns against 1.5 at 65536: the "cliff" was this,
+// not the shape of the passes).  Now a thread keeps up to kTcOffers offers (ncand <= 4096: n <= 262144; only beyond that
+// is the excess folded into the last offer) and every offer is ranked by counting over all of them.
+constexpr int kTcOffers = 4;
+
+// ranks the valid offers o[0 .. kTcOffers) of every thread among all offers of the workgroup (s_of: kTcOffers * kTcThreads
+// words): rank[r] = number of smaller keys; returns the number of valid offers in all.  nper = offers per thread in use.
+__device__ __forceinline__ uint32_t rank_offers(const uint64_t (&o)[kTcOffers], uint32_t nper, uint64_t* s_of, uint32_t (&rank)[kTcOffers])
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < kTcOffers; ++r) {
+        if ((uint32_t)r < nper) { s_of[(uint32_t)r * kTcThreads + tid] = o[r]; mine += o[r] != ~0ull ? 1u : 0u; }
+        rank[r] = 0u;
+    }
+    __syncthreads();
+    const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(s_of);
+    const uint32_t words2 = nper * (kTcThreads / 2);
+#pragma unroll
+    for (int r = 0; r < kTcOffers; ++r) {
+        if ((uint32_t)r >= nper || o[r] == ~0ull) continue;
+        const uint64_t me = o[r];
+        uint32_t c = 0;
+#pragma unroll 8
+        for (uint32_t u = 0; u < words2; ++u) {
+            const ulonglong2 v = p2[u];
+            c += v.x < me ? 1u : 0u;
+            c += v.y < me ? 1u : 0u;
+        }
+        rank[r] = c;
+    }
+    // total number of valid offers (block sum through the ballot counts of the barrier)
+    uint32_t total = 0;
+#pragma unroll
+    for (int r = 0; r < kTcOffers; ++r)
+        total += (uint32_t)__syncthreads_count((uint32_t)r < nper && o[r] != ~0ull);
+    (void)mine;
+    return total;
+}
 
 __global__ __launch_bounds__(kTcThreads)
 void k_la_top_cand(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32_t n,
@@ -563,38 +606,38 @@ void k_la_top_cand(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32
                    uint32_t* __restrict__ sw_list, DevState* st, uint32_t* hflags, uint32_t* __restrict__ slot_col,
                    uint32_t nsel /* columns of this sweep: 32, or 64 for the first one of a solve */)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t s_of[kTcThreads];
+    __shared__ __attribute__((aligned(16))) uint64_t s_of[kTcOffers * kTcThreads];
     if (st->done || !st->need_sweep) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t idx = st->idx;
     const uint32_t used = st->cache_used;                                 // (read before the barrier: thread 0 updates it at the end)
-    // one offer per thread (more candidates than threads: the best of a strided share), ranked by counting
-    uint64_t o1 = ~0ull;
-    for (uint32_t e = tid; e < ncand; e += kTcThreads) {
+    // up to kTcOffers offers per thread, every one ranked by counting over all of them
+    const uint32_t nper = ncand <= (uint32_t)kTcThreads ? 1u : (ncand + kTcThreads - 1u) / kTcThreads < (uint32_t)kTcOffers
+                              ? (ncand + kTcThreads - 1u) / kTcThreads : (uint32_t)kTcOffers;
+    uint64_t o[kTcOffers];
+#pragma unroll
+    for (int r = 0; r < kTcOffers; ++r) o[r] = ~0ull;
+    for (uint32_t e = tid, r = 0; e < ncand; e += kTcThreads, ++r) {
         const uint64_t pk = cand_top[e];
         const uint32_t cl = (uint32_t)pk;
         if (pk == ~0ull || cl >= n || cl == idx || insup[cl] || slot_of[cl] >= 0) continue;
-        if (pk < o1) o1 = pk;
+        const uint32_t rr = r < nper ? r : nper - 1u;                     // (beyond kTcOffers * 1024 candidates: the best of the excess)
+#pragma unroll
+        for (int q = 0; q < kTcOffers; ++q) if ((uint32_t)q == rr && pk < o[q]) o[q] = pk;
     }
-    s_of[tid] = o1;
-    const uint32_t total = (uint32_t)__syncthreads_count(o1 != ~0ull);
-    uint32_t r1 = 0;
-    if (o1 != ~0ull) {
-        const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(s_of);
-#pragma unroll 8
-        for (uint32_t u = 0; u < kTcThreads / 2; ++u) {
-            const ulonglong2 v = p2[u];
-            r1 += v.x < o1 ? 1u : 0u;
-            r1 += v.y < o1 ? 1u : 0u;
-        }
-    }
+    uint32_t rk[kTcOffers];
+    const uint32_t total = rank_offers(o, nper, s_of, rk);
     const uint32_t room = gcap > used ? gcap - used : 0u;                 // slots left (the entering column takes the first)
     uint32_t count = total < nsel - 1u ? total : nsel - 1u;
     if (room == 0u) count = 0u; else if (count + 1u > room) count = room - 1u;
-    if (o1 != ~0ull && r1 < count) {
-        const uint32_t cl = (uint32_t)o1, sl = used + 1u + r1;
-        sw_list[1 + r1] = cl; sw_list[kTcStride + 1 + r1] = sl; slot_of[cl] = (int32_t)sl;
-        if (slot_col != nullptr) slot_col[sl] = cl;
+#pragma unroll
+    for (int r = 0; r < kTcOffers; ++r) {
+        if ((uint32_t)r < nper && o[r] != ~0ull && rk[r] < count) {
+            const uint32_t r1 = rk[r];
+            const uint32_t cl = (uint32_t)o[r], sl = used + 1u + r1;
+            sw_list[1 + r1] = cl; sw_list[kTcStride + 1 + r1] = sl; slot_of[cl] = (int32_t)sl;
+            if (slot_col != nullptr) slot_col[sl] = cl;
+        }
     }
     if (tid >= 1u + count && tid < (uint32_t)kTcStride) { sw_list[tid] = 0xffffffffu; sw_list[kTcStride + tid] = 0xffffffffu; }
     if (tid == 0) {
@@ -630,39 +673,39 @@ void k_subset_pick(const uint64_t* __restrict__ cand_top, uint32_t ncand, uint32
     if (se_count != nullptr && threadIdx.x < 2u * (kSeCount + 2u)) se_count[threadIdx.x] = 0u;
     // (the progress hints of the solo launch that follows, one per subset position: nothing known yet)
     if (threadIdx.x < kSoloWidth) reinterpret_cast<float*>(sub_cols + kSoloWidth)[threadIdx.x] = Lim<float>::max();
-    __shared__ __attribute__((aligned(16))) uint64_t s_of[kTcThreads];
+    __shared__ __attribute__((aligned(16))) uint64_t s_of[kTcOffers * kTcThreads];
     if (st->done) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t idx = st->idx;
-    uint64_t o1 = ~0ull;
-    for (uint32_t e = tid; e < ncand; e += kTcThreads) {
+    const uint32_t nper = ncand <= (uint32_t)kTcThreads ? 1u : (ncand + kTcThreads - 1u) / kTcThreads < (uint32_t)kTcOffers
+                              ? (ncand + kTcThreads - 1u) / kTcThreads : (uint32_t)kTcOffers;
+    uint64_t o[kTcOffers];
+#pragma unroll
+    for (int r = 0; r < kTcOffers; ++r) o[r] = ~0ull;
+    for (uint32_t e = tid, r = 0; e < ncand; e += kTcThreads, ++r) {
         const uint64_t pk = cand_top[e];
         const uint32_t cl = (uint32_t)pk;
         if (pk == ~0ull || cl >= n || cl == idx) continue;
-        if (pk < o1) o1 = pk;
+        const uint32_t rr = r < nper ? r : nper - 1u;
+#pragma unroll
+        for (int q = 0; q < kTcOffers; ++q) if ((uint32_t)q == rr && pk < o[q]) o[q] = pk;
     }
-    s_of[tid] = o1;
-    const uint32_t total = (uint32_t)__syncthreads_count(o1 != ~0ull);
-    uint32_t r1 = 0;
-    if (o1 != ~0ull) {
-        const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(s_of);
-#pragma unroll 8
-        for (uint32_t u = 0; u < kTcThreads / 2; ++u) {
-            const ulonglong2 v = p2[u];
-            r1 += v.x < o1 ? 1u : 0u;
-            r1 += v.y < o1 ? 1u : 0u;
-        }
-    }
+    uint32_t rk[kTcOffers];
+    const uint32_t total = rank_offers(o, nper, s_of, rk);
     uint32_t nsub = total < kSoloWidth - 1u ? total : kSoloWidth - 1u;             // subset positions 1 .. nsub
     if (nsub > subset_cap) nsub = subset_cap;
     const uint32_t nslot = total < 63u ? total : 63u;                              // cache slots 1 .. nslot are set aside:
     const uint32_t nfirst = nslot < 31u ? nslot : 31u;                             // 1 .. nfirst for the first pass (given here),
-    if (o1 != ~0ull && r1 < nsub) {                                                // 32 .. nslot for the second (k_pick_pass_b)
-        const uint32_t cl = (uint32_t)o1;
-        sub_cols[1u + r1] = cl;
-        if (r1 < nfirst) {
-            sw_list[1u + r1] = cl; sw_list[kTcStride + 1u + r1] = 1u + r1; slot_of[cl] = (int32_t)(1u + r1);
-            if (slot_col != nullptr) slot_col[1u + r1] = cl;
+#pragma unroll
+    for (int r = 0; r < kTcOffers; ++r) {                                          // 32 .. nslot for the second (k_pick_pass_b)
+        if ((uint32_t)r < nper && o[r] != ~0ull && rk[r] < nsub) {
+            const uint32_t r1 = rk[r];
+            const uint32_t cl = (uint32_t)o[r];
+            sub_cols[1u + r1] = cl;
+            if (r1 < nfirst) {
+                sw_list[1u + r1] = cl; sw_list[kTcStride + 1u + r1] = 1u + r1; slot_of[cl] = (int32_t)(1u + r1);
+                if (slot_col != nullptr) slot_col[1u + r1] = cl;
+            }
         }
     }
     if (tid >= 1u + nsub && tid < kSoloWidth) sub_cols[tid] = 0xffffffffu;

@@ -258,6 +258,7 @@ struct ss_hip_ctx {
     hipEvent_t ev_join4 = nullptr;
     hipEvent_t ev_gate = nullptr, ev_b0 = nullptr, ev_join3 = nullptr;
     uint32_t* se_count = nullptr;     // [2][kSeCount + 2] device counters, one set per pass: arrivals per SE, arrivals in all, tiles taken
+    int cq_vec4 = 0;                  // option (A/B): threads of the batched Gram-form pass own four consecutive columns (16-byte loads) instead of four strided ones
     int batch_fused_scan = 1;         // option: the batched Gram forms scan inside the Gram-form pass (k_la_cqs: c, q stay in registers)
     int scan_blocks = 8;              // option: workgroups per slot of the batched Gram form's scan (0 = one per 1024 columns)
     int sweep_f64_variant = 0;        // option: tiling of the 32-column fp64 pass (0 = 256 columns / 512 threads / 1 per CU; 1, 2 = 128 / 256 / 2, 3 per CU)
@@ -440,10 +441,13 @@ hipError_t set_pass_debug(uint64_t* buf);      // developer aid: per-workgroup t
 hipError_t launch_pick_pass_b_f32(ss_hip_ctx* ctx, Workspace<float>& ws, hipStream_t on);
 hipError_t launch_gemm32w_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
                              uint32_t tiles128 = 0);
-inline uint32_t early_se_wgs(const ss_hip_ctx* ctx) { return ctx->early_se == 2 ? kSeCount : 2u * kSeCount; }
+inline uint32_t early_se_wgs(const ss_hip_ctx* ctx) { return ctx->early_se == 2 ? kSeCount : 2u * kSeCount; }   // (3: as 1, any tile count)
 // tiles first .. ntiles-1 of the same pass, two per shader engine except the solo workgroup's (early form)
 hipError_t launch_gemm32se_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
-                              uint32_t first, uint32_t ntiles, const DevState* st, uint32_t* se_count);
+                              uint32_t first, uint32_t ntiles, const DevState* st, uint32_t* se_count, uint32_t quota = 2u);
+// tiles [first, last) of a pass as a plain launch (the partial round of a wide dictionary)
+hipError_t launch_gemm32range_on(const ss_hip_ctx* ctx, hipStream_t on, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd,
+                                 uint32_t first, uint32_t last);
 hipError_t launch_wait_count(hipStream_t on, const uint32_t* counter, uint32_t target, const DevState* st);
 hipError_t launch_cols_gram_on(const ss_hip_ctx* ctx, hipStream_t on, uint32_t c0, uint32_t ncols, const uint32_t* rcols,
                                const uint32_t* drows, float* D, uint32_t ldd);

@@ -1509,3 +1509,38 @@ def test_full_gram_single_signal(sship, la_fused):
         assert itq == itoo and np.array_equal(np.nonzero(xq)[0], np.nonzero(xoo)[0])
         assert np.abs(xq - xoo).max() <= 1e-5 * np.abs(xoo).max()
         assert h.stats()["lookahead_sweeps"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [98304, 140000, 262144])
+def test_early_form_wide_dictionary_keeps_speculating(sship, n):
+    """Dictionaries beyond 65536 columns have more entrant candidates (4 per 256-column block) than the ranking kernels
+    have threads.  Round 2 kept one offer per thread — the best of a strided share — and now and then dropped a column
+    that was about to enter: the subset missed it, the first speculative launch failed its check on nearly every solve
+    and the context stopped speculating (the 2.4x "cliff" at 98304 columns).  Every offer is ranked now (solo.hip:
+    rank_offers): well-posed solves must pass their checks, and stay the plain form's bits."""
+    import torch
+    m, k = 4096, 40                      # (m >> k log(n / k): the subset of 256 columns holds every entrant, as at configs[1])
+    g = torch.Generator(device="cuda:0").manual_seed(n)
+    A = torch.randn((m, n), generator=g, device="cuda:0", dtype=torch.float32) / np.sqrt(m)
+    rng = np.random.default_rng(n)
+    x = torch.zeros(n, device="cuda:0")
+    with sship.Homotopy(A) as h:
+        fails = solo = 0
+        for s in range(6):
+            sup = np.sort(rng.choice(n, k, replace=False))
+            coef = torch.from_numpy((1 + np.abs(rng.standard_normal(k))).astype(np.float32)).to("cuda:0")
+            y = (A[:, torch.from_numpy(sup).to("cuda:0")] @ coef).contiguous()
+            h.set_option("early_solo", 1)
+            h.reset_stats()
+            _, it, e = h.solve(y, 1e-3, 4 * k, out=x)
+            st = h.stats()
+            xe = x.cpu().numpy().copy()
+            solo += st["solo_solves"]
+            fails += st["solo_retries"]
+            assert np.array_equal(np.nonzero(xe)[0], sup)
+            h.set_option("early_solo", 0)
+            _, it0, e0 = h.solve(y, 1e-3, 4 * k, out=x)
+            assert it0 == it and e0 == e and np.array_equal(x.cpu().numpy(), xe)
+        note("test_early_form_wide_dictionary_keeps_speculating", n=n, speculative_solves=solo, failed_checks=fails)
+        assert solo == 6 and fails <= 1

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sparse-solvers_amd", "python"))
 import sship
 M, K = 8192, 64
-for N in (17000, 24000, 32768, 49152, 65536, 98304, 131072):
+for N in (17000, 24000, 32768, 49152, 65536, 98304, 131072, 196608, 262144):
     g = torch.Generator(device="cuda:0").manual_seed(N)
     Ad = torch.randn((M, N), generator=g, device="cuda:0", dtype=torch.float32) / np.sqrt(M)
     sigs = []
@@ -20,7 +20,7 @@ for N in (17000, 24000, 32768, 49152, 65536, 98304, 131072):
     with sship.Homotopy(Ad) as h:
         del Ad
         out = []
-        for ep in (1, 0, 1, 0):
+        for ep in (1, 0, 3, 1, 0):
             h.set_option("early_se", ep)
             h.solve(sigs[0], 1e-3, 256, out=x)
             torch.cuda.synchronize()
