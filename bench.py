@@ -296,8 +296,8 @@ def run_batched(args, h, A, dev, rank, world, use_dist, torch, dist, sharding):
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_la_cq (batched Gram form): c = c0 - sum_j x_j G[j], q = sum_j d_j G[j] for every live signal, "
-                      "K rows of G per signal and round",
+            "kernel": "k_la_cqs (batched Gram form, the step-length scan inside): c = c0 - sum_j x_j G[j], q = sum_j d_j G[j] for "
+                      "every live signal, K rows of G per signal and round, lambda, scan and pick in the same launch",
             "achieved": cq_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cq_gbs / HBM_PEAK_GBS, "traffic": None,
             "bytes_per_launch": st["cq_bytes"] / max(1, st["cq_launches"]), "avg_launch_ms": cq_ms,
             "launches_timed": st["cq_launches"],
@@ -307,8 +307,10 @@ def run_batched(args, h, A, dev, rank, world, use_dist, torch, dist, sharding):
         "batch_rounds_per_step": st["batch_rounds"] / max(1, args.steps),
         "recovered": {"signals_checked": world * B, "support_exact": int(agg[0].item()),
                       "ran_to_max_iter": int(agg[1].item()), "max_rel_coef_err_rank0": cerr,
-                      "note": "checked on the records every rank received from the all_gather (last step); a signal "
-                              "that meets an exact tie runs to max_iter like the reference's (homotopy-cpu.cpp:143-153)"},
+                      "tie_reruns_rank0": int(st["tie_reruns"]),
+                      "note": "checked on the records every rank received from the all_gather (last step); a signal whose "
+                              "scan meets an exact tie (homotopy-cpu.cpp:143-153) is solved again in the reference-order "
+                              "engine (tie_reruns) and carries that result"},
         "iterations_mean": float(iters.mean()),
     }
 
@@ -407,6 +409,35 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         extras["omp"] = {"workload": "OMP (ss::omp<float>, parity unpinned: the reference has no OMP), the same A and signals, %d picks" % K_SPARSE,
                          "ms_per_solve": dto / args.steps * 1e3, "support_exact": oko, "signals": args.steps}
 
+    # extra (NOT `value`): the reference-order engine (engine 3: every reduction in the documented 8-partial order, two
+    # passes over A per iteration; the arbiter of exact ties) on the same matrix and signals — its sweep and a whole solve
+    if extras is not None and h.get_option("engine") >= 1:
+        try:
+            keep_engine = h.get_option("engine")
+            h.set_option("engine", 3)
+            _, ms_ro = h.gemv_t(sigs[0][0], 5)
+            xr = torch.zeros(N, device=dev, dtype=torch.float32)
+            h.solve(sigs[0][0], TOL, MAX_ITER, out=xr)
+            torch.cuda.synchronize()
+            tr_ = time.perf_counter()
+            nro = min(3, args.steps)
+            same = 0
+            for s_ in range(nro):
+                _, itr_, er_ = h.solve(sigs[args.warmup + s_][0], TOL, MAX_ITER, out=xr)
+                same += int(torch.equal(xr != 0, X[s_] != 0))
+            torch.cuda.synchronize()
+            dtr_ = (time.perf_counter() - tr_) / nro
+            h.set_option("engine", keep_engine)
+            b1 = M * N * 4 + M * 4 + N * 4
+            extras["reference_order_engine"] = {
+                "workload": "engine 3 (csrc/reforder.hip): bit-identical with the CPU oracle's summation order; configs[1] matrix and signals",
+                "sweep_ms": ms_ro, "sweep_GBs": b1 / ms_ro / 1e6, "sweep_frac_of_8TBs": b1 / ms_ro / 1e6 / HBM_PEAK_GBS,
+                "ms_per_solve": dtr_ * 1e3, "iterations": int(itr_), "passes_over_A_per_iteration": 2,
+                "same_support_as_timed_solves": same, "signals": nro}
+            del xr
+        except Exception as ex:
+            extras["reference_order_engine"] = {"error": repr(ex)}
+
     # extra (NOT `value`): a mid-size batch (64 signals sharing A, no G): lock-step in the column form — one pass
     # over A per round forms the Gram columns of the 64 entering columns — against one solve per signal
     if args.batch > 0 and extras is not None and h.get_option("engine") >= 1:
@@ -470,6 +501,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             "signals": Bx, "signals_per_s": runs[1]["signals_per_s"],
             "signals_per_s_first_batch_incl_G": runs[0]["signals_per_s"], "runs": runs,
             "support_exact": okb, "ran_to_max_iter": stuckb, "max_rel_coef_err": cerrb, "iterations_max": int(itb.max()),
+            "tie_reruns_last_batch": int(stb["tie_reruns"]),
             "roofline_gram_build": {
                 "bound": "mfma", "kernel": "k_gemm_tn_f32: G = A^T A (v_mfma_f32_32x32x2_f32, 128x128x32 tiles%s)"
                                            % (", tiles on and above the diagonal + mirrored store" if h.get_option("gram_symmetric") else ""),
@@ -477,7 +509,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                 "unit": "TFLOP/s", "frac": (gflops_exec / (g_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS) if g_ms > 0 else 0.0,
                 "traffic": None, "flops_per_launch": gflops_exec, "flops_full_product": gflops_full, "avg_launch_ms": g_ms},
             "roofline_gram_pass": {
-                "bound": "hbm", "kernel": "k_la_cq (batched Gram form): K rows of G per live signal and round",
+                "bound": "hbm", "kernel": "k_la_cqs (batched Gram form: K rows of G per live signal and round; lambda, the step-length scan and the pick in the same launch)",
                 "achieved": cq_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cq_gbs / HBM_PEAK_GBS, "traffic": None,
                 "bytes_total": stb["cq_bytes"], "ms_total": stb["cq_ms"], "launches_timed": stb["cq_launches"]},
         }

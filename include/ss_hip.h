@@ -358,7 +358,10 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    workgroups per CU (all 512 tiles of 8192 x 65536 resident on the 255 CUs the speculative launch
  *                    leaves: 0.49 ms per pass beside it); 0 = one 32-column tile per single-wave workgroup (0.52 ms).
  *                    Same results bit for bit
- *   "early_se"       1 (default) = the early form's two passes are dealt out around the speculative workgroup: the
+ *   "early_se"       (3 = the same dealing-out for ANY tile count: 7u tiles per shader engine in the main launch, the
+ *                    workgroups dealt out by SE come back until their SE has had u more — measured no faster than one launch per
+ *                    pass beyond 65536 columns, kept as an option)
+ *                    1 (default) = the early form's two passes are dealt out around the speculative workgroup: the
  *                    hardware gives every shader engine the same number of workgroups of a grid, and the SE of that
  *                    workgroup has 7 CUs for its share — so the main launch takes 14 tiles per SE, a second launch puts
  *                    two more workgroups on every SE, which pick their tile by where they run and leave at once on that
@@ -392,6 +395,14 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "scan_blocks"    workgroups per signal of the step-length scan in the lock-step Gram forms with 64 signals or more
  *                    (default 8: a launch of 4096 signals x 64 workgroups spends its time on reductions and tickets,
  *                    not on its 9 bytes per column; same results); 0 = one per 1024 columns
+ *   "batch_fused_scan" 1 (default) = the lock-step Gram forms scan inside the Gram-form pass (k_la_cqs: c and q of a
+ *                    workgroup's columns stay in registers while the signal's workgroups meet for lambda = ||c||_inf);
+ *                    0 = two kernels (k_la_cq writes c and q, k_scansel reads them back).  Same results bit for bit
+ *   "cq_cols" / "cq_rows"  columns per thread (4, 8, 16 (default), 32) and rows of G in flight per thread (1, 2 (default),
+ *                    3, 4, 8) of that pass: a workgroup of 256 threads reads runs of 256 * cq_cols columns of each of its
+ *                    signal's K rows of G — 16 KiB runs stream at 82 % of the HBM peak where 4 KiB runs reached 64 %.
+ *                    "cq_vec4" 1 = four consecutive columns per thread with 16-byte loads (cq_cols = 4 only; no faster).
+ *                    Same results bit for bit
  *   "gram_full_gib"  largest G — and largest column cache of the column form — that may be allocated
  *                    (default 64 GiB; 0 = never form G)
  *   "gram_full_after" opt-in (default 0 = never): single-signal solves (fp32) after which the context forms G

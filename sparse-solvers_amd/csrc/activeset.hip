@@ -582,13 +582,33 @@ __device__ __forceinline__ void load4(const double* __restrict__ p, double (&v)[
 
 // the four columns of a thread: VEC — consecutive (base + 4 tid .. + 3, one 16-byte load per row); else strided by the
 // workgroup (base + tid + 256 k, four 4-byte loads per row: each wave-instruction reads 256 contiguous bytes)
+// (lim: padded columns left from the workgroup's base — a multiple of 256, so the guards are uniform per workgroup and
+// per k: rows of c0 hold n_pad columns, a multiple of 256 but not of the workgroup's run)
 template <bool VEC, typename T>
-__device__ __forceinline__ void load_cols(const T* __restrict__ p, T (&v)[4])
+__device__ __forceinline__ void load_cols(const T* __restrict__ p, T (&v)[4], uint32_t lim)
 {
-    if (VEC) load4(p, v);
-    else {
+    if (VEC) {
+        if (4u * threadIdx.x < lim) load4(p, v);
+        else { v[0] = v[1] = v[2] = v[3] = T(0); }
+    } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = p[k * kSmallThreads];
+        for (int k = 0; k < 4; ++k) v[k] = ((uint32_t)k * kSmallThreads < lim) ? p[k * kSmallThreads] : T(0);
+    }
+}
+// the same with N columns per thread (strided form; VEC only with N == 4)
+// (lim: padded columns left from the workgroup's base, a multiple of 256: a wide workgroup at the end of a row reads
+// only the 256-column groups that exist — uniform per workgroup)
+template <bool VEC, int N, typename T>
+__device__ __forceinline__ void load_colsN(const T* __restrict__ p, T (&v)[N], uint32_t lim)
+{
+    static_assert(!VEC || N == 4, "16-byte form: four columns per thread");
+    if (VEC) {
+        T t[4] = { T(0), T(0), T(0), T(0) };
+        if (4u * threadIdx.x < lim) load4(p, t);
+        for (int k = 0; k < 4 && k < N; ++k) v[k] = t[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = ((uint32_t)k * kSmallThreads < lim) ? p[k * kSmallThreads] : T(0);
     }
 }
 template <bool VEC>
@@ -626,6 +646,7 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
     const uint32_t nt = st->ntouched;
     const uint32_t* touched = touched2 + (size_t)st->cur * L.kcap;
     const uint32_t base = blockIdx.x * kCqChunk;
+    const uint32_t lim = L.n_pad - base;                       // (padded columns left from here)
     const T* gbase = gcache + base + (VEC ? 4u : 1u) * threadIdx.x;               // gpitch % 1024 == 0: rows never run out
     T ax[4] = { T(0), T(0), T(0), T(0) }, ad[4] = { T(0), T(0), T(0), T(0) };
     for (uint32_t j0 = 0; j0 < nt; j0 += kCqTile) {
@@ -642,7 +663,7 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
         for (; j + 4 <= cnt; j += 4) {
             T gv[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) load_cols<VEC>(gbase + (size_t)s_slot[j + u] * gpitch, gv[u]);
+            for (int u = 0; u < 4; ++u) load_cols<VEC>(gbase + (size_t)s_slot[j + u] * gpitch, gv[u], lim);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const T xj = s_x[j + u], dj = s_d[j + u];
@@ -652,7 +673,7 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
         }
         for (; j < cnt; ++j) {
             T gv1[4];
-            load_cols<VEC>(gbase + (size_t)s_slot[j] * gpitch, gv1);
+            load_cols<VEC>(gbase + (size_t)s_slot[j] * gpitch, gv1, lim);
             const T xj = s_x[j], dj = s_d[j];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { ax[k] += xj * gv1[k]; ad[k] += dj * gv1[k]; }
@@ -661,7 +682,7 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
     T bv = T(-1);
     uint32_t bi = 0xffffffffu;
     T c0v[4];
-    load_cols<VEC>(c0 + base + (VEC ? 4u : 1u) * threadIdx.x, c0v);     // (n_pad is a multiple of 256, gpitch of 1024: no tail)
+    load_cols<VEC>(c0 + base + (VEC ? 4u : 1u) * threadIdx.x, c0v, lim);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t i = col_of<VEC>(base, threadIdx.x, k);
@@ -693,7 +714,7 @@ void k_la_cq(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, 
 // slot ends with SS_HIP_ERUNTIME instead of hanging the queue.
 constexpr uint32_t kCqsSpinLimit = 1u << 22;
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, int CPT, int RIF>
 __global__ __launch_bounds__(kSmallThreads)
 void k_la_cqs(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, const T* __restrict__ c0,
               T* __restrict__ x, const T* __restrict__ d, uint32_t* __restrict__ touched2, uint32_t* __restrict__ gam2,
@@ -724,9 +745,12 @@ void k_la_cqs(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of,
     __shared__ T s_d[kCqTile];
     const uint32_t nt = st->ntouched;
     const uint32_t* touched = touched2 + (size_t)st->cur * kcap;
-    const uint32_t base = blockIdx.x * kCqChunk;
+    const uint32_t base = blockIdx.x * (uint32_t)(kSmallThreads * CPT);      // CPT columns per thread
+    const uint32_t lim = L.n_pad - base;                                      // (n_pad, a multiple of 256, is what rows hold at least)
     const T* gbase = gcache + base + (VEC ? 4u : 1u) * threadIdx.x;
-    T ax[4] = { T(0), T(0), T(0), T(0) }, ad[4] = { T(0), T(0), T(0), T(0) };
+    T ax[CPT], ad[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) { ax[k] = T(0); ad[k] = T(0); }
     for (uint32_t j0 = 0; j0 < nt; j0 += kCqTile) {                  // (the loop of k_la_cq, statement for statement)
         const uint32_t cnt = (nt - j0 < kCqTile) ? (nt - j0) : kCqTile;
         __syncthreads();
@@ -738,33 +762,33 @@ void k_la_cqs(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of,
         }
         __syncthreads();
         uint32_t j = 0;
-        for (; j + 4 <= cnt; j += 4) {
-            T gv[4][4];
+        for (; j + RIF <= cnt; j += RIF) {                       // RIF rows of G in flight per thread
+            T gv[RIF][CPT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) load_cols<VEC>(gbase + (size_t)s_slot[j + u] * gpitch, gv[u]);
+            for (int u = 0; u < RIF; ++u) load_colsN<VEC, CPT>(gbase + (size_t)s_slot[j + u] * gpitch, gv[u], lim);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RIF; ++u) {
                 const T xj = s_x[j + u], dj = s_d[j + u];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { ax[k] += xj * gv[u][k]; ad[k] += dj * gv[u][k]; }
+                for (int k = 0; k < CPT; ++k) { ax[k] += xj * gv[u][k]; ad[k] += dj * gv[u][k]; }
             }
         }
         for (; j < cnt; ++j) {
-            T gv1[4];
-            load_cols<VEC>(gbase + (size_t)s_slot[j] * gpitch, gv1);
+            T gv1[CPT];
+            load_colsN<VEC, CPT>(gbase + (size_t)s_slot[j] * gpitch, gv1, lim);
             const T xj = s_x[j], dj = s_d[j];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { ax[k] += xj * gv1[k]; ad[k] += dj * gv1[k]; }
+            for (int k = 0; k < CPT; ++k) { ax[k] += xj * gv1[k]; ad[k] += dj * gv1[k]; }
         }
     }
-    T cv[4], qv[4];
-    uint8_t act[4];
+    T cv[CPT], qv[CPT];
+    uint8_t act[CPT];
     T bv = T(-1);
     uint32_t bi = 0xffffffffu;
-    T c0v[4];
-    load_cols<VEC>(c0 + base + (VEC ? 4u : 1u) * threadIdx.x, c0v);
+    T c0v[CPT];
+    load_colsN<VEC, CPT>(c0 + base + (VEC ? 4u : 1u) * threadIdx.x, c0v, lim);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < CPT; ++k) {
         const uint32_t i = col_of<VEC>(base, threadIdx.x, k);
         cv[k] = T(0); qv[k] = T(0); act[k] = 0;
         if (i < n) {
@@ -822,7 +846,7 @@ void k_la_cqs(const T* __restrict__ gcache, const int32_t* __restrict__ slot_of,
     T best_c = T(0), best_q = T(0);
     bool tie = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < CPT; ++k) {
         const uint32_t i = col_of<VEC>(base, threadIdx.x, k);
         if (i < n) {
             T m = Lim<T>::max();
@@ -2041,12 +2065,36 @@ hipError_t launch_cq_gram_batched(const ss_hip_ctx* ctx, Workspace<T>& ws, uint3
     if (round != 0) {
         if (nb > ws.dims.pmin_stride) return hipErrorInvalidValue;
 #define SS_CQS_LAUNCH(VEC)                                                                                                   \
-        hipLaunchKernelGGL((k_la_cqs<T, VEC>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, bslot,                    \
+        hipLaunchKernelGGL((k_la_cqs<T, VEC, 4, 4>), dim3(nb, nslots), dim3(kSmallThreads), 0, ctx->stream, G, bslot,              \
                            c0b, ws.x, (const T*)ws.d, ws.touched, ws.gam, n, gpitch, ws.dims, ws.c, ws.q,                           \
                            ws.pmax_val, ws.pmax_idx, ws.pmin_val, ws.pmin_idx, ws.insup, ws.st, round, tol, max_iter,               \
                            ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,          \
                            (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0)
-        if (ctx->cq_vec4) SS_CQS_LAUNCH(true); else SS_CQS_LAUNCH(false);
+#define SS_CQS_WIDE(CPT, RIF)                                                                                               \
+        {                                                                                                                    \
+            const uint32_t nbw = (n + (uint32_t)(kSmallThreads * CPT) - 1u) / (uint32_t)(kSmallThreads * CPT);                     \
+            hipLaunchKernelGGL((k_la_cqs<T, false, CPT, RIF>), dim3(nbw, nslots), dim3(kSmallThreads), 0, ctx->stream, G, bslot,   \
+                               c0b, ws.x, (const T*)ws.d, ws.touched, ws.gam, n, gpitch, ws.dims, ws.c, ws.q,                      \
+                               ws.pmax_val, ws.pmax_idx, ws.pmin_val, ws.pmin_idx, ws.insup, ws.st, round, tol, max_iter,          \
+                               ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,     \
+                               (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0);                                                       \
+            if (nparts_out) *nparts_out = nbw;                                                                               \
+        }
+        // columns per thread x Gram rows in flight (options cq_cols, cq_rows): wider workgroups read longer runs of a row
+        const int cc = ctx->cq_cols, rr = ctx->cq_rows;
+        if (cc == 8 && rr == 2) SS_CQS_WIDE(8, 2)
+        else if (cc == 8 && rr == 4) SS_CQS_WIDE(8, 4)
+        else if (cc == 8 && rr == 8) SS_CQS_WIDE(8, 8)
+        else if (cc == 16 && rr == 2) SS_CQS_WIDE(16, 2)
+        else if (cc == 16 && rr == 4) SS_CQS_WIDE(16, 4)
+        else if (cc == 4 && rr == 8) SS_CQS_WIDE(4, 8)
+        else if (cc == 32 && rr == 2) SS_CQS_WIDE(32, 2)
+        else if (cc == 8 && rr == 1) SS_CQS_WIDE(8, 1)
+        else if (cc == 16 && rr == 1) SS_CQS_WIDE(16, 1)
+        else if (cc == 32 && rr == 1) SS_CQS_WIDE(32, 1)
+        else if (cc == 16 && rr == 3) SS_CQS_WIDE(16, 3)
+        else if (ctx->cq_vec4) SS_CQS_LAUNCH(true); else SS_CQS_LAUNCH(false);
+#undef SS_CQS_WIDE
 #undef SS_CQS_LAUNCH
         return hipGetLastError();
     }

@@ -258,6 +258,9 @@ struct ss_hip_ctx {
     hipEvent_t ev_join4 = nullptr;
     hipEvent_t ev_gate = nullptr, ev_b0 = nullptr, ev_join3 = nullptr;
     uint32_t* se_count = nullptr;     // [2][kSeCount + 2] device counters, one set per pass: arrivals per SE, arrivals in all, tiles taken
+    int cq_rows = 2;                  // option: rows of G a thread of the fused batched Gram-form pass has in flight (1, 2, 3, 4, 8)
+    int cq_cols = 16;                 // option: columns per thread of that pass (4, 8, 16, 32): a workgroup reads runs of 256 * cq_cols columns of a
+                                      // row of G — 16 KiB at 16 (measured 9500 signals/s at 8192 x 65536 x 4096 against 7560 with 4: DESIGN.md §3.6)
     int cq_vec4 = 0;                  // option (A/B): threads of the batched Gram-form pass own four consecutive columns (16-byte loads) instead of four strided ones
     int batch_fused_scan = 1;         // option: the batched Gram forms scan inside the Gram-form pass (k_la_cqs: c, q stay in registers)
     int scan_blocks = 8;              // option: workgroups per slot of the batched Gram form's scan (0 = one per 1024 columns)

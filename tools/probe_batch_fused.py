@@ -16,9 +16,11 @@ rec = torch.zeros((B, rb), dtype=torch.uint8, device=dev)
 h.solve_batch_compact(Y, 1e-3, 256, kmax=96, out=rec)      # G
 torch.cuda.synchronize()
 keep = {}
-for fused, vec in ((1, 0), (0, 0), (1, 1), (0, 1), (1, 0), (0, 0)):
+vec = 0
+for fused, cols, rows in ((1, 4, 4), (1, 8, 2), (1, 16, 1), (1, 16, 2), (1, 32, 1), (0, 4, 4)):
     h.set_option("batch_fused_scan", fused)
-    h.set_option("cq_vec4", vec)
+    h.set_option("cq_cols", cols)
+    h.set_option("cq_rows", rows)
     h.set_profiling(True)
     h.reset_stats()
     t0 = time.perf_counter()
@@ -26,9 +28,9 @@ for fused, vec in ((1, 0), (0, 0), (1, 1), (0, 1), (1, 0), (0, 0)):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = h.stats()
-    keep[fused] = rec.cpu().numpy().copy()
-    print("vec4 %d fused %d: %.4f s = %.0f signals/s; pass kernel %.1f ms over %d launches = %.3f ms each, %.0f GB/s; tie_reruns %d" % (
-        vec, fused, dt, B / dt, st["cq_ms"], st["cq_launches"], st["cq_ms"] / max(1, st["cq_launches"]),
+    keep[(fused, cols, rows)] = rec.cpu().numpy().copy()
+    print("cols %d rows %d fused %d: %.4f s = %.0f signals/s; pass kernel %.1f ms over %d launches = %.3f ms each, %.0f GB/s; tie_reruns %d" % (
+        cols, rows, fused, dt, B / dt, st["cq_ms"], st["cq_launches"], st["cq_ms"] / max(1, st["cq_launches"]),
         st["cq_bytes"] / max(1e-9, st["cq_ms"] * 1e-3) / 1e9, st["tie_reruns"]), flush=True)
     h.set_profiling(False)
     h.reset_stats()
@@ -36,4 +38,4 @@ for fused, vec in ((1, 0), (0, 0), (1, 1), (0, 1), (1, 0), (0, 0)):
     h.solve_batch_compact(Y, 1e-3, 256, kmax=96, out=rec)
     torch.cuda.synchronize()
     print("          unprofiled: %.4f s = %.0f signals/s" % (time.perf_counter() - t0, B / (time.perf_counter() - t0)), flush=True)
-print("records equal:", np.array_equal(keep[0], keep[1]))
+print("records equal:", all(np.array_equal(v, list(keep.values())[0]) for v in keep.values()))
