@@ -409,8 +409,8 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         extras["omp"] = {"workload": "OMP (ss::omp<float>, parity unpinned: the reference has no OMP), the same A and signals, %d picks" % K_SPARSE,
                          "ms_per_solve": dto / args.steps * 1e3, "support_exact": oko, "signals": args.steps}
 
-    # extra (NOT `value`): the reference-order engine (engine 3: every reduction in the documented 8-partial order, two
-    # passes over A per iteration; the arbiter of exact ties) on the same matrix and signals — its sweep and a whole solve
+    # extra (NOT `value`): the reference-order engine (engine 3: every reduction in the documented 8-partial order, one
+    # fused pass over A per iteration; the arbiter of exact ties) on the same matrix and signals — its sweep and a whole solve
     if extras is not None and h.get_option("engine") >= 1:
         try:
             keep_engine = h.get_option("engine")
@@ -419,6 +419,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             xr = torch.zeros(N, device=dev, dtype=torch.float32)
             h.solve(sigs[0][0], TOL, MAX_ITER, out=xr)
             torch.cuda.synchronize()
+            resweeps0 = int(h.stats()["ro_resweeps"])
             tr_ = time.perf_counter()
             nro = min(3, args.steps)
             same = 0
@@ -432,7 +433,9 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             extras["reference_order_engine"] = {
                 "workload": "engine 3 (csrc/reforder.hip): bit-identical with the CPU oracle's summation order; configs[1] matrix and signals",
                 "sweep_ms": ms_ro, "sweep_GBs": b1 / ms_ro / 1e6, "sweep_frac_of_8TBs": b1 / ms_ro / 1e6 / HBM_PEAK_GBS,
-                "ms_per_solve": dtr_ * 1e3, "iterations": int(itr_), "passes_over_A_per_iteration": 2,
+                "sweep": "k_ro_sweep<float,1>: c = A^T y (gemv_t); the iterations run the 2-RHS form [c, q] = A^T [r, p]",
+                "ms_per_solve": dtr_ * 1e3, "iterations": int(itr_), "passes_over_A_per_iteration": 1,
+                "second_sweeps": int(h.stats()["ro_resweeps"]) - resweeps0,
                 "same_support_as_timed_solves": same, "signals": nro}
             del xr
         except Exception as ex:

@@ -255,6 +255,8 @@ typedef struct ss_hip_stats {
     uint64_t tie_reruns;           /* signals solved again in the reference-order engine because a step-length scan met an exact tie
                                       (option "tie_rerun"): an off-support column attained max|c|, the reference's strict t > 0
                                       (homotopy-cpu.cpp:143-153) skips it for good, and which rounding hits that is luck                 */
+    uint64_t ro_resweeps;          /* reference-order engine (engine 3): iterations whose direction had to be rebuilt from the signs of
+                                      the re-computed correlations, i.e. that took a second pass over A (otherwise one per iteration)   */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------

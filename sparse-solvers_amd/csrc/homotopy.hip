@@ -448,8 +448,8 @@ inline uint32_t miss_cols(const ss_hip_ctx* ctx, const Workspace<double>& ws, ui
 
 // early form of the speculative engine (fp32): the first solo launch runs on the subset Gram matrix beside the passes over A
 inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nparts, float tol, uint32_t max_iter, uint32_t lds_cols,
-                           hipEvent_t pe0, hipEvent_t pe1);
-inline void early_prologue(ss_hip_ctx*, Workspace<double>&, uint32_t, double, uint32_t, uint32_t, hipEvent_t, hipEvent_t)
+                           hipEvent_t pe0, hipEvent_t pe1, hipEvent_t pe2 = nullptr, hipEvent_t pe3 = nullptr);
+inline void early_prologue(ss_hip_ctx*, Workspace<double>&, uint32_t, double, uint32_t, uint32_t, hipEvent_t, hipEvent_t, hipEvent_t = nullptr, hipEvent_t = nullptr)
 { throw HipFail{ hipErrorInvalidConfiguration, "early_prologue<double>" }; }
 
 template <typename T> struct Lookahead {
@@ -601,7 +601,7 @@ template <typename T> struct Lookahead {
 // resident form for the last step of the path.  A solve that does not fit this mould (a pick outside the subset,
 // a miss, a failed check) simply continues in the plain pump below.
 inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nparts, float tol, uint32_t max_iter, uint32_t lds_cols,
-                           hipEvent_t pe0, hipEvent_t pe1)
+                           hipEvent_t pe0, hipEvent_t pe1, hipEvent_t pe2, hipEvent_t pe3)
 {
     hipStream_t st = ctx->stream;
     const int probe = ctx->early_probe;              // developer aid: 1 = no overlap (the passes first, then the solo launch)
@@ -710,7 +710,9 @@ inline void early_prologue(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t npart
             HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
             HIPCHK(launch_wait_count(ctx->stream2, ctx->se_count + (kSeCount + 2) + kSeCount, early_se_wgs(ctx), ws.st));
         }
+        if (pe2) HIPCHK(hipEventRecord(pe2, ctx->stream2));
         HIPCHK(launch_gemm32w_on(ctx, ctx->stream2, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch, main_tiles));
+        if (pe3) HIPCHK(hipEventRecord(pe3, ctx->stream2));
         if (range_last) HIPCHK(launch_gemm32range_on(ctx, ctx->stream2, ws.sw_list + 32, ws.sw_list + 96, ws.gcache, ws.gpitch, se_last, range_last));
         if (main_tiles) HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_join3, 0));
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
@@ -951,10 +953,11 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 uint32_t lc = std::min<uint32_t>((ws.dims.kcap + 15u) & ~15u, kLaLdsSmall);
                 if (ctx->la_fused < 2 || !la_persist_usable(ctx, lc)) lc = 0;
                 early_lds_cols = lc;
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (prof) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
-                early_prologue(ctx, ws, nb1, tol, max_iter, lc, e0, e1);
-                if (prof) { ctx->prof_kind.push_back(5); ++nprof; }       // 5 = the main launch of an early-form pass (its share of the columns)
+                hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+                if (prof) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); e2 = prof_event(ctx, 2 * nprof + 2); e3 = prof_event(ctx, 2 * nprof + 3); }
+                early_prologue(ctx, ws, nb1, tol, max_iter, lc, e0, e1, e2, e3);
+                // 5 = the main launch of an early-form pass (its share of the columns): both passes of the solve are timed
+                if (prof) { ctx->prof_kind.push_back(5); ctx->prof_kind.push_back(5); nprof += 2; }
                 // The typical solve is complete with what is queued now: its epilogue (state, x, record) goes right
                 // behind instead of after a trip through the host (host notices `done`, three enqueues: ~70 us).
                 // Should the pump below have to queue more work, the epilogue is simply issued again at the end.
@@ -969,7 +972,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             }
         } else if (ro) {
             // c = A^T y in reference order, first pick with the column norm as a chain dot product
-            HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, ws.c, ws.pmax_val, ws.pmax_idx, &ro_parts, ws.st));
+            HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, 0, ws.c, (T*)nullptr, ws.pmax_val, ws.pmax_idx, &ro_parts, ws.st));
             HIPCHK(launch_ro_init<T>(ctx, ws, ro_parts, tol));
         } else if (!omp) {
             // c = A^T y  (residual_vector with x = 0, homotopy-cpu.cpp:215)
@@ -1078,15 +1081,18 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 continue;
             }
             if (ro) {
-                // homotopy-cpu.cpp:236-272 in its own order: p = A d, q = A^T p, scan + toggle + x update, inverse
-                // update, r = y - A x, c = A^T r, then lambda, the while-test, sign(c_Gamma) and the new direction
-                HIPCHK(launch_ro_mv<T>(ctx, ws, 1));
-                HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs + rhs_stride, ws.q, (T*)nullptr, (uint32_t*)nullptr, nullptr, ws.st));
-                HIPCHK(launch_scansel_plain<T>(ctx, ws, (uint32_t)round, ro_parts, tol, max_iter));
-                HIPCHK(launch_ro_update<T>(ctx, ws, (uint32_t)round));
+                // homotopy-cpu.cpp:236-272 with ONE pass over A per iteration: r = y - A x and p = A d (the direction built
+                // from the signs of c - gamma q), the fused sweep [c, q] = A^T [r, p], lambda + the while-test + the check of
+                // those signs against the re-computed c (a mismatch rebuilds the direction; p and q are then formed again),
+                // the scan + toggle + x update, the inverse update and the next direction
                 HIPCHK(launch_ro_mv<T>(ctx, ws, 0));
-                HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, ws.c, ws.pmax_val, ws.pmax_idx, nullptr, ws.st));
-                HIPCHK(launch_ro_dir<T>(ctx, ws, ro_parts, tol, max_iter));
+                HIPCHK(launch_ro_mv<T>(ctx, ws, 1));
+                HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, rhs_stride, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, nullptr, ws.st));
+                HIPCHK(launch_ro_check<T>(ctx, ws, ro_parts, tol, max_iter));
+                HIPCHK(launch_ro_mv<T>(ctx, ws, 1, true));
+                HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs + rhs_stride, 0, ws.q, (T*)nullptr, (T*)nullptr, (uint32_t*)nullptr, nullptr, ws.st, true));
+                HIPCHK(launch_scansel_plain<T>(ctx, ws, (uint32_t)round, ro_parts, tol, max_iter));
+                HIPCHK(launch_ro_update<T>(ctx, ws, (uint32_t)round, tol));
                 continue;
             }
             if (omp) {
@@ -1208,6 +1214,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         }
         ctx->stats.iterations += hs.iter;
         if (la || la_omp) ctx->stats.lookahead_sweeps += hs.nsweeps;
+        if (ro) ctx->stats.ro_resweeps += hs.nsweeps;
         if (prof) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
@@ -1505,6 +1512,19 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 ctx->last_trace.resize(cnt);
                 HIPCHK(hipMemcpy(ctx->last_trace.data(), ws.trace, cnt * sizeof(TraceEntry), hipMemcpyDeviceToHost));
             }
+            // The fused scan's meeting of a signal's workgroups is a bounded wait (k_la_cqs): should it ever expire — the
+            // workgroups of a signal not resident together — the slot carries SS_HIP_ERUNTIME; this context then goes on with
+            // the two-kernel form and the chunk is solved again (nothing of it has been reported yet)
+            if (gram && ctx->batch_fused_scan) {
+                bool expired = false;
+                for (uint32_t b = 0; b < Bc; ++b) expired = expired || hs[b].status == SS_HIP_ERUNTIME;
+                if (expired) {
+                    ctx->batch_fused_scan = 0;
+                    ctx->stats.persist_fallbacks += 1;
+                    b0 -= chunk;                                 // (the loop adds it back: unsigned arithmetic)
+                    continue;
+                }
+            }
             std::vector<uint32_t> ties;                      // slots whose scan met a tie stall (DevState::tie_stall)
             for (uint32_t b = 0; b < Bc; ++b) {
                 if (!hs[b].done) { set_err(err, errlen, "solve_batch: internal error, a signal did not terminate"); return SS_HIP_ERUNTIME; }
@@ -1512,7 +1532,11 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                     ties.push_back(b);
                     continue;
                 }
-                if (hs[b].status != 0) { set_err(err, errlen, "solve_batch: active set outgrew the workspace capacity"); return (int)hs[b].status; }
+                if (hs[b].status != 0) {
+                    set_err(err, errlen, hs[b].status == SS_HIP_ECAPACITY ? "solve_batch: active set outgrew the workspace capacity"
+                                                                          : "solve_batch: internal error, a device-side wait expired");
+                    return (int)hs[b].status;
+                }
                 if (iter_out) iter_out[b0 + b] = hs[b].iter;
                 if (err_out) err_out[b0 + b] = hs[b].c_inf;
                 ctx->stats.iterations += hs[b].iter;
@@ -1676,7 +1700,7 @@ int gemv_t_impl(ss_hip_ctx* ctx, const T* r, T* c, int repeats, float* ms_out, c
         HIPCHK(hipEventRecord(ctx->ev_solve0, st));
         for (int i = 0; i < repeats; ++i) {
             // (option engine = 3: the reference-order sweep, reforder.hip)
-            if (ctx->engine == 3) HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, ws.c, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
+            if (ctx->engine == 3) HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, 0, ws.c, (T*)nullptr, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
             else HIPCHK(launch_sweep<T>(ctx, ws.rhs, 0, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
         }
         HIPCHK(hipEventRecord(ctx->ev_solve1, st));
@@ -2107,6 +2131,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "profile_solve_every")) { ctx->profile_solve_every = (int)std::max<long>(1, value); ctx->prof_solve_tick = 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "engine"))        { ctx->engine = (int)std::max<long>(0, std::min<long>(3, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_rerun"))     { ctx->tie_rerun = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "ro_force_resweep")) { ctx->ro_force_resweep = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_fused_scan")) { ctx->batch_fused_scan = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_vec4"))       { ctx->cq_vec4 = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_cols"))       { ctx->cq_cols = (int)value; return SS_HIP_OK; }
@@ -2184,6 +2209,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     }
     if (!std::strcmp(key, "engine"))        { *value = ctx->engine; return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_rerun"))     { *value = ctx->tie_rerun; return SS_HIP_OK; }
+    if (!std::strcmp(key, "ro_force_resweep")) { *value = ctx->ro_force_resweep; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_fused_scan")) { *value = ctx->batch_fused_scan; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_vec4"))       { *value = ctx->cq_vec4; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_cols"))       { *value = ctx->cq_cols; return SS_HIP_OK; }

@@ -22,8 +22,15 @@
 //   sign / direction / loop    src/solvers/homotopy-cpu.cpp:257-272   -> k_ro_dir
 //   first pick                 src/solvers/homotopy-cpu.cpp:215-229   -> k_ro_init
 //
-// Roofline: HBM (two passes over A per iteration: 2 x m n s bytes).  This engine is the arbiter, not the
-// headline path; its sweep streams 32-byte runs per column (two lanes per column, four partial sums each).
+// Schedule: ONE pass over A per iteration.  The reference forms the direction from sign(c_Gamma) of the correlations it
+// has just re-computed, which would take a second pass (q = A^T A d needs the direction); here the signs are taken from
+// c - gamma q (equal in exact arithmetic), the fused sweep [c, q] = A^T [r, p] runs, and k_ro_check compares the signs of
+// the re-computed c with the ones the direction was built from — equal: every word is the reference order's; different
+// (lambda within rounding of the tolerance): the direction is rebuilt from the true signs and q alone is swept again.
+// Which sweeps run is a schedule; the values are the same either way.
+//
+// Roofline: HBM (m n s bytes per iteration).  This engine is the arbiter, not the headline path; its sweep streams
+// 32-byte runs per column (two lanes per column, four partial sums each).
 #include "ss_hip_internal.h"
 #include "ss_hip_device.h"
 
@@ -37,6 +44,7 @@ template <> struct RoVec<double> { using V = v2d; static constexpr int VN = 2; s
 
 constexpr int kRoThreads = 256;
 constexpr int kRoUnroll = 8;            // 8-row groups a lane has in flight (8 x 16 B per lane)
+constexpr uint32_t kRoLdsBytes = 65536; // dynamic LDS of k_ro_sweep (beside its few static words: the attribute is raised)
 constexpr uint32_t kRoChunk = 4096;     // rows of the two columns a chain dot product stages in LDS at a time
 
 template <typename T>
@@ -62,22 +70,24 @@ __device__ __forceinline__ T combine_lanes(const T (&acc)[RoVec<T>::VN])
     }
 }
 
-// ---- k_ro_sweep: out = A^T v, 8 partial sums per column by row & 7 --------------------------------------
+// ---- k_ro_sweep: [out0, out1] = A^T [v0, v1], 8 partial sums per column and right-hand side by row & 7 ----------------
 // LPC lanes per column: lane h of a column reads rows 8 t + h*VN .. + VN - 1 (one 16-byte load) for ascending
-// t and keeps VN partial sums; v sits in LDS.  Per workgroup: max |out| and its first index (inf_norm).
-template <typename T>
+// t and keeps VN partial sums per right-hand side; the right-hand sides sit in LDS.  Per workgroup: max |out0| and its
+// first index (inf_norm).  gate != 0: the launch only runs when DevState::ro_redo is raised (the q-only sweep after a
+// direction that had to be rebuilt).
+template <typename T, int NRHS>
 __global__ __launch_bounds__(kRoThreads)
 void k_ro_sweep(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngroups, uint32_t mc,
-                const T* __restrict__ v, T* __restrict__ out, T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx,
-                const DevState* st)
+                const T* __restrict__ v, size_t v_stride, T* __restrict__ out0, T* __restrict__ out1,
+                T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx, const DevState* st, int gate)
 {
     using V = typename RoVec<T>::V;
     constexpr int VN = RoVec<T>::VN, LPC = RoVec<T>::LPC, CPB = kRoThreads / LPC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* lds = reinterpret_cast<T*>(smem);
+    T* lds = reinterpret_cast<T*>(smem);                              // [NRHS][mc]
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
-    if (st != nullptr && st->done != 0) return;
+    if (st != nullptr && (st->done != 0 || (gate && st->ro_redo == 0u))) return;
     const uint32_t h = threadIdx.x % LPC, cl = threadIdx.x / LPC;
     const uint32_t nchunks = (ldm + mc - 1) / mc;
     T best = T(-1);
@@ -85,16 +95,20 @@ void k_ro_sweep(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngr
     bool lds_valid = false;
     for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const uint32_t col = g * CPB + cl;
-        T acc[VN];
+        T acc[NRHS][VN];
 #pragma unroll
-        for (int e = 0; e < VN; ++e) acc[e] = T(0);
+        for (int k = 0; k < NRHS; ++k)
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[k][e] = T(0);
         for (uint32_t ch = 0; ch < nchunks; ++ch) {
             const uint32_t r0 = ch * mc;
             const uint32_t rows = (ldm - r0 < mc) ? (ldm - r0) : mc;
             if (nchunks > 1 || !lds_valid) {
                 if (lds_valid) __syncthreads();
-                for (uint32_t i = threadIdx.x * VN; i < rows; i += kRoThreads * VN)
-                    *reinterpret_cast<V*>(&lds[i]) = *reinterpret_cast<const V*>(&v[r0 + i]);
+#pragma unroll
+                for (int k = 0; k < NRHS; ++k)
+                    for (uint32_t i = threadIdx.x * VN; i < rows; i += kRoThreads * VN)
+                        *reinterpret_cast<V*>(&lds[(size_t)k * mc + i]) = *reinterpret_cast<const V*>(&v[(size_t)k * v_stride + r0 + i]);
                 __syncthreads();
                 lds_valid = true;
             }
@@ -107,16 +121,22 @@ void k_ro_sweep(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngr
                 for (int u = 0; u < kRoUnroll; ++u) a[u] = __builtin_nontemporal_load(cp + (size_t)(t + u) * LPC);
 #pragma unroll
                 for (int u = 0; u < kRoUnroll; ++u) {
-                    const V b = vp[(t + u) * LPC];
 #pragma unroll
-                    for (int e = 0; e < VN; ++e) acc[e] = acc[e] + a[u][e] * b[e];
+                    for (int k = 0; k < NRHS; ++k) {
+                        const V b = vp[(size_t)k * (mc / VN) + (t + u) * LPC];
+#pragma unroll
+                        for (int e = 0; e < VN; ++e) acc[k][e] = acc[k][e] + a[u][e] * b[e];
+                    }
                 }
             }
         }
-        const T s = combine_lanes<T>(acc);
+        const T s0 = combine_lanes<T>(acc[0]);
+        T s1 = T(0);
+        if (NRHS > 1) s1 = combine_lanes<T>(acc[NRHS - 1]);
         if (h == 0 && col < n) {
-            out[col] = s;
-            const T a = s < T(0) ? -s : s;
+            out0[col] = s0;
+            if (NRHS > 1) out1[col] = s1;
+            const T a = s0 < T(0) ? -s0 : s0;
             if (a > best) { best = a; best_idx = col; }               // ascending columns: first maximum kept
         }
     }
@@ -130,9 +150,9 @@ void k_ro_sweep(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngr
 template <typename T>
 __global__ __launch_bounds__(kRoThreads)
 void k_ro_mv(const T* __restrict__ At, SlotDims L, const T* __restrict__ y, const T* __restrict__ coef,
-             const uint32_t* __restrict__ list2, int mode, T* __restrict__ out, const DevState* st)
+             const uint32_t* __restrict__ list2, int mode, T* __restrict__ out, const DevState* st, int gate)
 {
-    if (st->done) return;
+    if (st->done || (gate && st->ro_redo == 0u)) return;
     const uint32_t i = blockIdx.x * kRoThreads + threadIdx.x;
     if (i >= L.ldm) return;
     const uint32_t cnt = mode == 0 ? st->ntouched : st->K;
@@ -222,6 +242,7 @@ void k_ro_init(const T* __restrict__ At, SlotDims L, const T* __restrict__ c,
         st->done = 0; st->status = 0; st->iter = 0;
         st->K = 1; st->ntouched = 1; st->idx = idx; st->rank = 0; st->added = 1; st->cur = 0;
         st->done_round = 0;
+        st->nsweeps = 0; st->ro_redo = 0;
         st->c_inf = (double)c_inf;
         st->gamma = 0.0;
         st->lambda0 = (float)c_inf;
@@ -237,7 +258,8 @@ void k_ro_init(const T* __restrict__ At, SlotDims L, const T* __restrict__ c,
 template <typename T>
 __global__ __launch_bounds__(kRoThreads)
 void k_ro_update(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict__ gam2,
-                 T* inv0, T* inv1, T* u1, T* u2, DevState* st)
+                 T* inv0, T* inv1, T* u1, T* u2, T* sgn, const T* __restrict__ c, const T* __restrict__ q, T* __restrict__ d, T tol,
+                 DevState* st)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* lds = reinterpret_cast<T*>(smem);
@@ -319,16 +341,43 @@ void k_ro_update(const T* __restrict__ At, SlotDims L, const uint32_t* __restric
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) st->cur = cur ^ 1u;
+    // the signs of the correlations after the step, taken from c - gamma q (homotopy-cpu.cpp:259-260 reads them off the
+    // re-computed c: k_ro_check compares once that exists), and direction = inv * sign (:263), 8 partials by position
+    {
+        const T g = (T)st->gamma;
+        const uint32_t* gam_old = gam2 + (size_t)cur * kcap;
+        for (uint32_t a = threadIdx.x; a < K_new; a += blockDim.x) {
+            const uint32_t col = gam_new[a];
+            sgn[a] = sign_tol(c[col] - g * q[col], tol);
+        }
+        for (uint32_t j = threadIdx.x; j < K_old; j += blockDim.x) d[gam_old[j]] = T(0);
+        __syncthreads();
+        for (uint32_t a = threadIdx.x; a < K_new; a += blockDim.x) {
+            T s8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s8[k] = T(0);
+            for (uint32_t b0 = 0; b0 < K_new; b0 += 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (b0 + (uint32_t)k < K_new) s8[k] = s8[k] + Inew[a * P + b0 + k] * sgn[b0 + k];
+            }
+            d[gam_new[a]] = combine8<T>(s8);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { st->cur = cur ^ 1u; st->ro_redo = 0u; }
 }
 
-// ---- k_ro_dir: lambda = ||c||_inf of the correlations just re-computed, the loop's while-test
-// ---- (homotopy-cpu.cpp:270-272), sign(c_Gamma) with the dead zone and direction = inv * sign (:257-267) -----
+// ---- k_ro_check: lambda = ||c||_inf of the correlations just re-computed and the loop's while-test
+// ---- (homotopy-cpu.cpp:270-272); then the signs the direction was built from (k_ro_update: c - gamma q) against
+// ---- sign(c_Gamma) of the re-computed c (:259-260).  Equal: nothing to do.  Different (lambda within rounding of the
+// ---- dead zone): the direction is rebuilt from the true signs (:263, 8 partials by position) and ro_redo is raised —
+// ---- p = A d and q = A^T p are then formed again before the scan.
 template <typename T>
 __global__ __launch_bounds__(kUpdThreads)
-void k_ro_dir(const T* __restrict__ c, const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
-              T* __restrict__ d, const uint32_t* __restrict__ gam2, const T* inv0, const T* inv1, T* sgn, SlotDims L,
-              T tol, uint32_t max_iter, DevState* st, uint32_t* hflags, uint32_t* ndone)
+void k_ro_check(const T* __restrict__ c, const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
+                T* __restrict__ d, const uint32_t* __restrict__ gam2, const T* inv0, const T* inv1, T* sgn, SlotDims L,
+                T tol, uint32_t max_iter, DevState* st, uint32_t* hflags, uint32_t* ndone, int force)
 {
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
@@ -337,6 +386,7 @@ void k_ro_dir(const T* __restrict__ c, const T* __restrict__ pmax_val, const uin
     uint32_t imax;
     reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, imax, sv, si);
     const uint32_t iter = st->iter;
+    if (iter == 0u) return;                                           // (the first direction carries the seed's sign: :223-227)
     if (!(iter < max_iter && c_inf > tol)) {
         if (threadIdx.x == 0) {
             st->c_inf = (double)c_inf;
@@ -347,53 +397,73 @@ void k_ro_dir(const T* __restrict__ c, const T* __restrict__ pmax_val, const uin
         return;
     }
     const uint32_t kcap = L.kcap;
-    const uint32_t cur = st->cur;                                     // (k_ro_update has flipped it)
+    const uint32_t cur = st->cur;
     const uint32_t K = st->K;
-    const uint32_t K_old = st->added ? K - 1u : K + 1u;
     const uint32_t* gam = gam2 + (size_t)cur * kcap;
-    const uint32_t* gam_old = gam2 + (size_t)(cur ^ 1u) * kcap;
     const T* I = cur ? inv1 : inv0;
     const size_t P = kcap;
+    int differs = force;
+    for (uint32_t a = threadIdx.x; a < K; a += blockDim.x) {
+        const T s_true = sign_tol(c[gam[a]], tol);
+        if (s_true != sgn[a]) { differs = 1; }
+    }
+    if (!__syncthreads_or(differs)) return;
     for (uint32_t a = threadIdx.x; a < K; a += blockDim.x) sgn[a] = sign_tol(c[gam[a]], tol);
-    for (uint32_t j = threadIdx.x; j < K_old; j += blockDim.x) d[gam_old[j]] = T(0);
     __syncthreads();
     for (uint32_t a = threadIdx.x; a < K; a += blockDim.x) {
-        T s[8];
+        T s8[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] = T(0);
+        for (int k = 0; k < 8; ++k) s8[k] = T(0);
         for (uint32_t b0 = 0; b0 < K; b0 += 8) {
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (b0 + (uint32_t)k < K) s[k] = s[k] + I[a * P + b0 + k] * sgn[b0 + k];
+                if (b0 + (uint32_t)k < K) s8[k] = s8[k] + I[a * P + b0 + k] * sgn[b0 + k];
         }
-        d[gam[a]] = combine8<T>(s);
+        d[gam[a]] = combine8<T>(s8);
     }
+    if (threadIdx.x == 0) { st->ro_redo = 1u; st->nsweeps = st->nsweeps + 1u; }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------
 template <typename T>
-hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, T* out, T* pmax_val, uint32_t* pmax_idx, uint32_t* nblocks_out,
-                           const DevState* st)
+hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, size_t v_stride, T* out0, T* out1, T* pmax_val, uint32_t* pmax_idx,
+                           uint32_t* nblocks_out, const DevState* st, bool gate)
 {
     constexpr uint32_t CPB = kRoThreads / RoVec<T>::LPC;
     const uint32_t ngroups = ctx->n_pad / CPB;                        // n_pad is a multiple of 256
-    uint32_t mc = (uint32_t)(65536 / sizeof(T));
+    const int nrhs = out1 != nullptr ? 2 : 1;
+    // the right-hand sides sit in LDS: up to 64 KiB of them (two workgroups per CU), whole when they fit
+    static const bool lds_ok = [] {
+        const int lim = (int)kRoLdsBytes;
+        const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ro_sweep<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+        const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ro_sweep<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+        if (!(a && b)) (void)hipGetLastError();
+        return a && b;
+    }();
+    uint32_t mc = (uint32_t)((lds_ok ? kRoLdsBytes : 32768u) / (sizeof(T) * nrhs));
+    mc -= mc % kRowPad;
     if (mc > ctx->ldm) mc = ctx->ldm;
     uint32_t grid = std::min<uint32_t>(ngroups, kMaxSweepBlocks);
     if (nblocks_out) *nblocks_out = grid;
-    hipLaunchKernelGGL((k_ro_sweep<T>), dim3(grid), dim3(kRoThreads), (size_t)mc * sizeof(T), ctx->stream,
-                       static_cast<const T*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, ngroups, mc, v, out, pmax_val, pmax_idx, st);
+    if (nrhs == 2)
+        hipLaunchKernelGGL((k_ro_sweep<T, 2>), dim3(grid), dim3(kRoThreads), (size_t)2 * mc * sizeof(T), ctx->stream,
+                           static_cast<const T*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, ngroups, mc, v, v_stride, out0, out1,
+                           pmax_val, pmax_idx, st, gate ? 1 : 0);
+    else
+        hipLaunchKernelGGL((k_ro_sweep<T, 1>), dim3(grid), dim3(kRoThreads), (size_t)mc * sizeof(T), ctx->stream,
+                           static_cast<const T*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, ngroups, mc, v, v_stride, out0, (T*)nullptr,
+                           pmax_val, pmax_idx, st, gate ? 1 : 0);
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_ro_mv(const ss_hip_ctx* ctx, Workspace<T>& ws, int mode)
+hipError_t launch_ro_mv(const ss_hip_ctx* ctx, Workspace<T>& ws, int mode, bool gate)
 {
     const uint32_t blocks = (ctx->ldm + kRoThreads - 1) / kRoThreads;
     T* out = mode == 0 ? ws.rhs : ws.rhs + (size_t)ws.dims.b_pad * ctx->ldm;
     hipLaunchKernelGGL((k_ro_mv<T>), dim3(blocks), dim3(kRoThreads), 0, ctx->stream, static_cast<const T*>(ctx->At), ws.dims,
                        (const T*)ws.y, mode == 0 ? (const T*)ws.x : (const T*)ws.d,
-                       mode == 0 ? (const uint32_t*)ws.touched : (const uint32_t*)ws.gam, mode, out, (const DevState*)ws.st);
+                       mode == 0 ? (const uint32_t*)ws.touched : (const uint32_t*)ws.gam, mode, out, (const DevState*)ws.st, gate ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -408,30 +478,31 @@ hipError_t launch_ro_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t npar
 }
 
 template <typename T>
-hipError_t launch_ro_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round)
+hipError_t launch_ro_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol)
 {
     uint32_t gb = round + 1;                                          // support size after this round is <= round + 1
     if (gb > ws.kcap) gb = ws.kcap;
     hipLaunchKernelGGL((k_ro_update<T>), dim3(gb), dim3(kRoThreads), 2 * (size_t)kRoChunk * sizeof(T), ctx->stream,
-                       static_cast<const T*>(ctx->At), ws.dims, (const uint32_t*)ws.gam, ws.inv[0], ws.inv[1], ws.u1, ws.u2, ws.st);
+                       static_cast<const T*>(ctx->At), ws.dims, (const uint32_t*)ws.gam, ws.inv[0], ws.inv[1], ws.u1, ws.u2,
+                       ws.sgn, (const T*)ws.c, (const T*)ws.q, ws.d, tol, ws.st);
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_ro_dir(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, uint32_t max_iter)
+hipError_t launch_ro_check(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, uint32_t max_iter)
 {
-    hipLaunchKernelGGL((k_ro_dir<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, (const T*)ws.c, (const T*)ws.pmax_val,
+    hipLaunchKernelGGL((k_ro_check<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, (const T*)ws.c, (const T*)ws.pmax_val,
                        (const uint32_t*)ws.pmax_idx, nparts, ws.d, (const uint32_t*)ws.gam, (const T*)ws.inv[0], (const T*)ws.inv[1],
-                       ws.sgn, ws.dims, tol, max_iter, ws.st, ctx->dev_flags, ws.ndone);
+                       ws.sgn, ws.dims, tol, max_iter, ws.st, ctx->dev_flags, ws.ndone, ctx->ro_force_resweep);
     return hipGetLastError();
 }
 
 #define SS_RO_INST(T)                                                                                                          \
-    template hipError_t launch_ro_sweep<T>(const ss_hip_ctx*, const T*, T*, T*, uint32_t*, uint32_t*, const DevState*);       \
-    template hipError_t launch_ro_mv<T>(const ss_hip_ctx*, Workspace<T>&, int);                                               \
+    template hipError_t launch_ro_sweep<T>(const ss_hip_ctx*, const T*, size_t, T*, T*, T*, uint32_t*, uint32_t*, const DevState*, bool); \
+    template hipError_t launch_ro_mv<T>(const ss_hip_ctx*, Workspace<T>&, int, bool);                                         \
     template hipError_t launch_ro_init<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, T);                                     \
-    template hipError_t launch_ro_update<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t);                                      \
-    template hipError_t launch_ro_dir<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, T, uint32_t);
+    template hipError_t launch_ro_update<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, T);                                   \
+    template hipError_t launch_ro_check<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, T, uint32_t);
 SS_RO_INST(float)
 SS_RO_INST(double)
 #undef SS_RO_INST

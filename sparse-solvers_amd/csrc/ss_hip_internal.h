@@ -81,7 +81,7 @@ struct DevState {
                            // the column that has just LEFT the support (it sits on the boundary by rule), nor when an off-support column
                            // dominates by a margin (a path already derailed, e.g. by the first-step sign quirk: every rounding agrees)
     float    lambda0;      // ||A^T y||_inf, the first lambda of the solve (the scale of the tie band, ss_hip_device.h: tie_band)
-    uint32_t pad0_[1];
+    uint32_t ro_redo;      // reference-order engine: the direction had to be rebuilt from the true signs — q = A^T A d is swept again (k_ro_check)
     // ---- words other workgroups touch concurrently inside a launch: one 128-B line each
     uint32_t ticket_scan; // arrival counter of k_scansel (reset by the last arriver)
     uint32_t pad1_[31];
@@ -301,6 +301,7 @@ struct ss_hip_ctx {
     int strict_sign = 0;
     int zero_on_removal = 0; // 0 = the reference's x + gamma*d residue on a leaving column (homotopy-cpu.cpp:252); 1 = exact 0 (opt-in)
     int tie_guard = 0;       // 0 = the reference's strict t > 0 (homotopy-cpu.cpp:135,145,151); 1 = zero-length step on an exact tie (opt-in)
+    int ro_force_resweep = 0; // developer option: the reference-order engine treats every sign check as failed (the second sweep of an iteration always runs)
     int tie_rerun = 1;       // 1 = a solve whose scan met a tie stall (DevState::tie_stall) is re-run in the reference-order engine
     int profiling = 0;
     int profile_every = 1;   // with profiling on, time every k-th fused sweep
@@ -366,13 +367,17 @@ hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32
 template <typename T>
 hipError_t launch_scansel_plain(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol, uint32_t max_iter);
 // ---- reference-order engine (reforder.hip): every reduction in the documented 8-partial order ------------
+// [out0, out1] = A^T [v, v + v_stride] (out1 == nullptr: one right-hand side); gate: only when DevState::ro_redo is raised
 template <typename T>
-hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, T* out, T* pmax_val, uint32_t* pmax_idx, uint32_t* nblocks_out,
-                           const DevState* st);
-template <typename T> hipError_t launch_ro_mv(const ss_hip_ctx* ctx, Workspace<T>& ws, int mode);     // 0: r = y - A x, 1: p = A d
+hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, size_t v_stride, T* out0, T* out1, T* pmax_val, uint32_t* pmax_idx,
+                           uint32_t* nblocks_out, const DevState* st, bool gate = false);
+template <typename T> hipError_t launch_ro_mv(const ss_hip_ctx* ctx, Workspace<T>& ws, int mode, bool gate = false);   // 0: r = y - A x, 1: p = A d
 template <typename T> hipError_t launch_ro_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol);
-template <typename T> hipError_t launch_ro_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round);
-template <typename T> hipError_t launch_ro_dir(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, uint32_t max_iter);
+// inverse update, then the signs taken from c - gamma q and the direction built from them
+template <typename T> hipError_t launch_ro_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol);
+// lambda and the while-test from the correlations just re-computed; the signs the direction was built from are checked
+// against them (a mismatch rebuilds the direction and raises DevState::ro_redo)
+template <typename T> hipError_t launch_ro_check(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, uint32_t max_iter);
 // list[0..count) = 128-row tiles that still hold a running signal, list[rows/128] = count
 hipError_t launch_tile_list(const ss_hip_ctx* ctx, const DevState* st, uint32_t nslots, uint32_t rows,
                             uint32_t* list);

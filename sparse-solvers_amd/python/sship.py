@@ -82,6 +82,7 @@ class Stats(ctypes.Structure):
         ("sweep32_timed_cols", ctypes.c_uint64),
         ("sweep32_bytes_timed", ctypes.c_uint64),
         ("tie_reruns", ctypes.c_uint64),
+        ("ro_resweeps", ctypes.c_uint64),
     ]
 
 

@@ -111,6 +111,40 @@ def test_removal_paths_bitwise(sship, dtype, flags):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_one_pass_schedule_and_the_second_sweep(sship, dtype):
+    """The engine runs ONE pass over A per iteration: the direction is built from the signs of c - gamma q and the
+    signs of the re-computed correlations are checked afterwards (k_ro_check).  Which sweeps run is a schedule, not
+    arithmetic: with every check forced to fail (the direction rebuilt, p = A d and q = A^T p formed again) the words
+    are the same; and on well-posed problems no iteration needs the second sweep."""
+    for m, n, k in [(128, 1000, 10), (512, 4096, 24)]:
+        A, y, x0, sup = make_gaussian_problem(500 + m, m, n, k, dtype)
+        tol = 1e-3 if dtype == np.float32 else 1e-9
+        with sship.Homotopy(A) as h:
+            h.set_option("engine", 3)
+            h.set_option("trace", 1)
+            h.reset_stats()
+            _, ito, _ = assert_bitwise(h, A, y, tol, 4 * k, tag=("one pass", m))
+            assert h.stats()["ro_resweeps"] == 0
+            h.set_option("ro_force_resweep", 1)
+            h.reset_stats()
+            assert_bitwise(h, A, y, tol, 4 * k, tag=("forced second sweep", m))
+            assert h.stats()["ro_resweeps"] == ito - 1        # (iteration 0 carries the seed's sign: no check)
+    # removal paths with the second sweep forced
+    for seed in range(1000, 1008):
+        rng = np.random.default_rng(seed)
+        m, n, k = 24, 64, 10
+        A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(dtype)
+        x0 = np.zeros(n)
+        x0[rng.choice(n, k, replace=False)] = 1 + np.abs(rng.standard_normal(k))
+        y = (A.astype(np.float64) @ x0).astype(dtype)
+        with sship.Homotopy(A) as h:
+            h.set_option("engine", 3)
+            h.set_option("trace", 1)
+            h.set_option("ro_force_resweep", 1)
+            assert_bitwise(h, A, y, 1e-4 if dtype == np.float32 else 1e-6, 200, tag=("forced", seed))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_exact_tie_bitwise_and_rerun(sship, dtype):
     """A = I, y = e_0 + e_1 + e_5 / 2: column 1 attains lambda exactly after column 0 entered, its candidate is
     t = 0 and the strict t > 0 of the reference skips it for good.  Engine 3 follows the oracle word for word;
