@@ -29,8 +29,9 @@
 // (lambda within rounding of the tolerance): the direction is rebuilt from the true signs and q alone is swept again.
 // Which sweeps run is a schedule; the values are the same either way.
 //
-// Roofline: HBM (m n s bytes per iteration).  This engine is the arbiter, not the headline path; its sweep streams
-// 32-byte runs per column (two lanes per column, four partial sums each).
+// Roofline: HBM (m n s bytes per iteration).  The order pins one lane to a (column, 4 classes) pair, so the sweep stages
+// the dictionary through LDS (k_ro_sweep_t: coalesced loads, every lane then reads its rows of its column from LDS):
+// 0.84 of the HBM peak on configs[1]; the direct form (k_ro_sweep, 16 bytes of every 32 per lane) reaches 0.35.
 #include "ss_hip_internal.h"
 #include "ss_hip_device.h"
 
@@ -44,7 +45,6 @@ template <> struct RoVec<double> { using V = v2d; static constexpr int VN = 2; s
 
 constexpr int kRoThreads = 256;
 constexpr int kRoUnroll = 8;            // 8-row groups a lane has in flight (8 x 16 B per lane)
-constexpr uint32_t kRoLdsBytes = 65536; // dynamic LDS of k_ro_sweep (beside its few static words: the attribute is raised)
 constexpr uint32_t kRoChunk = 4096;     // rows of the two columns a chain dot product stages in LDS at a time
 
 template <typename T>
@@ -130,6 +130,116 @@ void k_ro_sweep(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngr
                 }
             }
         }
+        const T s0 = combine_lanes<T>(acc[0]);
+        T s1 = T(0);
+        if (NRHS > 1) s1 = combine_lanes<T>(acc[NRHS - 1]);
+        if (h == 0 && col < n) {
+            out0[col] = s0;
+            if (NRHS > 1) out1[col] = s1;
+            const T a = s0 < T(0) ? -s0 : s0;
+            if (a > best) { best = a; best_idx = col; }               // ascending columns: first maximum kept
+        }
+    }
+    if (pmax_val == nullptr) return;
+    block_reduce_pair<T, true>(best, best_idx, sv, si);
+    if (threadIdx.x == 0) { pmax_val[blockIdx.x] = best; pmax_idx[blockIdx.x] = best_idx; }
+}
+
+// ---- k_ro_sweep_t: the same sums, the dictionary staged through LDS ------------------------------------------------
+// The order above pins ONE lane to all rows of a (column, 4 or 2 classes) pair, so a direct sweep reads 16 bytes out of
+// every 32 per lane and a wave-instruction touches 32 columns: a quarter of every cache line per request (measured:
+// 0.35-0.45 of the HBM peak).  Here the workgroup loads a tile of CPB columns x 64 rows the coalesced way (16 lanes per
+// 256 B of a column; f64: 32 lanes per 512 B), parks it in LDS (column pitch 64 rows + LPC vectors: conflict-free for
+// the loaders and for the readers) and every lane then reads ITS rows of ITS column from there, in the same ascending
+// order: bit for bit the sums of k_ro_sweep.  Two register sets of loads in flight (2 x 32 KiB per workgroup), two LDS
+// buffers, one barrier per stage; the 64 rows of the right-hand sides travel with the tile.
+constexpr uint32_t kRoStageRows = 64;
+
+template <typename T>
+constexpr uint32_t ro_stage_lds_vecs(int nrhs)      // 16-byte vectors of ONE buffer: the tile + the right-hand sides' rows
+{
+    return (uint32_t)(kRoThreads / RoVec<T>::LPC) * (kRoStageRows * sizeof(T) / 16 + RoVec<T>::LPC) + (uint32_t)nrhs * (kRoStageRows * sizeof(T) / 16);
+}
+
+template <typename T, int NRHS>
+__global__ __launch_bounds__(kRoThreads)
+void k_ro_sweep_t(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngroups,
+                  const T* __restrict__ v, size_t v_stride, T* __restrict__ out0, T* __restrict__ out1,
+                  T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx, const DevState* st, int gate)
+{
+    using V = typename RoVec<T>::V;
+    constexpr int VN = RoVec<T>::VN, LPC = RoVec<T>::LPC, CPB = kRoThreads / LPC;
+    constexpr uint32_t RS = kRoStageRows;
+    constexpr uint32_t VPC = RS * sizeof(T) / 16;                     // vectors of one column in a stage (16 / 32)
+    constexpr uint32_t PV = VPC + LPC;                                // column pitch in LDS, in vectors
+    constexpr uint32_t NLD = CPB * VPC / kRoThreads;                  // tile loads per lane and stage (8)
+    constexpr uint32_t RV = RS / VN;                                  // vectors of one right-hand side's rows in a stage
+    constexpr uint32_t BUFV = CPB * PV + NRHS * RV;
+    static_assert(CPB * VPC % kRoThreads == 0 && NRHS * RV <= kRoThreads, "stage shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V* lds = reinterpret_cast<V*>(smem);                              // [2][BUFV]
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    if (st != nullptr && (st->done != 0 || (gate && st->ro_redo == 0u))) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t h = tid % LPC, cl = tid / LPC;
+    const uint32_t nstages = ldm / RS;                                // ldm is a multiple of 256: a multiple of 4 stages
+    const bool has_rhs = tid < NRHS * RV;
+    const T* vsrc = v + (size_t)(tid / RV) * v_stride + (size_t)(tid % RV) * VN;   // (only read when has_rhs)
+    T best = T(-1);
+    uint32_t best_idx = 0xffffffffu;
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        // loader: vector j of this lane is part (j*256 + tid) % VPC of column (j*256 + tid) / VPC
+        const T* src[NLD];
+        uint32_t dst[NLD];
+#pragma unroll
+        for (uint32_t j = 0; j < NLD; ++j) {
+            const uint32_t vi = j * kRoThreads + tid;
+            const uint32_t c = vi / VPC, part = vi % VPC;
+            src[j] = At + (size_t)(g * CPB + c) * ldm + (size_t)part * VN;
+            dst[j] = c * PV + part;
+        }
+        V ra[2][NLD], rb[2];
+        rb[0] = rb[1] = V{};
+        auto issue = [&](int set, uint32_t s) {
+            const size_t r0 = (size_t)s * RS;
+#pragma unroll
+            for (uint32_t j = 0; j < NLD; ++j) ra[set][j] = __builtin_nontemporal_load(reinterpret_cast<const V*>(src[j] + r0));
+            if (has_rhs) rb[set] = *reinterpret_cast<const V*>(vsrc + r0);
+        };
+        T acc[NRHS][VN];
+#pragma unroll
+        for (int k = 0; k < NRHS; ++k)
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[k][e] = T(0);
+        auto stage = [&](int set, uint32_t s) {
+            V* buf = lds + (size_t)(s & 1u) * BUFV;
+#pragma unroll
+            for (uint32_t j = 0; j < NLD; ++j) buf[dst[j]] = ra[set][j];
+            if (has_rhs) buf[CPB * PV + tid] = rb[set];
+            if (s + 2 < nstages) issue(set, s + 2);
+            __syncthreads();
+            const V* ap = buf + cl * PV + h;
+            const V* bp = buf + CPB * PV + h;
+#pragma unroll
+            for (uint32_t t = 0; t < RS / 8; ++t) {
+                const V a = ap[t * LPC];
+#pragma unroll
+                for (int k = 0; k < NRHS; ++k) {
+                    const V b = bp[(uint32_t)k * RV + t * LPC];
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) acc[k][e] = acc[k][e] + a[e] * b[e];
+                }
+            }
+        };
+        __syncthreads();                                              // (the previous group's last stage is consumed)
+        issue(0, 0);
+        issue(1, 1);
+        for (uint32_t s = 0; s < nstages; s += 2) {
+            stage(0, s);
+            stage(1, s + 1);
+        }
+        const uint32_t col = g * CPB + cl;
         const T s0 = combine_lanes<T>(acc[0]);
         T s1 = T(0);
         if (NRHS > 1) s1 = combine_lanes<T>(acc[NRHS - 1]);
@@ -433,18 +543,31 @@ hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, size_t v_stride, T
     const uint32_t ngroups = ctx->n_pad / CPB;                        // n_pad is a multiple of 256
     const int nrhs = out1 != nullptr ? 2 : 1;
     // the right-hand sides sit in LDS: up to 64 KiB of them (two workgroups per CU), whole when they fit
-    static const bool lds_ok = [] {
-        const int lim = (int)kRoLdsBytes;
-        const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ro_sweep<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
-        const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ro_sweep<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
-        if (!(a && b)) (void)hipGetLastError();
-        return a && b;
-    }();
-    uint32_t mc = (uint32_t)((lds_ok ? kRoLdsBytes : 32768u) / (sizeof(T) * nrhs));
-    mc -= mc % kRowPad;
-    if (mc > ctx->ldm) mc = ctx->ldm;
     uint32_t grid = std::min<uint32_t>(ngroups, kMaxSweepBlocks);
     if (nblocks_out) *nblocks_out = grid;
+    if (ctx->ro_staged) {
+        static const bool staged_ok = [] {
+            const int lim = (int)(2 * ro_stage_lds_vecs<T>(2) * 16);
+            const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ro_sweep_t<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+            const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ro_sweep_t<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+            if (!(a && b)) (void)hipGetLastError();
+            return a && b;
+        }();
+        if (staged_ok) {
+            const size_t lds = (size_t)2 * ro_stage_lds_vecs<T>(nrhs) * 16;
+            if (nrhs == 2)
+                hipLaunchKernelGGL((k_ro_sweep_t<T, 2>), dim3(grid), dim3(kRoThreads), lds, ctx->stream, static_cast<const T*>(ctx->At),
+                                   ctx->ldm, (uint32_t)ctx->n, ngroups, v, v_stride, out0, out1, pmax_val, pmax_idx, st, gate ? 1 : 0);
+            else
+                hipLaunchKernelGGL((k_ro_sweep_t<T, 1>), dim3(grid), dim3(kRoThreads), lds, ctx->stream, static_cast<const T*>(ctx->At),
+                                   ctx->ldm, (uint32_t)ctx->n, ngroups, v, v_stride, out0, (T*)nullptr, pmax_val, pmax_idx, st, gate ? 1 : 0);
+            return hipGetLastError();
+        }
+    }
+    // direct form (option ro_staged = 0, or the LDS attribute was refused): the right-hand sides whole in LDS, up to 32 KiB
+    uint32_t mc = (uint32_t)(32768u / (sizeof(T) * nrhs));
+    mc -= mc % kRowPad;
+    if (mc > ctx->ldm) mc = ctx->ldm;
     if (nrhs == 2)
         hipLaunchKernelGGL((k_ro_sweep<T, 2>), dim3(grid), dim3(kRoThreads), (size_t)2 * mc * sizeof(T), ctx->stream,
                            static_cast<const T*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, ngroups, mc, v, v_stride, out0, out1,

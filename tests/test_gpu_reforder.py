@@ -56,6 +56,11 @@ def test_gaussian_bitwise(sship, shape, dtype):
         # and the sweep on its own: c = A^T y
         c, _ = h.gemv_t(y)
         assert np.array_equal(c, oracle.gemv_t(A, y))
+        # the direct form of the sweep (no LDS staging of the dictionary): the same sums, and the same path
+        h.set_option("ro_staged", 0)
+        c, _ = h.gemv_t(y)
+        assert np.array_equal(c, oracle.gemv_t(A, y))
+        assert_bitwise(h, A, y, tol, 4 * k, tag="direct sweep")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
