@@ -428,6 +428,17 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                 same += int(torch.equal(xr != 0, X[s_] != 0))
             torch.cuda.synchronize()
             dtr_ = (time.perf_counter() - tr_) / nro
+            # four signals in lock-step: [r, p] of each in ONE pass over A per iteration (k_ro_sweep_t<2, 4>)
+            Y4 = torch.stack([sigs[(args.warmup + s_) % len(sigs)][0] for s_ in range(4)]).contiguous()
+            X4 = torch.zeros((4, N), device=dev, dtype=torch.float32)
+            h.solve_batch(Y4, TOL, MAX_ITER, out=X4)
+            torch.cuda.synchronize()
+            t4_ = time.perf_counter()
+            h.solve_batch(Y4, TOL, MAX_ITER, out=X4)
+            torch.cuda.synchronize()
+            dt4_ = time.perf_counter() - t4_
+            same4 = int(torch.equal(X4[nro - 1], xr))          # (slot nro-1 carries the signal of the last single solve)
+            del X4, Y4
             h.set_option("engine", keep_engine)
             b1 = M * N * 4 + M * 4 + N * 4
             extras["reference_order_engine"] = {
@@ -436,6 +447,8 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                 "sweep": "k_ro_sweep<float,1>: c = A^T y (gemv_t); the iterations run the 2-RHS form [c, q] = A^T [r, p]",
                 "ms_per_solve": dtr_ * 1e3, "iterations": int(itr_), "passes_over_A_per_iteration": 1,
                 "second_sweeps": int(h.stats()["ro_resweeps"]) - resweeps0,
+                "lockstep_4_signals": {"ms": dt4_ * 1e3, "ms_per_signal": dt4_ * 1e3 / 4,
+                                       "last_single_solve_bit_identical_in_the_group": same4},
                 "same_support_as_timed_solves": same, "signals": nro}
             del xr
         except Exception as ex:

@@ -2170,16 +2170,16 @@ hipError_t launch_la_scansel(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t r
 // the same launch without the lookahead ranking and without the early exit: the reference-order engine
 // follows the path wherever its own rounding takes it
 template <typename T>
-hipError_t launch_scansel_plain(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol, uint32_t max_iter)
+hipError_t launch_scansel_plain(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts, T tol, uint32_t max_iter)
 {
     const uint32_t n = (uint32_t)ctx->n;
     const uint32_t per_block = kSmallThreads * kScanPerThread;
     uint32_t ns = (n + per_block - 1) / per_block;
     if (ns > ws.dims.pmin_stride) ns = ws.dims.pmin_stride;
-    hipLaunchKernelGGL((k_scansel<T>), dim3(ns, 1), dim3(kSmallThreads), 0, ctx->stream, round, tol,
+    hipLaunchKernelGGL((k_scansel<T>), dim3(ns, nslots), dim3(kSmallThreads), 0, ctx->stream, round, tol,
                        max_iter, n, ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx,
                        nparts, ws.pmin_val, ws.pmin_idx, ws.gam, ws.touched, ws.dims, ws.st,
-                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, 1u,
+                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.ndone, nslots,
                        (T*)nullptr, (const int32_t*)nullptr, 0);
     return hipGetLastError();
 }
@@ -2235,8 +2235,8 @@ template hipError_t launch_la_omp<double>(const ss_hip_ctx*, Workspace<double>&,
 template hipError_t launch_la_omp_update<float>(const ss_hip_ctx*, Workspace<float>&, float);
 template hipError_t launch_la_omp_update<double>(const ss_hip_ctx*, Workspace<double>&, double);
 template hipError_t launch_la_iter<double>(const ss_hip_ctx*, Workspace<double>&, double, uint32_t);
-template hipError_t launch_scansel_plain<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, float, uint32_t);
-template hipError_t launch_scansel_plain<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t, double, uint32_t);
+template hipError_t launch_scansel_plain<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, uint32_t, float, uint32_t);
+template hipError_t launch_scansel_plain<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t, uint32_t, double, uint32_t);
 template hipError_t launch_la_scansel<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t, float, uint32_t);
 template hipError_t launch_la_scansel<double>(const ss_hip_ctx*, Workspace<double>&, uint32_t, uint32_t, double, uint32_t);
 template hipError_t launch_absmax<float>(const ss_hip_ctx*, Workspace<float>&, uint32_t, uint32_t*);

@@ -972,8 +972,8 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             }
         } else if (ro) {
             // c = A^T y in reference order, first pick with the column norm as a chain dot product
-            HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, 0, ws.c, (T*)nullptr, ws.pmax_val, ws.pmax_idx, &ro_parts, ws.st));
-            HIPCHK(launch_ro_init<T>(ctx, ws, ro_parts, tol));
+            HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, 0, ws.c, 0, ws.dims.n_pad, 1, 1u, ws.pmax_val, ws.pmax_idx, ws.dims.pmax_stride, &ro_parts, ws.st, false));
+            HIPCHK(launch_ro_init<T>(ctx, ws, 1u, ro_parts, tol));
         } else if (!omp) {
             // c = A^T y  (residual_vector with x = 0, homotopy-cpu.cpp:215)
             uint32_t nb1 = 0;
@@ -1085,14 +1085,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 // from the signs of c - gamma q), the fused sweep [c, q] = A^T [r, p], lambda + the while-test + the check of
                 // those signs against the re-computed c (a mismatch rebuilds the direction; p and q are then formed again),
                 // the scan + toggle + x update, the inverse update and the next direction
-                HIPCHK(launch_ro_mv<T>(ctx, ws, 0));
-                HIPCHK(launch_ro_mv<T>(ctx, ws, 1));
-                HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, rhs_stride, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, nullptr, ws.st));
-                HIPCHK(launch_ro_check<T>(ctx, ws, ro_parts, tol, max_iter));
-                HIPCHK(launch_ro_mv<T>(ctx, ws, 1, true));
-                HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs + rhs_stride, 0, ws.q, (T*)nullptr, (T*)nullptr, (uint32_t*)nullptr, nullptr, ws.st, true));
-                HIPCHK(launch_scansel_plain<T>(ctx, ws, (uint32_t)round, ro_parts, tol, max_iter));
-                HIPCHK(launch_ro_update<T>(ctx, ws, (uint32_t)round, tol));
+                HIPCHK(launch_ro_round<T>(ctx, ws, 1u, (uint32_t)round, ro_parts, tol, max_iter));
                 continue;
             }
             if (omp) {
@@ -1338,6 +1331,122 @@ bool ensure_bcol(ss_hip_ctx* ctx, size_t per, uint32_t max_iter)
     return true;
 }
 
+// Several signals in the reference-order engine at once (reforder.hip): up to ro_slots_max() of them share every pass
+// over A — the sweep carries [r, p] of each — and run in lock-step like the batched forms; each signal's words are
+// exactly those of a solve on its own (the slots share nothing but the dictionary tile in LDS).  Used for a batch's tie
+// re-runs and for batches in engine 3.  sig: the signals' indices into Y / X / the outputs (nullptr: 0 .. count-1).
+template <typename T>
+int solve_batch_ro(ss_hip_ctx* ctx, const T* Y, const size_t* sig, size_t count, ptrdiff_t y_stride, ptrdiff_t incy, T tol,
+                   uint32_t max_iter, T* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out, double* err_out,
+                   char* err, size_t errlen, void* rec_out, uint32_t kmax)
+{
+    if (max_iter == 0) { set_err(err, errlen, "solve_batch: max_iterations must be > 0"); return SS_HIP_EINVAL; }
+    if (!(tol >= std::numeric_limits<T>::epsilon() && tol < T(1))) {
+        set_err(err, errlen, "solve_batch: tolerance must satisfy eps <= tolerance < 1");
+        return SS_HIP_EINVAL;
+    }
+    if (incy <= 0 || incx <= 0) { set_err(err, errlen, "solve_batch: increments must be positive"); return SS_HIP_EINVAL; }
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        const size_t m = ctx->m, n = ctx->n, ldm = ctx->ldm, np = ctx->n_pad;
+        const uint32_t kcap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n, (uint64_t)max_iter + 1), kKcapLimit);
+        const size_t per = std::max<uint32_t>(1u, std::min<uint32_t>(ro_slots_max(ctx, sizeof(T) == 8), (uint32_t)std::max(1, ctx->ro_slots)));
+        hipStream_t st = ctx->stream;
+        std::vector<DevState> hs;
+        for (size_t j0 = 0; j0 < count; j0 += per) {
+            const uint32_t R = (uint32_t)std::min(per, count - j0);
+            auto gidx = [&](uint32_t b) { return sig ? sig[j0 + b] : j0 + b; };
+            ensure_workspace<T>(ctx, R, kcap);
+            Workspace<T>& ws = *ws_of<T>(ctx);
+            const uint32_t want_trace = (ctx->tracing && gidx(0) == 0) ? (uint32_t)std::min<uint64_t>((uint64_t)max_iter + 2, 1u << 20) : 0u;
+            if (want_trace > ws.trace_cap) {
+                if (ws.trace) HIPCHK(hipFree(ws.trace));
+                ws.trace = nullptr;
+                ws.trace_cap = 0;
+                HIPCHK(hipMalloc(&ws.trace, (size_t)want_trace * sizeof(TraceEntry)));
+                ws.trace_cap = want_trace;
+            }
+            TraceEntry* const trace_keep = ws.trace;
+            if (want_trace == 0u) ws.trace = nullptr;
+            struct RestoreTrace { Workspace<T>& w; TraceEntry* p; ~RestoreTrace() { w.trace = p; } } restore_trace{ ws, trace_keep };
+
+            ctx->host_flags[0] = 0;
+            ctx->host_flags[1] = 0;
+            HIPCHK(hipMemsetAsync(ws.y, 0, (size_t)R * ldm * sizeof(T), st));
+            for (uint32_t b = 0; b < R; ++b) copy_in<T>(ctx, ws.y + (size_t)b * ldm, Y + (ptrdiff_t)gidx(b) * y_stride, incy, m);
+            HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)R * np * sizeof(T), st));
+            HIPCHK(hipMemsetAsync(ws.d, 0, (size_t)R * np * sizeof(T), st));
+            HIPCHK(hipMemsetAsync(ws.insup, 0, (size_t)R * np, st));
+            HIPCHK(hipMemsetAsync(ws.st, 0, (size_t)R * sizeof(DevState), st));
+            HIPCHK(hipMemsetAsync(ws.ndone, 0, sizeof(uint32_t), st));
+            // (the sweep reads whole slot groups of 1, 2, 4, 8 right-hand sides: the slots beyond R carry zeros)
+            const size_t bp = ws.dims.b_pad;
+            HIPCHK(hipMemsetAsync(ws.rhs, 0, 2 * bp * ldm * sizeof(T), st));
+
+            // c = A^T y of every slot in one pass (the slots' y rows are the right-hand sides), first picks
+            uint32_t nparts = 0;
+            HIPCHK(launch_ro_sweep<T>(ctx, ws.y, 0, ws.c, 0, ws.dims.n_pad, 1, R, ws.pmax_val, ws.pmax_idx, ws.dims.pmax_stride, &nparts,
+                                      ws.st, false));
+            HIPCHK(launch_ro_init<T>(ctx, ws, R, nparts, tol));
+            const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
+            volatile uint32_t* hf = ctx->host_flags;
+            const uint64_t last_round = (uint64_t)max_iter + 1;
+            for (uint64_t round = 1; round <= last_round; ++round) {
+                if (round > L) {
+                    const uint32_t need = (uint32_t)(round - L);
+                    uint32_t spins = 0;
+                    while (hf[1] == 0 && hf[0] < need) {
+                        if ((++spins & 0x3ffu) == 0) {
+                            const hipError_t q = hipStreamQuery(st);
+                            if (q == hipSuccess) break;
+                            if (q != hipErrorNotReady) throw HipFail{ q, "hipStreamQuery(reference-order batch loop)" };
+                        }
+                        std::this_thread::yield();
+                    }
+                    if (hf[1] != 0) break;
+                }
+                HIPCHK(launch_ro_round<T>(ctx, ws, R, (uint32_t)round, nparts, tol, max_iter));
+            }
+            hs.resize(R);
+            HIPCHK(hipMemcpyAsync(hs.data(), ws.st, (size_t)R * sizeof(DevState), hipMemcpyDeviceToHost, st));
+            if (rec_out) {
+                const size_t rb = record_bytes(kmax, sizeof(T));
+                const unsigned char* stage = pack_records<T>(ctx, ws, R, kmax);
+                for (uint32_t b = 0; b < R; ++b)
+                    HIPCHK(hipMemcpyAsync(static_cast<unsigned char*>(rec_out) + gidx(b) * rb, stage + (size_t)b * rb, rb, hipMemcpyDefault, st));
+            }
+            if (X)
+                for (uint32_t b = 0; b < R; ++b) copy_out<T>(ctx, X + (ptrdiff_t)gidx(b) * x_stride, incx, ws.x + (size_t)b * np, n);
+            HIPCHK(hipStreamSynchronize(st));
+            if (want_trace != 0u && ws.trace) {
+                const size_t cnt = std::min<size_t>((size_t)hs[0].iter + 1, ws.trace_cap);
+                ctx->last_trace.resize(cnt);
+                HIPCHK(hipMemcpy(ctx->last_trace.data(), ws.trace, cnt * sizeof(TraceEntry), hipMemcpyDeviceToHost));
+            }
+            for (uint32_t b = 0; b < R; ++b) {
+                if (!hs[b].done) { set_err(err, errlen, "solve_batch: internal error, a signal did not terminate"); return SS_HIP_ERUNTIME; }
+                if (hs[b].status != 0) {
+                    set_err(err, errlen, hs[b].status == SS_HIP_ECAPACITY ? "solve_batch: active set outgrew the workspace capacity"
+                                                                          : "solve_batch: internal error, a device-side wait expired");
+                    return (int)hs[b].status;
+                }
+                if (iter_out) iter_out[gidx(b)] = hs[b].iter;
+                if (err_out) err_out[gidx(b)] = hs[b].c_inf;
+                ctx->stats.iterations += hs[b].iter;
+                ctx->stats.ro_resweeps += hs[b].nsweeps;
+            }
+            ctx->stats.solves += R;
+        }
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        return SS_HIP_ERUNTIME;
+    } catch (const std::bad_alloc&) {
+        set_err(err, errlen, "solve_batch: out of host memory");
+        return SS_HIP_ENOMEM;
+    }
+    return SS_HIP_OK;
+}
+
 // `gram`: Gram form — the correlations of every signal come from rows of G = A^T A
 // (c = c0 - sum_j x_j G[j], q = sum_j d_j G[j]) instead of two GEMMs per round
 int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy,
@@ -1363,6 +1472,7 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
         const size_t chunk = cols_form ? (size_t)std::max(1, ctx->bcol_chunk) : (size_t)std::max(4, ctx->batch_chunk);
         hipStream_t st = ctx->stream;
         std::vector<DevState> hs;
+        std::vector<size_t> all_ties;                        // signals whose scan met a tie stall, over all chunks
         for (size_t b0 = 0; b0 < B; b0 += chunk) {
             const uint32_t Bc = (uint32_t)std::min(chunk, B - b0);
             ensure_workspace<T>(ctx, Bc, kcap);
@@ -1564,21 +1674,15 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 ctx->stats.cq_bytes += rows * (uint64_t)n * sizeof(T);
             }
             // Tie stalls: which implementation's rounding derails on an exact tie is luck (homotopy-cpu.cpp:143-153), so
-            // these signals are solved again, one by one, in the reference-order engine — the chunk's results are out,
-            // its workspace is free.  (A handful per 4096 signals at 8192 x 65536.)
-            for (uint32_t b : ties) {
-                const size_t g = b0 + b;
-                uint32_t it = 0;
-                double e = 0.0;
-                ctx->stats.tie_reruns += 1;
-                const int rc = solve_impl<T>(ctx, Y + (ptrdiff_t)g * y_stride, incy, tol, max_iter,
-                                             X ? X + (ptrdiff_t)g * x_stride : nullptr, incx, &it, &e, err, errlen, false, false, false,
-                                             rec_out ? static_cast<unsigned char*>(rec_out) + g * record_bytes(kmax, sizeof(T)) : nullptr,
-                                             kmax, true);
-                if (rc != SS_HIP_OK) return rc;
-                if (iter_out) iter_out[g] = it;
-                if (err_out) err_out[g] = e;
-            }
+            // these signals are solved again in the reference-order engine — after the last chunk, all of them together
+            // (up to 4 share every pass over A: solve_batch_ro).  (A handful per 4096 signals at 8192 x 65536.)
+            for (uint32_t b : ties) all_ties.push_back(b0 + b);
+        }
+        if (!all_ties.empty()) {
+            ctx->stats.tie_reruns += all_ties.size();
+            const int rc = solve_batch_ro<T>(ctx, Y, all_ties.data(), all_ties.size(), y_stride, incy, tol, max_iter, X, x_stride, incx,
+                                             iter_out, err_out, err, errlen, rec_out, kmax);
+            if (rc != SS_HIP_OK) return rc;
         }
     } catch (const HipFail& f) {
         set_err(err, errlen, hip_msg(f));
@@ -1613,9 +1717,9 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                          uint32_t max_iter, float* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
                          double* err_out, char* err, size_t errlen, void* rec_out = nullptr, uint32_t kmax = 0)
 {
-    // reference-order engine: one solve per signal (it is the arbiter, not a throughput path)
+    // reference-order engine: in lock-step, up to 4 signals per pass over A
     if (ctx->engine == 3)
-        return solve_batch_seq<float>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
+        return solve_batch_ro<float>(ctx, Y, nullptr, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
     // lock-step MFMA path once enough signals share the matrix (batch_min option, default 192)
     const bool lockstep = B >= (size_t)std::max(2, ctx->batch_min);
     int form = 0;
@@ -1661,6 +1765,9 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const double* Y, size_t B, ptrdiff_t y
                          uint32_t max_iter, double* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
                          double* err_out, char* err, size_t errlen, void* rec_out = nullptr, uint32_t kmax = 0)
 {
+    // reference-order engine: in lock-step, up to 4 signals per pass over A
+    if (ctx->engine == 3)
+        return solve_batch_ro<double>(ctx, Y, nullptr, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
     // fp64: one signal at a time (memory-bound sweep path)
     return solve_batch_seq<double>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
 }
@@ -1700,7 +1807,7 @@ int gemv_t_impl(ss_hip_ctx* ctx, const T* r, T* c, int repeats, float* ms_out, c
         HIPCHK(hipEventRecord(ctx->ev_solve0, st));
         for (int i = 0; i < repeats; ++i) {
             // (option engine = 3: the reference-order sweep, reforder.hip)
-            if (ctx->engine == 3) HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, 0, ws.c, (T*)nullptr, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
+            if (ctx->engine == 3) HIPCHK(launch_ro_sweep<T>(ctx, ws.rhs, 0, ws.c, 0, ws.dims.n_pad, 1, 1u, ws.pmax_val, ws.pmax_idx, ws.dims.pmax_stride, &nb, nullptr, false));
             else HIPCHK(launch_sweep<T>(ctx, ws.rhs, 0, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nb, nullptr));
         }
         HIPCHK(hipEventRecord(ctx->ev_solve1, st));
@@ -2133,6 +2240,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "tie_rerun"))     { ctx->tie_rerun = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_force_resweep")) { ctx->ro_force_resweep = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_staged"))     { ctx->ro_staged = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "ro_slots"))      { if (value < 1 || value > 4) return SS_HIP_EINVAL; ctx->ro_slots = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_fused_scan")) { ctx->batch_fused_scan = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_vec4"))       { ctx->cq_vec4 = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_cols"))       { ctx->cq_cols = (int)value; return SS_HIP_OK; }
@@ -2212,6 +2320,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "tie_rerun"))     { *value = ctx->tie_rerun; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_force_resweep")) { *value = ctx->ro_force_resweep; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_staged"))     { *value = ctx->ro_staged; return SS_HIP_OK; }
+    if (!std::strcmp(key, "ro_slots"))      { *value = ctx->ro_slots; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_fused_scan")) { *value = ctx->batch_fused_scan; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_vec4"))       { *value = ctx->cq_vec4; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_cols"))       { *value = ctx->cq_cols; return SS_HIP_OK; }

@@ -161,14 +161,17 @@ constexpr uint32_t ro_stage_lds_vecs(int nrhs)      // 16-byte vectors of ONE bu
     return (uint32_t)(kRoThreads / RoVec<T>::LPC) * (kRoStageRows * sizeof(T) / 16 + RoVec<T>::LPC) + (uint32_t)nrhs * (kRoStageRows * sizeof(T) / 16);
 }
 
-template <typename T, int NRHS>
-__global__ __launch_bounds__(kRoThreads)
+// Right-hand side k = b * NS + s is block b (0: r, 1: p) of slot s: v + b * blk_stride + s * ldm; its output goes to
+// out + b * out_blk + s * n_pad.  NS > 1: several signals share ONE pass over the dictionary (a batch's tie re-runs,
+// batches in engine 3); a slot that is done (or, gate != 0, whose direction stood the check) keeps its outputs.
+template <typename T, int NB, int NS>
+__global__ __launch_bounds__(kRoThreads, 2)
 void k_ro_sweep_t(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t ngroups,
-                  const T* __restrict__ v, size_t v_stride, T* __restrict__ out0, T* __restrict__ out1,
-                  T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx, const DevState* st, int gate)
+                  const T* __restrict__ v, size_t blk_stride, T* __restrict__ out, size_t out_blk, uint32_t n_pad,
+                  T* __restrict__ pmax_val, uint32_t* __restrict__ pmax_idx, uint32_t pmax_stride, const DevState* st, int gate)
 {
     using V = typename RoVec<T>::V;
-    constexpr int VN = RoVec<T>::VN, LPC = RoVec<T>::LPC, CPB = kRoThreads / LPC;
+    constexpr int VN = RoVec<T>::VN, LPC = RoVec<T>::LPC, CPB = kRoThreads / LPC, NRHS = NB * NS;
     constexpr uint32_t RS = kRoStageRows;
     constexpr uint32_t VPC = RS * sizeof(T) / 16;                     // vectors of one column in a stage (16 / 32)
     constexpr uint32_t PV = VPC + LPC;                                // column pitch in LDS, in vectors
@@ -180,14 +183,21 @@ void k_ro_sweep_t(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t n
     V* lds = reinterpret_cast<V*>(smem);                              // [2][BUFV]
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
-    if (st != nullptr && (st->done != 0 || (gate && st->ro_redo == 0u))) return;
+    uint32_t live = 0;                                                // slots this launch works for
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+        if (st == nullptr || (st[sl].done == 0 && (!gate || st[sl].ro_redo != 0u))) live |= 1u << sl;
+    if (live == 0u) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t h = tid % LPC, cl = tid / LPC;
     const uint32_t nstages = ldm / RS;                                // ldm is a multiple of 256: a multiple of 4 stages
     const bool has_rhs = tid < NRHS * RV;
-    const T* vsrc = v + (size_t)(tid / RV) * v_stride + (size_t)(tid % RV) * VN;   // (only read when has_rhs)
-    T best = T(-1);
-    uint32_t best_idx = 0xffffffffu;
+    const uint32_t rk = tid / RV;                                     // (only meaningful when has_rhs)
+    const T* vsrc = v + (size_t)(rk / NS) * blk_stride + (size_t)(rk % NS) * ldm + (size_t)(tid % RV) * VN;
+    T best[NS];
+    uint32_t best_idx[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) { best[sl] = T(-1); best_idx[sl] = 0xffffffffu; }
     for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         // loader: vector j of this lane is part (j*256 + tid) % VPC of column (j*256 + tid) / VPC
         const T* src[NLD];
@@ -201,8 +211,8 @@ void k_ro_sweep_t(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t n
         }
         V ra[2][NLD], rb[2];
         rb[0] = rb[1] = V{};
-        auto issue = [&](int set, uint32_t s) {
-            const size_t r0 = (size_t)s * RS;
+        auto issue = [&](int set, uint32_t sg) {
+            const size_t r0 = (size_t)sg * RS;
 #pragma unroll
             for (uint32_t j = 0; j < NLD; ++j) ra[set][j] = __builtin_nontemporal_load(reinterpret_cast<const V*>(src[j] + r0));
             if (has_rhs) rb[set] = *reinterpret_cast<const V*>(vsrc + r0);
@@ -212,16 +222,17 @@ void k_ro_sweep_t(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t n
         for (int k = 0; k < NRHS; ++k)
 #pragma unroll
             for (int e = 0; e < VN; ++e) acc[k][e] = T(0);
-        auto stage = [&](int set, uint32_t s) {
-            V* buf = lds + (size_t)(s & 1u) * BUFV;
+        auto stage = [&](int set, uint32_t sg) {
+            V* buf = lds + (size_t)(sg & 1u) * BUFV;
 #pragma unroll
             for (uint32_t j = 0; j < NLD; ++j) buf[dst[j]] = ra[set][j];
             if (has_rhs) buf[CPB * PV + tid] = rb[set];
-            if (s + 2 < nstages) issue(set, s + 2);
+            if (sg + 2 < nstages) issue(set, sg + 2);
             __syncthreads();
             const V* ap = buf + cl * PV + h;
             const V* bp = buf + CPB * PV + h;
-#pragma unroll
+            constexpr int TU = NRHS >= 8 ? 1 : (NRHS >= 4 ? 2 : (int)(RS / 8));   // (many right-hand sides: registers for the sums, not for look-ahead)
+#pragma unroll TU
             for (uint32_t t = 0; t < RS / 8; ++t) {
                 const V a = ap[t * LPC];
 #pragma unroll
@@ -235,24 +246,36 @@ void k_ro_sweep_t(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t n
         __syncthreads();                                              // (the previous group's last stage is consumed)
         issue(0, 0);
         issue(1, 1);
-        for (uint32_t s = 0; s < nstages; s += 2) {
-            stage(0, s);
-            stage(1, s + 1);
+        for (uint32_t sg = 0; sg < nstages; sg += 2) {
+            stage(0, sg);
+            stage(1, sg + 1);
         }
         const uint32_t col = g * CPB + cl;
-        const T s0 = combine_lanes<T>(acc[0]);
-        T s1 = T(0);
-        if (NRHS > 1) s1 = combine_lanes<T>(acc[NRHS - 1]);
-        if (h == 0 && col < n) {
-            out0[col] = s0;
-            if (NRHS > 1) out1[col] = s1;
-            const T a = s0 < T(0) ? -s0 : s0;
-            if (a > best) { best = a; best_idx = col; }               // ascending columns: first maximum kept
+#pragma unroll
+        for (int k = 0; k < NRHS; ++k) {
+            const T sum = combine_lanes<T>(acc[k]);
+            const int bl = k / NS, sl = k % NS;
+            if (h == 0 && col < n && ((live >> sl) & 1u)) {
+                out[(size_t)bl * out_blk + (size_t)sl * n_pad + col] = sum;
+                if (bl == 0) {
+                    const T a = sum < T(0) ? -sum : sum;
+                    if (a > best[sl]) { best[sl] = a; best_idx[sl] = col; }   // ascending columns: first maximum kept
+                }
+            }
         }
     }
     if (pmax_val == nullptr) return;
-    block_reduce_pair<T, true>(best, best_idx, sv, si);
-    if (threadIdx.x == 0) { pmax_val[blockIdx.x] = best; pmax_idx[blockIdx.x] = best_idx; }
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+        T bv = best[sl];
+        uint32_t bi = best_idx[sl];
+        block_reduce_pair<T, true>(bv, bi, sv, si);
+        if (threadIdx.x == 0 && ((live >> sl) & 1u)) {
+            pmax_val[(size_t)sl * pmax_stride + blockIdx.x] = bv;
+            pmax_idx[(size_t)sl * pmax_stride + blockIdx.x] = bi;
+        }
+        __syncthreads();
+    }
 }
 
 // ---- k_ro_mv: r = y - A x over the touched columns (mode 0), p = A d over the support (mode 1) ----------
@@ -260,8 +283,12 @@ void k_ro_sweep_t(const T* __restrict__ At, uint32_t ldm, uint32_t n, uint32_t n
 template <typename T>
 __global__ __launch_bounds__(kRoThreads)
 void k_ro_mv(const T* __restrict__ At, SlotDims L, const T* __restrict__ y, const T* __restrict__ coef,
-             const uint32_t* __restrict__ list2, int mode, T* __restrict__ out, const DevState* st, int gate)
+             const uint32_t* __restrict__ list2, int mode, T* __restrict__ out, const DevState* __restrict__ st, int gate)
 {
+    {   // slot = blockIdx.y
+        const size_t sl = blockIdx.y;
+        y += sl * L.ldm; coef += sl * L.n_pad; list2 += sl * 2 * L.kcap; out += sl * L.ldm; st += sl;
+    }
     if (st->done || (gate && st->ro_redo == 0u)) return;
     const uint32_t i = blockIdx.x * kRoThreads + threadIdx.x;
     if (i >= L.ldm) return;
@@ -335,6 +362,14 @@ void k_ro_init(const T* __restrict__ At, SlotDims L, const T* __restrict__ c,
     T* lds = reinterpret_cast<T*>(smem);
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
+    {   // slot = blockIdx.y
+        const size_t sl = blockIdx.y;
+        c += sl * L.n_pad; d += sl * L.n_pad; insup += sl * L.n_pad;
+        pmax_val += sl * L.pmax_stride; pmax_idx += sl * L.pmax_stride;
+        gam += sl * 2 * L.kcap; touched += sl * 2 * L.kcap; inv0 += sl * 2 * (size_t)L.kcap * L.kcap;
+        st += sl;
+        if (sl != 0) trace = nullptr;
+    }
     T c_inf;
     uint32_t idx;
     reduce_sweep_partials(pmax_val, pmax_idx, nb, c_inf, idx, sv, si);
@@ -368,13 +403,21 @@ void k_ro_init(const T* __restrict__ At, SlotDims L, const T* __restrict__ c,
 template <typename T>
 __global__ __launch_bounds__(kRoThreads)
 void k_ro_update(const T* __restrict__ At, SlotDims L, const uint32_t* __restrict__ gam2,
-                 T* inv0, T* inv1, T* u1, T* u2, T* sgn, const T* __restrict__ c, const T* __restrict__ q, T* __restrict__ d, T tol,
+                 T* inv0, T* inv1, T* u1, T* u2, T* sgn, const T* c, const T* q, T* d, T tol,
                  DevState* st)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* lds = reinterpret_cast<T*>(smem);
     __shared__ T s_d;
     __shared__ uint32_t s_flag;
+    {   // slot = blockIdx.y
+        const size_t sl = blockIdx.y;
+        gam2 += sl * 2 * L.kcap;
+        inv0 += sl * 2 * (size_t)L.kcap * L.kcap; inv1 += sl * 2 * (size_t)L.kcap * L.kcap;
+        u1 += sl * L.kcap; u2 += sl * L.kcap; sgn += sl * L.kcap;
+        c += sl * L.n_pad; q += sl * L.n_pad; d += sl * L.n_pad;
+        st += sl;
+    }
     if (st->done) return;
     const uint32_t ldm = L.ldm, kcap = L.kcap;
     const uint32_t cur = st->cur;
@@ -485,12 +528,20 @@ void k_ro_update(const T* __restrict__ At, SlotDims L, const uint32_t* __restric
 // ---- p = A d and q = A^T p are then formed again before the scan.
 template <typename T>
 __global__ __launch_bounds__(kUpdThreads)
-void k_ro_check(const T* __restrict__ c, const T* __restrict__ pmax_val, const uint32_t* __restrict__ pmax_idx, uint32_t nb,
-                T* __restrict__ d, const uint32_t* __restrict__ gam2, const T* inv0, const T* inv1, T* sgn, SlotDims L,
-                T tol, uint32_t max_iter, DevState* st, uint32_t* hflags, uint32_t* ndone, int force)
+void k_ro_check(const T* c, const T* pmax_val, const uint32_t* pmax_idx, uint32_t nb,
+                T* d, const uint32_t* gam2, const T* inv0, const T* inv1, T* sgn, SlotDims L,
+                T tol, uint32_t max_iter, DevState* st, uint32_t* hflags, uint32_t* ndone, uint32_t nslots, int force)
 {
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
+    {   // slot = blockIdx.y
+        const size_t sl = blockIdx.y;
+        c += sl * L.n_pad; d += sl * L.n_pad;
+        pmax_val += sl * L.pmax_stride; pmax_idx += sl * L.pmax_stride;
+        gam2 += sl * 2 * L.kcap; sgn += sl * L.kcap;
+        inv0 += sl * 2 * (size_t)L.kcap * L.kcap; inv1 += sl * 2 * (size_t)L.kcap * L.kcap;
+        st += sl;
+    }
     if (st->done) return;
     T c_inf;
     uint32_t imax;
@@ -502,7 +553,7 @@ void k_ro_check(const T* __restrict__ c, const T* __restrict__ pmax_val, const u
             st->c_inf = (double)c_inf;
             st->done_round = iter + 1u;
             st->done = 1;
-            signal_done(hflags, ndone, 1u, iter + 1u);
+            signal_done(hflags, ndone, nslots, iter + 1u);
         }
         return;
     }
@@ -535,65 +586,79 @@ void k_ro_check(const T* __restrict__ c, const T* __restrict__ pmax_val, const u
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------
+// most slots one pass carries: 8 right-hand sides (with 16 the sweep's LDS reads and sums cost more than a second pass)
+template <typename T> constexpr uint32_t ro_max_slots() { return 4u; }
+uint32_t ro_slots_max(const ss_hip_ctx* ctx, bool f64) { return ctx->ro_staged ? (f64 ? ro_max_slots<double>() : ro_max_slots<float>()) : 1u; }
+
+template <typename T, int NB, int NS>
+static hipError_t ro_sweep_go(const ss_hip_ctx* ctx, uint32_t grid, uint32_t ngroups, const T* v, size_t blk_stride, T* out, size_t out_blk,
+                              uint32_t n_pad, T* pmax_val, uint32_t* pmax_idx, uint32_t pmax_stride, const DevState* st, bool gate)
+{
+    static const bool attr_ok = [] {
+        const int lim = (int)(2 * ro_stage_lds_vecs<T>(NB * NS) * 16);
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ro_sweep_t<T, NB, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        return ok;
+    }();
+    if (!attr_ok) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_ro_sweep_t<T, NB, NS>), dim3(grid), dim3(kRoThreads), (size_t)2 * ro_stage_lds_vecs<T>(NB * NS) * 16, ctx->stream,
+                       static_cast<const T*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, ngroups, v, blk_stride, out, out_blk, n_pad,
+                       pmax_val, pmax_idx, pmax_stride, st, gate ? 1 : 0);
+    return hipGetLastError();
+}
+
+// [c, q](slot s) = A^T [r, p](slot s) for nslots slots of the workspace layout (nblk = 1: the first block only, from v to out)
 template <typename T>
-hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, size_t v_stride, T* out0, T* out1, T* pmax_val, uint32_t* pmax_idx,
-                           uint32_t* nblocks_out, const DevState* st, bool gate)
+hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, size_t blk_stride, T* out, size_t out_blk, uint32_t n_pad, int nblk,
+                           uint32_t nslots, T* pmax_val, uint32_t* pmax_idx, uint32_t pmax_stride, uint32_t* nblocks_out,
+                           const DevState* st, bool gate)
 {
     constexpr uint32_t CPB = kRoThreads / RoVec<T>::LPC;
     const uint32_t ngroups = ctx->n_pad / CPB;                        // n_pad is a multiple of 256
-    const int nrhs = out1 != nullptr ? 2 : 1;
-    // the right-hand sides sit in LDS: up to 64 KiB of them (two workgroups per CU), whole when they fit
     uint32_t grid = std::min<uint32_t>(ngroups, kMaxSweepBlocks);
     if (nblocks_out) *nblocks_out = grid;
-    if (ctx->ro_staged) {
-        static const bool staged_ok = [] {
-            const int lim = (int)(2 * ro_stage_lds_vecs<T>(2) * 16);
-            const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ro_sweep_t<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
-            const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ro_sweep_t<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
-            if (!(a && b)) (void)hipGetLastError();
-            return a && b;
-        }();
-        if (staged_ok) {
-            const size_t lds = (size_t)2 * ro_stage_lds_vecs<T>(nrhs) * 16;
-            if (nrhs == 2)
-                hipLaunchKernelGGL((k_ro_sweep_t<T, 2>), dim3(grid), dim3(kRoThreads), lds, ctx->stream, static_cast<const T*>(ctx->At),
-                                   ctx->ldm, (uint32_t)ctx->n, ngroups, v, v_stride, out0, out1, pmax_val, pmax_idx, st, gate ? 1 : 0);
-            else
-                hipLaunchKernelGGL((k_ro_sweep_t<T, 1>), dim3(grid), dim3(kRoThreads), lds, ctx->stream, static_cast<const T*>(ctx->At),
-                                   ctx->ldm, (uint32_t)ctx->n, ngroups, v, v_stride, out0, (T*)nullptr, pmax_val, pmax_idx, st, gate ? 1 : 0);
-            return hipGetLastError();
+    if (ctx->ro_staged || nslots > 1) {
+        hipError_t e = hipErrorInvalidValue;
+#define SS_RO_CASE(NBV, NSV) e = ro_sweep_go<T, NBV, NSV>(ctx, grid, ngroups, v, blk_stride, out, out_blk, n_pad, pmax_val, pmax_idx, pmax_stride, st, gate)
+        if (nblk == 1) {
+            if (nslots == 1) SS_RO_CASE(1, 1); else if (nslots == 2) SS_RO_CASE(1, 2); else if (nslots <= 4) SS_RO_CASE(1, 4);
+        } else {
+            if (nslots == 1) SS_RO_CASE(2, 1); else if (nslots == 2) SS_RO_CASE(2, 2); else if (nslots <= 4) SS_RO_CASE(2, 4);
         }
+#undef SS_RO_CASE
+        if (e == hipSuccess || nslots > 1) return e;
+        (void)hipGetLastError();                                      // (the LDS attribute was refused: the direct form)
     }
-    // direct form (option ro_staged = 0, or the LDS attribute was refused): the right-hand sides whole in LDS, up to 32 KiB
-    uint32_t mc = (uint32_t)(32768u / (sizeof(T) * nrhs));
+    // direct form (option ro_staged = 0, one slot): the right-hand sides whole in LDS, up to 32 KiB
+    uint32_t mc = (uint32_t)(32768u / (sizeof(T) * nblk));
     mc -= mc % kRowPad;
     if (mc > ctx->ldm) mc = ctx->ldm;
-    if (nrhs == 2)
+    if (nblk == 2)
         hipLaunchKernelGGL((k_ro_sweep<T, 2>), dim3(grid), dim3(kRoThreads), (size_t)2 * mc * sizeof(T), ctx->stream,
-                           static_cast<const T*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, ngroups, mc, v, v_stride, out0, out1,
+                           static_cast<const T*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, ngroups, mc, v, blk_stride, out, out + out_blk,
                            pmax_val, pmax_idx, st, gate ? 1 : 0);
     else
         hipLaunchKernelGGL((k_ro_sweep<T, 1>), dim3(grid), dim3(kRoThreads), (size_t)mc * sizeof(T), ctx->stream,
-                           static_cast<const T*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, ngroups, mc, v, v_stride, out0, (T*)nullptr,
+                           static_cast<const T*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, ngroups, mc, v, blk_stride, out, (T*)nullptr,
                            pmax_val, pmax_idx, st, gate ? 1 : 0);
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_ro_mv(const ss_hip_ctx* ctx, Workspace<T>& ws, int mode, bool gate)
+hipError_t launch_ro_mv(const ss_hip_ctx* ctx, Workspace<T>& ws, int mode, uint32_t nslots, bool gate)
 {
     const uint32_t blocks = (ctx->ldm + kRoThreads - 1) / kRoThreads;
     T* out = mode == 0 ? ws.rhs : ws.rhs + (size_t)ws.dims.b_pad * ctx->ldm;
-    hipLaunchKernelGGL((k_ro_mv<T>), dim3(blocks), dim3(kRoThreads), 0, ctx->stream, static_cast<const T*>(ctx->At), ws.dims,
+    hipLaunchKernelGGL((k_ro_mv<T>), dim3(blocks, nslots), dim3(kRoThreads), 0, ctx->stream, static_cast<const T*>(ctx->At), ws.dims,
                        (const T*)ws.y, mode == 0 ? (const T*)ws.x : (const T*)ws.d,
                        mode == 0 ? (const uint32_t*)ws.touched : (const uint32_t*)ws.gam, mode, out, (const DevState*)ws.st, gate ? 1 : 0);
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_ro_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol)
+hipError_t launch_ro_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t nparts, T tol)
 {
-    hipLaunchKernelGGL((k_ro_init<T>), dim3(1), dim3(kRoThreads), 2 * (size_t)kRoChunk * sizeof(T), ctx->stream,
+    hipLaunchKernelGGL((k_ro_init<T>), dim3(1, nslots), dim3(kRoThreads), 2 * (size_t)kRoChunk * sizeof(T), ctx->stream,
                        static_cast<const T*>(ctx->At), ws.dims, (const T*)ws.c, (const T*)ws.pmax_val,
                        (const uint32_t*)ws.pmax_idx, nparts, ws.d, ws.insup, ws.gam, ws.touched, ws.inv[0], tol,
                        ctx->strict_sign, ws.st, ws.trace);
@@ -601,31 +666,51 @@ hipError_t launch_ro_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t npar
 }
 
 template <typename T>
-hipError_t launch_ro_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol)
+hipError_t launch_ro_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, T tol)
 {
     uint32_t gb = round + 1;                                          // support size after this round is <= round + 1
     if (gb > ws.kcap) gb = ws.kcap;
-    hipLaunchKernelGGL((k_ro_update<T>), dim3(gb), dim3(kRoThreads), 2 * (size_t)kRoChunk * sizeof(T), ctx->stream,
+    hipLaunchKernelGGL((k_ro_update<T>), dim3(gb, nslots), dim3(kRoThreads), 2 * (size_t)kRoChunk * sizeof(T), ctx->stream,
                        static_cast<const T*>(ctx->At), ws.dims, (const uint32_t*)ws.gam, ws.inv[0], ws.inv[1], ws.u1, ws.u2,
                        ws.sgn, (const T*)ws.c, (const T*)ws.q, ws.d, tol, ws.st);
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_ro_check(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, uint32_t max_iter)
+hipError_t launch_ro_check(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t nparts, T tol, uint32_t max_iter)
 {
-    hipLaunchKernelGGL((k_ro_check<T>), dim3(1), dim3(kUpdThreads), 0, ctx->stream, (const T*)ws.c, (const T*)ws.pmax_val,
+    hipLaunchKernelGGL((k_ro_check<T>), dim3(1, nslots), dim3(kUpdThreads), 0, ctx->stream, (const T*)ws.c, (const T*)ws.pmax_val,
                        (const uint32_t*)ws.pmax_idx, nparts, ws.d, (const uint32_t*)ws.gam, (const T*)ws.inv[0], (const T*)ws.inv[1],
-                       ws.sgn, ws.dims, tol, max_iter, ws.st, ctx->dev_flags, ws.ndone, ctx->ro_force_resweep);
+                       ws.sgn, ws.dims, tol, max_iter, ws.st, ctx->dev_flags, ws.ndone, nslots, ctx->ro_force_resweep);
     return hipGetLastError();
 }
 
+// one round of the engine for the first nslots slots of the workspace (homotopy-cpu.cpp:236-272, one pass over A)
+template <typename T>
+hipError_t launch_ro_round(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts, T tol, uint32_t max_iter)
+{
+    const size_t rblk = (size_t)ws.dims.b_pad * ctx->ldm, cblk = (size_t)ws.dims.b_pad * ws.dims.n_pad;
+    hipError_t e;
+    if ((e = launch_ro_mv<T>(ctx, ws, 0, nslots, false)) != hipSuccess) return e;
+    if ((e = launch_ro_mv<T>(ctx, ws, 1, nslots, false)) != hipSuccess) return e;
+    if ((e = launch_ro_sweep<T>(ctx, ws.rhs, rblk, ws.c, cblk, ws.dims.n_pad, 2, nslots, ws.pmax_val, ws.pmax_idx, ws.dims.pmax_stride,
+                                nullptr, ws.st, false)) != hipSuccess) return e;
+    if ((e = launch_ro_check<T>(ctx, ws, nslots, nparts, tol, max_iter)) != hipSuccess) return e;
+    if ((e = launch_ro_mv<T>(ctx, ws, 1, nslots, true)) != hipSuccess) return e;
+    if ((e = launch_ro_sweep<T>(ctx, ws.rhs + rblk, rblk, ws.q, cblk, ws.dims.n_pad, 1, nslots, (T*)nullptr, (uint32_t*)nullptr, 0u,
+                                nullptr, ws.st, true)) != hipSuccess) return e;
+    if ((e = launch_scansel_plain<T>(ctx, ws, nslots, round, nparts, tol, max_iter)) != hipSuccess) return e;
+    return launch_ro_update<T>(ctx, ws, nslots, round, tol);
+}
+
 #define SS_RO_INST(T)                                                                                                          \
-    template hipError_t launch_ro_sweep<T>(const ss_hip_ctx*, const T*, size_t, T*, T*, T*, uint32_t*, uint32_t*, const DevState*, bool); \
-    template hipError_t launch_ro_mv<T>(const ss_hip_ctx*, Workspace<T>&, int, bool);                                         \
-    template hipError_t launch_ro_init<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, T);                                     \
-    template hipError_t launch_ro_update<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, T);                                   \
-    template hipError_t launch_ro_check<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, T, uint32_t);
+    template hipError_t launch_ro_sweep<T>(const ss_hip_ctx*, const T*, size_t, T*, size_t, uint32_t, int, uint32_t, T*, uint32_t*, uint32_t, \
+                                           uint32_t*, const DevState*, bool);                                                   \
+    template hipError_t launch_ro_mv<T>(const ss_hip_ctx*, Workspace<T>&, int, uint32_t, bool);                               \
+    template hipError_t launch_ro_init<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, uint32_t, T);                           \
+    template hipError_t launch_ro_update<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, uint32_t, T);                         \
+    template hipError_t launch_ro_check<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, uint32_t, T, uint32_t);                \
+    template hipError_t launch_ro_round<T>(const ss_hip_ctx*, Workspace<T>&, uint32_t, uint32_t, uint32_t, T, uint32_t);
 SS_RO_INST(float)
 SS_RO_INST(double)
 #undef SS_RO_INST

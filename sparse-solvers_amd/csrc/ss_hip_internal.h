@@ -302,6 +302,7 @@ struct ss_hip_ctx {
     int zero_on_removal = 0; // 0 = the reference's x + gamma*d residue on a leaving column (homotopy-cpu.cpp:252); 1 = exact 0 (opt-in)
     int tie_guard = 0;       // 0 = the reference's strict t > 0 (homotopy-cpu.cpp:135,145,151); 1 = zero-length step on an exact tie (opt-in)
     int ro_staged = 1;        // option: 1 = the reference-order sweep stages the dictionary through LDS (coalesced loads), 0 = direct 16-byte loads
+    int ro_slots = 4;         // option: signals the reference-order engine runs in lock-step per pass over A (1..4)
     int ro_force_resweep = 0; // developer option: the reference-order engine treats every sign check as failed (the second sweep of an iteration always runs)
     int tie_rerun = 1;       // 1 = a solve whose scan met a tie stall (DevState::tie_stall) is re-run in the reference-order engine
     int profiling = 0;
@@ -366,19 +367,26 @@ hipError_t launch_iteration_tail(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32
                                  uint32_t nparts, T tol, uint32_t max_iter);
 // the scan + select + toggle + x update of one iteration on its own (reference-order engine)
 template <typename T>
-hipError_t launch_scansel_plain(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, uint32_t nparts, T tol, uint32_t max_iter);
+hipError_t launch_scansel_plain(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts, T tol, uint32_t max_iter);
 // ---- reference-order engine (reforder.hip): every reduction in the documented 8-partial order ------------
-// [out0, out1] = A^T [v, v + v_stride] (out1 == nullptr: one right-hand side); gate: only when DevState::ro_redo is raised
+// reference-order engine (reforder.hip), for the first nslots slots of the workspace layout.
+// launch_ro_sweep: block b of slot s is v + b * blk_stride + s * ldm -> out + b * out_blk + s * n_pad (nblk = 1 or 2 blocks);
+// gate: only slots whose DevState::ro_redo is raised
 template <typename T>
-hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, size_t v_stride, T* out0, T* out1, T* pmax_val, uint32_t* pmax_idx,
-                           uint32_t* nblocks_out, const DevState* st, bool gate = false);
-template <typename T> hipError_t launch_ro_mv(const ss_hip_ctx* ctx, Workspace<T>& ws, int mode, bool gate = false);   // 0: r = y - A x, 1: p = A d
-template <typename T> hipError_t launch_ro_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol);
+hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, size_t blk_stride, T* out, size_t out_blk, uint32_t n_pad, int nblk,
+                           uint32_t nslots, T* pmax_val, uint32_t* pmax_idx, uint32_t pmax_stride, uint32_t* nblocks_out,
+                           const DevState* st, bool gate);
+template <typename T> hipError_t launch_ro_mv(const ss_hip_ctx* ctx, Workspace<T>& ws, int mode, uint32_t nslots, bool gate);   // 0: r = y - A x, 1: p = A d
+template <typename T> hipError_t launch_ro_init(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t nparts, T tol);
 // inverse update, then the signs taken from c - gamma q and the direction built from them
-template <typename T> hipError_t launch_ro_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol);
+template <typename T> hipError_t launch_ro_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, T tol);
 // lambda and the while-test from the correlations just re-computed; the signs the direction was built from are checked
 // against them (a mismatch rebuilds the direction and raises DevState::ro_redo)
-template <typename T> hipError_t launch_ro_check(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nparts, T tol, uint32_t max_iter);
+template <typename T> hipError_t launch_ro_check(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t nparts, T tol, uint32_t max_iter);
+// one whole round: r, p, the fused sweep, the check (+ the gated second sweep), scan + toggle, inverse + direction
+template <typename T>
+hipError_t launch_ro_round(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts, T tol, uint32_t max_iter);
+uint32_t ro_slots_max(const ss_hip_ctx* ctx, bool f64);      // signals one pass of the engine can carry (1 without the LDS-staged sweep)
 // list[0..count) = 128-row tiles that still hold a running signal, list[rows/128] = count
 hipError_t launch_tile_list(const ss_hip_ctx* ctx, const DevState* st, uint32_t nslots, uint32_t rows,
                             uint32_t* list);

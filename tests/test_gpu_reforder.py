@@ -150,6 +150,49 @@ def test_one_pass_schedule_and_the_second_sweep(sship, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lockstep_slots_bitwise(sship, dtype):
+    """Batches in engine 3 run in lock-step, up to 4 signals per pass over A (k_ro_sweep_t<NB, NS>): every
+    signal's words are those of its own solve — the oracle's — whatever the others in its group do (different
+    sparsities: they finish in different rounds; a group of one at the end), dense output and compact records alike."""
+    import sharding
+    m, n = 128, 1000
+    B = 11
+    rng = np.random.default_rng(77)
+    A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(dtype)
+    Y = np.zeros((B, m), dtype)
+    ks = [3, 12, 7, 1, 16, 9, 5, 14, 2, 11, 6]
+    for b in range(B):
+        x0 = np.zeros(n)
+        x0[rng.choice(n, ks[b], replace=False)] = (1 + np.abs(rng.standard_normal(ks[b]))) * rng.choice([-1.0, 1.0], ks[b])
+        Y[b] = (A.astype(np.float64) @ x0).astype(dtype)
+    Y[3] *= 0                                                # a zero signal: ends at the first pick
+    tol = 1e-3 if dtype == np.float32 else 1e-9
+    want = [oracle.homotopy(A, Y[b], tol, 64) for b in range(B)]
+    with sship.Homotopy(A) as h:
+        h.set_option("engine", 3)
+        for slots in (4, 3, 1):
+            h.set_option("ro_slots", slots)
+            X, it, err = h.solve_batch(Y, tol, 64)
+            for b in range(B):
+                xo, ito, eo = want[b][:3]
+                assert it[b] == ito and err[b] == eo, (slots, b, it[b], ito)
+                assert np.array_equal(X[b], xo), (slots, b)
+        h.set_option("ro_slots", 4)
+        rec = h.solve_batch_compact(Y, tol, 64, kmax=80)
+        recs = sharding.unpack_records(rec, 80, dtype)
+        for b in range(B):
+            xo, ito, eo = want[b][:3]
+            xr = np.zeros(n, dtype)
+            xr[recs[b]["idx"]] = recs[b]["val"]
+            assert recs[b]["iter"] == ito and recs[b]["err"] == eo and np.array_equal(xr, xo), b
+        # and with the second sweep forced in every iteration of every slot
+        h.set_option("ro_force_resweep", 1)
+        X, it, err = h.solve_batch(Y, tol, 64)
+        for b in range(B):
+            assert it[b] == want[b][1] and np.array_equal(X[b], want[b][0]), ("forced", b)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_exact_tie_bitwise_and_rerun(sship, dtype):
     """A = I, y = e_0 + e_1 + e_5 / 2: column 1 attains lambda exactly after column 0 entered, its candidate is
     t = 0 and the strict t > 0 of the reference skips it for good.  Engine 3 follows the oracle word for word;

@@ -29,3 +29,25 @@ with sship.Homotopy(A) as h:
             out.append(dict(staged=staged, sweep1_ms=ms, frac=M * N * 4 / ms / 1e6 / 8000, solve_ms=dt * 1e3, iters=int(it), same_bits=bool(torch.equal(xs, ref))))
             print(out[-1], flush=True)
 json.dump(out, open("gpurun_out/probe_ro.json", "w"))
+
+# lock-step slots: 8 signals in engine 3, 1 / 2 / 4 per pass over A
+rng = np.random.default_rng(9)
+Ys = []
+for b in range(8):
+    x0 = np.zeros(N, np.float32); sup = rng.choice(N, K, replace=False); x0[sup] = 1 + np.abs(rng.standard_normal(K))
+    Ys.append((A @ torch.from_numpy(x0).to(dev)))
+Y8 = torch.stack(Ys).contiguous()
+X8 = torch.zeros((8, N), device=dev)
+res = []
+with sship.Homotopy(A) as h:
+    h.set_option("engine", 3)
+    ref8 = None
+    for slots in (1, 2, 4):
+        h.set_option("ro_slots", slots)
+        h.solve_batch(Y8, 1e-3, 256, out=X8); torch.cuda.synchronize()
+        t = time.perf_counter(); _, it, _ = h.solve_batch(Y8, 1e-3, 256, out=X8); torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        if ref8 is None: ref8 = X8.clone()
+        res.append(dict(slots=slots, ms_for_8=dt * 1e3, ms_per_signal=dt * 1e3 / 8, iters=[int(v) for v in it], same_bits=bool(torch.equal(X8, ref8))))
+        print(res[-1], flush=True)
+json.dump(dict(single=out, slots=res), open("gpurun_out/probe_ro.json", "w"))
