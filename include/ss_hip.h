@@ -334,12 +334,19 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    is below 2^-14 (fp32) / 2^-42 (fp64) * ||A^T y||_inf, too tight for Gram-form
  *                    correlations: such a solve runs as 0; 2 = lookahead engine unconditionally;
  *                    0 = one fused 2-RHS sweep per iteration (residual form);
- *                    3 = reference-order engine (csrc/reforder.hip): the reference's iteration statement for statement
- *                    — c = A^T(y - A x) re-computed before the direction is formed, two passes over A per iteration —
+ *                    3 = reference-order engine (csrc/reforder.hip): the reference's values statement for statement
+ *                    — c = A^T(y - A x) re-computed, the direction formed from the signs of THAT c —
  *                    with every reduction in ONE documented order (8 partial sums, term r to partial r & 7, combined
  *                    ((0+1)+(2+3))+((4+5)+(6+7)), products and sums separately rounded): the path is reproducible bit
- *                    for bit by any implementation that states the same order.  Slower (2 x 2 GiB per iteration at
- *                    8192 x 65536); the arbiter of "tie_rerun".
+ *                    for bit by any implementation that states the same order.  One pass over A per iteration (2 GiB
+ *                    at 8192 x 65536, 0.84 of the HBM peak); batches run up to 4 signals per pass; the arbiter of
+ *                    "tie_rerun".
+ *   "ro_slots"       1..4 (default 4): signals the reference-order engine runs in lock-step per pass over A (batches in
+ *                    engine 3, a batch's tie re-runs); every signal's words are those of its own solve
+ *   "ro_staged"      1 (default) = its sweep stages the dictionary through LDS (coalesced loads); 0 = direct 16-byte
+ *                    loads (one signal per pass; the same bits at 0.35 of the HBM peak): A/B aid
+ *   "ro_force_resweep" developer aid: 1 = every iteration of engine 3 takes its second sweep (the check of the
+ *                    speculated signs is treated as failed): a schedule, not arithmetic — the same bits
  *   "la_fused"       form of the lookahead engine's iterations: 3 (default, fp32) = speculative resident form:
  *                    one workgroup iterates on a 256-column subset and every breakpoint is re-derived over
  *                    all columns, bit for bit, before anything is committed; 2 = one resident launch on all
