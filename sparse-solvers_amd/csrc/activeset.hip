@@ -1889,31 +1889,36 @@ __global__ __launch_bounds__(kSmallThreads)
 void k_la_reset(T* __restrict__ x, T* __restrict__ d, uint8_t* __restrict__ insup, int32_t* __restrict__ slot_of,
                 uint32_t n_pad, uint32_t* __restrict__ la_sync, uint32_t sync_head_words, uint32_t sync_words,
                 uint32_t* __restrict__ st_words, uint32_t st_nwords, uint32_t* __restrict__ ndone,
-                const T* __restrict__ y, T* __restrict__ rhs, uint32_t ldm)
+                T* __restrict__ y, T* __restrict__ rhs, uint32_t ldm, const T* __restrict__ y_user, long long incy, uint32_t m)
 {
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     for (uint32_t i = gtid; i < n_pad; i += gsz) {
         x[i] = T(0); d[i] = T(0); insup[i] = 0;
         if (slot_of != nullptr) slot_of[i] = -1;
     }
-    for (uint32_t i = gtid; i < ldm; i += gsz) rhs[i] = y[i];
+    if (y_user != nullptr) {
+        // the caller's signal is on the device: taken from there (no copy command in front of this launch)
+        for (uint32_t i = gtid; i < ldm; i += gsz) { const T v = i < m ? y_user[(long long)i * incy] : T(0); y[i] = v; rhs[i] = v; }
+    } else {
+        for (uint32_t i = gtid; i < ldm; i += gsz) rhs[i] = y[i];
+    }
     for (uint32_t i = gtid; i < sync_words; i += gsz) la_sync[i] = i < sync_head_words ? 0u : 0xffffffffu;
     for (uint32_t i = gtid; i < st_nwords; i += gsz) st_words[i] = 0u;
     if (gtid == 0) *ndone = 0u;
 }
 
 template <typename T>
-hipError_t launch_la_reset(const ss_hip_ctx* ctx, Workspace<T>& ws, bool clear_slots)
+hipError_t launch_la_reset(const ss_hip_ctx* ctx, Workspace<T>& ws, bool clear_slots, const T* y_user, ptrdiff_t incy)
 {
     const uint32_t grid = std::min<uint32_t>((ctx->n_pad + kSmallThreads - 1) / kSmallThreads, 256u);
     hipLaunchKernelGGL((k_la_reset<T>), dim3(grid), dim3(kSmallThreads), 0, ctx->stream, ws.x, ws.d, ws.insup,
                        clear_slots ? ws.slot_of : (int32_t*)nullptr, ctx->n_pad, reinterpret_cast<uint32_t*>(ws.la_sync),
                        (uint32_t)(sizeof(LaSync) / 4), (uint32_t)(kLaSyncBytes / 4), reinterpret_cast<uint32_t*>(ws.st),
-                       (uint32_t)(sizeof(DevState) / 4), ws.ndone, (const T*)ws.y, ws.rhs, ctx->ldm);
+                       (uint32_t)(sizeof(DevState) / 4), ws.ndone, ws.y, ws.rhs, ctx->ldm, y_user, (long long)incy, (uint32_t)ctx->m);
     return hipGetLastError();
 }
-template hipError_t launch_la_reset<float>(const ss_hip_ctx*, Workspace<float>&, bool);
-template hipError_t launch_la_reset<double>(const ss_hip_ctx*, Workspace<double>&, bool);
+template hipError_t launch_la_reset<float>(const ss_hip_ctx*, Workspace<float>&, bool, const float*, ptrdiff_t);
+template hipError_t launch_la_reset<double>(const ss_hip_ctx*, Workspace<double>&, bool, const double*, ptrdiff_t);
 
 template <typename T>
 hipError_t launch_la_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol)

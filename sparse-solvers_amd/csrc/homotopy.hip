@@ -852,7 +852,10 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         ctx->host_flags[3] = 0;
         ctx->host_flags[4] = 0;
         if (prof) HIPCHK(hipEventRecord(ctx->ev_solve0, st));
-        copy_in<T>(ctx, ws.y, y, incy, m);
+        // (lookahead engine with the signal on the device: k_la_reset reads it from the caller's buffer — no copy command)
+        const bool y_direct = !omp && !force_ro && ctx->engine != 3 && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual &&
+                              is_device_pointer(y);
+        if (!y_direct) copy_in<T>(ctx, ws.y, y, incy, m);
         // reference-order engine (reforder.hip; option engine = 3, and the arbiter of tie stalls): the reference's
         // iteration with every reduction in the documented 8-partial order, two passes over A per iteration
         const bool ro = !omp && (force_ro || ctx->engine == 3);
@@ -931,7 +934,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         } else if (la) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             enter_full_gram();
-            HIPCHK(launch_la_reset<T>(ctx, ws, !ws.gram_is_full));     // x, d, flags, slot map, exchange area, DevState, r = y
+            HIPCHK(launch_la_reset<T>(ctx, ws, !ws.gram_is_full, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, slot map, exchange area, DevState, r = y
             uint32_t nb1 = 0;
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));

@@ -402,7 +402,7 @@ template <typename T>
 hipError_t launch_la_update(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t round, T tol);
 // one launch for everything a lookahead solve clears before its first sweep (and r = y)
 template <typename T>
-hipError_t launch_la_reset(const ss_hip_ctx* ctx, Workspace<T>& ws, bool clear_slots);
+hipError_t launch_la_reset(const ss_hip_ctx* ctx, Workspace<T>& ws, bool clear_slots, const T* y_user = nullptr, ptrdiff_t incy = 1);   // y_user: the caller's signal, if it is on the device (else ws.y holds it)
 template <typename T>
 hipError_t launch_la_cq(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t* nparts_out);
 // fused iteration of the lookahead engine (c, q from the cache; scan; select; update)
