@@ -491,7 +491,15 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         h.solve_batch_compact(Yb[:8].contiguous(), TOL, MAX_ITER, kmax=KMAX_RECORD, out=rec[:8])   # workspace of a small batch
         torch.cuda.synchronize()
         runs = []
-        for label in ("first batch (allocates the batch workspace, forms G = A^T A)", "next batch (G kept)", "next batch, profiled"):
+        keep_subset = h.get_option("batch_subset")
+        checked = None
+        for label in ("first batch (allocates the batch workspace, forms G = A^T A)", "next batch (G kept)", "next batch, profiled",
+                      "lock-step form of the same batch (option batch_subset = 0), profiled"):
+            lockstep = label.startswith("lock-step")
+            if lockstep:
+                # (the records of the default form are checked before the lock-step run overwrites them)
+                checked = check_records(rec.cpu().numpy(), supb, coefb, MAX_ITER)
+                h.set_option("batch_subset", 0)
             h.reset_stats()
             h.set_profiling(label.endswith("profiled"))
             tb = time.perf_counter()
@@ -501,9 +509,16 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             stb = h.stats()
             runs.append({"which": label, "signals_per_s": Bx / dtb, "seconds": dtb, "rounds": int(stb["batch_rounds"]),
                          "gram_matrix_built": int(stb["gram_full_builds"]),
-                         "gram_build_ms": stb["gram_build_ms"], "gram_alloc_ms": stb["gram_alloc_ms"]})
+                         "gram_build_ms": stb["gram_build_ms"], "gram_alloc_ms": stb["gram_alloc_ms"],
+                         "subset_form": {"signals_accepted": int(stb["subset_signals"]), "signals_redone_in_lockstep": int(stb["subset_redone"]),
+                                         "select_and_solve_ms": stb["sub_solve_ms"], "check_over_all_columns_ms": stb["sub_verify_ms"]},
+                         "tie_reruns": int(stb["tie_reruns"])})
+            if label == "next batch, profiled":
+                st_sub = stb
+        h.set_option("batch_subset", keep_subset)
         h.set_profiling(False)
-        okb, stuckb, cerrb, itb = check_records(rec.cpu().numpy(), supb, coefb, MAX_ITER)
+        okb, stuckb, cerrb, itb = checked
+        okl, stuckl, cerrl, itl_ = check_records(rec.cpu().numpy(), supb, coefb, MAX_ITER)
         n_pad = (N + 255) // 256 * 256
         g_ms = runs[0]["gram_build_ms"]
         t128 = n_pad // 128
@@ -511,13 +526,17 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         gflops_exec = h.get_option("gram_symmetric") and 2.0 * M * 128 * 128 * (t128 * (t128 + 1) // 2) or gflops_full
         cq_gbs = stb["cq_bytes"] / (stb["cq_ms"] * 1e-3) / 1e9 if stb["cq_ms"] > 0 else 0.0
         batched = {
-            "workload": "configs[2]: %d signals sharing A (k=64, tol 1e-3, max_iter 256), lock-step, Gram form: correlations "
-                        "from rows of G = A^T A (formed once on the MFMA units, kept in the context), compact records "
+            "workload": "configs[2]: %d signals sharing A (k=64, tol 1e-3, max_iter 256), Gram form on G = A^T A (formed once on the MFMA "
+                        "units, kept in the context), SUBSET form (csrc/subbatch.hip): every signal solved by one workgroup on the 448 "
+                        "columns with the largest |A^T y|, every breakpoint then checked against all columns (16.8 MB of G per signal "
+                        "instead of 545); signals the form does not vouch for are solved again in the lock-step form; compact records "
                         "{K, iter, err, idx[96], val[96]}" % Bx,
             "signals": Bx, "signals_per_s": runs[1]["signals_per_s"],
             "signals_per_s_first_batch_incl_G": runs[0]["signals_per_s"], "runs": runs,
             "support_exact": okb, "ran_to_max_iter": stuckb, "max_rel_coef_err": cerrb, "iterations_max": int(itb.max()),
-            "tie_reruns_last_batch": int(stb["tie_reruns"]),
+            "tie_reruns_last_batch": int(st_sub["tie_reruns"]),
+            "lockstep_form": {"signals_per_s": runs[3]["signals_per_s"], "support_exact": okl, "ran_to_max_iter": stuckl,
+                              "max_rel_coef_err": cerrl},
             "roofline_gram_build": {
                 "bound": "mfma", "kernel": "k_gemm_tn_f32: G = A^T A (v_mfma_f32_32x32x2_f32, 128x128x32 tiles%s)"
                                            % (", tiles on and above the diagonal + mirrored store" if h.get_option("gram_symmetric") else ""),

@@ -257,6 +257,12 @@ typedef struct ss_hip_stats {
                                       (homotopy-cpu.cpp:143-153) skips it for good, and which rounding hits that is luck                 */
     uint64_t ro_resweeps;          /* reference-order engine (engine 3): iterations whose direction had to be rebuilt from the signs of
                                       the re-computed correlations, i.e. that took a second pass over A (otherwise one per iteration)   */
+    uint64_t subset_signals;       /* batched Gram form, subset form (csrc/subbatch.hip): signals solved by one workgroup on the 448 columns
+                                      with the largest |A^T y| and confirmed against all columns                                        */
+    uint64_t subset_redone;        /* ... signals that form declined (left its common path) or whose check failed: solved again in the
+                                      lock-step Gram form                                                                              */
+    double   sub_solve_ms;         /* profiling on: HIP-event time of the form's selection + per-signal solves                            */
+    double   sub_verify_ms;        /* ... and of its check over all columns                                                              */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------

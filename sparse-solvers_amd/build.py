@@ -44,6 +44,7 @@ HIP_UNITS = [
     ("reforder.hip", ["-ffp-contract=off"]),
     # column-sharded single-signal solve: replicated active-set arithmetic (separately rounded like activeset.hip)
     ("colshard.hip", ["-ffp-contract=off"]),
+    ("subbatch.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
 ]
 
 

@@ -1455,7 +1455,7 @@ int solve_batch_ro(ss_hip_ctx* ctx, const T* Y, const size_t* sig, size_t count,
 int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy,
                          float tol, uint32_t max_iter, float* X, ptrdiff_t x_stride, ptrdiff_t incx,
                          uint32_t* iter_out, double* err_out, char* err, size_t errlen, int form = 0,
-                         void* rec_out = nullptr, uint32_t kmax = 0)
+                         void* rec_out = nullptr, uint32_t kmax = 0, bool no_subset = false)
 {
     // form: 0 = two GEMMs per round (residual form), 1 = Gram form on the full G = A^T A, 2 = column form: Gram form
     // on a cache of the entering columns' Gram columns, formed round by round (mid-size batches, no G)
@@ -1476,6 +1476,7 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
         hipStream_t st = ctx->stream;
         std::vector<DevState> hs;
         std::vector<size_t> all_ties;                        // signals whose scan met a tie stall, over all chunks
+        std::vector<size_t> redo;                            // subset form: signals it declined or whose check failed
         for (size_t b0 = 0; b0 < B; b0 += chunk) {
             const uint32_t Bc = (uint32_t)std::min(chunk, B - b0);
             ensure_workspace<T>(ctx, Bc, kcap);
@@ -1564,12 +1565,37 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             const T* const Gsrc = cols_chunk ? bc.cache : ctx->gram_full;
             const uint32_t Gpitch = cols_chunk ? bc.pitch : ctx->gram_pitch;
 
+            // Subset form (subbatch.hip): with G at hand every signal is solved by one workgroup on the 448 columns with the
+            // largest |c0| and then checked against all columns — 16.8 MB of G per signal instead of 545
+            bool sub_chunk = gram_chunk && form == 1 && !no_subset && ctx->batch_subset && ctx->gram_full != nullptr && sub_form_usable(ctx);
+            if (sub_chunk) {
+                const size_t need = sub_buffer_bytes(Bc);
+                if (ctx->sub_buf_bytes < need) {
+                    if (ctx->sub_buf) HIPCHK(hipFree(ctx->sub_buf));
+                    ctx->sub_buf = nullptr;
+                    ctx->sub_buf_bytes = 0;
+                    if (hipMalloc(&ctx->sub_buf, need) != hipSuccess) { (void)hipGetLastError(); ctx->sub_buf = nullptr; sub_chunk = false; }
+                    else ctx->sub_buf_bytes = need;
+                }
+            }
             const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
             volatile uint32_t* hf = ctx->host_flags;
             const uint64_t last_round = (uint64_t)max_iter + 1;
             uint64_t rounds_run = 0;
             size_t ncq = 0;                                  // timed k_la_cq launches of this chunk (profiling on)
-            for (uint64_t round = 1; round <= last_round; ++round) {
+            if (sub_chunk) {
+                const bool timed = ctx->profiling != 0;
+                hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+                if (timed) { e0 = prof_event(ctx, 0); e1 = prof_event(ctx, 1); e2 = prof_event(ctx, 2); }
+                HIPCHK(launch_sub_form(ctx, ws, Bc, ctx->c0_batch, tol, max_iter, e0, e1, e2));
+                if (timed) {
+                    HIPCHK(hipEventSynchronize(e2));
+                    float ms = 0.f;
+                    HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ctx->stats.sub_solve_ms += ms;
+                    HIPCHK(hipEventElapsedTime(&ms, e1, e2)); ctx->stats.sub_verify_ms += ms;
+                }
+            }
+            for (uint64_t round = 1; round <= last_round && !sub_chunk; ++round) {
                 if (round > L) {
                     const uint32_t need = (uint32_t)(round - L);
                     uint32_t spins = 0;
@@ -1639,8 +1665,17 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 }
             }
             std::vector<uint32_t> ties;                      // slots whose scan met a tie stall (DevState::tie_stall)
+            uint32_t n_redo_chunk = 0;
             for (uint32_t b = 0; b < Bc; ++b) {
                 if (!hs[b].done) { set_err(err, errlen, "solve_batch: internal error, a signal did not terminate"); return SS_HIP_ERUNTIME; }
+                if (hs[b].status == kStatusSubsetDecline || hs[b].status == kStatusSubsetFail) {
+                    if (std::getenv("SS_HIP_SUB_DEBUG"))
+                        std::fprintf(stderr, "[subset form] signal %zu: status %u after %u iterations, %u breakpoints logged, K = %u, lambda %g\n",
+                                     b0 + b, hs[b].status, hs[b].iter, hs[b].solo_nlog, hs[b].K, hs[b].c_inf);
+                    redo.push_back(b0 + b);                  // (nothing of it is reported: solved again in the lock-step form below)
+                    ++n_redo_chunk;
+                    continue;
+                }
                 if (ctx->tie_rerun && !ctx->tie_guard && (hs[b].status == kStatusTieRerun || (hs[b].status == 0 && hs[b].tie_stall != 0))) {
                     ties.push_back(b);
                     continue;
@@ -1654,7 +1689,8 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 if (err_out) err_out[b0 + b] = hs[b].c_inf;
                 ctx->stats.iterations += hs[b].iter;
             }
-            ctx->stats.solves += Bc - (uint32_t)ties.size();
+            ctx->stats.solves += Bc - (uint32_t)ties.size() - n_redo_chunk;
+            if (sub_chunk) { ctx->stats.subset_signals += Bc - n_redo_chunk; ctx->stats.subset_redone += n_redo_chunk; }
             ctx->stats.batch_rounds += rounds_run;
             if (ncq != 0) {
                 // rounds enqueued behind the end of the batch are no-ops (microseconds): only launches that
@@ -1680,6 +1716,31 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             // these signals are solved again in the reference-order engine — after the last chunk, all of them together
             // (up to 4 share every pass over A: solve_batch_ro).  (A handful per 4096 signals at 8192 x 65536.)
             for (uint32_t b : ties) all_ties.push_back(b0 + b);
+        }
+        if (!redo.empty()) {
+            // the signals the subset form did not vouch for, gathered and solved in the lock-step Gram form (their own ties
+            // are arbitrated inside that call), results scattered back
+            const size_t nr = redo.size(), rb = record_bytes(kmax, sizeof(T));
+            T* Yg = nullptr; T* Xg = nullptr; unsigned char* Rg = nullptr;
+            struct FreeTmp { T*& a; T*& b; unsigned char*& c; ~FreeTmp() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (c) (void)hipFree(c); } } free_tmp{ Yg, Xg, Rg };
+            HIPCHK(hipMalloc(&Yg, nr * m * sizeof(T)));
+            if (X) HIPCHK(hipMalloc(&Xg, nr * n * sizeof(T)));
+            if (rec_out) HIPCHK(hipMalloc(&Rg, nr * rb));
+            for (size_t r = 0; r < nr; ++r) copy_in<T>(ctx, Yg + r * m, Y + (ptrdiff_t)redo[r] * y_stride, incy, m);
+            HIPCHK(hipStreamSynchronize(st));
+            std::vector<uint32_t> it_r(nr, 0u);
+            std::vector<double> er_r(nr, 0.0);
+            const int rc = solve_batch_gemm_f32(ctx, Yg, nr, (ptrdiff_t)m, 1, tol, max_iter, Xg, (ptrdiff_t)n, 1, it_r.data(), er_r.data(), err, errlen,
+                                                form, Rg, kmax, true);
+            if (rc != SS_HIP_OK) return rc;
+            for (size_t r = 0; r < nr; ++r) {
+                const size_t g = redo[r];
+                if (X) copy_out<T>(ctx, X + (ptrdiff_t)g * x_stride, incx, Xg + r * n, n);
+                if (rec_out) HIPCHK(hipMemcpyAsync(static_cast<unsigned char*>(rec_out) + g * rb, Rg + r * rb, rb, hipMemcpyDefault, st));
+                if (iter_out) iter_out[g] = it_r[r];
+                if (err_out) err_out[g] = er_r[r];
+            }
+            HIPCHK(hipStreamSynchronize(st));
         }
         if (!all_ties.empty()) {
             ctx->stats.tie_reruns += all_ties.size();
@@ -2068,6 +2129,7 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     sship::colshard_destroy(ctx);
     if (ctx->gram_full) (void)hipFree(ctx->gram_full);
     if (ctx->c0_batch) (void)hipFree(ctx->c0_batch);
+    if (ctx->sub_buf) (void)hipFree(ctx->sub_buf);
     if (ctx->bcol_cache) (void)hipFree(ctx->bcol_cache);
     if (ctx->bcol_slot) (void)hipFree(ctx->bcol_slot);
     if (ctx->bcol_lists) (void)hipFree(ctx->bcol_lists);
@@ -2243,6 +2305,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "tie_rerun"))     { ctx->tie_rerun = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_force_resweep")) { ctx->ro_force_resweep = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_staged"))     { ctx->ro_staged = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_subset"))  { ctx->batch_subset = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_slots"))      { if (value < 1 || value > 4) return SS_HIP_EINVAL; ctx->ro_slots = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_fused_scan")) { ctx->batch_fused_scan = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_vec4"))       { ctx->cq_vec4 = value ? 1 : 0; return SS_HIP_OK; }
@@ -2323,6 +2386,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "tie_rerun"))     { *value = ctx->tie_rerun; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_force_resweep")) { *value = ctx->ro_force_resweep; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_staged"))     { *value = ctx->ro_staged; return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_subset"))  { *value = ctx->batch_subset; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_slots"))      { *value = ctx->ro_slots; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_fused_scan")) { *value = ctx->batch_fused_scan; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_vec4"))       { *value = ctx->cq_vec4; return SS_HIP_OK; }

@@ -29,6 +29,10 @@ constexpr uint32_t kStatusRetryPlain = 101;
 // DevState::status raised by a step-length scan that met a tie stall (DevState::tie_stall) when the host asked for an early
 // exit: the signal is re-run in the reference-order engine (never leaves the library).
 constexpr uint32_t kStatusTieRerun = 102;
+// subset form of the batched Gram form (subbatch.hip): columns per subset, positions, breakpoints a signal may log
+constexpr uint32_t kSbS = 448, kSbRows = 72, kSbLog = 80;
+constexpr uint32_t kStatusSubsetDecline = 110;      // left the form's common path: solved again in the lock-step form
+constexpr uint32_t kStatusSubsetFail = 111;         // a column outside the subset would have changed a breakpoint
 // Gram form is used while tolerance >= guard * ||A^T y||_inf: 2^-14 in fp32, 2^-42 in fp64 (eps x ~1000)
 constexpr double kGramGuard = 1.0 / 16384.0;
 constexpr double kGramGuard64 = 1.0 / 4398046511104.0;
@@ -244,6 +248,10 @@ struct ss_hip_ctx {
     float* gram_full = nullptr;
     uint32_t gram_pitch = 0;
     float* c0_batch = nullptr;
+    void* sub_buf = nullptr;          // subset form (subbatch.hip): subsets, first picks, breakpoint logs of a chunk
+    size_t sub_buf_bytes = 0;
+    int sub_attr_set = -1;
+    int batch_subset = 1;             // option: 1 = large Gram-form batches run in the subset form (one workgroup per signal + a check over all columns)
     size_t c0_batch_rows = 0;
     // column form of mid-size batches: cache of Gram columns, row tables, pass lists (grown on demand)
     float* bcol_cache = nullptr;
@@ -386,7 +394,12 @@ template <typename T> hipError_t launch_ro_check(const ss_hip_ctx* ctx, Workspac
 // one whole round: r, p, the fused sweep, the check (+ the gated second sweep), scan + toggle, inverse + direction
 template <typename T>
 hipError_t launch_ro_round(const ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, uint32_t round, uint32_t nparts, T tol, uint32_t max_iter);
-uint32_t ro_slots_max(const ss_hip_ctx* ctx, bool f64);      // signals one pass of the engine can carry (1 without the LDS-staged sweep)
+uint32_t ro_slots_max(const ss_hip_ctx* ctx, bool f64);
+// subset form of the batched Gram form (subbatch.hip): select + solve + verify for the first nslots slots; c0 = A^T y of every slot
+bool sub_form_usable(ss_hip_ctx* ctx);
+size_t sub_buffer_bytes(uint32_t nslots);
+hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
+                           hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr);      // signals one pass of the engine can carry (1 without the LDS-staged sweep)
 // list[0..count) = 128-row tiles that still hold a running signal, list[rows/128] = count
 hipError_t launch_tile_list(const ss_hip_ctx* ctx, const DevState* st, uint32_t nslots, uint32_t rows,
                             uint32_t* list);

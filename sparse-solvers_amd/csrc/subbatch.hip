@@ -1,0 +1,651 @@
+// subbatch.hip — the SUBSET form of the batched Gram form (fp32, G = A^T A resident): every signal of a batch is solved
+// by ONE workgroup on a subset of 448 columns, then checked against all n columns.
+//
+// The lock-step Gram form (activeset.hip: k_la_cqs) re-derives c = c0 - G_S^T x_S and q = G_S^T d_S of ALL n columns
+// in every round: K rows of G per signal and round, 545 MB per signal at 8192 x 65536 with k = 64 — 2.2 TB per 4096
+// signals, 0.43 s at 0.82 of the HBM peak.  But a round only needs those values to (a) take max |c| and (b) find the
+// smallest step-length candidate (find_max_gamma, /root/reference/src/solvers/homotopy-cpu.cpp:100-164), and both are
+// decided among a handful of columns.  So, per signal:
+//
+//   k_sub_select   the 448 columns with the largest |c0| (two-level radix select, ties by index: deterministic),
+//                  sorted by column; the first pick (ixamax of |c0|, homotopy-cpu.cpp:217-221) is among them;
+//   k_sub_solve    ONE workgroup runs the whole path on that subset: Gram rows restricted to the subset (gathered
+//                  from G as columns enter, 1.75 KiB each), the explicit inverse (online_inverse.h:183-293) and all
+//                  vectors in LDS; every breakpoint is logged (positions' coefficients x, d; lambda; step; pick);
+//   k_sub_verify   for every column OUTSIDE the subset and every logged breakpoint: c and q by the same chain of fmas
+//                  from the same rows of G, then the reference's predicates — |c| must not exceed lambda, no candidate
+//                  may beat the logged step (or tie it from the left).  One pass over the K rows of G serves all
+//                  breakpoints: 16.8 MB per signal instead of 545.
+//
+// (The last step of a path that ends by tolerance is the one place where the check allows a tie: there every column's
+// candidate equals the step within rounding, whichever column is inserted enters with x = 0 and the path ends in the
+// next round — k_sub_verify.)
+// A signal whose check fails, or that leaves the common path (a column leaves the support with a rounding residue in
+// reference mode, more than 72 columns ever entered, more than 80 breakpoints, no positive candidate, an emptied
+// support), is DECLINED: nothing of it is reported, the host solves it again in the lock-step form (homotopy.hip).
+// An exact tie (DevState::tie_stall) goes to the reference-order engine as in every other form.
+//
+// Arithmetic of this form (both kernels, bit for bit the same): positions 0, 1, 2, ... are given out in order of
+// entry and never re-used (a column that left keeps its position with coefficients 0; re-entering takes a new one);
+//   c_j = c0_j, then  c_j = fma(-x_p, G[col_p][j], c_j)  for p = 0 .. P-1;   q_j = 0, then  q_j = fma(d_p, G[col_p][j], q_j).
+// Everything else follows the lock-step kernels (k_scansel's predicates, select_toggle's update, sign dead zone).
+#include "ss_hip_internal.h"
+#include "ss_hip_device.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace sship {
+
+// (kSbS columns per subset = threads of k_sub_solve; kSbRows positions; kSbLog breakpoints: ss_hip_internal.h)
+constexpr uint32_t kSbInvPitch = kSbRows + 1;
+constexpr uint32_t kSelThreads = 512;
+constexpr uint32_t kSelBins = 2048;
+
+__device__ __forceinline__ uint32_t mag_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+// exclusive block scan of one value per thread (kSelThreads threads); total in *tot.  scratch: kSelThreads + 1 words
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* scratch, uint32_t* tot)
+{
+    const uint32_t t = threadIdx.x;
+    __syncthreads();
+    scratch[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < kSelThreads; off <<= 1) {
+        const uint32_t add = t >= off ? scratch[t - off] : 0u;
+        __syncthreads();
+        scratch[t] += add;
+        __syncthreads();
+    }
+    const uint32_t incl = scratch[t];
+    *tot = scratch[kSelThreads - 1];
+    return incl - v;
+}
+
+// ---- k_sub_select: the kSbS largest |c0| of every slot, sorted by column ------------------------------------------
+__global__ __launch_bounds__(kSelThreads)
+void k_sub_select(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ sub,
+                  uint32_t* __restrict__ first_pick, float* __restrict__ first_val)
+{
+    __shared__ uint32_t hist[kSelBins];
+    __shared__ uint32_t scr[kSelThreads + 1];
+    __shared__ float sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_bin, s_above;
+    const uint32_t slot = blockIdx.x, t = threadIdx.x;
+    c0 += (size_t)slot * n_pad;
+    sub += (size_t)slot * kSbS;
+    const uint32_t chunk = (n + kSelThreads - 1) / kSelThreads;
+    const uint32_t lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t want = n < kSbS ? n : kSbS;
+
+    // ixamax of |c0| (left-most)
+    {
+        float bv = -1.f;
+        uint32_t bi = 0xffffffffu;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const float a = fabsf(c0[i]);
+            if (better_max(a, i, bv, bi)) { bv = a; bi = i; }
+        }
+        block_reduce_pair<float, true>(bv, bi, sv, si);
+        if (t == 0) { first_pick[slot] = bi == 0xffffffffu ? 0u : bi; first_val[slot] = bv; }
+    }
+
+    // two levels of 11 bits of the magnitude: threshold key T (22 bits), `above` = #columns with a larger key
+    uint32_t prefix_key = 0, above = 0;
+    for (int level = 0; level < 2; ++level) {
+        for (uint32_t b = t; b < kSelBins; b += kSelThreads) hist[b] = 0u;
+        __syncthreads();
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t m = mag_bits(c0[i]);
+            if (level == 0) atomicAdd(&hist[m >> 20], 1u);
+            else if ((m >> 20) == prefix_key) atomicAdd(&hist[(m >> 9) & 0x7ffu], 1u);
+        }
+        __syncthreads();
+        // thread t owns bins (from the top) 4t .. 4t+3
+        uint32_t mine = 0;
+        for (uint32_t u = 0; u < 4; ++u) mine += hist[kSelBins - 1u - (4u * t + u)];
+        uint32_t tot;
+        const uint32_t before = block_excl_scan(mine, scr, &tot);     // columns in bins above mine
+        if (above + before < want && above + before + mine >= want) {
+            uint32_t acc = above + before;
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t b = kSelBins - 1u - (4u * t + u);
+                if (acc + hist[b] >= want) { s_bin = b; s_above = acc; break; }
+                acc += hist[b];
+            }
+        }
+        __syncthreads();
+        if (level == 0) prefix_key = s_bin; else prefix_key = (prefix_key << 11) | s_bin;
+        above = s_above;
+        __syncthreads();
+    }
+    const uint32_t T22 = prefix_key;                 // key = magnitude >> 9
+    const uint32_t need_eq = want - above;           // columns taken from the threshold key, left-most first
+
+    uint32_t n_sel = 0, n_eq = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t k = mag_bits(c0[i]) >> 9;
+        n_sel += k > T22 ? 1u : 0u;
+        n_eq += k == T22 ? 1u : 0u;
+    }
+    uint32_t tot_eq, tot_all;
+    const uint32_t eq_before = block_excl_scan(n_eq, scr, &tot_eq);
+    uint32_t take = 0;
+    if (eq_before < need_eq) take = need_eq - eq_before < n_eq ? need_eq - eq_before : n_eq;
+    uint32_t out = block_excl_scan(n_sel + take, scr, &tot_all);
+    uint32_t taken = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t k = mag_bits(c0[i]) >> 9;
+        bool s = k > T22;
+        if (k == T22 && taken < take) { s = true; ++taken; }
+        if (s && out < kSbS) sub[out++] = i;
+    }
+    __syncthreads();
+    for (uint32_t p = tot_all + t; p < kSbS; p += kSelThreads) sub[p] = 0xffffffffu;
+}
+
+// ---- k_sub_solve: the whole path of one signal on its subset -----------------------------------------------------
+struct SubLds {
+    float* Gc;         // [kSbRows][kSbS]  Gram rows of the positions, restricted to the subset
+    float* I;          // [kSbRows][kSbInvPitch] explicit inverse over the positions (dead rows / columns are zero)
+    float* xs;         // [kSbRows] x of the positions
+    float* ds;         // [kSbRows] direction
+    float* u1;         // [kSbRows]
+    float* u2;         // [kSbRows]
+    float* sg;         // [kSbRows]
+    uint32_t* pcol;    // [kSbRows] column of a position
+    uint32_t* psub;    // [kSbRows] its index in the subset
+    uint32_t* alive;   // [kSbRows] 1 while the position is in the support
+    uint32_t* sub;     // [kSbS]
+    float* cs;         // [kSbS] c of the subset columns (this round)
+    float* qs;         // [kSbS]
+};
+__host__ __device__ inline size_t sub_lds_bytes()
+{
+    return ((size_t)kSbRows * kSbS + (size_t)kSbRows * kSbInvPitch + 8 * (size_t)kSbRows + 3 * (size_t)kSbS) * 4;
+}
+
+
+__global__ __launch_bounds__(kSbS)
+void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __restrict__ c0_all, uint32_t n, uint32_t n_pad,
+                 const uint32_t* __restrict__ sub_all, const uint32_t* __restrict__ first_pick,
+                 float tol, uint32_t max_iter, int strict_sign, int zero_on_removal, int tie_guard, int tie_exit,
+                 uint32_t* __restrict__ log_hdr, uint32_t* __restrict__ log_pcol, float* __restrict__ log_X, float* __restrict__ log_D,
+                 float* __restrict__ x_all, uint32_t* __restrict__ gam2_all, uint32_t* __restrict__ touched2_all, uint32_t kcap,
+                 DevState* __restrict__ st_all, TraceEntry* trace, uint32_t trace_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_u[4];
+    __shared__ float s_f[2];
+    SubLds L;
+    {
+        float* p = reinterpret_cast<float*>(smem);
+        L.Gc = p; p += (size_t)kSbRows * kSbS;
+        L.I = p; p += (size_t)kSbRows * kSbInvPitch;
+        L.xs = p; p += kSbRows; L.ds = p; p += kSbRows; L.u1 = p; p += kSbRows; L.u2 = p; p += kSbRows; L.sg = p; p += kSbRows;
+        L.pcol = reinterpret_cast<uint32_t*>(p); p += kSbRows;
+        L.psub = reinterpret_cast<uint32_t*>(p); p += kSbRows;
+        L.alive = reinterpret_cast<uint32_t*>(p); p += kSbRows;
+        L.sub = reinterpret_cast<uint32_t*>(p); p += kSbS;
+        L.cs = p; p += kSbS; L.qs = p;
+    }
+    const uint32_t slot = blockIdx.x, j = threadIdx.x;
+    const float* c0 = c0_all + (size_t)slot * n_pad;
+    float* x_out = x_all + (size_t)slot * n_pad;
+    uint32_t* gam_out = gam2_all + (size_t)slot * 2 * kcap;
+    uint32_t* tch_out = touched2_all + (size_t)slot * 2 * kcap;
+    DevState* st = st_all + slot;
+    uint32_t* hdr = log_hdr + (size_t)slot * kSbLog * 8;
+    float* LX = log_X + (size_t)slot * kSbLog * kSbRows;
+    float* LD = log_D + (size_t)slot * kSbLog * kSbRows;
+    if (slot != 0) trace = nullptr;
+
+    const uint32_t mycol = sub_all[(size_t)slot * kSbS + j];
+    const bool valid = mycol < n;
+    L.sub[j] = mycol;
+    const float c0v = valid ? c0[mycol] : 0.f;
+    for (uint32_t e = j; e < kSbRows * kSbInvPitch; e += kSbS) L.I[e] = 0.f;
+    for (uint32_t p = 0; p < kSbRows; ++p) L.Gc[(size_t)p * kSbS + j] = 0.f;      // (rows not yet given out are read with zero coefficients)
+    if (j < kSbRows) { L.xs[j] = 0.f; L.ds[j] = 0.f; L.u1[j] = 0.f; L.u2[j] = 0.f; L.sg[j] = 0.f; L.pcol[j] = 0xffffffffu; L.psub[j] = 0u; L.alive[j] = 0u; }
+    const uint32_t idx0 = first_pick[slot];
+    if (j == 0) s_u[0] = 0xffffffffu;
+    __syncthreads();
+    if (valid && mycol == idx0) s_u[0] = j;
+    __syncthreads();
+    int32_t mypos = -1;                       // position of my column while it is in the support
+    uint32_t P = 0, K = 0;                    // positions given out, support size
+    uint32_t status = 0, iter = 0, nlog = 0;
+    float c_inf = 0.f, lambda_prev = 0.f, gamma_prev = 0.f, lambda0 = 0.f;
+    uint32_t just_removed = 0xffffffffu;
+    bool tie_any = false;
+
+    auto gather_row = [&](uint32_t p, uint32_t col) {       // Gc[p][.] = G[col][sub[.]]
+        L.Gc[(size_t)p * kSbS + j] = valid ? G[(size_t)col * gpitch + mycol] : 0.f;
+    };
+    auto direction = [&]() {                                 // ds = I * sg over the positions, one thread per row
+        if (j < P) {
+            float acc = 0.f;
+            for (uint32_t b = 0; b < P; ++b) acc = __builtin_fmaf(L.I[j * kSbInvPitch + b], L.sg[b], acc);
+            L.ds[j] = L.alive[j] ? acc : 0.f;
+        }
+    };
+
+    if (s_u[0] == 0xffffffffu) {
+        status = kStatusSubsetDecline;        // (cannot happen: the largest |c0| is in the subset)
+    } else {
+        // first pick (homotopy-cpu.cpp:217-229): inv = [1 / ||a||^2] through the norm, direction = inv * sign
+        const uint32_t sp0 = s_u[0];
+        gather_row(0, idx0);
+        __syncthreads();
+        if (j == 0) {
+            const float dot = L.Gc[sp0];
+            const float nrm = sqrtf(dot);
+            const float inv00 = 1.f / (nrm * nrm);
+            const float cc = c0[idx0];
+            const float seed = strict_sign ? cc : fabsf(cc);
+            L.I[0] = inv00;
+            L.sg[0] = sign_tol(seed, tol);
+            L.pcol[0] = idx0; L.psub[0] = sp0; L.alive[0] = 1u; L.xs[0] = 0.f;
+            if (trace != nullptr) { trace[0].idx = idx0; trace[0].added = 1; trace[0].gamma = 0.0; trace[0].c_inf = (double)fabsf(cc); }
+        }
+        P = 1; K = 1;
+        if (j == sp0) mypos = 0;
+        __syncthreads();
+        direction();
+        __syncthreads();
+        lambda0 = fabsf(c0[idx0]);
+
+        for (uint32_t round = 1;; ++round) {
+            // ---- c, q of my column: the chain over the positions -----------------------------------------------
+            float cv = c0v, qv = 0.f;
+            for (uint32_t p = 0; p < P; p += 4) {                     // (whole groups of 4: positions >= P carry x = d = 0 and zero rows)
+                const v4f x4 = *reinterpret_cast<const v4f*>(&L.xs[p]), d4 = *reinterpret_cast<const v4f*>(&L.ds[p]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = L.Gc[(size_t)(p + e) * kSbS + j];
+                    cv = __builtin_fmaf(-x4[e], g, cv);
+                    qv = __builtin_fmaf(d4[e], g, qv);
+                }
+            }
+            L.cs[j] = cv; L.qs[j] = qv;
+            float mx = valid ? fabsf(cv) : -1.f;
+            uint32_t mxi = mycol;
+            block_reduce_pair<float, true>(mx, mxi, sv, si);
+            c_inf = mx;
+            // ---- loop control (homotopy-cpu.cpp:236, 272) ---------------------------------------------------------
+            const bool stop = (round > 1 && !(c_inf > tol)) || round > max_iter;
+            if (nlog >= kSbLog) { status = kStatusSubsetDecline; break; }
+            if (j == 0) {
+                uint32_t* h = hdr + nlog * 8;
+                h[0] = P; h[1] = stop ? 0u : 1u; h[2] = 0xffffffffu; h[3] = 0u; h[4] = __float_as_uint(c_inf); h[5] = 0u;
+                h[6] = just_removed; h[7] = tie_band<float>(c_inf, lambda_prev, gamma_prev, lambda0) ? 1u : 0u;
+            }
+            if (j < kSbRows) { LX[(size_t)nlog * kSbRows + j] = j < P ? L.xs[j] : 0.f; LD[(size_t)nlog * kSbRows + j] = j < P ? L.ds[j] : 0.f; }
+            if (stop) { iter = round - 1; ++nlog; break; }
+            // ---- find_max_gamma's scan (homotopy-cpu.cpp:122-163) over the subset ---------------------------------------
+            const bool in_band = tie_band<float>(c_inf, lambda_prev, gamma_prev, lambda0);
+            float m = Lim<float>::max();
+            bool tie = false;
+            if (valid) {
+                if (mypos >= 0) {
+                    const float t = -L.xs[mypos] / L.ds[mypos];
+                    if (t > 0.f && t < m) m = t;
+                } else {
+                    const float dl = 1.f - qv, dr = 1.f + qv;
+                    if (dl != 0.f) {
+                        float t = (c_inf - cv) / dl;
+                        if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
+                        if (t == 0.f && mycol != just_removed && in_band) tie = true;
+                        if (t > 0.f && t < m) m = t;
+                    }
+                    if (dr != 0.f) {
+                        float t = (c_inf + cv) / dr;
+                        if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
+                        if (t == 0.f && mycol != just_removed && in_band) tie = true;
+                        if (t > 0.f && t < m) m = t;
+                    }
+                }
+            }
+            tie_any = __syncthreads_or(tie ? 1 : 0) != 0 || tie_any;
+            float g = m;
+            uint32_t idx = valid ? mycol : 0xffffffffu;
+            block_reduce_pair<float, false>(g, idx, sv, si);
+            if (tie_any && tie_exit) { status = kStatusTieRerun; iter = round - 1; ++nlog; break; }
+            if (!(g < Lim<float>::max())) { status = kStatusSubsetDecline; break; }     // (no positive candidate: the reference toggles column 0)
+            // whose column is it, and is it in the support?
+            if (j == 0) { s_u[1] = 0xffffffffu; s_u[2] = 0u; }
+            __syncthreads();
+            if (valid && mycol == idx) { s_u[1] = j; s_u[2] = mypos >= 0 ? 1u + (uint32_t)mypos : 0u; }
+            __syncthreads();
+            const uint32_t spi = s_u[1];
+            const bool added = s_u[2] == 0u;
+            const uint32_t rpos = added ? P : s_u[2] - 1u;
+            if (j == 0) { hdr[nlog * 8 + 2] = idx; hdr[nlog * 8 + 3] = added ? 1u : 0u; hdr[nlog * 8 + 5] = __float_as_uint(g); }
+            ++nlog;
+            if (trace != nullptr && j == 0 && round < trace_cap) {
+                trace[round].idx = idx; trace[round].added = added ? 1u : 0u; trace[round].gamma = (double)g; trace[round].c_inf = (double)c_inf;
+            }
+            const uint32_t K_new = added ? K + 1u : K - 1u;
+            if (K_new == 0u || K_new > kcap || (added && P >= kSbRows)) { status = kStatusSubsetDecline; break; }
+            // ---- x += gamma d over the old support (homotopy-cpu.cpp:252) -----------------------------------------------
+            if (j < P && L.alive[j]) {
+                const float xn = L.xs[j] + g * L.ds[j];
+                L.xs[j] = xn;
+            }
+            __syncthreads();
+            if (!added) {
+                // the column leaves: in reference mode it keeps its rounding residue (and stays in c through it): not this form's path
+                const float res = L.xs[rpos];
+                if (res != 0.f && !zero_on_removal) { status = kStatusSubsetDecline; break; }
+                __syncthreads();
+                // deflate (online_inverse.h:275-290): u3 = -I[.][r] / I[r][r];  I' = I + (-I[r][r] u3) u3^T; row / column r zero
+                const float dd = L.I[rpos * kSbInvPitch + rpos];
+                if (j < P) L.u2[j] = L.I[j * kSbInvPitch + rpos] * (-(1.f / dd));
+                if (j == 0) { L.xs[rpos] = 0.f; L.alive[rpos] = 0u; }
+                __syncthreads();
+                for (uint32_t e = j; e < P * P; e += kSbS) {
+                    const uint32_t a = e / P, b = e - a * P;
+                    const float v = (a == rpos || b == rpos) ? 0.f : L.I[a * kSbInvPitch + b] + (-dd * L.u2[a]) * L.u2[b];
+                    L.I[a * kSbInvPitch + b] = v;
+                }
+                if ((int32_t)rpos == mypos) mypos = -1;
+                just_removed = idx;
+                K = K_new;
+            } else {
+                // the column enters at position P: its Gram row, u1 = G[idx][support], the bordered inverse (online_inverse.h:209-248)
+                gather_row(P, idx);
+                if (j == 0) { L.pcol[P] = idx; L.psub[P] = spi; L.xs[P] = 0.f; }
+                __syncthreads();
+                if (j < P) L.u1[j] = L.alive[j] ? L.Gc[(size_t)P * kSbS + L.psub[j]] : 0.f;
+                __syncthreads();
+                if (j < P) {
+                    float acc = 0.f;
+                    for (uint32_t b = 0; b < P; ++b) acc = __builtin_fmaf(L.I[j * kSbInvPitch + b], L.u1[b], acc);
+                    L.u2[j] = acc;
+                }
+                __syncthreads();
+                if (j == 0) {
+                    float s = 0.f;
+                    for (uint32_t b = 0; b < P; ++b) s = __builtin_fmaf(L.u1[b], L.u2[b], s);
+                    s_f[0] = 1.f / (L.Gc[(size_t)P * kSbS + spi] - s);
+                }
+                __syncthreads();
+                const float dv = s_f[0];
+                const uint32_t Pn = P + 1u;
+                for (uint32_t e = j; e < Pn * Pn; e += kSbS) {
+                    const uint32_t a = e / Pn, b = e - a * Pn;
+                    float v;
+                    if (a == P && b == P) v = dv;
+                    else if (a == P) v = -dv * L.u2[b];
+                    else if (b == P) v = -dv * L.u2[a];
+                    else v = L.I[a * kSbInvPitch + b] + (dv * L.u2[a]) * L.u2[b];
+                    L.I[a * kSbInvPitch + b] = v;
+                }
+                if (j == 0) L.alive[P] = 1u;
+                if (j == spi) mypos = (int32_t)P;
+                P = Pn;
+                K = K_new;
+                just_removed = 0xffffffffu;
+            }
+            __syncthreads();
+            // ---- sign(c_Gamma) of the correlations after the step (c - gamma q), dead zone tol; direction (homotopy-cpu.cpp:257-267)
+            if (j < P) {
+                const uint32_t sp = L.psub[j];
+                const float cn = L.cs[sp] - g * L.qs[sp];
+                L.sg[j] = L.alive[j] ? sign_tol(cn, tol) : 0.f;
+            }
+            __syncthreads();
+            direction();
+            __syncthreads();
+            iter = round;
+            lambda_prev = c_inf;
+            gamma_prev = g;
+        }
+    }
+    __syncthreads();
+    // ---- hand-over: dense x, sorted support / touched lists, the state -----------------------------------------------
+    if (j < kSbRows) log_pcol[(size_t)slot * kSbRows + j] = j < P ? L.pcol[j] : 0xffffffffu;
+    if (status == 0u || status == kStatusTieRerun) {
+        // (a column that re-entered holds two positions: the later one counts, the earlier is dead with x = 0)
+        if (j < P) {
+            bool last = true;
+            for (uint32_t e = j + 1; e < P; ++e) last = last && L.pcol[e] != L.pcol[j];
+            L.u1[j] = last ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (j < P && L.u1[j] != 0.f) {
+            const uint32_t col = L.pcol[j];
+            uint32_t rs = 0, rt = 0;
+            for (uint32_t b = 0; b < P; ++b) {
+                if (L.u1[b] != 0.f && L.pcol[b] < col) { ++rt; if (L.alive[b]) ++rs; }
+            }
+            tch_out[rt] = col;
+            if (L.alive[j]) gam_out[rs] = col;
+            x_out[col] = L.xs[j];
+        }
+        if (j == 0) {
+            uint32_t nt = 0;
+            for (uint32_t a = 0; a < P; ++a) nt += L.u1[a] != 0.f ? 1u : 0u;
+            st->ntouched = nt;
+        }
+    }
+    if (j == 0) {
+        st->done = 1;
+        st->status = status;
+        st->iter = iter;
+        st->K = K;
+        st->cur = 0;
+        st->c_inf = (double)c_inf;
+        st->gamma = (double)gamma_prev;
+        st->tie_stall = tie_any ? 1u : 0u;
+        st->lambda0 = lambda0;
+        st->solo_nlog = nlog;                  // breakpoints logged (k_sub_verify)
+        st->need_sweep = 0;                    // (k_sub_verify raises it when a breakpoint does not hold)
+        st->done_round = iter + 1u;
+    }
+}
+
+// ---- k_sub_verify: every column outside the subset against every logged breakpoint -----------------------------
+// One workgroup = 512 columns of one slot, a thread TWO of them (j and j + 256): their Gram values g[p] = G[col_p][j] sit in
+// registers (2 x 72), the coefficient tables of the log are staged in LDS once per workgroup and every 16-byte read of
+// them feeds 16 fmas (4 positions x {c, q} x 2 columns).  (Measured on the way: coefficients through the scalar cache —
+// the 37-KiB tables of a slot thrash its 16 KiB — 150-160 ms per 4096 signals at 8192 x 65536; one column per thread
+// from LDS is bound by the LDS pipe, every read serving 8 fmas.)  The chain per (column, breakpoint) is k_sub_solve's,
+// term for term.  A candidate is only evaluated exactly (IEEE division, the reference's predicates) when a conservative
+// bound cannot rule it out.
+constexpr int kVsThreads = 256;
+constexpr uint32_t kVsCols = 2 * kVsThreads;     // columns a workgroup checks
+constexpr uint32_t kVsPitch = kSbRows;           // floats per breakpoint row in LDS
+__host__ __device__ inline size_t sub_verify_lds_bytes() { return (2 * (size_t)kSbLog * kVsPitch + (size_t)kSbLog * 8 + kSbRows) * 4; }
+
+// the reference's predicates for one (column, breakpoint): cv, qv by the chain; h = the breakpoint's header
+__device__ __forceinline__ void sub_check(float cv, float qv, uint32_t j, uint32_t k, uint32_t nlog, const uint32_t* sH, float tol,
+                                          int tie_guard, DevState* st, bool& fail, bool& tie)
+{
+    const uint32_t* h = sH + k * 8;
+    const float lam = __uint_as_float(h[4]);
+    const float ac = fabsf(cv);
+    if (!(h[1] & 1u)) {
+        // the round the path ended in: ||c||_inf is REPORTED (homotopy_report::solution_error) and, unless the budget ran
+        // out, was compared with the tolerance — a larger |c| out here must leave that comparison as it was, and counts
+        if (!(ac <= lam)) {
+            if (!(lam > tol) && !(ac <= tol)) fail = true;
+            else if (ac == ac) atomicMax(reinterpret_cast<unsigned long long*>(&st->c_inf), (unsigned long long)__double_as_longlong((double)ac));
+            else fail = true;
+        }
+        return;
+    }
+    if (!(ac <= lam)) fail = true;                             // the true max |c| is larger (or NaN): every candidate changes
+    const float gam = __uint_as_float(h[5]);
+    const float dl = 1.f - qv, dr = 1.f + qv;
+    const float nl = lam - cv, nr = lam + cv;
+    // safe: the candidate is certainly larger than the step taken (1e-4 covers every rounding in between)
+    const float bound = gam * 1.0001f;
+    const bool safe_l = dl > 0.f && nl > dl * bound;
+    const bool safe_r = dr > 0.f && nr > dr * bound;
+    if (safe_l && safe_r) return;
+    const uint32_t pick = h[2];
+    const bool in_band = h[7] != 0u;
+    const uint32_t jr = h[6];
+    float m = Lim<float>::max();
+    if (dl != 0.f) {
+        float t = nl / dl;
+        if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
+        if (t == 0.f && j != jr && in_band) tie = true;
+        if (t > 0.f && t < m) m = t;
+    }
+    if (dr != 0.f) {
+        float t = nr / dr;
+        if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
+        if (t == 0.f && j != jr && in_band) tie = true;
+        if (t > 0.f && t < m) m = t;
+    }
+    if (better_min(m, j, gam, pick)) {
+        // it would have been picked instead.  One exception: the LAST step of a path that ends by tolerance — there
+        // lambda - gamma ~ 0 and every column's candidate ties with the step within rounding; whichever is
+        // inserted enters with x = 0 and the next round ends the path with the same coefficients.  A candidate
+        // within 1e-5 of the step taken is such a tie, a smaller one a real entrant.
+        const bool last_step = k + 2u == nlog && !(sH[(k + 1u) * 8 + 1] & 1u) && !(__uint_as_float(sH[(k + 1u) * 8 + 4]) > tol);
+        if (!(last_step && m >= gam * 0.99999f)) fail = true;
+    }
+}
+
+__global__ __launch_bounds__(kVsThreads, 2)
+void k_sub_verify(const float* __restrict__ G, uint32_t gpitch, const float* __restrict__ c0_all, uint32_t n, uint32_t n_pad,
+                  const uint32_t* __restrict__ sub_all, const uint32_t* __restrict__ log_hdr, const uint32_t* __restrict__ log_pcol,
+                  const float* __restrict__ log_X, const float* __restrict__ log_D, int tie_guard, float tol, DevState* __restrict__ st_all)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_in[kVsCols / 32u];
+    float* sX = reinterpret_cast<float*>(smem);                       // [kSbLog][kVsPitch]
+    float* sD = sX + (size_t)kSbLog * kVsPitch;
+    uint32_t* sH = reinterpret_cast<uint32_t*>(sD + (size_t)kSbLog * kVsPitch);   // [kSbLog][8]
+    uint32_t* sP = sH + (size_t)kSbLog * 8;                          // [kSbRows] columns of the positions
+    const uint32_t slot = blockIdx.y;
+    DevState* st = st_all + slot;
+    if (st->status != 0u) return;
+    const uint32_t nlog = st->solo_nlog;
+    if (nlog == 0u) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * kVsCols;
+    {
+        const uint32_t* hdr = log_hdr + (size_t)slot * kSbLog * 8;
+        const v4f* LX4 = reinterpret_cast<const v4f*>(log_X + (size_t)slot * kSbLog * kSbRows);
+        const v4f* LD4 = reinterpret_cast<const v4f*>(log_D + (size_t)slot * kSbLog * kSbRows);
+        const uint32_t nv = nlog * kSbRows / 4u;                      // (16-byte pieces: rows are 288 bytes)
+        for (uint32_t e = tid; e < nv; e += kVsThreads) { reinterpret_cast<v4f*>(sX)[e] = LX4[e]; reinterpret_cast<v4f*>(sD)[e] = LD4[e]; }
+        for (uint32_t e = tid; e < nlog * 8; e += kVsThreads) sH[e] = hdr[e];
+        if (tid < kSbRows) sP[tid] = log_pcol[(size_t)slot * kSbRows + tid];
+        if (tid < kVsCols / 32u) s_in[tid] = 0u;
+    }
+    __syncthreads();
+    // which of this workgroup's columns are in the subset (k_sub_solve dealt with those)
+    {
+        const uint32_t* sub = sub_all + (size_t)slot * kSbS;
+        for (uint32_t e = tid; e < kSbS; e += kVsThreads) {
+            const uint32_t c = sub[e];
+            if (c >= base && c < base + kVsCols) atomicOr(&s_in[(c - base) >> 5], 1u << ((c - base) & 31u));
+        }
+    }
+    __syncthreads();
+    const uint32_t Pfin = sH[(nlog - 1u) * 8];
+    const uint32_t j0 = base + tid, j1 = j0 + kVsThreads;
+    const bool mine0 = j0 < n && !((s_in[tid >> 5] >> (tid & 31u)) & 1u);
+    const bool mine1 = j1 < n && !((s_in[(tid + kVsThreads) >> 5] >> (tid & 31u)) & 1u);
+    const size_t jc0 = j0 < n ? j0 : 0u, jc1 = j1 < n ? j1 : 0u;
+    float g0[kSbRows], g1[kSbRows];
+#pragma unroll
+    for (uint32_t p = 0; p < kSbRows; ++p) {
+        const float* row = G + (size_t)sP[p < Pfin ? p : 0u] * gpitch;
+        g0[p] = p < Pfin ? row[jc0] : 0.f;
+        g1[p] = p < Pfin ? row[jc1] : 0.f;
+    }
+    const float* c0 = c0_all + (size_t)slot * n_pad;
+    const float c00 = mine0 ? c0[j0] : 0.f, c01 = mine1 ? c0[j1] : 0.f;
+    bool fail = false, tie = false;
+    for (uint32_t k = 0; k < nlog; ++k) {
+        const uint32_t Pk = sH[k * 8];
+        const float* xk = sX + (size_t)k * kVsPitch;
+        const float* dk = sD + (size_t)k * kVsPitch;
+        float cv0 = c00, qv0 = 0.f, cv1 = c01, qv1 = 0.f;
+#pragma unroll
+        for (uint32_t p4 = 0; p4 < kSbRows; p4 += 4) {
+            if (p4 < Pk) {                                           // (uniform; positions >= Pk carry zero coefficients)
+                const v4f x4 = *reinterpret_cast<const v4f*>(xk + p4), d4 = *reinterpret_cast<const v4f*>(dk + p4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cv0 = __builtin_fmaf(-x4[e], g0[p4 + e], cv0);
+                    qv0 = __builtin_fmaf(d4[e], g0[p4 + e], qv0);
+                    cv1 = __builtin_fmaf(-x4[e], g1[p4 + e], cv1);
+                    qv1 = __builtin_fmaf(d4[e], g1[p4 + e], qv1);
+                }
+            }
+        }
+        if (mine0) sub_check(cv0, qv0, j0, k, nlog, sH, tol, tie_guard, st, fail, tie);
+        if (mine1) sub_check(cv1, qv1, j1, k, nlog, sH, tol, tie_guard, st, fail, tie);
+    }
+    if (fail) __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by k_sub_finish)
+    if (tie) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// verdicts of k_sub_verify into the status word (its workgroups read `status` while they run)
+__global__ void k_sub_finish(DevState* __restrict__ st_all, uint32_t nslots)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    DevState* st = st_all + s;
+    if (st->status == 0u && st->need_sweep != 0u) st->status = kStatusSubsetFail;
+    st->need_sweep = 0u;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+bool sub_form_usable(ss_hip_ctx* ctx)
+{
+    if (ctx->sub_attr_set < 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sub_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)sub_lds_bytes());
+        if (e != hipSuccess) (void)hipGetLastError();
+        ctx->sub_attr_set = e == hipSuccess ? 1 : 0;
+    }
+    return ctx->sub_attr_set == 1;
+}
+
+size_t sub_buffer_bytes(uint32_t nslots)
+{
+    // sub, first pick + value, log header, position columns, X, D
+    return (size_t)nslots * ((size_t)kSbS * 4 + 8 + (size_t)kSbLog * 8 * 4 + (size_t)kSbRows * 4 + 2 * (size_t)kSbLog * kSbRows * 4);
+}
+
+hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
+                           hipEvent_t e0, hipEvent_t e1, hipEvent_t e2)
+{
+    if (!sub_form_usable(ctx) || ctx->sub_buf == nullptr || ctx->gram_full == nullptr) return hipErrorInvalidConfiguration;
+    unsigned char* b = static_cast<unsigned char*>(ctx->sub_buf);
+    uint32_t* sub = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * kSbS * 4;
+    uint32_t* fpick = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * 4;
+    float* fval = reinterpret_cast<float*>(b); b += (size_t)nslots * 4;
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * kSbLog * 8 * 4;
+    uint32_t* pcol = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * kSbRows * 4;
+    float* LX = reinterpret_cast<float*>(b); b += (size_t)nslots * kSbLog * kSbRows * 4;
+    float* LD = reinterpret_cast<float*>(b);
+    const uint32_t n = (uint32_t)ctx->n;
+    hipStream_t s = ctx->stream;
+    if (e0) (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, s, c0, n, ctx->n_pad, sub, fpick, fval);
+    hipLaunchKernelGGL(k_sub_solve, dim3(nslots), dim3(kSbS), sub_lds_bytes(), s, (const float*)ctx->gram_full, ctx->gram_pitch, c0, n,
+                       ctx->n_pad, (const uint32_t*)sub, (const uint32_t*)fpick, tol, max_iter, ctx->strict_sign, ctx->zero_on_removal,
+                       ctx->tie_guard, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0, hdr, pcol, LX, LD, ws.x, ws.gam, ws.touched,
+                       ws.dims.kcap, ws.st, ws.trace, ws.trace_cap);
+    if (e1) (void)hipEventRecord(e1, s);
+    hipLaunchKernelGGL(k_sub_verify, dim3((n + kVsCols - 1) / kVsCols, nslots), dim3(kVsThreads), sub_verify_lds_bytes(), s,
+                       (const float*)ctx->gram_full, ctx->gram_pitch, c0, n, ctx->n_pad, (const uint32_t*)sub, (const uint32_t*)hdr,
+                       (const uint32_t*)pcol, (const float*)LX, (const float*)LD, ctx->tie_guard, tol, ws.st);
+    hipLaunchKernelGGL(k_sub_finish, dim3((nslots + 255) / 256), dim3(256), 0, s, ws.st, nslots);
+    if (e2) (void)hipEventRecord(e2, s);
+    return hipGetLastError();
+}
+
+}  // namespace sship

@@ -83,6 +83,10 @@ class Stats(ctypes.Structure):
         ("sweep32_bytes_timed", ctypes.c_uint64),
         ("tie_reruns", ctypes.c_uint64),
         ("ro_resweeps", ctypes.c_uint64),
+        ("subset_signals", ctypes.c_uint64),
+        ("subset_redone", ctypes.c_uint64),
+        ("sub_solve_ms", ctypes.c_double),
+        ("sub_verify_ms", ctypes.c_double),
     ]
 
 

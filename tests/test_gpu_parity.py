@@ -383,6 +383,7 @@ def test_fused_scan_is_the_two_kernel_form(sship, shape, mode):
         set_mode(h, mode)
         if not cols_form:
             h.set_option("batch_min", 4)
+        h.set_option("batch_subset", 0)              # (the lock-step forms are compared here; the subset form has its own tests)
         for fused in (1, 0):
             h.set_option("batch_fused_scan", fused)
             h.reset_stats()
@@ -1462,17 +1463,25 @@ def test_omp_engines_agree(sship, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("subset", [1, 0])
 @pytest.mark.parametrize("B", [9, 130])
-def test_batch_gram_form_vs_oracle(sship, B):
-    """lock-step batch in Gram form: correlations from rows of the full G = A^T A instead of two GEMMs
-    per round (options batch_min / batch_gram_min lowered to exercise it on a small batch)"""
+def test_batch_gram_form_vs_oracle(sship, B, subset):
+    """batch in Gram form: correlations from rows of the full G = A^T A instead of two GEMMs per round (options
+    batch_min / batch_gram_min lowered to exercise it on a small batch) — in lock-step (subset = 0) and in the subset
+    form (csrc/subbatch.hip: one workgroup per signal on the 448 columns with the largest |c0|, every breakpoint
+    checked against all columns)"""
     A, Y, sups = _batch_problem(640 + B, 256, 640, B, 3, 9, np.float32)
     with sship.Homotopy(A) as h:
         h.set_option("batch_min", 4)
         h.set_option("batch_gram_min", 4)
+        h.set_option("batch_subset", subset)
         X, iters, errs = h.solve_batch(Y, 1e-3, 40)
         st = h.stats()
-        assert st["batch_rounds"] > 0 and st["gram_full_builds"] == 1
+        assert st["gram_full_builds"] == 1
+        if subset:
+            assert st["subset_signals"] + st["subset_redone"] + st["tie_reruns"] >= B and st["subset_signals"] >= B - 2
+        else:
+            assert st["batch_rounds"] > 0 and st["subset_signals"] == 0
         X2, iters2, errs2 = h.solve_batch(Y[: B // 2 + 1], 1e-3, 40)       # G is kept: no second build
         assert h.stats()["gram_full_builds"] == 1
         assert np.array_equal(X2, X[: B // 2 + 1]) and np.array_equal(iters2, iters[: B // 2 + 1])
@@ -1482,6 +1491,55 @@ def test_batch_gram_form_vs_oracle(sship, B):
         xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 40)
         assert_parity(X[b], int(iters[b]), float(errs[b]), xo, ito, eo, np.float32)
         assert np.array_equal(significant_support(X[b], 1e-3), sups[b])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("shape", [(256, 2048, 300, 20, 0), (128, 4096, 520, 12, 0), (48, 600, 260, 8, 1), (300, 400, 64, 12, 0)])
+def test_subset_form_against_lockstep(sship, shape, mode):
+    """The subset form of the batched Gram form (csrc/subbatch.hip) against the lock-step form of the same batch: the
+    same supports and iteration counts, coefficients to rounding (the two sum in different orders) — on well-posed
+    batches every signal; on a hard one (m = 48: removals, re-insertions, signals that run out of budget) the form must
+    DECLINE what leaves its common path (subset_redone > 0) and those signals carry the lock-step form's words.
+    The last shape has fewer columns than a subset holds (n = 400 < 448)."""
+    m, n, B, kmax_, hard = shape
+    A, Y, sups = _batch_problem(7000 + n + B, m, n, B, 2, kmax_, np.float32)
+    budget = 3 * kmax_ + 8
+    got = {}
+    with sship.Homotopy(A) as h:
+        set_mode(h, mode)
+        h.set_option("batch_min", 4)
+        h.set_option("batch_gram_min", 4)
+        for subset in (1, 0):
+            h.set_option("batch_subset", subset)
+            h.reset_stats()
+            X, it, err = h.solve_batch(Y, 1e-3, budget)
+            got[subset] = (X.copy(), it.copy(), err.copy(), h.stats())
+    (Xs, its, errs, sts), (Xl, itl, errl, stl) = got[1], got[0]
+    assert stl["subset_signals"] == 0 and sts["subset_signals"] + sts["subset_redone"] + sts["tie_reruns"] >= B
+    note("test_subset_form", shape=list(shape), mode=mode, accepted=int(sts["subset_signals"]), redone=int(sts["subset_redone"]),
+         tie_reruns=int(sts["tie_reruns"]))
+    differ = 0
+    for b in range(B):
+        # same path: same iteration count, coefficients to rounding.  (Not compared: WHICH near-zero entries are exactly
+        # zero — a leaving column's x + (-x/d) d is 0 or an ulp by rounding luck, homotopy-cpu.cpp:246-252 — and paths that
+        # part at a near-tie: rounding decides there, in any two implementations.)
+        if its[b] == itl[b]:
+            scale = max(np.abs(Xl[b]).max(), 1e-30)
+            assert np.abs(Xs[b] - Xl[b]).max() <= (2e-3 if hard else 2e-4) * scale, (b, np.abs(Xs[b] - Xl[b]).max() / scale)
+            assert np.array_equal(significant_support(Xs[b], 1e-3), significant_support(Xl[b], 1e-3)), b
+        else:
+            differ += 1
+            print("differs:", b, "iterations", its[b], itl[b], "err", errs[b], errl[b])
+    if hard:
+        assert sts["subset_redone"] > 0
+        assert differ <= B // 20, differ                    # (paths through exact bounces may part by rounding luck, as between engines)
+    else:
+        assert differ <= B // 100, differ
+        assert sts["subset_signals"] >= B // 2
+        for b in range(0, B, 7):
+            xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, budget, flags=MODES[mode][1])
+            assert its[b] == ito or itl[b] != ito, (b, its[b], itl[b], ito)      # (no further from the oracle than the lock-step form)
 
 
 @pytest.mark.gpu
