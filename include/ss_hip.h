@@ -347,6 +347,11 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    for bit by any implementation that states the same order.  One pass over A per iteration (2 GiB
  *                    at 8192 x 65536, 0.84 of the HBM peak); batches run up to 4 signals per pass; the arbiter of
  *                    "tie_rerun".
+ *   "batch_subset"   1 (default) = batches that run in Gram form on the full G = A^T A use the SUBSET form
+ *                    (csrc/subbatch.hip): every signal is solved by one workgroup on the 448 columns with the largest
+ *                    |A^T y| and every breakpoint is then checked against all columns by the same chain of fmas; a signal
+ *                    the form declines (left its common path) or whose check fails is solved again in the lock-step
+ *                    form (ss_hip_stats::subset_signals / subset_redone); 0 = the lock-step form for all
  *   "ro_slots"       1..4 (default 4): signals the reference-order engine runs in lock-step per pass over A (batches in
  *                    engine 3, a batch's tie re-runs); every signal's words are those of its own solve
  *   "ro_staged"      1 (default) = its sweep stages the dictionary through LDS (coalesced loads); 0 = direct 16-byte

@@ -685,17 +685,22 @@ def test_batch_full_size(sship, c2_host_matrix):
             if not stuckc[b]:
                 xo, ito, eo = oracle.homotopy(A, Yh[b], 1e-3, 256)
                 assert_parity(X[b].cpu().numpy(), int(itc[b]), float(erc[b]), xo, ito, eo, np.float32)
-        for form in ("gram", "gemm", "gram+tie_guard"):
+        # "gram": the default — the subset form (csrc/subbatch.hip) with the lock-step form behind it; "gram-lockstep": that alone
+        for form in ("gram", "gram-lockstep", "gemm", "gram+tie_guard"):
             if form == "gemm":
                 h.set_option("batch_gram_min", 0)
             else:
                 h.set_option("batch_gram_min", 512)
+            h.set_option("batch_subset", 0 if form == "gram-lockstep" else 1)
             h.set_option("tie_guard", 1 if form.endswith("tie_guard") else 0)
             h.reset_stats()
             _, iters, errs = h.solve_batch(Y, 1e-3, 256, out=X)
             torch.cuda.synchronize()
             st = h.stats()
-            assert st["batch_rounds"] > 0
+            if form in ("gram", "gram+tie_guard"):
+                assert st["subset_signals"] >= B - B // 50, (form, st["subset_signals"], st["subset_redone"])
+            else:
+                assert st["batch_rounds"] > 0 and st["subset_signals"] == 0
             nz = (X != 0)
             counts = nz.sum(1).cpu().numpy()
             sup_d = torch.from_numpy(sups).to("cuda:0")
@@ -716,7 +721,8 @@ def test_batch_full_size(sship, c2_host_matrix):
                 # exact ties: every exhausted signal against the oracle (no allowance)
                 nchk = check_exhausted_against_oracle(A, Yh, X, iters, 256, form)
                 assert st["tie_reruns"] >= nchk, (form, st["tie_reruns"], nchk)
-            note("test_batch_full_size", form=form, signals=B, exhausted=int(stuck.sum()), tie_reruns=st["tie_reruns"])
+            note("test_batch_full_size", form=form, signals=B, exhausted=int(stuck.sum()), tie_reruns=st["tie_reruns"],
+                 subset_accepted=int(st["subset_signals"]), subset_redone=int(st["subset_redone"]))
             if form == "gram":
                 assert st["gram_full_builds"] == 1
                 Xs = X[torch.from_numpy(picks).to("cuda:0")].cpu().numpy()
