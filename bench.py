@@ -270,6 +270,31 @@ def run_batched(args, h, A, dev, rank, world, use_dist, torch, dist, sharding):
         return None
     cq_ms = st["cq_ms"] / max(1, st["cq_launches"])
     cq_gbs = st["cq_bytes"] / (st["cq_ms"] * 1e-3) / 1e9 if st["cq_ms"] > 0 else 0.0
+    subset = st["subset_signals"] > 0
+    if subset:
+        # subset form: the batch GEMM c0 = A^T y of the step's signals is the launch with a roofline to stand against (MFMA);
+        # the check over all columns (k_sub_verify) is VALU / LDS work and is reported beside it
+        tfs = st["c0_gemm_flops"] / (st["c0_gemm_ms"] * 1e-3) / 1e12 if st["c0_gemm_ms"] > 0 else 0.0
+        roof = {"bound": "mfma",
+                "kernel": "k_gemm_tn_f32: C0 = Y A, c0 = A^T y of the step's %d signals (v_mfma_f32_32x32x2_f32, 128x128x32 tiles, blocked "
+                          "accumulation)" % B,
+                "achieved": tfs, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": tfs / MFMA_F32_PEAK_TFS, "traffic": None,
+                "flops_per_launch": st["c0_gemm_flops"] / max(1, args.steps), "avg_launch_ms": st["c0_gemm_ms"] / max(1, args.steps),
+                "launches_timed": args.steps,
+                "beside_it_per_step_ms": {"k_sub_select + k_sub_solve (one workgroup per signal on 448 columns)": st["sub_solve_ms"] / max(1, args.steps),
+                                          "k_sub_verify (every breakpoint against all columns: VALU + LDS)": st["sub_verify_ms"] / max(1, args.steps)},
+                "subset_form": {"signals_accepted": int(st["subset_signals"]), "signals_redone_in_lockstep": int(st["subset_redone"])}}
+    else:
+        roof = {
+            "bound": "hbm",
+            "kernel": "k_la_cqs (batched Gram form, the step-length scan inside): c = c0 - sum_j x_j G[j], q = sum_j d_j G[j] for "
+                      "every live signal, K rows of G per signal and round, lambda, scan and pick in the same launch",
+            "achieved": cq_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cq_gbs / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_launch": st["cq_bytes"] / max(1, st["cq_launches"]), "avg_launch_ms": cq_ms,
+            "launches_timed": st["cq_launches"],
+            "note": "bytes = sum over live signals of (K + 3) * n * 4 (K rows of G, c0, c, q); G rows shared by signals "
+                    "of one launch are re-served from L2 / Infinity Cache, so HBM traffic is below this figure",
+        }
     return {
         "metric": "signals recovered/sec (Homotopy l1, m=8192 n=65536 k=64 fp32)",
         "value": world * B * args.steps / elapsed,
@@ -285,8 +310,9 @@ def run_batched(args, h, A, dev, rank, world, use_dist, torch, dist, sharding):
         "data": "synthetic",
         "config": {
             "workload": "configs[3]: batch of %d x %d signals sharing A 8192x65536 fp32 (k=64 positive coefficients, "
-                        "tol 1e-3, max_iter 256), %d per rank and step in lock-step (Gram form: correlations from rows "
-                        "of G = A^T A, formed once per rank in the warm-up), compact records, one RCCL all_gather per step"
+                        "tol 1e-3, max_iter 256), %d per rank and step, Gram form on G = A^T A (formed once per rank in the warm-up), "
+                        "subset form: every signal solved by one workgroup on the 448 columns with the largest |A^T y| and checked "
+                        "against all columns (csrc/subbatch.hip; the lock-step form behind it), compact records, one RCCL all_gather per step"
                         % (world, B, B),
             "m": M, "n": N, "k": K_SPARSE, "signals_per_step_per_gpu": B,
             "sharding": "signals across ranks (contiguous blocks), A replicated, no data-path collective; one all_gather "
@@ -294,16 +320,7 @@ def run_batched(args, h, A, dev, rank, world, use_dist, torch, dist, sharding):
             "scaling_base": "the single-GPU rate of this same workload is `batched.signals_per_s` of the --gpus 1 line "
                             "(whose `value` is the single-signal configs[1] rate)",
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "k_la_cqs (batched Gram form, the step-length scan inside): c = c0 - sum_j x_j G[j], q = sum_j d_j G[j] for "
-                      "every live signal, K rows of G per signal and round, lambda, scan and pick in the same launch",
-            "achieved": cq_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cq_gbs / HBM_PEAK_GBS, "traffic": None,
-            "bytes_per_launch": st["cq_bytes"] / max(1, st["cq_launches"]), "avg_launch_ms": cq_ms,
-            "launches_timed": st["cq_launches"],
-            "note": "bytes = sum over live signals of (K + 3) * n * 4 (K rows of G, c0, c, q); G rows shared by signals "
-                    "of one launch are re-served from L2 / Infinity Cache, so HBM traffic is below this figure",
-        },
+        "roofline": roof,
         "batch_rounds_per_step": st["batch_rounds"] / max(1, args.steps),
         "recovered": {"signals_checked": world * B, "support_exact": int(agg[0].item()),
                       "ran_to_max_iter": int(agg[1].item()), "max_rel_coef_err_rank0": cerr,
@@ -415,6 +432,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         try:
             keep_engine = h.get_option("engine")
             h.set_option("engine", 3)
+            h.gemv_t(sigs[0][0], 1)                                   # (first launch: module load, LDS attribute)
             _, ms_ro = h.gemv_t(sigs[0][0], 5)
             xr = torch.zeros(N, device=dev, dtype=torch.float32)
             h.solve(sigs[0][0], TOL, MAX_ITER, out=xr)
@@ -423,11 +441,14 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             tr_ = time.perf_counter()
             nro = min(3, args.steps)
             same = 0
+            t_solves = 0.0
             for s_ in range(nro):
-                _, itr_, er_ = h.solve(sigs[args.warmup + s_][0], TOL, MAX_ITER, out=xr)
-                same += int(torch.equal(xr != 0, X[s_] != 0))
+                tq_ = time.perf_counter()
+                _, itr_, er_ = h.solve(sigs[args.warmup + s_][0], TOL, MAX_ITER, out=xr)      # (returns when x is in `xr`)
+                t_solves += time.perf_counter() - tq_
+                same += int(torch.equal(xr != 0, X[s_] != 0))      # (not timed: the first torch.equal loads its kernels, 0.1 s)
             torch.cuda.synchronize()
-            dtr_ = (time.perf_counter() - tr_) / nro
+            dtr_ = t_solves / nro
             # four signals in lock-step: [r, p] of each in ONE pass over A per iteration (k_ro_sweep_t<2, 4>)
             Y4 = torch.stack([sigs[(args.warmup + s_) % len(sigs)][0] for s_ in range(4)]).contiguous()
             X4 = torch.zeros((4, N), device=dev, dtype=torch.float32)
@@ -444,7 +465,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             extras["reference_order_engine"] = {
                 "workload": "engine 3 (csrc/reforder.hip): bit-identical with the CPU oracle's summation order; configs[1] matrix and signals",
                 "sweep_ms": ms_ro, "sweep_GBs": b1 / ms_ro / 1e6, "sweep_frac_of_8TBs": b1 / ms_ro / 1e6 / HBM_PEAK_GBS,
-                "sweep": "k_ro_sweep<float,1>: c = A^T y (gemv_t); the iterations run the 2-RHS form [c, q] = A^T [r, p]",
+                "sweep": "k_ro_sweep_t<float, 1, 1>: c = A^T y (gemv_t), the dictionary staged through LDS; the iterations run the 2-RHS form [c, q] = A^T [r, p]",
                 "ms_per_solve": dtr_ * 1e3, "iterations": int(itr_), "passes_over_A_per_iteration": 1,
                 "second_sweeps": int(h.stats()["ro_resweeps"]) - resweeps0,
                 "lockstep_4_signals": {"ms": dt4_ * 1e3, "ms_per_signal": dt4_ * 1e3 / 4,
@@ -511,7 +532,9 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                          "gram_matrix_built": int(stb["gram_full_builds"]),
                          "gram_build_ms": stb["gram_build_ms"], "gram_alloc_ms": stb["gram_alloc_ms"],
                          "subset_form": {"signals_accepted": int(stb["subset_signals"]), "signals_redone_in_lockstep": int(stb["subset_redone"]),
-                                         "select_and_solve_ms": stb["sub_solve_ms"], "check_over_all_columns_ms": stb["sub_verify_ms"]},
+                                         "select_and_solve_ms": stb["sub_solve_ms"], "check_over_all_columns_ms": stb["sub_verify_ms"],
+                                         "c0_gemm_ms": stb["c0_gemm_ms"],
+                                         "c0_gemm_TFLOPs": (stb["c0_gemm_flops"] / (stb["c0_gemm_ms"] * 1e-3) / 1e12) if stb["c0_gemm_ms"] > 0 else 0.0},
                          "tie_reruns": int(stb["tie_reruns"])})
             if label == "next batch, profiled":
                 st_sub = stb

@@ -263,6 +263,8 @@ typedef struct ss_hip_stats {
                                       lock-step Gram form                                                                              */
     double   sub_solve_ms;         /* profiling on: HIP-event time of the form's selection + per-signal solves                            */
     double   sub_verify_ms;        /* ... and of its check over all columns                                                              */
+    double   c0_gemm_ms;           /* ... and of the batch GEMM C0 = Y A (k_gemm_tn_f32: c0 = A^T y of every signal of a chunk)            */
+    double   c0_gemm_flops;        /* its algorithmic flops: 2 * rows * ldm * n_pad per chunk (rows = signals padded to 128)               */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------

@@ -1517,7 +1517,11 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
 
             // c_b = A^T y_b for every signal (residual_vector with x = 0, homotopy-cpu.cpp:215)
             uint32_t nparts = 0;
+            const bool time_c0 = ctx->profiling != 0;
+            if (time_c0 && !ctx->ev_c0a) { HIPCHK(hipEventCreate(&ctx->ev_c0a)); HIPCHK(hipEventCreate(&ctx->ev_c0b)); }
+            if (time_c0) HIPCHK(hipEventRecord(ctx->ev_c0a, st));
             HIPCHK(launch_gemm_tn_f32(ctx, Rblk, rows, (uint32_t)ldm, ws.c, (uint32_t)np, nullptr));
+            if (time_c0) HIPCHK(hipEventRecord(ctx->ev_c0b, st));
             HIPCHK(launch_absmax<T>(ctx, ws, Bc, &nparts));
             HIPCHK(launch_init<T>(ctx, ws, Bc, nparts, tol));
             bool gram_chunk = gram;
@@ -1586,13 +1590,17 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             if (sub_chunk) {
                 const bool timed = ctx->profiling != 0;
                 hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-                if (timed) { e0 = prof_event(ctx, 0); e1 = prof_event(ctx, 1); e2 = prof_event(ctx, 2); }
+                if (timed) { e0 = prof_event(ctx, 0); e1 = prof_event(ctx, 1); e2 = prof_event(ctx, 2); if (!ctx->ev_sub_sel) HIPCHK(hipEventCreate(&ctx->ev_sub_sel)); }
                 HIPCHK(launch_sub_form(ctx, ws, Bc, ctx->c0_batch, tol, max_iter, e0, e1, e2));
                 if (timed) {
                     HIPCHK(hipEventSynchronize(e2));
                     float ms = 0.f;
                     HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ctx->stats.sub_solve_ms += ms;
+                    if (std::getenv("SS_HIP_SUB_DEBUG")) { float ms2 = 0.f; HIPCHK(hipEventElapsedTime(&ms2, e0, ctx->ev_sub_sel)); std::fprintf(stderr, "[subset form] select %.3f ms, solve %.3f ms\n", ms2, ms - ms2); }
                     HIPCHK(hipEventElapsedTime(&ms, e1, e2)); ctx->stats.sub_verify_ms += ms;
+                    HIPCHK(hipEventElapsedTime(&ms, ctx->ev_c0a, ctx->ev_c0b));
+                    ctx->stats.c0_gemm_ms += ms;
+                    ctx->stats.c0_gemm_flops += 2.0 * (double)rows * (double)ldm * (double)np;
                 }
             }
             for (uint64_t round = 1; round <= last_round && !sub_chunk; ++round) {
@@ -2130,6 +2138,9 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     if (ctx->gram_full) (void)hipFree(ctx->gram_full);
     if (ctx->c0_batch) (void)hipFree(ctx->c0_batch);
     if (ctx->sub_buf) (void)hipFree(ctx->sub_buf);
+    if (ctx->ev_sub_sel) (void)hipEventDestroy(ctx->ev_sub_sel);
+    if (ctx->ev_c0a) (void)hipEventDestroy(ctx->ev_c0a);
+    if (ctx->ev_c0b) (void)hipEventDestroy(ctx->ev_c0b);
     if (ctx->bcol_cache) (void)hipFree(ctx->bcol_cache);
     if (ctx->bcol_slot) (void)hipFree(ctx->bcol_slot);
     if (ctx->bcol_lists) (void)hipFree(ctx->bcol_lists);

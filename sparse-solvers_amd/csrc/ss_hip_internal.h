@@ -251,6 +251,8 @@ struct ss_hip_ctx {
     void* sub_buf = nullptr;          // subset form (subbatch.hip): subsets, first picks, breakpoint logs of a chunk
     size_t sub_buf_bytes = 0;
     int sub_attr_set = -1;
+    hipEvent_t ev_sub_sel = nullptr;  // profiling: between the subset form's selection and its solves
+    hipEvent_t ev_c0a = nullptr, ev_c0b = nullptr;   // profiling: around the batch GEMM c0 = A^T y of a chunk
     int batch_subset = 1;             // option: 1 = large Gram-form batches run in the subset form (one workgroup per signal + a check over all columns)
     size_t c0_batch_rows = 0;
     // column form of mid-size batches: cache of Gram columns, row tables, pass lists (grown on demand)

@@ -87,6 +87,8 @@ class Stats(ctypes.Structure):
         ("subset_redone", ctypes.c_uint64),
         ("sub_solve_ms", ctypes.c_double),
         ("sub_verify_ms", ctypes.c_double),
+        ("c0_gemm_ms", ctypes.c_double),
+        ("c0_gemm_flops", ctypes.c_double),
     ]
 
 
