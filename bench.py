@@ -587,7 +587,9 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         dtg = time.perf_counter() - tg
         okg = int(((Xg != 0) == (X != 0)).all(dim=1).sum().item())
         del Xg
-        with_gram = {"workload": "the same single-signal solves with G = A^T A (17 GiB) as the Gram-column cache",
+        with_gram = {"workload": "the same single-signal solves with G = A^T A (17 GiB) in HBM (formed by the batch above; option gram_full_after "
+                                 "forms it after that many single solves): A^T y, then the subset form of the batches for ONE signal — one "
+                                 "workgroup on 448 columns, every breakpoint checked against all columns — no pass over A beyond A^T y",
                      "signals_per_s": args.steps / dtg, "ms_per_solve": dtg / args.steps * 1e3,
                      "same_support_as_timed_solves": okg}
 

@@ -798,11 +798,26 @@ unsigned char* pack_records(ss_hip_ctx* ctx, Workspace<T>& ws, uint32_t nslots, 
     return ctx->rec_stage;
 }
 
+// one signal in the subset form (subbatch.hip) when G = A^T A is at hand: c0 is in ws.c0
+inline hipError_t sub_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter)
+{
+    const size_t need = sub_buffer_bytes(1);
+    if (ctx->sub_buf_bytes < need) {
+        if (ctx->sub_buf) HIPCHK(hipFree(ctx->sub_buf));
+        ctx->sub_buf = nullptr;
+        ctx->sub_buf_bytes = 0;
+        HIPCHK(hipMalloc(&ctx->sub_buf, need));
+        ctx->sub_buf_bytes = need;
+    }
+    return launch_sub_form(ctx, ws, 1, ws.c0, tol, max_iter);
+}
+inline hipError_t sub_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t) { return hipErrorInvalidConfiguration; }
+
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
                ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
                bool omp = false, bool force_residual = false, bool no_solo = false,
-               void* rec_out = nullptr, uint32_t kmax = 0, bool force_ro = false)
+               void* rec_out = nullptr, uint32_t kmax = 0, bool force_ro = false, bool no_sub = false)
 {
     if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
     if (ctx->kind != 0) { set_err(err, errlen, "solve: this context was created for IRLS"); return SS_HIP_EINVAL; }
@@ -875,6 +890,11 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const bool la_omp = omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && ctx->la_fused >= 1;
         bool solo = false, solo_started = false, early = false;
         uint32_t early_lds_cols = 0, ro_parts = 0;
+        // With G = A^T A at hand (a large batch has run on the context, or option gram_full_after) a single signal takes the
+        // subset form of the batches (subbatch.hip): A^T y, one workgroup on 448 columns, the check over all columns — no
+        // pass over A beyond A^T y.  What the form does not vouch for is solved again the usual way (no_sub).
+        const bool sub1 = la && sizeof(T) == 4 && !no_sub && ctx->batch_subset && ctx->gram_single && ctx->gram_full != nullptr &&
+                          sub_form_usable(ctx);
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
         bool spec_epilogue = false, pump_enqueued = false;
         const bool x_on_device = x != nullptr && is_device_pointer(x);
@@ -931,6 +951,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
             if (!ws.gram_is_full) HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // nothing cached yet
+        } else if (sub1) {
+            Lookahead<T>::ensure(ctx, ws, kcap);
+            HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y
+            uint32_t nb1 = 0;
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+            HIPCHK(sub_single(ctx, ws, tol, max_iter));
         } else if (la) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             enter_full_gram();
@@ -994,7 +1022,9 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
         volatile uint32_t* hf = ctx->host_flags;
         const uint64_t last_round = (uint64_t)max_iter + 1;
-        if ((la && ctx->la_fused) || la_omp) {
+        if (sub1) {
+            // (everything is queued: selection, the solve, the check)
+        } else if ((la && ctx->la_fused) || la_omp) {
             // Fused lookahead engine: every launch of k_la_iter performs the next iteration, or
             // nothing while the device waits for a Gram column (hf[2] counts those waits).  The
             // host keeps L launches queued ahead and answers each wait with one fetch.
@@ -1127,6 +1157,11 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             ctx->stats.tie_reruns += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, false, false, no_solo, rec_out, kmax, true);
         }
+        if (sub1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
+            ctx->stats.subset_redone += 1;
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
+        }
+        if (sub1 && hs.status == 0) ctx->stats.subset_signals += 1;
         if (la && hs.status == kStatusRetryPlain) {
             // the early form's first launch used too many columns beyond the prefetched ones: plain form for this solve
             const int keep = ctx->early_solo;

@@ -1568,6 +1568,13 @@ def test_full_gram_single_signal(sship, la_fused):
             assert np.array_equal(trg["idx"][:-1], tro["idx"][:-1])
         st = h.stats()
         assert st["gram_full_builds"] == 1 and st["lookahead_sweeps"] == 0
+        # (with G at hand a single signal takes the subset form of the batches: csrc/subbatch.hip)
+        assert st["subset_signals"] + st["subset_redone"] >= 1
+        h.set_option("batch_subset", 0)                     # ... and without it G is the Gram-column cache of the lookahead engine
+        xg2, itg2, eg2 = h.solve(y, 1e-3, 4 * k)
+        assert_parity(xg2, itg2, eg2, xo, ito, eo, np.float32)
+        assert h.stats()["lookahead_sweeps"] == 0
+        h.set_option("batch_subset", 1)
         xq, itq, eq = h.solve_omp(y, 1e-3, 2 * k)
         xoo, itoo, eoo, _ = oracle.omp(A, y, 1e-3, 2 * k)
         assert itq == itoo and np.array_equal(np.nonzero(xq)[0], np.nonzero(xoo)[0])
