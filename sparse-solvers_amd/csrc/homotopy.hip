@@ -1393,8 +1393,9 @@ int solve_batch_ro(ss_hip_ctx* ctx, const T* Y, const size_t* sig, size_t count,
         std::vector<DevState> hs;
         for (size_t j0 = 0; j0 < count; j0 += per) {
             const uint32_t R = (uint32_t)std::min(per, count - j0);
+            const uint32_t Rg = R <= 2 ? R : 4u;                  // the sweep carries 1, 2 or 4 slots: the workspace holds that many
             auto gidx = [&](uint32_t b) { return sig ? sig[j0 + b] : j0 + b; };
-            ensure_workspace<T>(ctx, R, kcap);
+            ensure_workspace<T>(ctx, Rg, kcap);
             Workspace<T>& ws = *ws_of<T>(ctx);
             const uint32_t want_trace = (ctx->tracing && gidx(0) == 0) ? (uint32_t)std::min<uint64_t>((uint64_t)max_iter + 2, 1u << 20) : 0u;
             if (want_trace > ws.trace_cap) {
@@ -1410,12 +1411,14 @@ int solve_batch_ro(ss_hip_ctx* ctx, const T* Y, const size_t* sig, size_t count,
 
             ctx->host_flags[0] = 0;
             ctx->host_flags[1] = 0;
-            HIPCHK(hipMemsetAsync(ws.y, 0, (size_t)R * ldm * sizeof(T), st));
+            HIPCHK(hipMemsetAsync(ws.y, 0, (size_t)Rg * ldm * sizeof(T), st));
             for (uint32_t b = 0; b < R; ++b) copy_in<T>(ctx, ws.y + (size_t)b * ldm, Y + (ptrdiff_t)gidx(b) * y_stride, incy, m);
             HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)R * np * sizeof(T), st));
             HIPCHK(hipMemsetAsync(ws.d, 0, (size_t)R * np * sizeof(T), st));
             HIPCHK(hipMemsetAsync(ws.insup, 0, (size_t)R * np, st));
-            HIPCHK(hipMemsetAsync(ws.st, 0, (size_t)R * sizeof(DevState), st));
+            HIPCHK(hipMemsetAsync(ws.st, 0, (size_t)Rg * sizeof(DevState), st));
+            // (a slot of the group that carries no signal is "done" from the start: DevState::done is its first word)
+            for (uint32_t b = R; b < Rg; ++b) HIPCHK(hipMemsetAsync(&ws.st[b], 0x01, sizeof(uint32_t), st));
             HIPCHK(hipMemsetAsync(ws.ndone, 0, sizeof(uint32_t), st));
             // (the sweep reads whole slot groups of 1, 2, 4, 8 right-hand sides: the slots beyond R carry zeros)
             const size_t bp = ws.dims.b_pad;

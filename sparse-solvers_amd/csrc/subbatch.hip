@@ -269,6 +269,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
         direction();
         __syncthreads();
         lambda0 = fabsf(c0[idx0]);
+        lambda_prev = lambda0;                 // (k_init leaves c_inf = lambda0, gamma = 0: the first round's lambda is "where the last step left it")
 
         for (uint32_t round = 1;; ++round) {
             // ---- c, q of my column: the chain over the positions -----------------------------------------------

@@ -229,6 +229,21 @@ def test_exact_tie_bitwise_and_rerun(sship, dtype):
         for b in range(3):
             xb, itb, eb = oracle.homotopy(A, Y[b], 1e-3, 6)
             assert itb == iters[b] and np.array_equal(X[b], xb), b
+        if dtype == np.float32:
+            # the same through the batched Gram forms (G = A^T A; the subset form, then the lock-step form): the tie is met in
+            # the FIRST round there (lambda is still the first pick's), flagged, and the signal re-run
+            h.set_option("batch_min", 2)
+            h.set_option("batch_gram_min", 2)
+            for subset in (1, 0):
+                h.set_option("batch_subset", subset)
+                h.reset_stats()
+                X, iters, errs = h.solve_batch(Y, 1e-3, 6)
+                st = h.stats()
+                assert st["tie_reruns"] == 3, (subset, st["tie_reruns"])     # (the middle signal has an exact tie of its own: 0.75, 0.75)
+                assert (st["subset_signals"] > 0) == bool(subset)
+                for b in range(3):
+                    xb, itb, eb = oracle.homotopy(A, Y[b], 1e-3, 6)
+                    assert itb == iters[b] and np.array_equal(X[b], xb), (subset, b)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
