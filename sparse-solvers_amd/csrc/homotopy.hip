@@ -1830,8 +1830,11 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
     // reference-order engine: in lock-step, up to 4 signals per pass over A
     if (ctx->engine == 3)
         return solve_batch_ro<float>(ctx, Y, nullptr, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
-    // lock-step MFMA path once enough signals share the matrix (batch_min option, default 192)
-    const bool lockstep = B >= (size_t)std::max(2, ctx->batch_min);
+    // lock-step MFMA path once enough signals share the matrix (batch_min option, default 192) — or, with G = A^T A already
+    // in HBM, from four signals on: the subset form then runs every signal on a workgroup of its own (subbatch.hip)
+    const bool have_g = ctx->gram_full != nullptr && ctx->batch_subset && ctx->engine >= 1 && ctx->batch_gram_min > 0;
+    // (from four: the batch GEMM that forms c0 works on 128 rows at a time — 1.1 ms at 8192 x 65536, three single sweeps)
+    const bool lockstep = B >= (size_t)std::max(2, ctx->batch_min) || (have_g && B >= 4);
     int form = 0;
     // Gram form when G = A^T A is at hand, or the batch is large enough to pay for making it
     // (2 m n^2 flops once, against 4 m n flops per signal and round); same tolerance guard as engine 1

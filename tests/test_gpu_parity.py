@@ -1359,6 +1359,26 @@ def test_small_batches_run_signal_by_signal(sship):
 
 
 @pytest.mark.gpu
+def test_small_batches_take_the_subset_form_once_G_exists(sship):
+    """with G = A^T A in HBM (here: option gram_full_after = 1 and one solve) a batch of four or more signals no longer
+    runs signal by signal or in the column form: every signal gets a workgroup of its own (csrc/subbatch.hip)"""
+    A, Y, sups = _batch_problem(92, 256, 2048, 40, 4, 9, np.float32)
+    with sship.Homotopy(A) as h:
+        h.set_option("gram_full_after", 1)
+        h.solve(Y[0], 1e-3, 40)
+        assert h.stats()["gram_full_builds"] == 1
+        for B in (3, 4, 6, 40):
+            h.reset_stats()
+            X, iters, errs = h.solve_batch(Y[:B], 1e-3, 40)
+            st = h.stats()
+            assert st["subset_signals"] + st["subset_redone"] + st["tie_reruns"] >= B and st["batch_col_rounds"] == 0, (B, st["subset_signals"])
+            for b in range(B):
+                xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 40)
+                assert_parity(X[b], int(iters[b]), float(errs[b]), xo, ito, eo, np.float32)
+                assert np.array_equal(significant_support(X[b], 1e-3), sups[b])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("B", [24, 64, 65, 191, 300, 600])
 def test_mid_size_batches_column_form(sship, B, mode):
