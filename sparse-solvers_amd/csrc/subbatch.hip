@@ -521,8 +521,10 @@ __device__ __forceinline__ void sub_check(float cv, float qv, uint32_t j, uint32
         // lambda - gamma ~ 0 and every column's candidate ties with the step within rounding; whichever is
         // inserted enters with x = 0 and the next round ends the path with the same coefficients.  A candidate
         // within 1e-5 of the step taken is such a tie, a smaller one a real entrant.
-        const bool last_step = k + 2u == nlog && !(sH[(k + 1u) * 8 + 1] & 1u) && !(__uint_as_float(sH[(k + 1u) * 8 + 4]) > tol);
-        if (!(last_step && m >= gam * 0.99999f)) fail = true;
+        // (and taking the shorter step must still end the path: lambda after it is the logged one plus the difference)
+        const float lam_end = __uint_as_float(sH[(k + 1u) * 8 + 4]);
+        const bool last_step = k + 2u == nlog && !(sH[(k + 1u) * 8 + 1] & 1u) && !(lam_end > tol);
+        if (!(last_step && m >= gam * 0.99999f && lam_end + (gam - m) <= tol)) fail = true;
     }
 }
 
