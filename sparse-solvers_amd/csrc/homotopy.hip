@@ -893,8 +893,9 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         // With G = A^T A at hand (a large batch has run on the context, or option gram_full_after) a single signal takes the
         // subset form of the batches (subbatch.hip): A^T y, one workgroup on 448 columns, the check over all columns — no
         // pass over A beyond A^T y.  What the form does not vouch for is solved again the usual way (no_sub).
-        const bool sub1 = la && sizeof(T) == 4 && !no_sub && ctx->batch_subset && ctx->gram_single && ctx->gram_full != nullptr &&
-                          sub_form_usable(ctx);
+        bool sub1 = la && sizeof(T) == 4 && !no_sub && ctx->batch_subset && ctx->gram_single && ctx->gram_full != nullptr &&
+                    sub_form_usable(ctx);
+        if (sub1 && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; }
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
         bool spec_epilogue = false, pump_enqueued = false;
         const bool x_on_device = x != nullptr && is_device_pointer(x);
@@ -1156,6 +1157,16 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             // derails the path is decided by rounding — the reference-order engine is the arbiter
             ctx->stats.tie_reruns += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, false, false, no_solo, rec_out, kmax, true);
+        }
+        if (sub1) {
+            // (a context whose signals the form hands back more often than not stops trying for a while)
+            ctx->sub_seen += 1;
+            if (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail) ctx->sub_failed += 1;
+            if (ctx->sub_seen >= 8) {
+                if (2 * ctx->sub_failed > ctx->sub_seen) ctx->sub_off_solves = 64;
+                ctx->sub_seen = 0;
+                ctx->sub_failed = 0;
+            }
         }
         if (sub1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
             ctx->stats.subset_redone += 1;
@@ -1610,6 +1621,7 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             // Subset form (subbatch.hip): with G at hand every signal is solved by one workgroup on the 448 columns with the
             // largest |c0| and then checked against all columns — 16.8 MB of G per signal instead of 545
             bool sub_chunk = gram_chunk && form == 1 && !no_subset && ctx->batch_subset && ctx->gram_full != nullptr && sub_form_usable(ctx);
+            if (sub_chunk && ctx->sub_off_chunks > 0) { ctx->sub_off_chunks -= 1; sub_chunk = false; }     // (it handed back too much lately)
             if (sub_chunk) {
                 const size_t need = sub_buffer_bytes(Bc);
                 if (ctx->sub_buf_bytes < need) {
@@ -1736,7 +1748,11 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 ctx->stats.iterations += hs[b].iter;
             }
             ctx->stats.solves += Bc - (uint32_t)ties.size() - n_redo_chunk;
-            if (sub_chunk) { ctx->stats.subset_signals += Bc - n_redo_chunk; ctx->stats.subset_redone += n_redo_chunk; }
+            if (sub_chunk) {
+                ctx->stats.subset_signals += Bc - n_redo_chunk;
+                ctx->stats.subset_redone += n_redo_chunk;
+                if (Bc >= 16 && 3u * n_redo_chunk > Bc) ctx->sub_off_chunks = 8;
+            }
             ctx->stats.batch_rounds += rounds_run;
             if (ncq != 0) {
                 // rounds enqueued behind the end of the batch are no-ops (microseconds): only launches that

@@ -251,6 +251,9 @@ struct ss_hip_ctx {
     void* sub_buf = nullptr;          // subset form (subbatch.hip): subsets, first picks, breakpoint logs of a chunk
     size_t sub_buf_bytes = 0;
     int sub_attr_set = -1;
+    // the subset form steps aside where it does not pay: after a chunk (or a run of single solves) of which it had to hand
+    // back more than a third, the next 8 chunks (64 solves) go the other way at once, then it is tried again
+    uint32_t sub_off_chunks = 0, sub_off_solves = 0, sub_seen = 0, sub_failed = 0;
     hipEvent_t ev_sub_sel = nullptr;  // profiling: between the subset form's selection and its solves
     hipEvent_t ev_c0a = nullptr, ev_c0b = nullptr;   // profiling: around the batch GEMM c0 = A^T y of a chunk
     int batch_subset = 1;             // option: 1 = large Gram-form batches run in the subset form (one workgroup per signal + a check over all columns)
