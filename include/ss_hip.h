@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_HIP_ABI_VERSION 3
+#define SS_HIP_ABI_VERSION 4
 
 typedef struct ss_hip_ctx ss_hip_ctx;
 
@@ -265,6 +265,16 @@ typedef struct ss_hip_stats {
     double   sub_verify_ms;        /* ... and of its check over all columns                                                              */
     double   c0_gemm_ms;           /* ... and of the batch GEMM C0 = Y A (k_gemm_tn_f32: c0 = A^T y of every signal of a chunk)            */
     double   c0_gemm_flops;        /* its algorithmic flops: 2 * rows * ldm * n_pad per chunk (rows = signals padded to 128)               */
+    /* ABI version 4 */
+    uint64_t screen_signals;       /* single fp32 signals solved in the screened form (csrc/screen.hip): the subset solve on the subset's own
+                                      Gram matrix, every state of the path certified against all columns by one pass over the fp16 copy
+                                      of A (rigorous error bound; nothing reported comes from that pass)                                  */
+    uint64_t screen_redone;        /* ... signals that form declined or could not certify: solved again in the default engine              */
+    uint64_t screen_launches;      /* timed launches of the screening pass k_scr_gemm (profiling on)                                      */
+    double   screen_ms;            /* sum of their HIP-event durations                                                                    */
+    uint64_t screen_bytes;         /* their algorithmic bytes: ldm * n_pad * 2 (fp16 copy of A) + 96 * ldm * 2 + n_pad * 4 each             */
+    double   screen_headroom;      /* largest (|c~| + eps) / bound over the columns outside the subset and the states of the LAST
+                                      screened solve (< 1: certified; refreshed by ss_hip_get_stats)                                       */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------

@@ -45,6 +45,8 @@ HIP_UNITS = [
     # column-sharded single-signal solve: replicated active-set arithmetic (separately rounded like activeset.hip)
     ("colshard.hip", ["-ffp-contract=off"]),
     ("subbatch.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
+    # screened form of one signal: fp16 copy of A, the subset's Gram matrix, the screening pass (bounds, not reported values)
+    ("screen.hip", []),
 ]
 
 

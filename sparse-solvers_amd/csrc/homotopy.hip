@@ -813,6 +813,21 @@ inline hipError_t sub_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, u
 }
 inline hipError_t sub_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t) { return hipErrorInvalidConfiguration; }
 
+// one signal in the screened form (screen.hip): no G — the subset's own Gram matrix from A, then one pass over the fp16 copy of A
+inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, hipEvent_t e2, hipEvent_t e3)
+{
+    const size_t need = sub_buffer_bytes(1);
+    if (ctx->sub_buf_bytes < need) {
+        if (ctx->sub_buf) HIPCHK(hipFree(ctx->sub_buf));
+        ctx->sub_buf = nullptr;
+        ctx->sub_buf_bytes = 0;
+        HIPCHK(hipMalloc(&ctx->sub_buf, need));
+        ctx->sub_buf_bytes = need;
+    }
+    return launch_screen_form(ctx, ws, tol, max_iter, nullptr, nullptr, e2, e3);
+}
+inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
+
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
                ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
@@ -895,7 +910,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         // pass over A beyond A^T y.  What the form does not vouch for is solved again the usual way (no_sub).
         bool sub1 = la && sizeof(T) == 4 && !no_sub && ctx->batch_subset && ctx->gram_single && ctx->gram_full != nullptr &&
                     sub_form_usable(ctx);
-        if (sub1 && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; }
+        // Without G: the screened form (screen.hip) — the same subset solve on the subset's own Gram matrix (formed from A), every
+        // state of its path then screened against all columns by ONE pass over a half-precision copy of A with a rigorous error
+        // bound, instead of the default engine's two fp32 passes.  It stands in for the default speculative engine only
+        // (la_fused = 3 with the early form: contexts whose options ask for another engine get that engine).
+        bool scr1 = la && sizeof(T) == 4 && !no_sub && !sub1 && ctx->la_fused >= 3 && ctx->early_solo && !ctx->early_probe &&
+                    ctx->solo_subset == 256 && screen_form_usable(ctx);
+        if ((sub1 || scr1) && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; scr1 = false; }
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
         bool spec_epilogue = false, pump_enqueued = false;
         const bool x_on_device = x != nullptr && is_device_pointer(x);
@@ -952,14 +973,22 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
             if (!ws.gram_is_full) HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // nothing cached yet
-        } else if (sub1) {
+        } else if (sub1 || scr1) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y
             uint32_t nb1 = 0;
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
-            HIPCHK(sub_single(ctx, ws, tol, max_iter));
+            if (sub1) {
+                HIPCHK(sub_single(ctx, ws, tol, max_iter));
+            } else {
+                // (6 = the screening pass over the fp16 copy of A)
+                hipEvent_t e2 = nullptr, e3 = nullptr;
+                if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); }
+                HIPCHK(scr_single(ctx, ws, tol, max_iter, e2, e3));
+                if (prof) { ctx->prof_kind.push_back(6); ++nprof; }
+            }
         } else if (la) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             enter_full_gram();
@@ -1023,7 +1052,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
         volatile uint32_t* hf = ctx->host_flags;
         const uint64_t last_round = (uint64_t)max_iter + 1;
-        if (sub1) {
+        if (sub1 || scr1) {
             // (everything is queued: selection, the solve, the check)
         } else if ((la && ctx->la_fused) || la_omp) {
             // Fused lookahead engine: every launch of k_la_iter performs the next iteration, or
@@ -1158,7 +1187,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             ctx->stats.tie_reruns += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, false, false, no_solo, rec_out, kmax, true);
         }
-        if (sub1) {
+        if (sub1 || scr1) {
             // (a context whose signals the form hands back more often than not stops trying for a while)
             ctx->sub_seen += 1;
             if (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail) ctx->sub_failed += 1;
@@ -1168,6 +1197,11 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 ctx->sub_failed = 0;
             }
         }
+        if (scr1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
+            ctx->stats.screen_redone += 1;
+            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
+        }
+        if (scr1 && hs.status == 0) ctx->stats.screen_signals += 1;
         if (sub1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
             ctx->stats.subset_redone += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
@@ -1267,6 +1301,11 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 if (ctx->prof_kind[i] == 1) {
                     ctx->stats.sweep1_launches += 1;
                     ctx->stats.sweep1_ms += ms;
+                } else if (ctx->prof_kind[i] == 6) {
+                    // the screening pass: fp16 copy of A + the residual block (re-read from L2 by every workgroup: not counted) + norms
+                    ctx->stats.screen_launches += 1;
+                    ctx->stats.screen_ms += ms;
+                    ctx->stats.screen_bytes += (uint64_t)ctx->ldm * ctx->n_pad * 2ull + 96ull * ctx->ldm * 2ull + (uint64_t)ctx->n_pad * 4ull;
                 } else if (ctx->prof_kind[i] == 4) {
                     if (ms > 0.02f) {                          // (a launch of a solve that ended at the first pick is a no-op)
                         ctx->stats.sweep64_launches += 1;
@@ -2195,6 +2234,7 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     if (ctx->gram_full) (void)hipFree(ctx->gram_full);
     if (ctx->c0_batch) (void)hipFree(ctx->c0_batch);
     if (ctx->sub_buf) (void)hipFree(ctx->sub_buf);
+    sship::screen_free(ctx);
     if (ctx->ev_sub_sel) (void)hipEventDestroy(ctx->ev_sub_sel);
     if (ctx->ev_c0a) (void)hipEventDestroy(ctx->ev_c0a);
     if (ctx->ev_c0b) (void)hipEventDestroy(ctx->ev_c0b);
@@ -2337,6 +2377,10 @@ int ss_hip_set_profiling(ss_hip_ctx* ctx, int profiling)
 int ss_hip_get_stats(ss_hip_ctx* ctx, ss_hip_stats* out)
 {
     if (!ctx || !out) return SS_HIP_EINVAL;
+    if (ctx->screen != nullptr && ctx->stats.screen_signals + ctx->stats.screen_redone != 0) {
+        (void)hipSetDevice(ctx->device);
+        ctx->stats.screen_headroom = sship::screen_read_headroom(ctx);
+    }
     *out = ctx->stats;
     return SS_HIP_OK;
 }
@@ -2407,6 +2451,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "gram_single"))   { ctx->gram_single = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_symmetric")) { ctx->gram_symmetric = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { ctx->batch_chunk = (int)std::max<long>(4, value); return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_single")) { ctx->screen_single = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 
@@ -2479,6 +2524,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "gram_single"))   { *value = ctx->gram_single; return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_symmetric")) { *value = ctx->gram_symmetric; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { *value = ctx->batch_chunk; return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_single")) { *value = ctx->screen_single; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 

@@ -257,6 +257,10 @@ struct ss_hip_ctx {
     hipEvent_t ev_sub_sel = nullptr;  // profiling: between the subset form's selection and its solves
     hipEvent_t ev_c0a = nullptr, ev_c0b = nullptr;   // profiling: around the batch GEMM c0 = A^T y of a chunk
     int batch_subset = 1;             // option: 1 = large Gram-form batches run in the subset form (one workgroup per signal + a check over all columns)
+    void* screen = nullptr;           // sship::ScreenState* (screen.hip): fp16 copy of A, column norms, the subset's Gram matrix, residual block
+    int screen_single = 1;            // option: 1 = single fp32 signals on large dictionaries take the screened form (screen.hip), 2 = on every shape
+                                      // the form can run on (tests), 0 = never
+    int screen_failed_alloc = 0;      // the preparation did not fit: not tried again
     size_t c0_batch_rows = 0;
     // column form of mid-size batches: cache of Gram columns, row tables, pass lists (grown on demand)
     float* bcol_cache = nullptr;
@@ -403,6 +407,20 @@ uint32_t ro_slots_max(const ss_hip_ctx* ctx, bool f64);
 // subset form of the batched Gram form (subbatch.hip): select + solve + verify for the first nslots slots; c0 = A^T y of every slot
 bool sub_form_usable(ss_hip_ctx* ctx);
 size_t sub_buffer_bytes(uint32_t nslots);
+// the form's buffers inside ss_hip_ctx::sub_buf (sized by sub_buffer_bytes(nslots)) and its three stages on the context's stream
+struct SubBufs { uint32_t* sub; uint32_t* fpick; float* fval; uint32_t* hdr; uint32_t* pcol; float* LX; float* LD; };
+SubBufs sub_bufs(ss_hip_ctx* ctx, uint32_t nslots);
+hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0);
+hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs& B, uint32_t nslots, const float* G, uint32_t gpitch, int gsub,
+                            const float* c0, float tol, uint32_t max_iter);
+hipError_t launch_sub_finish(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots);
+// screened form of ONE signal (screen.hip): the subset form on the subset's own Gram matrix (formed from A), every state of
+// the path then screened against all columns by one pass over a half-precision copy of A with a rigorous error bound
+bool screen_form_usable(ss_hip_ctx* ctx);                 // shape / option test + one-time preparation (fp16 copy of A, column norms)
+hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
+                              hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
+void screen_free(ss_hip_ctx* ctx);
+double screen_read_headroom(ss_hip_ctx* ctx);             // largest (|c~| + eps) / bound of the last screened solve (synchronises)
 hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr);      // signals one pass of the engine can carry (1 without the LDS-staged sweep)
 // list[0..count) = 128-row tiles that still hold a running signal, list[rows/128] = count

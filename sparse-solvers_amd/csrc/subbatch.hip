@@ -185,8 +185,10 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                  float tol, uint32_t max_iter, int strict_sign, int zero_on_removal, int tie_guard, int tie_exit,
                  uint32_t* __restrict__ log_hdr, uint32_t* __restrict__ log_pcol, float* __restrict__ log_X, float* __restrict__ log_D,
                  float* __restrict__ x_all, uint32_t* __restrict__ gam2_all, uint32_t* __restrict__ touched2_all, uint32_t kcap,
-                 DevState* __restrict__ st_all, TraceEntry* trace, uint32_t trace_cap)
+                 DevState* __restrict__ st_all, TraceEntry* trace, uint32_t trace_cap, int gsub)
 {
+    // gsub != 0 (screened form of one signal, screen.hip): G is the subset's own Gram matrix Gs[kSbS][gpitch], rows and
+    // columns by subset index, instead of the full G = A^T A
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float sv[16];
     __shared__ uint32_t si[16];
@@ -234,8 +236,8 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
     uint32_t just_removed = 0xffffffffu;
     bool tie_any = false;
 
-    auto gather_row = [&](uint32_t p, uint32_t col) {       // Gc[p][.] = G[col][sub[.]]
-        L.Gc[(size_t)p * kSbS + j] = valid ? G[(size_t)col * gpitch + mycol] : 0.f;
+    auto gather_row = [&](uint32_t p, uint32_t col, uint32_t sidx) {       // Gc[p][.] = G[col][sub[.]]  (sidx: col's index in the subset)
+        L.Gc[(size_t)p * kSbS + j] = valid ? (gsub ? G[(size_t)sidx * gpitch + j] : G[(size_t)col * gpitch + mycol]) : 0.f;
     };
     auto direction = [&]() {                                 // ds = I * sg over the positions, one thread per row
         if (j < P) {
@@ -250,7 +252,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
     } else {
         // first pick (homotopy-cpu.cpp:217-229): inv = [1 / ||a||^2] through the norm, direction = inv * sign
         const uint32_t sp0 = s_u[0];
-        gather_row(0, idx0);
+        gather_row(0, idx0, sp0);
         __syncthreads();
         if (j == 0) {
             const float dot = L.Gc[sp0];
@@ -270,8 +272,10 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
         __syncthreads();
         lambda0 = fabsf(c0[idx0]);
         lambda_prev = lambda0;                 // (k_init leaves c_inf = lambda0, gamma = 0: the first round's lambda is "where the last step left it")
+        // (screened form: the tolerance guard of the Gram forms, k_la_init_pick's — the caller's usual engine decides what to do)
+        if (gsub && !((double)tol >= kGramGuard * (double)lambda0)) status = kStatusSubsetDecline;
 
-        for (uint32_t round = 1;; ++round) {
+        for (uint32_t round = 1; status == 0u; ++round) {
             // ---- c, q of my column: the chain over the positions -----------------------------------------------
             float cv = c0v, qv = 0.f;
             for (uint32_t p = 0; p < P; p += 4) {                     // (whole groups of 4: positions >= P carry x = d = 0 and zero rows)
@@ -369,7 +373,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 K = K_new;
             } else {
                 // the column enters at position P: its Gram row, u1 = G[idx][support], the bordered inverse (online_inverse.h:209-248)
-                gather_row(P, idx);
+                gather_row(P, idx, spi);
                 if (j == 0) { L.pcol[P] = idx; L.psub[P] = spi; L.xs[P] = 0.f; }
                 __syncthreads();
                 if (j < P) L.u1[j] = L.alive[j] ? L.Gc[(size_t)P * kSbS + L.psub[j]] : 0.f;
@@ -634,32 +638,59 @@ size_t sub_buffer_bytes(uint32_t nslots)
     return (size_t)nslots * ((size_t)kSbS * 4 + 8 + (size_t)kSbLog * 8 * 4 + (size_t)kSbRows * 4 + 2 * (size_t)kSbLog * kSbRows * 4);
 }
 
+SubBufs sub_bufs(ss_hip_ctx* ctx, uint32_t nslots)
+{
+    SubBufs B;
+    unsigned char* b = static_cast<unsigned char*>(ctx->sub_buf);
+    B.sub = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * kSbS * 4;
+    B.fpick = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * 4;
+    B.fval = reinterpret_cast<float*>(b); b += (size_t)nslots * 4;
+    B.hdr = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * kSbLog * 8 * 4;
+    B.pcol = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * kSbRows * 4;
+    B.LX = reinterpret_cast<float*>(b); b += (size_t)nslots * kSbLog * kSbRows * 4;
+    B.LD = reinterpret_cast<float*>(b);
+    return B;
+}
+
+hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0)
+{
+    hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
+    return hipGetLastError();
+}
+
+// G, gpitch: the full Gram matrix (gsub = 0) or the subset's own (gsub = 1, one slot: screen.hip)
+hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs& B, uint32_t nslots, const float* G, uint32_t gpitch, int gsub,
+                            const float* c0, float tol, uint32_t max_iter)
+{
+    hipLaunchKernelGGL(k_sub_solve, dim3(nslots), dim3(kSbS), sub_lds_bytes(), ctx->stream, G, gpitch, c0, (uint32_t)ctx->n,
+                       ctx->n_pad, (const uint32_t*)B.sub, (const uint32_t*)B.fpick, tol, max_iter, ctx->strict_sign, ctx->zero_on_removal,
+                       ctx->tie_guard, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0, B.hdr, B.pcol, B.LX, B.LD, ws.x, ws.gam, ws.touched,
+                       ws.dims.kcap, ws.st, ws.trace, ws.trace_cap, gsub);
+    return hipGetLastError();
+}
+
+hipError_t launch_sub_finish(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots)
+{
+    hipLaunchKernelGGL(k_sub_finish, dim3((nslots + 255) / 256), dim3(256), 0, ctx->stream, ws.st, nslots);
+    return hipGetLastError();
+}
+
 hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
                            hipEvent_t e0, hipEvent_t e1, hipEvent_t e2)
 {
     if (!sub_form_usable(ctx) || ctx->sub_buf == nullptr || ctx->gram_full == nullptr) return hipErrorInvalidConfiguration;
-    unsigned char* b = static_cast<unsigned char*>(ctx->sub_buf);
-    uint32_t* sub = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * kSbS * 4;
-    uint32_t* fpick = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * 4;
-    float* fval = reinterpret_cast<float*>(b); b += (size_t)nslots * 4;
-    uint32_t* hdr = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * kSbLog * 8 * 4;
-    uint32_t* pcol = reinterpret_cast<uint32_t*>(b); b += (size_t)nslots * kSbRows * 4;
-    float* LX = reinterpret_cast<float*>(b); b += (size_t)nslots * kSbLog * kSbRows * 4;
-    float* LD = reinterpret_cast<float*>(b);
+    const SubBufs B = sub_bufs(ctx, nslots);
     const uint32_t n = (uint32_t)ctx->n;
     hipStream_t s = ctx->stream;
     if (e0) (void)hipEventRecord(e0, s);
-    hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, s, c0, n, ctx->n_pad, sub, fpick, fval);
+    (void)launch_sub_select(ctx, B, nslots, c0);
     if (e0 && ctx->ev_sub_sel) (void)hipEventRecord(ctx->ev_sub_sel, s);
-    hipLaunchKernelGGL(k_sub_solve, dim3(nslots), dim3(kSbS), sub_lds_bytes(), s, (const float*)ctx->gram_full, ctx->gram_pitch, c0, n,
-                       ctx->n_pad, (const uint32_t*)sub, (const uint32_t*)fpick, tol, max_iter, ctx->strict_sign, ctx->zero_on_removal,
-                       ctx->tie_guard, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0, hdr, pcol, LX, LD, ws.x, ws.gam, ws.touched,
-                       ws.dims.kcap, ws.st, ws.trace, ws.trace_cap);
+    (void)launch_sub_solve(ctx, ws, B, nslots, (const float*)ctx->gram_full, ctx->gram_pitch, 0, c0, tol, max_iter);
     if (e1) (void)hipEventRecord(e1, s);
     hipLaunchKernelGGL(k_sub_verify, dim3((n + kVsCols - 1) / kVsCols, nslots), dim3(kVsThreads), sub_verify_lds_bytes(), s,
-                       (const float*)ctx->gram_full, ctx->gram_pitch, c0, n, ctx->n_pad, (const uint32_t*)sub, (const uint32_t*)hdr,
-                       (const uint32_t*)pcol, (const float*)LX, (const float*)LD, ctx->tie_guard, tol, ws.st);
-    hipLaunchKernelGGL(k_sub_finish, dim3((nslots + 255) / 256), dim3(256), 0, s, ws.st, nslots);
+                       (const float*)ctx->gram_full, ctx->gram_pitch, c0, n, ctx->n_pad, (const uint32_t*)B.sub, (const uint32_t*)B.hdr,
+                       (const uint32_t*)B.pcol, (const float*)B.LX, (const float*)B.LD, ctx->tie_guard, tol, ws.st);
+    (void)launch_sub_finish(ctx, ws, nslots);
     if (e2) (void)hipEventRecord(e2, s);
     return hipGetLastError();
 }

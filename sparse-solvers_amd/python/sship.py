@@ -89,6 +89,12 @@ class Stats(ctypes.Structure):
         ("sub_verify_ms", ctypes.c_double),
         ("c0_gemm_ms", ctypes.c_double),
         ("c0_gemm_flops", ctypes.c_double),
+        ("screen_signals", ctypes.c_uint64),
+        ("screen_redone", ctypes.c_uint64),
+        ("screen_launches", ctypes.c_uint64),
+        ("screen_ms", ctypes.c_double),
+        ("screen_bytes", ctypes.c_uint64),
+        ("screen_headroom", ctypes.c_double),
     ]
 
 
