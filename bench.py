@@ -388,6 +388,35 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
     st = h.stats()
     single_value = world * args.steps / elapsed
 
+    # outside the timed region: the same signals through the engine the screened form stands in for (three fp32 passes over A),
+    # with its lookahead sweep timed — what the headline was before csrc/screen.hip, and what an uncertified signal falls back to
+    unscreened = None
+    st_un = None
+    if st["screen_signals"] > 0 and rank == 0 and world == 1:
+        h.set_option("screen_single", 0)
+        h.set_profiling(True)
+        h.set_option("profile_solve_every", 4 if args.steps >= 8 else 1)
+        h.reset_stats()
+        Xu = torch.zeros((args.steps, N), device=dev, dtype=torch.float32)
+        h.solve(sigs[0][0], TOL, MAX_ITER, out=xw)
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        for s in range(args.steps):
+            h.solve(sigs[args.warmup + s][0], TOL, MAX_ITER, out=Xu[s])
+        torch.cuda.synchronize()
+        dtu = time.perf_counter() - tu
+        st_un = h.stats()
+        h.set_profiling(False)
+        h.set_option("profile_solve_every", 1)
+        h.set_option("screen_single", 1)
+        same_sup = int(((Xu != 0) == (X != 0)).all(dim=1).sum().item())
+        dmax = float(((Xu - X).abs().max() / X.abs().max()).item())
+        del Xu
+        unscreened = {"workload": "the timed signals with option screen_single = 0: A^T y + two 32-column fp32 passes over A beside the speculative "
+                                  "iterations (early form), every breakpoint verified over all columns in fp32",
+                      "ms_per_solve": dtu / args.steps * 1e3, "signals_per_s": args.steps / dtu,
+                      "same_support_as_timed_solves": same_sup, "max_rel_diff_of_coefficients": dmax}
+
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
@@ -654,6 +683,42 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             roof = hbm_roof
         s1_ms = st["sweep1_ms"] / max(1, st["sweep1_launches"])
         s1_gbs = st["sweep1_bytes"] / (s1_ms * 1e-3) / 1e9 if s1_ms > 0 else 0.0
+        screened = st["screen_signals"] > 0
+        scr_roof = None
+        if screened:
+            # screened form (csrc/screen.hip): the passes over A are c = A^T y (fp32, k_sweep) and the screening pass over the
+            # fp16 copy of A; the dominant kernel with a roofline is the GEMV the metric names
+            roof = {"bound": "hbm", "kernel": "k_sweep<float,1 rhs> c = A^T y: the correlation GEMV of the metric, the one fp32 pass over A "
+                                              "of a solve in the screened form (coalesced column loads, LDS-staged partial dot products)",
+                    "achieved": s1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s1_gbs / HBM_PEAK_GBS,
+                    "traffic": tj.get("sweep1_hbm_bytes_per_launch"), "bytes_per_launch": st["sweep1_bytes"],
+                    "avg_launch_ms": s1_ms, "launches_timed": st["sweep1_launches"],
+                    "traffic_source": ("profiles/traffic.json (%s): HBM bytes per launch from separate rocprofv3 --pmc passes (recorded once, "
+                                       "replayed here; NOT measured in this run)" % tj.get("sweep1_source")) if tj.get("sweep1_hbm_bytes_per_launch") else None}
+            sc_ms = st["screen_ms"] / max(1, st["screen_launches"])
+            sc_bytes = st["screen_bytes"] / max(1, st["screen_launches"])
+            sc_gbs = sc_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0
+            scr_roof = {"bound": "hbm", "kernel": "k_scr_gemm: C~ = A16^T [r_1 .. r_K] (v_mfma_f32_32x32x16_f16, 128 columns x 96 right-hand sides per "
+                                                  "workgroup) + the certificate |c~| + eps <= bound of every (column outside the subset, state)",
+                        "achieved": sc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sc_gbs / HBM_PEAK_GBS,
+                        "traffic": tj.get("screen_hbm_bytes_per_launch"), "bytes_per_launch": sc_bytes, "avg_launch_ms": sc_ms,
+                        "launches_timed": st["screen_launches"],
+                        "certificate_headroom": st["screen_headroom"],
+                        "note": "bytes = the fp16 copy of A (ldm * n_pad * 2) + the residual block + the column norms; headroom = largest "
+                                "(|c~| + eps) / bound of the last solve (< 1: certified)"}
+            if st_un is not None:
+                # the default engine's lookahead sweep, from the untimed run of the same signals
+                launches, ms_sum = st_un["sweep32_launches"], st_un["sweep32_ms"]
+                nb = st_un["sweep32_bytes_timed"] / launches if launches else 0.0
+                avg_ms = ms_sum / max(1, launches)
+                ach = nb / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+                hbm_roof = {"bound": "hbm", "kernel": "k_gemm32_tn_f32<128, 256, 3>, main launch of a 32-column fp32 pass of the DEFAULT engine (untimed run, "
+                                                      "option screen_single = 0), beside the speculative iterations",
+                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                            "traffic": tj.get("gemm32_hbm_bytes_per_launch"), "bytes_per_launch": nb, "avg_launch_ms": avg_ms,
+                            "launches_timed": launches}
+            else:
+                hbm_roof = None
         ms_per_step = elapsed / args.steps * 1e3
         first_ms = st["sweep64_ms"] / max(1, st["sweep64_launches"]) if st["sweep64_launches"] else 0.0
         # (device counter: sweeps of all widths; the first one of each solve is the 64-column pass when it ran)
@@ -683,23 +748,35 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             "roofline": roof,
             # the 32-column lookahead sweep (HBM-bound), when any of the timed solves needed one
             "lookahead_sweep_32rhs": hbm_roof if roof is not hbm_roof else None,
+            # screened form: the pass over the fp16 copy of A that certifies every state of the path against all columns
+            "screening_pass": scr_roof,
+            "without_screening": unscreened,
             # the plain correlation GEMV c = A^T y (k_sweep, 1 right-hand side): one per solve
             "atr_gemv": {"kernel": "k_sweep<float,1 rhs> c = A^T y", "achieved": s1_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": s1_gbs / HBM_PEAK_GBS, "bytes_per_launch": st["sweep1_bytes"],
                          "avg_launch_ms": s1_ms, "launches_timed": st["sweep1_launches"]},
             "sweeps_per_solve": {"lookahead_64rhs_first": 1.0 if st["sweep64_launches"] else 0.0,
                                  "lookahead_32rhs": max(0.0, n32) if engine >= 1 else 0.0,
-                                 "atr_1rhs": 1, "reference_gemv_per_iteration": 4},
+                                 "atr_1rhs": 1, "screening_fp16": st["screen_signals"] / max(1, st["solves"]),
+                                 "reference_gemv_per_iteration": 4},
+            "screened_form": {"signals_certified": int(st["screen_signals"]), "signals_redone_in_the_default_engine": int(st["screen_redone"])},
             # where a solve's time goes (event-timed sweeps; the rest is the iteration kernels, latency-bound)
-            "ms_per_solve": {"total": ms_per_step,
-                             "atr_1rhs_sweep": s1_ms,
-                             "lookahead_sweeps": la_ms,
-                             "iterations_and_rest": (ms_per_step - s1_ms - la_ms) if engine >= 1 else None,
-                             "us_per_iteration": (1e3 * (ms_per_step - s1_ms - la_ms) / max(1.0, st["iterations"] / max(1, st["solves"]))) if engine >= 1 else None},
+            "ms_per_solve": ({"total": ms_per_step, "atr_1rhs_sweep": s1_ms, "screening_pass": scr_roof["avg_launch_ms"],
+                              "selection_subset_gram_iterations_and_rest": ms_per_step - s1_ms - scr_roof["avg_launch_ms"],
+                              "us_per_iteration": 1e3 * (ms_per_step - s1_ms - scr_roof["avg_launch_ms"]) / max(1.0, st["iterations"] / max(1, st["solves"]))}
+                             if screened else
+                             {"total": ms_per_step,
+                              "atr_1rhs_sweep": s1_ms,
+                              "lookahead_sweeps": la_ms,
+                              "iterations_and_rest": (ms_per_step - s1_ms - la_ms) if engine >= 1 else None,
+                              "us_per_iteration": (1e3 * (ms_per_step - s1_ms - la_ms) / max(1.0, st["iterations"] / max(1, st["solves"]))) if engine >= 1 else None}),
             "batched": batched,
             "single_signal_with_gram_matrix": with_gram,
             "iterations_mean": float(iters.mean()),
-            "engine": (("lookahead (cached Gram columns), speculative iterations on the subset Gram matrix beside the passes over A "
+            "engine": ("screened form (csrc/screen.hip): c0 = A^T y in fp32, the whole path by one workgroup on the 448 columns with the largest |c0| "
+                       "(their Gram matrix formed from A on the fp32 MFMA), every state of the path certified against all columns by one pass "
+                       "over an fp16 copy of A with a rigorous error bound; an uncertified signal is solved again by the default engine") if screened else
+                      (("lookahead (cached Gram columns), speculative iterations on the subset Gram matrix beside the passes over A "
                         "(early form; every breakpoint verified over all columns)" if h.get_option("early_solo") else
                         "lookahead (cached Gram columns), speculative resident iterations (one workgroup + verification of every breakpoint)")
                        if h.get_option("la_fused") >= 3 else "lookahead (cached Gram columns), resident iteration kernel") if engine >= 1 else "one fused sweep per iteration",

@@ -379,6 +379,9 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
         HIPCHK(hipStreamSynchronize(ctx->stream));
         upload_matrix<T>(ctx, A, rs, cs);
         ctx->kind = kind;
+        // (SS_HIP_SCREEN_SINGLE = 0 / 1 / 2: the initial value of option "screen_single" — the test suite pins the engines it
+        // examines one by one with it; ss_hip_set_option overrides)
+        if (const char* ev = std::getenv("SS_HIP_SCREEN_SINGLE")) ctx->screen_single = std::max(0, std::min(2, std::atoi(ev)));
         if (kind == 1) HIPCHK(irls_factor<T>(ctx));
         else ensure_workspace<T>(ctx, 1, 64);
         HIPCHK(hipHostMalloc(&ctx->host_flags, 64 * sizeof(uint32_t), hipHostMallocMapped));
@@ -1199,6 +1202,9 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         }
         if (scr1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
             ctx->stats.screen_redone += 1;
+            if (std::getenv("SS_HIP_SUB_DEBUG"))
+                std::fprintf(stderr, "[screened form] status %u after %u iterations, %u states logged, K = %u, lambda %g, lambda0 %g\n",
+                             hs.status, hs.iter, hs.solo_nlog, hs.K, hs.c_inf, (double)hs.lambda0);
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
         }
         if (scr1 && hs.status == 0) ctx->stats.screen_signals += 1;

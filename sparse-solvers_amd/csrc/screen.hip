@@ -71,9 +71,8 @@ struct ScreenState {
     float* anorm = nullptr;      // [n_pad] ||a_i||_2, rounded up
     float* meta = nullptr;       // [0] sA  [1] 1 / sA  [2] bits(max |A|)  [3] headroom of the last solve (bits, as uint)
     __half* r16 = nullptr;       // [kScrRhs][ldm] fl16(s_k * r_k)
-    float* rn2 = nullptr;        // [kScrRhs] ||r_k||^2
+    float* rn2p = nullptr;       // [ldm / 64][kScrRhs] partial sums of ||r_k||^2, one per workgroup of k_scr_residuals
     float* tab = nullptr;        // [kScrRhs][kScrTab]
-    uint32_t* mask = nullptr;    // [n_pad / 32] bit set: the column is in the subset
     float* gs_part = nullptr;    // [kSgSplit][kSbS][kSbS]
     float* gs = nullptr;         // [kSbS][kSbS]
     int gemm_attr = -1;
@@ -210,8 +209,10 @@ void k_sgram_sum(const float* __restrict__ part, uint32_t nsplit, float* __restr
 }
 
 // ---- r_k = y - A_S x_S(k) of every logged state k >= 1, scaled and rounded to fp16 -----------------------------------
-// One workgroup per 64 rows: the support's columns' 64 rows and the coefficient table in LDS; thread = (row, states
-// sg, sg + 4, ...).  Workgroup 0 also writes the per-state table and marks the subset's columns.
+// One workgroup per 64 rows: the support's columns' 64 rows and the coefficient table (transposed: [position][state]) in
+// LDS; a thread owns 4 rows x 4 states (two 16-byte LDS reads per 16 fmas), states beyond 64 in a second round.
+// ||r_k||^2 leaves as one partial per (workgroup, state) — summed in a fixed order by the screening pass.  Workgroup 0
+// also writes the per-state table.  (Positions >= P_k carry x = 0 in the log: every state runs over all positions.)
 __device__ __forceinline__ float scr_state_scale(float lam_eff)
 {
     int e = 12;
@@ -221,14 +222,13 @@ __device__ __forceinline__ float scr_state_scale(float lam_eff)
 }
 
 __global__ __launch_bounds__(256)
-void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t m, uint32_t n, const float* __restrict__ y,
-                     const uint32_t* __restrict__ sub, const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pcol,
+void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, const float* __restrict__ y,
+                     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pcol,
                      const float* __restrict__ LX, float tol, const float* __restrict__ meta, __half* __restrict__ r16,
-                     float* __restrict__ rn2, float* __restrict__ tab, uint32_t* __restrict__ mask, DevState* __restrict__ st)
+                     float* __restrict__ rn2p, float* __restrict__ tab, uint32_t* __restrict__ headroom, DevState* __restrict__ st)
 {
     __shared__ __attribute__((aligned(16))) float sAc[kSbRows][64];
-    __shared__ __attribute__((aligned(16))) float sX[kSbLog][kSbRows];
-    __shared__ uint32_t sP[kSbLog];
+    __shared__ __attribute__((aligned(16))) float sXt[kSbRows][kSbLog];
     __shared__ float sS[kSbLog];
     if (st->status != 0u) return;
     const uint32_t nlog = st->solo_nlog;
@@ -237,13 +237,19 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t m, uin
     const uint32_t tid = threadIdx.x;
     const uint32_t r0 = blockIdx.x * 64u;
     const uint32_t Pfin = hdr[(nlog - 1u) * 8u];
-    for (uint32_t e = tid; e < nst * kSbRows; e += 256u) sX[e / kSbRows][e % kSbRows] = LX[(size_t)kSbRows + e];     // (state k = kk + 1)
-    if (tid < nst) {
-        const uint32_t* hh = hdr + (size_t)(tid + 1u) * 8u;
-        sP[tid] = hh[0];
-        const float lam = __uint_as_float(hh[4]);
-        const bool final_state = !(hh[1] & 1u);
-        sS[tid] = scr_state_scale(final_state ? fmaxf(lam, tol) : lam);
+    for (uint32_t e = tid; e < kSbLog * kSbRows; e += 256u) {
+        const uint32_t kk = e / kSbRows, p = e - kk * kSbRows;
+        sXt[p][kk] = kk < nst ? LX[(size_t)kSbRows + e] : 0.f;                 // (state k = kk + 1)
+    }
+    if (tid < kSbLog) {
+        float sc = 1.f;
+        if (tid < nst) {
+            const uint32_t* hh = hdr + (size_t)(tid + 1u) * 8u;
+            const float lam = __uint_as_float(hh[4]);
+            const bool final_state = !(hh[1] & 1u);
+            sc = scr_state_scale(final_state ? fmaxf(lam, tol) : lam);
+        }
+        sS[tid] = sc;
     }
     for (uint32_t p = tid >> 4; p < Pfin; p += 16u) {
         const uint32_t col = pcol[p];
@@ -252,23 +258,44 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t m, uin
         *reinterpret_cast<scr_v4f*>(&sAc[p][4u * (tid & 15u)]) = v;
     }
     __syncthreads();
-    const uint32_t row = tid & 63u, sg = tid >> 6;
-    const float yv = (r0 + row) < m ? y[r0 + row] : 0.f;
+    const uint32_t rg = tid & 15u, sgp = tid >> 4;
+    const scr_v4f yv = *reinterpret_cast<const scr_v4f*>(y + r0 + 4u * rg);         // (rows m .. ldm - 1 of y and of A are zero)
     bool ovf = false;
-    for (uint32_t kk = sg; kk < nst; kk += 4u) {
-        const uint32_t Pk = sP[kk];
-        float acc = yv;
-        for (uint32_t p = 0; p < Pk; ++p) acc = __builtin_fmaf(-sX[kk][p], sAc[p][row], acc);
-        if ((r0 + row) >= m) acc = 0.f;
-        const float v = acc * sS[kk];
-        if (!(fabsf(v) < 60000.f)) ovf = true;
-        r16[(size_t)kk * ldm + r0 + row] = __float2half_rn(v);
-        const float s2 = wave_sum(acc * acc);
-        if ((tid & 63u) == 0u) atomicAdd(&rn2[kk], s2);
+    for (uint32_t s0 = 4u * sgp; s0 < nst; s0 += 64u) {
+        scr_v4f acc[4] = { yv, yv, yv, yv };
+        for (uint32_t p = 0; p < Pfin; ++p) {
+            const scr_v4f a4 = *reinterpret_cast<const scr_v4f*>(&sAc[p][4u * rg]);
+            const scr_v4f x4 = *reinterpret_cast<const scr_v4f*>(&sXt[p][s0]);
+#pragma unroll
+            for (int si = 0; si < 4; ++si)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) acc[si][ri] = __builtin_fmaf(-x4[si], a4[ri], acc[si][ri]);
+        }
+#pragma unroll
+        for (int si = 0; si < 4; ++si) {
+            const uint32_t kk = s0 + (uint32_t)si;                    // (uniform over the 16 lanes of a state group)
+            float ss = 0.f;
+            const float sc = sS[kk < kSbLog ? kk : 0u];
+            __half hv[4];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const float r = acc[si][ri];
+                ss = __builtin_fmaf(r, r, ss);
+                const float v = r * sc;
+                if (kk < nst && !(fabsf(v) < 60000.f)) ovf = true;
+                hv[ri] = __float2half_rn(v);
+            }
+            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+            if (kk < nst) {
+                *reinterpret_cast<uint2*>(r16 + (size_t)kk * ldm + r0 + 4u * rg) = *reinterpret_cast<const uint2*>(hv);
+                if (rg == 0u) rn2p[(size_t)blockIdx.x * kScrRhs + kk] = ss;
+            }
+        }
     }
     if (ovf) __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blockIdx.x == 0u) {
         const float lam0 = st->lambda0;
+        if (tid == 0u) *headroom = 0u;
         if (tid < nst) {
             const uint32_t* hh = hdr + (size_t)(tid + 1u) * 8u;
             const float lam = __uint_as_float(hh[4]);
@@ -283,27 +310,25 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t m, uin
             tab[tid * kScrTab + 2] = inv_sk;
             tab[tid * kScrTab + 3] = lam;
         }
-        for (uint32_t e = tid; e < kSbS; e += 256u) {
-            const uint32_t c = sub[e];
-            if (c < n) atomicOr(&mask[c >> 5], 1u << (c & 31u));
-        }
     }
 }
 
 // ---- the screening pass: C~ = A16^T R16 and the test of every (column outside the subset, state) -------------------
-// Workgroup = 128 dictionary columns x all 96 right-hand sides; wave = 32 columns x 3 MFMA tiles of 32 states.  A stage is
-// 128 rows: 32 KB of A16 and 24 KB of R16 (from L2) land in LDS by 16-byte stores of coalesced 256-byte runs; the next
-// stage's loads are in flight under the 24 MFMAs of a wave.  HBM-bound: 1.07 GB at 8192 x 65536.
+// Workgroup = 128 dictionary columns x up to 96 right-hand sides; wave = 32 columns x 2 or 3 MFMA tiles of 32 states (the
+// third only when the path logged more than 64 states).  A stage is 128 rows: 32 KB of A16 and 16 / 24 KB of R16 (from
+// L2) land in LDS by 16-byte stores of coalesced 256-byte runs; TWO stages of loads are in flight (two register sets)
+// under the MFMAs of a third.  HBM-bound: 1.07 GB at 8192 x 65536.
 __global__ __launch_bounds__(256, 2)
 void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const __half* __restrict__ r16,
-                const float* __restrict__ anorm, const float* __restrict__ rn2, const float* __restrict__ tab,
-                const uint32_t* __restrict__ mask, const float* __restrict__ meta, DevState* __restrict__ st, uint32_t* __restrict__ headroom)
+                const float* __restrict__ anorm, const float* __restrict__ rn2p, const float* __restrict__ tab,
+                const uint32_t* __restrict__ sub, const float* __restrict__ meta, DevState* __restrict__ st, uint32_t* __restrict__ headroom)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->status != 0u) return;
     const uint32_t nlog = st->solo_nlog;
     if (nlog < 2u) return;
     const uint32_t nst = nlog - 1u;
+    const bool t3 = nst > 64u;                                   // (uniform) the third tile of states is in use
     unsigned char* sA = smem;                                   // [128][272]
     unsigned char* sR = smem + (size_t)kScrCols * kScrPitchB;   // [96][272]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -311,13 +336,18 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     const uint32_t lc = tid >> 4, piece = tid & 15u;
     const __half* ga = a16 + (size_t)(col0 + lc) * ldm + 8u * piece;
     const __half* gr = r16 + (size_t)lc * ldm + 8u * piece;
-    scr_u4 pa[8], pr[6];
-#define SCR_LOAD(R0)                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                 \
-        pa[i] = __builtin_nontemporal_load(reinterpret_cast<const scr_u4*>(ga + (size_t)(16 * i) * ldm + (R0)));  \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                                 \
-        pr[i] = *reinterpret_cast<const scr_u4*>(gr + (size_t)(16 * i) * ldm + (R0));
-    SCR_LOAD(0u)
+    scr_u4 pa0[8], pr0[6], pa1[8], pr1[6];
+#define SCR_LOAD(PA, PR, R0)                                                                                      \
+    {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                             \
+            PA[i] = __builtin_nontemporal_load(reinterpret_cast<const scr_u4*>(ga + (size_t)(16 * i) * ldm + (R0)));  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+            PR[i] = *reinterpret_cast<const scr_u4*>(gr + (size_t)(16 * i) * ldm + (R0));                         \
+        if (t3) {                                                                                                 \
+            _Pragma("unroll") for (int i = 4; i < 6; ++i)                                                         \
+                PR[i] = *reinterpret_cast<const scr_u4*>(gr + (size_t)(16 * i) * ldm + (R0));                     \
+        }                                                                                                         \
+    }
     scr_v16f acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -326,34 +356,68 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     const uint32_t r = lane & 31u, h = lane >> 5;
     const unsigned char* rdA = sA + (size_t)(32u * w + r) * kScrPitchB + 16u * h;
     const unsigned char* rdR = sR + (size_t)r * kScrPitchB + 16u * h;
-    for (uint32_t r0 = 0; r0 < ldm; r0 += kScrKc) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<scr_u4*>(sA + (size_t)(lc + 16u * (uint32_t)i) * kScrPitchB + 16u * piece) = pa[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) *reinterpret_cast<scr_u4*>(sR + (size_t)(lc + 16u * (uint32_t)i) * kScrPitchB + 16u * piece) = pr[i];
-        __syncthreads();
-        if (r0 + kScrKc < ldm) { SCR_LOAD(r0 + kScrKc) }
-#pragma unroll
-        for (uint32_t ks = 0; ks < kScrKc / 16u; ++ks) {
-            const scr_h8 bq = *reinterpret_cast<const scr_h8*>(rdA + 32u * ks);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const scr_h8 aq = *reinterpret_cast<const scr_h8*>(rdR + (size_t)(32 * t) * kScrPitchB + 32u * ks);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq, acc[t], 0, 0, 0);
-            }
-        }
+#define SCR_STAGE(PA, PR, MORE, RNEXT)                                                                                \
+    {                                                                                                             \
+        __syncthreads();                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                             \
+            *reinterpret_cast<scr_u4*>(sA + (size_t)(lc + 16u * (uint32_t)i) * kScrPitchB + 16u * piece) = PA[i]; \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+            *reinterpret_cast<scr_u4*>(sR + (size_t)(lc + 16u * (uint32_t)i) * kScrPitchB + 16u * piece) = PR[i]; \
+        if (t3) {                                                                                                 \
+            _Pragma("unroll") for (int i = 4; i < 6; ++i)                                                         \
+                *reinterpret_cast<scr_u4*>(sR + (size_t)(lc + 16u * (uint32_t)i) * kScrPitchB + 16u * piece) = PR[i]; \
+        }                                                                                                         \
+        __syncthreads();                                                                                          \
+        if (MORE) SCR_LOAD(PA, PR, (RNEXT))                                                                       \
+        _Pragma("unroll") for (uint32_t ks = 0; ks < kScrKc / 16u; ++ks) {                                        \
+            const scr_h8 bq = *reinterpret_cast<const scr_h8*>(rdA + 32u * ks);                                   \
+            const scr_h8 aq0 = *reinterpret_cast<const scr_h8*>(rdR + 32u * ks);                                  \
+            const scr_h8 aq1 = *reinterpret_cast<const scr_h8*>(rdR + (size_t)32 * kScrPitchB + 32u * ks);        \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq0, bq, acc[0], 0, 0, 0);                            \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq1, bq, acc[1], 0, 0, 0);                            \
+            if (t3) {                                                                                             \
+                const scr_h8 aq2 = *reinterpret_cast<const scr_h8*>(rdR + (size_t)64 * kScrPitchB + 32u * ks);    \
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq2, bq, acc[2], 0, 0, 0);                        \
+            }                                                                                                     \
+        }                                                                                                         \
     }
+    // (ldm is a multiple of 256: an even number of stages.)  Every workgroup starts at a row offset of its own and wraps
+    // around — the sum's order is free here — so that the 512 workgroups do not walk the same 256-byte phase of their
+    // 16-KiB-strided columns together (the HBM channels are selected by those address bits)
+    const uint32_t nstage = ldm / kScrKc;
+    const uint32_t sbase = (blockIdx.x * 29u) % nstage;
+#define SCR_ROW(S) ((sbase + (S) >= nstage ? sbase + (S) - nstage : sbase + (S)) * kScrKc)
+    SCR_LOAD(pa0, pr0, SCR_ROW(0u))
+    SCR_LOAD(pa1, pr1, SCR_ROW(1u))
+    for (uint32_t sidx = 0; sidx < nstage; sidx += 2u) {
+        SCR_STAGE(pa0, pr0, sidx + 2u < nstage, SCR_ROW(sidx + 2u))
+        SCR_STAGE(pa1, pr1, sidx + 3u < nstage, SCR_ROW(sidx + 3u))
+    }
+#undef SCR_ROW
+#undef SCR_STAGE
 #undef SCR_LOAD
-    // ---- epilogue: the per-state table into LDS, then every (column, state) of this wave ------------------------------
+    // ---- epilogue: the per-state table and the subset's columns into LDS, then every (column, state) of this wave ------
     __syncthreads();
     float* sT = reinterpret_cast<float*>(smem);                 // [96][4]: 1/(sA s_k), bound, eps factor 1 (x ||a||), eps term 2
+    uint32_t* sSub = reinterpret_cast<uint32_t*>(smem) + kScrRhs * 4u;   // [kSbS] the subset's columns, ascending (0xffffffff: none)
+    float* sPart = reinterpret_cast<float*>(smem) + kScrRhs * 4u + kSbS; // [ldm / 64][96] the partial sums of ||r_k||^2
     const float inv_sA = meta[1];
     const float sq_ldm = sqrtf((float)ldm);
+    const uint32_t nblk = ldm / 64u;
+    // (128 workgroups' partials in flight at once, summed per state in the order of the workgroups that wrote them: deterministic)
+    float s2 = 0.f;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 128u) {
+        const uint32_t nb = nblk - b0 < 128u ? nblk - b0 : 128u;
+        for (uint32_t e = tid; e < nb * kScrRhs; e += 256u) sPart[e] = rn2p[(size_t)b0 * kScrRhs + e];
+        __syncthreads();
+        if (tid < nst)
+            for (uint32_t b = 0; b < nb; ++b) s2 += sPart[(size_t)b * kScrRhs + tid];
+        __syncthreads();
+    }
     if (tid < kScrRhs) {
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
         if (tid < nst) {
-            const float rn = sqrtf(rn2[tid]) * 1.001f;
+            const float rn = sqrtf(s2) * 1.001f;
             const float inv_sk = tab[tid * kScrTab + 2];
             f0 = tab[tid * kScrTab + 0];
             f1 = tab[tid * kScrTab + 1];
@@ -362,9 +426,13 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
         }
         sT[tid * 4 + 0] = f0; sT[tid * 4 + 1] = f1; sT[tid * 4 + 2] = f2; sT[tid * 4 + 3] = f3;
     }
+    for (uint32_t e = tid; e < kSbS; e += 256u) sSub[e] = sub[e];
     __syncthreads();
     const uint32_t col = col0 + 32u * w + r;
-    const bool mine = col < n && !((mask[col >> 5] >> (col & 31u)) & 1u);
+    // is the column in the subset (k_sub_solve dealt with those)?  lower bound in the ascending list
+    uint32_t lo = 0, hi = kSbS;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sSub[mid] < col) lo = mid + 1u; else hi = mid; }
+    const bool mine = col < n && !(lo < kSbS && sSub[lo] == col);
     const float an = anorm[col < n ? col : 0u];
     bool flag = false;
     float worst = 0.f;
@@ -396,14 +464,15 @@ void screen_free(ss_hip_ctx* ctx)
 {
     ScreenState* S = scr_of(ctx);
     if (!S) return;
-    void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2, S->tab, S->mask, S->gs_part, S->gs };
+    void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete S;
     ctx->screen = nullptr;
 }
 
-static size_t scr_gemm_lds() { return (size_t)(kScrCols + kScrRhs) * kScrPitchB; }
+// (the main loop's two tiles; the epilogue's tables — 96 x 4 + 448 + 128 x 96 floats — fit inside)
+static size_t scr_gemm_lds(uint32_t) { return std::max<size_t>((size_t)(kScrCols + kScrRhs) * kScrPitchB, ((size_t)kScrRhs * 4 + kSbS + (size_t)128 * kScrRhs) * 4); }
 
 // Shape / option test, and — the first time it says yes — the preparation: the fp16 copy of A (half of A's bytes again),
 // the column norms.  A failed allocation switches the form off for this context (the default engine goes on as before).
@@ -426,14 +495,13 @@ bool screen_form_usable(ss_hip_ctx* ctx)
     alloc(reinterpret_cast<void**>(&S->anorm), (size_t)np * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->meta), 4 * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->r16), (size_t)kScrRhs * ldm * sizeof(__half));
-    alloc(reinterpret_cast<void**>(&S->rn2), (size_t)kScrRhs * sizeof(float));
+    alloc(reinterpret_cast<void**>(&S->rn2p), (size_t)(ldm / 64u) * kScrRhs * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->tab), (size_t)kScrRhs * kScrTab * sizeof(float));
-    alloc(reinterpret_cast<void**>(&S->mask), (size_t)np / 8);
     alloc(reinterpret_cast<void**>(&S->gs_part), (size_t)kSgSplit * kSbS * kSbS * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->gs), (size_t)kSbS * kSbS * sizeof(float));
     if (ok) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)scr_gemm_lds());
+                                                 (int)scr_gemm_lds(ldm));
         if (e != hipSuccess) { (void)hipGetLastError(); ok = false; }
     }
     if (!ok) { screen_free(ctx); ctx->screen_failed_alloc = 1; return false; }
@@ -469,15 +537,12 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256), dim3(256), 0, s, (const float*)S->gs_part, nsplit, S->gs);
     (void)launch_sub_solve(ctx, ws, B, 1, (const float*)S->gs, kSbS, 1, ws.c0, tol, max_iter);
     if (e1) (void)hipEventRecord(e1, s);
-    (void)hipMemsetAsync(S->rn2, 0, (size_t)kScrRhs * sizeof(float), s);
-    (void)hipMemsetAsync(S->mask, 0, (size_t)np / 8, s);
-    (void)hipMemsetAsync(reinterpret_cast<uint32_t*>(S->meta) + 3, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u), dim3(256), 0, s, At, ldm, (uint32_t)ctx->m, n, (const float*)ws.rhs,
-                       (const uint32_t*)B.sub, (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
-                       (const float*)S->meta, S->r16, S->rn2, S->tab, S->mask, ws.st);
+    hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs,
+                       (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
+                       (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st);
     if (e2) (void)hipEventRecord(e2, s);
-    hipLaunchKernelGGL(k_scr_gemm, dim3(np / kScrCols), dim3(256), scr_gemm_lds(), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
-                       (const float*)S->anorm, (const float*)S->rn2, (const float*)S->tab, (const uint32_t*)S->mask, (const float*)S->meta,
+    hipLaunchKernelGGL(k_scr_gemm, dim3(np / kScrCols), dim3(256), scr_gemm_lds(ldm), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
+                       (const float*)S->anorm, (const float*)S->rn2p, (const float*)S->tab, (const uint32_t*)B.sub, (const float*)S->meta,
                        ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3);
     if (e3) (void)hipEventRecord(e3, s);
     (void)launch_sub_finish(ctx, ws, 1);

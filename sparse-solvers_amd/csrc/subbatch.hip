@@ -157,6 +157,142 @@ void k_sub_select(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint
     for (uint32_t p = want + t; p < kSbS; p += kSelThreads) sub[p] = 0xffffffffu;
 }
 
+// ---- k_sub_select1: the same selection for ONE slot, for latency ----------------------------------------------------
+// k_sub_select walks c0 four times with four loads in flight per thread: fine with 4096 slots in the grid, 118 us for one.
+// Here one workgroup of 1024 threads reads the (<= 65536) values ONCE, 16 coalesced 16-byte loads per thread all in
+// flight together, and keeps them in registers; the two histogram levels run on the registers, the chosen columns go
+// through two LDS bit masks (above the threshold key / of the key) and are written out in column order from there.
+// Same rule, same result: the kSbS largest by the 22-bit key, left-most first within the threshold key.
+constexpr uint32_t kSel1Threads = 1024, kSel1J = 16;
+__global__ __launch_bounds__(kSel1Threads)
+void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ sub,
+                   uint32_t* __restrict__ first_pick, float* __restrict__ first_val)
+{
+    constexpr uint32_t NW = kSel1Threads / 64u;
+    __shared__ uint32_t hist[kSelBins];
+    __shared__ uint32_t m_sel[kSel1Threads * 2u], m_eq[kSel1Threads * 2u];
+    __shared__ float sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_bin, s_above;
+    __shared__ uint32_t w_tot[NW];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t want = n < kSbS ? n : kSbS;
+    v4f v[kSel1J];
+#pragma unroll
+    for (uint32_t j = 0; j < kSel1J; ++j) {
+        const uint32_t base = 4u * (j * kSel1Threads + t);
+        v[j] = base < n_pad ? *reinterpret_cast<const v4f*>(c0 + base) : v4f{ 0.f, 0.f, 0.f, 0.f };
+    }
+    m_sel[2u * t] = 0u; m_sel[2u * t + 1u] = 0u; m_eq[2u * t] = 0u; m_eq[2u * t + 1u] = 0u;
+    // exclusive prefix of a per-thread count over the workgroup (in thread order) and the total
+    auto block_excl = [&](uint32_t mine, uint32_t& total) -> uint32_t {
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += up; }
+        __syncthreads();
+        if (lane == 63u) w_tot[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine, tot = 0u;
+        for (uint32_t w = 0; w < NW; ++w) { if (w < wave) before += w_tot[w]; tot += w_tot[w]; }
+        total = tot;
+        return before;
+    };
+
+    // Level -1: a floor for the threshold from the THREADS' maxima — every one of them is an element, so the bin in which
+    // their count from the top reaches `want` is at or below the threshold's bin, and only elements from that bin up
+    // (a few hundred to a few thousand of 65536) enter the histograms.  (All 65536 in one histogram: their magnitudes share a
+    // handful of bins, the LDS atomics on those serialise — 60 of the kernel's 75 us.)
+    uint32_t prefix_key = 0, above = 0, floor_bin = 0;
+    for (int level = -1; level < 2; ++level) {
+        hist[2u * t] = 0u; hist[2u * t + 1u] = 0u;
+        __syncthreads();
+        float bv = -1.f;
+        uint32_t bi = 0xffffffffu;
+        if (level == -1) {
+            uint32_t mmax = 0u;
+            bool any = false;
+#pragma unroll
+            for (uint32_t j = 0; j < kSel1J; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t i = 4u * (j * kSel1Threads + t) + (uint32_t)e;
+                    if (i >= n) continue;
+                    const uint32_t m = mag_bits(v[j][e]);
+                    mmax = m > mmax ? m : mmax;
+                    any = true;
+                    const float a = fabsf(v[j][e]);
+                    if (better_max(a, i, bv, bi)) { bv = a; bi = i; }
+                }
+            }
+            if (any) atomicAdd(&hist[mmax >> 20], 1u);
+            // ixamax of |c0| (left-most): the first pick
+            block_reduce_pair<float, true>(bv, bi, sv, si);
+            if (t == 0) { first_pick[0] = bi == 0xffffffffu ? 0u : bi; first_val[0] = bv; }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < kSel1J; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t i = 4u * (j * kSel1Threads + t) + (uint32_t)e;
+                    if (i >= n) continue;
+                    const uint32_t m = mag_bits(v[j][e]);
+                    if (level == 0) { if ((m >> 20) >= floor_bin) atomicAdd(&hist[m >> 20], 1u); }
+                    else if ((m >> 20) == prefix_key) atomicAdd(&hist[(m >> 9) & 0x7ffu], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // thread t owns bins (from the top) 2t, 2t + 1: the crossing of `want` by the running count from the top
+        const uint32_t h0 = hist[kSelBins - 1u - 2u * t], h1 = hist[kSelBins - 2u - 2u * t];
+        uint32_t total = 0;
+        const uint32_t base_above = level == 1 ? above : 0u;
+        const uint32_t before = block_excl(h0 + h1, total);
+        if (t == 0) { s_bin = 0u; s_above = 0u; }               // (level -1 with fewer than `want` thread maxima: no floor)
+        __syncthreads();
+        if (base_above + before < want && base_above + before + h0 + h1 >= want) {
+            const uint32_t acc = base_above + before;
+            if (acc + h0 >= want) { s_bin = kSelBins - 1u - 2u * t; s_above = acc; }
+            else { s_bin = kSelBins - 2u - 2u * t; s_above = acc + h0; }
+        }
+        __syncthreads();
+        if (level == -1) floor_bin = s_bin;
+        else if (level == 0) { prefix_key = s_bin; above = s_above; }
+        else { prefix_key = (prefix_key << 11) | s_bin; above = s_above; }
+        __syncthreads();
+    }
+    const uint32_t T22 = prefix_key;
+    const uint32_t need_eq = want - above;
+#pragma unroll
+    for (uint32_t j = 0; j < kSel1J; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t i = 4u * (j * kSel1Threads + t) + (uint32_t)e;
+            if (i >= n) continue;
+            const uint32_t k = mag_bits(v[j][e]) >> 9;
+            if (k > T22) atomicOr(&m_sel[i >> 5], 1u << (i & 31u));
+            else if (k == T22) atomicOr(&m_eq[i >> 5], 1u << (i & 31u));
+        }
+    }
+    __syncthreads();
+    // thread t owns the columns 64 t .. 64 t + 63
+    const uint64_t sel64 = (uint64_t)m_sel[2u * t] | ((uint64_t)m_sel[2u * t + 1u] << 32);
+    uint64_t eq64 = (uint64_t)m_eq[2u * t] | ((uint64_t)m_eq[2u * t + 1u] << 32);
+    uint32_t tot = 0;
+    const uint32_t eq_before = block_excl((uint32_t)__popcll(eq64), tot);
+    uint32_t take = eq_before < need_eq ? need_eq - eq_before : 0u;
+    uint64_t eq_take = 0ull;
+    while (take != 0u && eq64 != 0ull) { const uint64_t low = eq64 & (0ull - eq64); eq_take |= low; eq64 ^= low; --take; }
+    uint64_t chosen = sel64 | eq_take;
+    uint32_t out = block_excl((uint32_t)__popcll(chosen), tot);
+    while (chosen != 0ull) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(chosen);
+        chosen &= chosen - 1ull;
+        if (out < kSbS) sub[out] = 64u * t + b;
+        ++out;
+    }
+    for (uint32_t p = want + t; p < kSbS; p += kSel1Threads) sub[p] = 0xffffffffu;
+}
+
 // ---- k_sub_solve: the whole path of one signal on its subset -----------------------------------------------------
 struct SubLds {
     float* Gc;         // [kSbRows][kSbS]  Gram rows of the positions, restricted to the subset
@@ -654,7 +790,10 @@ SubBufs sub_bufs(ss_hip_ctx* ctx, uint32_t nslots)
 
 hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0)
 {
-    hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
+    if (nslots == 1 && ctx->n_pad <= 4u * kSel1J * kSel1Threads)        // (one slot: the register-resident form, for latency)
+        hipLaunchKernelGGL(k_sub_select1, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
+    else
+        hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
     return hipGetLastError();
 }
 

@@ -10,6 +10,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "sparse-solvers
         sys.path.insert(0, p)
 
 
+# The engine tests of test_gpu_parity.py examine the lookahead engine's forms one by one (early form, speculative launches,
+# resident kernel ...) on shapes where a context would by default take the screened form of csrc/screen.hip instead: the
+# initial value of option "screen_single" is 0 in this process; tests/test_gpu_screen.py and test_full_size_vs_oracle set
+# the option themselves.  (bench.py and __graft_entry__.smoke() run the shipped default.)
+os.environ.setdefault("SS_HIP_SCREEN_SINGLE", "0")
+
+
 def note(test, **facts):
     """Counts a test observed but does not assert on exactly (diverged paths, tie re-runs, stuck signals):
     printed (pytest -s / the failure report shows them) and appended to gpurun_out/test_notes.jsonl, which

@@ -594,10 +594,18 @@ def test_full_size_vs_oracle(sship, c2_host_matrix):
     assert ito == k and np.array_equal(np.nonzero(xo)[0], sup)
     with sship.Homotopy(A) as h:
         h.set_option("trace", 1)
-        for engine in (1, 0):
+        # (screened, engine): the shipped default — the screened form of csrc/screen.hip —, the lookahead engine it stands
+        # in for, the sweep-per-iteration engine
+        for screen, engine in ((1, 1), (0, 1), (0, 0)):
+            h.set_option("screen_single", screen)
             h.set_option("engine", engine)
+            h.reset_stats()
             xg, itg, eg = h.solve(y, 1e-3, 256)
             trg = h.trace()
+            stg = h.stats()
+            assert stg["screen_signals"] == screen and stg["screen_redone"] == 0
+            if screen:
+                assert 0.0 < stg["screen_headroom"] < 0.6      # (the largest |c| outside the subset sits at ~0.37 lambda here)
             assert itg == ito == k
             assert np.array_equal(np.nonzero(xg)[0], np.nonzero(xo)[0])
             assert np.array_equal(np.nonzero(xg)[0], sup)

@@ -1,0 +1,131 @@
+"""GPU tests of the screened form of one fp32 signal (csrc/screen.hip; run with `-m gpu`): the subset solve on the subset's
+own Gram matrix, every state of its path certified against all columns by one pass over the fp16 copy of A.
+
+What must hold: (1) a certified signal is the oracle's — equal iterations, identical support, coefficients within 1e-5,
+the same breakpoints; (2) a signal the form cannot certify, or whose path leaves the form's common path, is solved again by
+the default engine and is THAT engine's result bit for bit; (3) the certificate is a bound, not a guess: the fp16 product
+plus its error term really dominates the fp32 correlation of every column and state.
+Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import make_gaussian_problem, note
+from test_gpu_parity import assert_parity, significant_support, MODES, set_mode
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sship():
+    import sship as mod
+    assert mod.device_count() >= 1, "no HIP device visible"
+    return mod
+
+
+SHAPES = [(1024, 8192, 16), (1024, 8192, 40), (768, 2048, 20), (2048, 16384, 48), (4096, 8192, 64), (1536, 6000, 30),
+          (1024, 1000, 12)]
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("shape", SHAPES)
+def test_screened_form_vs_oracle(sship, shape, mode):
+    """option screen_single = 2 (any shape the form can run on): well-posed Gaussian problems are certified and equal the
+    oracle — iterations, support, coefficients, breakpoints — in both modes."""
+    m, n, k = shape
+    A, y, x0, sup = make_gaussian_problem(9100 + m + k, m, n, k, np.float32)
+    with sship.Homotopy(A) as h:
+        flags = set_mode(h, mode)
+        h.set_option("screen_single", 2)
+        h.set_option("trace", 1)
+        h.reset_stats()
+        xg, itg, eg = h.solve(y, 1e-3, 4 * k)
+        trg = h.trace()
+        st = h.stats()
+    xo, ito, eo, tro = oracle.homotopy(A, y, 1e-3, 4 * k, flags=flags, trace=True)
+    assert st["screen_signals"] + st["screen_redone"] == 1
+    note("test_screened_form_vs_oracle", shape=list(shape), mode=mode, certified=st["screen_signals"], headroom=st["screen_headroom"])
+    assert_parity(xg, itg, eg, xo, ito, eo, np.float32)
+    assert np.array_equal(significant_support(xg, 1e-4), sup)
+    assert np.array_equal(trg["idx"][:-1], tro["idx"][:-1])
+    assert np.array_equal(trg["added"][:-1], tro["added"][:-1])
+    assert np.allclose(trg["gamma"][:-1], tro["gamma"][:-1], rtol=1e-3, atol=1e-6)
+    if st["screen_signals"]:
+        assert 0.0 < st["screen_headroom"] < 1.0
+
+
+def test_screened_form_hands_back_what_it_cannot_certify(sship):
+    """Signals the form must not report: a support column outside the 448 largest |c0| (dense support in few rows), paths
+    with removals in reference mode, more columns than the form holds.  Each is solved again by the default engine and is
+    that engine's result bit for bit."""
+    cases = [(400, 9000, 30, 0.0), (512, 4096, 100, 0.0), (300, 2000, 40, 0.05), (1024, 8192, 80, 0.0)]
+    redone = 0
+    for ci, (m, n, k, noise) in enumerate(cases):
+        rng = np.random.default_rng(9200 + ci)
+        A, y, x0, sup = make_gaussian_problem(9200 + ci, m, n, k, np.float32)
+        if noise:
+            y = (y + noise * rng.standard_normal(m)).astype(np.float32)
+        with sship.Homotopy(A) as h:
+            h.set_option("screen_single", 2)
+            h.reset_stats()
+            x1, it1, e1 = h.solve(y, 1e-3, 3 * k)
+            st = h.stats()
+            h.set_option("screen_single", 0)
+            x0_, it0, e0 = h.solve(y, 1e-3, 3 * k)
+        assert st["screen_signals"] + st["screen_redone"] == 1
+        redone += st["screen_redone"]
+        if st["screen_redone"]:
+            assert it1 == it0 and e1 == e0 and np.array_equal(x1, x0_), (m, n, k, "a handed-back signal is not the default engine's")
+        else:
+            xo, ito, eo = oracle.homotopy(A, y, 1e-3, 3 * k)
+            assert_parity(x1, it1, e1, xo, ito, eo, np.float32)
+    note("test_screened_form_hands_back", redone=redone, cases=len(cases))
+    assert redone >= 2
+
+
+def test_screen_certificate_is_a_bound(sship):
+    """The certificate of csrc/screen.hip, recomputed on the host in float64 from the solve's own breakpoints: for every state
+    of the path and every column outside the 448-column subset, |a_i . r_k| in float64 must be below lambda_k by at least
+    the margin whenever the device certified the signal — the fp16 pass plus its error term may be loose, never wrong."""
+    m, n, k = 2048, 16384, 40
+    A, y, x0, sup = make_gaussian_problem(9300, m, n, k, np.float32)
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.set_option("trace", 1)
+        h.reset_stats()
+        xg, itg, eg = h.solve(y, 1e-3, 4 * k)
+        tr = h.trace()
+        st = h.stats()
+        c0, _ = h.gemv_t(y)
+    assert st["screen_signals"] == 1
+    A64 = A.astype(np.float64)
+    sub = np.sort(np.argsort(-np.abs(c0), kind="stable")[:448])
+    outside = np.ones(n, dtype=bool)
+    outside[sub] = False
+    # replay the path in float64 from the trace: x after every breakpoint
+    x = np.zeros(n)
+    S = []
+    worst = 0.0
+    for t in range(1, len(tr["idx"])):
+        # state before toggle t: lambda = c_inf[t], support S (entry 0 is the first pick)
+        if t == 1:
+            S = [int(tr["idx"][0])]
+        As = A64[:, S]
+        r = y.astype(np.float64) - As @ x[S]
+        c = A64.T @ r
+        lam = float(tr["c_inf"][t])
+        if t > 1:
+            worst = max(worst, float(np.abs(c[outside]).max() / lam))
+            assert np.abs(c[outside]).max() <= 0.875 * lam + 1e-6
+        # the step: direction on S from the float64 normal equations, length gamma[t]
+        sg = np.sign(c[S])
+        d = np.linalg.solve(As.T @ As, sg)
+        x[S] += float(tr["gamma"][t]) * d
+        j = int(tr["idx"][t])
+        if tr["added"][t]:
+            S.append(j)
+        else:
+            S.remove(j)
+    note("test_screen_certificate_is_a_bound", worst_ratio=worst, headroom=st["screen_headroom"])
+    assert worst <= st["screen_headroom"] + 1e-3         # the device's figure (|c~| + eps) / bound dominates |c| / (0.875 lambda)... loosely
