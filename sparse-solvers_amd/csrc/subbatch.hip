@@ -159,9 +159,10 @@ void k_sub_select(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint
 
 // ---- k_sub_select1: the same selection for ONE slot, for latency ----------------------------------------------------
 // k_sub_select walks c0 four times with four loads in flight per thread: fine with 4096 slots in the grid, 118 us for one.
-// Here one workgroup of 1024 threads reads the (<= 65536) values ONCE, 16 coalesced 16-byte loads per thread all in
-// flight together, and keeps them in registers; the two histogram levels run on the registers, the chosen columns go
-// through two LDS bit masks (above the threshold key / of the key) and are written out in column order from there.
+// Here one workgroup of 1024 threads walks the (<= 65536) values with 16 coalesced 16-byte loads per thread all in flight
+// together (one L2 round trip per walk; holding the 64 values of a thread in registers across the levels spills at 1024
+// threads); the chosen columns go through two LDS bit masks (above the threshold key / of the key) and are written out in
+// column order from there.
 // Same rule, same result: the kSbS largest by the 22-bit key, left-most first within the threshold key.
 constexpr uint32_t kSel1Threads = 1024, kSel1J = 16;
 __global__ __launch_bounds__(kSel1Threads)
@@ -177,12 +178,6 @@ void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uin
     __shared__ uint32_t w_tot[NW];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t want = n < kSbS ? n : kSbS;
-    v4f v[kSel1J];
-#pragma unroll
-    for (uint32_t j = 0; j < kSel1J; ++j) {
-        const uint32_t base = 4u * (j * kSel1Threads + t);
-        v[j] = base < n_pad ? *reinterpret_cast<const v4f*>(c0 + base) : v4f{ 0.f, 0.f, 0.f, 0.f };
-    }
     m_sel[2u * t] = 0u; m_sel[2u * t + 1u] = 0u; m_eq[2u * t] = 0u; m_eq[2u * t + 1u] = 0u;
     // exclusive prefix of a per-thread count over the workgroup (in thread order) and the total
     auto block_excl = [&](uint32_t mine, uint32_t& total) -> uint32_t {
@@ -197,49 +192,43 @@ void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uin
         total = tot;
         return before;
     };
+    // one walk over the values: 16 coalesced 16-byte loads per thread, all in flight together (c0 sits in L2: the sweep wrote it)
+#define SEL1_WALK(BODY)                                                                        \
+    {                                                                                          \
+        v4f v_[kSel1J];                                                                        \
+        _Pragma("unroll") for (uint32_t j_ = 0; j_ < kSel1J; ++j_) {                           \
+            const uint32_t base_ = 4u * (j_ * kSel1Threads + t);                               \
+            v_[j_] = base_ < n_pad ? *reinterpret_cast<const v4f*>(c0 + base_) : v4f{ 0.f, 0.f, 0.f, 0.f }; \
+        }                                                                                      \
+        _Pragma("unroll") for (uint32_t j_ = 0; j_ < kSel1J; ++j_) {                           \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                 \
+                const uint32_t i = 4u * (j_ * kSel1Threads + t) + (uint32_t)e_;                \
+                if (i < n) { const float val = v_[j_][e_]; const uint32_t m = mag_bits(val); BODY } \
+            }                                                                                  \
+        }                                                                                      \
+    }
 
     // Level -1: a floor for the threshold from the THREADS' maxima — every one of them is an element, so the bin in which
     // their count from the top reaches `want` is at or below the threshold's bin, and only elements from that bin up
     // (a few hundred to a few thousand of 65536) enter the histograms.  (All 65536 in one histogram: their magnitudes share a
-    // handful of bins, the LDS atomics on those serialise — 60 of the kernel's 75 us.)
+    // handful of bins and the LDS atomics on those serialise.)
     uint32_t prefix_key = 0, above = 0, floor_bin = 0;
     for (int level = -1; level < 2; ++level) {
         hist[2u * t] = 0u; hist[2u * t + 1u] = 0u;
         __syncthreads();
-        float bv = -1.f;
-        uint32_t bi = 0xffffffffu;
         if (level == -1) {
-            uint32_t mmax = 0u;
+            float bv = -1.f;
+            uint32_t bi = 0xffffffffu, mmax = 0u;
             bool any = false;
-#pragma unroll
-            for (uint32_t j = 0; j < kSel1J; ++j) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t i = 4u * (j * kSel1Threads + t) + (uint32_t)e;
-                    if (i >= n) continue;
-                    const uint32_t m = mag_bits(v[j][e]);
-                    mmax = m > mmax ? m : mmax;
-                    any = true;
-                    const float a = fabsf(v[j][e]);
-                    if (better_max(a, i, bv, bi)) { bv = a; bi = i; }
-                }
-            }
+            SEL1_WALK({ mmax = m > mmax ? m : mmax; any = true; const float a = fabsf(val); if (better_max(a, i, bv, bi)) { bv = a; bi = i; } })
             if (any) atomicAdd(&hist[mmax >> 20], 1u);
             // ixamax of |c0| (left-most): the first pick
             block_reduce_pair<float, true>(bv, bi, sv, si);
             if (t == 0) { first_pick[0] = bi == 0xffffffffu ? 0u : bi; first_val[0] = bv; }
+        } else if (level == 0) {
+            SEL1_WALK({ (void)val; if ((m >> 20) >= floor_bin) atomicAdd(&hist[m >> 20], 1u); })
         } else {
-#pragma unroll
-            for (uint32_t j = 0; j < kSel1J; ++j) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t i = 4u * (j * kSel1Threads + t) + (uint32_t)e;
-                    if (i >= n) continue;
-                    const uint32_t m = mag_bits(v[j][e]);
-                    if (level == 0) { if ((m >> 20) >= floor_bin) atomicAdd(&hist[m >> 20], 1u); }
-                    else if ((m >> 20) == prefix_key) atomicAdd(&hist[(m >> 9) & 0x7ffu], 1u);
-                }
-            }
+            SEL1_WALK({ (void)val; if ((m >> 20) == prefix_key) atomicAdd(&hist[(m >> 9) & 0x7ffu], 1u); })
         }
         __syncthreads();
         // thread t owns bins (from the top) 2t, 2t + 1: the crossing of `want` by the running count from the top
@@ -262,17 +251,10 @@ void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uin
     }
     const uint32_t T22 = prefix_key;
     const uint32_t need_eq = want - above;
-#pragma unroll
-    for (uint32_t j = 0; j < kSel1J; ++j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t i = 4u * (j * kSel1Threads + t) + (uint32_t)e;
-            if (i >= n) continue;
-            const uint32_t k = mag_bits(v[j][e]) >> 9;
-            if (k > T22) atomicOr(&m_sel[i >> 5], 1u << (i & 31u));
-            else if (k == T22) atomicOr(&m_eq[i >> 5], 1u << (i & 31u));
-        }
-    }
+    SEL1_WALK({ (void)val; const uint32_t k = m >> 9;
+                if (k > T22) atomicOr(&m_sel[i >> 5], 1u << (i & 31u));
+                else if (k == T22) atomicOr(&m_eq[i >> 5], 1u << (i & 31u)); })
+#undef SEL1_WALK
     __syncthreads();
     // thread t owns the columns 64 t .. 64 t + 63
     const uint64_t sel64 = (uint64_t)m_sel[2u * t] | ((uint64_t)m_sel[2u * t + 1u] << 32);
@@ -375,10 +357,25 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
     auto gather_row = [&](uint32_t p, uint32_t col, uint32_t sidx) {       // Gc[p][.] = G[col][sub[.]]  (sidx: col's index in the subset)
         L.Gc[(size_t)p * kSbS + j] = valid ? (gsub ? G[(size_t)sidx * gpitch + j] : G[(size_t)col * gpitch + mycol]) : 0.f;
     };
+    // acc = sum_b M[b] * v[b] over the positions, the chain in position order; eight operands are read ahead of their fmas
+    // (a plain loop waits an LDS round trip per term).  Entries of I, sg, u1, u2 at positions >= P are zero: whole groups of 8.
+    auto row_dot = [&](const float* Mrow, const float* vec) -> float {
+        float acc = 0.f;
+        for (uint32_t b0 = 0; b0 < P; b0 += 8u) {
+            float mv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mv[e] = Mrow[b0 + (uint32_t)e];
+            const v4f v0 = *reinterpret_cast<const v4f*>(vec + b0), v1 = *reinterpret_cast<const v4f*>(vec + b0 + 4u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(mv[e], v0[e], acc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(mv[4 + e], v1[e], acc);
+        }
+        return acc;
+    };
     auto direction = [&]() {                                 // ds = I * sg over the positions, one thread per row
         if (j < P) {
-            float acc = 0.f;
-            for (uint32_t b = 0; b < P; ++b) acc = __builtin_fmaf(L.I[j * kSbInvPitch + b], L.sg[b], acc);
+            const float acc = row_dot(&L.I[j * kSbInvPitch], L.sg);
             L.ds[j] = L.alive[j] ? acc : 0.f;
         }
     };
@@ -476,6 +473,10 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
             const uint32_t spi = s_u[1];
             const bool added = s_u[2] == 0u;
             const uint32_t rpos = added ? P : s_u[2] - 1u;
+            // (the entering column's Gram value of my column: the round's only trip to memory, on its way under the log, the x update and
+            // their barriers; it lands in the position's row further down)
+            float gpre = 0.f;
+            if (added && P < kSbRows && valid) gpre = gsub ? G[(size_t)spi * gpitch + j] : G[(size_t)idx * gpitch + mycol];
             if (j == 0) { hdr[nlog * 8 + 2] = idx; hdr[nlog * 8 + 3] = added ? 1u : 0u; hdr[nlog * 8 + 5] = __float_as_uint(g); }
             ++nlog;
             if (trace != nullptr && j == 0 && round < trace_cap) {
@@ -499,8 +500,10 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 if (j < P) L.u2[j] = L.I[j * kSbInvPitch + rpos] * (-(1.f / dd));
                 if (j == 0) { L.xs[rpos] = 0.f; L.alive[rpos] = 0u; }
                 __syncthreads();
-                for (uint32_t e = j; e < P * P; e += kSbS) {
-                    const uint32_t a = e / P, b = e - a * P;
+                const uint32_t qa = kSbS / P, rb = kSbS - qa * P;
+                uint32_t a = j / P, b = j - a * P;
+                for (uint32_t e = j; e < P * P; e += kSbS, a += qa, b += rb) {
+                    if (b >= P) { b -= P; ++a; }
                     const float v = (a == rpos || b == rpos) ? 0.f : L.I[a * kSbInvPitch + b] + (-dd * L.u2[a]) * L.u2[b];
                     L.I[a * kSbInvPitch + b] = v;
                 }
@@ -509,27 +512,25 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 K = K_new;
             } else {
                 // the column enters at position P: its Gram row, u1 = G[idx][support], the bordered inverse (online_inverse.h:209-248)
-                gather_row(P, idx, spi);
+                L.Gc[(size_t)P * kSbS + j] = gpre;
                 if (j == 0) { L.pcol[P] = idx; L.psub[P] = spi; L.xs[P] = 0.f; }
                 __syncthreads();
                 if (j < P) L.u1[j] = L.alive[j] ? L.Gc[(size_t)P * kSbS + L.psub[j]] : 0.f;
                 __syncthreads();
-                if (j < P) {
-                    float acc = 0.f;
-                    for (uint32_t b = 0; b < P; ++b) acc = __builtin_fmaf(L.I[j * kSbInvPitch + b], L.u1[b], acc);
-                    L.u2[j] = acc;
-                }
+                if (j < P) L.u2[j] = row_dot(&L.I[j * kSbInvPitch], L.u1);
                 __syncthreads();
                 if (j == 0) {
-                    float s = 0.f;
-                    for (uint32_t b = 0; b < P; ++b) s = __builtin_fmaf(L.u1[b], L.u2[b], s);
+                    const float s = row_dot(L.u1, L.u2);
                     s_f[0] = 1.f / (L.Gc[(size_t)P * kSbS + spi] - s);
                 }
                 __syncthreads();
                 const float dv = s_f[0];
                 const uint32_t Pn = P + 1u;
-                for (uint32_t e = j; e < Pn * Pn; e += kSbS) {
-                    const uint32_t a = e / Pn, b = e - a * Pn;
+                // (element e = a * Pn + b for e = j, j + 448, ...: the row / column advance without a division per element)
+                const uint32_t qa = kSbS / Pn, rb = kSbS - qa * Pn;
+                uint32_t a = j / Pn, b = j - a * Pn;
+                for (uint32_t e = j; e < Pn * Pn; e += kSbS, a += qa, b += rb) {
+                    if (b >= Pn) { b -= Pn; ++a; }
                     float v;
                     if (a == P && b == P) v = dv;
                     else if (a == P) v = -dv * L.u2[b];

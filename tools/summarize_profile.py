@@ -87,42 +87,53 @@ def main():
                 out["overlap_us"] = ov
             lines.append("")
 
-    traffic = {}
-    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        f = glob.glob(os.path.join(src, "pmc_" + kind, "*", "*_counter_collection.csv"))
-        if not f:
+    # kernels whose HBM traffic is priced: (key in traffic.json, substring of the kernel name, algorithmic bytes per launch or None = from the bench line)
+    if len(sys.argv) > 2:
+        targets = [("gemm32" if "gemm32" in KERNEL_KEY else "sweep2", KERNEL_KEY, None)]
+    else:
+        # the screened form of a single signal (csrc/screen.hip): the fp32 GEMV c = A^T y and the screening pass over the fp16 copy of A
+        targets = [("sweep1", "k_sweep<float, 1", 8192 * 65536 * 4 + 8192 * 4 + 65536 * 4),
+                   ("screen", "k_scr_gemm", 8192 * 65536 * 2 + 96 * 8192 * 2 + 65536 * 4),
+                   ("gemm32", "k_gemm32_tn_f32<128, 256, 3", 57344 * 8192 * 4 + 32 * 8192 * 4 + 32 * 57344 * 4)]
+    for key, kkey, alg_fixed in targets:
+        traffic = {}
+        for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            f = glob.glob(os.path.join(src, "pmc_" + kind, "*", "*_counter_collection.csv"))
+            if not f:
+                continue
+            rows = list(csv.DictReader(open(f[0])))
+            vals = [float(r["Counter_Value"]) for r in rows
+                    if kkey in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            # drop the no-op launches (solve already finished): they move (almost) nothing
+            thresh = 0.5 * max(vals) if vals else 0
+            vals = [v for v in vals if v >= thresh]
+            if vals:
+                traffic[counter] = {"launches": len(vals), "mean_raw_KiB": statistics.mean(vals)}
+        if not traffic:
             continue
-        rows = list(csv.DictReader(open(f[0])))
-        vals = [float(r["Counter_Value"]) for r in rows
-                if KERNEL_KEY in r["Kernel_Name"] and r["Counter_Name"] == counter]
-        # drop the no-op launches (solve already finished): they move (almost) nothing
-        thresh = 0.5 * max(vals) if vals else 0
-        vals = [v for v in vals if v >= thresh]
-        if vals:
-            traffic[counter] = {"launches": len(vals), "mean_raw_KiB": statistics.mean(vals)}
-    if traffic:
         rd = traffic.get("FETCH_SIZE", {}).get("mean_raw_KiB", 0.0) * 1024 * 2
         wr = traffic.get("WRITE_SIZE", {}).get("mean_raw_KiB", 0.0) * 1024
-        key = "gemm32" if "gemm32" in KERNEL_KEY else "sweep2"
         out[key + "_hbm_read_bytes_per_launch"] = rd
         out[key + "_hbm_write_bytes_per_launch"] = wr
         out[key + "_hbm_bytes_per_launch"] = rd + wr
-        out["pmc_raw"] = traffic
-        nrhs = 32 if key == "gemm32" else 2
-        alg = 8192 * 65536 * 4 + nrhs * 8192 * 4 + nrhs * 65536 * 4
-        # (the bench line of the traced run knows the timed launch's own algorithmic bytes — the main launch of a pass that
-        # is dealt out by shader engine covers 57344 of the 65536 columns)
-        blog = os.path.join(src, "bench_trace.log")
-        if os.path.exists(blog):
-            for ln in open(blog):
-                if ln.startswith("{"):
-                    try:
-                        alg = int(json.loads(ln)["roofline"]["bytes_per_launch"])
-                    except Exception:
-                        pass
-        lines += ["## HBM traffic of `%s` (PMC, separate passes)" % KERNEL_KEY, "",
-                  "- FETCH_SIZE mean %.1f KiB x 1024 x 2 (gfx950 correction) = %.0f B read" % (
-                      traffic.get("FETCH_SIZE", {}).get("mean_raw_KiB", 0.0), rd),
+        out.setdefault("pmc_raw", {})[key] = traffic
+        alg = alg_fixed
+        if alg is None:
+            nrhs = 32 if key == "gemm32" else 2
+            alg = 8192 * 65536 * 4 + nrhs * 8192 * 4 + nrhs * 65536 * 4
+            # (the bench line of the traced run knows the timed launch's own algorithmic bytes — the main launch of a pass that
+            # is dealt out by shader engine covers 57344 of the 65536 columns)
+            blog = os.path.join(src, "bench_trace.log")
+            if os.path.exists(blog):
+                for ln in open(blog):
+                    if ln.startswith("{"):
+                        try:
+                            alg = int(json.loads(ln)["roofline"]["bytes_per_launch"])
+                        except Exception:
+                            pass
+        lines += ["## HBM traffic of `%s` (PMC, separate passes)" % kkey, "",
+                  "- FETCH_SIZE mean %.1f KiB x 1024 x 2 (gfx950 correction) = %.0f B read (%d launches)" % (
+                      traffic.get("FETCH_SIZE", {}).get("mean_raw_KiB", 0.0), rd, traffic.get("FETCH_SIZE", {}).get("launches", 0)),
                   "- WRITE_SIZE mean %.1f KiB x 1024 = %.0f B written" % (
                       traffic.get("WRITE_SIZE", {}).get("mean_raw_KiB", 0.0), wr),
                   "- algorithmic bytes per launch: %d; traffic / algorithmic = %.4f" % (alg, (rd + wr) / alg), ""]
