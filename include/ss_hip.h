@@ -364,6 +364,16 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    |A^T y| and every breakpoint is then checked against all columns by the same chain of fmas; a signal
  *                    the form declines (left its common path) or whose check fails is solved again in the lock-step
  *                    form (ss_hip_stats::subset_signals / subset_redone); 0 = the lock-step form for all
+ *   "screen_single"  1 (default) = single fp32 signals on dictionaries of >= 16 Mi entries and >= 8192 columns take the
+ *                    SCREENED form (csrc/screen.hip): c0 = A^T y in fp32, the whole path by one workgroup on the 448 columns
+ *                    with the largest |c0| (their Gram matrix formed from A), then ONE pass over an fp16 copy of A (kept by
+ *                    the context: half of A's bytes again) that certifies every state of the path against all columns —
+ *                    |c~| + eps <= 7/8 lambda with eps = 2^-9 ||a_i|| ||r_k|| + flush terms, a rigorous bound.  Nothing
+ *                    reported comes from that pass; a signal it cannot certify, or whose path leaves the subset form's
+ *                    common path, is solved again by the default engine (ss_hip_stats::screen_signals / screen_redone).
+ *                    2 = on every shape the form can run on (tests); 0 = never.  Initial value: environment variable
+ *                    SS_HIP_SCREEN_SINGLE when set.  Stands in for the default speculative engine only ("la_fused" = 3,
+ *                    "early_solo" = 1); with G = A^T A in HBM the subset form on G is used instead ("gram_single").
  *   "ro_slots"       1..4 (default 4): signals the reference-order engine runs in lock-step per pass over A (batches in
  *                    engine 3, a batch's tie re-runs); every signal's words are those of its own solve
  *   "ro_staged"      1 (default) = its sweep stages the dictionary through LDS (coalesced loads); 0 = direct 16-byte
