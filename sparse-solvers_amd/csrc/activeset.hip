@@ -1339,8 +1339,11 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
                T* pmax_val, uint32_t* pmax_idx, T* pmin_val, uint32_t* pmin_idx,
                uint32_t* gam2, uint32_t* touched2, T* inv0, T* inv1, T* u1, T* u2, T* sgn,
                T* __restrict__ tcand, SlotDims L, DevState* st, uint32_t* hflags,
-               TraceEntry* trace, uint32_t trace_cap, int zero_on_removal, int tie_guard, uint64_t* dbg)
+               TraceEntry* trace, uint32_t trace_cap, int zero_on_removal, int tie_guard, uint64_t* dbg,
+               unsigned char* slog, uint32_t slog_cap, uint32_t slog_kmax)
 {
+    // slog (optional, screen.hip's fp64 form): the state every launch STARTS from — lambda and the non-zero coefficients —
+    // logged by workgroup 0: cnt[cap] u32, lambda[cap] f64, cols[cap][kmax] u32, vals[cap][kmax] T
     uint64_t ts[8];
     ts[0] = wall_clock64();
     __shared__ T sv[16];
@@ -1439,6 +1442,24 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
     T c_inf;
     uint32_t imax;
     reduce_partials_agent(pmax_val, pmax_idx, gridDim.x, c_inf, imax, sv, si);
+
+    if (slog != nullptr && blockIdx.x == 0) {
+        const uint32_t t = round - 1u;
+        if (t < slog_cap) {
+            uint32_t* l_cnt = reinterpret_cast<uint32_t*>(slog);
+            double* l_lam = reinterpret_cast<double*>(slog + (((size_t)slog_cap * 4 + 7) & ~(size_t)7));
+            uint32_t* l_cols = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(l_lam) + (size_t)slog_cap * 8);
+            T* l_vals = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(l_cols) + ((((size_t)slog_cap * slog_kmax * 4) + 7) & ~(size_t)7));
+            const bool fits = nt <= slog_kmax;
+            if (fits)
+                for (uint32_t j = tid; j < nt; j += blockDim.x) {
+                    const uint32_t col = touched[j];
+                    l_cols[(size_t)t * slog_kmax + j] = col;
+                    l_vals[(size_t)t * slog_kmax + j] = x[col];
+                }
+            if (tid == 0) { l_cnt[t] = fits ? nt : 0xffffffffu; l_lam[t] = (double)c_inf; }
+        }
+    }
 
     // do { ... } while (iter < max_iter && c_inf > tolerance)   (homotopy-cpu.cpp:236,272)
     if ((round > 1 && !(c_inf > tol)) || round > max_iter) {
@@ -1958,7 +1979,8 @@ hipError_t launch_la_iter(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32
                        (const T*)ws.gcache, (const int32_t*)ws.slot_of, (const T*)ws.c0, ws.gpitch,
                        ws.c, ws.q, ws.x, ws.d, ws.insup, ws.pmax_val, ws.pmax_idx, ws.pmin_val, ws.pmin_idx,
                        ws.gam, ws.touched, ws.inv[0], ws.inv[1], ws.u1, ws.u2, ws.sgn, ws.tcand, ws.dims, ws.st,
-                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.la_dbg);
+                       ctx->dev_flags, ws.trace, ws.trace_cap, ctx->zero_on_removal, ctx->tie_guard, ws.la_dbg,
+                       static_cast<unsigned char*>(ctx->slog), ctx->slog_cap, ctx->slog_kmax);
     return hipGetLastError();
 }
 

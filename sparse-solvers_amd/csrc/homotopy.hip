@@ -830,6 +830,14 @@ inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, u
     return launch_screen_form(ctx, ws, tol, max_iter, nullptr, nullptr, e2, e3);
 }
 inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
+// (typed shims of the fp64 screened form: never reached for float)
+inline hipError_t scr64_gather(ss_hip_ctx* ctx, const double* c0) { return screen64_gather(ctx, c0); }
+inline hipError_t scr64_gather(ss_hip_ctx*, const float*) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K, hipEvent_t e2, hipEvent_t e3)
+{
+    return screen64_certify(ctx, ws, y, T, tol, c_inf, K, e2, e3);
+}
+inline hipError_t scr64_certify(ss_hip_ctx*, Workspace<float>&, const float*, uint32_t, float, double, uint32_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
 
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
@@ -919,7 +927,12 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         // (la_fused = 3 with the early form: contexts whose options ask for another engine get that engine).
         bool scr1 = la && sizeof(T) == 4 && !no_sub && !sub1 && ctx->la_fused >= 3 && ctx->early_solo && !ctx->early_probe &&
                     ctx->solo_subset == 256 && screen_form_usable(ctx);
-        if ((sub1 || scr1) && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; scr1 = false; }
+        // fp64: the same certificate around the fp64 engine — the path is solved by a context of its own on the 2048 columns with
+        // the largest |c0| (passes and iterations on 1.6 % of the dictionary), its logged states are screened against all columns
+        bool scr64 = la && sizeof(T) == 8 && !no_sub && !ctx->tracing && rec_out == nullptr && ctx->la_fused >= 1 && max_iter < 190u * 4u &&
+                     screen64_usable(ctx);
+        if ((sub1 || scr1 || scr64) && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; scr1 = false; scr64 = false; }
+        uint32_t scr_launches = 1;
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
         bool spec_epilogue = false, pump_enqueued = false;
         const bool x_on_device = x != nullptr && is_device_pointer(x);
@@ -976,6 +989,44 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
             if (!ws.gram_is_full) HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // nothing cached yet
+        } else if (scr64) {
+            Lookahead<T>::ensure(ctx, ws, kcap);
+            HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y
+            uint32_t nb1 = 0;
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+            HIPCHK(scr64_gather(ctx, ws.c0));
+            HIPCHK(hipStreamSynchronize(st));
+            bool handed_back = true;
+            if constexpr (sizeof(T) == 8) {
+                ss_hip_ctx* sub = screen64_sub(ctx);
+                sub->strict_sign = ctx->strict_sign; sub->zero_on_removal = ctx->zero_on_removal; sub->tie_guard = ctx->tie_guard;
+                sub->tie_rerun = ctx->tie_rerun; sub->engine = ctx->engine; sub->lookahead = ctx->lookahead;
+                sub->sweep_f64_variant = 2;               // (128-column tiles: the sub-dictionary has 16 of them)
+                const uint64_t ties0 = sub->stats.tie_reruns, gf0 = sub->stats.gram_fallbacks, pf0 = sub->stats.persist_fallbacks;
+                uint32_t it_s = 0;
+                double e_s = 0.0;
+                const int rc_s = solve_impl<T>(sub, ws.rhs, 1, tol, max_iter, screen64_xsub(ctx), 1, &it_s, &e_s, err, errlen, false, false, false,
+                                               nullptr, 0, false, true);
+                HIPCHK(hipSetDevice(ctx->device));
+                const bool clean = rc_s == SS_HIP_OK && sub->stats.tie_reruns == ties0 && sub->stats.gram_fallbacks == gf0 &&
+                                   sub->stats.persist_fallbacks == pf0 && it_s >= 1u && it_s <= 192u;
+                if (clean) {
+                    const DevState hsub = *static_cast<const DevState*>(sub->hs_pinned);
+                    hipEvent_t e2 = nullptr, e3 = nullptr;
+                    if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); }
+                    HIPCHK(scr64_certify(ctx, ws, ws.rhs, it_s, tol, e_s, hsub.K, e2, e3));
+                    if (prof) { ctx->prof_kind.push_back(6); ++nprof; }
+                    scr_launches = (it_s + 95u) / 96u;
+                    handed_back = false;
+                }
+            }
+            if (handed_back) {
+                // the sub-context's solve left its common path (a tie re-run, a residual-form retry, too many states): the usual engine
+                ctx->stats.screen_redone += 1;
+                return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
+            }
         } else if (sub1 || scr1) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y
@@ -1055,7 +1106,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
         volatile uint32_t* hf = ctx->host_flags;
         const uint64_t last_round = (uint64_t)max_iter + 1;
-        if (sub1 || scr1) {
+        if (sub1 || scr1 || scr64) {
             // (everything is queued: selection, the solve, the check)
         } else if ((la && ctx->la_fused) || la_omp) {
             // Fused lookahead engine: every launch of k_la_iter performs the next iteration, or
@@ -1190,7 +1241,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             ctx->stats.tie_reruns += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, false, false, no_solo, rec_out, kmax, true);
         }
-        if (sub1 || scr1) {
+        if (sub1 || scr1 || scr64) {
             // (a context whose signals the form hands back more often than not stops trying for a while)
             ctx->sub_seen += 1;
             if (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail) ctx->sub_failed += 1;
@@ -1200,14 +1251,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 ctx->sub_failed = 0;
             }
         }
-        if (scr1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
+        if ((scr1 || scr64) && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
             ctx->stats.screen_redone += 1;
             if (std::getenv("SS_HIP_SUB_DEBUG"))
                 std::fprintf(stderr, "[screened form] status %u after %u iterations, %u states logged, K = %u, lambda %g, lambda0 %g\n",
                              hs.status, hs.iter, hs.solo_nlog, hs.K, hs.c_inf, (double)hs.lambda0);
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
         }
-        if (scr1 && hs.status == 0) ctx->stats.screen_signals += 1;
+        if ((scr1 || scr64) && hs.status == 0) ctx->stats.screen_signals += 1;
         if (sub1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
             ctx->stats.subset_redone += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
@@ -1309,9 +1360,9 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     ctx->stats.sweep1_ms += ms;
                 } else if (ctx->prof_kind[i] == 6) {
                     // the screening pass: fp16 copy of A + the residual block (re-read from L2 by every workgroup: not counted) + norms
-                    ctx->stats.screen_launches += 1;
+                    ctx->stats.screen_launches += scr_launches;
                     ctx->stats.screen_ms += ms;
-                    ctx->stats.screen_bytes += (uint64_t)ctx->ldm * ctx->n_pad * 2ull + 96ull * ctx->ldm * 2ull + (uint64_t)ctx->n_pad * 4ull;
+                    ctx->stats.screen_bytes += (uint64_t)scr_launches * ((uint64_t)ctx->ldm * ctx->n_pad * 2ull + 96ull * ctx->ldm * 2ull + (uint64_t)ctx->n_pad * 4ull);
                 } else if (ctx->prof_kind[i] == 4) {
                     if (ms > 0.02f) {                          // (a launch of a solve that ended at the first pick is a no-op)
                         ctx->stats.sweep64_launches += 1;

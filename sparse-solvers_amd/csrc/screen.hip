@@ -63,6 +63,9 @@ constexpr uint32_t kSgSplit = 8;                 // row chunks of the subset Gra
 constexpr uint32_t kSgT = 64;                    // its tile: 64 x 64 outputs per workgroup, a 32 x 32 quadrant per wave
 constexpr uint32_t kSgStep = 64;                 // rows staged per step
 constexpr uint32_t kSgPitchF = kSgStep + 4;      // floats per LDS row
+constexpr uint32_t kS64Sub = 2048;               // fp64 form: columns of the sub-dictionary the path is solved on
+constexpr uint32_t kS64Rhs = 192;                // ... states it can certify (two launches of the screening pass)
+constexpr uint32_t kS64LogCap = 200, kS64LogK = 200;   // ... state log of the sub-context: states, coefficients per state
 static_assert(kSbS % kSgT == 0, "subset Gram tiles");
 static_assert(kSbLog - 1 <= kScrRhs, "screening pass: right-hand sides");
 
@@ -76,19 +79,26 @@ struct ScreenState {
     float* gs_part = nullptr;    // [kSgSplit][kSbS][kSbS]
     float* gs = nullptr;         // [kSbS][kSbS]
     int gemm_attr = -1;
+    // fp64 form: the path is solved by a context of its own over a sub-dictionary of kS64Sub columns
+    ss_hip_ctx* sub = nullptr;
+    float* cabs = nullptr;       // [n_pad] float(|c0|): what the selection ranks
+    uint32_t* sublist = nullptr; // [kS64Sub] the sub-dictionary's columns, ascending; then first pick + value (2 words)
+    double* xsub = nullptr;      // [kS64Sub] the sub-context's solution
+    double* xd = nullptr;        // [kS64LogK][kS64Rhs + 8] coefficients of the screened states over the final list of touched columns (transposed)
+    uint32_t* ctl = nullptr;     // [8] device words: [0] failure raised while the certificate was prepared
 };
 
 // ---- one-time preparation ---------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256)
-void k_a16_stats(const float* __restrict__ At, uint32_t ldm, float* __restrict__ anorm, float* __restrict__ meta)
+void k_a16_stats(const T* __restrict__ At, uint32_t ldm, float* __restrict__ anorm, float* __restrict__ meta)
 {
     __shared__ float sv[16];
-    const float* a = At + (size_t)blockIdx.x * ldm;
+    const T* a = At + (size_t)blockIdx.x * ldm;
     float ss = 0.f, mx = 0.f;
     for (uint32_t r = threadIdx.x * 4u; r < ldm; r += 1024u) {
-        const scr_v4f v = *reinterpret_cast<const scr_v4f*>(a + r);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ss = __builtin_fmaf(v[e], v[e], ss); mx = fmaxf(mx, fabsf(v[e])); }
+        for (int e = 0; e < 4; ++e) { const float v = (float)a[r + (uint32_t)e]; ss = __builtin_fmaf(v, v, ss); mx = fmaxf(mx, fabsf(v)); }
     }
     ss = block_sum(ss, sv);
     __syncthreads();
@@ -99,7 +109,7 @@ void k_a16_stats(const float* __restrict__ At, uint32_t ldm, float* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-        anorm[blockIdx.x] = sqrtf(ss) * 1.0001f;                       // (rounded up: it scales an upper bound)
+        anorm[blockIdx.x] = sqrtf(ss) * 1.0001f;                       // (rounded up: it scales an upper bound; fp64 sources: the cast's 2^-24 is inside)
         atomicMax(reinterpret_cast<uint32_t*>(meta) + 2, __float_as_uint(mx));
     }
 }
@@ -114,15 +124,16 @@ __global__ void k_a16_scale(float* __restrict__ meta)
     meta[1] = ldexpf(1.f, -e);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256)
-void k_a16_convert(const float* __restrict__ At, size_t total8, const float* __restrict__ meta, __half* __restrict__ a16)
+void k_a16_convert(const T* __restrict__ At, size_t total8, const float* __restrict__ meta, __half* __restrict__ a16)
 {
-    const float sA = meta[0];
+    // (fp64 sources: one rounding, double -> half, of the exactly scaled value)
+    const T sA = (T)meta[0];
     for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256u) {
-        const scr_v4f v0 = *reinterpret_cast<const scr_v4f*>(At + 8u * i), v1 = *reinterpret_cast<const scr_v4f*>(At + 8u * i + 4u);
         scr_h8 h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { h[e] = (_Float16)(v0[e] * sA); h[4 + e] = (_Float16)(v1[e] * sA); }
+        for (int e = 0; e < 8; ++e) h[e] = (_Float16)(At[8u * i + (size_t)e] * sA);
         *reinterpret_cast<scr_h8*>(a16 + 8u * i) = h;
     }
 }
@@ -320,14 +331,20 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
 // under the MFMAs of a third.  HBM-bound: 1.07 GB at 8192 x 65536.
 __global__ __launch_bounds__(256, 2)
 void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const __half* __restrict__ r16,
-                const float* __restrict__ anorm, const float* __restrict__ rn2p, const float* __restrict__ tab,
-                const uint32_t* __restrict__ sub, const float* __restrict__ meta, DevState* __restrict__ st, uint32_t* __restrict__ headroom)
+                const float* __restrict__ anorm, const float* __restrict__ rn2p, uint32_t rn_pitch, const float* __restrict__ tab,
+                const uint32_t* __restrict__ sub, uint32_t nsub, const float* __restrict__ meta, DevState* __restrict__ st,
+                uint32_t* __restrict__ headroom, uint32_t nst_fixed)
 {
+    // nst_fixed = 0: the fp32 form — the number of states and the go-ahead come from the slot's state (k_sub_solve's log);
+    // > 0: that many states (<= 96) of the caller's block of right-hand sides (the fp64 form: r16, rn2p, tab point at it)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (st->status != 0u) return;
-    const uint32_t nlog = st->solo_nlog;
-    if (nlog < 2u) return;
-    const uint32_t nst = nlog - 1u;
+    uint32_t nst = nst_fixed;
+    if (nst_fixed == 0u) {
+        if (st->status != 0u) return;
+        const uint32_t nlog = st->solo_nlog;
+        if (nlog < 2u) return;
+        nst = nlog - 1u;
+    }
     const bool t3 = nst > 64u;                                   // (uniform) the third tile of states is in use
     unsigned char* sA = smem;                                   // [128][272]
     unsigned char* sR = smem + (size_t)kScrCols * kScrPitchB;   // [96][272]
@@ -399,8 +416,8 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     // ---- epilogue: the per-state table and the subset's columns into LDS, then every (column, state) of this wave ------
     __syncthreads();
     float* sT = reinterpret_cast<float*>(smem);                 // [96][4]: 1/(sA s_k), bound, eps factor 1 (x ||a||), eps term 2
-    uint32_t* sSub = reinterpret_cast<uint32_t*>(smem) + kScrRhs * 4u;   // [kSbS] the subset's columns, ascending (0xffffffff: none)
-    float* sPart = reinterpret_cast<float*>(smem) + kScrRhs * 4u + kSbS; // [ldm / 64][96] the partial sums of ||r_k||^2
+    uint32_t* sSub = reinterpret_cast<uint32_t*>(smem) + kScrRhs * 4u;   // [nsub] the subset's columns, ascending (0xffffffff: none)
+    float* sPart = reinterpret_cast<float*>(smem) + kScrRhs * 4u + nsub; // [128][96] partial sums of ||r_k||^2, 128 workgroups' at a time
     const float inv_sA = meta[1];
     const float sq_ldm = sqrtf((float)ldm);
     const uint32_t nblk = ldm / 64u;
@@ -408,7 +425,7 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     float s2 = 0.f;
     for (uint32_t b0 = 0; b0 < nblk; b0 += 128u) {
         const uint32_t nb = nblk - b0 < 128u ? nblk - b0 : 128u;
-        for (uint32_t e = tid; e < nb * kScrRhs; e += 256u) sPart[e] = rn2p[(size_t)b0 * kScrRhs + e];
+        for (uint32_t e = tid; e < nb * kScrRhs; e += 256u) { const uint32_t b = e / kScrRhs, k = e - b * kScrRhs; sPart[e] = rn2p[(size_t)(b0 + b) * rn_pitch + k]; }
         __syncthreads();
         if (tid < nst)
             for (uint32_t b = 0; b < nb; ++b) s2 += sPart[(size_t)b * kScrRhs + tid];
@@ -421,18 +438,18 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
             const float inv_sk = tab[tid * kScrTab + 2];
             f0 = tab[tid * kScrTab + 0];
             f1 = tab[tid * kScrTab + 1];
-            f2 = 0.001953125f * rn + 6.103515625e-05f * sq_ldm * inv_sk;        // x ||a_i||:  2^-9 ||r_k|| + 2^-14 sqrt(ldm) / s_k
+            f2 = 0.0019726562f * rn + 6.103515625e-05f * sq_ldm * inv_sk;       // x ||a_i||:  2^-9 (+ 1 %) ||r_k|| + 2^-14 sqrt(ldm) / s_k
             f3 = 6.103515625e-05f * sq_ldm * rn * inv_sA;                        // 2^-14 sqrt(ldm) ||r_k|| / sA
         }
         sT[tid * 4 + 0] = f0; sT[tid * 4 + 1] = f1; sT[tid * 4 + 2] = f2; sT[tid * 4 + 3] = f3;
     }
-    for (uint32_t e = tid; e < kSbS; e += 256u) sSub[e] = sub[e];
+    for (uint32_t e = tid; e < nsub; e += 256u) sSub[e] = sub[e];
     __syncthreads();
     const uint32_t col = col0 + 32u * w + r;
     // is the column in the subset (k_sub_solve dealt with those)?  lower bound in the ascending list
-    uint32_t lo = 0, hi = kSbS;
+    uint32_t lo = 0, hi = nsub;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sSub[mid] < col) lo = mid + 1u; else hi = mid; }
-    const bool mine = col < n && !(lo < kSbS && sSub[lo] == col);
+    const bool mine = col < n && !(lo < nsub && sSub[lo] == col);
     const float an = anorm[col < n ? col : 0u];
     bool flag = false;
     float worst = 0.f;
@@ -457,6 +474,196 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     if (lane == 0u && worst > 0.f) atomicMax(headroom, __float_as_uint(worst));
 }
 
+
+// ======== fp64: the same certificate around the launch-per-iteration engine ============================================
+// No fp64 subset solve fits one workgroup's LDS (128 positions x 448 columns x 8 bytes).  The fp64 form therefore solves the
+// path with the EXISTING fp64 engine on a sub-dictionary — the kS64Sub columns with the largest |c0|, gathered into a context
+// of their own, where a pass over "A" is 268 MB instead of 16 GiB and an iteration touches 2048 columns instead of 131 072
+// — and certifies every state of that path (k_la_iter logs them: DevState / ss_hip_ctx::slog) against all columns of the
+// full dictionary with the same fp16 screening pass.  Reported values are the sub-context's fp64 arithmetic.
+
+__global__ __launch_bounds__(256)
+void k_s64_cabs(const double* __restrict__ c0, uint32_t n, uint32_t n_pad, float* __restrict__ cabs)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_pad) cabs[i] = i < n ? (float)fabs(c0[i]) : 0.f;
+}
+
+// sub-dictionary: column j of dst = column sub[j] of src (16-byte copies; a missing entry leaves a zero column)
+__global__ __launch_bounds__(256)
+void k_s64_gather(const double* __restrict__ src, uint32_t ldm, uint32_t n, const uint32_t* __restrict__ sub, double* __restrict__ dst)
+{
+    const uint32_t j = blockIdx.x;
+    const uint32_t col = sub[j];
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d* s2 = reinterpret_cast<const v2d*>(src + (size_t)(col < n ? col : 0u) * ldm);
+    v2d* d2 = reinterpret_cast<v2d*>(dst + (size_t)j * ldm);
+    for (uint32_t r = threadIdx.x; r < ldm / 2u; r += 256u) d2[r] = col < n ? s2[r] : v2d{ 0.0, 0.0 };
+}
+
+// The states' coefficients over ONE list — the final list of touched columns (sub-indices, ascending: every earlier list is a
+// subset of it) — transposed: xd[u][kk] = coefficient of list entry u in state kk + 1.  One workgroup per state.
+__global__ __launch_bounds__(256)
+void k_s64_dense(const unsigned char* __restrict__ slog, uint32_t T, double* __restrict__ xd, uint32_t* __restrict__ ctl)
+{
+    const uint32_t* l_cnt = reinterpret_cast<const uint32_t*>(slog);
+    const double* l_lam = reinterpret_cast<const double*>(slog + (((size_t)kS64LogCap * 4 + 7) & ~(size_t)7));
+    const uint32_t* l_cols = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(l_lam) + (size_t)kS64LogCap * 8);
+    const double* l_vals = reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(l_cols) + ((((size_t)kS64LogCap * kS64LogK * 4) + 7) & ~(size_t)7));
+    const uint32_t kk = blockIdx.x, t = kk + 1u;
+    const uint32_t nfin = l_cnt[T], cnt = l_cnt[t];
+    constexpr uint32_t pitch = kS64Rhs + 8u;
+    if (nfin == 0xffffffffu || cnt == 0xffffffffu || cnt > nfin || nfin > kS64LogK) { if (threadIdx.x == 0) ctl[0] = 1u; return; }
+    const uint32_t* fin = l_cols + (size_t)T * kS64LogK;
+    for (uint32_t u = threadIdx.x; u < kS64LogK; u += 256u) xd[(size_t)u * pitch + kk] = 0.0;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < cnt; j += 256u) {
+        const uint32_t col = l_cols[(size_t)t * kS64LogK + j];
+        uint32_t lo = 0, hi = nfin;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (fin[mid] < col) lo = mid + 1u; else hi = mid; }
+        if (lo < nfin && fin[lo] == col) xd[(size_t)lo * pitch + kk] = l_vals[(size_t)t * kS64LogK + j];
+        else ctl[0] = 1u;                                     // (a column that left the list: cannot happen, lists only grow)
+    }
+}
+
+// r_k = y - A_sub[:, list] xd[:, k] in fp64, scaled and rounded to fp16; partial sums of ||r_k||^2; workgroup 0: the table.
+// One workgroup per 64 rows, a thread owns 4 rows x 4 states x 3 rounds of 64 states; the list is walked 16 entries at a time.
+__global__ __launch_bounds__(256)
+void k_s64_residuals(const double* __restrict__ Asub, uint32_t ldm, const double* __restrict__ y, const unsigned char* __restrict__ slog,
+                     uint32_t T, const double* __restrict__ xd, double tol, const float* __restrict__ meta,
+                     __half* __restrict__ r16, float* __restrict__ rn2p, float* __restrict__ tab, uint32_t* __restrict__ ctl,
+                     uint32_t* __restrict__ headroom)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) double sAc[16][64];
+    __shared__ __attribute__((aligned(16))) double sXt[16][kS64Rhs + 8];
+    __shared__ float sS[kS64Rhs];
+    const uint32_t* l_cnt = reinterpret_cast<const uint32_t*>(slog);
+    const double* l_lam = reinterpret_cast<const double*>(slog + (((size_t)kS64LogCap * 4 + 7) & ~(size_t)7));
+    const uint32_t* l_cols = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(l_lam) + (size_t)kS64LogCap * 8);
+    if (ctl[0] != 0u) return;
+    const uint32_t nst = T;                                      // states 1 .. T
+    const uint32_t nfin = l_cnt[T];
+    if (nfin == 0xffffffffu || nfin > kS64LogK) return;           // (k_s64_dense raised the flag)
+    const uint32_t* fin = l_cols + (size_t)T * kS64LogK;
+    constexpr uint32_t pitch = kS64Rhs + 8u;
+    const uint32_t tid = threadIdx.x, r0 = blockIdx.x * 64u;
+    if (tid < kS64Rhs) {
+        float sc = 1.f;
+        if (tid < nst) {
+            const double lam = l_lam[tid + 1u];
+            const bool final_state = tid + 1u == T;
+            sc = scr_state_scale((float)(final_state ? fmax(lam, tol) : lam));
+        }
+        sS[tid] = sc;
+    }
+    const uint32_t rg = tid & 15u, sgp = tid >> 4;
+    double acc[3][4][4];
+    {
+        const v2d y0 = *reinterpret_cast<const v2d*>(y + r0 + 4u * rg), y1 = *reinterpret_cast<const v2d*>(y + r0 + 4u * rg + 2u);
+#pragma unroll
+        for (int rd = 0; rd < 3; ++rd)
+#pragma unroll
+            for (int si = 0; si < 4; ++si) { acc[rd][si][0] = y0[0]; acc[rd][si][1] = y0[1]; acc[rd][si][2] = y1[0]; acc[rd][si][3] = y1[1]; }
+    }
+    for (uint32_t u0 = 0; u0 < nfin; u0 += 16u) {
+        __syncthreads();
+        {   // 16 list entries x 64 rows of the sub-dictionary, 16 x 192 coefficients
+            const uint32_t p = tid >> 4, q4 = tid & 15u;
+            const uint32_t u = u0 + p;
+            const uint32_t col = u < nfin ? fin[u] : 0xffffffffu;
+            v2d a0 = { 0.0, 0.0 }, a1 = { 0.0, 0.0 };
+            if (col < kS64Sub) {
+                a0 = *reinterpret_cast<const v2d*>(Asub + (size_t)col * ldm + r0 + 4u * q4);
+                a1 = *reinterpret_cast<const v2d*>(Asub + (size_t)col * ldm + r0 + 4u * q4 + 2u);
+            }
+            *reinterpret_cast<v2d*>(&sAc[p][4u * q4]) = a0;
+            *reinterpret_cast<v2d*>(&sAc[p][4u * q4 + 2u]) = a1;
+            for (uint32_t e = tid; e < 16u * pitch; e += 256u) {
+                const uint32_t pp = e / pitch, k = e - pp * pitch;
+                sXt[pp][k] = (u0 + pp < nfin && k < nst) ? xd[(size_t)(u0 + pp) * pitch + k] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rd = 0; rd < 3; ++rd) {
+            const uint32_t s0 = 64u * (uint32_t)rd + 4u * sgp;
+            if (s0 < nst) {                                           // (uniform over the 16 lanes of a state group)
+#pragma unroll 4
+                for (uint32_t p = 0; p < 16u; ++p) {
+                    const v2d a0 = *reinterpret_cast<const v2d*>(&sAc[p][4u * rg]), a1 = *reinterpret_cast<const v2d*>(&sAc[p][4u * rg + 2u]);
+                    const v2d x0 = *reinterpret_cast<const v2d*>(&sXt[p][s0]), x1 = *reinterpret_cast<const v2d*>(&sXt[p][s0 + 2u]);
+                    const double av[4] = { a0[0], a0[1], a1[0], a1[1] }, xv[4] = { x0[0], x0[1], x1[0], x1[1] };
+#pragma unroll
+                    for (int si = 0; si < 4; ++si)
+#pragma unroll
+                        for (int ri = 0; ri < 4; ++ri) acc[rd][si][ri] = __builtin_fma(-xv[si], av[ri], acc[rd][si][ri]);
+                }
+            }
+        }
+    }
+    bool ovf = false;
+#pragma unroll
+    for (int rd = 0; rd < 3; ++rd) {
+#pragma unroll
+        for (int si = 0; si < 4; ++si) {
+            const uint32_t kk = 64u * (uint32_t)rd + 4u * sgp + (uint32_t)si;
+            const float sc = sS[kk < kS64Rhs ? kk : 0u];
+            float ss = 0.f;
+            __half hv[4];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const float r = (float)acc[rd][si][ri];
+                ss = __builtin_fmaf(r, r, ss);
+                const float v = r * sc;
+                if (kk < nst && !(fabsf(v) < 60000.f)) ovf = true;
+                hv[ri] = __float2half_rn(v);
+            }
+            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+            if (kk < nst) {
+                *reinterpret_cast<uint2*>(r16 + (size_t)kk * ldm + r0 + 4u * rg) = *reinterpret_cast<const uint2*>(hv);
+                if (rg == 0u) rn2p[(size_t)blockIdx.x * kS64Rhs + kk] = ss * 1.0001f;     // (the cast of r to float: inside)
+            }
+        }
+    }
+    if (ovf) ctl[0] = 1u;
+    if (blockIdx.x == 0u) {
+        if (tid == 0u) *headroom = 0u;
+        if (tid < nst) {
+            const float lam = (float)l_lam[tid + 1u];
+            const bool final_state = tid + 1u == T;
+            const float slack = 1e-12f * (float)l_lam[0];           // (state 0: x = 0, lambda_0 = ||A^T y||_inf; fp64: the reference's own rounding is 1e-16)
+            float bound;
+            if (final_state && !((double)lam > tol)) bound = (float)tol * 0.9375f - slack;
+            else bound = lam * 0.875f - slack;
+            const float inv_sk = 1.f / sS[tid];
+            tab[tid * kScrTab + 0] = meta[1] * inv_sk;
+            tab[tid * kScrTab + 1] = bound;
+            tab[tid * kScrTab + 2] = inv_sk;
+            tab[tid * kScrTab + 3] = lam;
+        }
+    }
+}
+
+// the sub-context's solution back onto the dictionary's columns, and the verdict into the slot's state
+__global__ __launch_bounds__(256)
+void k_s64_finish(const uint32_t* __restrict__ sub, const double* __restrict__ xsub, uint32_t n, double* __restrict__ x,
+                  DevState* __restrict__ st, const uint32_t* __restrict__ ctl, uint32_t iter, double c_inf, uint32_t K)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j < kS64Sub) { const uint32_t col = sub[j]; if (col < n) x[col] = xsub[j]; }
+    if (j == 0u) {
+        const bool fail = ctl[0] != 0u || st->need_sweep != 0u;
+        st->status = fail ? kStatusSubsetFail : 0u;
+        st->need_sweep = 0u;
+        st->iter = iter;
+        st->K = K;
+        st->c_inf = c_inf;
+        st->done_round = iter + 1u;
+        st->done = 1u;
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 static ScreenState* scr_of(ss_hip_ctx* ctx) { return static_cast<ScreenState*>(ctx->screen); }
 
@@ -464,15 +671,20 @@ void screen_free(ss_hip_ctx* ctx)
 {
     ScreenState* S = scr_of(ctx);
     if (!S) return;
-    void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs };
+    void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->cabs, S->sublist, S->xsub, S->xd, S->ctl };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (S->sub) {
+        if (S->sub->slog) (void)hipFree(S->sub->slog);
+        S->sub->slog = nullptr;
+        ss_hip_homotopy_destroy(S->sub);
+    }
     delete S;
     ctx->screen = nullptr;
 }
 
 // (the main loop's two tiles; the epilogue's tables — 96 x 4 + 448 + 128 x 96 floats — fit inside)
-static size_t scr_gemm_lds(uint32_t) { return std::max<size_t>((size_t)(kScrCols + kScrRhs) * kScrPitchB, ((size_t)kScrRhs * 4 + kSbS + (size_t)128 * kScrRhs) * 4); }
+static size_t scr_gemm_lds(uint32_t nsub) { return std::max<size_t>((size_t)(kScrCols + kScrRhs) * kScrPitchB, ((size_t)kScrRhs * 4 + nsub + (size_t)128 * kScrRhs) * 4); }
 
 // Shape / option test, and — the first time it says yes — the preparation: the fp16 copy of A (half of A's bytes again),
 // the column norms.  A failed allocation switches the form off for this context (the default engine goes on as before).
@@ -501,7 +713,7 @@ bool screen_form_usable(ss_hip_ctx* ctx)
     alloc(reinterpret_cast<void**>(&S->gs), (size_t)kSbS * kSbS * sizeof(float));
     if (ok) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)scr_gemm_lds(ldm));
+                                                 (int)scr_gemm_lds(kS64Sub));
         if (e != hipSuccess) { (void)hipGetLastError(); ok = false; }
     }
     if (!ok) { screen_free(ctx); ctx->screen_failed_alloc = 1; return false; }
@@ -509,10 +721,10 @@ bool screen_form_usable(ss_hip_ctx* ctx)
     const float* At = static_cast<const float*>(ctx->At);
     (void)hipMemsetAsync(S->meta, 0, 4 * sizeof(float), s);
     (void)hipMemsetAsync(S->r16, 0, (size_t)kScrRhs * ldm * sizeof(__half), s);
-    hipLaunchKernelGGL(k_a16_stats, dim3(np), dim3(256), 0, s, At, ldm, S->anorm, S->meta);
+    hipLaunchKernelGGL((k_a16_stats<float>), dim3(np), dim3(256), 0, s, At, ldm, S->anorm, S->meta);
     hipLaunchKernelGGL(k_a16_scale, dim3(1), dim3(1), 0, s, S->meta);
     const size_t total8 = (size_t)np * ldm / 8;
-    hipLaunchKernelGGL(k_a16_convert, dim3((unsigned)std::min<size_t>((total8 + 255) / 256, 65536)), dim3(256), 0, s, At, total8,
+    hipLaunchKernelGGL((k_a16_convert<float>), dim3((unsigned)std::min<size_t>((total8 + 255) / 256, 65536)), dim3(256), 0, s, At, total8,
                        (const float*)S->meta, S->a16);
     if (hipGetLastError() != hipSuccess) { screen_free(ctx); ctx->screen_failed_alloc = 1; return false; }
     return true;
@@ -541,11 +753,124 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
                        (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st);
     if (e2) (void)hipEventRecord(e2, s);
-    hipLaunchKernelGGL(k_scr_gemm, dim3(np / kScrCols), dim3(256), scr_gemm_lds(ldm), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
-                       (const float*)S->anorm, (const float*)S->rn2p, (const float*)S->tab, (const uint32_t*)B.sub, (const float*)S->meta,
-                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3);
+    hipLaunchKernelGGL(k_scr_gemm, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
+                       (const float*)S->anorm, (const float*)S->rn2p, kScrRhs, (const float*)S->tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u);
     if (e3) (void)hipEventRecord(e3, s);
     (void)launch_sub_finish(ctx, ws, 1);
+    return hipGetLastError();
+}
+
+
+// ---- fp64 form, host side ------------------------------------------------------------------------------------------------
+static size_t s64_log_bytes()
+{
+    size_t b = ((size_t)kS64LogCap * 4 + 7) & ~(size_t)7;
+    b += (size_t)kS64LogCap * 8;
+    b += (((size_t)kS64LogCap * kS64LogK * 4) + 7) & ~(size_t)7;
+    b += (size_t)kS64LogCap * kS64LogK * 8;
+    return b;
+}
+
+// Shape / option test and the one-time preparation: the fp16 copy of A, the column norms, the sub-context (created over the
+// first kS64Sub columns: every solve gathers its own into it).
+bool screen64_usable(ss_hip_ctx* ctx)
+{
+    if (ctx->screen_single == 0 || !ctx->is_f64 || ctx->kind != 0 || ctx->screen_failed_alloc || ctx->colshard != nullptr) return false;
+    const uint32_t ldm = ctx->ldm, np = ctx->n_pad;
+    if (ldm % kScrKc != 0 || np % kScrCols != 0 || ldm > 16384u) return false;
+    // where it pays: a dictionary many times the sub-dictionary (option 2: from 4 x)
+    if (ctx->n < (ctx->screen_single >= 2 ? 4u : 16u) * kS64Sub) return false;
+    if (ctx->screen_single < 2 && (size_t)ctx->m * ctx->n < ((size_t)64 << 20)) return false;
+    if (ctx->screen != nullptr) return true;
+    ScreenState* S = new ScreenState();
+    ctx->screen = S;
+    bool ok = true;
+    auto alloc = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; } };
+    alloc(reinterpret_cast<void**>(&S->a16), (size_t)np * ldm * sizeof(__half));
+    alloc(reinterpret_cast<void**>(&S->anorm), (size_t)np * sizeof(float));
+    alloc(reinterpret_cast<void**>(&S->meta), 4 * sizeof(float));
+    alloc(reinterpret_cast<void**>(&S->r16), (size_t)kS64Rhs * ldm * sizeof(__half));
+    alloc(reinterpret_cast<void**>(&S->rn2p), (size_t)(ldm / 64u) * kS64Rhs * sizeof(float));
+    alloc(reinterpret_cast<void**>(&S->tab), (size_t)kS64Rhs * kScrTab * sizeof(float));
+    alloc(reinterpret_cast<void**>(&S->cabs), (size_t)np * sizeof(float));
+    alloc(reinterpret_cast<void**>(&S->sublist), ((size_t)kS64Sub + 2) * sizeof(uint32_t));
+    alloc(reinterpret_cast<void**>(&S->xsub), (size_t)kS64Sub * sizeof(double));
+    alloc(reinterpret_cast<void**>(&S->xd), (size_t)kS64LogK * (kS64Rhs + 8) * sizeof(double));
+    alloc(reinterpret_cast<void**>(&S->ctl), 8 * sizeof(uint32_t));
+    if (ok) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)scr_gemm_lds(kS64Sub));
+        if (e != hipSuccess) { (void)hipGetLastError(); ok = false; }
+    }
+    if (ok) {
+        char err[256];
+        S->sub = ss_hip_homotopy_create_f64(static_cast<const double*>(ctx->At), ctx->m, kS64Sub, 1, (ptrdiff_t)ldm, ctx->device, err, sizeof(err));
+        if (S->sub == nullptr) ok = false;
+        else {
+            S->sub->screen_single = 0;
+            (void)hipSetDevice(ctx->device);
+            if (hipMalloc(&S->sub->slog, s64_log_bytes()) != hipSuccess) { (void)hipGetLastError(); S->sub->slog = nullptr; ok = false; }
+            S->sub->slog_cap = kS64LogCap;
+            S->sub->slog_kmax = kS64LogK;
+        }
+    }
+    if (!ok) { screen_free(ctx); ctx->screen_failed_alloc = 1; return false; }
+    hipStream_t s = ctx->stream;
+    const double* At = static_cast<const double*>(ctx->At);
+    (void)hipMemsetAsync(S->meta, 0, 4 * sizeof(float), s);
+    (void)hipMemsetAsync(S->r16, 0, (size_t)kS64Rhs * ldm * sizeof(__half), s);
+    hipLaunchKernelGGL((k_a16_stats<double>), dim3(np), dim3(256), 0, s, At, ldm, S->anorm, S->meta);
+    hipLaunchKernelGGL(k_a16_scale, dim3(1), dim3(1), 0, s, S->meta);
+    const size_t total8 = (size_t)np * ldm / 8;
+    hipLaunchKernelGGL((k_a16_convert<double>), dim3((unsigned)std::min<size_t>((total8 + 255) / 256, 65536)), dim3(256), 0, s, At, total8,
+                       (const float*)S->meta, S->a16);
+    if (hipGetLastError() != hipSuccess) { screen_free(ctx); ctx->screen_failed_alloc = 1; return false; }
+    return true;
+}
+
+ss_hip_ctx* screen64_sub(ss_hip_ctx* ctx) { return scr_of(ctx) ? scr_of(ctx)->sub : nullptr; }
+double* screen64_xsub(ss_hip_ctx* ctx) { return scr_of(ctx) ? scr_of(ctx)->xsub : nullptr; }
+
+// c0 = A^T y is in c0 (device): the kS64Sub columns with the largest |c0|, gathered into the sub-context's dictionary
+hipError_t screen64_gather(ss_hip_ctx* ctx, const double* c0)
+{
+    ScreenState* S = scr_of(ctx);
+    if (S == nullptr || S->sub == nullptr) return hipErrorInvalidConfiguration;
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t)ctx->n, np = ctx->n_pad;
+    hipLaunchKernelGGL(k_s64_cabs, dim3((np + 255) / 256), dim3(256), 0, s, c0, n, np, S->cabs);
+    (void)launch_select_top(ctx, S->cabs, n, np, kS64Sub, S->sublist, S->sublist + kS64Sub, reinterpret_cast<float*>(S->sublist + kS64Sub + 1));
+    hipLaunchKernelGGL(k_s64_gather, dim3(kS64Sub), dim3(256), 0, s, static_cast<const double*>(ctx->At), ctx->ldm, n,
+                       (const uint32_t*)S->sublist, static_cast<double*>(S->sub->At));
+    return hipGetLastError();
+}
+
+// After the sub-context's solve (T iterations, synchronised): the certificate of its T states against all columns, the
+// solution scattered into x, the verdict into the slot's state.  y = the signal (device, ldm entries, zero padded).
+hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K,
+                            hipEvent_t e2, hipEvent_t e3)
+{
+    ScreenState* S = scr_of(ctx);
+    if (S == nullptr || S->sub == nullptr || T == 0u || T > kS64Rhs) return hipErrorInvalidConfiguration;
+    hipStream_t s = ctx->stream;
+    const uint32_t ldm = ctx->ldm, n = (uint32_t)ctx->n, np = ctx->n_pad;
+    (void)hipMemsetAsync(S->ctl, 0, 8 * sizeof(uint32_t), s);
+    const unsigned char* slog = static_cast<const unsigned char*>(S->sub->slog);
+    hipLaunchKernelGGL(k_s64_dense, dim3(T), dim3(256), 0, s, slog, T, S->xd, S->ctl);
+    hipLaunchKernelGGL(k_s64_residuals, dim3(ldm / 64u), dim3(256), 0, s, static_cast<const double*>(S->sub->At), ldm, y, slog, T,
+                       (const double*)S->xd, tol, (const float*)S->meta, S->r16, S->rn2p, S->tab, S->ctl, reinterpret_cast<uint32_t*>(S->meta) + 3);
+    if (e2) (void)hipEventRecord(e2, s);
+    for (uint32_t k0 = 0; k0 < T; k0 += kScrRhs) {
+        const uint32_t cnt = std::min<uint32_t>(kScrRhs, T - k0);
+        hipLaunchKernelGGL(k_scr_gemm, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub), s, (const __half*)S->a16, ldm, n,
+                           (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
+                           (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
+                           ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt);
+    }
+    if (e3) (void)hipEventRecord(e3, s);
+    hipLaunchKernelGGL(k_s64_finish, dim3((kS64Sub + 255) / 256), dim3(256), 0, s, (const uint32_t*)S->sublist, (const double*)S->xsub, n, ws.x,
+                       ws.st, (const uint32_t*)S->ctl, T, c_inf, K);
     return hipGetLastError();
 }
 

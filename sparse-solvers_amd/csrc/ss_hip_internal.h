@@ -261,6 +261,10 @@ struct ss_hip_ctx {
     int screen_single = 1;            // option: 1 = single fp32 signals on large dictionaries take the screened form (screen.hip), 2 = on every shape
                                       // the form can run on (tests), 0 = never
     int screen_failed_alloc = 0;      // the preparation did not fit: not tried again
+    // state log of the launch-per-iteration form (k_la_iter; on in the sub-context of the fp64 screened form, screen.hip):
+    // cnt[cap] u32, lambda[cap] f64, cols[cap][kmax] u32, vals[cap][kmax] T — the state every launch starts from
+    void* slog = nullptr;
+    uint32_t slog_cap = 0, slog_kmax = 0;
     size_t c0_batch_rows = 0;
     // column form of mid-size batches: cache of Gram columns, row tables, pass lists (grown on demand)
     float* bcol_cache = nullptr;
@@ -414,12 +418,21 @@ hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots,
 hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs& B, uint32_t nslots, const float* G, uint32_t gpitch, int gsub,
                             const float* c0, float tol, uint32_t max_iter);
 hipError_t launch_sub_finish(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots);
+hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval);
 // screened form of ONE signal (screen.hip): the subset form on the subset's own Gram matrix (formed from A), every state of
 // the path then screened against all columns by one pass over a half-precision copy of A with a rigorous error bound
 bool screen_form_usable(ss_hip_ctx* ctx);                 // shape / option test + one-time preparation (fp16 copy of A, column norms)
 hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                               hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
 void screen_free(ss_hip_ctx* ctx);
+// fp64: the path is solved by the fp64 engine on a sub-dictionary (a context of its own: the kS64Sub columns with the largest
+// |A^T y|), its states are logged (ss_hip_ctx::slog) and certified against all columns by the same fp16 pass
+bool screen64_usable(ss_hip_ctx* ctx);
+ss_hip_ctx* screen64_sub(ss_hip_ctx* ctx);
+double* screen64_xsub(ss_hip_ctx* ctx);
+hipError_t screen64_gather(ss_hip_ctx* ctx, const double* c0);
+hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K,
+                            hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
 double screen_read_headroom(ss_hip_ctx* ctx);             // largest (|c~| + eps) / bound of the last screened solve (synchronises)
 hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr);      // signals one pass of the engine can carry (1 without the LDS-staged sweep)

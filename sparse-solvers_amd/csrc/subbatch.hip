@@ -51,8 +51,9 @@ __device__ __forceinline__ uint32_t mag_bits(float v) { return __float_as_uint(v
 // chunk: 64 cache lines per load instruction, 20 ms per 4096 signals against 8 for their solves).
 __global__ __launch_bounds__(kSelThreads)
 void k_sub_select(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ sub,
-                  uint32_t* __restrict__ first_pick, float* __restrict__ first_val)
+                  uint32_t* __restrict__ first_pick, float* __restrict__ first_val, uint32_t nsel)
 {
+    // nsel: columns to select per slot (kSbS for the subset form; the fp64 screened form takes more: screen.hip)
     constexpr uint32_t NW = kSelThreads / 64u;
     __shared__ uint32_t hist[kSelBins];
     __shared__ float sv[16];
@@ -61,10 +62,10 @@ void k_sub_select(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint
     __shared__ uint32_t w_sel[NW], w_eq[NW];
     const uint32_t slot = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     c0 += (size_t)slot * n_pad;
-    sub += (size_t)slot * kSbS;
+    sub += (size_t)slot * nsel;
     const uint32_t seg = ((n + NW - 1) / NW + 63u) & ~63u;
     const uint32_t lo = wave * seg < n ? wave * seg : n, hi = lo + seg < n ? lo + seg : n;
-    const uint32_t want = n < kSbS ? n : kSbS;
+    const uint32_t want = n < nsel ? n : nsel;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     uint32_t prefix_key = 0, above = 0;
@@ -149,12 +150,12 @@ void k_sub_select(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint
         const bool chosen = (i < hi && k > T22) || (is_eq && rank_eq < take);
         const uint64_t bch = __ballot(chosen);
         const uint32_t pos = out + (uint32_t)__popcll(bch & lt_mask);
-        if (chosen && pos < kSbS) sub[pos] = i;
+        if (chosen && pos < nsel) sub[pos] = i;
         out += (uint32_t)__popcll(bch);
         eq_run += (uint32_t)__popcll(beq);
     }
     // (fewer than kSbS columns in all: the rest of the list is "no column")
-    for (uint32_t p = want + t; p < kSbS; p += kSelThreads) sub[p] = 0xffffffffu;
+    for (uint32_t p = want + t; p < nsel; p += kSelThreads) sub[p] = 0xffffffffu;
 }
 
 // ---- k_sub_select1: the same selection for ONE slot, for latency ----------------------------------------------------
@@ -794,7 +795,14 @@ hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots,
     if (nslots == 1 && ctx->n_pad <= 4u * kSel1J * kSel1Threads)        // (one slot: the register-resident form, for latency)
         hipLaunchKernelGGL(k_sub_select1, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
     else
-        hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
+        hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS);
+    return hipGetLastError();
+}
+
+// the nsel columns with the largest |v| of ONE vector, ascending (screen.hip's fp64 form: v = float(|A^T y|))
+hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval)
+{
+    hipLaunchKernelGGL(k_sub_select, dim3(1), dim3(kSelThreads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel);
     return hipGetLastError();
 }
 

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""The fp64 screened form (csrc/screen.hip): small shapes forced (screen_single = 2) against the oracle, then configs[4]
+(A 16384 x 131072 fp64, k = 128) timed with and without it.    python tools/probe_screen64.py [--no-big]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sparse-solvers_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle  # noqa: E402
+import sship  # noqa: E402
+
+
+def small():
+    bad = 0
+    for (m, n, k, seed) in [(1024, 16384, 24, 1), (2048, 16384, 60, 2), (1536, 9000, 40, 3), (1024, 16384, 100, 4)]:
+        rng = np.random.default_rng(5000 + seed)
+        A = rng.standard_normal((m, n)) / np.sqrt(m)
+        sup = np.sort(rng.choice(n, k, replace=False))
+        x0 = np.zeros(n)
+        x0[sup] = 1.0 + np.abs(rng.standard_normal(k))
+        y = A @ x0
+        with sship.Homotopy(A, device=0) as h:
+            h.set_option("screen_single", 2)
+            x, it, err = h.solve(y, 1e-9, 4 * k)
+            st = h.stats()
+            h.set_option("screen_single", 0)
+            xd, itd, errd = h.solve(y, 1e-9, 4 * k)
+        xo, ito, eo = oracle.homotopy(A, y, 1e-9, 4 * k)
+        same = np.array_equal(np.nonzero(x)[0], np.nonzero(xo)[0])
+        rel = np.abs(x - xo).max() / np.abs(xo).max()
+        reld = np.abs(xd - xo).max() / np.abs(xo).max()
+        print("m %5d n %6d k %3d | screened %d redone %d headroom %.3f | iter %d / default %d / oracle %d | support %s | rel err %.2e (default %.2e)"
+              % (m, n, k, st["screen_signals"], st["screen_redone"], st["screen_headroom"], it, itd, ito, same, rel, reld), flush=True)
+        if it != ito or not same or rel > 1e-10:
+            bad += 1
+    return bad
+
+
+def big():
+    import torch
+    dev = torch.device("cuda", 0)
+    m5, n5, k5 = 16384, 131072, 128
+    g5 = torch.Generator(device=dev).manual_seed(4321)
+    A5 = torch.randn((m5, n5), generator=g5, device=dev, dtype=torch.float64)
+    A5 /= np.sqrt(m5)
+    sigs = []
+    for s in range(4):
+        rng5 = np.random.default_rng(4322 + s)
+        sup5 = np.sort(rng5.choice(n5, k5, replace=False))
+        coef5 = 1.0 + np.abs(rng5.standard_normal(k5))
+        y5 = (A5[:, torch.from_numpy(sup5).to(dev)] @ torch.from_numpy(coef5).to(dev)).contiguous()
+        sigs.append((y5, sup5, coef5))
+    h5 = sship.Homotopy(A5, device=0)
+    del A5
+    torch.cuda.empty_cache()
+    x5 = torch.zeros(n5, device=dev, dtype=torch.float64)
+    res = {}
+    for mode in (1, 0, 1):
+        h5.set_option("screen_single", mode)
+        h5.reset_stats()
+        h5.solve(sigs[0][0], 1e-9, 512, out=x5)
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        ok = 0
+        cerr = 0.0
+        its = []
+        for (y5, sup5, coef5) in sigs:
+            _, it5, e5 = h5.solve(y5, 1e-9, 512, out=x5)
+            xh = x5.cpu().numpy()
+            ok += int(np.array_equal(np.nonzero(xh)[0], sup5))
+            cerr = max(cerr, float(np.abs(xh[sup5] - coef5).max() / coef5.max()))
+            its.append(it5)
+            res[(mode, len(its))] = xh.copy()
+        dt5 = (time.perf_counter() - t5) / len(sigs)
+        st = h5.stats()
+        print("configs[4] screen_single %d: %.3f ms per solve (incl. the copy of x to the host), iterations %s, supports exact %d / %d, max rel coef err %.2e, "
+              "screened %d redone %d headroom %.3f" % (mode, dt5 * 1e3, its, ok, len(sigs), cerr, st["screen_signals"], st["screen_redone"],
+                                                      st["screen_headroom"]), flush=True)
+    d = max(np.abs(res[(1, i)] - res[(0, i)]).max() / np.abs(res[(0, i)]).max() for i in range(1, len(sigs) + 1))
+    print("screened vs default engine: max |x - x'| / max |x| = %.2e" % d)
+    # clean timing without host copies
+    for mode in (1, 0):
+        h5.set_option("screen_single", mode)
+        h5.solve(sigs[0][0], 1e-9, 512, out=x5)
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        for r in range(3):
+            h5.solve(sigs[r + 1][0], 1e-9, 512, out=x5)
+        torch.cuda.synchronize()
+        print("configs[4] screen_single %d: %.3f ms per solve" % (mode, (time.perf_counter() - t5) / 3 * 1e3), flush=True)
+    h5.close()
+
+
+if __name__ == "__main__":
+    bad = small()
+    print("small shapes: %d bad" % bad, flush=True)
+    if "--no-big" not in sys.argv:
+        big()
+    sys.exit(1 if bad else 0)
