@@ -694,10 +694,14 @@ __global__ __launch_bounds__(HT, BPC)
 void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__ rcols,
                      const uint32_t* __restrict__ drows, double* __restrict__ D,
                      uint32_t K, uint32_t ldq, uint32_t ldd, uint32_t ntiles,
-                     const DevState* __restrict__ st)
+                     const DevState* __restrict__ st, uint32_t part_stride = 0)
 {
     if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;   // no sweep needed this round
     static_assert(HN / 32 == HT / 64 && RH * 8 <= HT, "one 32-column block per wave; the R tile is staged in one pass");
+    // part_stride != 0 (narrow dictionaries: too few column tiles to fill the chip): the rows are split over gridDim.y
+    // workgroups — this one takes rows blockIdx.y * K .. + K and stores its partial sums, indexed by right-hand side, at
+    // D + blockIdx.y * part_stride; k_gemm_f64_sum adds them up in order
+    if (part_stride != 0u) { At += (size_t)blockIdx.y * K; D += (size_t)blockIdx.y * part_stride; }
     constexpr int RB = RH / 16;                                 // 16-row blocks of right-hand sides (2 or 4)
     __shared__ __attribute__((aligned(16))) double sR[2][RH][DLD];
     __shared__ __attribute__((aligned(16))) double sQ[2][HN][DLD];
@@ -825,16 +829,48 @@ void k_gemm32_tn_f64(const double* __restrict__ At, const uint32_t* __restrict__
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t row = 16 * i + 4 * e + kq;
                     const uint32_t dr = drows[row];
-                    if (dr != 0xffffffffu) D[(size_t)dr * ldd + col] = acc[i][j][e];
+                    if (dr != 0xffffffffu) D[(size_t)(part_stride != 0u ? row : dr) * ldd + col] = acc[i][j][e];
                 }
             }
     }
+}
+
+// D[drows[s]][col] = sum over the row chunks, in order, of the partial sums of a split pass
+__global__ __launch_bounds__(256)
+void k_gemm_f64_sum(const double* __restrict__ part, uint32_t nsplit, uint32_t part_stride, uint32_t ncols, uint32_t nrhs,
+                    const uint32_t* __restrict__ drows, double* __restrict__ D, uint32_t ldd, const DevState* __restrict__ st)
+{
+    if (st != nullptr && (st->done != 0 || st->need_sweep != 1)) return;
+    const uint32_t col = blockIdx.x * 256u + threadIdx.x, s = blockIdx.y;
+    if (col >= ncols || s >= nrhs) return;
+    const uint32_t dr = drows[s];
+    if (dr == 0xffffffffu) return;
+    double acc = part[(size_t)s * ncols + col];
+    for (uint32_t c = 1; c < nsplit; ++c) acc += part[(size_t)c * part_stride + (size_t)s * ncols + col];
+    D[(size_t)dr * ldd + col] = acc;
+}
+
+// narrow dictionaries (option pass_ksplit > 1: the sub-context of the fp64 screened form): RH right-hand sides, rows split
+template <int RH>
+static hipError_t launch_gemm_split_f64(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows, double* D, uint32_t ldd,
+                                        const DevState* st)
+{
+    const uint32_t ns = (uint32_t)ctx->pass_ksplit, np = ctx->n_pad;
+    const uint32_t ntiles = np / 256, Kc = ctx->ldm / ns;
+    const uint32_t stride = 64u * np;                            // doubles per row chunk (64 right-hand sides at most)
+    double* part = static_cast<double*>(ctx->pass_part);
+    hipLaunchKernelGGL((k_gemm32_tn_f64<RH>), dim3(ntiles, ns), dim3(512), 0, ctx->stream, static_cast<const double*>(ctx->At),
+                       rcols, drows, part, Kc, ctx->ldm, np, ntiles, st, stride);
+    hipLaunchKernelGGL(k_gemm_f64_sum, dim3((np + 255) / 256, RH), dim3(256), 0, ctx->stream, (const double*)part, ns, stride, np, (uint32_t)RH,
+                       drows, D, ldd, st);
+    return hipGetLastError();
 }
 
 hipError_t launch_gemm32_tn_f64(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows,
                                 double* D, uint32_t ldd, const DevState* st)
 {
     if (ctx->n_pad % 256 != 0 || ctx->ldm % DK != 0) return hipErrorInvalidValue;
+    if (ctx->pass_ksplit > 1 && ctx->pass_part != nullptr) return launch_gemm_split_f64<32>(ctx, rcols, drows, D, ldd, st);
     if (ctx->sweep_f64_variant == 1 || ctx->sweep_f64_variant == 2) {
         // 128-column tiles, 256 threads, two or three workgroups per CU
         const uint32_t nt = ctx->n_pad / 128;
@@ -860,6 +896,7 @@ hipError_t launch_gemm64_tn_f64(const ss_hip_ctx* ctx, const uint32_t* rcols, co
                                 double* D, uint32_t ldd, const DevState* st)
 {
     if (ctx->n_pad % 256 != 0 || ctx->ldm % DK != 0) return hipErrorInvalidValue;
+    if (ctx->pass_ksplit > 1 && ctx->pass_part != nullptr) return launch_gemm_split_f64<64>(ctx, rcols, drows, D, ldd, st);
     const uint32_t ntiles = ctx->n_pad / 256;
     const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;
     hipLaunchKernelGGL(k_gemm32_tn_f64<64>, dim3(grid), dim3(512), 0, ctx->stream, static_cast<const double*>(ctx->At),

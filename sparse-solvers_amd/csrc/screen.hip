@@ -677,6 +677,9 @@ void screen_free(ss_hip_ctx* ctx)
     if (S->sub) {
         if (S->sub->slog) (void)hipFree(S->sub->slog);
         S->sub->slog = nullptr;
+        if (S->sub->pass_part) (void)hipFree(S->sub->pass_part);
+        S->sub->pass_part = nullptr;
+        S->sub->pass_ksplit = 0;
         ss_hip_homotopy_destroy(S->sub);
     }
     delete S;
@@ -813,6 +816,11 @@ bool screen64_usable(ss_hip_ctx* ctx)
             if (hipMalloc(&S->sub->slog, s64_log_bytes()) != hipSuccess) { (void)hipGetLastError(); S->sub->slog = nullptr; ok = false; }
             S->sub->slog_cap = kS64LogCap;
             S->sub->slog_kmax = kS64LogK;
+            // its passes: 8 column tiles only — the rows split 16 (32) ways fill the chip
+            uint32_t ks = 32;
+            while (ks > 1 && (ldm % (ks * 16u) != 0 || ldm / ks < 256u)) ks >>= 1;
+            if (ks > 1 && hipMalloc(&S->sub->pass_part, (size_t)ks * 64 * S->sub->n_pad * sizeof(double)) == hipSuccess) S->sub->pass_ksplit = (int)ks;
+            else { (void)hipGetLastError(); S->sub->pass_part = nullptr; S->sub->pass_ksplit = 0; }
         }
     }
     if (!ok) { screen_free(ctx); ctx->screen_failed_alloc = 1; return false; }

@@ -265,6 +265,10 @@ struct ss_hip_ctx {
     // cnt[cap] u32, lambda[cap] f64, cols[cap][kmax] u32, vals[cap][kmax] T — the state every launch starts from
     void* slog = nullptr;
     uint32_t slog_cap = 0, slog_kmax = 0;
+    // narrow fp64 dictionaries (the same sub-context): the passes split their rows over pass_ksplit workgroups per column tile,
+    // partial sums in pass_part ([pass_ksplit][64][n_pad] doubles), added up in order (gemm.hip: launch_gemm_split_f64)
+    int pass_ksplit = 0;
+    void* pass_part = nullptr;
     size_t c0_batch_rows = 0;
     // column form of mid-size batches: cache of Gram columns, row tables, pass lists (grown on demand)
     float* bcol_cache = nullptr;
