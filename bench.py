@@ -816,6 +816,25 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         ok5 = bool(np.array_equal(np.nonzero(x5h)[0], sup5))
         err5 = float(np.abs(x5h[sup5] - coef5).max() / coef5.max())
         st5 = h5.stats()
+        # the same solves through the engine the fp64 screened form stands in for (option screen_single = 0)
+        un5 = None
+        if st5["screen_signals"] > 0:
+            h5.set_option("screen_single", 0)
+            h5.reset_stats()
+            xu5 = torch.zeros(n5, device=dev, dtype=torch.float64)
+            h5.solve(y5, 1e-9, 512, out=xu5)
+            torch.cuda.synchronize()
+            tu5 = time.perf_counter()
+            for _ in range(3):
+                _, itu5, _ = h5.solve(y5, 1e-9, 512, out=xu5)
+            torch.cuda.synchronize()
+            dtu5 = (time.perf_counter() - tu5) / 3
+            stu5 = h5.stats()
+            un5 = {"ms_per_solve": dtu5 * 1e3, "iterations": int(itu5),
+                   "lookahead_sweeps_per_solve": stu5["lookahead_sweeps"] / max(1, stu5["solves"]),
+                   "max_rel_diff_of_coefficients": float(((xu5 - x5).abs().max() / x5.abs().max()).item())}
+            del xu5
+            h5.set_option("screen_single", 1)
         _, ms32 = h5.gram_cols(np.arange(0, 32000, 1000, dtype=np.uint32), 5)
         _, ms1 = h5.gemv_t(y5, 3)
         b32 = m5 * n5 * 8 + 32 * m5 * 8 + 32 * n5 * 8
@@ -823,6 +842,12 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         extras["fp64_configs4"] = {
             "workload": "configs[4] shape: Homotopy fp64, A 16384x131072 (16 GiB, torch.randn seed 4321 / sqrt(m)), k=128, tol 1e-9, max_iter 512",
             "ms_per_solve": dt5 * 1e3, "iterations": int(it5), "support_exact": ok5, "max_rel_coef_err": err5,
+            "engine": ("fp64 screened form (csrc/screen.hip): A^T y in fp64, the path solved by the fp64 engine on a sub-dictionary of the 2048 columns "
+                       "with the largest |c0| (a context of its own), every state certified against all columns by the pass over the fp16 copy of A"
+                       if st5["screen_signals"] > 0 else "lookahead engine, one launch per iteration"),
+            "screened_form": {"signals_certified": int(st5["screen_signals"]), "signals_redone_in_the_default_engine": int(st5["screen_redone"]),
+                              "certificate_headroom": st5["screen_headroom"]},
+            "without_screening": un5,
             "lookahead_sweeps_per_solve": st5["lookahead_sweeps"] / max(1, st5["solves"]),
             "lookahead_sweep_f64": {"ms": ms32, "GB/s": b32 / ms32 / 1e6, "frac_of_8TBs": b32 / ms32 / 1e6 / HBM_PEAK_GBS},
             "atr_gemv_f64": {"ms": ms1, "GB/s": b1 / ms1 / 1e6, "frac_of_8TBs": b1 / ms1 / 1e6 / HBM_PEAK_GBS}}

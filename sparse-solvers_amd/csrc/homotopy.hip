@@ -1022,6 +1022,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     handed_back = false;
                 }
             }
+            if (handed_back && std::getenv("SS_HIP_SUB_DEBUG")) {
+                ss_hip_ctx* sub = screen64_sub(ctx);
+                const DevState hsub = *static_cast<const DevState*>(sub->hs_pinned);
+                std::fprintf(stderr, "[screened form, fp64] handed back: sub-context status %u iter %u K %u ties %llu gram fallbacks %llu persist fallbacks %llu (%s)\n",
+                             hsub.status, hsub.iter, hsub.K, (unsigned long long)sub->stats.tie_reruns, (unsigned long long)sub->stats.gram_fallbacks,
+                             (unsigned long long)sub->stats.persist_fallbacks, err ? err : "");
+            }
             if (handed_back) {
                 // the sub-context's solve left its common path (a tie re-run, a residual-form retry, too many states): the usual engine
                 ctx->stats.screen_redone += 1;

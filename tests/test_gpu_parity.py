@@ -784,6 +784,18 @@ def test_fp64_full_size_vs_oracle(sship):
         assert it == k and err <= 1e-9
         assert np.array_equal(np.nonzero(x)[0], sup)
         assert np.abs(x[sup] - coef).max() <= 1e-10 * coef.max()
+        # the shipped default at this size: the fp64 screened form (csrc/screen.hip) — the path solved on the 2048 columns with
+        # the largest |c0|, every state certified against all 131 072 columns; against the default engine's result above
+        h.set_option("screen_single", 1)
+        h.reset_stats()
+        xs, its, errs = h.solve(y, 1e-9, 512)
+        sts = h.stats()
+        h.set_option("screen_single", 0)
+        assert sts["screen_signals"] == 1 and sts["screen_redone"] == 0 and 0.0 < sts["screen_headroom"] < 0.7
+        assert its == it and errs <= 1e-9
+        assert np.array_equal(np.nonzero(xs)[0], sup)
+        assert np.abs(xs[sup] - coef).max() <= 1e-10 * coef.max()
+        assert np.abs(xs - x).max() <= 1e-12 * np.abs(x).max()
         xq, itq, eq = h.solve_omp(y, 1e-9, 512)
         assert itq == k and eq <= 1e-9
         assert np.array_equal(np.nonzero(xq)[0], sup)

@@ -129,3 +129,30 @@ def test_screen_certificate_is_a_bound(sship):
             S.remove(j)
     note("test_screen_certificate_is_a_bound", worst_ratio=worst, headroom=st["screen_headroom"])
     assert worst <= st["screen_headroom"] + 1e-3         # the device's figure (|c~| + eps) / bound dominates |c| / (0.875 lambda)... loosely
+
+
+@pytest.mark.parametrize("shape", [(1024, 16384, 24), (1536, 9000, 40), (2048, 16384, 60), (1024, 12000, 16)])
+def test_screened_form_fp64_vs_oracle(sship, shape):
+    """fp64: the path is solved by the fp64 engine on a sub-dictionary (the 2048 columns with the largest |c0|, a context of its
+    own, every state logged) and certified against all columns by the fp16 pass.  Certified signals equal the oracle within
+    1e-10; what the form hands back (a support column outside the sub-dictionary: the sub-solve wanders) is the default
+    engine's result bit for bit."""
+    m, n, k = shape
+    A, y, x0, sup = make_gaussian_problem(9400 + m + k, m, n, k, np.float64)
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.reset_stats()
+        xg, itg, eg = h.solve(y, 1e-9, 4 * k)
+        st = h.stats()
+        h.set_option("screen_single", 0)
+        xd, itd, ed = h.solve(y, 1e-9, 4 * k)
+    xo, ito, eo = oracle.homotopy(A, y, 1e-9, 4 * k)
+    note("test_screened_form_fp64_vs_oracle", shape=list(shape), certified=st["screen_signals"], redone=st["screen_redone"],
+         headroom=st["screen_headroom"])
+    assert st["screen_signals"] + st["screen_redone"] == 1
+    assert_parity(xg, itg, eg, xo, ito, eo, np.float64)
+    if st["screen_redone"]:
+        assert itg == itd and eg == ed and np.array_equal(xg, xd)
+    else:
+        assert 0.0 < st["screen_headroom"] < 1.0
+        assert np.abs(xg - xd).max() <= 1e-12 * np.abs(xd).max()
