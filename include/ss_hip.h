@@ -371,6 +371,8 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    |c~| + eps <= 7/8 lambda with eps = 2^-9 ||a_i|| ||r_k|| + flush terms, a rigorous bound.  Nothing
  *                    reported comes from that pass; a signal it cannot certify, or whose path leaves the subset form's
  *                    common path, is solved again by the default engine (ss_hip_stats::screen_signals / screen_redone).
+ *                    fp64 contexts (>= 32768 columns, >= 64 Mi entries): the same certificate around the fp64 engine, which
+ *                    solves the path on a sub-dictionary of the 2048 columns with the largest |c0| (a context of its own).
  *                    2 = on every shape the form can run on (tests); 0 = never.  Initial value: environment variable
  *                    SS_HIP_SCREEN_SINGLE when set.  Stands in for the default speculative engine only ("la_fused" = 3,
  *                    "early_solo" = 1); with G = A^T A in HBM the subset form on G is used instead ("gram_single").

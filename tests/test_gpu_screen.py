@@ -156,3 +156,27 @@ def test_screened_form_fp64_vs_oracle(sship, shape):
     else:
         assert 0.0 < st["screen_headroom"] < 1.0
         assert np.abs(xg - xd).max() <= 1e-12 * np.abs(xd).max()
+
+
+def test_screened_form_fp64_hands_back(sship):
+    """A support column outside the 2048-column sub-dictionary: the sub-context's solve wanders beyond the states the form can
+    certify and the signal is handed back — the default engine's result, bit for bit, and the oracle's."""
+    m, n, k = 2048, 16384, 60
+    rng = np.random.default_rng(5002)
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    sup = np.sort(rng.choice(n, k, replace=False))
+    x0 = np.zeros(n)
+    x0[sup] = 1.0 + np.abs(rng.standard_normal(k))
+    y = A @ x0
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.reset_stats()
+        xg, itg, eg = h.solve(y, 1e-9, 4 * k)
+        st = h.stats()
+        h.set_option("screen_single", 0)
+        xd, itd, ed = h.solve(y, 1e-9, 4 * k)
+    xo, ito, eo = oracle.homotopy(A, y, 1e-9, 4 * k)
+    note("test_screened_form_fp64_hands_back", certified=st["screen_signals"], redone=st["screen_redone"])
+    assert st["screen_signals"] + st["screen_redone"] == 1
+    assert itg == itd and eg == ed and np.array_equal(xg, xd)
+    assert_parity(xg, itg, eg, xo, ito, eo, np.float64)
