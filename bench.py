@@ -835,6 +835,19 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                    "max_rel_diff_of_coefficients": float(((xu5 - x5).abs().max() / x5.abs().max()).item())}
             del xu5
             h5.set_option("screen_single", 1)
+        # configs[4] names OMP: the same signal through ss::omp<double> (parity unpinned: the reference has no OMP)
+        xo5 = torch.zeros(n5, device=dev, dtype=torch.float64)
+        h5.solve_omp(y5, 1e-9, 512, out=xo5)
+        torch.cuda.synchronize()
+        to5 = time.perf_counter()
+        for _ in range(2):
+            _, ito5, _ = h5.solve_omp(y5, 1e-9, 512, out=xo5)
+        torch.cuda.synchronize()
+        dto5 = (time.perf_counter() - to5) / 2
+        xo5h = xo5.cpu().numpy()
+        omp5 = {"ms_per_solve": dto5 * 1e3, "picks": int(ito5), "support_exact": bool(np.array_equal(np.nonzero(xo5h)[0], sup5)),
+                "max_rel_coef_err": float(np.abs(xo5h[sup5] - coef5).max() / coef5.max())}
+        del xo5
         _, ms32 = h5.gram_cols(np.arange(0, 32000, 1000, dtype=np.uint32), 5)
         _, ms1 = h5.gemv_t(y5, 3)
         b32 = m5 * n5 * 8 + 32 * m5 * 8 + 32 * n5 * 8
@@ -848,6 +861,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             "screened_form": {"signals_certified": int(st5["screen_signals"]), "signals_redone_in_the_default_engine": int(st5["screen_redone"]),
                               "certificate_headroom": st5["screen_headroom"]},
             "without_screening": un5,
+            "omp_fp64_same_signal": omp5,
             "lookahead_sweeps_per_solve": st5["lookahead_sweeps"] / max(1, st5["solves"]),
             "lookahead_sweep_f64": {"ms": ms32, "GB/s": b32 / ms32 / 1e6, "frac_of_8TBs": b32 / ms32 / 1e6 / HBM_PEAK_GBS},
             "atr_gemv_f64": {"ms": ms1, "GB/s": b1 / ms1 / 1e6, "frac_of_8TBs": b1 / ms1 / 1e6 / HBM_PEAK_GBS}}

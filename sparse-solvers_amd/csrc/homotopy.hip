@@ -929,8 +929,8 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     ctx->solo_subset == 256 && screen_form_usable(ctx);
         // fp64: the same certificate around the fp64 engine — the path is solved by a context of its own on the 2048 columns with
         // the largest |c0| (passes and iterations on 1.6 % of the dictionary), its logged states are screened against all columns
-        bool scr64 = la && sizeof(T) == 8 && !no_sub && !ctx->tracing && rec_out == nullptr && ctx->la_fused >= 1 && max_iter < 190u * 4u &&
-                     screen64_usable(ctx);
+        // (not with a trace or compact records asked for: the sub-context's lists are over ITS columns)
+        bool scr64 = la && sizeof(T) == 8 && !no_sub && !ctx->tracing && rec_out == nullptr && ctx->la_fused >= 1 && screen64_usable(ctx);
         if ((sub1 || scr1 || scr64) && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; scr1 = false; scr64 = false; }
         uint32_t scr_launches = 1;
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
