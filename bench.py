@@ -835,7 +835,8 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                    "max_rel_diff_of_coefficients": float(((xu5 - x5).abs().max() / x5.abs().max()).item())}
             del xu5
             h5.set_option("screen_single", 1)
-        # configs[4] names OMP: the same signal through ss::omp<double> (parity unpinned: the reference has no OMP)
+        # configs[4] names OMP: the same signal through ss::omp<double> (parity unpinned: the reference has no OMP); it takes the fp64
+        # screened form as well (the sub-context runs k_la_omp)
         xo5 = torch.zeros(n5, device=dev, dtype=torch.float64)
         h5.solve_omp(y5, 1e-9, 512, out=xo5)
         torch.cuda.synchronize()

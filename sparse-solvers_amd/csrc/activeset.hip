@@ -1582,8 +1582,10 @@ void k_la_omp(T tol, uint32_t max_iter, uint32_t n, T gram_guard,
               const T* __restrict__ gcache, const int32_t* __restrict__ slot_of, const T* __restrict__ c0,
               uint32_t gpitch, T* c, T* x, uint8_t* insup, T* pmax_val, uint32_t* pmax_idx,
               uint32_t* gam2, uint32_t* touched2, T* inv0, T* inv1, T* u1, T* u2, T* sgn, T* q_unused, T* d_unused,
-              SlotDims L, DevState* st, uint32_t* hflags, TraceEntry* trace, uint32_t trace_cap)
+              SlotDims L, DevState* st, uint32_t* hflags, TraceEntry* trace, uint32_t trace_cap,
+              unsigned char* slog, uint32_t slog_cap, uint32_t slog_kmax)
 {
+    // (slog: the state every launch starts from, as in k_la_iter — the fp64 screened form's sub-context)
     __shared__ T sv[16];
     __shared__ uint32_t si[16];
     __shared__ uint32_t s_flag;
@@ -1659,6 +1661,23 @@ void k_la_omp(T tol, uint32_t max_iter, uint32_t n, T gram_guard,
     T c_inf;
     uint32_t idx;
     reduce_partials_agent(pmax_val, pmax_idx, gridDim.x, c_inf, idx, sv, si);
+    if (slog != nullptr) {
+        const uint32_t t = round - 1u;
+        if (t < slog_cap) {
+            uint32_t* l_cnt = reinterpret_cast<uint32_t*>(slog);
+            double* l_lam = reinterpret_cast<double*>(slog + (((size_t)slog_cap * 4 + 7) & ~(size_t)7));
+            uint32_t* l_cols = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(l_lam) + (size_t)slog_cap * 8);
+            T* l_vals = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(l_cols) + ((((size_t)slog_cap * slog_kmax * 4) + 7) & ~(size_t)7));
+            const bool fits = K <= slog_kmax;
+            if (fits)
+                for (uint32_t j = tid; j < K; j += blockDim.x) {
+                    const uint32_t col = gam[j];
+                    l_cols[(size_t)t * slog_kmax + j] = col;
+                    l_vals[(size_t)t * slog_kmax + j] = x[col];
+                }
+            if (tid == 0) { l_cnt[t] = fits ? K : 0xffffffffu; l_lam[t] = (double)c_inf; }
+        }
+    }
     if (round == 1u && gram_guard > T(0) && tol < gram_guard * c_inf) {
         // tolerance too tight for Gram-form correlations: the host re-runs in residual form
         if (tid == 0) {
@@ -1996,7 +2015,8 @@ hipError_t launch_la_omp(const ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_
     hipLaunchKernelGGL((k_la_omp<T>), dim3(nb), dim3(kItThreads), 0, ctx->stream, tol, max_iter, n, guard,
                        (const T*)ws.gcache, (const int32_t*)ws.slot_of, (const T*)ws.c0, ws.gpitch,
                        ws.c, ws.x, ws.insup, ws.pmax_val, ws.pmax_idx, ws.gam, ws.touched, ws.inv[0], ws.inv[1],
-                       ws.u1, ws.u2, ws.sgn, ws.q, ws.d, ws.dims, ws.st, ctx->dev_flags, ws.trace, ws.trace_cap);
+                       ws.u1, ws.u2, ws.sgn, ws.q, ws.d, ws.dims, ws.st, ctx->dev_flags, ws.trace, ws.trace_cap,
+                       static_cast<unsigned char*>(ctx->slog), ctx->slog_cap, ctx->slog_kmax);
     return hipGetLastError();
 }
 

@@ -930,7 +930,8 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         // fp64: the same certificate around the fp64 engine — the path is solved by a context of its own on the 2048 columns with
         // the largest |c0| (passes and iterations on 1.6 % of the dictionary), its logged states are screened against all columns
         // (not with a trace or compact records asked for: the sub-context's lists are over ITS columns)
-        bool scr64 = la && sizeof(T) == 8 && !no_sub && !ctx->tracing && rec_out == nullptr && ctx->la_fused >= 1 && screen64_usable(ctx);
+        // (OMP too: the sub-context runs k_la_omp, the certificate is the same — nothing outside the sub-dictionary reaches the pick's |c|)
+        bool scr64 = (la || la_omp) && sizeof(T) == 8 && !no_sub && !ctx->tracing && rec_out == nullptr && ctx->la_fused >= 1 && screen64_usable(ctx);
         if ((sub1 || scr1 || scr64) && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; scr1 = false; scr64 = false; }
         uint32_t scr_launches = 1;
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
@@ -981,17 +982,9 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             ws.gram_is_full = true;
             full_view.on = true;
         };
-        if (la_omp) {
+        if (scr64) {
             Lookahead<T>::ensure(ctx, ws, kcap);
-            enter_full_gram();
-            uint32_t nb1 = 0;
-            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
-            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
-            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
-            if (!ws.gram_is_full) HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // nothing cached yet
-        } else if (scr64) {
-            Lookahead<T>::ensure(ctx, ws, kcap);
-            HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y
+            if (!omp) HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y (OMP: done above)
             uint32_t nb1 = 0;
             if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
             HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
@@ -1007,7 +1000,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 const uint64_t ties0 = sub->stats.tie_reruns, gf0 = sub->stats.gram_fallbacks, pf0 = sub->stats.persist_fallbacks;
                 uint32_t it_s = 0;
                 double e_s = 0.0;
-                const int rc_s = solve_impl<T>(sub, ws.rhs, 1, tol, max_iter, screen64_xsub(ctx), 1, &it_s, &e_s, err, errlen, false, false, false,
+                const int rc_s = solve_impl<T>(sub, ws.rhs, 1, tol, max_iter, screen64_xsub(ctx), 1, &it_s, &e_s, err, errlen, omp, false, false,
                                                nullptr, 0, false, true);
                 HIPCHK(hipSetDevice(ctx->device));
                 const bool clean = rc_s == SS_HIP_OK && sub->stats.tie_reruns == ties0 && sub->stats.gram_fallbacks == gf0 &&
@@ -1034,6 +1027,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 ctx->stats.screen_redone += 1;
                 return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
             }
+        } else if (la_omp) {
+            Lookahead<T>::ensure(ctx, ws, kcap);
+            enter_full_gram();
+            uint32_t nb1 = 0;
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+            if (!ws.gram_is_full) HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // nothing cached yet
         } else if (sub1 || scr1) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y

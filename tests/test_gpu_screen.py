@@ -180,3 +180,34 @@ def test_screened_form_fp64_hands_back(sship):
     assert st["screen_signals"] + st["screen_redone"] == 1
     assert itg == itd and eg == ed and np.array_equal(xg, xd)
     assert_parity(xg, itg, eg, xo, ito, eo, np.float64)
+
+
+@pytest.mark.parametrize("shape", [(1024, 16384, 24), (1536, 9000, 40), (2048, 16384, 60)])
+def test_screened_form_fp64_omp(sship, shape):
+    """OMP (ss::omp<double>; no reference implementation: pinned against this library's default OMP engine and numpy's least
+    squares on the planted support) through the fp64 screened form: the sub-context runs k_la_omp, the certificate is that no
+    column outside the sub-dictionary reaches the pick's |c|."""
+    m, n, k = shape
+    seed = {24: 1, 40: 3, 60: 2}[k]
+    rng = np.random.default_rng(5000 + seed)
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    sup = np.sort(rng.choice(n, k, replace=False))
+    x0 = np.zeros(n)
+    x0[sup] = 1.0 + np.abs(rng.standard_normal(k))
+    y = A @ x0
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.reset_stats()
+        xg, itg, eg = h.solve_omp(y, 1e-9, 4 * k)
+        st = h.stats()
+        h.set_option("screen_single", 0)
+        xd, itd, ed = h.solve_omp(y, 1e-9, 4 * k)
+    note("test_screened_form_fp64_omp", shape=list(shape), certified=st["screen_signals"], redone=st["screen_redone"], headroom=st["screen_headroom"])
+    assert st["screen_signals"] + st["screen_redone"] == 1
+    assert itg == itd == k and np.array_equal(np.nonzero(xg)[0], sup)
+    if st["screen_redone"]:
+        assert eg == ed and np.array_equal(xg, xd)
+    else:
+        assert np.abs(xg - xd).max() <= 1e-12 * np.abs(xd).max()
+    ls = np.linalg.lstsq(A[:, sup], y, rcond=None)[0]
+    assert np.abs(xg[sup] - ls).max() <= 1e-10 * np.abs(ls).max()
