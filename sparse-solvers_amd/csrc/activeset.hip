@@ -1448,7 +1448,8 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
         if (t < slog_cap) {
             uint32_t* l_cnt = reinterpret_cast<uint32_t*>(slog);
             double* l_lam = reinterpret_cast<double*>(slog + (((size_t)slog_cap * 4 + 7) & ~(size_t)7));
-            uint32_t* l_cols = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(l_lam) + (size_t)slog_cap * 8);
+            double* l_exp = l_lam + slog_cap;                  // where the previous step left lambda: lambda_prev - gamma_prev
+            uint32_t* l_cols = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(l_exp) + (size_t)slog_cap * 8);
             T* l_vals = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(l_cols) + ((((size_t)slog_cap * slog_kmax * 4) + 7) & ~(size_t)7));
             const bool fits = nt <= slog_kmax;
             if (fits)
@@ -1457,7 +1458,7 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
                     l_cols[(size_t)t * slog_kmax + j] = col;
                     l_vals[(size_t)t * slog_kmax + j] = x[col];
                 }
-            if (tid == 0) { l_cnt[t] = fits ? nt : 0xffffffffu; l_lam[t] = (double)c_inf; }
+            if (tid == 0) { l_cnt[t] = fits ? nt : 0xffffffffu; l_lam[t] = (double)c_inf; l_exp[t] = st->c_inf - st->gamma; }
         }
     }
 
@@ -1666,7 +1667,8 @@ void k_la_omp(T tol, uint32_t max_iter, uint32_t n, T gram_guard,
         if (t < slog_cap) {
             uint32_t* l_cnt = reinterpret_cast<uint32_t*>(slog);
             double* l_lam = reinterpret_cast<double*>(slog + (((size_t)slog_cap * 4 + 7) & ~(size_t)7));
-            uint32_t* l_cols = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(l_lam) + (size_t)slog_cap * 8);
+            double* l_exp = l_lam + slog_cap;                  // (OMP takes no step lengths: the pick's |c| itself is what counts)
+            uint32_t* l_cols = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(l_exp) + (size_t)slog_cap * 8);
             T* l_vals = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(l_cols) + ((((size_t)slog_cap * slog_kmax * 4) + 7) & ~(size_t)7));
             const bool fits = K <= slog_kmax;
             if (fits)
@@ -1675,7 +1677,7 @@ void k_la_omp(T tol, uint32_t max_iter, uint32_t n, T gram_guard,
                     l_cols[(size_t)t * slog_kmax + j] = col;
                     l_vals[(size_t)t * slog_kmax + j] = x[col];
                 }
-            if (tid == 0) { l_cnt[t] = fits ? K : 0xffffffffu; l_lam[t] = (double)c_inf; }
+            if (tid == 0) { l_cnt[t] = fits ? K : 0xffffffffu; l_lam[t] = (double)c_inf; l_exp[t] = (double)c_inf; }
         }
     }
     if (round == 1u && gram_guard > T(0) && tol < gram_guard * c_inf) {

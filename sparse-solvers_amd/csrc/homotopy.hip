@@ -833,11 +833,11 @@ inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, 
 // (typed shims of the fp64 screened form: never reached for float)
 inline hipError_t scr64_gather(ss_hip_ctx* ctx, const double* c0) { return screen64_gather(ctx, c0); }
 inline hipError_t scr64_gather(ss_hip_ctx*, const float*) { return hipErrorInvalidConfiguration; }
-inline hipError_t scr64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K, hipEvent_t e2, hipEvent_t e3)
+inline hipError_t scr64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K, hipEvent_t e2, hipEvent_t e3, bool omp)
 {
-    return screen64_certify(ctx, ws, y, T, tol, c_inf, K, e2, e3);
+    return screen64_certify(ctx, ws, y, T, tol, c_inf, K, e2, e3, omp);
 }
-inline hipError_t scr64_certify(ss_hip_ctx*, Workspace<float>&, const float*, uint32_t, float, double, uint32_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr64_certify(ss_hip_ctx*, Workspace<float>&, const float*, uint32_t, float, double, uint32_t, hipEvent_t, hipEvent_t, bool) { return hipErrorInvalidConfiguration; }
 
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
@@ -1009,7 +1009,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     const DevState hsub = *static_cast<const DevState*>(sub->hs_pinned);
                     hipEvent_t e2 = nullptr, e3 = nullptr;
                     if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); }
-                    HIPCHK(scr64_certify(ctx, ws, ws.rhs, it_s, tol, e_s, hsub.K, e2, e3));
+                    HIPCHK(scr64_certify(ctx, ws, ws.rhs, it_s, tol, e_s, hsub.K, e2, e3, omp));
                     if (prof) { ctx->prof_kind.push_back(6); ++nprof; }
                     scr_launches = (it_s + 95u) / 96u;
                     handed_back = false;

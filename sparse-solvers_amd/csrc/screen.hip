@@ -25,10 +25,14 @@
 // the reference skips; a positive one gives t > gamma_k  <=>  +/- c_i(k+1) < lambda_{k+1}.  So the reference's scan over
 // all n columns picks what the subset's scan picked, state after state.  The bound keeps a MARGIN (1/8 of lambda_k, and
 // 1e-5 lambda_0 absolute) between "certified" and "equal", far above any fp32 rounding of the reference's own correlations
-// (the columns that matter sit at ~0.4 lambda on a Gaussian dictionary; the subset holds the ones near lambda).  The state
-// a path ENDS in (lambda <= tolerance) is certified against the tolerance itself: no column outside the subset keeps the
-// path going.  The last step before it is the rounding-level tie of every column that every form of this library treats
-// the same way (whichever column the reference inserts there enters with x = 0).
+// (the columns that matter sit at ~0.4 lambda on a Gaussian dictionary; the subset holds the ones near lambda).  "lambda_{k+1}"
+// above is where the step LEFT lambda, lambda_k - gamma_k: on a regular path that is the next max |c|, on a derailed one
+// (the reference's first-step sign quirk) max |c| can sit above it — the bound takes the smaller of the two
+// (tools/stress_screen.py found both this and the next point).  The state a path ENDS in by tolerance: if its last step
+// landed on lambda = 0 within rounding (the least-squares jump of a noise-free path) every column's candidate ties with that
+// step — whichever column the reference inserts there enters with x = 0 — and the state is certified against the
+// tolerance itself: nothing out there keeps the path going.  A path that crosses the tolerance on a regular step (noise) has
+// that step certified like any other.
 //
 // The error bound.  a16 = fl16(sA a), r16 = fl16(s_k r) with powers of two sA, s_k; round-to-nearest gives relative
 // errors <= 2^-11 each in the normal range, the MFMA accumulates in fp32 (<= ldm 2^-24 relative to sum |a||r| at worst),
@@ -312,9 +316,23 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
             const float lam = __uint_as_float(hh[4]);
             const bool final_state = !(hh[1] & 1u);
             const float slack = 1e-5f * lam0;
+            // where the step INTO this state left lambda: lambda_{k-1} - gamma_{k-1}.  On a regular path that is lambda_k; on a
+            // derailed one (the first-step sign quirk) max |c| can sit above it — and the candidate test of that step compares
+            // the column's next correlation with lambda_{k-1} - gamma_{k-1}, not with max |c|: the smaller of the two counts
+            const uint32_t* hp = hdr + (size_t)tid * 8u;
+            const float lam_exp = __uint_as_float(hp[4]) - __uint_as_float(hp[5]);
+            // The state a path ends in by tolerance.  If the last step landed on lambda = 0 within rounding (the least-squares jump
+            // of a noise-free path) every column's candidate ties with it — whichever the reference inserts enters with x = 0
+            //  — and what is left to certify is that nothing out there keeps the path going: |c| <= tolerance.
+            // Otherwise (noise: the path crosses the tolerance on a regular step) that step is certified like any other.
+            const bool ls_jump = final_state && !(lam > tol) && !(lam_exp > 2e-6f * lam0);
             float bound;
-            if (final_state && !(lam > tol)) bound = tol * 0.9375f - slack;     // the path ended by tolerance: nothing out there keeps it going
-            else bound = lam * 0.875f - slack;
+            if (ls_jump) bound = tol * 0.9375f - slack;
+            else bound = fminf(lam, lam_exp) * 0.875f - slack;
+            // only REGULAR paths are certified: every step inserts a column and lambda goes down.  On a path with removals, or one
+            // the first-step sign quirk has derailed, steps of rounding size decide what is toggled next, and the subset's Gram
+            // matrix is the default engine's only to rounding (see k_s64_dense): those go back to that engine
+            if (hp[3] == 0u || lam > __uint_as_float(hp[4]) * 1.00001f) bound = -1.f;
             const float inv_sk = 1.f / sS[tid];
             tab[tid * kScrTab + 0] = meta[1] * inv_sk;
             tab[tid * kScrTab + 1] = bound;
@@ -504,16 +522,21 @@ void k_s64_gather(const double* __restrict__ src, uint32_t ldm, uint32_t n, cons
 // The states' coefficients over ONE list — the final list of touched columns (sub-indices, ascending: every earlier list is a
 // subset of it) — transposed: xd[u][kk] = coefficient of list entry u in state kk + 1.  One workgroup per state.
 __global__ __launch_bounds__(256)
-void k_s64_dense(const unsigned char* __restrict__ slog, uint32_t T, double* __restrict__ xd, uint32_t* __restrict__ ctl)
+void k_s64_dense(const unsigned char* __restrict__ slog, uint32_t T, double* __restrict__ xd, uint32_t* __restrict__ ctl, int omp)
 {
     const uint32_t* l_cnt = reinterpret_cast<const uint32_t*>(slog);
     const double* l_lam = reinterpret_cast<const double*>(slog + (((size_t)kS64LogCap * 4 + 7) & ~(size_t)7));
-    const uint32_t* l_cols = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(l_lam) + (size_t)kS64LogCap * 8);
+    const uint32_t* l_cols = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(l_lam) + (size_t)2 * kS64LogCap * 8);
     const double* l_vals = reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(l_cols) + ((((size_t)kS64LogCap * kS64LogK * 4) + 7) & ~(size_t)7));
     const uint32_t kk = blockIdx.x, t = kk + 1u;
     const uint32_t nfin = l_cnt[T], cnt = l_cnt[t];
     constexpr uint32_t pitch = kS64Rhs + 8u;
     if (nfin == 0xffffffffu || cnt == 0xffffffffu || cnt > nfin || nfin > kS64LogK) { if (threadIdx.x == 0) ctl[0] = 1u; return; }
+    // Homotopy: only REGULAR paths are certified — every iteration inserts a column and lambda goes down.  On a path with removals or
+    // one the first-step sign quirk has derailed, steps of rounding size (a support coefficient of 1e-16) decide what is toggled next,
+    // and the sub-dictionary's Gram columns are the full engine's only to rounding (their rows are summed in chunks): such a signal goes
+    // back to the engine whose roundings are the reference's to compare with (tools/dbg_screen224.py: iteration 47 of that path).
+    if (!omp && (cnt != t + 1u || l_lam[t] > l_lam[t - 1u] * (1.0 + 1e-12))) { if (threadIdx.x == 0) ctl[0] = 1u; return; }
     const uint32_t* fin = l_cols + (size_t)T * kS64LogK;
     for (uint32_t u = threadIdx.x; u < kS64LogK; u += 256u) xd[(size_t)u * pitch + kk] = 0.0;
     __syncthreads();
@@ -540,7 +563,8 @@ void k_s64_residuals(const double* __restrict__ Asub, uint32_t ldm, const double
     __shared__ float sS[kS64Rhs];
     const uint32_t* l_cnt = reinterpret_cast<const uint32_t*>(slog);
     const double* l_lam = reinterpret_cast<const double*>(slog + (((size_t)kS64LogCap * 4 + 7) & ~(size_t)7));
-    const uint32_t* l_cols = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(l_lam) + (size_t)kS64LogCap * 8);
+    const double* l_exp = l_lam + kS64LogCap;
+    const uint32_t* l_cols = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(l_exp) + (size_t)kS64LogCap * 8);
     if (ctl[0] != 0u) return;
     const uint32_t nst = T;                                      // states 1 .. T
     const uint32_t nfin = l_cnt[T];
@@ -634,8 +658,10 @@ void k_s64_residuals(const double* __restrict__ Asub, uint32_t ldm, const double
             const bool final_state = tid + 1u == T;
             const float slack = 1e-12f * (float)l_lam[0];           // (state 0: x = 0, lambda_0 = ||A^T y||_inf; fp64: the reference's own rounding is 1e-16)
             float bound;
-            if (final_state && !((double)lam > tol)) bound = (float)tol * 0.9375f - slack;
-            else bound = lam * 0.875f - slack;
+            // (the smaller of max |c| and lambda_prev - gamma_prev: see k_scr_residuals)
+            const bool ls_jump = final_state && !((double)lam > tol) && !(l_exp[tid + 1u] > 1e-13 * l_lam[0]);
+            if (ls_jump) bound = (float)tol * 0.9375f - slack;
+            else bound = fminf(lam, (float)l_exp[tid + 1u]) * 0.875f - slack;
             const float inv_sk = 1.f / sS[tid];
             tab[tid * kScrTab + 0] = meta[1] * inv_sk;
             tab[tid * kScrTab + 1] = bound;
@@ -769,7 +795,7 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
 static size_t s64_log_bytes()
 {
     size_t b = ((size_t)kS64LogCap * 4 + 7) & ~(size_t)7;
-    b += (size_t)kS64LogCap * 8;
+    b += (size_t)2 * kS64LogCap * 8;
     b += (((size_t)kS64LogCap * kS64LogK * 4) + 7) & ~(size_t)7;
     b += (size_t)kS64LogCap * kS64LogK * 8;
     return b;
@@ -857,7 +883,7 @@ hipError_t screen64_gather(ss_hip_ctx* ctx, const double* c0)
 // After the sub-context's solve (T iterations, synchronised): the certificate of its T states against all columns, the
 // solution scattered into x, the verdict into the slot's state.  y = the signal (device, ldm entries, zero padded).
 hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K,
-                            hipEvent_t e2, hipEvent_t e3)
+                            hipEvent_t e2, hipEvent_t e3, bool omp)
 {
     ScreenState* S = scr_of(ctx);
     if (S == nullptr || S->sub == nullptr || T == 0u || T > kS64Rhs) return hipErrorInvalidConfiguration;
@@ -865,7 +891,7 @@ hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double
     const uint32_t ldm = ctx->ldm, n = (uint32_t)ctx->n, np = ctx->n_pad;
     (void)hipMemsetAsync(S->ctl, 0, 8 * sizeof(uint32_t), s);
     const unsigned char* slog = static_cast<const unsigned char*>(S->sub->slog);
-    hipLaunchKernelGGL(k_s64_dense, dim3(T), dim3(256), 0, s, slog, T, S->xd, S->ctl);
+    hipLaunchKernelGGL(k_s64_dense, dim3(T), dim3(256), 0, s, slog, T, S->xd, S->ctl, omp ? 1 : 0);
     hipLaunchKernelGGL(k_s64_residuals, dim3(ldm / 64u), dim3(256), 0, s, static_cast<const double*>(S->sub->At), ldm, y, slog, T,
                        (const double*)S->xd, tol, (const float*)S->meta, S->r16, S->rn2p, S->tab, S->ctl, reinterpret_cast<uint32_t*>(S->meta) + 3);
     if (e2) (void)hipEventRecord(e2, s);

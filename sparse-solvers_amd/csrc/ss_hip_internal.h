@@ -262,7 +262,7 @@ struct ss_hip_ctx {
                                       // the form can run on (tests), 0 = never
     int screen_failed_alloc = 0;      // the preparation did not fit: not tried again
     // state log of the launch-per-iteration form (k_la_iter; on in the sub-context of the fp64 screened form, screen.hip):
-    // cnt[cap] u32, lambda[cap] f64, cols[cap][kmax] u32, vals[cap][kmax] T — the state every launch starts from
+    // cnt[cap] u32, lambda[cap] f64, lambda_prev - gamma_prev [cap] f64, cols[cap][kmax] u32, vals[cap][kmax] T — the state every launch starts from
     void* slog = nullptr;
     uint32_t slog_cap = 0, slog_kmax = 0;
     // narrow fp64 dictionaries (the same sub-context): the passes split their rows over pass_ksplit workgroups per column tile,
@@ -436,7 +436,7 @@ ss_hip_ctx* screen64_sub(ss_hip_ctx* ctx);
 double* screen64_xsub(ss_hip_ctx* ctx);
 hipError_t screen64_gather(ss_hip_ctx* ctx, const double* c0);
 hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K,
-                            hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
+                            hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr, bool omp = false);
 double screen_read_headroom(ss_hip_ctx* ctx);             // largest (|c~| + eps) / bound of the last screened solve (synchronises)
 hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr);      // signals one pass of the engine can carry (1 without the LDS-staged sweep)

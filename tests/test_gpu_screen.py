@@ -211,3 +211,60 @@ def test_screened_form_fp64_omp(sship, shape):
         assert np.abs(xg - xd).max() <= 1e-12 * np.abs(xd).max()
     ls = np.linalg.lstsq(A[:, sup], y, rcond=None)[0]
     assert np.abs(xg[sup] - ls).max() <= 1e-10 * np.abs(ls).max()
+
+
+def test_screened_form_random_problems(sship):
+    """tools/stress_screen.py in small: random shapes, fp32 and fp64, signed coefficients (the reference's first-step sign quirk
+    derails those paths), noise, both modes.  Whatever the form certifies must be the oracle's; whatever it hands back must be the
+    default engine's bit for bit.  (This is the test that found the two holes of the first certificate: a bound against max |c|
+    instead of lambda_prev - gamma_prev on derailed paths, and the uncertified last regular step of a noisy path.)"""
+    rng = np.random.default_rng(20261004)
+    cert = redone = 0
+    for case in range(45):
+        f64 = case % 3 == 2
+        dt = np.float64 if f64 else np.float32
+        m = int(rng.choice([512, 768, 1024, 1536, 2048]))
+        n = int(rng.choice([8192, 12000, 16384] if f64 else [2048, 4096, 8192, 16384]))
+        k = int(rng.integers(4, max(5, m // 24)))
+        signed = bool(rng.integers(0, 2))
+        noise = float(rng.choice([0.0, 0.0, 1e-4, 1e-2]))
+        fixes = bool(rng.integers(0, 2))
+        A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(dt)
+        sup = np.sort(rng.choice(n, k, replace=False))
+        x0 = np.zeros(n)
+        x0[sup] = 1.0 + np.abs(rng.standard_normal(k))
+        if signed:
+            x0[sup] *= rng.choice([-1.0, 1.0], k)
+        y = A.astype(np.float64) @ x0
+        if noise:
+            y = y + noise * rng.standard_normal(m)
+        y = y.astype(dt)
+        tol = 1e-9 if f64 else 1e-3
+        budget = 3 * k + 8
+        flags = oracle.SPARSE_NOTRANS | ((oracle.ZERO_ON_REMOVAL | oracle.TIE_GUARD) if fixes else 0)
+        with sship.Homotopy(A) as h:
+            if fixes:
+                h.set_option("tie_guard", 1)
+                h.set_option("zero_on_removal", 1)
+            h.set_option("screen_single", 2)
+            h.reset_stats()
+            x, it, e = h.solve(y, tol, budget)
+            st = h.stats()
+            h.set_option("screen_single", 0)
+            xd, itd, ed = h.solve(y, tol, budget)
+        tag = (case, m, n, k, signed, noise, fixes)
+        assert st["screen_signals"] + st["screen_redone"] == 1, tag
+        if st["screen_redone"]:
+            redone += 1
+            assert it == itd and np.array_equal(x, xd), tag
+            continue
+        cert += 1
+        xo, ito, eo = oracle.homotopy(A, y, tol, budget, flags=flags)
+        lim = 1e-10 if f64 else 1e-5
+        reld = np.abs(xd.astype(np.float64) - xo).max() / np.abs(xo).max()
+        assert it == ito, tag
+        assert np.array_equal(significant_support(x, 100 * lim), significant_support(xo, 100 * lim)), tag
+        assert np.abs(x.astype(np.float64) - xo).max() <= max(lim, 3 * reld) * np.abs(xo).max(), tag
+        assert 0.0 < st["screen_headroom"] < 1.0, tag
+    note("test_screened_form_random_problems", certified=cert, handed_back=redone)
+    assert cert >= 8 and redone >= 8
