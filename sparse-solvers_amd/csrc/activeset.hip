@@ -1388,6 +1388,8 @@ void k_la_iter(T tol, uint32_t max_iter, uint32_t n,
             __syncthreads();
             // whole groups of UNR rows with all their loads in flight; a short last group is padded with
             // zero coefficients on a valid row (exact zeros) — a row at a time would be a memory round trip each
+            // (more rows in flight were tried for the narrow dictionary of the fp64 screened form's sub-context, where this phase is two
+            // workgroups walking K rows: 16 change nothing — 14 us, two CUs' bandwidth —, 32 spill at 1024 threads: 60 us)
             constexpr int UNR = 8;
             for (uint32_t j = 0; j < cnt; j += UNR) {
                 T gv[UNR][COLS];

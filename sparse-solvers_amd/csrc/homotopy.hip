@@ -1308,7 +1308,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         }
         if (iter_out) *iter_out = hs.iter;
         if (err_out) *err_out = hs.c_inf;
-        if (la && ws.la_dbg) {
+        if (la && ws.la_dbg && !scr64) {                 // (fp64 screened form: the stamps are the sub-context's, dumped by its solve)
             if (const char* path = std::getenv("SS_HIP_LA_DEBUG")) {
                 std::vector<uint64_t> tsb(2048 * 8);
                 HIPCHK(hipMemcpy(tsb.data(), ws.la_dbg, tsb.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
