@@ -410,6 +410,9 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
         if (gsub && !((double)tol >= kGramGuard * (double)lambda0)) status = kStatusSubsetDecline;
 
         for (uint32_t round = 1; status == 0u; ++round) {
+            // (the round's hand-shake words — whose column was picked, a tie seen — are cleared here: the reductions' barriers lie
+            // between this and their writers, the previous round's readers are many barriers back)
+            if (j == 0) { s_u[1] = 0xffffffffu; s_u[2] = 0u; s_u[3] = 0u; }
             // ---- c, q of my column: the chain over the positions -----------------------------------------------
             float cv = c0v, qv = 0.f;
             for (uint32_t p = 0; p < P; p += 4) {                     // (whole groups of 4: positions >= P carry x = d = 0 and zero rows)
@@ -460,15 +463,14 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                     }
                 }
             }
-            tie_any = __syncthreads_or(tie ? 1 : 0) != 0 || tie_any;
+            if (tie) s_u[3] = 1u;                                    // (read behind the reduction's two barriers)
             float g = m;
             uint32_t idx = valid ? mycol : 0xffffffffu;
             block_reduce_pair<float, false>(g, idx, sv, si);
+            tie_any = s_u[3] != 0u || tie_any;
             if (tie_any && tie_exit) { status = kStatusTieRerun; iter = round - 1; ++nlog; break; }
             if (!(g < Lim<float>::max())) { status = kStatusSubsetDecline; break; }     // (no positive candidate: the reference toggles column 0)
             // whose column is it, and is it in the support?
-            if (j == 0) { s_u[1] = 0xffffffffu; s_u[2] = 0u; }
-            __syncthreads();
             if (valid && mycol == idx) { s_u[1] = j; s_u[2] = mypos >= 0 ? 1u + (uint32_t)mypos : 0u; }
             __syncthreads();
             const uint32_t spi = s_u[1];
@@ -489,6 +491,11 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
             if (j < P && L.alive[j]) {
                 const float xn = L.xs[j] + g * L.ds[j];
                 L.xs[j] = xn;
+            }
+            if (added) {
+                // the column enters at position P: its Gram row and its bookkeeping share the x update's barrier
+                L.Gc[(size_t)P * kSbS + j] = gpre;
+                if (j == 0) { L.pcol[P] = idx; L.psub[P] = spi; L.xs[P] = 0.f; }
             }
             __syncthreads();
             if (!added) {
@@ -511,11 +518,14 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 if ((int32_t)rpos == mypos) mypos = -1;
                 just_removed = idx;
                 K = K_new;
+                // sign(c_Gamma) after the step (below): nothing reads sg before the barrier that follows
+                if (j < P) {
+                    const uint32_t sp = L.psub[j];
+                    const float cn = L.cs[sp] - g * L.qs[sp];
+                    L.sg[j] = (L.alive[j] && j != rpos) ? sign_tol(cn, tol) : 0.f;
+                }
             } else {
-                // the column enters at position P: its Gram row, u1 = G[idx][support], the bordered inverse (online_inverse.h:209-248)
-                L.Gc[(size_t)P * kSbS + j] = gpre;
-                if (j == 0) { L.pcol[P] = idx; L.psub[P] = spi; L.xs[P] = 0.f; }
-                __syncthreads();
+                // u1 = G[idx][support], the bordered inverse (online_inverse.h:209-248)
                 if (j < P) L.u1[j] = L.alive[j] ? L.Gc[(size_t)P * kSbS + L.psub[j]] : 0.f;
                 __syncthreads();
                 if (j < P) L.u2[j] = row_dot(&L.I[j * kSbInvPitch], L.u1);
@@ -541,18 +551,19 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 }
                 if (j == 0) L.alive[P] = 1u;
                 if (j == spi) mypos = (int32_t)P;
+                // ---- sign(c_Gamma) of the correlations after the step (c - gamma q), dead zone tol (homotopy-cpu.cpp:257-267); the new
+                // position is alive (its flag is being written by thread 0 right now)
+                if (j < Pn) {
+                    const uint32_t sp = L.psub[j];
+                    const float cn = L.cs[sp] - g * L.qs[sp];
+                    L.sg[j] = (j == P || L.alive[j]) ? sign_tol(cn, tol) : 0.f;
+                }
                 P = Pn;
                 K = K_new;
                 just_removed = 0xffffffffu;
             }
             __syncthreads();
-            // ---- sign(c_Gamma) of the correlations after the step (c - gamma q), dead zone tol; direction (homotopy-cpu.cpp:257-267)
-            if (j < P) {
-                const uint32_t sp = L.psub[j];
-                const float cn = L.cs[sp] - g * L.qs[sp];
-                L.sg[j] = L.alive[j] ? sign_tol(cn, tol) : 0.f;
-            }
-            __syncthreads();
+            // ---- the direction from those signs
             direction();
             __syncthreads();
             iter = round;
