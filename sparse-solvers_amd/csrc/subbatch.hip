@@ -530,12 +530,8 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 __syncthreads();
                 if (j < P) L.u2[j] = row_dot(&L.I[j * kSbInvPitch], L.u1);
                 __syncthreads();
-                if (j == 0) {
-                    const float s = row_dot(L.u1, L.u2);
-                    s_f[0] = 1.f / (L.Gc[(size_t)P * kSbS + spi] - s);
-                }
-                __syncthreads();
-                const float dv = s_f[0];
+                // (every thread walks the same chain u1 . u2 — the value thread 0 alone used to publish through another barrier)
+                const float dv = 1.f / (L.Gc[(size_t)P * kSbS + spi] - row_dot(L.u1, L.u2));
                 const uint32_t Pn = P + 1u;
                 // (element e = a * Pn + b for e = j, j + 448, ...: the row / column advance without a division per element)
                 const uint32_t qa = kSbS / Pn, rb = kSbS - qa * Pn;
