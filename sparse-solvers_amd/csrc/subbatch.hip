@@ -276,6 +276,140 @@ void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uin
     for (uint32_t p = want + t; p < kSbS; p += kSel1Threads) sub[p] = 0xffffffffu;
 }
 
+// ---- k_sub_select1w: ONE slot, dictionaries wider than 65536 columns -------------------------------------------------
+// k_sub_select1's walks in chunks of 65536 columns; the chosen columns go through two short LDS lists instead of bit masks
+// (which would need n bits): the < 448 above the threshold key and the columns OF the key, of which the left-most are
+// taken — by counting ranks, the lists are short.  Should the key's list overflow (thousands of equal magnitudes) the
+// columns are written out by an ordered walk instead (two block-wide prefix sums per 4096 columns: slow, and only then).
+constexpr uint32_t kSel1ECap = 1024;
+__global__ __launch_bounds__(kSel1Threads)
+void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ sub,
+                    uint32_t* __restrict__ first_pick, float* __restrict__ first_val)
+{
+    constexpr uint32_t NW = kSel1Threads / 64u;
+    constexpr uint32_t CH = 4u * kSel1J * kSel1Threads;          // columns per chunk of a walk
+    __shared__ uint32_t hist[kSelBins];
+    __shared__ uint32_t s_list[kSbS], e_list[kSel1ECap];
+    __shared__ float sv[16];
+    __shared__ uint32_t si[16];
+    __shared__ uint32_t s_bin, s_above, s_ns, s_ne;
+    __shared__ uint32_t w_tot[NW];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t want = n < kSbS ? n : kSbS;
+    auto block_excl = [&](uint32_t mine, uint32_t& total) -> uint32_t {
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += up; }
+        __syncthreads();
+        if (lane == 63u) w_tot[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine, tot = 0u;
+        for (uint32_t w = 0; w < NW; ++w) { if (w < wave) before += w_tot[w]; tot += w_tot[w]; }
+        total = tot;
+        return before;
+    };
+#define SEL1W_WALK(BODY)                                                                       \
+    for (uint32_t cb_ = 0; cb_ < n_pad; cb_ += CH) {                                           \
+        v4f v_[kSel1J];                                                                        \
+        _Pragma("unroll") for (uint32_t j_ = 0; j_ < kSel1J; ++j_) {                           \
+            const uint32_t base_ = cb_ + 4u * (j_ * kSel1Threads + t);                         \
+            v_[j_] = base_ < n_pad ? *reinterpret_cast<const v4f*>(c0 + base_) : v4f{ 0.f, 0.f, 0.f, 0.f }; \
+        }                                                                                      \
+        _Pragma("unroll") for (uint32_t j_ = 0; j_ < kSel1J; ++j_) {                           \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                 \
+                const uint32_t i = cb_ + 4u * (j_ * kSel1Threads + t) + (uint32_t)e_;          \
+                if (i < n) { const float val = v_[j_][e_]; const uint32_t m = mag_bits(val); BODY } \
+            }                                                                                  \
+        }                                                                                      \
+    }
+    uint32_t prefix_key = 0, above = 0, floor_bin = 0;
+    for (int level = -1; level < 2; ++level) {
+        hist[2u * t] = 0u; hist[2u * t + 1u] = 0u;
+        __syncthreads();
+        if (level == -1) {
+            float bv = -1.f;
+            uint32_t bi = 0xffffffffu, mmax = 0u;
+            bool any = false;
+            SEL1W_WALK({ mmax = m > mmax ? m : mmax; any = true; const float a = fabsf(val); if (better_max(a, i, bv, bi)) { bv = a; bi = i; } })
+            if (any) atomicAdd(&hist[mmax >> 20], 1u);
+            block_reduce_pair<float, true>(bv, bi, sv, si);
+            if (t == 0) { first_pick[0] = bi == 0xffffffffu ? 0u : bi; first_val[0] = bv; }
+        } else if (level == 0) {
+            SEL1W_WALK({ (void)val; if ((m >> 20) >= floor_bin) atomicAdd(&hist[m >> 20], 1u); })
+        } else {
+            SEL1W_WALK({ (void)val; if ((m >> 20) == prefix_key) atomicAdd(&hist[(m >> 9) & 0x7ffu], 1u); })
+        }
+        __syncthreads();
+        const uint32_t h0 = hist[kSelBins - 1u - 2u * t], h1 = hist[kSelBins - 2u - 2u * t];
+        uint32_t total = 0;
+        const uint32_t base_above = level == 1 ? above : 0u;
+        const uint32_t before = block_excl(h0 + h1, total);
+        if (t == 0) { s_bin = 0u; s_above = 0u; s_ns = 0u; s_ne = 0u; }
+        __syncthreads();
+        if (base_above + before < want && base_above + before + h0 + h1 >= want) {
+            const uint32_t acc = base_above + before;
+            if (acc + h0 >= want) { s_bin = kSelBins - 1u - 2u * t; s_above = acc; }
+            else { s_bin = kSelBins - 2u - 2u * t; s_above = acc + h0; }
+        }
+        __syncthreads();
+        if (level == -1) floor_bin = s_bin;
+        else if (level == 0) { prefix_key = s_bin; above = s_above; }
+        else { prefix_key = (prefix_key << 11) | s_bin; above = s_above; }
+        __syncthreads();
+    }
+    const uint32_t T22 = prefix_key;
+    const uint32_t need_eq = want - above;
+    SEL1W_WALK({ (void)val; const uint32_t k = m >> 9;
+                 if (k > T22) { const uint32_t p_ = atomicAdd(&s_ns, 1u); if (p_ < kSbS) s_list[p_] = i; }
+                 else if (k == T22) { const uint32_t p_ = atomicAdd(&s_ne, 1u); if (p_ < kSel1ECap) e_list[p_] = i; } })
+    __syncthreads();
+    const uint32_t ns = s_ns, ne = s_ne;                       // (ns = `above` < want)
+    if (ne <= kSel1ECap) {
+        // the need_eq left-most columns of the key join the list; then every entry goes to its rank
+        if (t < ne) {
+            const uint32_t me = e_list[t];
+            uint32_t rank = 0;
+            for (uint32_t e = 0; e < ne; ++e) rank += e_list[e] < me ? 1u : 0u;
+            if (rank < need_eq && ns + rank < kSbS) s_list[ns + rank] = me;
+        }
+        __syncthreads();
+        const uint32_t tot = ns + need_eq < kSbS ? ns + need_eq : kSbS;      // = want
+        if (t < tot) {
+            const uint32_t me = s_list[t];
+            uint32_t rank = 0;
+            for (uint32_t e = 0; e < tot; ++e) rank += s_list[e] < me ? 1u : 0u;
+            sub[rank] = me;
+        }
+    } else {
+        // ordered walk: 4096 consecutive columns per step, thread t its four
+        uint32_t out = 0, eq_run = 0;
+        for (uint32_t b0 = 0; b0 < n_pad; b0 += 4u * kSel1Threads) {
+            const uint32_t base = b0 + 4u * t;
+            const v4f v = base < n_pad ? *reinterpret_cast<const v4f*>(c0 + base) : v4f{ 0.f, 0.f, 0.f, 0.f };
+            uint32_t isel = 0, ieq = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t i = base + (uint32_t)e;
+                if (i >= n) continue;
+                const uint32_t k = mag_bits(v[e]) >> 9;
+                if (k > T22) isel |= 1u << e; else if (k == T22) ieq |= 1u << e;
+            }
+            uint32_t tot = 0;
+            const uint32_t eq_before = eq_run + block_excl((uint32_t)__popc(ieq), tot);
+            eq_run += tot;
+            uint32_t take = eq_before < need_eq ? need_eq - eq_before : 0u, chosen = isel;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if ((ieq >> e) & 1u) { if (take != 0u) { chosen |= 1u << e; --take; } }
+            uint32_t pos = out + block_excl((uint32_t)__popc(chosen), tot);
+            out += tot;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if ((chosen >> e) & 1u) { if (pos < kSbS) sub[pos] = base + (uint32_t)e; ++pos; }
+        }
+    }
+#undef SEL1W_WALK
+    for (uint32_t p = want + t; p < kSbS; p += kSel1Threads) sub[p] = 0xffffffffu;
+}
+
 // ---- k_sub_solve: the whole path of one signal on its subset -----------------------------------------------------
 struct SubLds {
     float* Gc;         // [kSbRows][kSbS]  Gram rows of the positions, restricted to the subset
@@ -799,8 +933,10 @@ SubBufs sub_bufs(ss_hip_ctx* ctx, uint32_t nslots)
 
 hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0)
 {
-    if (nslots == 1 && ctx->n_pad <= 4u * kSel1J * kSel1Threads)        // (one slot: the register-resident form, for latency)
+    if (nslots == 1 && ctx->n_pad <= 4u * kSel1J * kSel1Threads)        // (one slot: the walking form, for latency)
         hipLaunchKernelGGL(k_sub_select1, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
+    else if (nslots == 1)                                               // (... in chunks of 65536 columns)
+        hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
     else
         hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS);
     return hipGetLastError();

@@ -268,3 +268,49 @@ def test_screened_form_random_problems(sship):
         assert 0.0 < st["screen_headroom"] < 1.0, tag
     note("test_screened_form_random_problems", certified=cert, handed_back=redone)
     assert cert >= 8 and redone >= 8
+
+
+@pytest.mark.parametrize("n", [98304, 140000])
+def test_screened_form_wide_dictionary(sship, n):
+    """More than 65536 columns: the one-slot selection walks c0 in chunks (k_sub_select1w).  Against the oracle; and on a
+    dictionary with 3000 identical columns among the largest |c0| — thousands of equal magnitudes at the selection's threshold:
+    its ordered walk — against the default engine."""
+    m, k = 1024, 14
+    A, y, x0, sup = make_gaussian_problem(9500 + n % 1000, m, n, k, np.float32)
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.reset_stats()
+        xg, itg, eg = h.solve(y, 1e-3, 4 * k)
+        st = h.stats()
+    xo, ito, eo = oracle.homotopy(A, y, 1e-3, 4 * k)
+    assert st["screen_signals"] + st["screen_redone"] == 1
+    assert_parity(xg, itg, eg, xo, ito, eo, np.float32)
+    note("test_screened_form_wide_dictionary", n=n, certified=st["screen_signals"], headroom=st["screen_headroom"])
+    # 3000 copies of one column whose |c0| sits between the support's and the noise's
+    rng = np.random.default_rng(n)
+    dup = np.sort(rng.choice(n, 3000, replace=False))
+    dup = dup[~np.isin(dup, sup)]
+    v = rng.standard_normal(m).astype(np.float32)
+    v /= np.linalg.norm(v)
+    c0 = A.T @ y
+    target = 0.5 * (np.sort(np.abs(c0[sup]))[0] + np.sort(np.abs(c0))[-k - 1])      # between the weakest support column and the strongest other
+    r = y / np.linalg.norm(y)
+    w = v - (v @ r) * r
+    w /= np.linalg.norm(w)
+    a = float(target / np.linalg.norm(y))
+    col = (a * r + np.sqrt(max(0.0, 1.0 - a * a)) * w).astype(np.float32)
+    A2 = A.copy()
+    A2[:, dup] = col[:, None]
+    with sship.Homotopy(A2) as h:
+        h.set_option("screen_single", 2)
+        h.reset_stats()
+        x1, it1, e1 = h.solve(y, 1e-3, 4 * k)
+        st2 = h.stats()
+        h.set_option("screen_single", 0)
+        x0_, it0, e0 = h.solve(y, 1e-3, 4 * k)
+    assert st2["screen_signals"] + st2["screen_redone"] == 1
+    if st2["screen_redone"]:
+        assert it1 == it0 and np.array_equal(x1, x0_)
+    else:
+        assert it1 == it0 and np.array_equal(np.nonzero(x1)[0], np.nonzero(x0_)[0])
+        assert np.abs(x1 - x0_).max() <= 1e-4 * np.abs(x0_).max()
