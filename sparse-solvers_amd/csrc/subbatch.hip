@@ -281,21 +281,22 @@ void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uin
 // (which would need n bits): the < 448 above the threshold key and the columns OF the key, of which the left-most are
 // taken — by counting ranks, the lists are short.  Should the key's list overflow (thousands of equal magnitudes) the
 // columns are written out by an ordered walk instead (two block-wide prefix sums per 4096 columns: slow, and only then).
-constexpr uint32_t kSel1ECap = 1024;
+constexpr uint32_t kSel1ECap = 1024, kSel1SCap = 2048;
 __global__ __launch_bounds__(kSel1Threads)
 void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ sub,
-                    uint32_t* __restrict__ first_pick, float* __restrict__ first_val)
+                    uint32_t* __restrict__ first_pick, float* __restrict__ first_val, uint32_t nsel)
 {
+    // nsel <= kSel1SCap columns are selected (kSbS for the subset form; the fp64 screened form's sub-dictionary takes 2048)
     constexpr uint32_t NW = kSel1Threads / 64u;
     constexpr uint32_t CH = 4u * kSel1J * kSel1Threads;          // columns per chunk of a walk
     __shared__ uint32_t hist[kSelBins];
-    __shared__ uint32_t s_list[kSbS], e_list[kSel1ECap];
+    __shared__ uint32_t s_list[kSel1SCap], e_list[kSel1ECap];
     __shared__ float sv[16];
     __shared__ uint32_t si[16];
     __shared__ uint32_t s_bin, s_above, s_ns, s_ne;
     __shared__ uint32_t w_tot[NW];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t want = n < kSbS ? n : kSbS;
+    const uint32_t want = n < nsel ? n : nsel;
     auto block_excl = [&](uint32_t mine, uint32_t& total) -> uint32_t {
         uint32_t incl = mine;
 #pragma unroll
@@ -360,7 +361,7 @@ void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, ui
     const uint32_t T22 = prefix_key;
     const uint32_t need_eq = want - above;
     SEL1W_WALK({ (void)val; const uint32_t k = m >> 9;
-                 if (k > T22) { const uint32_t p_ = atomicAdd(&s_ns, 1u); if (p_ < kSbS) s_list[p_] = i; }
+                 if (k > T22) { const uint32_t p_ = atomicAdd(&s_ns, 1u); if (p_ < nsel) s_list[p_] = i; }
                  else if (k == T22) { const uint32_t p_ = atomicAdd(&s_ne, 1u); if (p_ < kSel1ECap) e_list[p_] = i; } })
     __syncthreads();
     const uint32_t ns = s_ns, ne = s_ne;                       // (ns = `above` < want)
@@ -370,12 +371,12 @@ void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, ui
             const uint32_t me = e_list[t];
             uint32_t rank = 0;
             for (uint32_t e = 0; e < ne; ++e) rank += e_list[e] < me ? 1u : 0u;
-            if (rank < need_eq && ns + rank < kSbS) s_list[ns + rank] = me;
+            if (rank < need_eq && ns + rank < nsel) s_list[ns + rank] = me;
         }
         __syncthreads();
-        const uint32_t tot = ns + need_eq < kSbS ? ns + need_eq : kSbS;      // = want
-        if (t < tot) {
-            const uint32_t me = s_list[t];
+        const uint32_t tot = ns + need_eq < nsel ? ns + need_eq : nsel;      // = want
+        for (uint32_t q = t; q < tot; q += kSel1Threads) {
+            const uint32_t me = s_list[q];
             uint32_t rank = 0;
             for (uint32_t e = 0; e < tot; ++e) rank += s_list[e] < me ? 1u : 0u;
             sub[rank] = me;
@@ -403,11 +404,11 @@ void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, ui
             uint32_t pos = out + block_excl((uint32_t)__popc(chosen), tot);
             out += tot;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if ((chosen >> e) & 1u) { if (pos < kSbS) sub[pos] = base + (uint32_t)e; ++pos; }
+            for (int e = 0; e < 4; ++e) if ((chosen >> e) & 1u) { if (pos < nsel) sub[pos] = base + (uint32_t)e; ++pos; }
         }
     }
 #undef SEL1W_WALK
-    for (uint32_t p = want + t; p < kSbS; p += kSel1Threads) sub[p] = 0xffffffffu;
+    for (uint32_t p = want + t; p < nsel; p += kSel1Threads) sub[p] = 0xffffffffu;
 }
 
 // ---- k_sub_solve: the whole path of one signal on its subset -----------------------------------------------------
@@ -936,7 +937,7 @@ hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots,
     if (nslots == 1 && ctx->n_pad <= 4u * kSel1J * kSel1Threads)        // (one slot: the walking form, for latency)
         hipLaunchKernelGGL(k_sub_select1, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
     else if (nslots == 1)                                               // (... in chunks of 65536 columns)
-        hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
+        hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS);
     else
         hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS);
     return hipGetLastError();
@@ -945,7 +946,8 @@ hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots,
 // the nsel columns with the largest |v| of ONE vector, ascending (screen.hip's fp64 form: v = float(|A^T y|))
 hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval)
 {
-    hipLaunchKernelGGL(k_sub_select, dim3(1), dim3(kSelThreads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel);
+    if (nsel <= kSel1SCap) hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel);
+    else hipLaunchKernelGGL(k_sub_select, dim3(1), dim3(kSelThreads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel);
     return hipGetLastError();
 }
 
