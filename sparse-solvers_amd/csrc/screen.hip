@@ -347,14 +347,19 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
 // third only when the path logged more than 64 states).  A stage is 128 rows: 32 KB of A16 and 16 / 24 KB of R16 (from
 // L2) land in LDS by 16-byte stores of coalesced 256-byte runs; TWO stages of loads are in flight (two register sets)
 // under the MFMAs of a third.  HBM-bound: 1.07 GB at 8192 x 65536.
+template <int NT>
 __global__ __launch_bounds__(256, 2)
 void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const __half* __restrict__ r16,
                 const float* __restrict__ anorm, const float* __restrict__ rn2p, uint32_t rn_pitch, const float* __restrict__ tab,
                 const uint32_t* __restrict__ sub, uint32_t nsub, const float* __restrict__ meta, DevState* __restrict__ st,
                 uint32_t* __restrict__ headroom, uint32_t nst_fixed)
 {
+    // NT: tiles of 32 states a workgroup carries — 3 (two register sets of loads in flight), or 5 for the fp64 form's longer paths
+    // (160 states in ONE pass over the fp16 copy; one register set).
     // nst_fixed = 0: the fp32 form — the number of states and the go-ahead come from the slot's state (k_sub_solve's log);
-    // > 0: that many states (<= 96) of the caller's block of right-hand sides (the fp64 form: r16, rn2p, tab point at it)
+    // > 0: that many states (<= 32 NT) of the caller's block of right-hand sides (the fp64 form: r16, rn2p, tab point at it)
+    constexpr int RH = 32 * NT, NPR = 2 * NT;
+    constexpr bool TWO = NT <= 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t nst = nst_fixed;
     if (nst_fixed == 0u) {
@@ -363,29 +368,25 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
         if (nlog < 2u) return;
         nst = nlog - 1u;
     }
-    const bool t3 = nst > 64u;                                   // (uniform) the third tile of states is in use
+    const uint32_t ntu = (nst + 31u) / 32u;                      // (uniform) tiles of states in use
     unsigned char* sA = smem;                                   // [128][272]
-    unsigned char* sR = smem + (size_t)kScrCols * kScrPitchB;   // [96][272]
+    unsigned char* sR = smem + (size_t)kScrCols * kScrPitchB;   // [32 NT][272]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const uint32_t col0 = blockIdx.x * kScrCols;
     const uint32_t lc = tid >> 4, piece = tid & 15u;
     const __half* ga = a16 + (size_t)(col0 + lc) * ldm + 8u * piece;
     const __half* gr = r16 + (size_t)lc * ldm + 8u * piece;
-    scr_u4 pa0[8], pr0[6], pa1[8], pr1[6];
+    scr_u4 pa0[8], pr0[NPR], pa1[TWO ? 8 : 1], pr1[TWO ? NPR : 1];
 #define SCR_LOAD(PA, PR, R0)                                                                                      \
     {                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                             \
             PA[i] = __builtin_nontemporal_load(reinterpret_cast<const scr_u4*>(ga + (size_t)(16 * i) * ldm + (R0)));  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
-            PR[i] = *reinterpret_cast<const scr_u4*>(gr + (size_t)(16 * i) * ldm + (R0));                         \
-        if (t3) {                                                                                                 \
-            _Pragma("unroll") for (int i = 4; i < 6; ++i)                                                         \
-                PR[i] = *reinterpret_cast<const scr_u4*>(gr + (size_t)(16 * i) * ldm + (R0));                     \
-        }                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < NPR; ++i)                                                           \
+            if ((uint32_t)(i / 2) < ntu) PR[i] = *reinterpret_cast<const scr_u4*>(gr + (size_t)(16 * i) * ldm + (R0)); \
     }
-    scr_v16f acc[3];
+    scr_v16f acc[NT];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     const uint32_t r = lane & 31u, h = lane >> 5;
@@ -396,23 +397,18 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
         __syncthreads();                                                                                          \
         _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                             \
             *reinterpret_cast<scr_u4*>(sA + (size_t)(lc + 16u * (uint32_t)i) * kScrPitchB + 16u * piece) = PA[i]; \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
-            *reinterpret_cast<scr_u4*>(sR + (size_t)(lc + 16u * (uint32_t)i) * kScrPitchB + 16u * piece) = PR[i]; \
-        if (t3) {                                                                                                 \
-            _Pragma("unroll") for (int i = 4; i < 6; ++i)                                                         \
+        _Pragma("unroll") for (int i = 0; i < NPR; ++i)                                                           \
+            if ((uint32_t)(i / 2) < ntu)                                                                          \
                 *reinterpret_cast<scr_u4*>(sR + (size_t)(lc + 16u * (uint32_t)i) * kScrPitchB + 16u * piece) = PR[i]; \
-        }                                                                                                         \
         __syncthreads();                                                                                          \
         if (MORE) SCR_LOAD(PA, PR, (RNEXT))                                                                       \
         _Pragma("unroll") for (uint32_t ks = 0; ks < kScrKc / 16u; ++ks) {                                        \
             const scr_h8 bq = *reinterpret_cast<const scr_h8*>(rdA + 32u * ks);                                   \
-            const scr_h8 aq0 = *reinterpret_cast<const scr_h8*>(rdR + 32u * ks);                                  \
-            const scr_h8 aq1 = *reinterpret_cast<const scr_h8*>(rdR + (size_t)32 * kScrPitchB + 32u * ks);        \
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq0, bq, acc[0], 0, 0, 0);                            \
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq1, bq, acc[1], 0, 0, 0);                            \
-            if (t3) {                                                                                             \
-                const scr_h8 aq2 = *reinterpret_cast<const scr_h8*>(rdR + (size_t)64 * kScrPitchB + 32u * ks);    \
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq2, bq, acc[2], 0, 0, 0);                        \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
+                if ((uint32_t)t < ntu) {                                                                          \
+                    const scr_h8 aq = *reinterpret_cast<const scr_h8*>(rdR + (size_t)(32 * t) * kScrPitchB + 32u * ks); \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq, acc[t], 0, 0, 0);                     \
+                }                                                                                                 \
             }                                                                                                     \
         }                                                                                                         \
     }
@@ -423,33 +419,40 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     const uint32_t sbase = (blockIdx.x * 29u) % nstage;
 #define SCR_ROW(S) ((sbase + (S) >= nstage ? sbase + (S) - nstage : sbase + (S)) * kScrKc)
     SCR_LOAD(pa0, pr0, SCR_ROW(0u))
-    SCR_LOAD(pa1, pr1, SCR_ROW(1u))
-    for (uint32_t sidx = 0; sidx < nstage; sidx += 2u) {
-        SCR_STAGE(pa0, pr0, sidx + 2u < nstage, SCR_ROW(sidx + 2u))
-        SCR_STAGE(pa1, pr1, sidx + 3u < nstage, SCR_ROW(sidx + 3u))
+    if constexpr (TWO) {
+        SCR_LOAD(pa1, pr1, SCR_ROW(1u))
+        for (uint32_t sidx = 0; sidx < nstage; sidx += 2u) {
+            SCR_STAGE(pa0, pr0, sidx + 2u < nstage, SCR_ROW(sidx + 2u))
+            SCR_STAGE(pa1, pr1, sidx + 3u < nstage, SCR_ROW(sidx + 3u))
+        }
+    } else {
+        for (uint32_t sidx = 0; sidx < nstage; ++sidx) {
+            SCR_STAGE(pa0, pr0, sidx + 1u < nstage, SCR_ROW(sidx + 1u))
+        }
     }
 #undef SCR_ROW
 #undef SCR_STAGE
 #undef SCR_LOAD
     // ---- epilogue: the per-state table and the subset's columns into LDS, then every (column, state) of this wave ------
     __syncthreads();
-    float* sT = reinterpret_cast<float*>(smem);                 // [96][4]: 1/(sA s_k), bound, eps factor 1 (x ||a||), eps term 2
-    uint32_t* sSub = reinterpret_cast<uint32_t*>(smem) + kScrRhs * 4u;   // [nsub] the subset's columns, ascending (0xffffffff: none)
-    float* sPart = reinterpret_cast<float*>(smem) + kScrRhs * 4u + nsub; // [128][96] partial sums of ||r_k||^2, 128 workgroups' at a time
+    constexpr uint32_t PB = NT <= 3 ? 128u : 64u;               // workgroups' partials staged at a time
+    float* sT = reinterpret_cast<float*>(smem);                 // [32 NT][4]: 1/(sA s_k), bound, eps factor 1 (x ||a||), eps term 2
+    uint32_t* sSub = reinterpret_cast<uint32_t*>(smem) + (uint32_t)RH * 4u;   // [nsub] the subset's columns, ascending (0xffffffff: none)
+    float* sPart = reinterpret_cast<float*>(smem) + (uint32_t)RH * 4u + nsub; // [PB][32 NT] partial sums of ||r_k||^2
     const float inv_sA = meta[1];
     const float sq_ldm = sqrtf((float)ldm);
     const uint32_t nblk = ldm / 64u;
     // (128 workgroups' partials in flight at once, summed per state in the order of the workgroups that wrote them: deterministic)
     float s2 = 0.f;
-    for (uint32_t b0 = 0; b0 < nblk; b0 += 128u) {
-        const uint32_t nb = nblk - b0 < 128u ? nblk - b0 : 128u;
-        for (uint32_t e = tid; e < nb * kScrRhs; e += 256u) { const uint32_t b = e / kScrRhs, k = e - b * kScrRhs; sPart[e] = rn2p[(size_t)(b0 + b) * rn_pitch + k]; }
+    for (uint32_t b0 = 0; b0 < nblk; b0 += PB) {
+        const uint32_t nb = nblk - b0 < PB ? nblk - b0 : PB;
+        for (uint32_t e = tid; e < nb * (uint32_t)RH; e += 256u) { const uint32_t b = e / (uint32_t)RH, k = e - b * (uint32_t)RH; sPart[e] = rn2p[(size_t)(b0 + b) * rn_pitch + k]; }
         __syncthreads();
         if (tid < nst)
-            for (uint32_t b = 0; b < nb; ++b) s2 += sPart[(size_t)b * kScrRhs + tid];
+            for (uint32_t b = 0; b < nb; ++b) s2 += sPart[(size_t)b * RH + tid];
         __syncthreads();
     }
-    if (tid < kScrRhs) {
+    if (tid < (uint32_t)RH) {
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
         if (tid < nst) {
             const float rn = sqrtf(s2) * 1.001f;
@@ -472,7 +475,7 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     bool flag = false;
     float worst = 0.f;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const uint32_t kk = 32u * (uint32_t)t + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * h;
@@ -713,7 +716,11 @@ void screen_free(ss_hip_ctx* ctx)
 }
 
 // (the main loop's two tiles; the epilogue's tables — 96 x 4 + 448 + 128 x 96 floats — fit inside)
-static size_t scr_gemm_lds(uint32_t nsub) { return std::max<size_t>((size_t)(kScrCols + kScrRhs) * kScrPitchB, ((size_t)kScrRhs * 4 + nsub + (size_t)128 * kScrRhs) * 4); }
+static size_t scr_gemm_lds(uint32_t nsub, uint32_t nt = 3)
+{
+    const size_t rh = 32 * (size_t)nt, pb = nt <= 3 ? 128 : 64;
+    return std::max<size_t>((size_t)(kScrCols + rh) * kScrPitchB, (rh * 4 + nsub + pb * rh) * 4);
+}
 
 // Shape / option test, and — the first time it says yes — the preparation: the fp16 copy of A (half of A's bytes again),
 // the column norms.  A failed allocation switches the form off for this context (the default engine goes on as before).
@@ -741,7 +748,7 @@ bool screen_form_usable(ss_hip_ctx* ctx)
     alloc(reinterpret_cast<void**>(&S->gs_part), (size_t)kSgSplit * kSbS * kSbS * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->gs), (size_t)kSbS * kSbS * sizeof(float));
     if (ok) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)scr_gemm_lds(kS64Sub));
         if (e != hipSuccess) { (void)hipGetLastError(); ok = false; }
     }
@@ -782,7 +789,7 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
                        (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st);
     if (e2) (void)hipEventRecord(e2, s);
-    hipLaunchKernelGGL(k_scr_gemm, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
+    hipLaunchKernelGGL(k_scr_gemm<3>, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
                        (const float*)S->anorm, (const float*)S->rn2p, kScrRhs, (const float*)S->tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
                        ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u);
     if (e3) (void)hipEventRecord(e3, s);
@@ -828,9 +835,11 @@ bool screen64_usable(ss_hip_ctx* ctx)
     alloc(reinterpret_cast<void**>(&S->xd), (size_t)kS64LogK * (kS64Rhs + 8) * sizeof(double));
     alloc(reinterpret_cast<void**>(&S->ctl), 8 * sizeof(uint32_t));
     if (ok) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)scr_gemm_lds(kS64Sub));
-        if (e != hipSuccess) { (void)hipGetLastError(); ok = false; }
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)scr_gemm_lds(kS64Sub, 3));
+        const hipError_t e5 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)scr_gemm_lds(kS64Sub, 5));
+        if (e != hipSuccess || e5 != hipSuccess) { (void)hipGetLastError(); ok = false; }
     }
     if (ok) {
         char err[256];
@@ -895,12 +904,21 @@ hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double
     hipLaunchKernelGGL(k_s64_residuals, dim3(ldm / 64u), dim3(256), 0, s, static_cast<const double*>(S->sub->At), ldm, y, slog, T,
                        (const double*)S->xd, tol, (const float*)S->meta, S->r16, S->rn2p, S->tab, S->ctl, reinterpret_cast<uint32_t*>(S->meta) + 3);
     if (e2) (void)hipEventRecord(e2, s);
-    for (uint32_t k0 = 0; k0 < T; k0 += kScrRhs) {
-        const uint32_t cnt = std::min<uint32_t>(kScrRhs, T - k0);
-        hipLaunchKernelGGL(k_scr_gemm, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub), s, (const __half*)S->a16, ldm, n,
-                           (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
-                           (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
-                           ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt);
+    // (up to 160 states in ONE pass over the fp16 copy — five tiles of 32 per workgroup —, the rest in passes of 96)
+    for (uint32_t k0 = 0; k0 < T;) {
+        const bool wide = T - k0 > kScrRhs;
+        const uint32_t cnt = std::min<uint32_t>(wide ? 160u : kScrRhs, T - k0);
+        if (wide)
+            hipLaunchKernelGGL(k_scr_gemm<5>, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 5), s, (const __half*)S->a16, ldm, n,
+                               (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
+                               (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
+                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt);
+        else
+            hipLaunchKernelGGL(k_scr_gemm<3>, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 3), s, (const __half*)S->a16, ldm, n,
+                               (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
+                               (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
+                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt);
+        k0 += cnt;
     }
     if (e3) (void)hipEventRecord(e3, s);
     hipLaunchKernelGGL(k_s64_finish, dim3((kS64Sub + 255) / 256), dim3(256), 0, s, (const uint32_t*)S->sublist, (const double*)S->xsub, n, ws.x,
