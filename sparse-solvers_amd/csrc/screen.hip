@@ -50,6 +50,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 namespace sship {
 
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256, 2)
 void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const __half* __restrict__ r16,
                 const float* __restrict__ anorm, const float* __restrict__ rn2p, uint32_t rn_pitch, const float* __restrict__ tab,
                 const uint32_t* __restrict__ sub, uint32_t nsub, const float* __restrict__ meta, DevState* __restrict__ st,
-                uint32_t* __restrict__ headroom, uint32_t nst_fixed)
+                uint32_t* __restrict__ headroom, uint32_t nst_fixed, uint32_t skew)
 {
     // NT: tiles of 32 states a workgroup carries — 3 (two register sets of loads in flight), or 5 for the fp64 form's longer paths
     // (160 states in ONE pass over the fp16 copy; one register set).
@@ -416,7 +417,7 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     // around — the sum's order is free here — so that the 512 workgroups do not walk the same 256-byte phase of their
     // 16-KiB-strided columns together (the HBM channels are selected by those address bits)
     const uint32_t nstage = ldm / kScrKc;
-    const uint32_t sbase = (blockIdx.x * 29u) % nstage;
+    const uint32_t sbase = (blockIdx.x * skew) % nstage;
 #define SCR_ROW(S) ((sbase + (S) >= nstage ? sbase + (S) - nstage : sbase + (S)) * kScrKc)
     SCR_LOAD(pa0, pr0, SCR_ROW(0u))
     if constexpr (TWO) {
@@ -716,6 +717,13 @@ void screen_free(ss_hip_ctx* ctx)
 }
 
 // (the main loop's two tiles; the epilogue's tables — 96 x 4 + 448 + 128 x 96 floats — fit inside)
+// row offset of workgroup b = (b * skew) mod stages (developer aid: SS_HIP_SCR_SKEW overrides the multiplier)
+static uint32_t scr_skew()
+{
+    static const uint32_t v = [] { const char* e = std::getenv("SS_HIP_SCR_SKEW"); return e ? (uint32_t)std::atoi(e) : 29u; }();
+    return v;
+}
+
 static size_t scr_gemm_lds(uint32_t nsub, uint32_t nt = 3)
 {
     const size_t rh = 32 * (size_t)nt, pb = nt <= 3 ? 128 : 64;
@@ -791,7 +799,7 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     if (e2) (void)hipEventRecord(e2, s);
     hipLaunchKernelGGL(k_scr_gemm<3>, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
                        (const float*)S->anorm, (const float*)S->rn2p, kScrRhs, (const float*)S->tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
-                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u);
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew());
     if (e3) (void)hipEventRecord(e3, s);
     (void)launch_sub_finish(ctx, ws, 1);
     return hipGetLastError();
@@ -912,12 +920,12 @@ hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double
             hipLaunchKernelGGL(k_scr_gemm<5>, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 5), s, (const __half*)S->a16, ldm, n,
                                (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
                                (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
-                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt);
+                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew());
         else
             hipLaunchKernelGGL(k_scr_gemm<3>, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 3), s, (const __half*)S->a16, ldm, n,
                                (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
                                (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
-                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt);
+                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew());
         k0 += cnt;
     }
     if (e3) (void)hipEventRecord(e3, s);
