@@ -1611,7 +1611,8 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                          void* rec_out = nullptr, uint32_t kmax = 0, bool no_subset = false)
 {
     // form: 0 = two GEMMs per round (residual form), 1 = Gram form on the full G = A^T A, 2 = column form: Gram form
-    // on a cache of the entering columns' Gram columns, formed round by round (mid-size batches, no G)
+    // on a cache of the entering columns' Gram columns, formed round by round (mid-size batches, no G), 3 = screened form
+    // (screen.hip): c0 by the batch GEMM, one workgroup per signal on its subset's own Gram matrix, one screening launch per chunk
     using T = float;
     const bool gram = form != 0, cols_form = form == 2;
     if (max_iter == 0) { set_err(err, errlen, "solve_batch: max_iterations must be > 0"); return SS_HIP_EINVAL; }
@@ -1625,7 +1626,9 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
         const size_t m = ctx->m, n = ctx->n, ldm = ctx->ldm, np = ctx->n_pad;
         const uint32_t kcap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n, (uint64_t)max_iter + 1), kKcapLimit);
         // (column form: chunks of at most 448 signals = 7 full passes per round, fewer if the cache budget says so)
-        const size_t chunk = cols_form ? (size_t)std::max(1, ctx->bcol_chunk) : (size_t)std::max(4, ctx->batch_chunk);
+        const bool scr_form = form == 3;
+        const size_t chunk = scr_form ? (size_t)screen_batch_cap()
+                                      : cols_form ? (size_t)std::max(1, ctx->bcol_chunk) : (size_t)std::max(4, ctx->batch_chunk);
         hipStream_t st = ctx->stream;
         std::vector<DevState> hs;
         std::vector<size_t> all_ties;                        // signals whose scan met a tie stall, over all chunks
@@ -1726,14 +1729,18 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             // largest |c0| and then checked against all columns — 16.8 MB of G per signal instead of 545
             bool sub_chunk = gram_chunk && form == 1 && !no_subset && ctx->batch_subset && ctx->gram_full != nullptr && sub_form_usable(ctx);
             if (sub_chunk && ctx->sub_off_chunks > 0) { ctx->sub_off_chunks -= 1; sub_chunk = false; }     // (it handed back too much lately)
-            if (sub_chunk) {
+            const bool scr_chunk = gram_chunk && scr_form && !no_subset;
+            // (a chunk whose tolerance is too tight for Gram-form correlations runs the residual-form rounds below, as in every form)
+            if (sub_chunk || scr_chunk) {
                 const size_t need = sub_buffer_bytes(Bc);
                 if (ctx->sub_buf_bytes < need) {
                     if (ctx->sub_buf) HIPCHK(hipFree(ctx->sub_buf));
                     ctx->sub_buf = nullptr;
                     ctx->sub_buf_bytes = 0;
-                    if (hipMalloc(&ctx->sub_buf, need) != hipSuccess) { (void)hipGetLastError(); ctx->sub_buf = nullptr; sub_chunk = false; }
-                    else ctx->sub_buf_bytes = need;
+                    if (hipMalloc(&ctx->sub_buf, need) != hipSuccess) {
+                        (void)hipGetLastError(); ctx->sub_buf = nullptr; sub_chunk = false;
+                        if (scr_chunk) throw HipFail{ hipErrorOutOfMemory, "screened batch form: log buffers" };
+                    } else ctx->sub_buf_bytes = need;
                 }
             }
             const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
@@ -1757,7 +1764,8 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                     ctx->stats.c0_gemm_flops += 2.0 * (double)rows * (double)ldm * (double)np;
                 }
             }
-            for (uint64_t round = 1; round <= last_round && !sub_chunk; ++round) {
+            if (scr_chunk) HIPCHK(launch_screen_batch(ctx, ws, Bc, ctx->c0_batch, tol, max_iter));
+            for (uint64_t round = 1; round <= last_round && !sub_chunk && !scr_chunk; ++round) {
                 if (round > L) {
                     const uint32_t need = (uint32_t)(round - L);
                     uint32_t spins = 0;
@@ -1857,6 +1865,10 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
                 ctx->stats.subset_redone += n_redo_chunk;
                 if (Bc >= 16 && 3u * n_redo_chunk > Bc) ctx->sub_off_chunks = 8;
             }
+            if (scr_chunk) {
+                ctx->stats.screen_signals += Bc - n_redo_chunk - (uint32_t)ties.size();
+                ctx->stats.screen_redone += n_redo_chunk;
+            }
             ctx->stats.batch_rounds += rounds_run;
             if (ncq != 0) {
                 // rounds enqueued behind the end of the batch are no-ops (microseconds): only launches that
@@ -1882,6 +1894,20 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             // these signals are solved again in the reference-order engine — after the last chunk, all of them together
             // (up to 4 share every pass over A: solve_batch_ro).  (A handful per 4096 signals at 8192 x 65536.)
             for (uint32_t b : ties) all_ties.push_back(b0 + b);
+        }
+        if (!redo.empty() && scr_form) {
+            // screened batch form: what it hands back is solved by the default single-signal engine, one by one
+            const size_t rb = record_bytes(kmax, sizeof(T));
+            for (size_t g : redo) {
+                uint32_t it = 0;
+                double e = 0.0;
+                const int rc = solve_impl<T>(ctx, Y + (ptrdiff_t)g * y_stride, incy, tol, max_iter, X ? X + (ptrdiff_t)g * x_stride : nullptr, incx, &it, &e,
+                                             err, errlen, false, false, false, rec_out ? static_cast<unsigned char*>(rec_out) + g * rb : nullptr, kmax, false, true);
+                if (rc != SS_HIP_OK) return rc;
+                if (iter_out) iter_out[g] = it;
+                if (err_out) err_out[g] = e;
+            }
+            redo.clear();
         }
         if (!redo.empty()) {
             // the signals the subset form did not vouch for, gathered and solved in the lock-step Gram form (their own ties
@@ -1967,6 +1993,10 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             return SS_HIP_ERUNTIME;
         }
     }
+    // screened form for the batches in between (4 .. batch_gram_min - 1 signals, no G; option batch_screen): c0 of a chunk by the
+    // batch GEMM, every signal solved by one workgroup on its subset's own Gram matrix, one screening launch per chunk of 64
+    if (form == 0 && !ctx->gram_full && ctx->batch_screen && ctx->engine >= 1 && B >= 4 && ctx->la_fused >= 3 && ctx->early_solo &&
+        ctx->solo_subset == 256 && ctx->sub_off_chunks == 0 && !ctx->tracing && screen_form_usable(ctx)) form = 3;
     // column form for the batches in between (batch_cols_min .. batch_cols_max signals, no G): in lock-step, one pass
     // over A per round and 64 signals forms the Gram columns of the entering columns (half the flops of the two GEMMs
     // of form 0, and one pass serves 64 signals where a single solve spends three on one).  The cache holds one row
@@ -1988,7 +2018,7 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
         if (per >= B) per = B; else per = per / 64 * 64;
         if ((per >= 64 || (per == B && per > 0)) && ensure_bcol(ctx, per, max_iter)) { form = 2; ctx->bcol_chunk = (int)std::max<size_t>(per, 1); }
     }
-    if (lockstep || form == 2)
+    if (lockstep || form == 2 || form == 3)
         return solve_batch_gemm_f32(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, form,
                                     rec_out, kmax);
     return solve_batch_seq<float>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
@@ -2517,6 +2547,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "gram_symmetric")) { ctx->gram_symmetric = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { ctx->batch_chunk = (int)std::max<long>(4, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_single")) { ctx->screen_single = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_screen"))  { ctx->batch_screen = value ? 1 : 0; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 
@@ -2590,6 +2621,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "gram_symmetric")) { *value = ctx->gram_symmetric; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { *value = ctx->batch_chunk; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_single")) { *value = ctx->screen_single; return SS_HIP_OK; }
+    if (!std::strcmp(key, "batch_screen"))  { *value = ctx->batch_screen; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 

@@ -68,6 +68,7 @@ constexpr uint32_t kSgSplit = 8;                 // row chunks of the subset Gra
 constexpr uint32_t kSgT = 64;                    // its tile: 64 x 64 outputs per workgroup, a 32 x 32 quadrant per wave
 constexpr uint32_t kSgStep = 64;                 // rows staged per step
 constexpr uint32_t kSgPitchF = kSgStep + 4;      // floats per LDS row
+constexpr uint32_t kScrBatch = 64;               // slots of a batch chunk in the screened form
 constexpr uint32_t kS64Sub = 2048;               // fp64 form: columns of the sub-dictionary the path is solved on
 constexpr uint32_t kS64Rhs = 192;                // ... states it can certify (two launches of the screening pass)
 constexpr uint32_t kS64LogCap = 200, kS64LogK = 200;   // ... state log of the sub-context: states, coefficients per state
@@ -84,6 +85,12 @@ struct ScreenState {
     float* gs_part = nullptr;    // [kSgSplit][kSbS][kSbS]
     float* gs = nullptr;         // [kSbS][kSbS]
     int gemm_attr = -1;
+    // a batch chunk in the screened form (kScrBatch slots): every slot its own residual block, subset Gram matrix, table
+    __half* b_r16 = nullptr;     // [kScrBatch][kScrRhs][ldm]
+    float* b_rn2p = nullptr;     // [kScrBatch][ldm / 64][kScrRhs]
+    float* b_tab = nullptr;      // [kScrBatch][kScrRhs][kScrTab]
+    float* b_gs_part = nullptr;  // [kScrBatch][kSgSplit][kSbS][kSbS]
+    float* b_gs = nullptr;       // [kScrBatch][kSbS][kSbS]
     // fp64 form: the path is solved by a context of its own over a sub-dictionary of kS64Sub columns
     ss_hip_ctx* sub = nullptr;
     float* cabs = nullptr;       // [n_pad] float(|c0|): what the selection ranks
@@ -151,6 +158,9 @@ __global__ __launch_bounds__(256)
 void k_sgram_part(const float* __restrict__ At, uint32_t ldm, uint32_t n, const uint32_t* __restrict__ sub, uint32_t rows_per,
                   float* __restrict__ part)
 {
+    // (blockIdx.z = slot of a batch: its subset, its partials)
+    sub += (size_t)blockIdx.z * kSbS;
+    part += (size_t)blockIdx.z * gridDim.y * kSbS * kSbS;
     __shared__ __attribute__((aligned(16))) float sI[kSgT][kSgPitchF];
     __shared__ __attribute__((aligned(16))) float sJ[kSgT][kSgPitchF];
     constexpr uint32_t NT = kSbS / kSgT;                        // 7 tiles per side
@@ -217,6 +227,8 @@ void k_sgram_part(const float* __restrict__ At, uint32_t ldm, uint32_t n, const 
 __global__ __launch_bounds__(256)
 void k_sgram_sum(const float* __restrict__ part, uint32_t nsplit, float* __restrict__ gs)
 {
+    part += (size_t)blockIdx.y * nsplit * kSbS * kSbS;           // (blockIdx.y = slot of a batch)
+    gs += (size_t)blockIdx.y * kSbS * kSbS;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= kSbS * kSbS) return;
     float s = part[i];
@@ -246,6 +258,17 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
     __shared__ __attribute__((aligned(16))) float sAc[kSbRows][64];
     __shared__ __attribute__((aligned(16))) float sXt[kSbRows][kSbLog];
     __shared__ float sS[kSbLog];
+    {   // (blockIdx.y = slot of a batch: its signal, its log, its block of residuals)
+        const uint32_t slot = blockIdx.y;
+        y += (size_t)slot * ldm;
+        hdr += (size_t)slot * kSbLog * 8;
+        pcol += (size_t)slot * kSbRows;
+        LX += (size_t)slot * kSbLog * kSbRows;
+        r16 += (size_t)slot * kScrRhs * ldm;
+        rn2p += (size_t)slot * (ldm / 64u) * kScrRhs;
+        tab += (size_t)slot * kScrRhs * kScrTab;
+        st += slot;
+    }
     if (st->status != 0u) return;
     const uint32_t nlog = st->solo_nlog;
     if (nlog < 2u) return;
@@ -311,7 +334,7 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
     if (ovf) __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blockIdx.x == 0u) {
         const float lam0 = st->lambda0;
-        if (tid == 0u) *headroom = 0u;
+        if (tid == 0u && blockIdx.y == 0u) *headroom = 0u;
         if (tid < nst) {
             const uint32_t* hh = hdr + (size_t)(tid + 1u) * 8u;
             const float lam = __uint_as_float(hh[4]);
@@ -355,6 +378,16 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
                 const uint32_t* __restrict__ sub, uint32_t nsub, const float* __restrict__ meta, DevState* __restrict__ st,
                 uint32_t* __restrict__ headroom, uint32_t nst_fixed, uint32_t skew)
 {
+    // grid = (slots, column tiles): the workgroups of one tile of A16 — one per slot of a batch — are neighbours in the launch
+    // order, so the tile comes from HBM once and from L2 for the others (one slot: a plain 1 x tiles grid)
+    {
+        const uint32_t slot = blockIdx.x;
+        r16 += (size_t)slot * kScrRhs * ldm;
+        rn2p += (size_t)slot * (ldm / 64u) * rn_pitch;
+        tab += (size_t)slot * kScrRhs * kScrTab;
+        sub += (size_t)slot * nsub;
+        st += slot;
+    }
     // NT: tiles of 32 states a workgroup carries — 3 (two register sets of loads in flight), or 5 for the fp64 form's longer paths
     // (160 states in ONE pass over the fp16 copy; one register set).
     // nst_fixed = 0: the fp32 form — the number of states and the go-ahead come from the slot's state (k_sub_solve's log);
@@ -373,7 +406,7 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     unsigned char* sA = smem;                                   // [128][272]
     unsigned char* sR = smem + (size_t)kScrCols * kScrPitchB;   // [32 NT][272]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint32_t col0 = blockIdx.x * kScrCols;
+    const uint32_t col0 = blockIdx.y * kScrCols;
     const uint32_t lc = tid >> 4, piece = tid & 15u;
     const __half* ga = a16 + (size_t)(col0 + lc) * ldm + 8u * piece;
     const __half* gr = r16 + (size_t)lc * ldm + 8u * piece;
@@ -417,7 +450,7 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     // around — the sum's order is free here — so that the 512 workgroups do not walk the same 256-byte phase of their
     // 16-KiB-strided columns together (the HBM channels are selected by those address bits)
     const uint32_t nstage = ldm / kScrKc;
-    const uint32_t sbase = (blockIdx.x * skew) % nstage;
+    const uint32_t sbase = (blockIdx.y * skew) % nstage;
 #define SCR_ROW(S) ((sbase + (S) >= nstage ? sbase + (S) - nstage : sbase + (S)) * kScrKc)
     SCR_LOAD(pa0, pr0, SCR_ROW(0u))
     if constexpr (TWO) {
@@ -701,7 +734,8 @@ void screen_free(ss_hip_ctx* ctx)
 {
     ScreenState* S = scr_of(ctx);
     if (!S) return;
-    void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->cabs, S->sublist, S->xsub, S->xd, S->ctl };
+    void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->cabs, S->sublist, S->xsub, S->xd, S->ctl,
+                     S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (S->sub) {
@@ -797,7 +831,7 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
                        (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st);
     if (e2) (void)hipEventRecord(e2, s);
-    hipLaunchKernelGGL(k_scr_gemm<3>, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
+    hipLaunchKernelGGL(k_scr_gemm<3>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
                        (const float*)S->anorm, (const float*)S->rn2p, kScrRhs, (const float*)S->tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
                        ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew());
     if (e3) (void)hipEventRecord(e3, s);
@@ -805,6 +839,55 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     return hipGetLastError();
 }
 
+
+
+// ---- a batch chunk in the screened form ------------------------------------------------------------------------------------
+// The same six steps with a slot dimension: selection and the subset solves one workgroup per slot (the subset form's batch
+// kernels), one subset Gram matrix per slot, and ONE screening launch whose workgroups of a tile of A16 — one per slot — are
+// neighbours in the launch order: the tile comes from HBM once.  c0 of every slot comes from the batch GEMM (8.6 us per signal
+// instead of a 330-us sweep each).
+uint32_t screen_batch_cap() { return kScrBatch; }
+
+hipError_t launch_screen_batch(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0_all, float tol, uint32_t max_iter)
+{
+    ScreenState* S = scr_of(ctx);
+    if (S == nullptr || ctx->sub_buf == nullptr || nslots == 0 || nslots > kScrBatch) return hipErrorInvalidConfiguration;
+    const uint32_t ldm = ctx->ldm, n = (uint32_t)ctx->n, np = ctx->n_pad;
+    if (S->b_r16 == nullptr) {
+        bool ok = true;
+        auto alloc = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; } };
+        alloc(reinterpret_cast<void**>(&S->b_r16), (size_t)kScrBatch * kScrRhs * ldm * sizeof(__half));
+        alloc(reinterpret_cast<void**>(&S->b_rn2p), (size_t)kScrBatch * (ldm / 64u) * kScrRhs * sizeof(float));
+        alloc(reinterpret_cast<void**>(&S->b_tab), (size_t)kScrBatch * kScrRhs * kScrTab * sizeof(float));
+        alloc(reinterpret_cast<void**>(&S->b_gs_part), (size_t)kScrBatch * kSgSplit * kSbS * kSbS * sizeof(float));
+        alloc(reinterpret_cast<void**>(&S->b_gs), (size_t)kScrBatch * kSbS * kSbS * sizeof(float));
+        if (ok && hipMemsetAsync(S->b_r16, 0, (size_t)kScrBatch * kScrRhs * ldm * sizeof(__half), ctx->stream) != hipSuccess) ok = false;
+        if (!ok) {
+            void* ptrs[] = { S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs };
+            for (void* p : ptrs) if (p) (void)hipFree(p);
+            S->b_r16 = nullptr; S->b_rn2p = nullptr; S->b_tab = nullptr; S->b_gs_part = nullptr; S->b_gs = nullptr;
+            (void)hipGetLastError();
+            return hipErrorOutOfMemory;
+        }
+    }
+    const SubBufs B = sub_bufs(ctx, nslots);
+    hipStream_t s = ctx->stream;
+    const float* At = static_cast<const float*>(ctx->At);
+    (void)launch_sub_select(ctx, B, nslots, c0_all);
+    const uint32_t nsplit = (ldm % (kSgSplit * kSgStep) == 0) ? kSgSplit : 4u;
+    constexpr uint32_t NT = kSbS / kSgT;
+    hipLaunchKernelGGL(k_sgram_part, dim3(NT * (NT + 1) / 2, nsplit, nslots), dim3(256), 0, s, At, ldm, n, (const uint32_t*)B.sub, ldm / nsplit, S->b_gs_part);
+    hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256, nslots), dim3(256), 0, s, (const float*)S->b_gs_part, nsplit, S->b_gs);
+    (void)launch_sub_solve(ctx, ws, B, nslots, (const float*)S->b_gs, kSbS, 1, c0_all, tol, max_iter, kSbS * kSbS);
+    hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u, nslots), dim3(256), 0, s, At, ldm, n, (const float*)ws.y,
+                       (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
+                       (const float*)S->meta, S->b_r16, S->b_rn2p, S->b_tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st);
+    hipLaunchKernelGGL(k_scr_gemm<3>, dim3(nslots, np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->b_r16,
+                       (const float*)S->anorm, (const float*)S->b_rn2p, kScrRhs, (const float*)S->b_tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew());
+    (void)launch_sub_finish(ctx, ws, nslots);
+    return hipGetLastError();
+}
 
 // ---- fp64 form, host side ------------------------------------------------------------------------------------------------
 static size_t s64_log_bytes()
@@ -917,12 +1000,12 @@ hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double
         const bool wide = T - k0 > kScrRhs;
         const uint32_t cnt = std::min<uint32_t>(wide ? 160u : kScrRhs, T - k0);
         if (wide)
-            hipLaunchKernelGGL(k_scr_gemm<5>, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 5), s, (const __half*)S->a16, ldm, n,
+            hipLaunchKernelGGL(k_scr_gemm<5>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 5), s, (const __half*)S->a16, ldm, n,
                                (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
                                (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
                                ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew());
         else
-            hipLaunchKernelGGL(k_scr_gemm<3>, dim3(np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 3), s, (const __half*)S->a16, ldm, n,
+            hipLaunchKernelGGL(k_scr_gemm<3>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 3), s, (const __half*)S->a16, ldm, n,
                                (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
                                (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
                                ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew());

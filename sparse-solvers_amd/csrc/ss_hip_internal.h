@@ -261,6 +261,7 @@ struct ss_hip_ctx {
     int screen_single = 1;            // option: 1 = single fp32 signals on large dictionaries take the screened form (screen.hip), 2 = on every shape
                                       // the form can run on (tests), 0 = never
     int screen_failed_alloc = 0;      // the preparation did not fit: not tried again
+    int batch_screen = 1;             // option: 1 = fp32 batches of 4 .. batch_gram_min - 1 signals (no G) run in the screened form, 64 per chunk
     // state log of the launch-per-iteration form (k_la_iter; on in the sub-context of the fp64 screened form, screen.hip):
     // cnt[cap] u32, lambda[cap] f64, lambda_prev - gamma_prev [cap] f64, cols[cap][kmax] u32, vals[cap][kmax] T — the state every launch starts from
     void* slog = nullptr;
@@ -420,7 +421,7 @@ struct SubBufs { uint32_t* sub; uint32_t* fpick; float* fval; uint32_t* hdr; uin
 SubBufs sub_bufs(ss_hip_ctx* ctx, uint32_t nslots);
 hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0);
 hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs& B, uint32_t nslots, const float* G, uint32_t gpitch, int gsub,
-                            const float* c0, float tol, uint32_t max_iter);
+                            const float* c0, float tol, uint32_t max_iter, uint32_t g_slot_stride = 0);
 hipError_t launch_sub_finish(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots);
 hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval);
 // screened form of ONE signal (screen.hip): the subset form on the subset's own Gram matrix (formed from A), every state of
@@ -428,6 +429,10 @@ hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32
 bool screen_form_usable(ss_hip_ctx* ctx);                 // shape / option test + one-time preparation (fp16 copy of A, column norms)
 hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                               hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
+// a batch chunk of nslots <= screen_batch_cap() signals in the screened form: c0 = A^T y of every slot in c0_all ([nslots][n_pad]), the
+// signals in ws.y; the slots' verdicts in their states (k_sub_finish) like the subset form's
+uint32_t screen_batch_cap();
+hipError_t launch_screen_batch(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0_all, float tol, uint32_t max_iter);
 void screen_free(ss_hip_ctx* ctx);
 // fp64: the path is solved by the fp64 engine on a sub-dictionary (a context of its own: the kS64Sub columns with the largest
 // |A^T y|), its states are logged (ss_hip_ctx::slog) and certified against all columns by the same fp16 pass

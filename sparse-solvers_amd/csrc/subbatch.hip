@@ -439,7 +439,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                  float tol, uint32_t max_iter, int strict_sign, int zero_on_removal, int tie_guard, int tie_exit,
                  uint32_t* __restrict__ log_hdr, uint32_t* __restrict__ log_pcol, float* __restrict__ log_X, float* __restrict__ log_D,
                  float* __restrict__ x_all, uint32_t* __restrict__ gam2_all, uint32_t* __restrict__ touched2_all, uint32_t kcap,
-                 DevState* __restrict__ st_all, TraceEntry* trace, uint32_t trace_cap, int gsub)
+                 DevState* __restrict__ st_all, TraceEntry* trace, uint32_t trace_cap, int gsub, uint32_t g_slot_stride)
 {
     // gsub != 0 (screened form of one signal, screen.hip): G is the subset's own Gram matrix Gs[kSbS][gpitch], rows and
     // columns by subset index, instead of the full G = A^T A
@@ -461,6 +461,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
         L.cs = p; p += kSbS; L.qs = p;
     }
     const uint32_t slot = blockIdx.x, j = threadIdx.x;
+    if (gsub) G += (size_t)slot * g_slot_stride;               // (a batch in the screened form: every slot its own subset Gram matrix)
     const float* c0 = c0_all + (size_t)slot * n_pad;
     float* x_out = x_all + (size_t)slot * n_pad;
     uint32_t* gam_out = gam2_all + (size_t)slot * 2 * kcap;
@@ -953,12 +954,12 @@ hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32
 
 // G, gpitch: the full Gram matrix (gsub = 0) or the subset's own (gsub = 1, one slot: screen.hip)
 hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs& B, uint32_t nslots, const float* G, uint32_t gpitch, int gsub,
-                            const float* c0, float tol, uint32_t max_iter)
+                            const float* c0, float tol, uint32_t max_iter, uint32_t g_slot_stride)
 {
     hipLaunchKernelGGL(k_sub_solve, dim3(nslots), dim3(kSbS), sub_lds_bytes(), ctx->stream, G, gpitch, c0, (uint32_t)ctx->n,
                        ctx->n_pad, (const uint32_t*)B.sub, (const uint32_t*)B.fpick, tol, max_iter, ctx->strict_sign, ctx->zero_on_removal,
                        ctx->tie_guard, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0, B.hdr, B.pcol, B.LX, B.LD, ws.x, ws.gam, ws.touched,
-                       ws.dims.kcap, ws.st, ws.trace, ws.trace_cap, gsub);
+                       ws.dims.kcap, ws.st, ws.trace, ws.trace_cap, gsub, g_slot_stride);
     return hipGetLastError();
 }
 
