@@ -396,11 +396,12 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     constexpr bool TWO = NT <= 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t nst = nst_fixed;
-    if (nst_fixed == 0u) {
+    if (nst_fixed == 0u || nst_fixed == 0xffffffffu) {
         if (st->status != 0u) return;
         const uint32_t nlog = st->solo_nlog;
         if (nlog < 2u) return;
         nst = nlog - 1u;
+        if (nst_fixed == 0xffffffffu && nst <= 64u) return;     // (batch chunk: k_scr_gemm_b carries the slots of up to 64 states)
     }
     const uint32_t ntu = (nst + 31u) / 32u;                      // (uniform) tiles of states in use
     unsigned char* sA = smem;                                   // [128][272]
@@ -529,6 +530,169 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     if (lane == 0u && worst > 0.f) atomicMax(headroom, __float_as_uint(worst));
 }
 
+
+
+// ---- the screening pass of a batch chunk: FOUR slots per workgroup ----------------------------------------------------
+// k_scr_gemm with a slot per workgroup re-stages every tile of A16 once per slot: 64 slots = 64 x 0.17 ms, whatever L2 holds
+// — a workgroup's own pipeline (LDS staging, barriers) is what a launch takes.  Here a workgroup carries 128 columns x 4 slots
+// x 64 states (8 MFMA tiles per wave: 128 accumulator registers; one workgroup per CU, one wave per SIMD): the A16 tile is
+// staged once per stage for 256 right-hand sides, and the launch is MFMA-bound.  Slots whose path logged more than 64 states
+// are left to k_scr_gemm<3> (launched beside this one; each kernel skips the other's slots).
+constexpr uint32_t kScrSL = 4;                               // slots per workgroup
+constexpr uint32_t kScrBS = 64;                              // states per slot here
+__global__ __launch_bounds__(256, 1)
+void k_scr_gemm_b(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const __half* __restrict__ r16_all,
+                  const float* __restrict__ anorm, const float* __restrict__ rn2p_all, const float* __restrict__ tab_all,
+                  const uint32_t* __restrict__ sub_all, const float* __restrict__ meta, DevState* __restrict__ st_all,
+                  uint32_t* __restrict__ headroom, uint32_t nslots, uint32_t skew)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_nst[kScrSL];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t slot0 = blockIdx.x * kScrSL;
+    if (tid < kScrSL) {
+        uint32_t v = 0;
+        const uint32_t sl = slot0 + tid;
+        if (sl < nslots && st_all[sl].status == 0u) {
+            const uint32_t nlog = st_all[sl].solo_nlog;
+            if (nlog >= 2u && nlog - 1u <= kScrBS) v = nlog - 1u;
+        }
+        s_nst[tid] = v;
+    }
+    __syncthreads();
+    uint32_t nst[kScrSL];
+    bool any = false;
+#pragma unroll
+    for (uint32_t q = 0; q < kScrSL; ++q) { nst[q] = s_nst[q]; any = any || nst[q] != 0u; }
+    if (!any) return;
+    unsigned char* sA = smem;                                   // [128][272]
+    unsigned char* sR = smem + (size_t)kScrCols * kScrPitchB;   // [4 x 64][272]
+    const uint32_t col0 = blockIdx.y * kScrCols;
+    const uint32_t lc = tid >> 4, piece = tid & 15u;
+    const __half* ga = a16 + (size_t)(col0 + lc) * ldm + 8u * piece;
+    // rows of the R tile: row = 64 q + state; thread (lc, piece) loads rows lc + 16 i, i < 16: slot q = i / 4
+    const __half* gr[kScrSL];
+#pragma unroll
+    for (uint32_t q = 0; q < kScrSL; ++q) {
+        const uint32_t sl = slot0 + q < nslots ? slot0 + q : slot0;
+        gr[q] = r16_all + ((size_t)sl * kScrRhs + lc) * ldm + 8u * piece;
+    }
+    scr_u4 pa0[8], pr0[16], pa1[8], pr1[16];
+#define SCB_LOAD(PA, PR, R0)                                                                                      \
+    {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                             \
+            PA[i] = __builtin_nontemporal_load(reinterpret_cast<const scr_u4*>(ga + (size_t)(16 * i) * ldm + (R0)));  \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                            \
+            if (nst[i / 4] != 0u) PR[i] = *reinterpret_cast<const scr_u4*>(gr[i / 4] + (size_t)(16 * (i % 4)) * ldm + (R0)); \
+    }
+    scr_v16f acc[2 * kScrSL];
+#pragma unroll
+    for (int t = 0; t < (int)(2 * kScrSL); ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const unsigned char* rdA = sA + (size_t)(32u * w + r) * kScrPitchB + 16u * h;
+    const unsigned char* rdR = sR + (size_t)r * kScrPitchB + 16u * h;
+#define SCB_STAGE(PA, PR, MORE, RNEXT)                                                                            \
+    {                                                                                                             \
+        __syncthreads();                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                             \
+            *reinterpret_cast<scr_u4*>(sA + (size_t)(lc + 16u * (uint32_t)i) * kScrPitchB + 16u * piece) = PA[i]; \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                            \
+            if (nst[i / 4] != 0u)                                                                                 \
+                *reinterpret_cast<scr_u4*>(sR + (size_t)(lc + 16u * (uint32_t)i) * kScrPitchB + 16u * piece) = PR[i]; \
+        __syncthreads();                                                                                          \
+        if (MORE) SCB_LOAD(PA, PR, (RNEXT))                                                                       \
+        _Pragma("unroll") for (uint32_t ks = 0; ks < kScrKc / 16u; ++ks) {                                        \
+            const scr_h8 bq = *reinterpret_cast<const scr_h8*>(rdA + 32u * ks);                                   \
+            _Pragma("unroll") for (int t = 0; t < (int)(2 * kScrSL); ++t) {                                       \
+                if (32u * (uint32_t)(t & 1) < nst[t / 2]) {                                                       \
+                    const scr_h8 aq = *reinterpret_cast<const scr_h8*>(rdR + (size_t)(32 * t) * kScrPitchB + 32u * ks); \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq, acc[t], 0, 0, 0);                     \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+    const uint32_t nstage = ldm / kScrKc;
+    const uint32_t sbase = (blockIdx.y * skew) % nstage;
+#define SCB_ROW(S) ((sbase + (S) >= nstage ? sbase + (S) - nstage : sbase + (S)) * kScrKc)
+    SCB_LOAD(pa0, pr0, SCB_ROW(0u))
+    SCB_LOAD(pa1, pr1, SCB_ROW(1u))
+    for (uint32_t sidx = 0; sidx < nstage; sidx += 2u) {
+        SCB_STAGE(pa0, pr0, sidx + 2u < nstage, SCB_ROW(sidx + 2u))
+        SCB_STAGE(pa1, pr1, sidx + 3u < nstage, SCB_ROW(sidx + 3u))
+    }
+#undef SCB_ROW
+#undef SCB_STAGE
+#undef SCB_LOAD
+    // ---- epilogue, slot by slot: its table, its subset, then this wave's (column, state) pairs ---------------------------
+    float* sT = reinterpret_cast<float*>(smem);                 // [64][4]
+    uint32_t* sSub = reinterpret_cast<uint32_t*>(smem) + kScrBS * 4u;          // [kSbS]
+    float* sPart = reinterpret_cast<float*>(smem) + kScrBS * 4u + kSbS;        // [128][64]
+    const float inv_sA = meta[1];
+    const float sq_ldm = sqrtf((float)ldm);
+    const uint32_t nblk = ldm / 64u;
+    const uint32_t col = col0 + 32u * w + r;
+    const float an = anorm[col < n ? col : 0u];
+    float worst = 0.f;
+#pragma unroll
+    for (uint32_t q = 0; q < kScrSL; ++q) {
+        const uint32_t ns = nst[q];
+        if (ns == 0u) continue;                                   // (uniform)
+        const uint32_t sl = slot0 + q;
+        const float* rn2p = rn2p_all + (size_t)sl * nblk * kScrRhs;
+        const float* tab = tab_all + (size_t)sl * kScrRhs * kScrTab;
+        const uint32_t* sub = sub_all + (size_t)sl * kSbS;
+        float s2 = 0.f;
+        for (uint32_t b0 = 0; b0 < nblk; b0 += 128u) {
+            const uint32_t nb = nblk - b0 < 128u ? nblk - b0 : 128u;
+            __syncthreads();
+            for (uint32_t e = tid; e < nb * kScrBS; e += 256u) { const uint32_t b = e / kScrBS, k = e - b * kScrBS; sPart[e] = rn2p[(size_t)(b0 + b) * kScrRhs + k]; }
+            __syncthreads();
+            if (tid < ns)
+                for (uint32_t b = 0; b < nb; ++b) s2 += sPart[(size_t)b * kScrBS + tid];
+        }
+        __syncthreads();
+        if (tid < kScrBS) {
+            float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+            if (tid < ns) {
+                const float rn = sqrtf(s2) * 1.001f;
+                const float inv_sk = tab[tid * kScrTab + 2];
+                f0 = tab[tid * kScrTab + 0];
+                f1 = tab[tid * kScrTab + 1];
+                f2 = 0.0019726562f * rn + 6.103515625e-05f * sq_ldm * inv_sk;
+                f3 = 6.103515625e-05f * sq_ldm * rn * inv_sA;
+            }
+            sT[tid * 4 + 0] = f0; sT[tid * 4 + 1] = f1; sT[tid * 4 + 2] = f2; sT[tid * 4 + 3] = f3;
+        }
+        for (uint32_t e = tid; e < kSbS; e += 256u) sSub[e] = sub[e];
+        __syncthreads();
+        uint32_t lo = 0, hi = kSbS;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sSub[mid] < col) lo = mid + 1u; else hi = mid; }
+        const bool mine = col < n && !(lo < kSbS && sSub[lo] == col);
+        bool flag = false;
+        float wq = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t kk = 32u * (uint32_t)tt + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * h;
+                if (kk < ns) {
+                    const scr_v4f T4 = *reinterpret_cast<const scr_v4f*>(&sT[kk * 4u]);
+                    const float v = fabsf(acc[2 * q + tt][e]) * T4[0] + (an * T4[2] + T4[3]);
+                    if (!(v <= T4[1])) flag = true;
+                    const float ratio = T4[1] > 0.f ? v / T4[1] : 3.0e38f;
+                    wq = fmaxf(wq, ratio == ratio ? ratio : 3.0e38f);
+                }
+            }
+        }
+        if (mine && flag) __hip_atomic_store(&st_all[sl].need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mine) worst = fmaxf(worst, wq);
+    }
+    worst = fmaxf(worst, __shfl_xor(worst, 1)); worst = fmaxf(worst, __shfl_xor(worst, 2)); worst = fmaxf(worst, __shfl_xor(worst, 4));
+    worst = fmaxf(worst, __shfl_xor(worst, 8)); worst = fmaxf(worst, __shfl_xor(worst, 16)); worst = fmaxf(worst, __shfl_xor(worst, 32));
+    if (lane == 0u && worst > 0.f) atomicMax(headroom, __float_as_uint(worst));
+}
 
 // ======== fp64: the same certificate around the launch-per-iteration engine ============================================
 // No fp64 subset solve fits one workgroup's LDS (128 positions x 448 columns x 8 bytes).  The fp64 form therefore solves the
@@ -841,6 +1005,11 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
 
 
 
+static size_t scr_gemm_b_lds()
+{
+    return std::max<size_t>((size_t)(kScrCols + kScrSL * kScrBS) * kScrPitchB, ((size_t)kScrBS * 4 + kSbS + (size_t)128 * kScrBS) * 4);
+}
+
 // ---- a batch chunk in the screened form ------------------------------------------------------------------------------------
 // The same six steps with a slot dimension: selection and the subset solves one workgroup per slot (the subset form's batch
 // kernels), one subset Gram matrix per slot, and ONE screening launch whose workgroups of a tile of A16 — one per slot — are
@@ -882,9 +1051,20 @@ hipError_t launch_screen_batch(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t n
     hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u, nslots), dim3(256), 0, s, At, ldm, n, (const float*)ws.y,
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
                        (const float*)S->meta, S->b_r16, S->b_rn2p, S->b_tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st);
+    static const bool b_attr = [] {
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scr_gemm_b_lds()) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        return ok;
+    }();
+    if (b_attr) {
+        hipLaunchKernelGGL(k_scr_gemm_b, dim3((nslots + kScrSL - 1) / kScrSL, np / kScrCols), dim3(256), scr_gemm_b_lds(), s, (const __half*)S->a16, ldm, n,
+                           (const __half*)S->b_r16, (const float*)S->anorm, (const float*)S->b_rn2p, (const float*)S->b_tab, (const uint32_t*)B.sub,
+                           (const float*)S->meta, ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, nslots, scr_skew());
+    }
+    // (slots whose path logged more than 64 states — and every slot, should the wide kernel's LDS request be refused)
     hipLaunchKernelGGL(k_scr_gemm<3>, dim3(nslots, np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->b_r16,
                        (const float*)S->anorm, (const float*)S->b_rn2p, kScrRhs, (const float*)S->b_tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
-                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew());
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, b_attr ? 0xffffffffu : 0u, scr_skew());
     (void)launch_sub_finish(ctx, ws, nslots);
     return hipGetLastError();
 }

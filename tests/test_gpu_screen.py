@@ -314,3 +314,39 @@ def test_screened_form_wide_dictionary(sship, n):
     else:
         assert it1 == it0 and np.array_equal(np.nonzero(x1)[0], np.nonzero(x0_)[0])
         assert np.abs(x1 - x0_).max() <= 1e-4 * np.abs(x0_).max()
+
+
+@pytest.mark.parametrize("B", [5, 40, 70])
+def test_screened_batch_form(sship, B):
+    """Batches without G in the screened form (option batch_screen, chunks of 64, four slots per workgroup of the screening
+    launch; B not a multiple of four, B beyond one chunk): every signal against the oracle; a signal the form hands back
+    (here: one whose support is too dense for the subset) is the default engine's."""
+    m, n, k = 1024, 8192, 12
+    rng = np.random.default_rng(9600 + B)
+    A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(np.float32)
+    Y = np.empty((B, m), np.float32)
+    sups = []
+    for b in range(B):
+        kb = k if b != 3 else 90                       # (signal 3: more columns than the form holds)
+        sup = np.sort(rng.choice(n, kb, replace=False))
+        x0 = np.zeros(n)
+        x0[sup] = 1.0 + np.abs(rng.standard_normal(kb))
+        Y[b] = (A.astype(np.float64) @ x0).astype(np.float32)
+        sups.append(sup)
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.reset_stats()
+        X, its, errs = h.solve_batch(Y, 1e-3, 200)
+        st = h.stats()
+        h.set_option("batch_screen", 0)
+        h.set_option("screen_single", 0)
+        x3, it3, e3 = h.solve(Y[3], 1e-3, 200)
+    note("test_screened_batch_form", B=B, certified=st["screen_signals"], redone=st["screen_redone"], headroom=st["screen_headroom"])
+    assert st["screen_signals"] + st["screen_redone"] + st["tie_reruns"] == B and st["screen_redone"] >= 1
+    assert its[3] == it3 and np.array_equal(X[3], x3)
+    for b in range(B):
+        if b == 3:
+            continue
+        xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 200)
+        assert_parity(X[b], int(its[b]), float(errs[b]), xo, ito, eo, np.float32)
+        assert np.array_equal(significant_support(X[b], 1e-4), sups[b])
