@@ -513,7 +513,10 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         recm = torch.zeros((Bm, rbm), dtype=torch.uint8, device=dev)
         mid = {}
         keep_min = h.get_option("batch_cols_min")
-        for label, cmin in (("column_form", keep_min), ("one_solve_per_signal", 0)):
+        # (screened form: c0 by the batch GEMM, one workgroup per signal, one screening launch per 64 signals — the default;
+        # column form: the lock-step form it stands in for; one solve per signal: each in the single-signal screened form)
+        for label, scr, cmin in (("screened_form", 1, keep_min), ("column_form", 0, keep_min), ("one_solve_per_signal", 0, 0)):
+            h.set_option("batch_screen", scr)
             h.set_option("batch_cols_min", cmin)
             h.solve_batch_compact(Ym, TOL, MAX_ITER, kmax=KMAX_RECORD, out=recm)          # allocations
             torch.cuda.synchronize()
@@ -522,12 +525,15 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             h.solve_batch_compact(Ym, TOL, MAX_ITER, kmax=KMAX_RECORD, out=recm)
             torch.cuda.synchronize()
             dtm = time.perf_counter() - tm
+            stm = h.stats()
             okm, stuckm, cerrm, itm = check_records(recm.cpu().numpy(), supm, coefm, MAX_ITER)
-            mid[label] = {"signals_per_s": Bm / dtm, "ms": dtm * 1e3, "rounds": int(h.stats()["batch_col_rounds"]),
-                          "support_exact": okm, "max_rel_coef_err": cerrm, "iterations_max": int(itm.max())}
+            mid[label] = {"signals_per_s": Bm / dtm, "ms": dtm * 1e3, "rounds": int(stm["batch_col_rounds"]),
+                          "support_exact": okm, "max_rel_coef_err": cerrm, "iterations_max": int(itm.max()),
+                          "screened": int(stm["screen_signals"]), "redone": int(stm["screen_redone"])}
         h.set_option("batch_cols_min", keep_min)
-        mid["workload"] = "64 signals sharing A (k=64, tol 1e-3, max_iter 256), compact records"
-        mid["speedup"] = mid["column_form"]["signals_per_s"] / mid["one_solve_per_signal"]["signals_per_s"]
+        h.set_option("batch_screen", 1)
+        mid["workload"] = "64 signals sharing A (k=64, tol 1e-3, max_iter 256), no G, compact records"
+        mid["speedup"] = mid["screened_form"]["signals_per_s"] / mid["one_solve_per_signal"]["signals_per_s"]
         extras["mid_size_batch"] = mid
         del recm, Ym
 

@@ -359,6 +359,12 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    for bit by any implementation that states the same order.  One pass over A per iteration (2 GiB
  *                    at 8192 x 65536, 0.84 of the HBM peak); batches run up to 4 signals per pass; the arbiter of
  *                    "tie_rerun".
+ *   "batch_screen"   1 (default) = fp32 batches of 4 .. batch_gram_min - 1 signals on a context without G = A^T A, on dictionaries
+ *                    the screened form applies to ("screen_single"), run in that form chunk by chunk (64 signals): c0 of the chunk
+ *                    by the batch GEMM, every signal solved by one workgroup on its subset's own Gram matrix, one screening launch
+ *                    over the fp16 copy of A for the whole chunk (four signals per workgroup); a signal it hands back is solved by
+ *                    the default single-signal engine.  Results agree with solve() to rounding, not bit for bit; 0 = the column
+ *                    form ("batch_cols_min") or one solve per signal as before
  *   "batch_subset"   1 (default) = batches that run in Gram form on the full G = A^T A use the SUBSET form
  *                    (csrc/subbatch.hip): every signal is solved by one workgroup on the 448 columns with the largest
  *                    |A^T y| and every breakpoint is then checked against all columns by the same chain of fmas; a signal
