@@ -25,6 +25,7 @@
 #include "ss_hip_device.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace sship {
 
@@ -38,6 +39,8 @@ struct IrlsState {
     T* rdiag = nullptr;   // [n]
     T* vec = nullptr;     // qTb, s, xnext, w, x: 5 x [n]; then t, y: 2 x [ldm]
     IrlsResult* res = nullptr;   // device copy of the report
+    void* ctl = nullptr;         // IrlsCtl<T>: loop state of the blocked form
+    uint32_t* done_host = nullptr;   // pinned: the while-test of the blocked form, read once per Newton iteration
 };
 
 constexpr int kQrThreads = 256;
@@ -331,6 +334,355 @@ void k_irls_solve(const T* __restrict__ Qt, const T* __restrict__ R, const T* __
     }
 }
 
+
+// ==== the Newton loop as a chain of launches (n >= kIrlsBlockedMin): blocked Cholesky, blocked triangular solves, ==========
+// ==== the products with Q on all CUs ==========================================================================================
+// k_irls_solve above keeps the whole loop in ONE workgroup: at n = 1024 its column-by-column Cholesky is 1024 steps of two
+// barriers with every inner product a round trip to L2 (30 ms per iteration), its three triangular solves 2048 barriers each,
+// and the two products with Q (16 MB each) pass through one CU.  Here: the Cholesky factor by panels of 32 columns — diagonal
+// block in LDS by one wave, the panel below it one row per thread, the trailing update by 32 x 32 tiles on all CUs (3 launches
+// per panel) —, the triangular solves by blocks of 32 (one barrier pair per block instead of per unknown), t = Q s and Q^T t
+// spread over the chip.  The host reads one word per Newton iteration (the while-test).  Same formulas as the reference
+// (irls-cpu.cpp:39-124, cholesky_decomposition.h:56-100); sums are formed in different orders (parity by tolerance, as before).
+constexpr uint32_t kIrlsBlockedMin = 96;
+constexpr uint32_t kChB = 32;                     // panel width / solve block
+
+template <typename T>
+struct IrlsCtl {                                  // device-resident loop state
+    T eps, abstol, second;
+    uint32_t iter, done, spd_bad, pad_;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_irls_init(T* __restrict__ vec, uint32_t n, IrlsCtl<T>* __restrict__ ctl)
+{
+    T* xnext = vec + 2 * (size_t)n;
+    T* w = vec + 3 * (size_t)n;
+    T* x = vec + 4 * (size_t)n;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) { x[i] = T(0); w[i] = T(1); xnext[i] = T(1); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->eps = T(1); ctl->abstol = T(1); ctl->second = T(0); ctl->iter = 0; ctl->done = 0; ctl->spd_bad = 0; }
+}
+
+// out[j] = Qt[j] . v   (one wave per column of Q; Q^T y and Q^T t)
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_irls_qt_vec(const T* __restrict__ Qt, uint32_t ldm, uint32_t m, uint32_t n, const T* __restrict__ v, T* __restrict__ out,
+                   const IrlsCtl<T>* __restrict__ ctl)
+{
+    if (ctl != nullptr && ctl->done) return;
+    const uint32_t lane = threadIdx.x & 63u, j = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const T* q = Qt + (size_t)j * ldm;
+    T acc = T(0);
+    for (uint32_t r = lane; r < m; r += 64u) acc += q[r] * v[r];
+    acc = wave_sum(acc);
+    if (lane == 0) out[j] = acc;
+}
+
+// t[r] = sum_j Qt[j][r] s[j]   (a thread per row, coalesced over the rows of Q^T)
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_irls_q_vec(const T* __restrict__ Qt, uint32_t ldm, uint32_t m, uint32_t n, const T* __restrict__ s, T* __restrict__ t,
+                  const IrlsCtl<T>* __restrict__ ctl)
+{
+    if (ctl->done) return;
+    __shared__ T ss[256];
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    T acc = T(0);
+    for (uint32_t j0 = 0; j0 < n; j0 += 256u) {
+        __syncthreads();
+        if (j0 + threadIdx.x < n) ss[threadIdx.x] = s[j0 + threadIdx.x];
+        __syncthreads();
+        const uint32_t cnt = n - j0 < 256u ? n - j0 : 256u;
+        if (r < m)
+            for (uint32_t j = 0; j < cnt; ++j) acc += Qt[(size_t)(j0 + j) * ldm + r] * ss[j];
+    }
+    if (r < m) t[r] = acc;
+}
+
+// L = tril(Q^T Q) with column j scaled by w_j (irls-cpu.cpp:48-49)
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_irls_scale(const T* __restrict__ G0, const T* __restrict__ w, T* __restrict__ L, uint32_t n, const IrlsCtl<T>* __restrict__ ctl)
+{
+    if (ctl->done) return;
+    const size_t e = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (e >= (size_t)n * n) return;
+    const uint32_t i = (uint32_t)(e / n), j = (uint32_t)(e - (size_t)i * n);
+    L[e] = j <= i ? G0[e] * w[j] : T(0);
+}
+
+// Cholesky, panel k0: the diagonal block (one wave, in LDS), then — same launch, the other workgroups wait for nothing: they
+// are a second kernel — see k_chol_below.  Pivot rule of the reference: ajj = sqrt(a_jj); ajj <= eps marks the matrix not SPD.
+template <typename T>
+__global__ __launch_bounds__(64)
+void k_chol_diag(T* __restrict__ L, uint32_t n, uint32_t k0, IrlsCtl<T>* __restrict__ ctl)
+{
+    if (ctl->done) return;
+    __shared__ T D[kChB][kChB + 1];
+    const uint32_t l = threadIdx.x;
+    const uint32_t nb = n - k0 < kChB ? n - k0 : kChB;
+    if (l < nb)
+        for (uint32_t c = 0; c < nb; ++c) D[l][c] = c <= l ? L[(size_t)(k0 + l) * n + k0 + c] : T(0);
+    __syncthreads();
+    bool bad = false;
+    for (uint32_t c = 0; c < nb; ++c) {
+        const T ajj = sqrt(D[c][c]);
+        if (ajj <= Lim<T>::eps()) bad = true;
+        const T inv = T(1) / ajj;
+        __syncthreads();
+        if (l >= c && l < nb) D[l][c] *= inv;
+        __syncthreads();
+        // right-looking inside the block: a_lc' -= l_lc l_c'c for c' > c, l >= c'
+        for (uint32_t c2 = c + 1; c2 < nb; ++c2)
+            if (l >= c2 && l < nb) D[l][c2] -= D[l][c] * D[c2][c];
+        __syncthreads();
+    }
+    if (l < nb)
+        for (uint32_t c = 0; c <= l; ++c) L[(size_t)(k0 + l) * n + k0 + c] = D[l][c];
+    if (l == 0 && bad) ctl->spd_bad = 1;
+}
+
+// ... the panel below the diagonal block: row i solves x L11^T = a_i (32 unknowns), one row per thread
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_chol_below(T* __restrict__ L, uint32_t n, uint32_t k0, const IrlsCtl<T>* __restrict__ ctl)
+{
+    if (ctl->done) return;
+    __shared__ T D[kChB][kChB + 1];
+    const uint32_t nb = kChB;                                   // (called only for full diagonal blocks with rows below)
+    for (uint32_t e = threadIdx.x; e < kChB * kChB; e += 256u) { const uint32_t a = e / kChB, b = e % kChB; D[a][b] = L[(size_t)(k0 + a) * n + k0 + b]; }
+    __syncthreads();
+    const uint32_t i = k0 + kChB + blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    T* row = L + (size_t)i * n + k0;
+    T xv[kChB];
+#pragma unroll
+    for (uint32_t c = 0; c < nb; ++c) {
+        T a = row[c];
+#pragma unroll
+        for (uint32_t c2 = 0; c2 < c; ++c2) a -= xv[c2] * D[c][c2];
+        xv[c] = a / D[c][c];
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < nb; ++c) row[c] = xv[c];
+}
+
+// ... the trailing update, lower triangle only: A22[i][j] -= sum_c P[i][c] P[j][c], 32 x 32 tiles
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_chol_trail(T* __restrict__ L, uint32_t n, uint32_t k0, const IrlsCtl<T>* __restrict__ ctl)
+{
+    if (ctl->done) return;
+    __shared__ T Pi[kChB][kChB + 1], Pj[kChB][kChB + 1];
+    const uint32_t b = blockIdx.x;
+    uint32_t t = (uint32_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while (t * (t + 1u) / 2u > b) --t;
+    while ((t + 1u) * (t + 2u) / 2u <= b) ++t;
+    const uint32_t ti = t, tj = b - t * (t + 1u) / 2u;          // ti >= tj
+    const uint32_t base = k0 + kChB;
+    const uint32_t i0 = base + ti * kChB, j0 = base + tj * kChB;
+    for (uint32_t e = threadIdx.x; e < kChB * kChB; e += 256u) {
+        const uint32_t a = e / kChB, c = e % kChB;
+        Pi[a][c] = i0 + a < n ? L[(size_t)(i0 + a) * n + k0 + c] : T(0);
+        Pj[a][c] = j0 + a < n ? L[(size_t)(j0 + a) * n + k0 + c] : T(0);
+    }
+    __syncthreads();
+    const uint32_t jj = threadIdx.x & 31u, ib = threadIdx.x >> 5;           // 8 row groups of 4
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t ii = ib * 4u + q;
+        const uint32_t i = i0 + ii, j = j0 + jj;
+        if (i < n && j < n && j <= i) {
+            T acc = T(0);
+#pragma unroll
+            for (uint32_t c = 0; c < kChB; ++c) acc += Pi[ii][c] * Pj[jj][c];
+            L[(size_t)i * n + j] -= acc;
+        }
+    }
+}
+
+// s = (L L^T)^-1 qTb by blocks of 32 (cholesky_decomposition.h:90-100).  One workgroup; s in LDS.
+template <typename T>
+__global__ __launch_bounds__(kIrlsThreads)
+void k_irls_chol_solve(const T* __restrict__ L, uint32_t n, T* __restrict__ vec, IrlsCtl<T>* __restrict__ ctl)
+{
+    if (ctl->done) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cs[];
+    T* ss = reinterpret_cast<T*>(smem_cs);                       // [n]
+    __shared__ T D[kChB][kChB + 1];
+    __shared__ T z[kChB];
+    const uint32_t tid = threadIdx.x;
+    if (ctl->spd_bad) {                                          // irls-cpu.cpp: a failed factorisation ends the loop
+        if (tid == 0) ctl->done = 1;
+        return;
+    }
+    const T* qTb = vec;
+    T* s = vec + n;
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) ss[i] = qTb[i];
+    __syncthreads();
+    // L z = b, top to bottom
+    for (uint32_t b0 = 0; b0 < n; b0 += kChB) {
+        const uint32_t nb = n - b0 < kChB ? n - b0 : kChB;
+        for (uint32_t e = tid; e < kChB * kChB; e += kIrlsThreads) { const uint32_t a = e / kChB, c = e % kChB; D[a][c] = (a < nb && c <= a) ? L[(size_t)(b0 + a) * n + b0 + c] : T(0); }
+        __syncthreads();
+        if (tid < 64) {
+            T mine = tid < nb ? ss[b0 + tid] : T(0);
+            for (uint32_t c = 0; c < nb; ++c) {
+                const T zc = lane_value(mine, (int)c) / D[c][c];
+                if (tid == c) mine = zc;
+                else if (tid > c && tid < nb) mine -= D[tid][c] * zc;
+            }
+            if (tid < nb) { ss[b0 + tid] = mine; z[tid] = mine; }
+        }
+        __syncthreads();
+        for (uint32_t i = b0 + kChB + tid; i < n; i += kIrlsThreads) {
+            const T* row = L + (size_t)i * n + b0;
+            T acc = T(0);
+#pragma unroll 8
+            for (uint32_t c = 0; c < kChB; ++c) acc += row[c] * z[c];
+            ss[i] -= acc;
+        }
+        __syncthreads();
+    }
+    // L^T x = z, bottom to top
+    const uint32_t nblk = (n + kChB - 1) / kChB;
+    for (uint32_t bb = nblk; bb-- > 0;) {
+        const uint32_t b0 = bb * kChB;
+        const uint32_t nb = n - b0 < kChB ? n - b0 : kChB;
+        for (uint32_t e = tid; e < kChB * kChB; e += kIrlsThreads) { const uint32_t a = e / kChB, c = e % kChB; D[a][c] = (a < nb && c <= a) ? L[(size_t)(b0 + a) * n + b0 + c] : T(0); }
+        __syncthreads();
+        if (tid < 64) {
+            T mine = tid < nb ? ss[b0 + tid] : T(0);
+            for (uint32_t cc = nb; cc-- > 0;) {
+                const T xc = lane_value(mine, (int)cc) / D[cc][cc];
+                if (tid == cc) mine = xc;
+                else if (tid < cc) mine -= D[cc][tid] * xc;          // (L^T)[tid][cc] = L[cc][tid]
+            }
+            if (tid < nb) { ss[b0 + tid] = mine; z[tid] = mine; }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < b0; i += kIrlsThreads) {
+            T acc = T(0);
+            for (uint32_t c = 0; c < nb; ++c) acc += L[(size_t)(b0 + c) * n + i] * z[c];
+            ss[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) s[i] = ss[i];
+}
+
+// R x = x (upper triangular, by blocks of 32), then run_solver's part of the iteration (irls-cpu.cpp:100-116) and the while-test.
+template <typename T>
+__global__ __launch_bounds__(kIrlsThreads)
+void k_irls_tail(const T* __restrict__ R, uint32_t n, T* __restrict__ vec, T tol, uint32_t max_iter, IrlsCtl<T>* __restrict__ ctl)
+{
+    if (ctl->done) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tl[];
+    T* xs = reinterpret_cast<T*>(smem_tl);                       // [n]
+    __shared__ T D[kChB][kChB + 1];
+    __shared__ T z[kChB];
+    __shared__ T sv[16];
+    __shared__ uint32_t si[16];
+    const uint32_t tid = threadIdx.x;
+    T* xnext = vec + 2 * (size_t)n;
+    T* w = vec + 3 * (size_t)n;
+    T* x = vec + 4 * (size_t)n;
+    const T p = T(0.9);
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) xs[i] = xnext[i];
+    __syncthreads();
+    const uint32_t nblk = (n + kChB - 1) / kChB;
+    for (uint32_t bb = nblk; bb-- > 0;) {
+        const uint32_t b0 = bb * kChB;
+        const uint32_t nb = n - b0 < kChB ? n - b0 : kChB;
+        for (uint32_t e = tid; e < kChB * kChB; e += kIrlsThreads) { const uint32_t a = e / kChB, c = e % kChB; D[a][c] = (a < nb && c < nb && c >= a) ? R[(size_t)(b0 + a) * n + b0 + c] : T(0); }
+        __syncthreads();
+        if (tid < 64) {
+            T mine = tid < nb ? xs[b0 + tid] : T(0);
+            for (uint32_t cc = nb; cc-- > 0;) {
+                const T xc = lane_value(mine, (int)cc) / D[cc][cc];
+                if (tid == cc) mine = xc;
+                else if (tid < cc) mine -= D[tid][cc] * xc;
+            }
+            if (tid < nb) { xs[b0 + tid] = mine; z[tid] = mine; }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < b0; i += kIrlsThreads) {
+            const T* row = R + (size_t)i * n + b0;
+            T acc = T(0);
+            for (uint32_t c = 0; c < nb; ++c) acc += row[c] * z[c];
+            xs[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) xnext[i] = xs[i];
+    __syncthreads();
+    // ---- run_solver ------------------------------------------------------------------------------
+    T mx;
+    uint32_t mi;
+    block_max_excl(xnext, n, 0xffffffffu, mx, mi, sv, si);
+    const T abstol = mx * tol;                                    // :100
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) {            // :103-104
+        const T v = xnext[i] < abstol ? T(0) : xnext[i];
+        xnext[i] = v;
+        x[i] = v;
+    }
+    __syncthreads();
+    block_max_excl(xnext, n, 0xffffffffu, mx, mi, sv, si);
+    T second;
+    if (n >= 2) {
+        T m2;
+        uint32_t i2;
+        block_max_excl(xnext, n, mi, m2, i2, sv, si);
+        second = m2;
+    } else {
+        second = mx;
+    }
+    T eps = ctl->eps;
+    {
+        const T cand = second / T(n);                             // :110
+        if (cand < eps) eps = cand;
+    }
+    T part = T(0);
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) {            // :113
+        const T v = (T)pow((double)(x[i] * x[i] + eps), (double)p / 2.0 - 1.0);
+        w[i] = v;
+        part += v;
+    }
+    const T sum = block_sum(part, sv);
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) w[i] /= sum;   // :114
+    if (tid == 0) {
+        const uint32_t it = ctl->iter + 1u;
+        ctl->iter = it;
+        ctl->eps = eps;
+        ctl->abstol = abstol;
+        ctl->second = second;
+        if (!(it < max_iter && second > abstol)) ctl->done = 1;     // the do-while test (:117)
+    }
+}
+
+// finally, normalise x (:121) and publish the report
+template <typename T>
+__global__ __launch_bounds__(kIrlsThreads)
+void k_irls_finish(T* __restrict__ vec, uint32_t n, const IrlsCtl<T>* __restrict__ ctl, IrlsResult* __restrict__ res)
+{
+    __shared__ T sv[16];
+    T* x = vec + 4 * (size_t)n;
+    const uint32_t tid = threadIdx.x;
+    T part = T(0);
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) part += x[i];
+    const T sum = block_sum(part, sv);
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kIrlsThreads) x[i] /= sum;
+    if (tid == 0) {
+        res->iter = ctl->iter;
+        res->spd_failure = ctl->spd_bad;
+        res->solution_error = (double)ctl->eps;
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 template <typename T>
 static IrlsState<T>* state_of(ss_hip_ctx* ctx) { return static_cast<IrlsState<T>*>(ctx->irls); }
@@ -351,6 +703,8 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
     IRLS_TRY(hipMalloc(&S->rdiag, (size_t)n * sizeof(T)));
     IRLS_TRY(hipMalloc(&S->vec, (5 * (size_t)n + 2 * (size_t)ldm) * sizeof(T)));
     IRLS_TRY(hipMalloc(&S->res, sizeof(IrlsResult)));
+    IRLS_TRY(hipMalloc(&S->ctl, sizeof(IrlsCtl<T>)));
+    IRLS_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->done_host), 64, hipHostMallocDefault));
     IRLS_TRY(hipMemsetAsync(S->Qt, 0, (size_t)n * ldm * sizeof(T), ctx->stream));
     IRLS_TRY(hipMemsetAsync(S->vec, 0, (5 * (size_t)n + 2 * (size_t)ldm) * sizeof(T), ctx->stream));
     T* At = static_cast<T*>(ctx->At);
@@ -375,10 +729,58 @@ hipError_t irls_solve(ss_hip_ctx* ctx, T tol, uint32_t max_iter, IrlsResult* res
 {
     IrlsState<T>* S = state_of<T>(ctx);
     hipError_t e;
-    hipLaunchKernelGGL((k_irls_solve<T>), dim3(1), dim3(kIrlsThreads), 0, ctx->stream, (const T*)S->Qt, (const T*)S->R,
-                       (const T*)S->G0, S->L, S->vec, ctx->ldm, (uint32_t)ctx->m, (uint32_t)ctx->n, tol, max_iter, S->res);
+    const uint32_t n = (uint32_t)ctx->n, m = (uint32_t)ctx->m, ldm = ctx->ldm;
+    hipStream_t st = ctx->stream;
+    // (the solve kernels keep one vector of n elements in LDS)
+    const size_t vec_lds = (size_t)n * sizeof(T);
+    if (n < kIrlsBlockedMin || vec_lds > 96 * 1024 || std::getenv("SS_HIP_IRLS_FUSED")) {
+        hipLaunchKernelGGL((k_irls_solve<T>), dim3(1), dim3(kIrlsThreads), 0, st, (const T*)S->Qt, (const T*)S->R,
+                           (const T*)S->G0, S->L, S->vec, ldm, m, n, tol, max_iter, S->res);
+        IRLS_TRY(hipGetLastError());
+        IRLS_TRY(hipMemcpyAsync(res_host, S->res, sizeof(IrlsResult), hipMemcpyDeviceToHost, st));
+        return hipSuccess;
+    }
+    static const bool attr_ok = [] {
+        const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_irls_chol_solve<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+        const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_irls_tail<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+        if (!(a && b)) (void)hipGetLastError();
+        return a && b;
+    }();
+    if (!attr_ok) return hipErrorInvalidConfiguration;
+    IrlsCtl<T>* ctl = static_cast<IrlsCtl<T>*>(S->ctl);
+    T* vec = S->vec;
+    T* qTb = vec;
+    T* s = vec + n;
+    T* xnext = vec + 2 * (size_t)n;
+    T* w = vec + 3 * (size_t)n;
+    T* t = vec + 5 * (size_t)n;
+    const T* y = t + ldm;
+    hipLaunchKernelGGL((k_irls_init<T>), dim3((n + 255) / 256), dim3(256), 0, st, vec, n, ctl);
+    hipLaunchKernelGGL((k_irls_qt_vec<T>), dim3((n + 3) / 4), dim3(256), 0, st, (const T*)S->Qt, ldm, m, n, y, qTb, (const IrlsCtl<T>*)nullptr);
     IRLS_TRY(hipGetLastError());
-    IRLS_TRY(hipMemcpyAsync(res_host, S->res, sizeof(IrlsResult), hipMemcpyDeviceToHost, ctx->stream));
+    for (uint32_t it = 0; it < max_iter; ++it) {
+        hipLaunchKernelGGL((k_irls_scale<T>), dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, (const T*)S->G0, (const T*)w, S->L, n, (const IrlsCtl<T>*)ctl);
+        for (uint32_t k0 = 0; k0 < n; k0 += kChB) {
+            hipLaunchKernelGGL((k_chol_diag<T>), dim3(1), dim3(64), 0, st, S->L, n, k0, ctl);
+            if (k0 + kChB < n) {
+                const uint32_t below = n - (k0 + kChB);
+                hipLaunchKernelGGL((k_chol_below<T>), dim3((below + 255) / 256), dim3(256), 0, st, S->L, n, k0, (const IrlsCtl<T>*)ctl);
+                const uint32_t T_ = (below + kChB - 1) / kChB;
+                hipLaunchKernelGGL((k_chol_trail<T>), dim3(T_ * (T_ + 1) / 2), dim3(256), 0, st, S->L, n, k0, (const IrlsCtl<T>*)ctl);
+            }
+        }
+        hipLaunchKernelGGL((k_irls_chol_solve<T>), dim3(1), dim3(kIrlsThreads), vec_lds, st, (const T*)S->L, n, vec, ctl);
+        hipLaunchKernelGGL((k_irls_q_vec<T>), dim3((m + 255) / 256), dim3(256), 0, st, (const T*)S->Qt, ldm, m, n, (const T*)s, t, (const IrlsCtl<T>*)ctl);
+        hipLaunchKernelGGL((k_irls_qt_vec<T>), dim3((n + 3) / 4), dim3(256), 0, st, (const T*)S->Qt, ldm, m, n, (const T*)t, xnext, (const IrlsCtl<T>*)ctl);
+        hipLaunchKernelGGL((k_irls_tail<T>), dim3(1), dim3(kIrlsThreads), vec_lds, st, (const T*)S->R, n, vec, tol, max_iter, ctl);
+        IRLS_TRY(hipGetLastError());
+        IRLS_TRY(hipMemcpyAsync(S->done_host, &ctl->done, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        IRLS_TRY(hipStreamSynchronize(st));
+        if (*S->done_host != 0u) break;
+    }
+    hipLaunchKernelGGL((k_irls_finish<T>), dim3(1), dim3(kIrlsThreads), 0, st, vec, n, (const IrlsCtl<T>*)ctl, S->res);
+    IRLS_TRY(hipGetLastError());
+    IRLS_TRY(hipMemcpyAsync(res_host, S->res, sizeof(IrlsResult), hipMemcpyDeviceToHost, st));
     return hipSuccess;
 #undef IRLS_TRY
 }
@@ -390,7 +792,8 @@ template <typename T>
 static void free_state(IrlsState<T>* S)
 {
     if (!S) return;
-    void* ptrs[] = { S->Vt, S->Qt, S->R, S->G0, S->L, S->rdiag, S->vec, S->res };
+    void* ptrs[] = { S->Vt, S->Qt, S->R, S->G0, S->L, S->rdiag, S->vec, S->res, S->ctl };
+    if (S->done_host) (void)hipHostFree(S->done_host);
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete S;
