@@ -138,6 +138,52 @@ void k_qr_formq(const T* __restrict__ Vt, T* __restrict__ Qt, uint32_t ldm, uint
     for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) qc[i] += s * v[i];
 }
 
+
+// The reflectors k0 .. k0 + nb - 1 of a factored panel applied, in order, to one trailing column per workgroup: the same
+// statements as k_qr_step's (the reflector read from Vt, where k_qr_step's workgroup 0 left exactly the values the other
+// workgroups form for themselves), so a column receives the same arithmetic in the same order — one launch per panel
+// instead of one per reflector.
+template <typename T>
+__global__ __launch_bounds__(kQrThreads)
+void k_qr_apply_panel(T* __restrict__ At, const T* __restrict__ Vt, uint32_t ldm, uint32_t m, uint32_t k0, uint32_t nb)
+{
+    __shared__ T sv[16];
+    T* a = At + (size_t)(k0 + nb + blockIdx.x) * ldm;
+    for (uint32_t k = k0; k < k0 + nb; ++k) {
+        const T* v = Vt + (size_t)k * ldm;
+        const T vk = v[k];
+        if (vk == T(0)) continue;                               // (a zero pivot column: k_qr_step leaves the others alone)
+        T part = T(0);
+        for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) part += v[i] * a[i];
+        const T s = block_sum(part, sv) / -vk;
+        for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) a[i] += v[i] * s;
+        __syncthreads();
+    }
+}
+
+// Back-accumulation of the thin Q, all steps of one column in one workgroup: column j of Q starts as e_j at step j and then
+// receives the reflectors j, j - 1, ... 0 — independent of every other column (k_qr_formq's statements, its order).
+template <typename T>
+__global__ __launch_bounds__(kQrThreads)
+void k_qr_formq_all(const T* __restrict__ Vt, T* __restrict__ Qt, uint32_t ldm, uint32_t m)
+{
+    __shared__ T sv[16];
+    const uint32_t j = blockIdx.x;
+    T* qc = Qt + (size_t)j * ldm;
+    for (uint32_t i = threadIdx.x; i < ldm; i += kQrThreads) qc[i] = (i == j) ? T(1) : T(0);
+    __syncthreads();
+    for (uint32_t kk = j + 1; kk-- > 0;) {
+        const T* v = Vt + (size_t)kk * ldm;
+        const T vk = v[kk];
+        if (vk == T(0)) continue;
+        T part = T(0);
+        for (uint32_t i = kk + threadIdx.x; i < m; i += kQrThreads) part += v[i] * qc[i];
+        const T s = -block_sum(part, sv) / vk;
+        for (uint32_t i = kk + threadIdx.x; i < m; i += kQrThreads) qc[i] += s * v[i];
+        __syncthreads();
+    }
+}
+
 // R (qr_decomposition.h:174-190) and the lower triangle of Q^T Q; workgroup i does row i
 template <typename T>
 __global__ __launch_bounds__(kQrThreads)
@@ -708,12 +754,33 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
     IRLS_TRY(hipMemsetAsync(S->Qt, 0, (size_t)n * ldm * sizeof(T), ctx->stream));
     IRLS_TRY(hipMemsetAsync(S->vec, 0, (5 * (size_t)n + 2 * (size_t)ldm) * sizeof(T), ctx->stream));
     T* At = static_cast<T*>(ctx->At);
-    for (uint32_t k = 0; k < n; ++k) {
-        hipLaunchKernelGGL((k_qr_step<T>), dim3(n - k), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k);
-        IRLS_TRY(hipGetLastError());
-    }
-    for (uint32_t kk = n; kk-- > 0;) {
-        hipLaunchKernelGGL((k_qr_formq<T>), dim3(n - kk), dim3(kQrThreads), 0, ctx->stream, (const T*)S->Vt, S->Qt, ldm, m, kk);
+    if (std::getenv("SS_HIP_IRLS_FUSED")) {
+        // (A/B aid: the round-2 form — every reflector a launch over all trailing columns)
+        for (uint32_t k = 0; k < n; ++k) {
+            hipLaunchKernelGGL((k_qr_step<T>), dim3(n - k), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k);
+            IRLS_TRY(hipGetLastError());
+        }
+        for (uint32_t kk = n; kk-- > 0;) {
+            hipLaunchKernelGGL((k_qr_formq<T>), dim3(n - kk), dim3(kQrThreads), 0, ctx->stream, (const T*)S->Vt, S->Qt, ldm, m, kk);
+            IRLS_TRY(hipGetLastError());
+        }
+    } else {
+        // By panels of 32 columns: the panel's own columns step by step (launches of <= 32 workgroups), then its 32 reflectors
+        // applied to every trailing column in ONE launch; Q's columns are independent of each other: one launch for all of them.
+        // Same arithmetic per column, in the same order: the same bits as the round-2 form.
+        constexpr uint32_t NBQ = 32;
+        for (uint32_t k0 = 0; k0 < n; k0 += NBQ) {
+            const uint32_t nb = std::min<uint32_t>(NBQ, n - k0);
+            for (uint32_t k = k0; k < k0 + nb; ++k) {
+                hipLaunchKernelGGL((k_qr_step<T>), dim3(k0 + nb - k), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k);
+                IRLS_TRY(hipGetLastError());
+            }
+            if (k0 + nb < n) {
+                hipLaunchKernelGGL((k_qr_apply_panel<T>), dim3(n - (k0 + nb)), dim3(kQrThreads), 0, ctx->stream, At, (const T*)S->Vt, ldm, m, k0, nb);
+                IRLS_TRY(hipGetLastError());
+            }
+        }
+        hipLaunchKernelGGL((k_qr_formq_all<T>), dim3(n), dim3(kQrThreads), 0, ctx->stream, (const T*)S->Vt, S->Qt, ldm, m);
         IRLS_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL((k_irls_setup<T>), dim3(n), dim3(kQrThreads), 0, ctx->stream, (const T*)At, (const T*)S->Qt,
