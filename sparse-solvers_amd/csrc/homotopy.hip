@@ -827,6 +827,10 @@ inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, u
         HIPCHK(hipMalloc(&ctx->sub_buf, need));
         ctx->sub_buf_bytes = need;
     }
+    if (ctx->sub_dbg == nullptr && std::getenv("SS_HIP_SUB_STAMPS")) {
+        HIPCHK(hipMalloc(&ctx->sub_dbg, 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(ctx->sub_dbg, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    }
     return launch_screen_form(ctx, ws, tol, max_iter, nullptr, nullptr, e2, e3);
 }
 inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
@@ -1267,6 +1271,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
         }
         if ((scr1 || scr64) && hs.status == 0) ctx->stats.screen_signals += 1;
+        if (scr1 && ctx->sub_dbg != nullptr) {
+            unsigned long long tp[9];
+            HIPCHK(hipMemcpy(tp, ctx->sub_dbg, sizeof(tp), hipMemcpyDeviceToHost));
+            const double r = tp[8] ? (double)tp[8] : 1.0;
+            std::fprintf(stderr, "[k_sub_solve, cycles per round over %llu rounds] chain %.0f  max|c| %.0f  log+scan %.0f  arg-min %.0f  hand-shake+x %.0f  u1/u2 %.0f  "
+                                 "inverse+signs %.0f  direction %.0f\n", tp[8], tp[0] / r, tp[1] / r, tp[2] / r, tp[3] / r, tp[4] / r, tp[5] / r, tp[6] / r, tp[7] / r);
+        }
         if (sub1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
             ctx->stats.subset_redone += 1;
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
@@ -2329,6 +2340,7 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     if (ctx->gram_full) (void)hipFree(ctx->gram_full);
     if (ctx->c0_batch) (void)hipFree(ctx->c0_batch);
     if (ctx->sub_buf) (void)hipFree(ctx->sub_buf);
+    if (ctx->sub_dbg) (void)hipFree(ctx->sub_dbg);
     sship::screen_free(ctx);
     if (ctx->ev_sub_sel) (void)hipEventDestroy(ctx->ev_sub_sel);
     if (ctx->ev_c0a) (void)hipEventDestroy(ctx->ev_c0a);

@@ -433,14 +433,20 @@ __host__ __device__ inline size_t sub_lds_bytes()
 }
 
 
+template <bool STAMPS>
 __global__ __launch_bounds__(kSbS)
 void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __restrict__ c0_all, uint32_t n, uint32_t n_pad,
                  const uint32_t* __restrict__ sub_all, const uint32_t* __restrict__ first_pick,
                  float tol, uint32_t max_iter, int strict_sign, int zero_on_removal, int tie_guard, int tie_exit,
                  uint32_t* __restrict__ log_hdr, uint32_t* __restrict__ log_pcol, float* __restrict__ log_X, float* __restrict__ log_D,
                  float* __restrict__ x_all, uint32_t* __restrict__ gam2_all, uint32_t* __restrict__ touched2_all, uint32_t kcap,
-                 DevState* __restrict__ st_all, TraceEntry* trace, uint32_t trace_cap, int gsub, uint32_t g_slot_stride)
+                 DevState* __restrict__ st_all, TraceEntry* trace, uint32_t trace_cap, int gsub, uint32_t g_slot_stride, unsigned long long* dbg)
 {
+    // dbg (developer aid, SS_HIP_SUB_STAMPS): cycles of slot 0 by phase, summed over the rounds: [0] chain, [1] max |c|, [2] log + scan,
+    // [3] arg-min, [4] hand-shake + x update, [5] u1 / u2, [6] inverse update + signs, [7] direction, [8] rounds
+    unsigned long long tph[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long tlast = 0;
+#define SUB_STAMP(P) if constexpr (STAMPS) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[P] += now_ - tlast; tlast = now_; }
     // gsub != 0 (screened form of one signal, screen.hip): G is the subset's own Gram matrix Gs[kSbS][gpitch], rows and
     // columns by subset index, instead of the full G = A^T A
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -549,6 +555,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
             // (the round's hand-shake words — whose column was picked, a tie seen — are cleared here: the reductions' barriers lie
             // between this and their writers, the previous round's readers are many barriers back)
             if (j == 0) { s_u[1] = 0xffffffffu; s_u[2] = 0u; s_u[3] = 0u; }
+            if constexpr (STAMPS) tlast = __builtin_readcyclecounter();
             // ---- c, q of my column: the chain over the positions -----------------------------------------------
             float cv = c0v, qv = 0.f;
             for (uint32_t p = 0; p < P; p += 4) {                     // (whole groups of 4: positions >= P carry x = d = 0 and zero rows)
@@ -561,10 +568,12 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 }
             }
             L.cs[j] = cv; L.qs[j] = qv;
+            SUB_STAMP(0)
             float mx = valid ? fabsf(cv) : -1.f;
             uint32_t mxi = mycol;
             block_reduce_pair<float, true>(mx, mxi, sv, si);
             c_inf = mx;
+            SUB_STAMP(1)
             // ---- loop control (homotopy-cpu.cpp:236, 272) ---------------------------------------------------------
             const bool stop = (round > 1 && !(c_inf > tol)) || round > max_iter;
             if (nlog >= kSbLog) { status = kStatusSubsetDecline; break; }
@@ -599,11 +608,13 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                     }
                 }
             }
+            SUB_STAMP(2)
             if (tie) s_u[3] = 1u;                                    // (read behind the reduction's two barriers)
             float g = m;
             uint32_t idx = valid ? mycol : 0xffffffffu;
             block_reduce_pair<float, false>(g, idx, sv, si);
             tie_any = s_u[3] != 0u || tie_any;
+            SUB_STAMP(3)
             if (tie_any && tie_exit) { status = kStatusTieRerun; iter = round - 1; ++nlog; break; }
             if (!(g < Lim<float>::max())) { status = kStatusSubsetDecline; break; }     // (no positive candidate: the reference toggles column 0)
             // whose column is it, and is it in the support?
@@ -634,6 +645,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 if (j == 0) { L.pcol[P] = idx; L.psub[P] = spi; L.xs[P] = 0.f; }
             }
             __syncthreads();
+            SUB_STAMP(4)
             if (!added) {
                 // the column leaves: in reference mode it keeps its rounding residue (and stays in c through it): not this form's path
                 const float res = L.xs[rpos];
@@ -666,6 +678,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 __syncthreads();
                 if (j < P) L.u2[j] = row_dot(&L.I[j * kSbInvPitch], L.u1);
                 __syncthreads();
+                SUB_STAMP(5)
                 // (every thread walks the same chain u1 . u2 — the value thread 0 alone used to publish through another barrier)
                 const float dv = 1.f / (L.Gc[(size_t)P * kSbS + spi] - row_dot(L.u1, L.u2));
                 const uint32_t Pn = P + 1u;
@@ -695,9 +708,12 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 just_removed = 0xffffffffu;
             }
             __syncthreads();
+            SUB_STAMP(6)
             // ---- the direction from those signs
             direction();
             __syncthreads();
+            SUB_STAMP(7)
+            if constexpr (STAMPS) tph[8] += 1;
             iter = round;
             lambda_prev = c_inf;
             gamma_prev = g;
@@ -744,6 +760,11 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
         st->need_sweep = 0;                    // (k_sub_verify raises it when a breakpoint does not hold)
         st->done_round = iter + 1u;
     }
+    if constexpr (STAMPS) {
+        if (dbg != nullptr && slot == 0u && j == 0u)
+            for (int q = 0; q < 9; ++q) dbg[q] = tph[q];
+    }
+#undef SUB_STAMP
 }
 
 // ---- k_sub_verify: every column outside the subset against every logged breakpoint -----------------------------
@@ -905,7 +926,7 @@ __global__ void k_sub_finish(DevState* __restrict__ st_all, uint32_t nslots)
 bool sub_form_usable(ss_hip_ctx* ctx)
 {
     if (ctx->sub_attr_set < 0) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sub_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sub_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)sub_lds_bytes());
         if (e != hipSuccess) (void)hipGetLastError();
         ctx->sub_attr_set = e == hipSuccess ? 1 : 0;
@@ -956,10 +977,19 @@ hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32
 hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs& B, uint32_t nslots, const float* G, uint32_t gpitch, int gsub,
                             const float* c0, float tol, uint32_t max_iter, uint32_t g_slot_stride)
 {
-    hipLaunchKernelGGL(k_sub_solve, dim3(nslots), dim3(kSbS), sub_lds_bytes(), ctx->stream, G, gpitch, c0, (uint32_t)ctx->n,
+    if (ctx->sub_dbg != nullptr) {
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sub_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sub_lds_bytes()) == hipSuccess;
+        if (ok)
+            hipLaunchKernelGGL(k_sub_solve<true>, dim3(nslots), dim3(kSbS), sub_lds_bytes(), ctx->stream, G, gpitch, c0, (uint32_t)ctx->n,
+                               ctx->n_pad, (const uint32_t*)B.sub, (const uint32_t*)B.fpick, tol, max_iter, ctx->strict_sign, ctx->zero_on_removal,
+                               ctx->tie_guard, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0, B.hdr, B.pcol, B.LX, B.LD, ws.x, ws.gam, ws.touched,
+                               ws.dims.kcap, ws.st, ws.trace, ws.trace_cap, gsub, g_slot_stride, static_cast<unsigned long long*>(ctx->sub_dbg));
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_sub_solve<false>, dim3(nslots), dim3(kSbS), sub_lds_bytes(), ctx->stream, G, gpitch, c0, (uint32_t)ctx->n,
                        ctx->n_pad, (const uint32_t*)B.sub, (const uint32_t*)B.fpick, tol, max_iter, ctx->strict_sign, ctx->zero_on_removal,
                        ctx->tie_guard, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0, B.hdr, B.pcol, B.LX, B.LD, ws.x, ws.gam, ws.touched,
-                       ws.dims.kcap, ws.st, ws.trace, ws.trace_cap, gsub, g_slot_stride);
+                       ws.dims.kcap, ws.st, ws.trace, ws.trace_cap, gsub, g_slot_stride, static_cast<unsigned long long*>(ctx->sub_dbg));
     return hipGetLastError();
 }
 
