@@ -411,6 +411,28 @@ void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, ui
     for (uint32_t p = want + t; p < nsel; p += kSel1Threads) sub[p] = 0xffffffffu;
 }
 
+// block_reduce_pair with ONE barrier: the caller gives every use in a round a scratch pair of its own, so no barrier has to
+// protect the previous use's readers (the next write to the same pair is a whole round of barriers away).  Same comparisons in
+// the same order: the same result.
+template <typename T, bool MAX>
+__device__ __forceinline__ void block_reduce_pair_1b(T& v, uint32_t& i, T* sv, uint32_t* si)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    wave_reduce_pair<T, MAX>(v, i);
+    if (lane == 0) { sv[wave] = v; si[wave] = i; }
+    __syncthreads();
+    T bv = sv[0];
+    uint32_t bi = si[0];
+    for (int w = 1; w < nw; ++w) {
+        const T ov = sv[w];
+        const uint32_t oi = si[w];
+        const bool take = MAX ? better_max(ov, oi, bv, bi) : better_min(ov, oi, bv, bi);
+        if (take) { bv = ov; bi = oi; }
+    }
+    v = bv;
+    i = bi;
+}
+
 // ---- k_sub_solve: the whole path of one signal on its subset -----------------------------------------------------
 struct SubLds {
     float* Gc;         // [kSbRows][kSbS]  Gram rows of the positions, restricted to the subset
@@ -452,6 +474,8 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float sv[16];
     __shared__ uint32_t si[16];
+    __shared__ float sv2[16];
+    __shared__ uint32_t si2[16];
     __shared__ uint32_t s_u[4];
     __shared__ float s_f[2];
     SubLds L;
@@ -571,7 +595,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
             SUB_STAMP(0)
             float mx = valid ? fabsf(cv) : -1.f;
             uint32_t mxi = mycol;
-            block_reduce_pair<float, true>(mx, mxi, sv, si);
+            block_reduce_pair_1b<float, true>(mx, mxi, sv, si);
             c_inf = mx;
             SUB_STAMP(1)
             // ---- loop control (homotopy-cpu.cpp:236, 272) ---------------------------------------------------------
@@ -609,10 +633,10 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 }
             }
             SUB_STAMP(2)
-            if (tie) s_u[3] = 1u;                                    // (read behind the reduction's two barriers)
+            if (tie) s_u[3] = 1u;                                    // (read behind the reduction's barrier)
             float g = m;
             uint32_t idx = valid ? mycol : 0xffffffffu;
-            block_reduce_pair<float, false>(g, idx, sv, si);
+            block_reduce_pair_1b<float, false>(g, idx, sv2, si2);
             tie_any = s_u[3] != 0u || tie_any;
             SUB_STAMP(3)
             if (tie_any && tie_exit) { status = kStatusTieRerun; iter = round - 1; ++nlog; break; }
