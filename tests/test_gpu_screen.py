@@ -350,3 +350,39 @@ def test_screened_batch_form(sship, B):
         xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 200)
         assert_parity(X[b], int(its[b]), float(errs[b]), xo, ito, eo, np.float32)
         assert np.array_equal(significant_support(X[b], 1e-4), sups[b])
+
+
+@pytest.mark.parametrize("B", [3, 9])
+def test_screened_form_compact_records_and_strides(sship, B):
+    """The compact records {K, iter, err, idx, val} and strided host vectors through the screened forms (B = 3: one screened
+    solve per signal; B = 9: the screened batch form) carry what the dense solves return."""
+    import sharding
+    m, n, k = 1024, 8192, 10
+    rng = np.random.default_rng(9700 + B)
+    A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(np.float32)
+    Y = np.empty((B, m), np.float32)
+    for b in range(B):
+        sup = np.sort(rng.choice(n, k, replace=False))
+        x0 = np.zeros(n)
+        x0[sup] = 1.0 + np.abs(rng.standard_normal(k))
+        Y[b] = (A.astype(np.float64) @ x0).astype(np.float32)
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.reset_stats()
+        rec = h.solve_batch_compact(Y, 1e-3, 100, kmax=32)
+        st = h.stats()
+        X, its, errs = h.solve_batch(Y, 1e-3, 100)
+        # a strided signal and a strided solution vector through the single-signal screened form
+        ybig = np.zeros(2 * m, np.float32)
+        ybig[::2] = Y[0]
+        xbig = np.full(3 * n, -7.0, np.float32)
+        h.solve(ybig[::2], 1e-3, 100, out=xbig[::3])
+    assert st["screen_signals"] == B
+    recs = sharding.unpack_records(rec, 32, np.float32)
+    for b in range(B):
+        r = recs[b]
+        nz = np.nonzero(X[b])[0]
+        assert r["K"] == len(nz) and r["iter"] == its[b] and r["err"] == errs[b]
+        assert np.array_equal(r["idx"][:r["K"]], nz) and np.array_equal(r["val"][:r["K"]], X[b][nz])
+    assert np.array_equal(xbig[::3], X[0]) or np.abs(xbig[::3] - X[0]).max() <= 1e-5 * np.abs(X[0]).max()
+    assert np.all(xbig[1::3] == -7.0) and np.all(xbig[2::3] == -7.0)
