@@ -1879,6 +1879,8 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             if (scr_chunk) {
                 ctx->stats.screen_signals += Bc - n_redo_chunk - (uint32_t)ties.size();
                 ctx->stats.screen_redone += n_redo_chunk;
+                // (a context whose signals the form mostly hands back — dense supports — goes the other way for the next 8 batches)
+                if (Bc >= 8 && 3u * n_redo_chunk > Bc) ctx->sub_off_chunks = 8;
             }
             ctx->stats.batch_rounds += rounds_run;
             if (ncq != 0) {
@@ -2007,7 +2009,10 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
     // screened form for the batches in between (4 .. batch_gram_min - 1 signals, no G; option batch_screen): c0 of a chunk by the
     // batch GEMM, every signal solved by one workgroup on its subset's own Gram matrix, one screening launch per chunk of 64
     if (form == 0 && !ctx->gram_full && ctx->batch_screen && ctx->engine >= 1 && B >= 4 && ctx->la_fused >= 3 && ctx->early_solo &&
-        ctx->solo_subset == 256 && ctx->sub_off_chunks == 0 && !ctx->tracing && screen_form_usable(ctx)) form = 3;
+        ctx->solo_subset == 256 && !ctx->tracing && screen_form_usable(ctx)) {
+        if (ctx->sub_off_chunks > 0) ctx->sub_off_chunks -= 1;      // (it handed back too much lately)
+        else form = 3;
+    }
     // column form for the batches in between (batch_cols_min .. batch_cols_max signals, no G): in lock-step, one pass
     // over A per round and 64 signals forms the Gram columns of the entering columns (half the flops of the two GEMMs
     // of form 0, and one pass serves 64 signals where a single solve spends three on one).  The cache holds one row
