@@ -359,7 +359,7 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    for bit by any implementation that states the same order.  One pass over A per iteration (2 GiB
  *                    at 8192 x 65536, 0.84 of the HBM peak); batches run up to 4 signals per pass; the arbiter of
  *                    "tie_rerun".
- *   "batch_screen"   1 (default) = fp32 batches of 4 .. batch_gram_min - 1 signals on a context without G = A^T A, on dictionaries
+ *   "batch_screen"   1 (default) = fp32 batches of at least 4 signals on a context without G = A^T A (see "batch_gram_min"), on dictionaries
  *                    the screened form applies to ("screen_single"), run in that form chunk by chunk (64 signals): c0 of the chunk
  *                    by the batch GEMM, every signal solved by one workgroup on its subset's own Gram matrix, one screening launch
  *                    over the fp16 copy of A for the whole chunk (four signals per workgroup); a signal it hands back is solved by
@@ -432,7 +432,9 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "batch_min"      smallest fp32 batch that takes the lock-step MFMA path (default 192: below
  *                    that, one lookahead solve per signal is faster)
  *   "batch_chunk"    signals processed together by the batched path (default 4096)
- *   "batch_gram_min" smallest lock-step batch that forms G = A^T A (n^2 fp32, 2 m n^2 flops once) and then
+ *   "batch_gram_min" (where the screened batch form applies — "batch_screen" — G pays later and is formed for a batch of at
+ *                    least max(batch_gram_min, 1536) signals, or once the context has received 3072 signals in batches)
+ *                    smallest lock-step batch that forms G = A^T A (n^2 fp32, 2 m n^2 flops once) and then
  *                    takes every signal's correlations from rows of G instead of two GEMMs per round
  *                    (default 512; once G exists every lock-step batch uses it; 0 = never)
  *   "batch_cols_min" / "batch_cols_max"  fp32 batches of at least batch_cols_min signals (default 24; max 0 = no upper

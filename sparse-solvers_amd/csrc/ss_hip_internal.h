@@ -261,6 +261,7 @@ struct ss_hip_ctx {
     int screen_single = 1;            // option: 1 = single fp32 signals on large dictionaries take the screened form (screen.hip), 2 = on every shape
                                       // the form can run on (tests), 0 = never
     int screen_failed_alloc = 0;      // the preparation did not fit: not tried again
+    uint64_t batch_signals_seen = 0;  // signals this context has received in batches (when G starts to pay: solve_batch_dispatch)
     void* sub_dbg = nullptr;          // developer aid (SS_HIP_SUB_STAMPS): 16 x u64 cycle stamps of k_sub_solve's phases (slot 0)
     int batch_screen = 1;             // option: 1 = fp32 batches of 4 .. batch_gram_min - 1 signals (no G) run in the screened form, 64 per chunk
     // state log of the launch-per-iteration form (k_la_iter; on in the sub-context of the fp64 screened form, screen.hip):
