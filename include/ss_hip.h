@@ -382,7 +382,7 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    2 = on every shape the form can run on (tests); 0 = never.  Initial value: environment variable
  *                    SS_HIP_SCREEN_SINGLE when set.  Stands in for the default speculative engine only ("la_fused" = 3,
  *                    "early_solo" = 1); with G = A^T A in HBM the subset form on G is used instead ("gram_single").
- *   "ro_slots"       1..4 (default 4): signals the reference-order engine runs in lock-step per pass over A (batches in
+ *   "ro_slots"       1..8 (default 8; fp64 contexts use at most 4): signals the reference-order engine runs in lock-step per pass over A (batches in
  *                    engine 3, a batch's tie re-runs); every signal's words are those of its own solve
  *   "ro_staged"      1 (default) = its sweep stages the dictionary through LDS (coalesced loads); 0 = direct 16-byte
  *                    loads (one signal per pass; the same bits at 0.35 of the HBM peak): A/B aid

@@ -1519,7 +1519,7 @@ int solve_batch_ro(ss_hip_ctx* ctx, const T* Y, const size_t* sig, size_t count,
         std::vector<DevState> hs;
         for (size_t j0 = 0; j0 < count; j0 += per) {
             const uint32_t R = (uint32_t)std::min(per, count - j0);
-            const uint32_t Rg = R <= 2 ? R : 4u;                  // the sweep carries 1, 2 or 4 slots: the workspace holds that many
+            const uint32_t Rg = R <= 2 ? R : (R <= 4 ? 4u : 8u);  // the sweep carries 1, 2, 4 or 8 slots: the workspace holds that many
             auto gidx = [&](uint32_t b) { return sig ? sig[j0 + b] : j0 + b; };
             ensure_workspace<T>(ctx, Rg, kcap);
             Workspace<T>& ws = *ws_of<T>(ctx);
@@ -2537,7 +2537,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "ro_force_resweep")) { ctx->ro_force_resweep = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "ro_staged"))     { ctx->ro_staged = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_subset"))  { ctx->batch_subset = value ? 1 : 0; return SS_HIP_OK; }
-    if (!std::strcmp(key, "ro_slots"))      { if (value < 1 || value > 4) return SS_HIP_EINVAL; ctx->ro_slots = (int)value; return SS_HIP_OK; }
+    if (!std::strcmp(key, "ro_slots"))      { if (value < 1 || value > 8) return SS_HIP_EINVAL; ctx->ro_slots = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_fused_scan")) { ctx->batch_fused_scan = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_vec4"))       { ctx->cq_vec4 = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "cq_cols"))       { ctx->cq_cols = (int)value; return SS_HIP_OK; }

@@ -587,7 +587,8 @@ void k_ro_check(const T* c, const T* pmax_val, const uint32_t* pmax_idx, uint32_
 
 // ---- launchers -----------------------------------------------------------------------------------------------
 // most slots one pass carries: 8 right-hand sides (with 16 the sweep's LDS reads and sums cost more than a second pass)
-template <typename T> constexpr uint32_t ro_max_slots() { return 4u; }
+// (fp32: 8 slots = 16 right-hand sides per pass — the stage's right-hand-side loaders are the 256 threads —, fp64: 4)
+template <typename T> constexpr uint32_t ro_max_slots() { return sizeof(T) == 4 ? 8u : 4u; }
 uint32_t ro_slots_max(const ss_hip_ctx* ctx, bool f64) { return ctx->ro_staged ? (f64 ? ro_max_slots<double>() : ro_max_slots<float>()) : 1u; }
 
 template <typename T, int NB, int NS>
@@ -622,8 +623,10 @@ hipError_t launch_ro_sweep(const ss_hip_ctx* ctx, const T* v, size_t blk_stride,
 #define SS_RO_CASE(NBV, NSV) e = ro_sweep_go<T, NBV, NSV>(ctx, grid, ngroups, v, blk_stride, out, out_blk, n_pad, pmax_val, pmax_idx, pmax_stride, st, gate)
         if (nblk == 1) {
             if (nslots == 1) SS_RO_CASE(1, 1); else if (nslots == 2) SS_RO_CASE(1, 2); else if (nslots <= 4) SS_RO_CASE(1, 4);
+            else if constexpr (sizeof(T) == 4) { if (nslots <= 8) SS_RO_CASE(1, 8); }
         } else {
             if (nslots == 1) SS_RO_CASE(2, 1); else if (nslots == 2) SS_RO_CASE(2, 2); else if (nslots <= 4) SS_RO_CASE(2, 4);
+            else if constexpr (sizeof(T) == 4) { if (nslots <= 8) SS_RO_CASE(2, 8); }
         }
 #undef SS_RO_CASE
         if (e == hipSuccess || nslots > 1) return e;

@@ -330,7 +330,7 @@ struct ss_hip_ctx {
     int zero_on_removal = 0; // 0 = the reference's x + gamma*d residue on a leaving column (homotopy-cpu.cpp:252); 1 = exact 0 (opt-in)
     int tie_guard = 0;       // 0 = the reference's strict t > 0 (homotopy-cpu.cpp:135,145,151); 1 = zero-length step on an exact tie (opt-in)
     int ro_staged = 1;        // option: 1 = the reference-order sweep stages the dictionary through LDS (coalesced loads), 0 = direct 16-byte loads
-    int ro_slots = 4;         // option: signals the reference-order engine runs in lock-step per pass over A (1..4)
+    int ro_slots = 8;         // option: signals the reference-order engine runs in lock-step per pass over A (1..8 in fp32, ..4 in fp64)
     int ro_force_resweep = 0; // developer option: the reference-order engine treats every sign check as failed (the second sweep of an iteration always runs)
     int tie_rerun = 1;       // 1 = a solve whose scan met a tie stall (DevState::tie_stall) is re-run in the reference-order engine
     int profiling = 0;

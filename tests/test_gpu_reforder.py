@@ -151,7 +151,7 @@ def test_one_pass_schedule_and_the_second_sweep(sship, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_lockstep_slots_bitwise(sship, dtype):
-    """Batches in engine 3 run in lock-step, up to 4 signals per pass over A (k_ro_sweep_t<NB, NS>): every
+    """Batches in engine 3 run in lock-step, up to 8 (fp32) / 4 (fp64) signals per pass over A (k_ro_sweep_t<NB, NS>): every
     signal's words are those of its own solve — the oracle's — whatever the others in its group do (different
     sparsities: they finish in different rounds; a group of one at the end), dense output and compact records alike."""
     import sharding
@@ -170,7 +170,7 @@ def test_lockstep_slots_bitwise(sship, dtype):
     want = [oracle.homotopy(A, Y[b], tol, 64) for b in range(B)]
     with sship.Homotopy(A) as h:
         h.set_option("engine", 3)
-        for slots in (4, 3, 1):
+        for slots in (8, 6, 5, 4, 3, 1):                      # (fp64 contexts carry at most 4 per pass whatever is asked)
             h.set_option("ro_slots", slots)
             X, it, err = h.solve_batch(Y, tol, 64)
             for b in range(B):
