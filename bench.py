@@ -6,10 +6,13 @@
 
 N = 1 — configs[1], the configuration the metric is quoted on: a step is ONE Homotopy solve of one signal
 (A 8192 x 65536 fp32, k = 64) with inputs resident in HBM; `value` = signals/s; `roofline` = the dominant HBM
-kernel (the 32-column lookahead sweep), timed live with HIP events on the solver's stream; `atr_gemv` = the
-plain A^T y sweep.  Outside the timed region the same run reports: configs[2] (a batch of 4096 signals
-sharing A, with the MFMA roofline of the G = A^T A build and the HBM roofline of the Gram-form pass),
-the drop-in surface timed with host arrays, OMP, configs[4] in fp64, and the CPU baseline (the reference's
+kernel — in the screened form (csrc/screen.hip, the default) the correlation GEMV c = A^T y itself —, timed live with
+HIP events on the solver's stream; `screening_pass` = the pass over the fp16 copy of A that certifies the path;
+`without_screening` / `lookahead_sweep_32rhs` = the engine behind it (three fp32 passes over A), outside the timed
+region.  Outside the timed region the same run also reports: configs[2] (a batch of 4096 signals
+sharing A, with the MFMA roofline of the G = A^T A build and the HBM roofline of the Gram-form pass), a 64-signal
+batch without G (screened batch form), the drop-in surface timed with host arrays, OMP, configs[4] in fp64
+(Homotopy and OMP, fp64 screened form), IRLS, and the CPU baseline (the reference's
 algorithm on the host cores, with a dlopen'd CBLAS and with the oracle's own loops) with full-solve parity.
 
 N > 1 — configs[3], the batched configuration north_star scales: signals are independent given A, so every
