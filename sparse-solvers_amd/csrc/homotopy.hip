@@ -817,7 +817,8 @@ inline hipError_t sub_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, u
 inline hipError_t sub_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t) { return hipErrorInvalidConfiguration; }
 
 // one signal in the screened form (screen.hip): no G — the subset's own Gram matrix from A, then one pass over the fp16 copy of A
-inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, hipEvent_t e2, hipEvent_t e3)
+inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, hipEvent_t e0, hipEvent_t e1,
+                             hipEvent_t e2, hipEvent_t e3)
 {
     const size_t need = sub_buffer_bytes(1);
     if (ctx->sub_buf_bytes < need) {
@@ -831,9 +832,9 @@ inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, u
         HIPCHK(hipMalloc(&ctx->sub_dbg, 16 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(ctx->sub_dbg, 0, 16 * sizeof(unsigned long long), ctx->stream));
     }
-    return launch_screen_form(ctx, ws, tol, max_iter, nullptr, nullptr, e2, e3);
+    return launch_screen_form(ctx, ws, tol, max_iter, first16, e0, e1, e2, e3);
 }
-inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
 // (typed shims of the fp64 screened form: never reached for float)
 inline hipError_t scr64_gather(ss_hip_ctx* ctx, const double* c0) { return screen64_gather(ctx, c0); }
 inline hipError_t scr64_gather(ss_hip_ctx*, const float*) { return hipErrorInvalidConfiguration; }
@@ -1042,17 +1043,22 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         } else if (sub1 || scr1) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y
+            // (the screened form's first pass — A^T y over all columns — reads the half-precision copy too: screen.hip, k_scr_first)
+            const bool first16 = scr1 && screen_first16_usable(ctx);
             uint32_t nb1 = 0;
-            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
-            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
-            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+            if (!first16) {
+                if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+                HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+                if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+            }
             if (sub1) {
                 HIPCHK(sub_single(ctx, ws, tol, max_iter));
             } else {
-                // (6 = the screening pass over the fp16 copy of A)
-                hipEvent_t e2 = nullptr, e3 = nullptr;
+                // (6 = a pass over the fp16 copy of A: the screening pass, and the first pass when it runs there)
+                hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+                if (prof && first16) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(6); ++nprof; }
                 if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); }
-                HIPCHK(scr_single(ctx, ws, tol, max_iter, e2, e3));
+                HIPCHK(scr_single(ctx, ws, tol, max_iter, first16, e0, e1, e2, e3));
                 if (prof) { ctx->prof_kind.push_back(6); ++nprof; }
             }
         } else if (la) {
@@ -2571,6 +2577,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "gram_symmetric")) { ctx->gram_symmetric = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { ctx->batch_chunk = (int)std::max<long>(4, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_single")) { ctx->screen_single = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_first16")) { ctx->screen_first16 = value != 0 ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_screen"))  { ctx->batch_screen = value ? 1 : 0; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
@@ -2645,6 +2652,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "gram_symmetric")) { *value = ctx->gram_symmetric; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { *value = ctx->batch_chunk; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_single")) { *value = ctx->screen_single; return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_first16")) { *value = ctx->screen_first16; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_screen"))  { *value = ctx->batch_screen; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }

@@ -63,6 +63,7 @@ constexpr uint32_t kScrRhs = 96;                 // right-hand sides of the scre
 constexpr uint32_t kScrCols = 128;               // dictionary columns per workgroup of the pass
 constexpr uint32_t kScrKc = 128;                 // rows per stage
 constexpr uint32_t kScrPitchB = kScrKc * 2 + 16; // bytes per LDS row: 272 (16-byte reads of 8 consecutive rows: conflict-free)
+constexpr uint32_t kScrMeta = 8;                 // floats of ScreenState::meta
 constexpr uint32_t kScrTab = 4;                  // floats per state in the table: 1 / (sA s_k), bound_k, 1 / s_k, spare
 constexpr uint32_t kSgSplit = 8;                 // row chunks of the subset Gram matrix (partials summed in order)
 constexpr uint32_t kSgT = 64;                    // its tile: 64 x 64 outputs per workgroup, a 32 x 32 quadrant per wave
@@ -79,6 +80,7 @@ struct ScreenState {
     __half* a16 = nullptr;       // [n_pad][ldm] fl16(sA * A), column-contiguous like A
     float* anorm = nullptr;      // [n_pad] ||a_i||_2, rounded up
     float* meta = nullptr;       // [0] sA  [1] 1 / sA  [2] bits(max |A|)  [3] headroom of the last solve (bits, as uint)
+                                 // [4] max ||a_i||  [5] ||y||^2 (k_scr_first)  [6] what the columns left out of the subset stay below (selection)
     __half* r16 = nullptr;       // [kScrRhs][ldm] fl16(s_k * r_k)
     float* rn2p = nullptr;       // [ldm / 64][kScrRhs] partial sums of ||r_k||^2, one per workgroup of k_scr_residuals
     float* tab = nullptr;        // [kScrRhs][kScrTab]
@@ -123,6 +125,7 @@ void k_a16_stats(const T* __restrict__ At, uint32_t ldm, float* __restrict__ ano
         mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
         anorm[blockIdx.x] = sqrtf(ss) * 1.0001f;                       // (rounded up: it scales an upper bound; fp64 sources: the cast's 2^-24 is inside)
         atomicMax(reinterpret_cast<uint32_t*>(meta) + 2, __float_as_uint(mx));
+        atomicMax(reinterpret_cast<uint32_t*>(meta) + 4, __float_as_uint(sqrtf(ss) * 1.0001f));      // (non-negative floats order like their bits)
     }
 }
 
@@ -147,6 +150,101 @@ void k_a16_convert(const T* __restrict__ At, size_t total8, const float* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) h[e] = (_Float16)(At[8u * i + (size_t)e] * sA);
         *reinterpret_cast<scr_h8*>(a16 + 8u * i) = h;
+    }
+}
+
+// ---- the FIRST pass in half precision: c~0 = A16^T y --------------------------------------------------------------
+// What the subset form needs from A^T y over ALL columns is a ranking (which 448 columns are worth solving on) and the same
+// question as every later state: does anything left out reach lambda_0?  Both are answered from the half-precision copy,
+// 1.07 GB instead of the 2.15 GB of the fp32 sweep: this kernel writes c~0 (fp16 A, fp32 y, fp32 sums), the selection ranks
+// |c~0| and reports a value T every column it left out stays below, k_sgram_sum forms the EXACT fp32 c0 of the chosen
+// columns beside the subset Gram matrix — lambda_0, the first pick and the whole path come from those — and
+// k_scr_residuals certifies state 0:   T + eps_0 <= 0.875 lambda_0 - slack,   eps_0 = 2^-9 max ||a_i|| ||y|| + the flush term
+// (|c~0 - c0| <= (2^-11 + ldm 2^-24) sum |a||y| <= 2^-9 ||a|| ||y|| for ldm <= 16384; entries below the fp16 normal range:
+// 2^-14 per entry in scaled units).  A signal whose state 0 is not certified goes back to the default engine like any other.
+// Layout: sweep.hip's — a wave owns CPW columns and streams them with 16-byte loads (8 rows per lane, 512 rows per step);
+// y sits in LDS, permuted so that the two 16-byte reads of a lane are conflict-free.  Every group of columns starts at a
+// row step of its own and wraps around (the sum's order is free here): the HBM channel phases of the 16-KiB-strided columns.
+template <int CPW, int DEPTH>
+__global__ __launch_bounds__(512, 2)
+void k_scr_first(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, uint32_t ngroups, const float* __restrict__ y,
+                 float* __restrict__ meta, float* __restrict__ c0h, uint32_t skew)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float sv[16];
+    float* ly = reinterpret_cast<float*>(smem);                  // [ldm]: rows 512 s + 8 l + 4 u + e  at  512 s + 256 u + 4 l + e
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float ss = 0.f;
+    for (uint32_t i = tid * 4u; i < ldm; i += 2048u) {
+        const scr_v4f v = *reinterpret_cast<const scr_v4f*>(y + i);
+        const uint32_t wq = i & 511u;
+        *reinterpret_cast<scr_v4f*>(&ly[(i & ~511u) + ((wq & 4u) << 6) + ((wq >> 3) << 2)]) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss = __builtin_fmaf(v[e], v[e], ss);
+    }
+    if (blockIdx.x == 0u) {
+        ss = block_sum(ss, sv);
+        if (tid == 0u) meta[5] = ss;
+    }
+    __syncthreads();
+    const float inv_sA = meta[1];
+    const uint32_t nsteps = ldm >> 9;
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint32_t col0 = g * (8u * CPW) + wave * CPW;
+        const char* cb[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) cb[c] = reinterpret_cast<const char*>(a16 + (size_t)(col0 + c) * ldm) + lane * 16u;
+        float acc[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) acc[c] = 0.f;
+        const uint32_t ts0 = (g * skew + wave) % nsteps;
+        scr_u4 a[DEPTH][CPW];
+#define F16_ROW(T) ((ts0 + (T)) >= nsteps ? (ts0 + (T)) - nsteps : (ts0 + (T)))
+#define F16_LOAD(STAGE, T)                                                                          \
+        {                                                                                           \
+            const uint32_t rr_ = F16_ROW(T);                                                        \
+            _Pragma("unroll") for (int c = 0; c < CPW; ++c)                                         \
+                a[STAGE][c] = __builtin_nontemporal_load(reinterpret_cast<const scr_u4*>(cb[c] + (size_t)rr_ * 1024u)); \
+        }
+#define F16_COMPUTE(STAGE, T)                                                                       \
+        {                                                                                           \
+            const uint32_t rr_ = F16_ROW(T);                                                        \
+            const scr_v4f y0_ = *reinterpret_cast<const scr_v4f*>(&ly[(rr_ << 9) + 4u * lane]);     \
+            const scr_v4f y1_ = *reinterpret_cast<const scr_v4f*>(&ly[(rr_ << 9) + 256u + 4u * lane]); \
+            _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                                       \
+                const scr_h8 h_ = __builtin_bit_cast(scr_h8, a[STAGE][c]);                          \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[c] = __builtin_fmaf((float)h_[e], y0_[e], acc[c]);     \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[c] = __builtin_fmaf((float)h_[4 + e], y1_[e], acc[c]); \
+            }                                                                                       \
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < DEPTH - 1; ++sidx)
+            if ((uint32_t)sidx < nsteps) F16_LOAD(sidx, (uint32_t)sidx)
+        uint32_t t = 0;
+        for (; t + (2 * DEPTH - 1) <= nsteps; t += DEPTH) {
+#pragma unroll
+            for (int sidx = 0; sidx < DEPTH; ++sidx) {
+                F16_LOAD((sidx + DEPTH - 1) % DEPTH, t + (uint32_t)(sidx + DEPTH - 1))
+                F16_COMPUTE(sidx, t + (uint32_t)sidx)
+            }
+        }
+        for (; t < nsteps; t += DEPTH) {
+#pragma unroll
+            for (int sidx = 0; sidx < DEPTH; ++sidx) {
+                if (t + (uint32_t)(sidx + DEPTH - 1) < nsteps) F16_LOAD((sidx + DEPTH - 1) % DEPTH, t + (uint32_t)(sidx + DEPTH - 1))
+                if (t + (uint32_t)sidx < nsteps) F16_COMPUTE(sidx, t + (uint32_t)sidx)
+            }
+        }
+#undef F16_COMPUTE
+#undef F16_LOAD
+#undef F16_ROW
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const float v = wave_sum(acc[c]) * inv_sA;
+            const uint32_t col = col0 + (uint32_t)c;
+            if (lane == 0u) c0h[col] = col < n ? v : 0.f;
+        }
     }
 }
 
@@ -225,8 +323,35 @@ void k_sgram_part(const float* __restrict__ At, uint32_t ldm, uint32_t n, const 
 }
 
 __global__ __launch_bounds__(256)
-void k_sgram_sum(const float* __restrict__ part, uint32_t nsplit, float* __restrict__ gs)
+void k_sgram_sum(const float* __restrict__ part, uint32_t nsplit, float* __restrict__ gs, const float* __restrict__ At, uint32_t ldm,
+                 const float* __restrict__ y, const uint32_t* __restrict__ sub, uint32_t n, float* __restrict__ c0)
 {
+    constexpr uint32_t NB = (kSbS * kSbS + 255u) / 256u;
+    if (blockIdx.x >= NB) {
+        // Workgroups beyond the sum (one signal whose first pass ran in half precision: k_scr_first): the EXACT fp32 c0 = a_j . y
+        // of one subset column each — the tiles have just read those columns — written where k_sub_solve reads it.  A thread owns
+        // the float4s 256 apart (8 loads in flight per round), the workgroup's sum in the fixed order of block_sum.
+        __shared__ float sv[16];
+        const uint32_t col = sub[blockIdx.x - NB];
+        const float* a = At + (size_t)(col < n ? col : 0u) * ldm;
+        float acc = 0.f;
+        for (uint32_t r0 = 4u * threadIdx.x; r0 < ldm; r0 += 8u * 1024u) {
+            scr_v4f av[8], yv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t r = r0 + 1024u * (uint32_t)q;
+                av[q] = r < ldm ? *reinterpret_cast<const scr_v4f*>(a + r) : scr_v4f{ 0.f, 0.f, 0.f, 0.f };
+                yv[q] = r < ldm ? *reinterpret_cast<const scr_v4f*>(y + r) : scr_v4f{ 0.f, 0.f, 0.f, 0.f };
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(av[q][e], yv[q][e], acc);
+        }
+        acc = block_sum(acc, sv);
+        if (threadIdx.x == 0u && col < n) c0[col] = acc;
+        return;
+    }
     part += (size_t)blockIdx.y * nsplit * kSbS * kSbS;           // (blockIdx.y = slot of a batch)
     gs += (size_t)blockIdx.y * kSbS * kSbS;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -253,7 +378,8 @@ __global__ __launch_bounds__(256)
 void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, const float* __restrict__ y,
                      const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pcol,
                      const float* __restrict__ LX, float tol, const float* __restrict__ meta, __half* __restrict__ r16,
-                     float* __restrict__ rn2p, float* __restrict__ tab, uint32_t* __restrict__ headroom, DevState* __restrict__ st)
+                     float* __restrict__ rn2p, float* __restrict__ tab, uint32_t* __restrict__ headroom, DevState* __restrict__ st,
+                     int first16)
 {
     __shared__ __attribute__((aligned(16))) float sAc[kSbRows][64];
     __shared__ __attribute__((aligned(16))) float sXt[kSbRows][kSbLog];
@@ -270,10 +396,25 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
         st += slot;
     }
     if (st->status != 0u) return;
-    const uint32_t nlog = st->solo_nlog;
-    if (nlog < 2u) return;
-    const uint32_t nst = nlog - 1u;
     const uint32_t tid = threadIdx.x;
+    float ratio0 = 0.f;
+    if (first16 && blockIdx.x == 0u && tid == 0u) {
+        // state 0 after a first pass in half precision (k_scr_first): every column left out of the subset has |c~0| < T, so
+        // |c0| < T + eps_0 — certified against lambda_0 (the subset's exact max |c0|) with the margin of every other state
+        const float lam0 = st->lambda0;
+        const float yn = sqrtf(meta[5]) * 1.001f;
+        const float eps0 = 0.0019726562f * yn * meta[4] + 6.103515625e-05f * sqrtf((float)ldm) * yn * meta[1];
+        const float bound0 = lam0 * 0.875f - 1e-5f * lam0;
+        const float v0 = meta[6] + eps0;
+        if (!(v0 <= bound0)) __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ratio0 = bound0 > 0.f && v0 == v0 ? v0 / bound0 : 3.0e38f;
+    }
+    const uint32_t nlog = st->solo_nlog;
+    if (nlog < 2u) {
+        if (blockIdx.x == 0u && tid == 0u && blockIdx.y == 0u) *headroom = __float_as_uint(ratio0);
+        return;
+    }
+    const uint32_t nst = nlog - 1u;
     const uint32_t r0 = blockIdx.x * 64u;
     const uint32_t Pfin = hdr[(nlog - 1u) * 8u];
     for (uint32_t e = tid; e < kSbLog * kSbRows; e += 256u) {
@@ -334,7 +475,7 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
     if (ovf) __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blockIdx.x == 0u) {
         const float lam0 = st->lambda0;
-        if (tid == 0u && blockIdx.y == 0u) *headroom = 0u;
+        if (tid == 0u && blockIdx.y == 0u) *headroom = __float_as_uint(ratio0);
         if (tid < nst) {
             const uint32_t* hh = hdr + (size_t)(tid + 1u) * 8u;
             const float lam = __uint_as_float(hh[4]);
@@ -947,7 +1088,7 @@ bool screen_form_usable(ss_hip_ctx* ctx)
     auto alloc = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; } };
     alloc(reinterpret_cast<void**>(&S->a16), (size_t)np * ldm * sizeof(__half));
     alloc(reinterpret_cast<void**>(&S->anorm), (size_t)np * sizeof(float));
-    alloc(reinterpret_cast<void**>(&S->meta), 4 * sizeof(float));
+    alloc(reinterpret_cast<void**>(&S->meta), kScrMeta * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->r16), (size_t)kScrRhs * ldm * sizeof(__half));
     alloc(reinterpret_cast<void**>(&S->rn2p), (size_t)(ldm / 64u) * kScrRhs * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->tab), (size_t)kScrRhs * kScrTab * sizeof(float));
@@ -961,7 +1102,7 @@ bool screen_form_usable(ss_hip_ctx* ctx)
     if (!ok) { screen_free(ctx); ctx->screen_failed_alloc = 1; return false; }
     hipStream_t s = ctx->stream;
     const float* At = static_cast<const float*>(ctx->At);
-    (void)hipMemsetAsync(S->meta, 0, 4 * sizeof(float), s);
+    (void)hipMemsetAsync(S->meta, 0, kScrMeta * sizeof(float), s);
     (void)hipMemsetAsync(S->r16, 0, (size_t)kScrRhs * ldm * sizeof(__half), s);
     hipLaunchKernelGGL((k_a16_stats<float>), dim3(np), dim3(256), 0, s, At, ldm, S->anorm, S->meta);
     hipLaunchKernelGGL(k_a16_scale, dim3(1), dim3(1), 0, s, S->meta);
@@ -972,9 +1113,18 @@ bool screen_form_usable(ss_hip_ctx* ctx)
     return true;
 }
 
-// c0 = A^T y is in ws.c0, r = y in ws.rhs (block 0); everything on the context's stream.  e0..e3 (profiling): before the
-// selection, before the residuals, before and after the screening pass.
-hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, hipEvent_t e0, hipEvent_t e1,
+// r = y in ws.rhs (block 0); c0 = A^T y in ws.c0 — or, first16, nothing yet: the first pass runs here, over the fp16 copy
+// (k_scr_first; ws.c0 then holds c~0 with the subset's entries exact).  Everything on the context's stream.  Profiling events:
+// e0, e1 around the half-precision first pass, e2, e3 around the screening pass.
+bool screen_first16_usable(const ss_hip_ctx* ctx) { return ctx->screen_first16 != 0 && ctx->ldm % 512u == 0u && ctx->ldm <= 15872u; }    // (y in LDS: 4 ldm bytes + the reduction scratch)
+
+static uint32_t scr_first_variant()
+{
+    static const uint32_t v = [] { const char* e = std::getenv("SS_HIP_SCR_FIRST"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    return v;
+}
+
+hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, hipEvent_t e0, hipEvent_t e1,
                               hipEvent_t e2, hipEvent_t e3)
 {
     ScreenState* S = scr_of(ctx);
@@ -983,17 +1133,29 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     hipStream_t s = ctx->stream;
     const uint32_t ldm = ctx->ldm, n = (uint32_t)ctx->n, np = ctx->n_pad;
     const float* At = static_cast<const float*>(ctx->At);
-    if (e0) (void)hipEventRecord(e0, s);
-    (void)launch_sub_select(ctx, B, 1, ws.c0);
     const uint32_t nsplit = (ldm % (kSgSplit * kSgStep) == 0) ? kSgSplit : 4u;        // (ldm is a multiple of 256)
     constexpr uint32_t NT = kSbS / kSgT;
+    if (first16) {
+        if (e0) (void)hipEventRecord(e0, s);
+        const uint32_t grid = std::min<uint32_t>(np / 32u, (uint32_t)ctx->num_cus * 2u);
+        const size_t lds = (size_t)ldm * sizeof(float);
+        const uint32_t skew = scr_skew() == 0u ? 0u : 5u;
+        switch (scr_first_variant()) {
+        case 1:  hipLaunchKernelGGL((k_scr_first<4, 2>), dim3(grid), dim3(512), lds, s, (const __half*)S->a16, ldm, n, np / 32u, (const float*)ws.rhs, S->meta, ws.c0, skew); break;
+        case 2:  hipLaunchKernelGGL((k_scr_first<4, 4>), dim3(grid), dim3(512), lds, s, (const __half*)S->a16, ldm, n, np / 32u, (const float*)ws.rhs, S->meta, ws.c0, skew); break;
+        case 3:  hipLaunchKernelGGL((k_scr_first<2, 4>), dim3(std::min<uint32_t>(np / 16u, (uint32_t)ctx->num_cus * 2u)), dim3(512), lds, s, (const __half*)S->a16, ldm, n, np / 16u, (const float*)ws.rhs, S->meta, ws.c0, skew); break;
+        default: hipLaunchKernelGGL((k_scr_first<4, 3>), dim3(grid), dim3(512), lds, s, (const __half*)S->a16, ldm, n, np / 32u, (const float*)ws.rhs, S->meta, ws.c0, skew); break;
+        }
+        if (e1) (void)hipEventRecord(e1, s);
+    }
+    (void)launch_sub_select(ctx, B, 1, ws.c0, first16 ? S->meta + 6 : nullptr);
     hipLaunchKernelGGL(k_sgram_part, dim3(NT * (NT + 1) / 2, nsplit), dim3(256), 0, s, At, ldm, n, (const uint32_t*)B.sub, ldm / nsplit, S->gs_part);
-    hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256), dim3(256), 0, s, (const float*)S->gs_part, nsplit, S->gs);
-    (void)launch_sub_solve(ctx, ws, B, 1, (const float*)S->gs, kSbS, 1, ws.c0, tol, max_iter);
-    if (e1) (void)hipEventRecord(e1, s);
+    hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256 + (first16 ? kSbS : 0u)), dim3(256), 0, s, (const float*)S->gs_part, nsplit, S->gs,
+                       At, ldm, (const float*)ws.rhs, (const uint32_t*)B.sub, n, ws.c0);
+    (void)launch_sub_solve(ctx, ws, B, 1, (const float*)S->gs, kSbS, first16 ? 2 : 1, ws.c0, tol, max_iter);
     hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs,
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
-                       (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st);
+                       (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, first16 ? 1 : 0);
     if (e2) (void)hipEventRecord(e2, s);
     hipLaunchKernelGGL(k_scr_gemm<3>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
                        (const float*)S->anorm, (const float*)S->rn2p, kScrRhs, (const float*)S->tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
@@ -1046,11 +1208,11 @@ hipError_t launch_screen_batch(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t n
     const uint32_t nsplit = (ldm % (kSgSplit * kSgStep) == 0) ? kSgSplit : 4u;
     constexpr uint32_t NT = kSbS / kSgT;
     hipLaunchKernelGGL(k_sgram_part, dim3(NT * (NT + 1) / 2, nsplit, nslots), dim3(256), 0, s, At, ldm, n, (const uint32_t*)B.sub, ldm / nsplit, S->b_gs_part);
-    hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256, nslots), dim3(256), 0, s, (const float*)S->b_gs_part, nsplit, S->b_gs);
+    hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256, nslots), dim3(256), 0, s, (const float*)S->b_gs_part, nsplit, S->b_gs, (const float*)nullptr, 0u, (const float*)nullptr, (const uint32_t*)nullptr, 0u, (float*)nullptr);
     (void)launch_sub_solve(ctx, ws, B, nslots, (const float*)S->b_gs, kSbS, 1, c0_all, tol, max_iter, kSbS * kSbS);
     hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u, nslots), dim3(256), 0, s, At, ldm, n, (const float*)ws.y,
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
-                       (const float*)S->meta, S->b_r16, S->b_rn2p, S->b_tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st);
+                       (const float*)S->meta, S->b_r16, S->b_rn2p, S->b_tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, 0);
     static const bool b_attr = [] {
         const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scr_gemm_b_lds()) == hipSuccess;
         if (!ok) (void)hipGetLastError();
@@ -1096,7 +1258,7 @@ bool screen64_usable(ss_hip_ctx* ctx)
     auto alloc = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; } };
     alloc(reinterpret_cast<void**>(&S->a16), (size_t)np * ldm * sizeof(__half));
     alloc(reinterpret_cast<void**>(&S->anorm), (size_t)np * sizeof(float));
-    alloc(reinterpret_cast<void**>(&S->meta), 4 * sizeof(float));
+    alloc(reinterpret_cast<void**>(&S->meta), kScrMeta * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->r16), (size_t)kS64Rhs * ldm * sizeof(__half));
     alloc(reinterpret_cast<void**>(&S->rn2p), (size_t)(ldm / 64u) * kS64Rhs * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->tab), (size_t)kS64Rhs * kScrTab * sizeof(float));
@@ -1132,7 +1294,7 @@ bool screen64_usable(ss_hip_ctx* ctx)
     if (!ok) { screen_free(ctx); ctx->screen_failed_alloc = 1; return false; }
     hipStream_t s = ctx->stream;
     const double* At = static_cast<const double*>(ctx->At);
-    (void)hipMemsetAsync(S->meta, 0, 4 * sizeof(float), s);
+    (void)hipMemsetAsync(S->meta, 0, kScrMeta * sizeof(float), s);
     (void)hipMemsetAsync(S->r16, 0, (size_t)kS64Rhs * ldm * sizeof(__half), s);
     hipLaunchKernelGGL((k_a16_stats<double>), dim3(np), dim3(256), 0, s, At, ldm, S->anorm, S->meta);
     hipLaunchKernelGGL(k_a16_scale, dim3(1), dim3(1), 0, s, S->meta);

@@ -258,6 +258,7 @@ struct ss_hip_ctx {
     hipEvent_t ev_c0a = nullptr, ev_c0b = nullptr;   // profiling: around the batch GEMM c0 = A^T y of a chunk
     int batch_subset = 1;             // option: 1 = large Gram-form batches run in the subset form (one workgroup per signal + a check over all columns)
     void* screen = nullptr;           // sship::ScreenState* (screen.hip): fp16 copy of A, column norms, the subset's Gram matrix, residual block
+    int screen_first16 = 1;           // option: the screened form's first pass (A^T y over all columns) reads the half-precision copy too
     int screen_single = 1;            // option: 1 = single fp32 signals on large dictionaries take the screened form (screen.hip), 2 = on every shape
                                       // the form can run on (tests), 0 = never
     int screen_failed_alloc = 0;      // the preparation did not fit: not tried again
@@ -421,7 +422,7 @@ size_t sub_buffer_bytes(uint32_t nslots);
 // the form's buffers inside ss_hip_ctx::sub_buf (sized by sub_buffer_bytes(nslots)) and its three stages on the context's stream
 struct SubBufs { uint32_t* sub; uint32_t* fpick; float* fval; uint32_t* hdr; uint32_t* pcol; float* LX; float* LD; };
 SubBufs sub_bufs(ss_hip_ctx* ctx, uint32_t nslots);
-hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0);
+hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0, float* thr_out = nullptr);
 hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs& B, uint32_t nslots, const float* G, uint32_t gpitch, int gsub,
                             const float* c0, float tol, uint32_t max_iter, uint32_t g_slot_stride = 0);
 hipError_t launch_sub_finish(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots);
@@ -429,8 +430,9 @@ hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32
 // screened form of ONE signal (screen.hip): the subset form on the subset's own Gram matrix (formed from A), every state of
 // the path then screened against all columns by one pass over a half-precision copy of A with a rigorous error bound
 bool screen_form_usable(ss_hip_ctx* ctx);                 // shape / option test + one-time preparation (fp16 copy of A, column norms)
-hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
-                              hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
+bool screen_first16_usable(const ss_hip_ctx* ctx);        // ... with the FIRST pass (A^T y) over the half-precision copy too
+hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, hipEvent_t e0 = nullptr,
+                              hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
 // a batch chunk of nslots <= screen_batch_cap() signals in the screened form: c0 = A^T y of every slot in c0_all ([nslots][n_pad]), the
 // signals in ws.y; the slots' verdicts in their states (k_sub_finish) like the subset form's
 uint32_t screen_batch_cap();

@@ -168,7 +168,7 @@ void k_sub_select(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint
 constexpr uint32_t kSel1Threads = 1024, kSel1J = 16;
 __global__ __launch_bounds__(kSel1Threads)
 void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ sub,
-                   uint32_t* __restrict__ first_pick, float* __restrict__ first_val)
+                   uint32_t* __restrict__ first_pick, float* __restrict__ first_val, float* __restrict__ thr_out)
 {
     constexpr uint32_t NW = kSel1Threads / 64u;
     __shared__ uint32_t hist[kSelBins];
@@ -252,6 +252,8 @@ void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uin
     }
     const uint32_t T22 = prefix_key;
     const uint32_t need_eq = want - above;
+    // (what every column left out stays below: the end of the threshold key's range — screen.hip's half-precision first pass)
+    if (thr_out != nullptr && t == 0) thr_out[0] = __uint_as_float(T22 + 1u >= (0x7f800000u >> 9) ? 0x7f800000u : (T22 + 1u) << 9);
     SEL1_WALK({ (void)val; const uint32_t k = m >> 9;
                 if (k > T22) atomicOr(&m_sel[i >> 5], 1u << (i & 31u));
                 else if (k == T22) atomicOr(&m_eq[i >> 5], 1u << (i & 31u)); })
@@ -284,7 +286,7 @@ void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uin
 constexpr uint32_t kSel1ECap = 1024, kSel1SCap = 2048;
 __global__ __launch_bounds__(kSel1Threads)
 void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ sub,
-                    uint32_t* __restrict__ first_pick, float* __restrict__ first_val, uint32_t nsel)
+                    uint32_t* __restrict__ first_pick, float* __restrict__ first_val, uint32_t nsel, float* __restrict__ thr_out)
 {
     // nsel <= kSel1SCap columns are selected (kSbS for the subset form; the fp64 screened form's sub-dictionary takes 2048)
     constexpr uint32_t NW = kSel1Threads / 64u;
@@ -360,6 +362,7 @@ void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, ui
     }
     const uint32_t T22 = prefix_key;
     const uint32_t need_eq = want - above;
+    if (thr_out != nullptr && t == 0) thr_out[0] = __uint_as_float(T22 + 1u >= (0x7f800000u >> 9) ? 0x7f800000u : (T22 + 1u) << 9);
     SEL1W_WALK({ (void)val; const uint32_t k = m >> 9;
                  if (k > T22) { const uint32_t p_ = atomicAdd(&s_ns, 1u); if (p_ < nsel) s_list[p_] = i; }
                  else if (k == T22) { const uint32_t p_ = atomicAdd(&s_ne, 1u); if (p_ < kSel1ECap) e_list[p_] = i; } })
@@ -509,7 +512,15 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
     for (uint32_t e = j; e < kSbRows * kSbInvPitch; e += kSbS) L.I[e] = 0.f;
     for (uint32_t p = 0; p < kSbRows; ++p) L.Gc[(size_t)p * kSbS + j] = 0.f;      // (rows not yet given out are read with zero coefficients)
     if (j < kSbRows) { L.xs[j] = 0.f; L.ds[j] = 0.f; L.u1[j] = 0.f; L.u2[j] = 0.f; L.sg[j] = 0.f; L.pcol[j] = 0xffffffffu; L.psub[j] = 0u; L.alive[j] = 0u; }
-    const uint32_t idx0 = first_pick[slot];
+    uint32_t idx0 = first_pick[slot];
+    if (gsub == 2) {
+        // (screen.hip's half-precision first pass ranked the columns by an APPROXIMATE A^T y; c0 of the subset's columns is exact:
+        // the first pick is the left-most largest of those — the screening pass vouches for every column outside)
+        float bv = valid ? fabsf(c0v) : -1.f;
+        uint32_t bi = valid ? mycol : 0xffffffffu;
+        block_reduce_pair<float, true>(bv, bi, sv, si);
+        idx0 = bi;
+    }
     if (j == 0) s_u[0] = 0xffffffffu;
     __syncthreads();
     if (valid && mycol == idx0) s_u[0] = j;
@@ -978,12 +989,13 @@ SubBufs sub_bufs(ss_hip_ctx* ctx, uint32_t nslots)
     return B;
 }
 
-hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0)
+hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0, float* thr_out)
 {
+    // (thr_out, one slot only: a value every column left out stays below)
     if (nslots == 1 && ctx->n_pad <= 4u * kSel1J * kSel1Threads)        // (one slot: the walking form, for latency)
-        hipLaunchKernelGGL(k_sub_select1, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval);
+        hipLaunchKernelGGL(k_sub_select1, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, thr_out);
     else if (nslots == 1)                                               // (... in chunks of 65536 columns)
-        hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS);
+        hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS, thr_out);
     else
         hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS);
     return hipGetLastError();
@@ -992,7 +1004,7 @@ hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots,
 // the nsel columns with the largest |v| of ONE vector, ascending (screen.hip's fp64 form: v = float(|A^T y|))
 hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval)
 {
-    if (nsel <= kSel1SCap) hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel);
+    if (nsel <= kSel1SCap) hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel, (float*)nullptr);
     else hipLaunchKernelGGL(k_sub_select, dim3(1), dim3(kSelThreads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel);
     return hipGetLastError();
 }

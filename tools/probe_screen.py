@@ -2,7 +2,7 @@
 """The screened form of one signal (csrc/screen.hip) against the default engine and the oracle: small shapes with the form
 forced (option screen_single = 2), then configs[1] timed with and without it.
 
-    python tools/probe_screen.py [--no-big]
+    python tools/probe_screen.py [--no-big] [--no-small]
 """
 import os
 import sys
@@ -36,22 +36,24 @@ def small():
     for (m, n, k, noise, signed) in [(1024, 8192, 16, 0.0, False), (1024, 8192, 40, 0.0, False), (512, 4096, 12, 0.0, True),
                                      (1024, 8192, 24, 1e-3, True), (768, 2048, 20, 0.0, False), (2048, 16384, 48, 0.0, False)]:
         A, y, sup = problem(m, n, k, 1000 + k, noise, signed)
-        with sship.Homotopy(A, device=0) as h:
-            h.set_option("screen_single", 2)
-            x, it, err = h.solve(y, 1e-3, 4 * k)
-            st = h.stats()
-            h.set_option("screen_single", 0)
-            xd, itd, errd = h.solve(y, 1e-3, 4 * k)
         xo, ito, eo = oracle.homotopy(A, y, 1e-3, 4 * k)
-        same_sup = np.array_equal(np.nonzero(x)[0], np.nonzero(xo)[0])
-        rel = np.abs(x - xo).max() / max(1e-30, np.abs(xo).max())
-        reld = np.abs(xd - xo).max() / max(1e-30, np.abs(xo).max())
-        print("m %5d n %6d k %3d noise %g signed %d | screened %d redone %d headroom %.3f | iter %d / default %d / oracle %d | support %s | "
-              "rel err %.2e (default engine %.2e) | err %.3e %.3e %.3e" % (
-                  m, n, k, noise, signed, st["screen_signals"], st["screen_redone"], st["screen_headroom"], it, itd, ito, same_sup, rel, reld,
-                  err, errd, eo), flush=True)
-        if it != ito or not same_sup or rel > 1e-5 + 2 * reld:
-            bad += 1
+        for first16 in (1, 0):
+            with sship.Homotopy(A, device=0) as h:
+                h.set_option("screen_single", 2)
+                h.set_option("screen_first16", first16)
+                x, it, err = h.solve(y, 1e-3, 4 * k)
+                st = h.stats()
+                h.set_option("screen_single", 0)
+                xd, itd, errd = h.solve(y, 1e-3, 4 * k)
+            same_sup = np.array_equal(np.nonzero(x)[0], np.nonzero(xo)[0])
+            rel = np.abs(x - xo).max() / max(1e-30, np.abs(xo).max())
+            reld = np.abs(xd - xo).max() / max(1e-30, np.abs(xo).max())
+            print("m %5d n %6d k %3d noise %g signed %d first16 %d | screened %d redone %d headroom %.3f | iter %d / default %d / oracle %d | "
+                  "support %s | rel err %.2e (default engine %.2e) | err %.3e %.3e %.3e" % (
+                      m, n, k, noise, signed, first16, st["screen_signals"], st["screen_redone"], st["screen_headroom"], it, itd, ito, same_sup,
+                      rel, reld, err, errd, eo), flush=True)
+            if it != ito or not same_sup or rel > 1e-5 + 2 * reld:
+                bad += 1
     return bad
 
 
@@ -72,8 +74,12 @@ def big():
     h = sship.Homotopy(A, device=0)
     X = torch.zeros((len(sigs), N), device=dev, dtype=torch.float32)
     res = {}
-    for mode in (1, 0, 1):
+    modes = ((1, 1), (1, 0), (0, 0), (1, 1))
+    if os.environ.get("PROBE_MODES"):                       # e.g. "1,1;1,0": (screen_single, screen_first16) per timed round
+        modes = tuple(tuple(int(v) for v in p.split(",")) for p in os.environ["PROBE_MODES"].split(";"))
+    for mode, first16 in modes:
         h.set_option("screen_single", mode)
+        h.set_option("screen_first16", first16)
         h.reset_stats()
         for s in range(3):
             h.solve(sigs[s][0], 1e-3, 256, out=X[s])
@@ -90,11 +96,12 @@ def big():
         ok = sum(np.array_equal(np.nonzero(Xh[s])[0], sigs[s][1]) for s in range(len(sigs)))
         cerr = max(np.abs(Xh[s][sigs[s][1]] - sigs[s][2]).max() / sigs[s][2].max() for s in range(len(sigs)))
         res[mode] = Xh.copy()
-        print("configs[1] screen_single %d: %.4f ms per solve (%.0f signals/s), iterations %s, supports exact %d / %d, max rel coef err %.2e, "
-              "screened %d redone %d headroom %.3f" % (mode, dt * 1e3, 1.0 / dt, sorted(set(its)), ok, len(sigs), cerr, st["screen_signals"],
+        print("configs[1] screen_single %d first16 %d: %.4f ms per solve (%.0f signals/s), iterations %s, supports exact %d / %d, max rel coef err %.2e, "
+              "screened %d redone %d headroom %.3f" % (mode, first16, dt * 1e3, 1.0 / dt, sorted(set(its)), ok, len(sigs), cerr, st["screen_signals"],
                                                       st["screen_redone"], st["screen_headroom"]), flush=True)
-    d = np.abs(res[1] - res[0]).max() / np.abs(res[0]).max()
-    print("screened vs default engine: max |x - x'| / max |x| = %.2e" % d)
+    if 0 in res and 1 in res:
+        d = np.abs(res[1] - res[0]).max() / np.abs(res[0]).max()
+        print("screened vs default engine: max |x - x'| / max |x| = %.2e" % d)
     # profiled solves: where the time goes
     h.set_option("screen_single", 1)
     h.set_profiling(True)
@@ -112,8 +119,10 @@ def big():
 
 
 if __name__ == "__main__":
-    bad = small()
-    print("small shapes: %d bad" % bad, flush=True)
+    bad = 0
+    if "--no-small" not in sys.argv:
+        bad = small()
+        print("small shapes: %d bad" % bad, flush=True)
     if "--no-big" not in sys.argv:
         big()
     sys.exit(1 if bad else 0)
