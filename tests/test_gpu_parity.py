@@ -594,10 +594,12 @@ def test_full_size_vs_oracle(sship, c2_host_matrix):
     assert ito == k and np.array_equal(np.nonzero(xo)[0], sup)
     with sship.Homotopy(A) as h:
         h.set_option("trace", 1)
-        # (screened, engine): the shipped default — the screened form of csrc/screen.hip —, the lookahead engine it stands
-        # in for, the sweep-per-iteration engine
-        for screen, engine in ((1, 1), (0, 1), (0, 0)):
+        # (screened, first pass over the fp16 copy, engine): the shipped default — the screened form of csrc/screen.hip with
+        # both of its passes over the half-precision copy —, the same with A^T y over the fp32 dictionary, the lookahead engine
+        # it stands in for, the sweep-per-iteration engine
+        for screen, first16, engine in ((1, 1, 1), (1, 0, 1), (0, 0, 1), (0, 0, 0)):
             h.set_option("screen_single", screen)
+            h.set_option("screen_first16", first16)
             h.set_option("engine", engine)
             h.reset_stats()
             xg, itg, eg = h.solve(y, 1e-3, 256)

@@ -28,16 +28,19 @@ SHAPES = [(1024, 8192, 16), (1024, 8192, 40), (768, 2048, 20), (2048, 16384, 48)
           (1024, 1000, 12)]
 
 
+@pytest.mark.parametrize("first16", [1, 0])
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("shape", SHAPES)
-def test_screened_form_vs_oracle(sship, shape, mode):
+def test_screened_form_vs_oracle(sship, shape, mode, first16):
     """option screen_single = 2 (any shape the form can run on): well-posed Gaussian problems are certified and equal the
-    oracle — iterations, support, coefficients, breakpoints — in both modes."""
+    oracle — iterations, support, coefficients, breakpoints — in both modes, with the first pass (A^T y) over the
+    half-precision copy (option screen_first16, the default where the row count allows) and over the fp32 dictionary."""
     m, n, k = shape
     A, y, x0, sup = make_gaussian_problem(9100 + m + k, m, n, k, np.float32)
     with sship.Homotopy(A) as h:
         flags = set_mode(h, mode)
         h.set_option("screen_single", 2)
+        h.set_option("screen_first16", first16)
         h.set_option("trace", 1)
         h.reset_stats()
         xg, itg, eg = h.solve(y, 1e-3, 4 * k)
@@ -68,6 +71,7 @@ def test_screened_form_hands_back_what_it_cannot_certify(sship):
             y = (y + noise * rng.standard_normal(m)).astype(np.float32)
         with sship.Homotopy(A) as h:
             h.set_option("screen_single", 2)
+            h.set_option("screen_first16", ci % 2)
             h.reset_stats()
             x1, it1, e1 = h.solve(y, 1e-3, 3 * k)
             st = h.stats()
@@ -82,6 +86,31 @@ def test_screened_form_hands_back_what_it_cannot_certify(sship):
             assert_parity(x1, it1, e1, xo, ito, eo, np.float32)
     note("test_screened_form_hands_back", redone=redone, cases=len(cases))
     assert redone >= 2
+
+
+@pytest.mark.parametrize("first16", [1, 0])
+def test_screened_form_crowded_first_state(sship, first16):
+    """More than 448 columns within a few percent of lambda_0 (600 noisy copies of one atom): whatever subset is chosen,
+    columns left out reach the bound of state 0 — with the first pass in half precision that is the state-0 certificate
+    (T + eps_0 against 0.875 lambda_0), with the fp32 first pass the certificate of state 1.  The signal goes back to the
+    default engine and is its result bit for bit."""
+    m, n, k = 1024, 8192, 12
+    rng = np.random.default_rng(9250)
+    A, y, x0, sup = make_gaussian_problem(9250, m, n, k, np.float32)
+    u = A[:, 7].copy()
+    A[:, 1000:1600] = u[:, None] + (2e-3 / np.sqrt(m)) * rng.standard_normal((m, 600)).astype(np.float32)
+    y = (y + 6.0 * u).astype(np.float32)
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.set_option("screen_first16", first16)
+        h.reset_stats()
+        x1, it1, e1 = h.solve(y, 1e-3, 3 * k)
+        st = h.stats()
+        h.set_option("screen_single", 0)
+        x0_, it0, e0 = h.solve(y, 1e-3, 3 * k)
+    note("test_screened_form_crowded_first_state", first16=first16, certified=st["screen_signals"], redone=st["screen_redone"])
+    assert st["screen_signals"] == 0 and st["screen_redone"] == 1
+    assert it1 == it0 and e1 == e0 and np.array_equal(x1, x0_)
 
 
 def test_screen_certificate_is_a_bound(sship):
