@@ -6,9 +6,11 @@
 
 N = 1 — configs[1], the configuration the metric is quoted on: a step is ONE Homotopy solve of one signal
 (A 8192 x 65536 fp32, k = 64) with inputs resident in HBM; `value` = signals/s; `roofline` = the dominant HBM
-kernel — in the screened form (csrc/screen.hip, the default) the correlation GEMV c = A^T y itself —, timed live with
-HIP events on the solver's stream; `screening_pass` = the pass over the fp16 copy of A that certifies the path;
-`without_screening` / `lookahead_sweep_32rhs` = the engine behind it (three fp32 passes over A), outside the timed
+kernel — in the screened form (csrc/screen.hip, the default) the correlation GEMV of the metric itself, c~0 = A16^T y
+over the half-precision copy of A (k_scr_first; priced on the bytes of that copy, with SURVEY 8d's fp32 figure beside
+it) —, timed live with HIP events on the solver's stream; `screening_pass` = the second pass over the fp16 copy, which
+certifies the path; `fp32_first_pass` / `atr_gemv` = the same form with c0 = A^T y by the fp32 sweep (k_sweep);
+`without_screening` / `lookahead_sweep_32rhs` = the engine behind it (three fp32 passes over A); those outside the timed
 region.  Outside the timed region the same run also reports: configs[2] (a batch of 4096 signals
 sharing A, with the MFMA roofline of the G = A^T A build and the HBM roofline of the Gram-form pass), a 64-signal
 batch without G (screened batch form), the drop-in surface timed with host arrays, OMP, configs[4] in fp64
@@ -420,6 +422,31 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                       "ms_per_solve": dtu / args.steps * 1e3, "signals_per_s": args.steps / dtu,
                       "same_support_as_timed_solves": same_sup, "max_rel_diff_of_coefficients": dmax}
 
+    # ... and in the screened form with the FIRST pass over the fp32 dictionary (option screen_first16 = 0: what the headline was before
+    # k_scr_first), its 1-RHS sweep timed
+    fp32_first = None
+    st_f32 = None
+    if st["screen_signals"] > 0 and st["first16_launches"] > 0 and rank == 0 and world == 1:
+        h.set_option("screen_first16", 0)
+        h.set_profiling(True)
+        h.set_option("profile_solve_every", 4 if args.steps >= 8 else 1)
+        h.reset_stats()
+        h.solve(sigs[0][0], TOL, MAX_ITER, out=xw)
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        for s in range(args.steps):
+            h.solve(sigs[args.warmup + s][0], TOL, MAX_ITER, out=xw)
+        torch.cuda.synchronize()
+        dtu = time.perf_counter() - tu
+        st_f32 = h.stats()
+        h.set_profiling(False)
+        h.set_option("profile_solve_every", 1)
+        h.set_option("screen_first16", 1)
+        fp32_first = {"workload": "the timed signals with option screen_first16 = 0: c0 = A^T y by the fp32 sweep (2.15 GB), then the same subset "
+                                  "solve and screening pass",
+                      "ms_per_solve": dtu / args.steps * 1e3, "signals_per_s": args.steps / dtu,
+                      "signals_certified": int(st_f32["screen_signals"])}
+
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
@@ -690,13 +717,36 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                                        "(recorded once, replayed here; NOT measured in this run)") if traffic is not None else None}
         if roof is None:
             roof = hbm_roof
-        s1_ms = st["sweep1_ms"] / max(1, st["sweep1_launches"])
-        s1_gbs = st["sweep1_bytes"] / (s1_ms * 1e-3) / 1e9 if s1_ms > 0 else 0.0
+        # (the fp32 1-RHS sweep: from the timed solves — or, when those ran both passes over the fp16 copy, from the untimed run with
+        # the fp32 first pass)
+        st_s1 = st if st["sweep1_launches"] > 0 or st_f32 is None else st_f32
+        s1_ms = st_s1["sweep1_ms"] / max(1, st_s1["sweep1_launches"])
+        s1_gbs = st_s1["sweep1_bytes"] / (s1_ms * 1e-3) / 1e9 if s1_ms > 0 else 0.0       # (sweep1_bytes: per launch)
         screened = st["screen_signals"] > 0
         scr_roof = None
-        if screened:
-            # screened form (csrc/screen.hip): the passes over A are c = A^T y (fp32, k_sweep) and the screening pass over the
-            # fp16 copy of A; the dominant kernel with a roofline is the GEMV the metric names
+        first16 = st["first16_launches"] > 0
+        f16_ms = st["first16_ms"] / max(1, st["first16_launches"])
+        f16_bytes = st["first16_bytes"] / max(1, st["first16_launches"])
+        f16_gbs = f16_bytes / (f16_ms * 1e-3) / 1e9 if f16_ms > 0 else 0.0
+        if screened and first16:
+            # screened form with BOTH passes over the fp16 copy of A (csrc/screen.hip, the default): the dominant HBM-bound kernel is the
+            # correlation GEMV of the metric itself, c~0 = A16^T y (k_scr_first).  Priced on the bytes it is given to read — the
+            # half-precision copy; by SURVEY 8d's fp32 figure for a sweep (m n 4 + m 4 + n 4) the same launch would read as
+            # `by_survey_8d_fp32_bytes` (above the HBM peak: the pass answers the sweep's question from half the bytes)
+            s8d = float(M) * N * 4 + M * 4 + N * 4
+            roof = {"bound": "hbm", "kernel": "k_scr_first<4 columns per wave, 3 stages>: c~0 = A16^T y, the correlation GEMV of the metric over the "
+                                              "half-precision copy of A (16-byte column loads, y in LDS, fp32 sums) — the first of the two passes "
+                                              "over A16 of a solve in the screened form; no fp32 pass over A is left in a certified solve",
+                    "achieved": f16_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f16_gbs / HBM_PEAK_GBS,
+                    "traffic": tj.get("first16_hbm_bytes_per_launch"), "bytes_per_launch": f16_bytes,
+                    "avg_launch_ms": f16_ms, "launches_timed": st["first16_launches"],
+                    "by_survey_8d_fp32_bytes": {"bytes_per_launch": s8d, "achieved": s8d / (f16_ms * 1e-3) / 1e9 if f16_ms > 0 else 0.0,
+                                                "frac": (s8d / (f16_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if f16_ms > 0 else 0.0},
+                    "traffic_source": ("profiles/traffic.json (%s): HBM bytes per launch from separate rocprofv3 --pmc passes (recorded once, "
+                                       "replayed here; NOT measured in this run)" % tj.get("first16_source")) if tj.get("first16_hbm_bytes_per_launch") else None}
+        elif screened:
+            # screened form with the fp32 first pass (option screen_first16 = 0, or a row count the half-precision first pass does not
+            # take): the passes over A are c = A^T y (fp32, k_sweep) and the screening pass over the fp16 copy of A
             roof = {"bound": "hbm", "kernel": "k_sweep<float,1 rhs> c = A^T y: the correlation GEMV of the metric, the one fp32 pass over A "
                                               "of a solve in the screened form (coalesced column loads, LDS-staged partial dot products)",
                     "achieved": s1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s1_gbs / HBM_PEAK_GBS,
@@ -704,6 +754,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                     "avg_launch_ms": s1_ms, "launches_timed": st["sweep1_launches"],
                     "traffic_source": ("profiles/traffic.json (%s): HBM bytes per launch from separate rocprofv3 --pmc passes (recorded once, "
                                        "replayed here; NOT measured in this run)" % tj.get("sweep1_source")) if tj.get("sweep1_hbm_bytes_per_launch") else None}
+        if screened:
             sc_ms = st["screen_ms"] / max(1, st["screen_launches"])
             sc_bytes = st["screen_bytes"] / max(1, st["screen_launches"])
             sc_gbs = sc_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0
@@ -757,22 +808,32 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             "roofline": roof,
             # the 32-column lookahead sweep (HBM-bound), when any of the timed solves needed one
             "lookahead_sweep_32rhs": hbm_roof if roof is not hbm_roof else None,
-            # screened form: the pass over the fp16 copy of A that certifies every state of the path against all columns
+            # screened form: the (second) pass over the fp16 copy of A that certifies every state of the path against all columns
             "screening_pass": scr_roof,
             "without_screening": unscreened,
-            # the plain correlation GEMV c = A^T y (k_sweep, 1 right-hand side): one per solve
+            "fp32_first_pass": fp32_first,
+            # the plain fp32 correlation GEMV c = A^T y (k_sweep, 1 right-hand side): one per solve unless the first pass reads the fp16
+            # copy — then timed in the untimed run with option screen_first16 = 0
             "atr_gemv": {"kernel": "k_sweep<float,1 rhs> c = A^T y", "achieved": s1_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": s1_gbs / HBM_PEAK_GBS, "bytes_per_launch": st["sweep1_bytes"],
-                         "avg_launch_ms": s1_ms, "launches_timed": st["sweep1_launches"]},
+                         "avg_launch_ms": s1_ms, "launches_timed": st_s1["sweep1_launches"],
+                         "timed_in": "the timed solves" if st_s1 is st else "the untimed run with option screen_first16 = 0",
+                         "traffic": tj.get("sweep1_hbm_bytes_per_launch")},
             "sweeps_per_solve": {"lookahead_64rhs_first": 1.0 if st["sweep64_launches"] else 0.0,
                                  "lookahead_32rhs": max(0.0, n32) if engine >= 1 else 0.0,
-                                 "atr_1rhs": 1, "screening_fp16": st["screen_signals"] / max(1, st["solves"]),
+                                 "atr_1rhs_fp32": 0 if (screened and first16) else 1,
+                                 "first_pass_fp16": 1 if (screened and first16) else 0,
+                                 "screening_fp16": st["screen_signals"] / max(1, st["solves"]),
                                  "reference_gemv_per_iteration": 4},
             "screened_form": {"signals_certified": int(st["screen_signals"]), "signals_redone_in_the_default_engine": int(st["screen_redone"])},
-            # where a solve's time goes (event-timed sweeps; the rest is the iteration kernels, latency-bound)
-            "ms_per_solve": ({"total": ms_per_step, "atr_1rhs_sweep": s1_ms, "screening_pass": scr_roof["avg_launch_ms"],
-                              "selection_subset_gram_iterations_and_rest": ms_per_step - s1_ms - scr_roof["avg_launch_ms"],
-                              "us_per_iteration": 1e3 * (ms_per_step - s1_ms - scr_roof["avg_launch_ms"]) / max(1.0, st["iterations"] / max(1, st["solves"]))}
+            # where a solve's time goes (event-timed passes; the rest is selection, the subset Gram matrix and the iteration kernel: latency-bound)
+            "ms_per_solve": (({"total": ms_per_step, "first_pass_fp16": f16_ms, "screening_pass": scr_roof["avg_launch_ms"],
+                               "selection_subset_gram_iterations_and_rest": ms_per_step - f16_ms - scr_roof["avg_launch_ms"],
+                               "us_per_iteration": 1e3 * (ms_per_step - f16_ms - scr_roof["avg_launch_ms"]) / max(1.0, st["iterations"] / max(1, st["solves"]))}
+                              if first16 else
+                              {"total": ms_per_step, "atr_1rhs_sweep": s1_ms, "screening_pass": scr_roof["avg_launch_ms"],
+                               "selection_subset_gram_iterations_and_rest": ms_per_step - s1_ms - scr_roof["avg_launch_ms"],
+                               "us_per_iteration": 1e3 * (ms_per_step - s1_ms - scr_roof["avg_launch_ms"]) / max(1.0, st["iterations"] / max(1, st["solves"]))})
                              if screened else
                              {"total": ms_per_step,
                               "atr_1rhs_sweep": s1_ms,
@@ -782,9 +843,13 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             "batched": batched,
             "single_signal_with_gram_matrix": with_gram,
             "iterations_mean": float(iters.mean()),
-            "engine": ("screened form (csrc/screen.hip): c0 = A^T y in fp32, the whole path by one workgroup on the 448 columns with the largest |c0| "
-                       "(their Gram matrix formed from A on the fp32 MFMA), every state of the path certified against all columns by one pass "
-                       "over an fp16 copy of A with a rigorous error bound; an uncertified signal is solved again by the default engine") if screened else
+            "engine": (("screened form (csrc/screen.hip), both passes over the fp16 copy of A: c~0 = A16^T y ranks the columns, the exact fp32 c0 and "
+                        "Gram matrix of the 448 chosen ones are formed from A (fp32 MFMA), the whole path is solved by one workgroup on those in "
+                        "fp32, every state of the path — state 0 included — is certified against all columns with a rigorous error bound by the "
+                        "second pass over A16; an uncertified signal is solved again by the default engine") if first16 else
+                       ("screened form (csrc/screen.hip): c0 = A^T y in fp32, the whole path by one workgroup on the 448 columns with the largest |c0| "
+                        "(their Gram matrix formed from A on the fp32 MFMA), every state of the path certified against all columns by one pass "
+                        "over an fp16 copy of A with a rigorous error bound; an uncertified signal is solved again by the default engine")) if screened else
                       (("lookahead (cached Gram columns), speculative iterations on the subset Gram matrix beside the passes over A "
                         "(early form; every breakpoint verified over all columns)" if h.get_option("early_solo") else
                         "lookahead (cached Gram columns), speculative resident iterations (one workgroup + verification of every breakpoint)")

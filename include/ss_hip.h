@@ -275,6 +275,10 @@ typedef struct ss_hip_stats {
     uint64_t screen_bytes;         /* their algorithmic bytes: ldm * n_pad * 2 (fp16 copy of A) + 96 * ldm * 2 + n_pad * 4 each             */
     double   screen_headroom;      /* largest (|c~| + eps) / bound over the columns outside the subset and the states of the LAST
                                       screened solve (< 1: certified; refreshed by ss_hip_get_stats)                                       */
+    uint64_t first16_launches;     /* timed launches of the screened form's first pass over the fp16 copy, k_scr_first (option
+                                      "screen_first16"; profiling on)                                                                     */
+    double   first16_ms;           /* sum of their HIP-event durations                                                                    */
+    uint64_t first16_bytes;        /* their algorithmic bytes: ldm * n_pad * 2 (fp16 copy of A) + ldm * 4 (y) + n_pad * 4 (c~0) each        */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------
@@ -382,6 +386,12 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    2 = on every shape the form can run on (tests); 0 = never.  Initial value: environment variable
  *                    SS_HIP_SCREEN_SINGLE when set.  Stands in for the default speculative engine only ("la_fused" = 3,
  *                    "early_solo" = 1); with G = A^T A in HBM the subset form on G is used instead ("gram_single").
+ *   "screen_first16" 1 (default) = the screened form of one fp32 signal reads the fp16 copy for its FIRST pass too (row counts padded to
+ *                    a multiple of 512, at most 15872): c~0 = A16^T y ranks the columns, the exact fp32 c0 of the 448 chosen ones
+ *                    is formed beside their Gram matrix (lambda_0, the first pick and the path come from those), and state 0 is
+ *                    certified like every other state: T + eps_0 <= 7/8 lambda_0 with T above every |c~0| left out and
+ *                    eps_0 = 2^-9 max ||a_i|| ||y|| + the flush term.  No fp32 pass over A is left in a certified solve
+ *                    (ss_hip_stats::first16_*); 0 = c0 = A^T y by the fp32 sweep
  *   "ro_slots"       1..8 (default 8; fp64 contexts use at most 4): signals the reference-order engine runs in lock-step per pass over A (batches in
  *                    engine 3, a batch's tie re-runs); every signal's words are those of its own solve
  *   "ro_staged"      1 (default) = its sweep stages the dictionary through LDS (coalesced loads); 0 = direct 16-byte

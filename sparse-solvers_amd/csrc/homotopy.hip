@@ -1054,9 +1054,9 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             if (sub1) {
                 HIPCHK(sub_single(ctx, ws, tol, max_iter));
             } else {
-                // (6 = a pass over the fp16 copy of A: the screening pass, and the first pass when it runs there)
+                // (6 = the screening pass over the fp16 copy of A, 7 = the first pass when it runs there too)
                 hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-                if (prof && first16) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(6); ++nprof; }
+                if (prof && first16) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(7); ++nprof; }
                 if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); }
                 HIPCHK(scr_single(ctx, ws, tol, max_iter, first16, e0, e1, e2, e3));
                 if (prof) { ctx->prof_kind.push_back(6); ++nprof; }
@@ -1388,6 +1388,10 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     ctx->stats.screen_launches += scr_launches;
                     ctx->stats.screen_ms += ms;
                     ctx->stats.screen_bytes += (uint64_t)scr_launches * ((uint64_t)ctx->ldm * ctx->n_pad * 2ull + 96ull * ctx->ldm * 2ull + (uint64_t)ctx->n_pad * 4ull);
+                } else if (ctx->prof_kind[i] == 7) {
+                    ctx->stats.first16_launches += 1;
+                    ctx->stats.first16_ms += ms;
+                    ctx->stats.first16_bytes += (uint64_t)ctx->ldm * ctx->n_pad * 2ull + (uint64_t)ctx->ldm * 4ull + (uint64_t)ctx->n_pad * 4ull;
                 } else if (ctx->prof_kind[i] == 4) {
                     if (ms > 0.02f) {                          // (a launch of a solve that ended at the first pick is a no-op)
                         ctx->stats.sweep64_launches += 1;

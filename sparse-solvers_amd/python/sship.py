@@ -95,6 +95,9 @@ class Stats(ctypes.Structure):
         ("screen_ms", ctypes.c_double),
         ("screen_bytes", ctypes.c_uint64),
         ("screen_headroom", ctypes.c_double),
+        ("first16_launches", ctypes.c_uint64),
+        ("first16_ms", ctypes.c_double),
+        ("first16_bytes", ctypes.c_uint64),
     ]
 
 

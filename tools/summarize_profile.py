@@ -63,15 +63,17 @@ def main():
         lines.append("")
         # timeline of one timed solve (kernel trace timestamps, us from the start of its A^T y sweep): the second
         # hardware queue carries the passes that run beside the speculative launch
-        starts = [i for i, r in enumerate(rows) if "k_sweep" in r["Kernel_Name"]]
+        # (a solve starts with its first pass over A: k_scr_first — the screened form with both passes over the fp16 copy — or k_sweep)
+        first_pass = "k_scr_first" if any("k_scr_first" in r["Kernel_Name"] for r in rows) else "k_sweep"
+        starts = [i for i, r in enumerate(rows) if first_pass in r["Kernel_Name"]]
         if len(starts) >= 4:
             a = starts[len(starts) // 2]
             t0 = int(rows[a]["Start_Timestamp"])
-            lines += ["## Timeline of one solve (us from the start of `k_sweep`; queue = hardware queue id)", "",
+            lines += ["## Timeline of one solve (us from the start of `%s`; queue = hardware queue id)" % first_pass, "",
                       "| start | end | queue | kernel |", "|---|---|---|---|"]
             i = a
             tl = []
-            while i < len(rows) and (i == a or "k_sweep" not in rows[i]["Kernel_Name"]):
+            while i < len(rows) and (i == a or ("k_sweep" not in rows[i]["Kernel_Name"] and "k_scr_first" not in rows[i]["Kernel_Name"])):
                 r = rows[i]
                 tl.append(((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3, r["Queue_Id"],
                            short(r["Kernel_Name"]).replace("sship::", "")))
@@ -91,8 +93,9 @@ def main():
     if len(sys.argv) > 2:
         targets = [("gemm32" if "gemm32" in KERNEL_KEY else "sweep2", KERNEL_KEY, None)]
     else:
-        # the screened form of a single signal (csrc/screen.hip): the fp32 GEMV c = A^T y and the screening pass over the fp16 copy of A
-        targets = [("sweep1", "k_sweep<float, 1", 8192 * 65536 * 4 + 8192 * 4 + 65536 * 4),
+        # the screened form of a single signal (csrc/screen.hip): its two passes over the fp16 copy of A, the fp32 GEMV c = A^T y (untimed run)
+        targets = [("first16", "k_scr_first", 8192 * 65536 * 2 + 8192 * 4 + 65536 * 4),
+                   ("sweep1", "k_sweep<float, 1", 8192 * 65536 * 4 + 8192 * 4 + 65536 * 4),
                    ("screen", "k_scr_gemm", 8192 * 65536 * 2 + 96 * 8192 * 2 + 65536 * 4),
                    ("gemm32", "k_gemm32_tn_f32<128, 256, 3", 57344 * 8192 * 4 + 32 * 8192 * 4 + 32 * 57344 * 4)]
     for key, kkey, alg_fixed in targets:
