@@ -909,6 +909,30 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                    "max_rel_diff_of_coefficients": float(((xu5 - x5).abs().max() / x5.abs().max()).item())}
             del xu5
             h5.set_option("screen_single", 1)
+        # ... and in the fp64 screened form with the first pass over the fp64 dictionary (option screen_first16 = 0: A^T y by the fp64 sweep)
+        f64first5 = None
+        if st5["screen_signals"] > 0 and h5.get_option("screen_first16"):
+            h5.set_option("screen_first16", 0)
+            h5.solve(y5, 1e-9, 512, out=x5)
+            torch.cuda.synchronize()
+            tf5 = time.perf_counter()
+            for _ in range(3):
+                h5.solve(y5, 1e-9, 512, out=x5)
+            torch.cuda.synchronize()
+            f64first5 = {"ms_per_solve": (time.perf_counter() - tf5) / 3 * 1e3}
+            h5.set_option("screen_first16", 1)
+            # (the first pass over the fp16 copy, timed: k_scr_first<double y>, 4.3 GB)
+            h5.set_profiling(True)
+            h5.reset_stats()
+            for _ in range(3):
+                h5.solve(y5, 1e-9, 512, out=x5)
+            stf5 = h5.stats()
+            h5.set_profiling(False)
+            if stf5["first16_launches"] > 0:
+                f_ms = stf5["first16_ms"] / stf5["first16_launches"]
+                f_b = stf5["first16_bytes"] / stf5["first16_launches"]
+                f64first5["first_pass_fp16"] = {"kernel": "k_scr_first: c~0 = A16^T y (the ranking of the columns)", "ms": f_ms, "bytes_per_launch": f_b,
+                                                "GB/s": f_b / f_ms / 1e6, "frac_of_8TBs": f_b / f_ms / 1e6 / HBM_PEAK_GBS}
         # configs[4] names OMP: the same signal through ss::omp<double> (parity unpinned: the reference has no OMP); it takes the fp64
         # screened form as well (the sub-context runs k_la_omp)
         xo5 = torch.zeros(n5, device=dev, dtype=torch.float64)
@@ -930,12 +954,15 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         extras["fp64_configs4"] = {
             "workload": "configs[4] shape: Homotopy fp64, A 16384x131072 (16 GiB, torch.randn seed 4321 / sqrt(m)), k=128, tol 1e-9, max_iter 512",
             "ms_per_solve": dt5 * 1e3, "iterations": int(it5), "support_exact": ok5, "max_rel_coef_err": err5,
-            "engine": ("fp64 screened form (csrc/screen.hip): A^T y in fp64, the path solved by the fp64 engine on a sub-dictionary of the 2048 columns "
-                       "with the largest |c0| (a context of its own), every state certified against all columns by the pass over the fp16 copy of A"
+            "engine": ("fp64 screened form (csrc/screen.hip): the columns ranked by c~0 = A16^T y over the fp16 copy of A (option screen_first16; 0 = A^T y "
+                       "by the fp64 sweep), the path solved by the fp64 engine on a sub-dictionary of the 2048 best (a context of its own; lambda_0 and "
+                       "every value reported are its fp64 arithmetic), every state — state 0 included — certified against all columns by the "
+                       "pass over the fp16 copy"
                        if st5["screen_signals"] > 0 else "lookahead engine, one launch per iteration"),
             "screened_form": {"signals_certified": int(st5["screen_signals"]), "signals_redone_in_the_default_engine": int(st5["screen_redone"]),
                               "certificate_headroom": st5["screen_headroom"]},
             "without_screening": un5,
+            "fp64_first_pass": f64first5,
             "omp_fp64_same_signal": omp5,
             "lookahead_sweeps_per_solve": st5["lookahead_sweeps"] / max(1, st5["solves"]),
             "lookahead_sweep_f64": {"ms": ms32, "GB/s": b32 / ms32 / 1e6, "frac_of_8TBs": b32 / ms32 / 1e6 / HBM_PEAK_GBS},

@@ -836,13 +836,14 @@ inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, u
 }
 inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
 // (typed shims of the fp64 screened form: never reached for float)
-inline hipError_t scr64_gather(ss_hip_ctx* ctx, const double* c0) { return screen64_gather(ctx, c0); }
-inline hipError_t scr64_gather(ss_hip_ctx*, const float*) { return hipErrorInvalidConfiguration; }
-inline hipError_t scr64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K, hipEvent_t e2, hipEvent_t e3, bool omp)
+inline hipError_t scr64_gather(ss_hip_ctx* ctx, const double* c0, const double* y, hipEvent_t e0, hipEvent_t e1) { return screen64_gather(ctx, c0, y, e0, e1); }
+inline hipError_t scr64_gather(ss_hip_ctx*, const float*, const float*, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K, hipEvent_t e2, hipEvent_t e3, bool omp,
+                                bool first16)
 {
-    return screen64_certify(ctx, ws, y, T, tol, c_inf, K, e2, e3, omp);
+    return screen64_certify(ctx, ws, y, T, tol, c_inf, K, e2, e3, omp, first16);
 }
-inline hipError_t scr64_certify(ss_hip_ctx*, Workspace<float>&, const float*, uint32_t, float, double, uint32_t, hipEvent_t, hipEvent_t, bool) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr64_certify(ss_hip_ctx*, Workspace<float>&, const float*, uint32_t, float, double, uint32_t, hipEvent_t, hipEvent_t, bool, bool) { return hipErrorInvalidConfiguration; }
 
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
@@ -990,11 +991,19 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         if (scr64) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             if (!omp) HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y (OMP: done above)
+            // (the first pass — A^T y over all columns, which here only ranks them — over the fp16 copy: k_scr_first; 7 = that pass)
+            const bool first16 = screen_first16_usable(ctx);
             uint32_t nb1 = 0;
-            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
-            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
-            if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
-            HIPCHK(scr64_gather(ctx, ws.c0));
+            if (first16) {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (prof) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(7); ++nprof; }
+                HIPCHK(scr64_gather(ctx, (const T*)nullptr, ws.rhs, e0, e1));
+            } else {
+                if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+                HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+                if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+                HIPCHK(scr64_gather(ctx, ws.c0, ws.rhs, nullptr, nullptr));
+            }
             HIPCHK(hipStreamSynchronize(st));
             bool handed_back = true;
             if constexpr (sizeof(T) == 8) {
@@ -1014,7 +1023,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     const DevState hsub = *static_cast<const DevState*>(sub->hs_pinned);
                     hipEvent_t e2 = nullptr, e3 = nullptr;
                     if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); }
-                    HIPCHK(scr64_certify(ctx, ws, ws.rhs, it_s, tol, e_s, hsub.K, e2, e3, omp));
+                    HIPCHK(scr64_certify(ctx, ws, ws.rhs, it_s, tol, e_s, hsub.K, e2, e3, omp, first16));
                     if (prof) { ctx->prof_kind.push_back(6); ++nprof; }
                     scr_launches = (it_s + 95u) / 96u;
                     handed_back = false;
@@ -1391,7 +1400,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 } else if (ctx->prof_kind[i] == 7) {
                     ctx->stats.first16_launches += 1;
                     ctx->stats.first16_ms += ms;
-                    ctx->stats.first16_bytes += (uint64_t)ctx->ldm * ctx->n_pad * 2ull + (uint64_t)ctx->ldm * 4ull + (uint64_t)ctx->n_pad * 4ull;
+                    ctx->stats.first16_bytes += (uint64_t)ctx->ldm * ctx->n_pad * 2ull + (uint64_t)ctx->ldm * sizeof(T) + (uint64_t)ctx->n_pad * 4ull;
                 } else if (ctx->prof_kind[i] == 4) {
                     if (ms > 0.02f) {                          // (a launch of a solve that ended at the first pick is a no-op)
                         ctx->stats.sweep64_launches += 1;

@@ -165,19 +165,22 @@ void k_a16_convert(const T* __restrict__ At, size_t total8, const float* __restr
 // Layout: sweep.hip's — a wave owns CPW columns and streams them with 16-byte loads (8 rows per lane, 512 rows per step);
 // y sits in LDS, permuted so that the two 16-byte reads of a lane are conflict-free.  Every group of columns starts at a
 // row step of its own and wraps around (the sum's order is free here): the HBM channel phases of the 16-KiB-strided columns.
-template <int CPW, int DEPTH>
+template <typename TY, int CPW, int DEPTH>
 __global__ __launch_bounds__(512, 2)
-void k_scr_first(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, uint32_t ngroups, const float* __restrict__ y,
+void k_scr_first(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, uint32_t ngroups, const TY* __restrict__ y,
                  float* __restrict__ meta, float* __restrict__ c0h, uint32_t skew)
 {
+    // (TY = double: the fp64 form — y is rounded to fp32 on its way into LDS: 2^-24 per entry, inside the bound's 2^-9)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ float sv[16];
     float* ly = reinterpret_cast<float*>(smem);                  // [ldm]: rows 512 s + 8 l + 4 u + e  at  512 s + 256 u + 4 l + e
+    float* sv = ly + ldm;                                        // [16] reduction scratch
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float ss = 0.f;
     for (uint32_t i = tid * 4u; i < ldm; i += 2048u) {
-        const scr_v4f v = *reinterpret_cast<const scr_v4f*>(y + i);
+        scr_v4f v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)y[i + (uint32_t)e];
         const uint32_t wq = i & 511u;
         *reinterpret_cast<scr_v4f*>(&ly[(i & ~511u) + ((wq & 4u) << 6) + ((wq >> 3) << 2)]) = v;
 #pragma unroll
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(256)
 void k_s64_residuals(const double* __restrict__ Asub, uint32_t ldm, const double* __restrict__ y, const unsigned char* __restrict__ slog,
                      uint32_t T, const double* __restrict__ xd, double tol, const float* __restrict__ meta,
                      __half* __restrict__ r16, float* __restrict__ rn2p, float* __restrict__ tab, uint32_t* __restrict__ ctl,
-                     uint32_t* __restrict__ headroom)
+                     uint32_t* __restrict__ headroom, int first16)
 {
     typedef double v2d __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) double sAc[16][64];
@@ -994,7 +997,21 @@ void k_s64_residuals(const double* __restrict__ Asub, uint32_t ldm, const double
     }
     if (ovf) ctl[0] = 1u;
     if (blockIdx.x == 0u) {
-        if (tid == 0u) *headroom = 0u;
+        if (tid == 0u) {
+            float ratio0 = 0.f;
+            if (first16) {
+                // state 0 after a first pass in half precision (k_scr_first; see k_scr_residuals): every column left out of the
+                // sub-dictionary has |c~0| < T — certified against the sub-context's exact lambda_0
+                const float lam0 = (float)l_lam[0] * 0.9999999f;
+                const float yn = sqrtf(meta[5]) * 1.001f;
+                const float eps0 = 0.0019726562f * yn * meta[4] + 6.103515625e-05f * sqrtf((float)ldm) * yn * meta[1];
+                const float bound0 = lam0 * 0.875f - 1e-12f * lam0;
+                const float v0 = meta[6] + eps0;
+                if (!(v0 <= bound0)) ctl[0] = 1u;
+                ratio0 = bound0 > 0.f && v0 == v0 ? v0 / bound0 : 3.0e38f;
+            }
+            *headroom = __float_as_uint(ratio0);
+        }
         if (tid < nst) {
             const float lam = (float)l_lam[tid + 1u];
             const bool final_state = tid + 1u == T;
@@ -1116,12 +1133,37 @@ bool screen_form_usable(ss_hip_ctx* ctx)
 // r = y in ws.rhs (block 0); c0 = A^T y in ws.c0 — or, first16, nothing yet: the first pass runs here, over the fp16 copy
 // (k_scr_first; ws.c0 then holds c~0 with the subset's entries exact).  Everything on the context's stream.  Profiling events:
 // e0, e1 around the half-precision first pass, e2, e3 around the screening pass.
-bool screen_first16_usable(const ss_hip_ctx* ctx) { return ctx->screen_first16 != 0 && ctx->ldm % 512u == 0u && ctx->ldm <= 15872u; }    // (y in LDS: 4 ldm bytes + the reduction scratch)
-
-static uint32_t scr_first_variant()
+// (y in LDS: 4 ldm bytes + the reduction scratch — beyond 64 KiB the kernel's dynamic-LDS ceiling is raised first)
+template <typename TY>
+static bool scr_first_attr()
 {
-    static const uint32_t v = [] { const char* e = std::getenv("SS_HIP_SCR_FIRST"); return e ? (uint32_t)std::atoi(e) : 0u; }();
-    return v;
+    static const bool ok = [] {
+        const bool r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_first<TY, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           16384 * (int)sizeof(float) + 64) == hipSuccess;
+        if (!r) (void)hipGetLastError();
+        return r;
+    }();
+    return ok;
+}
+
+bool screen_first16_usable(const ss_hip_ctx* ctx)
+{
+    if (ctx->screen_first16 == 0 || ctx->ldm % 512u != 0u || ctx->ldm > 16384u) return false;
+    if ((size_t)ctx->ldm * sizeof(float) + 64 <= 65536) return true;
+    return ctx->is_f64 ? scr_first_attr<double>() : scr_first_attr<float>();
+}
+
+// c~0 = A16^T y / sA into c0h ([n_pad] floats), ||y||^2 into meta[5]
+template <typename TY>
+static hipError_t launch_scr_first(ss_hip_ctx* ctx, ScreenState* S, const TY* y, float* c0h)
+{
+    const uint32_t ldm = ctx->ldm, np = ctx->n_pad;
+    const size_t lds = (size_t)ldm * sizeof(float) + 64;
+    if (lds > 65536u && !scr_first_attr<TY>()) return hipErrorInvalidConfiguration;
+    const uint32_t grid = std::min<uint32_t>(np / 32u, (uint32_t)ctx->num_cus * 2u);
+    hipLaunchKernelGGL((k_scr_first<TY, 4, 3>), dim3(grid), dim3(512), lds, ctx->stream, (const __half*)S->a16, ldm, (uint32_t)ctx->n, np / 32u, y,
+                       S->meta, c0h, scr_skew() == 0u ? 0u : 5u);
+    return hipGetLastError();
 }
 
 hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, hipEvent_t e0, hipEvent_t e1,
@@ -1137,15 +1179,7 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     constexpr uint32_t NT = kSbS / kSgT;
     if (first16) {
         if (e0) (void)hipEventRecord(e0, s);
-        const uint32_t grid = std::min<uint32_t>(np / 32u, (uint32_t)ctx->num_cus * 2u);
-        const size_t lds = (size_t)ldm * sizeof(float);
-        const uint32_t skew = scr_skew() == 0u ? 0u : 5u;
-        switch (scr_first_variant()) {
-        case 1:  hipLaunchKernelGGL((k_scr_first<4, 2>), dim3(grid), dim3(512), lds, s, (const __half*)S->a16, ldm, n, np / 32u, (const float*)ws.rhs, S->meta, ws.c0, skew); break;
-        case 2:  hipLaunchKernelGGL((k_scr_first<4, 4>), dim3(grid), dim3(512), lds, s, (const __half*)S->a16, ldm, n, np / 32u, (const float*)ws.rhs, S->meta, ws.c0, skew); break;
-        case 3:  hipLaunchKernelGGL((k_scr_first<2, 4>), dim3(std::min<uint32_t>(np / 16u, (uint32_t)ctx->num_cus * 2u)), dim3(512), lds, s, (const __half*)S->a16, ldm, n, np / 16u, (const float*)ws.rhs, S->meta, ws.c0, skew); break;
-        default: hipLaunchKernelGGL((k_scr_first<4, 3>), dim3(grid), dim3(512), lds, s, (const __half*)S->a16, ldm, n, np / 32u, (const float*)ws.rhs, S->meta, ws.c0, skew); break;
-        }
+        { const hipError_t ef = launch_scr_first<float>(ctx, S, (const float*)ws.rhs, ws.c0); if (ef != hipSuccess) return ef; }
         if (e1) (void)hipEventRecord(e1, s);
     }
     (void)launch_sub_select(ctx, B, 1, ws.c0, first16 ? S->meta + 6 : nullptr);
@@ -1309,14 +1343,23 @@ ss_hip_ctx* screen64_sub(ss_hip_ctx* ctx) { return scr_of(ctx) ? scr_of(ctx)->su
 double* screen64_xsub(ss_hip_ctx* ctx) { return scr_of(ctx) ? scr_of(ctx)->xsub : nullptr; }
 
 // c0 = A^T y is in c0 (device): the kS64Sub columns with the largest |c0|, gathered into the sub-context's dictionary
-hipError_t screen64_gather(ss_hip_ctx* ctx, const double* c0)
+// (c0 == nullptr: the first pass runs here, over the fp16 copy — y = the signal (device, ldm entries): k_scr_first ranks the columns,
+// the selection reports what the columns left out stay below (meta[6]), k_s64_residuals certifies state 0)
+hipError_t screen64_gather(ss_hip_ctx* ctx, const double* c0, const double* y, hipEvent_t e0, hipEvent_t e1)
 {
     ScreenState* S = scr_of(ctx);
     if (S == nullptr || S->sub == nullptr) return hipErrorInvalidConfiguration;
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t)ctx->n, np = ctx->n_pad;
-    hipLaunchKernelGGL(k_s64_cabs, dim3((np + 255) / 256), dim3(256), 0, s, c0, n, np, S->cabs);
-    (void)launch_select_top(ctx, S->cabs, n, np, kS64Sub, S->sublist, S->sublist + kS64Sub, reinterpret_cast<float*>(S->sublist + kS64Sub + 1));
+    if (c0 != nullptr) hipLaunchKernelGGL(k_s64_cabs, dim3((np + 255) / 256), dim3(256), 0, s, c0, n, np, S->cabs);
+    else {
+        if (e0) (void)hipEventRecord(e0, s);
+        const hipError_t ef = launch_scr_first<double>(ctx, S, y, S->cabs);
+        if (ef != hipSuccess) return ef;
+        if (e1) (void)hipEventRecord(e1, s);
+    }
+    (void)launch_select_top(ctx, S->cabs, n, np, kS64Sub, S->sublist, S->sublist + kS64Sub, reinterpret_cast<float*>(S->sublist + kS64Sub + 1),
+                            c0 == nullptr ? S->meta + 6 : nullptr);
     hipLaunchKernelGGL(k_s64_gather, dim3(kS64Sub), dim3(256), 0, s, static_cast<const double*>(ctx->At), ctx->ldm, n,
                        (const uint32_t*)S->sublist, static_cast<double*>(S->sub->At));
     return hipGetLastError();
@@ -1325,7 +1368,7 @@ hipError_t screen64_gather(ss_hip_ctx* ctx, const double* c0)
 // After the sub-context's solve (T iterations, synchronised): the certificate of its T states against all columns, the
 // solution scattered into x, the verdict into the slot's state.  y = the signal (device, ldm entries, zero padded).
 hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K,
-                            hipEvent_t e2, hipEvent_t e3, bool omp)
+                            hipEvent_t e2, hipEvent_t e3, bool omp, bool first16)
 {
     ScreenState* S = scr_of(ctx);
     if (S == nullptr || S->sub == nullptr || T == 0u || T > kS64Rhs) return hipErrorInvalidConfiguration;
@@ -1335,7 +1378,8 @@ hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double
     const unsigned char* slog = static_cast<const unsigned char*>(S->sub->slog);
     hipLaunchKernelGGL(k_s64_dense, dim3(T), dim3(256), 0, s, slog, T, S->xd, S->ctl, omp ? 1 : 0);
     hipLaunchKernelGGL(k_s64_residuals, dim3(ldm / 64u), dim3(256), 0, s, static_cast<const double*>(S->sub->At), ldm, y, slog, T,
-                       (const double*)S->xd, tol, (const float*)S->meta, S->r16, S->rn2p, S->tab, S->ctl, reinterpret_cast<uint32_t*>(S->meta) + 3);
+                       (const double*)S->xd, tol, (const float*)S->meta, S->r16, S->rn2p, S->tab, S->ctl, reinterpret_cast<uint32_t*>(S->meta) + 3,
+                       first16 ? 1 : 0);
     if (e2) (void)hipEventRecord(e2, s);
     // (up to 160 states in ONE pass over the fp16 copy — five tiles of 32 per workgroup —, the rest in passes of 96)
     for (uint32_t k0 = 0; k0 < T;) {

@@ -426,7 +426,8 @@ hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots,
 hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs& B, uint32_t nslots, const float* G, uint32_t gpitch, int gsub,
                             const float* c0, float tol, uint32_t max_iter, uint32_t g_slot_stride = 0);
 hipError_t launch_sub_finish(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots);
-hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval);
+hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval,
+                             float* thr_out = nullptr);
 // screened form of ONE signal (screen.hip): the subset form on the subset's own Gram matrix (formed from A), every state of
 // the path then screened against all columns by one pass over a half-precision copy of A with a rigorous error bound
 bool screen_form_usable(ss_hip_ctx* ctx);                 // shape / option test + one-time preparation (fp16 copy of A, column norms)
@@ -443,9 +444,9 @@ void screen_free(ss_hip_ctx* ctx);
 bool screen64_usable(ss_hip_ctx* ctx);
 ss_hip_ctx* screen64_sub(ss_hip_ctx* ctx);
 double* screen64_xsub(ss_hip_ctx* ctx);
-hipError_t screen64_gather(ss_hip_ctx* ctx, const double* c0);
+hipError_t screen64_gather(ss_hip_ctx* ctx, const double* c0, const double* y, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // (c0 = nullptr: the first pass over the fp16 copy, here; e0, e1 around it)
 hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K,
-                            hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr, bool omp = false);
+                            hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr, bool omp = false, bool first16 = false);
 double screen_read_headroom(ss_hip_ctx* ctx);             // largest (|c~| + eps) / bound of the last screened solve (synchronises)
 hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr);      // signals one pass of the engine can carry (1 without the LDS-staged sweep)

@@ -1002,9 +1002,12 @@ hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots,
 }
 
 // the nsel columns with the largest |v| of ONE vector, ascending (screen.hip's fp64 form: v = float(|A^T y|))
-hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval)
+hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval,
+                             float* thr_out)
 {
-    if (nsel <= kSel1SCap) hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel, (float*)nullptr);
+    // (thr_out: a value every entry left out stays below; only the one-workgroup kernel reports it — nsel <= kSel1SCap)
+    if (nsel <= kSel1SCap) hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel, thr_out);
+    else if (thr_out != nullptr) return hipErrorInvalidConfiguration;
     else hipLaunchKernelGGL(k_sub_select, dim3(1), dim3(kSelThreads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel);
     return hipGetLastError();
 }

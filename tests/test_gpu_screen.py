@@ -160,16 +160,19 @@ def test_screen_certificate_is_a_bound(sship):
     assert worst <= st["screen_headroom"] + 1e-3         # the device's figure (|c~| + eps) / bound dominates |c| / (0.875 lambda)... loosely
 
 
+@pytest.mark.parametrize("first16", [1, 0])
 @pytest.mark.parametrize("shape", [(1024, 16384, 24), (1536, 9000, 40), (2048, 16384, 60), (1024, 12000, 16)])
-def test_screened_form_fp64_vs_oracle(sship, shape):
-    """fp64: the path is solved by the fp64 engine on a sub-dictionary (the 2048 columns with the largest |c0|, a context of its
-    own, every state logged) and certified against all columns by the fp16 pass.  Certified signals equal the oracle within
+def test_screened_form_fp64_vs_oracle(sship, shape, first16):
+    """fp64: the path is solved by the fp64 engine on a sub-dictionary (the 2048 columns with the largest |c0| — ranked by the
+    half-precision first pass, option screen_first16, or by the fp64 sweep —, a context of its own, every state logged) and
+    certified against all columns by the fp16 pass.  Certified signals equal the oracle within
     1e-10; what the form hands back (a support column outside the sub-dictionary: the sub-solve wanders) is the default
     engine's result bit for bit."""
     m, n, k = shape
     A, y, x0, sup = make_gaussian_problem(9400 + m + k, m, n, k, np.float64)
     with sship.Homotopy(A) as h:
         h.set_option("screen_single", 2)
+        h.set_option("screen_first16", first16)
         h.reset_stats()
         xg, itg, eg = h.solve(y, 1e-9, 4 * k)
         st = h.stats()
@@ -211,8 +214,9 @@ def test_screened_form_fp64_hands_back(sship):
     assert_parity(xg, itg, eg, xo, ito, eo, np.float64)
 
 
+@pytest.mark.parametrize("first16", [1, 0])
 @pytest.mark.parametrize("shape", [(1024, 16384, 24), (1536, 9000, 40), (2048, 16384, 60)])
-def test_screened_form_fp64_omp(sship, shape):
+def test_screened_form_fp64_omp(sship, shape, first16):
     """OMP (ss::omp<double>; no reference implementation: pinned against this library's default OMP engine and numpy's least
     squares on the planted support) through the fp64 screened form: the sub-context runs k_la_omp, the certificate is that no
     column outside the sub-dictionary reaches the pick's |c|."""
@@ -226,6 +230,7 @@ def test_screened_form_fp64_omp(sship, shape):
     y = A @ x0
     with sship.Homotopy(A) as h:
         h.set_option("screen_single", 2)
+        h.set_option("screen_first16", first16)
         h.reset_stats()
         xg, itg, eg = h.solve_omp(y, 1e-9, 4 * k)
         st = h.stats()

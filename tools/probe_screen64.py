@@ -23,21 +23,24 @@ def small():
         x0 = np.zeros(n)
         x0[sup] = 1.0 + np.abs(rng.standard_normal(k))
         y = A @ x0
-        with sship.Homotopy(A, device=0) as h:
-            h.set_option("screen_single", 2)
-            x, it, err = h.solve(y, 1e-9, 4 * k)
-            st = h.stats()
-            h.set_option("screen_single", 0)
-            xd, itd, errd = h.solve(y, 1e-9, 4 * k)
         xo, ito, eo = oracle.homotopy(A, y, 1e-9, 4 * k)
-        same = np.array_equal(np.nonzero(x)[0], np.nonzero(xo)[0])
-        rel = np.abs(x - xo).max() / np.abs(xo).max()
-        reld = np.abs(xd - xo).max() / np.abs(xo).max()
-        print("m %5d n %6d k %3d | screened %d redone %d headroom %.3f | iter %d / default %d / oracle %d | support %s | rel err %.2e (default %.2e)"
-              % (m, n, k, st["screen_signals"], st["screen_redone"], st["screen_headroom"], it, itd, ito, same, rel, reld), flush=True)
-        # (a path with removals leaves rounding residue on its columns in the default engine as well: compared with that)
-        if it != ito or rel > max(1e-10, 3 * reld) or (not same and not np.array_equal(np.nonzero(x)[0], np.nonzero(xd)[0])):
-            bad += 1
+        for first16 in (1, 0):
+            with sship.Homotopy(A, device=0) as h:
+                h.set_option("screen_single", 2)
+                h.set_option("screen_first16", first16)
+                x, it, err = h.solve(y, 1e-9, 4 * k)
+                st = h.stats()
+                h.set_option("screen_single", 0)
+                xd, itd, errd = h.solve(y, 1e-9, 4 * k)
+            same = np.array_equal(np.nonzero(x)[0], np.nonzero(xo)[0])
+            rel = np.abs(x - xo).max() / np.abs(xo).max()
+            reld = np.abs(xd - xo).max() / np.abs(xo).max()
+            print("m %5d n %6d k %3d first16 %d | screened %d redone %d headroom %.3f | iter %d / default %d / oracle %d | support %s | "
+                  "rel err %.2e (default %.2e)" % (m, n, k, first16, st["screen_signals"], st["screen_redone"], st["screen_headroom"], it, itd, ito,
+                                                   same, rel, reld), flush=True)
+            # (a path with removals leaves rounding residue on its columns in the default engine as well: compared with that)
+            if it != ito or rel > max(1e-10, 3 * reld) or (not same and not np.array_equal(np.nonzero(x)[0], np.nonzero(xd)[0])):
+                bad += 1
     return bad
 
 
@@ -60,8 +63,9 @@ def big():
     torch.cuda.empty_cache()
     x5 = torch.zeros(n5, device=dev, dtype=torch.float64)
     res = {}
-    for mode in (1, 0, 1):
+    for mode, first16 in ((1, 1), (0, 0), (1, 0)):
         h5.set_option("screen_single", mode)
+        h5.set_option("screen_first16", first16)
         h5.reset_stats()
         h5.solve(sigs[0][0], 1e-9, 512, out=x5)
         torch.cuda.synchronize()
@@ -78,21 +82,22 @@ def big():
             res[(mode, len(its))] = xh.copy()
         dt5 = (time.perf_counter() - t5) / len(sigs)
         st = h5.stats()
-        print("configs[4] screen_single %d: %.3f ms per solve (incl. the copy of x to the host), iterations %s, supports exact %d / %d, max rel coef err %.2e, "
-              "screened %d redone %d headroom %.3f" % (mode, dt5 * 1e3, its, ok, len(sigs), cerr, st["screen_signals"], st["screen_redone"],
+        print("configs[4] screen_single %d first16 %d: %.3f ms per solve (incl. the copy of x to the host), iterations %s, supports exact %d / %d, max rel coef err %.2e, "
+              "screened %d redone %d headroom %.3f" % (mode, first16, dt5 * 1e3, its, ok, len(sigs), cerr, st["screen_signals"], st["screen_redone"],
                                                       st["screen_headroom"]), flush=True)
     d = max(np.abs(res[(1, i)] - res[(0, i)]).max() / np.abs(res[(0, i)]).max() for i in range(1, len(sigs) + 1))
     print("screened vs default engine: max |x - x'| / max |x| = %.2e" % d)
     # clean timing without host copies
-    for mode in (1, 0):
+    for mode, first16 in ((1, 1), (1, 0), (0, 0)):
         h5.set_option("screen_single", mode)
+        h5.set_option("screen_first16", first16)
         h5.solve(sigs[0][0], 1e-9, 512, out=x5)
         torch.cuda.synchronize()
         t5 = time.perf_counter()
         for r in range(3):
             h5.solve(sigs[r + 1][0], 1e-9, 512, out=x5)
         torch.cuda.synchronize()
-        print("configs[4] screen_single %d: %.3f ms per solve" % (mode, (time.perf_counter() - t5) / 3 * 1e3), flush=True)
+        print("configs[4] screen_single %d first16 %d: %.3f ms per solve" % (mode, first16, (time.perf_counter() - t5) / 3 * 1e3), flush=True)
     h5.close()
 
 
