@@ -7,9 +7,11 @@
 // (column i outside the subset, state k of the path): is |c_i| = |a_i . r_k| below lambda_k — by how much is irrelevant.
 // Here it is answered by ONE pass over a half-precision copy of A with a rigorous error bound:
 //
+//   k_scr_first    (option screen_first16, the default) c~0 = A16^T y over the half-precision copy instead of the fp32 sweep: the
+//                  ranking only — see the kernel's comment; state 0 is then certified like every other
 //   k_sub_select   the 448 columns with the largest |c0| (subbatch.hip)
 //   k_sgram_part / k_sgram_sum    Gs = A_S^T A_S of those columns from the fp32 A (v_mfma_f32_32x32x2_f32, 8 row chunks
-//                  summed in a fixed order: deterministic)
+//                  summed in a fixed order: deterministic); with k_scr_first: their exact fp32 c0 = a_j . y beside the sum
 //   k_sub_solve    the whole path on the subset, all arithmetic in fp32 on Gs (subbatch.hip, gsub = 1): this is what is
 //                  REPORTED — support, coefficients, iterations, lambda
 //   k_scr_residuals   r_k = y - A_S x_S(k) for every logged state k >= 1, in fp32, then scaled by a power of two and
