@@ -1262,7 +1262,10 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             set_err(err, errlen, "solve: internal error, device loop did not terminate");
             return SS_HIP_ERUNTIME;
         }
-        if (!ro && !omp && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun)) {
+        // (a tie met by the screened form's subset solve is a tie of the SUBSET's view — on a subset that cannot be certified it may not
+        // exist over all columns: such a signal goes to the default engine below, which meets the tie itself if it is real)
+        const bool scr_tie = scr1 && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun);
+        if (!ro && !omp && !scr_tie && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun)) {
             // a step-length scan met an exact tie (DevState::tie_stall): whether the strict t > 0 of the reference then
             // derails the path is decided by rounding — the reference-order engine is the arbiter
             ctx->stats.tie_reruns += 1;
@@ -1271,14 +1274,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         if (sub1 || scr1 || scr64) {
             // (a context whose signals the form hands back more often than not stops trying for a while)
             ctx->sub_seen += 1;
-            if (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail) ctx->sub_failed += 1;
+            if (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie) ctx->sub_failed += 1;
             if (ctx->sub_seen >= 8) {
                 if (2 * ctx->sub_failed > ctx->sub_seen) ctx->sub_off_solves = 64;
                 ctx->sub_seen = 0;
                 ctx->sub_failed = 0;
             }
         }
-        if ((scr1 || scr64) && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
+        if ((scr1 || scr64) && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie)) {
             ctx->stats.screen_redone += 1;
             if (std::getenv("SS_HIP_SUB_DEBUG"))
                 std::fprintf(stderr, "[screened form] status %u after %u iterations, %u states logged, K = %u, lambda %g, lambda0 %g\n",

@@ -65,6 +65,7 @@ constexpr uint32_t kScrRhs = 96;                 // right-hand sides of the scre
 constexpr uint32_t kScrCols = 128;               // dictionary columns per workgroup of the pass
 constexpr uint32_t kScrKc = 128;                 // rows per stage
 constexpr uint32_t kScrPitchB = kScrKc * 2 + 16; // bytes per LDS row: 272 (16-byte reads of 8 consecutive rows: conflict-free)
+constexpr uint32_t kScrWmax = 8192;              // floats of ScreenState::wmax (2 workgroups per CU x 8 waves)
 constexpr uint32_t kScrMeta = 8;                 // floats of ScreenState::meta
 constexpr uint32_t kScrTab = 4;                  // floats per state in the table: 1 / (sA s_k), bound_k, 1 / s_k, spare
 constexpr uint32_t kSgSplit = 8;                 // row chunks of the subset Gram matrix (partials summed in order)
@@ -88,6 +89,7 @@ struct ScreenState {
     float* tab = nullptr;        // [kScrRhs][kScrTab]
     float* gs_part = nullptr;    // [kSgSplit][kSbS][kSbS]
     float* gs = nullptr;         // [kSbS][kSbS]
+    float* wmax = nullptr;       // [kScrWmax] k_scr_first: largest |c~0| per wave of its launch (the selection's floor)
     int gemm_attr = -1;
     // a batch chunk in the screened form (kScrBatch slots): every slot its own residual block, subset Gram matrix, table
     __half* b_r16 = nullptr;     // [kScrBatch][kScrRhs][ldm]
@@ -170,7 +172,7 @@ void k_a16_convert(const T* __restrict__ At, size_t total8, const float* __restr
 template <typename TY, int CPW, int DEPTH>
 __global__ __launch_bounds__(512, 2)
 void k_scr_first(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, uint32_t ngroups, const TY* __restrict__ y,
-                 float* __restrict__ meta, float* __restrict__ c0h, uint32_t skew)
+                 float* __restrict__ meta, float* __restrict__ c0h, uint32_t skew, float* __restrict__ wmax)
 {
     // (TY = double: the fp64 form — y is rounded to fp32 on its way into LDS: 2^-24 per entry, inside the bound's 2^-9)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -195,6 +197,7 @@ void k_scr_first(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, uint3
     __syncthreads();
     const float inv_sA = meta[1];
     const uint32_t nsteps = ldm >> 9;
+    float wmx = 0.f;                                             // largest |c~0| of this wave's columns: the selection's floor comes from these
     for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const uint32_t col0 = g * (8u * CPW) + wave * CPW;
         const char* cb[CPW];
@@ -249,8 +252,10 @@ void k_scr_first(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, uint3
             const float v = wave_sum(acc[c]) * inv_sA;
             const uint32_t col = col0 + (uint32_t)c;
             if (lane == 0u) c0h[col] = col < n ? v : 0.f;
+            if (col < n) wmx = fmaxf(wmx, fabsf(v));
         }
     }
+    if (wmax != nullptr && lane == 0u) wmax[blockIdx.x * 8u + wave] = wmx;
 }
 
 // ---- Gs = A_S^T A_S of the 448 subset columns, from the fp32 A ------------------------------------------------------
@@ -1058,7 +1063,7 @@ void screen_free(ss_hip_ctx* ctx)
 {
     ScreenState* S = scr_of(ctx);
     if (!S) return;
-    void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->cabs, S->sublist, S->xsub, S->xd, S->ctl,
+    void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->wmax, S->cabs, S->sublist, S->xsub, S->xd, S->ctl,
                      S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1113,6 +1118,7 @@ bool screen_form_usable(ss_hip_ctx* ctx)
     alloc(reinterpret_cast<void**>(&S->tab), (size_t)kScrRhs * kScrTab * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->gs_part), (size_t)kSgSplit * kSbS * kSbS * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->gs), (size_t)kSbS * kSbS * sizeof(float));
+    alloc(reinterpret_cast<void**>(&S->wmax), (size_t)kScrWmax * sizeof(float));
     if (ok) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)scr_gemm_lds(kS64Sub));
@@ -1157,14 +1163,16 @@ bool screen_first16_usable(const ss_hip_ctx* ctx)
 
 // c~0 = A16^T y / sA into c0h ([n_pad] floats), ||y||^2 into meta[5]
 template <typename TY>
-static hipError_t launch_scr_first(ss_hip_ctx* ctx, ScreenState* S, const TY* y, float* c0h)
+static hipError_t launch_scr_first(ss_hip_ctx* ctx, ScreenState* S, const TY* y, float* c0h, float* wmax = nullptr, uint32_t* nwmax = nullptr)
 {
     const uint32_t ldm = ctx->ldm, np = ctx->n_pad;
     const size_t lds = (size_t)ldm * sizeof(float) + 64;
     if (lds > 65536u && !scr_first_attr<TY>()) return hipErrorInvalidConfiguration;
     const uint32_t grid = std::min<uint32_t>(np / 32u, (uint32_t)ctx->num_cus * 2u);
+    if (grid * 8u > kScrWmax) wmax = nullptr;
     hipLaunchKernelGGL((k_scr_first<TY, 4, 3>), dim3(grid), dim3(512), lds, ctx->stream, (const __half*)S->a16, ldm, (uint32_t)ctx->n, np / 32u, y,
-                       S->meta, c0h, scr_skew() == 0u ? 0u : 5u);
+                       S->meta, c0h, scr_skew() == 0u ? 0u : 5u, wmax);
+    if (nwmax != nullptr) *nwmax = wmax != nullptr ? grid * 8u : 0u;
     return hipGetLastError();
 }
 
@@ -1179,12 +1187,13 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     const float* At = static_cast<const float*>(ctx->At);
     const uint32_t nsplit = (ldm % (kSgSplit * kSgStep) == 0) ? kSgSplit : 4u;        // (ldm is a multiple of 256)
     constexpr uint32_t NT = kSbS / kSgT;
+    uint32_t nwmax = 0;
     if (first16) {
         if (e0) (void)hipEventRecord(e0, s);
-        { const hipError_t ef = launch_scr_first<float>(ctx, S, (const float*)ws.rhs, ws.c0); if (ef != hipSuccess) return ef; }
+        { const hipError_t ef = launch_scr_first<float>(ctx, S, (const float*)ws.rhs, ws.c0, S->wmax, &nwmax); if (ef != hipSuccess) return ef; }
         if (e1) (void)hipEventRecord(e1, s);
     }
-    (void)launch_sub_select(ctx, B, 1, ws.c0, first16 ? S->meta + 6 : nullptr);
+    (void)launch_sub_select(ctx, B, 1, ws.c0, first16 ? S->meta + 6 : nullptr, nwmax != 0u ? (const float*)S->wmax : nullptr, nwmax);
     hipLaunchKernelGGL(k_sgram_part, dim3(NT * (NT + 1) / 2, nsplit), dim3(256), 0, s, At, ldm, n, (const uint32_t*)B.sub, ldm / nsplit, S->gs_part);
     hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256 + (first16 ? kSbS : 0u)), dim3(256), 0, s, (const float*)S->gs_part, nsplit, S->gs,
                        At, ldm, (const float*)ws.rhs, (const uint32_t*)B.sub, n, ws.c0);

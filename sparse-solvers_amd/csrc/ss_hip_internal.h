@@ -422,7 +422,8 @@ size_t sub_buffer_bytes(uint32_t nslots);
 // the form's buffers inside ss_hip_ctx::sub_buf (sized by sub_buffer_bytes(nslots)) and its three stages on the context's stream
 struct SubBufs { uint32_t* sub; uint32_t* fpick; float* fval; uint32_t* hdr; uint32_t* pcol; float* LX; float* LD; };
 SubBufs sub_bufs(ss_hip_ctx* ctx, uint32_t nslots);
-hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0, float* thr_out = nullptr);
+hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0, float* thr_out = nullptr, const float* wmax = nullptr,
+                             uint32_t nwmax = 0);
 hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs& B, uint32_t nslots, const float* G, uint32_t gpitch, int gsub,
                             const float* c0, float tol, uint32_t max_iter, uint32_t g_slot_stride = 0);
 hipError_t launch_sub_finish(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots);

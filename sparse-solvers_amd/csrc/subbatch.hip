@@ -168,8 +168,15 @@ void k_sub_select(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint
 constexpr uint32_t kSel1Threads = 1024, kSel1J = 16;
 __global__ __launch_bounds__(kSel1Threads)
 void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ sub,
-                   uint32_t* __restrict__ first_pick, float* __restrict__ first_val, float* __restrict__ thr_out)
+                   uint32_t* __restrict__ first_pick, float* __restrict__ first_val, float* __restrict__ thr_out,
+                   const float* __restrict__ wmax, uint32_t nwmax)
 {
+    // wmax != nullptr (screen.hip's half-precision first pass): the values are a RANKING aid, not the path's c0, and the pass
+    // left the maxima of its waves' columns in wmax[nwmax] — elements, so the floor comes from those without a walk — and the
+    // selection stops at the 11-bit key (exponent + 3 mantissa bits): the 448 largest by that key, left-most first within the
+    // threshold key; thr_out = the end of that key's range.  No first pick (k_sub_solve takes it from the subset's exact c0).
+    const bool coarse = wmax != nullptr;
+    const uint32_t kshift = coarse ? 20u : 9u;
     constexpr uint32_t NW = kSel1Threads / 64u;
     __shared__ uint32_t hist[kSelBins];
     __shared__ uint32_t m_sel[kSel1Threads * 2u], m_eq[kSel1Threads * 2u];
@@ -214,10 +221,13 @@ void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uin
     // (a few hundred to a few thousand of 65536) enter the histograms.  (All 65536 in one histogram: their magnitudes share a
     // handful of bins and the LDS atomics on those serialise.)
     uint32_t prefix_key = 0, above = 0, floor_bin = 0;
-    for (int level = -1; level < 2; ++level) {
+    for (int level = -1; level < (coarse ? 1 : 2); ++level) {
         hist[2u * t] = 0u; hist[2u * t + 1u] = 0u;
         __syncthreads();
-        if (level == -1) {
+        if (level == -1 && coarse) {
+            for (uint32_t i = t; i < nwmax; i += kSel1Threads) atomicAdd(&hist[mag_bits(wmax[i]) >> 20], 1u);
+            if (nwmax < want) floor_bin = 0u;
+        } else if (level == -1) {
             float bv = -1.f;
             uint32_t bi = 0xffffffffu, mmax = 0u;
             bool any = false;
@@ -250,11 +260,11 @@ void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uin
         else { prefix_key = (prefix_key << 11) | s_bin; above = s_above; }
         __syncthreads();
     }
-    const uint32_t T22 = prefix_key;
+    const uint32_t T22 = prefix_key;                              // (coarse: the 11-bit key)
     const uint32_t need_eq = want - above;
     // (what every column left out stays below: the end of the threshold key's range — screen.hip's half-precision first pass)
-    if (thr_out != nullptr && t == 0) thr_out[0] = __uint_as_float(T22 + 1u >= (0x7f800000u >> 9) ? 0x7f800000u : (T22 + 1u) << 9);
-    SEL1_WALK({ (void)val; const uint32_t k = m >> 9;
+    if (thr_out != nullptr && t == 0) thr_out[0] = __uint_as_float(T22 + 1u >= (0x7f800000u >> kshift) ? 0x7f800000u : (T22 + 1u) << kshift);
+    SEL1_WALK({ (void)val; const uint32_t k = m >> kshift;
                 if (k > T22) atomicOr(&m_sel[i >> 5], 1u << (i & 31u));
                 else if (k == T22) atomicOr(&m_eq[i >> 5], 1u << (i & 31u)); })
 #undef SEL1_WALK
@@ -989,11 +999,12 @@ SubBufs sub_bufs(ss_hip_ctx* ctx, uint32_t nslots)
     return B;
 }
 
-hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0, float* thr_out)
+hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots, const float* c0, float* thr_out, const float* wmax, uint32_t nwmax)
 {
-    // (thr_out, one slot only: a value every column left out stays below)
+    // (thr_out, one slot only: a value every column left out stays below; wmax: see k_sub_select1)
     if (nslots == 1 && ctx->n_pad <= 4u * kSel1J * kSel1Threads)        // (one slot: the walking form, for latency)
-        hipLaunchKernelGGL(k_sub_select1, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, thr_out);
+        hipLaunchKernelGGL(k_sub_select1, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, thr_out,
+                           wmax, nwmax);
     else if (nslots == 1)                                               // (... in chunks of 65536 columns)
         hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS, thr_out);
     else

@@ -92,8 +92,8 @@ def test_screened_form_hands_back_what_it_cannot_certify(sship):
 def test_screened_form_crowded_first_state(sship, first16):
     """More than 448 columns within a few percent of lambda_0 (600 noisy copies of one atom): whatever subset is chosen,
     columns left out reach the bound of state 0 — with the first pass in half precision that is the state-0 certificate
-    (T + eps_0 against 0.875 lambda_0), with the fp32 first pass the certificate of state 1.  The signal goes back to the
-    default engine and is its result bit for bit."""
+    (T + eps_0 against 0.875 lambda_0), with the fp32 first pass the certificate of state 1 (or the subset's path meets a tie
+    of its own view first).  The signal goes back to the default engine and is its result bit for bit."""
     m, n, k = 1024, 8192, 12
     rng = np.random.default_rng(9250)
     A, y, x0, sup = make_gaussian_problem(9250, m, n, k, np.float32)
