@@ -215,14 +215,20 @@ void k_pack_records(const T* __restrict__ x, const uint32_t* __restrict__ gam2, 
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_epilogue(const uint32_t* __restrict__ st_words, uint32_t* __restrict__ hs_mapped, uint32_t st_nwords,
-                const T* __restrict__ x_src, T* __restrict__ x_dst, long long incx, uint32_t n)
+                const T* __restrict__ x_src, T* __restrict__ x_dst, long long incx, uint32_t n, uint32_t status_word, uint32_t flag_word)
 {
+    // status_word != 0xffffffff (the screened form of one signal): the verdict of its certificate — "a column was not certified"
+    // (the word at flag_word, raised by the screening pass) makes a clean status kStatusSubsetFail — is applied to the copy the host
+    // reads, instead of a launch of its own (k_sub_finish) before this one
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     if (x_dst != nullptr)
         for (uint32_t i = gtid; i < n; i += gsz) x_dst[(long long)i * incx] = x_src[i];
     if (blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < st_nwords; i += blockDim.x)
-            __hip_atomic_store(&hs_mapped[i], st_words[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (uint32_t i = threadIdx.x; i < st_nwords; i += blockDim.x) {
+            uint32_t w = st_words[i];
+            if (i == status_word && w == 0u && st_words[flag_word] != 0u) w = kStatusSubsetFail;
+            __hip_atomic_store(&hs_mapped[i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
 }
 
 template <typename T>
@@ -832,7 +838,8 @@ inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, u
         HIPCHK(hipMalloc(&ctx->sub_dbg, 16 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(ctx->sub_dbg, 0, 16 * sizeof(unsigned long long), ctx->stream));
     }
-    return launch_screen_form(ctx, ws, tol, max_iter, first16, e0, e1, e2, e3);
+    // (with the state mirrored to mapped host memory the epilogue launch applies the certificate's verdict: no k_sub_finish)
+    return launch_screen_form(ctx, ws, tol, max_iter, first16, ctx->hs_mapped == nullptr, e0, e1, e2, e3);
 }
 inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
 // (typed shims of the fp64 screened form: never reached for float)
@@ -949,7 +956,8 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 const uint32_t grid = x_on_device ? std::min<uint32_t>(((uint32_t)n + 1023u) / 1024u, 256u) : 1u;
                 hipLaunchKernelGGL((k_epilogue<T>), dim3(std::max(1u, grid)), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ws.st),
                                    static_cast<uint32_t*>(ctx->hs_mapped), (uint32_t)(sizeof(DevState) / 4), (const T*)ws.x,
-                                   x_on_device ? x : (T*)nullptr, (long long)incx, (uint32_t)n);
+                                   x_on_device ? x : (T*)nullptr, (long long)incx, (uint32_t)n,
+                                   scr1 ? (uint32_t)(offsetof(DevState, status) / 4) : 0xffffffffu, (uint32_t)(offsetof(DevState, need_sweep) / 4));
                 HIPCHK(hipGetLastError());
                 if (x && !x_on_device) copy_out<T>(ctx, x, incx, ws.x, n);
             } else {

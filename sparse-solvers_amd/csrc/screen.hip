@@ -324,11 +324,22 @@ void k_sgram_part(const float* __restrict__ At, uint32_t ldm, uint32_t n, const 
 #undef SGM_LOAD
     float* P = part + (size_t)chunk * kSbS * kSbS;
     const uint32_t gjj = bj * kSgT + 32u * wj + r;
+    // (the mirrored tile goes through LDS so that it, too, is written in 256-byte runs: lane-per-row stores of a column would be
+    // 4-byte writes 1792 bytes apart)
+    float* sT = &sI[0][0];                                        // [64][65]
+    constexpr uint32_t TP = kSgT + 1u;
+    static_assert(kSgT * (kSgT + 1u) <= kSgT * kSgPitchF, "transpose tile fits the staging buffer");
+    if (bi != bj) __syncthreads();                                // (uniform: the last step's operand reads are done)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const uint32_t gii = bi * kSgT + 32u * wi + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * h;
-        P[(size_t)gii * kSbS + gjj] = acc[e];
-        if (bi != bj) P[(size_t)gjj * kSbS + gii] = acc[e];
+        const uint32_t li = 32u * wi + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * h;
+        P[(size_t)(bi * kSgT + li) * kSbS + gjj] = acc[e];
+        if (bi != bj) sT[li * TP + 32u * wj + r] = acc[e];
+    }
+    if (bi != bj) {
+        __syncthreads();
+        for (uint32_t c = w; c < kSgT; c += 4u)
+            P[(size_t)(bj * kSgT + c) * kSbS + bi * kSgT + lane] = sT[lane * TP + c];
     }
 }
 
@@ -1176,8 +1187,8 @@ static hipError_t launch_scr_first(ss_hip_ctx* ctx, ScreenState* S, const TY* y,
     return hipGetLastError();
 }
 
-hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, hipEvent_t e0, hipEvent_t e1,
-                              hipEvent_t e2, hipEvent_t e3)
+hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, bool finish, hipEvent_t e0,
+                              hipEvent_t e1, hipEvent_t e2, hipEvent_t e3)
 {
     ScreenState* S = scr_of(ctx);
     if (S == nullptr || ctx->sub_buf == nullptr) return hipErrorInvalidConfiguration;
@@ -1206,7 +1217,8 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
                        (const float*)S->anorm, (const float*)S->rn2p, kScrRhs, (const float*)S->tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
                        ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew());
     if (e3) (void)hipEventRecord(e3, s);
-    (void)launch_sub_finish(ctx, ws, 1);
+    // (finish = false: the caller's epilogue launch turns "a column was not certified" into the status the host reads)
+    if (finish) (void)launch_sub_finish(ctx, ws, 1);
     return hipGetLastError();
 }
 
