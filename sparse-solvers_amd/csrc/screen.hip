@@ -555,7 +555,7 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     // nst_fixed = 0: the fp32 form — the number of states and the go-ahead come from the slot's state (k_sub_solve's log);
     // > 0: that many states (<= 32 NT) of the caller's block of right-hand sides (the fp64 form: r16, rn2p, tab point at it)
     constexpr int RH = 32 * NT, NPR = 2 * NT;
-    constexpr bool TWO = NT <= 3;
+    constexpr bool TWO = NT <= 4;                               // (4 tiles: 128 states — configs[4] — with two register sets)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t nst = nst_fixed;
     if (nst_fixed == 0u || nst_fixed == 0xffffffffu) {
@@ -1329,7 +1329,9 @@ bool screen64_usable(ss_hip_ctx* ctx)
                                                  (int)scr_gemm_lds(kS64Sub, 3));
         const hipError_t e5 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   (int)scr_gemm_lds(kS64Sub, 5));
-        if (e != hipSuccess || e5 != hipSuccess) { (void)hipGetLastError(); ok = false; }
+        const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)scr_gemm_lds(kS64Sub, 4));
+        if (e != hipSuccess || e5 != hipSuccess || e4 != hipSuccess) { (void)hipGetLastError(); ok = false; }
     }
     if (ok) {
         char err[256];
@@ -1407,8 +1409,14 @@ hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double
     // (up to 160 states in ONE pass over the fp16 copy — five tiles of 32 per workgroup —, the rest in passes of 96)
     for (uint32_t k0 = 0; k0 < T;) {
         const bool wide = T - k0 > kScrRhs;
+        const bool four = wide && T - k0 <= 128u;                 // (up to 128 states: four tiles, two register sets of loads in flight)
         const uint32_t cnt = std::min<uint32_t>(wide ? 160u : kScrRhs, T - k0);
-        if (wide)
+        if (four)
+            hipLaunchKernelGGL(k_scr_gemm<4>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 4), s, (const __half*)S->a16, ldm, n,
+                               (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
+                               (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
+                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew());
+        else if (wide)
             hipLaunchKernelGGL(k_scr_gemm<5>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 5), s, (const __half*)S->a16, ldm, n,
                                (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
                                (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
