@@ -642,6 +642,8 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
     # over A beyond A^T y
     with_gram = None
     if batched is not None:
+        # (the screened form would take these signals — it is the faster of the two: option screen_single = 0 for this section)
+        h.set_option("screen_single", 0)
         h.solve(sigs[0][0], TOL, MAX_ITER, out=xw)                # (first solve in this mode fills the identity map)
         torch.cuda.synchronize()
         tg = time.perf_counter()
@@ -652,8 +654,10 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         dtg = time.perf_counter() - tg
         okg = int(((Xg != 0) == (X != 0)).all(dim=1).sum().item())
         del Xg
+        h.set_option("screen_single", 1)
         with_gram = {"workload": "the same single-signal solves with G = A^T A (17 GiB) in HBM (formed by the batch above; option gram_full_after "
-                                 "forms it after that many single solves): A^T y, then the subset form of the batches for ONE signal — one "
+                                 "forms it after that many single solves) and option screen_single = 0 (by default the screened form takes single "
+                                 "signals on such a context too: the timed region's rate): A^T y, then the subset form of the batches for ONE signal — one "
                                  "workgroup on 448 columns, every breakpoint checked against all columns — no pass over A beyond A^T y",
                      "signals_per_s": args.steps / dtg, "ms_per_solve": dtg / args.steps * 1e3,
                      "same_support_as_timed_solves": okg}

@@ -385,7 +385,8 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    solves the path on a sub-dictionary of the 2048 columns with the largest |c0| (a context of its own).
  *                    2 = on every shape the form can run on (tests); 0 = never.  Initial value: environment variable
  *                    SS_HIP_SCREEN_SINGLE when set.  Stands in for the default speculative engine only ("la_fused" = 3,
- *                    "early_solo" = 1); with G = A^T A in HBM the subset form on G is used instead ("gram_single").
+ *                    "early_solo" = 1); with G = A^T A in HBM the subset form on G ("gram_single") is used instead only where the
+ *                    half-precision first pass ("screen_first16") does not apply — with it the screened form is the faster one.
  *   "screen_first16" 1 (default) = the screened form of one fp32 signal reads the fp16 copy for its FIRST pass too (row counts padded to
  *                    a multiple of 512, at most 15872): c~0 = A16^T y ranks the columns, the exact fp32 c0 of the 448 chosen ones
  *                    is formed beside their Gram matrix (lambda_0, the first pick and the path come from those), and state 0 is

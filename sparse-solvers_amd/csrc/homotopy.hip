@@ -932,14 +932,17 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         // With G = A^T A at hand (a large batch has run on the context, or option gram_full_after) a single signal takes the
         // subset form of the batches (subbatch.hip): A^T y, one workgroup on 448 columns, the check over all columns — no
         // pass over A beyond A^T y.  What the form does not vouch for is solved again the usual way (no_sub).
+        // (where the screened form below applies it is the faster of the two since its first pass reads the fp16 copy — 0.82 ms against
+        // 1.16 at configs[1] — and takes the signal; option screen_single = 0 leaves it to this form)
         bool sub1 = la && sizeof(T) == 4 && !no_sub && ctx->batch_subset && ctx->gram_single && ctx->gram_full != nullptr &&
                     sub_form_usable(ctx);
         // Without G: the screened form (screen.hip) — the same subset solve on the subset's own Gram matrix (formed from A), every
         // state of its path then screened against all columns by ONE pass over a half-precision copy of A with a rigorous error
         // bound, instead of the default engine's two fp32 passes.  It stands in for the default speculative engine only
         // (la_fused = 3 with the early form: contexts whose options ask for another engine get that engine).
-        bool scr1 = la && sizeof(T) == 4 && !no_sub && !sub1 && ctx->la_fused >= 3 && ctx->early_solo && !ctx->early_probe &&
-                    ctx->solo_subset == 256 && screen_form_usable(ctx);
+        bool scr1 = la && sizeof(T) == 4 && !no_sub && ctx->la_fused >= 3 && ctx->early_solo && !ctx->early_probe &&
+                    ctx->solo_subset == 256 && (!sub1 || screen_first16_usable(ctx)) && screen_form_usable(ctx);
+        if (scr1) sub1 = false;
         // fp64: the same certificate around the fp64 engine — the path is solved by a context of its own on the 2048 columns with
         // the largest |c0| (passes and iterations on 1.6 % of the dictionary), its logged states are screened against all columns
         // (not with a trace or compact records asked for: the sub-context's lists are over ITS columns)

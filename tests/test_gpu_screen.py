@@ -113,6 +113,32 @@ def test_screened_form_crowded_first_state(sship, first16):
     assert it1 == it0 and e1 == e0 and np.array_equal(x1, x0_)
 
 
+def test_screened_form_on_a_context_with_gram_matrix(sship):
+    """A context that holds G = A^T A (here: option gram_full_after) used to send single signals through the subset form on G;
+    with the half-precision first pass the screened form is the faster of the two and takes them (option screen_single = 0
+    leaves them to the form on G).  Either way the oracle's result."""
+    m, n, k = 1024, 8192, 20
+    A, y, x0, sup = make_gaussian_problem(9260, m, n, k, np.float32)
+    xo, ito, eo = oracle.homotopy(A, y, 1e-3, 4 * k)
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 0)
+        h.set_option("gram_full_after", 1)
+        x0_, it0, e0 = h.solve(y, 1e-3, 4 * k)
+        assert h.stats()["gram_full_builds"] == 1
+        h.reset_stats()
+        xg, itg, eg = h.solve(y, 1e-3, 4 * k)                     # the subset form on G
+        stg = h.stats()
+        h.set_option("screen_single", 2)
+        h.reset_stats()
+        xs, its, es = h.solve(y, 1e-3, 4 * k)                     # the screened form, G or not
+        sts = h.stats()
+    assert stg["subset_signals"] == 1 and stg["screen_signals"] == 0
+    assert sts["screen_signals"] == 1 and sts["subset_signals"] == 0
+    for (x_, it_, e_) in ((x0_, it0, e0), (xg, itg, eg), (xs, its, es)):
+        assert_parity(x_, it_, e_, xo, ito, eo, np.float32)
+        assert np.array_equal(significant_support(x_, 1e-4), sup)
+
+
 def test_screen_certificate_is_a_bound(sship):
     """The certificate of csrc/screen.hip, recomputed on the host in float64 from the solve's own breakpoints: for every state
     of the path and every column outside the 448-column subset, |a_i . r_k| in float64 must be below lambda_k by at least
