@@ -428,7 +428,7 @@ hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs
                             const float* c0, float tol, uint32_t max_iter, uint32_t g_slot_stride = 0);
 hipError_t launch_sub_finish(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots);
 hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval,
-                             float* thr_out = nullptr);
+                             float* thr_out = nullptr, const float* wmax = nullptr, uint32_t nwmax = 0);
 // screened form of ONE signal (screen.hip): the subset form on the subset's own Gram matrix (formed from A), every state of
 // the path then screened against all columns by one pass over a half-precision copy of A with a rigorous error bound
 bool screen_form_usable(ss_hip_ctx* ctx);                 // shape / option test + one-time preparation (fp16 copy of A, column norms)

@@ -293,11 +293,16 @@ void k_sub_select1(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uin
 // (which would need n bits): the < 448 above the threshold key and the columns OF the key, of which the left-most are
 // taken — by counting ranks, the lists are short.  Should the key's list overflow (thousands of equal magnitudes) the
 // columns are written out by an ordered walk instead (two block-wide prefix sums per 4096 columns: slow, and only then).
-constexpr uint32_t kSel1ECap = 1024, kSel1SCap = 2048;
+constexpr uint32_t kSel1ECap = 2048, kSel1SCap = 2048;          // (the 11-bit key's threshold bin holds up to ~1000 columns)
 __global__ __launch_bounds__(kSel1Threads)
 void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ sub,
-                    uint32_t* __restrict__ first_pick, float* __restrict__ first_val, uint32_t nsel, float* __restrict__ thr_out)
+                    uint32_t* __restrict__ first_pick, float* __restrict__ first_val, uint32_t nsel, float* __restrict__ thr_out,
+                    const float* __restrict__ wmax, uint32_t nwmax)
 {
+    // (wmax != nullptr: the ranking after screen.hip's half-precision first pass — floor from the pass's wave maxima, 11-bit key,
+    // no first pick: see k_sub_select1)
+    const bool coarse = wmax != nullptr;
+    const uint32_t kshift = coarse ? 20u : 9u;
     // nsel <= kSel1SCap columns are selected (kSbS for the subset form; the fp64 screened form's sub-dictionary takes 2048)
     constexpr uint32_t NW = kSel1Threads / 64u;
     constexpr uint32_t CH = 4u * kSel1J * kSel1Threads;          // columns per chunk of a walk
@@ -336,10 +341,12 @@ void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, ui
         }                                                                                      \
     }
     uint32_t prefix_key = 0, above = 0, floor_bin = 0;
-    for (int level = -1; level < 2; ++level) {
+    for (int level = -1; level < (coarse ? 1 : 2); ++level) {
         hist[2u * t] = 0u; hist[2u * t + 1u] = 0u;
         __syncthreads();
-        if (level == -1) {
+        if (level == -1 && coarse) {
+            for (uint32_t i = t; i < nwmax; i += kSel1Threads) atomicAdd(&hist[mag_bits(wmax[i]) >> 20], 1u);
+        } else if (level == -1) {
             float bv = -1.f;
             uint32_t bi = 0xffffffffu, mmax = 0u;
             bool any = false;
@@ -372,16 +379,16 @@ void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, ui
     }
     const uint32_t T22 = prefix_key;
     const uint32_t need_eq = want - above;
-    if (thr_out != nullptr && t == 0) thr_out[0] = __uint_as_float(T22 + 1u >= (0x7f800000u >> 9) ? 0x7f800000u : (T22 + 1u) << 9);
-    SEL1W_WALK({ (void)val; const uint32_t k = m >> 9;
+    if (thr_out != nullptr && t == 0) thr_out[0] = __uint_as_float(T22 + 1u >= (0x7f800000u >> kshift) ? 0x7f800000u : (T22 + 1u) << kshift);
+    SEL1W_WALK({ (void)val; const uint32_t k = m >> kshift;
                  if (k > T22) { const uint32_t p_ = atomicAdd(&s_ns, 1u); if (p_ < nsel) s_list[p_] = i; }
                  else if (k == T22) { const uint32_t p_ = atomicAdd(&s_ne, 1u); if (p_ < kSel1ECap) e_list[p_] = i; } })
     __syncthreads();
     const uint32_t ns = s_ns, ne = s_ne;                       // (ns = `above` < want)
     if (ne <= kSel1ECap) {
         // the need_eq left-most columns of the key join the list; then every entry goes to its rank
-        if (t < ne) {
-            const uint32_t me = e_list[t];
+        for (uint32_t q = t; q < ne; q += kSel1Threads) {
+            const uint32_t me = e_list[q];
             uint32_t rank = 0;
             for (uint32_t e = 0; e < ne; ++e) rank += e_list[e] < me ? 1u : 0u;
             if (rank < need_eq && ns + rank < nsel) s_list[ns + rank] = me;
@@ -405,7 +412,7 @@ void k_sub_select1w(const float* __restrict__ c0, uint32_t n, uint32_t n_pad, ui
             for (int e = 0; e < 4; ++e) {
                 const uint32_t i = base + (uint32_t)e;
                 if (i >= n) continue;
-                const uint32_t k = mag_bits(v[e]) >> 9;
+                const uint32_t k = mag_bits(v[e]) >> kshift;
                 if (k > T22) isel |= 1u << e; else if (k == T22) ieq |= 1u << e;
             }
             uint32_t tot = 0;
@@ -1006,7 +1013,8 @@ hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots,
         hipLaunchKernelGGL(k_sub_select1, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, thr_out,
                            wmax, nwmax);
     else if (nslots == 1)                                               // (... in chunks of 65536 columns)
-        hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS, thr_out);
+        hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS, thr_out,
+                           wmax, nwmax);
     else
         hipLaunchKernelGGL(k_sub_select, dim3(nslots), dim3(kSelThreads), 0, ctx->stream, c0, (uint32_t)ctx->n, ctx->n_pad, B.sub, B.fpick, B.fval, kSbS);
     return hipGetLastError();
@@ -1014,10 +1022,11 @@ hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots,
 
 // the nsel columns with the largest |v| of ONE vector, ascending (screen.hip's fp64 form: v = float(|A^T y|))
 hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval,
-                             float* thr_out)
+                             float* thr_out, const float* wmax, uint32_t nwmax)
 {
-    // (thr_out: a value every entry left out stays below; only the one-workgroup kernel reports it — nsel <= kSel1SCap)
-    if (nsel <= kSel1SCap) hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel, thr_out);
+    // (thr_out: a value every entry left out stays below; only the one-workgroup kernel reports it — nsel <= kSel1SCap; wmax: see k_sub_select1)
+    if (nsel <= kSel1SCap) hipLaunchKernelGGL(k_sub_select1w, dim3(1), dim3(kSel1Threads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel, thr_out,
+                                              wmax, nwmax);
     else if (thr_out != nullptr) return hipErrorInvalidConfiguration;
     else hipLaunchKernelGGL(k_sub_select, dim3(1), dim3(kSelThreads), 0, ctx->stream, v, n, n_pad, sub, fpick, fval, nsel);
     return hipGetLastError();

@@ -1,5 +1,5 @@
 """The screened form across dictionary widths (m = 8192, k = 64, fp32): ms per solve with and without it, and the time the
-bytes alone would take at the rates of configs[1] (A^T y at 6.6 TB/s + the fp16 pass at 5.9 TB/s)."""
+bytes alone would take at the rates of configs[1] (the two passes over the fp16 copy at 6.5 and 5.9 TB/s)."""
 import os, sys, time
 import numpy as np
 import torch
@@ -33,6 +33,6 @@ for N in (17000, 24000, 32768, 49152, 65536, 98304, 131072, 196608, 262144):
             st = h.stats()
             out.append("%s %.3f ms (certified %d, redone %d)" % ("screened" if mode else "default engine", (time.perf_counter() - t0) / len(sigs[2:]) * 1e3,
                                                               st["screen_signals"], st["screen_redone"]))
-        floor = M * N * 4 / 6.6e9 + M * N * 2 / 5.9e9 + 0.38 + 0.09          # + 64 iterations + select / Gs / tail
+        floor = M * N * 2 / 6.5e9 + M * N * 2 / 5.9e9 + 0.38 + 0.07          # + 64 iterations + select / Gs / tail
         print("n = %6d  %s | %s | bytes + iterations: %.3f ms" % (N, out[0], out[1], floor), flush=True)
     torch.cuda.empty_cache()
