@@ -8,8 +8,9 @@ N = 1 — configs[1], the configuration the metric is quoted on: a step is ONE H
 (A 8192 x 65536 fp32, k = 64) with inputs resident in HBM; `value` = signals/s; `roofline` = the dominant HBM
 kernel — in the screened form (csrc/screen.hip, the default) the correlation GEMV of the metric itself, c~0 = A16^T y
 over the half-precision copy of A (k_scr_first; priced on the bytes of that copy, with SURVEY 8d's fp32 figure beside
-it) —, timed live with HIP events on the solver's stream; `screening_pass` = the second pass over the fp16 copy, which
-certifies the path; `fp32_first_pass` / `atr_gemv` = the same form with c0 = A^T y by the fp32 sweep (k_sweep);
+it) —, timed live with HIP events on the solver's stream, its `traffic` measured in the same run (two short child runs of
+tools/pmc_probe.py under `rocprofv3 --pmc`; profiles/traffic.json only as the labelled fallback); `screening_pass` = the second
+pass over the fp16 copy, which certifies the path; `fp32_first_pass` / `atr_gemv` = the same form with c0 = A^T y by the fp32 sweep (k_sweep);
 `without_screening` / `lookahead_sweep_32rhs` = the engine behind it (three fp32 passes over A); those outside the timed
 region.  Outside the timed region the same run also reports: configs[2] (a batch of 4096 signals
 sharing A, with the MFMA roofline of the G = A^T A build and the HBM roofline of the Gram-form pass), a 64-signal
@@ -155,6 +156,71 @@ def cpu_baseline(A, y, h, y_dev, iters_full, budget_s):
     return out
 
 
+def measure_traffic_live(timeout_s=150.0):
+    """HBM bytes per launch of the two passes over the fp16 copy, measured NOW: two child runs of tools/pmc_probe.py under
+    `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE: separate passes, as MI355X_MICROARCH.md prescribes; gfx950 corrections: FETCH_SIZE
+    KiB x 1024 x 2, WRITE_SIZE KiB x 1024).  -> {"first16": bytes, "screen": bytes, ...} or None (no rocprofv3, a profiler
+    already attached to this process, a child that failed or ran out of time: the caller then replays profiles/traffic.json and
+    says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    if any(k.startswith("ROCP") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None                                   # (this run is itself being profiled: no nested profiler)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    got = {}
+    t_start = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ss_pmc_", dir="/tmp")
+        try:
+            left = timeout_s - (time.perf_counter() - t_start)
+            if left < 20.0:
+                return None
+            # (the program itself after `--`: no env / shell hop between the profiler and python)
+            p = subprocess.Popen([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                  os.path.join(ROOT, "tools", "pmc_probe.py")], cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=left)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, 9)               # (exactly the process group this call started)
+                except OSError:
+                    pass
+                p.wait()
+                return None
+            if rc != 0:
+                return None
+            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if not files:
+                return None
+            per = {}
+            for r in csv.DictReader(open(files[0])):
+                if r.get("Counter_Name") != counter:
+                    continue
+                for key, sub in (("first16", "k_scr_first"), ("screen", "k_scr_gemm")):
+                    if sub in r["Kernel_Name"]:
+                        per.setdefault(key, []).append(float(r["Counter_Value"]))
+            for key, vals in per.items():
+                vals = [v for v in vals if v >= 0.5 * max(vals)]
+                got.setdefault(key, {})[counter] = (sum(vals) / len(vals), len(vals))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for key, c in got.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            out[key] = c["FETCH_SIZE"][0] * 1024.0 * 2.0 + c["WRITE_SIZE"][0] * 1024.0
+            out[key + "_launches"] = min(c["FETCH_SIZE"][1], c["WRITE_SIZE"][1])
+    out["seconds"] = time.perf_counter() - t_start
+    return out if "first16" in out else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +237,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096,
                     help="signals per rank of the batched workload (configs[2] / configs[3]; 0 = skip the N = 1 extra)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not start the rocprofv3 --pmc child runs that measure roofline.traffic in this run (then replayed from profiles/traffic.json)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the drop-in, OMP and fp64 (configs[4]) extras (single-GPU runs only)")
     ap.add_argument("--cpu-budget-s", type=float, default=24.0)
@@ -672,6 +740,17 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                 tj = json.load(open(tpath))
             except Exception:
                 tj = {}
+        # roofline.traffic of the two passes over the fp16 copy: measured in THIS run by two short child runs under rocprofv3 --pmc
+        # (tools/pmc_probe.py; ~25 s) — profiles/traffic.json is the fallback, labelled as a replay
+        live = None
+        if world == 1 and st["first16_launches"] > 0 and not args.no_live_traffic:
+            try:
+                live = measure_traffic_live()
+            except Exception:
+                live = None
+        live_src = ("measured in this run: child runs of tools/pmc_probe.py (4 configs[1] solves) under rocprofv3 --pmc FETCH_SIZE and "
+                    "--pmc WRITE_SIZE (separate passes), FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024 (gfx950 corrections), mean over "
+                    "%d launches; %.0f s" % (live.get("first16_launches", 0), live.get("seconds", 0.0))) if live else None
         n_pad = (N + 255) // 256 * 256
         roof = None
         if engine >= 1 and st["sweep64_launches"] > 0:
@@ -742,12 +821,13 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                                               "half-precision copy of A (16-byte column loads, y in LDS, fp32 sums) — the first of the two passes "
                                               "over A16 of a solve in the screened form; no fp32 pass over A is left in a certified solve",
                     "achieved": f16_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f16_gbs / HBM_PEAK_GBS,
-                    "traffic": tj.get("first16_hbm_bytes_per_launch"), "bytes_per_launch": f16_bytes,
+                    "traffic": live["first16"] if live else tj.get("first16_hbm_bytes_per_launch"), "bytes_per_launch": f16_bytes,
                     "avg_launch_ms": f16_ms, "launches_timed": st["first16_launches"],
                     "by_survey_8d_fp32_bytes": {"bytes_per_launch": s8d, "achieved": s8d / (f16_ms * 1e-3) / 1e9 if f16_ms > 0 else 0.0,
                                                 "frac": (s8d / (f16_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if f16_ms > 0 else 0.0},
-                    "traffic_source": ("profiles/traffic.json (%s): HBM bytes per launch from separate rocprofv3 --pmc passes (recorded once, "
-                                       "replayed here; NOT measured in this run)" % tj.get("first16_source")) if tj.get("first16_hbm_bytes_per_launch") else None}
+                    "traffic_source": live_src if live else
+                                      (("profiles/traffic.json (%s): HBM bytes per launch from separate rocprofv3 --pmc passes (recorded once, "
+                                        "replayed here; NOT measured in this run)" % tj.get("first16_source")) if tj.get("first16_hbm_bytes_per_launch") else None)}
         elif screened:
             # screened form with the fp32 first pass (option screen_first16 = 0, or a row count the half-precision first pass does not
             # take): the passes over A are c = A^T y (fp32, k_sweep) and the screening pass over the fp16 copy of A
@@ -765,7 +845,9 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             scr_roof = {"bound": "hbm", "kernel": "k_scr_gemm: C~ = A16^T [r_1 .. r_K] (v_mfma_f32_32x32x16_f16, 128 columns x 96 right-hand sides per "
                                                   "workgroup) + the certificate |c~| + eps <= bound of every (column outside the subset, state)",
                         "achieved": sc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sc_gbs / HBM_PEAK_GBS,
-                        "traffic": tj.get("screen_hbm_bytes_per_launch"), "bytes_per_launch": sc_bytes, "avg_launch_ms": sc_ms,
+                        "traffic": live["screen"] if (live and "screen" in live) else tj.get("screen_hbm_bytes_per_launch"),
+                        "traffic_source": live_src if (live and "screen" in live) else "profiles/traffic.json (replayed; NOT measured in this run)",
+                        "bytes_per_launch": sc_bytes, "avg_launch_ms": sc_ms,
                         "launches_timed": st["screen_launches"],
                         "certificate_headroom": st["screen_headroom"],
                         "note": "bytes = the fp16 copy of A (ldm * n_pad * 2) + the residual block + the column norms; headroom = largest "

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""A few configs[1] solves in the screened form — the child process of bench.py's live HBM-traffic measurement:
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir> -- python3 tools/pmc_probe.py
+
+(bench.py starts it once per counter, reads <dir>/**/*_counter_collection.csv and applies the gfx950 corrections of
+MI355X_MICROARCH.md: FETCH_SIZE KiB x 1024 x 2, WRITE_SIZE KiB x 1024.)  Nothing here reads /root/reference or oracle/."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sparse-solvers_amd", "python"))
+import sship  # noqa: E402
+
+M, N, K = 8192, 65536, 64
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(1234)
+A = torch.randn((M, N), generator=g, device=dev, dtype=torch.float32) / np.sqrt(M)      # (traffic does not depend on the entries)
+x = torch.zeros(N, device=dev)
+with sship.Homotopy(A, device=0) as h:
+    for s in range(4):
+        rng = np.random.default_rng(4000 + s)
+        sup = np.sort(rng.choice(N, K, replace=False))
+        coef = 1.0 + np.abs(rng.standard_normal(K))
+        y = (A[:, torch.from_numpy(sup).to(dev)].double() @ torch.from_numpy(coef).to(dev)).float().contiguous()
+        h.solve(y, 1e-3, 256, out=x)
+    st = h.stats()
+torch.cuda.synchronize()
+print("pmc_probe: %d solves, %d certified" % (st["solves"], st["screen_signals"]))
