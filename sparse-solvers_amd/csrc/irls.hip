@@ -161,6 +161,86 @@ void k_qr_apply_panel(T* __restrict__ At, const T* __restrict__ Vt, uint32_t ldm
     }
 }
 
+// A whole panel of nb <= 32 columns factored in ONE launch: workgroup j owns column k0 + j.  It applies the reflectors
+// k0 .. k0 + j - 1 to its column as each becomes available (k_qr_apply_panel's statements), then forms its own reflector
+// (k_qr_step's statements, its column being the pivot) and publishes it: Vt row, rdiag, then a flag — release / acquire at
+// agent scope, the pattern of arrive_last (ss_hip_device.h): the reader's leader spins on the flag, acquires, and the
+// workgroup reads the row with vector loads behind a barrier.  A workgroup only ever waits for lower-numbered ones, all
+// nb <= 32 workgroups are resident: no deadlock.  Same arithmetic per column in the same order as one launch per
+// reflector — the same bits — without the 32 launches (15.6 us each) of a panel.
+template <typename T>
+__global__ __launch_bounds__(kQrThreads)
+void k_qr_panel(T* __restrict__ At, T* __restrict__ Vt, T* __restrict__ rdiag, uint32_t ldm, uint32_t m, uint32_t k0,
+                uint32_t* __restrict__ ready)
+{
+    __shared__ T sv[16];
+    __shared__ uint32_t s_gave_up;
+    const uint32_t kown = k0 + blockIdx.x;
+    T* a = At + (size_t)kown * ldm;
+    if (threadIdx.x == 0) s_gave_up = 0u;
+    for (uint32_t k = k0; k < kown; ++k) {
+        if (threadIdx.x == 0) {
+            // (bounded: a producer that never shows up — it cannot happen with <= 32 resident workgroups — must not hang the device:
+            // the column then publishes a NaN diagonal, which every later stage carries into the result)
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&ready[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && spins < (1u << 26)) { __builtin_amdgcn_s_sleep(2); ++spins; }
+            if (spins >= (1u << 26)) s_gave_up = 1u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (s_gave_up != 0u) break;
+        const T* v = Vt + (size_t)k * ldm;
+        const T vk = v[k];
+        if (vk == T(0)) continue;                               // (a zero pivot column: the others are left alone)
+        T part = T(0);
+        for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) part += v[i] * a[i];
+        const T s = block_sum(part, sv) / -vk;
+        for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) a[i] += v[i] * s;
+        __syncthreads();
+    }
+    // my column is the pivot of step kown
+    const uint32_t k = kown;
+    const T* piv = a;
+    if (s_gave_up != 0u) {
+        for (uint32_t i = threadIdx.x; i < ldm; i += kQrThreads) Vt[(size_t)k * ldm + i] = T(0);
+        if (threadIdx.x == 0) rdiag[k] = T(0) / T(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(&ready[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    T amax = T(0);
+    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) amax = max(amax, t_abs(piv[i]));
+    amax = block_max(amax, sv);
+    T nrm2 = T(0);
+    if (amax > T(0)) {
+        T part = T(0);
+        for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) { const T z = piv[i] / amax; part += z * z; }
+        nrm2 = amax * sqrt(block_sum(part, sv));
+        __syncthreads();
+    }
+    if (nrm2 == T(0)) {
+        for (uint32_t i = threadIdx.x; i < ldm; i += kQrThreads) Vt[(size_t)k * ldm + i] = T(0);
+        if (threadIdx.x == 0) rdiag[k] = -nrm2;
+    } else {
+        if (piv[k] < T(0)) nrm2 = -nrm2;
+        const T vk = piv[k] / nrm2 + T(1);
+        for (uint32_t i = threadIdx.x; i < ldm; i += kQrThreads)
+            Vt[(size_t)k * ldm + i] = (i < k || i >= m) ? T(0) : (i == k ? vk : piv[i] / nrm2);
+        if (threadIdx.x == 0) rdiag[k] = -nrm2;
+    }
+    // publish: every wave's stores drained, then the leader releases and raises the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&ready[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // Back-accumulation of the thin Q, all steps of one column in one workgroup: column j of Q starts as e_j at step j and then
 // receives the reflectors j, j - 1, ... 0 — independent of every other column (k_qr_formq's statements, its order).
 template <typename T>
@@ -754,6 +834,7 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
     IRLS_TRY(hipMemsetAsync(S->Qt, 0, (size_t)n * ldm * sizeof(T), ctx->stream));
     IRLS_TRY(hipMemsetAsync(S->vec, 0, (5 * (size_t)n + 2 * (size_t)ldm) * sizeof(T), ctx->stream));
     T* At = static_cast<T*>(ctx->At);
+    uint32_t* qr_ready = nullptr;                                 // (flags of the one-launch panel kernel; freed below)
     if (std::getenv("SS_HIP_IRLS_FUSED")) {
         // (A/B aid: the round-2 form — every reflector a launch over all trailing columns)
         for (uint32_t k = 0; k < n; ++k) {
@@ -769,11 +850,22 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
         // applied to every trailing column in ONE launch; Q's columns are independent of each other: one launch for all of them.
         // Same arithmetic per column, in the same order: the same bits as the round-2 form.
         constexpr uint32_t NBQ = 32;
+        // (one flag per column for the one-launch panel kernel; SS_HIP_IRLS_QR_STEPS keeps a launch per reflector: A/B aid)
+        if (!std::getenv("SS_HIP_IRLS_QR_STEPS")) {
+            if (hipMalloc(&qr_ready, (size_t)n * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); qr_ready = nullptr; }
+            else if (hipMemsetAsync(qr_ready, 0, (size_t)n * sizeof(uint32_t), ctx->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(qr_ready); qr_ready = nullptr; }
+        }
+        uint32_t* const ready = qr_ready;
         for (uint32_t k0 = 0; k0 < n; k0 += NBQ) {
             const uint32_t nb = std::min<uint32_t>(NBQ, n - k0);
-            for (uint32_t k = k0; k < k0 + nb; ++k) {
-                hipLaunchKernelGGL((k_qr_step<T>), dim3(k0 + nb - k), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k);
+            if (ready != nullptr) {
+                hipLaunchKernelGGL((k_qr_panel<T>), dim3(nb), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k0, ready);
                 IRLS_TRY(hipGetLastError());
+            } else {
+                for (uint32_t k = k0; k < k0 + nb; ++k) {
+                    hipLaunchKernelGGL((k_qr_step<T>), dim3(k0 + nb - k), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k);
+                    IRLS_TRY(hipGetLastError());
+                }
             }
             if (k0 + nb < n) {
                 hipLaunchKernelGGL((k_qr_apply_panel<T>), dim3(n - (k0 + nb)), dim3(kQrThreads), 0, ctx->stream, At, (const T*)S->Vt, ldm, m, k0, nb);
@@ -787,6 +879,7 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
                        (const T*)S->rdiag, S->R, S->G0, ldm, m, n);
     IRLS_TRY(hipGetLastError());
     IRLS_TRY(hipStreamSynchronize(ctx->stream));
+    if (qr_ready != nullptr) (void)hipFree(qr_ready);
     return hipSuccess;
 }
 
