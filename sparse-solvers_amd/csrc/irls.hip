@@ -178,6 +178,7 @@ void k_qr_panel(T* __restrict__ At, T* __restrict__ Vt, T* __restrict__ rdiag, u
     const uint32_t kown = k0 + blockIdx.x;
     T* a = At + (size_t)kown * ldm;
     if (threadIdx.x == 0) s_gave_up = 0u;
+    __syncthreads();
     for (uint32_t k = k0; k < kown; ++k) {
         if (threadIdx.x == 0) {
             // (bounded: a producer that never shows up — it cannot happen with <= 32 resident workgroups — must not hang the device:
