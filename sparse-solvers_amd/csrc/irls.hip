@@ -828,14 +828,16 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
     IRLS_TRY(hipMalloc(&S->G0, (size_t)n * n * sizeof(T)));
     IRLS_TRY(hipMalloc(&S->L, (size_t)n * n * sizeof(T)));
     IRLS_TRY(hipMalloc(&S->rdiag, (size_t)n * sizeof(T)));
-    IRLS_TRY(hipMalloc(&S->vec, (5 * (size_t)n + 2 * (size_t)ldm) * sizeof(T)));
+    // (behind the vectors: one flag per column for the one-launch panel kernel of the factorisation, zeroed with them)
+    const size_t vec_bytes = (5 * (size_t)n + 2 * (size_t)ldm) * sizeof(T);
+    IRLS_TRY(hipMalloc(&S->vec, vec_bytes + (size_t)n * sizeof(uint32_t)));
     IRLS_TRY(hipMalloc(&S->res, sizeof(IrlsResult)));
     IRLS_TRY(hipMalloc(&S->ctl, sizeof(IrlsCtl<T>)));
     IRLS_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->done_host), 64, hipHostMallocDefault));
     IRLS_TRY(hipMemsetAsync(S->Qt, 0, (size_t)n * ldm * sizeof(T), ctx->stream));
-    IRLS_TRY(hipMemsetAsync(S->vec, 0, (5 * (size_t)n + 2 * (size_t)ldm) * sizeof(T), ctx->stream));
+    IRLS_TRY(hipMemsetAsync(S->vec, 0, vec_bytes + (size_t)n * sizeof(uint32_t), ctx->stream));
     T* At = static_cast<T*>(ctx->At);
-    uint32_t* qr_ready = nullptr;                                 // (flags of the one-launch panel kernel; freed below)
+    uint32_t* qr_ready = nullptr;                                 // (flags of the one-launch panel kernel: behind S->vec, zeroed above)
     if (std::getenv("SS_HIP_IRLS_FUSED")) {
         // (A/B aid: the round-2 form — every reflector a launch over all trailing columns)
         for (uint32_t k = 0; k < n; ++k) {
@@ -852,10 +854,8 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
         // Same arithmetic per column, in the same order: the same bits as the round-2 form.
         constexpr uint32_t NBQ = 32;
         // (one flag per column for the one-launch panel kernel; SS_HIP_IRLS_QR_STEPS keeps a launch per reflector: A/B aid)
-        if (!std::getenv("SS_HIP_IRLS_QR_STEPS")) {
-            if (hipMalloc(&qr_ready, (size_t)n * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); qr_ready = nullptr; }
-            else if (hipMemsetAsync(qr_ready, 0, (size_t)n * sizeof(uint32_t), ctx->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(qr_ready); qr_ready = nullptr; }
-        }
+        if (!std::getenv("SS_HIP_IRLS_QR_STEPS"))
+            qr_ready = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(S->vec) + vec_bytes);
         uint32_t* const ready = qr_ready;
         for (uint32_t k0 = 0; k0 < n; k0 += NBQ) {
             const uint32_t nb = std::min<uint32_t>(NBQ, n - k0);
@@ -880,7 +880,6 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
                        (const T*)S->rdiag, S->R, S->G0, ldm, m, n);
     IRLS_TRY(hipGetLastError());
     IRLS_TRY(hipStreamSynchronize(ctx->stream));
-    if (qr_ready != nullptr) (void)hipFree(qr_ready);
     return hipSuccess;
 }
 
