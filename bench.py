@@ -172,7 +172,9 @@ def measure_traffic_live(timeout_s=150.0):
         return None
     if any(k.startswith("ROCP") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None                                   # (this run is itself being profiled: no nested profiler)
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    # (the child runs the shipped defaults: none of this process's SS_HIP_* developer switches, no rendezvous variables)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("SS_HIP_")}
     env["TMPDIR"] = "/tmp"
     got = {}
     t_start = time.perf_counter()
