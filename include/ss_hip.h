@@ -279,6 +279,24 @@ typedef struct ss_hip_stats {
                                       "screen_first16"; profiling on)                                                                     */
     double   first16_ms;           /* sum of their HIP-event durations                                                                    */
     uint64_t first16_bytes;        /* their algorithmic bytes: ldm * n_pad * 2 (fp16 copy of A) + ldm * 4 (y) + n_pad * 4 (c~0) each        */
+    /* ABI version 5 */
+    uint64_t screen_resident;      /* screened signals (fp32 and fp64) whose path ran in the resident kernel (csrc/resident.hip: one workgroup,
+                                      Gram values in registers) and was certified                                                         */
+    uint64_t screen_tier2;         /* fp64: signals the resident tier (256 columns) did not report and the sub-dictionary tier (2048 columns,
+                                      launch-per-iteration engine) took next                                                              */
+    /* why a signal of the subset / screened forms was NOT reported by the tier that tried it (one signal may count in several;
+       a signal that ends up in the default engine is counted once in screen_redone / subset_redone as before)                          */
+    uint64_t why_removal;          /* a column would leave the support (only regular paths are certified)                                  */
+    uint64_t why_positions;        /* more support columns than the subset kernel holds (72 fp32 / 144 fp64)                               */
+    uint64_t why_breakpoints;      /* more states than its log holds (80 / 160)                                                           */
+    uint64_t why_guard;            /* tolerance below the Gram-form guard                                                                 */
+    uint64_t why_no_candidate;     /* no positive step-length candidate on the subset                                                     */
+    uint64_t why_first_state;      /* state 0 not certified: the columns left out of the subset may reach lambda_0 (crowded first state)   */
+    uint64_t why_irregular;        /* lambda went up along the path (e.g. derailed by the reference's first-step sign quirk)               */
+    uint64_t why_overflow;         /* a residual overflowed the half-precision range                                                      */
+    uint64_t why_column;           /* the screening pass (or the subset form's check) could not certify a (column, state)                  */
+    uint64_t why_tie;              /* the subset's scan met an exact tie (its view: the default engine decides)                            */
+    uint64_t screen_recheck;       /* screened signals whose uncertified (column, state) pairs were re-derived exactly in fp32 and passed   */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------

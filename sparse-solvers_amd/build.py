@@ -47,6 +47,8 @@ HIP_UNITS = [
     ("subbatch.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
     # screened form of one signal: fp16 copy of A, the subset's Gram matrix, the screening pass (bounds, not reported values)
     ("screen.hip", []),
+    # the resident subset solve (one workgroup, Gram values in registers): scalar bookkeeping rounds like the reference's
+    ("resident.hip", ["-ffp-contract=off"]),
 ]
 
 

@@ -13,6 +13,7 @@
 // no-op), the host only polls a copy of that flag `lookahead` rounds behind the queue
 // head, so the GPU never waits for the host between iterations.
 #include "ss_hip_internal.h"
+#include "resident.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -852,11 +853,34 @@ inline hipError_t scr64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const do
 }
 inline hipError_t scr64_certify(ss_hip_ctx*, Workspace<float>&, const float*, uint32_t, float, double, uint32_t, hipEvent_t, hipEvent_t, bool, bool) { return hipErrorInvalidConfiguration; }
 
+inline hipError_t scr64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp, hipEvent_t e0, hipEvent_t e1,
+                                 hipEvent_t e2, hipEvent_t e3)
+{
+    return launch_screen64_resident(ctx, ws, tol, max_iter, first16, omp, e0, e1, e2, e3);
+}
+inline hipError_t scr64_resident(ss_hip_ctx*, Workspace<float>&, float, uint32_t, bool, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
+
+// why a subset / screened solve was not reported: DevState::sub_reason's bits into the statistics
+inline void count_reasons(ss_hip_ctx* ctx, uint32_t r, bool tie)
+{
+    ss_hip_stats& S = ctx->stats;
+    if (r & kReasonRemoval) S.why_removal += 1;
+    if (r & kReasonPositions) S.why_positions += 1;
+    if (r & kReasonLog) S.why_breakpoints += 1;
+    if (r & kReasonGuard) S.why_guard += 1;
+    if (r & kReasonNoCand) S.why_no_candidate += 1;
+    if (r & kReasonFirstState) S.why_first_state += 1;
+    if (r & kReasonIrregular) S.why_irregular += 1;
+    if (r & kReasonOverflow) S.why_overflow += 1;
+    if (r & kReasonColumn) S.why_column += 1;
+    if (tie || (r & kReasonTie)) S.why_tie += 1;
+}
+
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
                ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
                bool omp = false, bool force_residual = false, bool no_solo = false,
-               void* rec_out = nullptr, uint32_t kmax = 0, bool force_ro = false, bool no_sub = false)
+               void* rec_out = nullptr, uint32_t kmax = 0, bool force_ro = false, bool no_sub = false, bool no_res = false)
 {
     if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
     if (ctx->kind != 0) { set_err(err, errlen, "solve: this context was created for IRLS"); return SS_HIP_EINVAL; }
@@ -948,7 +972,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         // (not with a trace or compact records asked for: the sub-context's lists are over ITS columns)
         // (OMP too: the sub-context runs k_la_omp, the certificate is the same — nothing outside the sub-dictionary reaches the pick's |c|)
         bool scr64 = (la || la_omp) && sizeof(T) == 8 && !no_sub && !ctx->tracing && rec_out == nullptr && ctx->la_fused >= 1 && screen64_usable(ctx);
-        if ((sub1 || scr1 || scr64) && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; scr1 = false; scr64 = false; }
+        // ... and before that tier, the RESIDENT tier (resident.hip): the path on the 256 best-ranked columns in ONE workgroup with the
+        // Gram values in registers — no sub-context, no host round trip, everything queued in one go; its lists are over the
+        // dictionary's own columns, so a trace and compact records work too.  What it does not report goes to the tier above.
+        bool scr64r = (la || la_omp) && sizeof(T) == 8 && !no_sub && !no_res && ctx->screen_resident && ctx->la_fused >= 1 && !(omp && ctx->tracing) &&
+                      screen64_usable(ctx) && screen64_resident_usable(ctx);
+        if ((sub1 || scr1 || scr64 || scr64r) && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; scr1 = false; scr64 = false; scr64r = false; }
+        if (scr64r && ctx->res_off_solves > 0) { ctx->res_off_solves -= 1; scr64r = false; }
+        if (scr64r) scr64 = false;
         uint32_t scr_launches = 1;
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
         bool spec_epilogue = false, pump_enqueued = false;
@@ -960,7 +991,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 hipLaunchKernelGGL((k_epilogue<T>), dim3(std::max(1u, grid)), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ws.st),
                                    static_cast<uint32_t*>(ctx->hs_mapped), (uint32_t)(sizeof(DevState) / 4), (const T*)ws.x,
                                    x_on_device ? x : (T*)nullptr, (long long)incx, (uint32_t)n,
-                                   scr1 ? (uint32_t)(offsetof(DevState, status) / 4) : 0xffffffffu, (uint32_t)(offsetof(DevState, need_sweep) / 4));
+                                   (scr1 || scr64r) ? (uint32_t)(offsetof(DevState, status) / 4) : 0xffffffffu, (uint32_t)(offsetof(DevState, need_sweep) / 4));
                 HIPCHK(hipGetLastError());
                 if (x && !x_on_device) copy_out<T>(ctx, x, incx, ws.x, n);
             } else {
@@ -999,7 +1030,22 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             ws.gram_is_full = true;
             full_view.on = true;
         };
-        if (scr64) {
+        if (scr64r) {
+            Lookahead<T>::ensure(ctx, ws, kcap);
+            if (!omp) HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y (OMP: done above)
+            const bool first16 = screen_first16_usable(ctx);
+            uint32_t nb1 = 0;
+            if (!first16) {
+                if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+                HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
+                if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
+            }
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+            if (prof && first16) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(7); ++nprof; }
+            if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); }
+            HIPCHK(scr64_resident(ctx, ws, tol, max_iter, first16, omp, e0, e1, e2, e3));
+            if (prof) { ctx->prof_kind.push_back(6); ++nprof; }
+        } else if (scr64) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             if (!omp) HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y (OMP: done above)
             // (the first pass — A^T y over all columns, which here only ranks them — over the fp16 copy: k_scr_first; 7 = that pass)
@@ -1144,7 +1190,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
         volatile uint32_t* hf = ctx->host_flags;
         const uint64_t last_round = (uint64_t)max_iter + 1;
-        if (sub1 || scr1 || scr64) {
+        if (sub1 || scr1 || scr64 || scr64r) {
             // (everything is queued: selection, the solve, the check)
         } else if ((la && ctx->la_fused) || la_omp) {
             // Fused lookahead engine: every launch of k_la_iter performs the next iteration, or
@@ -1275,7 +1321,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         }
         // (a tie met by the screened form's subset solve is a tie of the SUBSET's view — on a subset that cannot be certified it may not
         // exist over all columns: such a signal goes to the default engine below, which meets the tie itself if it is real)
-        const bool scr_tie = scr1 && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun);
+        const bool scr_tie = (scr1 || scr64r) && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun);
         if (!ro && !omp && !scr_tie && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun)) {
             // a step-length scan met an exact tie (DevState::tie_stall): whether the strict t > 0 of the reference then
             // derails the path is decided by rounding — the reference-order engine is the arbiter
@@ -1292,8 +1338,29 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 ctx->sub_failed = 0;
             }
         }
+        if (scr64r) {
+            const bool back = hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie;
+            ctx->res_seen += 1;
+            if (back) ctx->res_failed += 1;
+            if (ctx->res_seen >= 8) {
+                if (2 * ctx->res_failed > ctx->res_seen) ctx->res_off_solves = 64;
+                ctx->res_seen = 0;
+                ctx->res_failed = 0;
+            }
+            if (back) {
+                // the resident tier does not report this signal: the sub-dictionary tier (2048 columns) takes it next
+                ctx->stats.screen_tier2 += 1;
+                count_reasons(ctx, hs.sub_reason, scr_tie);
+                if (std::getenv("SS_HIP_SUB_DEBUG"))
+                    std::fprintf(stderr, "[screened form, fp64 resident tier] status %u reason 0x%x after %u iterations, %u states logged, K = %u, lambda %g\n",
+                                 hs.status, hs.sub_reason, hs.iter, hs.solo_nlog, hs.K, hs.c_inf);
+                return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, false, true);
+            }
+            if (hs.status == 0) { ctx->stats.screen_signals += 1; ctx->stats.screen_resident += 1; }
+        }
         if ((scr1 || scr64) && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie)) {
             ctx->stats.screen_redone += 1;
+            count_reasons(ctx, hs.sub_reason, scr_tie);
             if (std::getenv("SS_HIP_SUB_DEBUG"))
                 std::fprintf(stderr, "[screened form] status %u after %u iterations, %u states logged, K = %u, lambda %g, lambda0 %g\n",
                              hs.status, hs.iter, hs.solo_nlog, hs.K, hs.c_inf, (double)hs.lambda0);
@@ -1309,6 +1376,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         }
         if (sub1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
             ctx->stats.subset_redone += 1;
+            count_reasons(ctx, hs.sub_reason, false);
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
         }
         if (sub1 && hs.status == 0) ctx->stats.subset_signals += 1;
@@ -2606,6 +2674,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "screen_single")) { ctx->screen_single = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_first16")) { ctx->screen_first16 = value != 0 ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_screen"))  { ctx->batch_screen = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_resident")) { ctx->screen_resident = value ? 1 : 0; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 
@@ -2681,6 +2750,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "screen_single")) { *value = ctx->screen_single; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_first16")) { *value = ctx->screen_first16; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_screen"))  { *value = ctx->batch_screen; return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_resident")) { *value = ctx->screen_resident; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 

@@ -46,6 +46,7 @@
 // the host solves it again in the default engine (exact fp32 passes over A) — like every declined signal of the subset form.
 #include "ss_hip_internal.h"
 #include "ss_hip_device.h"
+#include "resident.h"
 
 #include <hip/hip_fp16.h>
 
@@ -104,7 +105,16 @@ struct ScreenState {
     double* xsub = nullptr;      // [kS64Sub] the sub-context's solution
     double* xd = nullptr;        // [kS64LogK][kS64Rhs + 8] coefficients of the screened states over the final list of touched columns (transposed)
     uint32_t* ctl = nullptr;     // [8] device words: [0] failure raised while the certificate was prepared
+    // fp64 resident tier (resident.hip): the path on the 256 columns with the largest |c~0|, in ONE workgroup
+    uint32_t* sub256 = nullptr;  // [256] ascending, then first pick + value (2 words)
+    double* gs64 = nullptr;      // [256][256] the subset's Gram matrix
+    double* gs64_part = nullptr; // [kSg64MaxSplit][256][256] its row-chunk partials
+    uint32_t* rl_hdr = nullptr;  // the resident solve's log: headers [160][8]
+    double* rl_H = nullptr;      // ... {lambda, gamma} [160][2]
+    uint32_t* rl_pcol = nullptr; // ... the positions' columns [144]
+    double* rl_X = nullptr;      // ... x by position of every state [160][144]
 };
+static_assert(kS64Rhs == 192, "the residual block of the fp64 forms (resident.hip: kR64Rhs)");
 
 // ---- one-time preparation ---------------------------------------------------------------------------------------
 template <typename T>
@@ -427,7 +437,7 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
         const float eps0 = 0.0019726562f * yn * meta[4] + 6.103515625e-05f * sqrtf((float)ldm) * yn * meta[1];
         const float bound0 = lam0 * 0.875f - 1e-5f * lam0;
         const float v0 = meta[6] + eps0;
-        if (!(v0 <= bound0)) __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(v0 <= bound0)) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonFirstState); }
         ratio0 = bound0 > 0.f && v0 == v0 ? v0 / bound0 : 3.0e38f;
     }
     const uint32_t nlog = st->solo_nlog;
@@ -493,7 +503,7 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
             }
         }
     }
-    if (ovf) __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ovf) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonOverflow); }
     if (blockIdx.x == 0u) {
         const float lam0 = st->lambda0;
         if (tid == 0u && blockIdx.y == 0u) *headroom = __float_as_uint(ratio0);
@@ -518,7 +528,7 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
             // only REGULAR paths are certified: every step inserts a column and lambda goes down.  On a path with removals, or one
             // the first-step sign quirk has derailed, steps of rounding size decide what is toggled next, and the subset's Gram
             // matrix is the default engine's only to rounding (see k_s64_dense): those go back to that engine
-            if (hp[3] == 0u || lam > __uint_as_float(hp[4]) * 1.00001f) bound = -1.f;
+            if (hp[3] == 0u || lam > __uint_as_float(hp[4]) * 1.00001f) { bound = -1.f; atomicOr(&st->sub_reason, kReasonIrregular); }
             const float inv_sk = 1.f / sS[tid];
             tab[tid * kScrTab + 0] = meta[1] * inv_sk;
             tab[tid * kScrTab + 1] = bound;
@@ -538,8 +548,10 @@ __global__ __launch_bounds__(256, 2)
 void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const __half* __restrict__ r16,
                 const float* __restrict__ anorm, const float* __restrict__ rn2p, uint32_t rn_pitch, const float* __restrict__ tab,
                 const uint32_t* __restrict__ sub, uint32_t nsub, const float* __restrict__ meta, DevState* __restrict__ st,
-                uint32_t* __restrict__ headroom, uint32_t nst_fixed, uint32_t skew)
+                uint32_t* __restrict__ headroom, uint32_t nst_fixed, uint32_t skew, uint32_t gate)
 {
+    // gate (states from the slot's log only): 1 = this launch only if the log holds <= 128 states, 2 = only if more (the fp64
+    // resident form queues a four-tile and a five-tile launch without the host knowing the path's length)
     // grid = (slots, column tiles): the workgroups of one tile of A16 — one per slot of a batch — are neighbours in the launch
     // order, so the tile comes from HBM once and from L2 for the others (one slot: a plain 1 x tiles grid)
     {
@@ -564,6 +576,11 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
         if (nlog < 2u) return;
         nst = nlog - 1u;
         if (nst_fixed == 0xffffffffu && nst <= 64u) return;     // (batch chunk: k_scr_gemm_b carries the slots of up to 64 states)
+        if ((gate == 1u && nst > 128u) || (gate == 2u && nst <= 128u)) return;
+        if (nst > 32u * (uint32_t)NT) {                           // (more states than this launch carries: nothing is certified)
+            if (threadIdx.x == 0 && blockIdx.y == 0) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonLog); }
+            return;
+        }
     }
     const uint32_t ntu = (nst + 31u) / 32u;                      // (uniform) tiles of states in use
     unsigned char* sA = smem;                                   // [128][272]
@@ -685,7 +702,10 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
             }
         }
     }
-    if (mine && flag) __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by k_sub_finish)
+    if (mine && flag) {
+        __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by k_sub_finish)
+        if (!(__hip_atomic_load(&st->sub_reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kReasonColumn)) atomicOr(&st->sub_reason, kReasonColumn);
+    }
     if (!mine) worst = 0.f;
     worst = fmaxf(worst, __shfl_xor(worst, 1)); worst = fmaxf(worst, __shfl_xor(worst, 2)); worst = fmaxf(worst, __shfl_xor(worst, 4));
     worst = fmaxf(worst, __shfl_xor(worst, 8)); worst = fmaxf(worst, __shfl_xor(worst, 16)); worst = fmaxf(worst, __shfl_xor(worst, 32));
@@ -848,7 +868,10 @@ void k_scr_gemm_b(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, cons
                 }
             }
         }
-        if (mine && flag) __hip_atomic_store(&st_all[sl].need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mine && flag) {
+            __hip_atomic_store(&st_all[sl].need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(__hip_atomic_load(&st_all[sl].sub_reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kReasonColumn)) atomicOr(&st_all[sl].sub_reason, kReasonColumn);
+        }
         if (mine) worst = fmaxf(worst, wq);
     }
     worst = fmaxf(worst, __shfl_xor(worst, 1)); worst = fmaxf(worst, __shfl_xor(worst, 2)); worst = fmaxf(worst, __shfl_xor(worst, 4));
@@ -1075,7 +1098,7 @@ void screen_free(ss_hip_ctx* ctx)
     ScreenState* S = scr_of(ctx);
     if (!S) return;
     void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->wmax, S->cabs, S->sublist, S->xsub, S->xd, S->ctl,
-                     S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs };
+                     S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs, S->sub256, S->gs64, S->gs64_part, S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (S->sub) {
@@ -1208,14 +1231,21 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     hipLaunchKernelGGL(k_sgram_part, dim3(NT * (NT + 1) / 2, nsplit), dim3(256), 0, s, At, ldm, n, (const uint32_t*)B.sub, ldm / nsplit, S->gs_part);
     hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256 + (first16 ? kSbS : 0u)), dim3(256), 0, s, (const float*)S->gs_part, nsplit, S->gs,
                        At, ldm, (const float*)ws.rhs, (const uint32_t*)B.sub, n, ws.c0);
-    (void)launch_sub_solve(ctx, ws, B, 1, (const float*)S->gs, kSbS, first16 ? 2 : 1, ws.c0, tol, max_iter);
+    // the path on the subset: the resident kernel (resident.hip: Gram values in registers, four barriers per iteration) or, option
+    // screen_resident = 0, k_sub_solve (subbatch.hip) — the same log either way
+    if (ctx->screen_resident && res_solve_usable<float>()) {
+        const ResLog<float> log{ B.hdr, nullptr, B.pcol, B.LX };
+        (void)launch_res_solve<float>(ctx, 1, (const float*)S->gs, kSbS, 0, (const float*)ws.c0, 0, (const uint32_t*)B.sub, tol, max_iter, ws.dims.kcap, log, ws.x, 0,
+                                      ws.gam, ws.touched, ws.st, ws.trace, ws.trace_cap, false);
+    } else
+        (void)launch_sub_solve(ctx, ws, B, 1, (const float*)S->gs, kSbS, first16 ? 2 : 1, ws.c0, tol, max_iter);
     hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs,
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
                        (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, first16 ? 1 : 0);
     if (e2) (void)hipEventRecord(e2, s);
     hipLaunchKernelGGL(k_scr_gemm<3>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
                        (const float*)S->anorm, (const float*)S->rn2p, kScrRhs, (const float*)S->tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
-                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew());
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 0u);
     if (e3) (void)hipEventRecord(e3, s);
     // (finish = false: the caller's epilogue launch turns "a column was not certified" into the status the host reads)
     if (finish) (void)launch_sub_finish(ctx, ws, 1);
@@ -1266,7 +1296,12 @@ hipError_t launch_screen_batch(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t n
     constexpr uint32_t NT = kSbS / kSgT;
     hipLaunchKernelGGL(k_sgram_part, dim3(NT * (NT + 1) / 2, nsplit, nslots), dim3(256), 0, s, At, ldm, n, (const uint32_t*)B.sub, ldm / nsplit, S->b_gs_part);
     hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256, nslots), dim3(256), 0, s, (const float*)S->b_gs_part, nsplit, S->b_gs, (const float*)nullptr, 0u, (const float*)nullptr, (const uint32_t*)nullptr, 0u, (float*)nullptr);
-    (void)launch_sub_solve(ctx, ws, B, nslots, (const float*)S->b_gs, kSbS, 1, c0_all, tol, max_iter, kSbS * kSbS);
+    if (ctx->screen_resident && res_solve_usable<float>()) {
+        const ResLog<float> log{ B.hdr, nullptr, B.pcol, B.LX };
+        (void)launch_res_solve<float>(ctx, nslots, (const float*)S->b_gs, kSbS, (size_t)kSbS * kSbS, c0_all, np, (const uint32_t*)B.sub, tol, max_iter, ws.dims.kcap, log,
+                                      ws.x, np, ws.gam, ws.touched, ws.st, ws.trace, ws.trace_cap, false);
+    } else
+        (void)launch_sub_solve(ctx, ws, B, nslots, (const float*)S->b_gs, kSbS, 1, c0_all, tol, max_iter, kSbS * kSbS);
     hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u, nslots), dim3(256), 0, s, At, ldm, n, (const float*)ws.y,
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
                        (const float*)S->meta, S->b_r16, S->b_rn2p, S->b_tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, 0);
@@ -1283,7 +1318,7 @@ hipError_t launch_screen_batch(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t n
     // (slots whose path logged more than 64 states — and every slot, should the wide kernel's LDS request be refused)
     hipLaunchKernelGGL(k_scr_gemm<3>, dim3(nslots, np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->b_r16,
                        (const float*)S->anorm, (const float*)S->b_rn2p, kScrRhs, (const float*)S->b_tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
-                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, b_attr ? 0xffffffffu : 0u, scr_skew());
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, b_attr ? 0xffffffffu : 0u, scr_skew(), 0u);
     (void)launch_sub_finish(ctx, ws, nslots);
     return hipGetLastError();
 }
@@ -1324,6 +1359,16 @@ bool screen64_usable(ss_hip_ctx* ctx)
     alloc(reinterpret_cast<void**>(&S->xsub), (size_t)kS64Sub * sizeof(double));
     alloc(reinterpret_cast<void**>(&S->xd), (size_t)kS64LogK * (kS64Rhs + 8) * sizeof(double));
     alloc(reinterpret_cast<void**>(&S->ctl), 8 * sizeof(uint32_t));
+    {
+        typedef ResCfg<double> RC;
+        alloc(reinterpret_cast<void**>(&S->sub256), ((size_t)RC::S + 2) * sizeof(uint32_t));
+        alloc(reinterpret_cast<void**>(&S->gs64), (size_t)RC::S * RC::S * sizeof(double));
+        alloc(reinterpret_cast<void**>(&S->gs64_part), (size_t)kSg64MaxSplit * RC::S * RC::S * sizeof(double));
+        alloc(reinterpret_cast<void**>(&S->rl_hdr), (size_t)RC::LOGCAP * 8 * sizeof(uint32_t));
+        alloc(reinterpret_cast<void**>(&S->rl_H), (size_t)RC::LOGCAP * 2 * sizeof(double));
+        alloc(reinterpret_cast<void**>(&S->rl_pcol), (size_t)RC::PCAP * sizeof(uint32_t));
+        alloc(reinterpret_cast<void**>(&S->rl_X), (size_t)RC::LOGCAP * RC::PCAP * sizeof(double));
+    }
     if (ok) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)scr_gemm_lds(kS64Sub, 3));
@@ -1415,22 +1460,71 @@ hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double
             hipLaunchKernelGGL(k_scr_gemm<4>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 4), s, (const __half*)S->a16, ldm, n,
                                (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
                                (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
-                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew());
+                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew(), 0u);
         else if (wide)
             hipLaunchKernelGGL(k_scr_gemm<5>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 5), s, (const __half*)S->a16, ldm, n,
                                (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
                                (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
-                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew());
+                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew(), 0u);
         else
             hipLaunchKernelGGL(k_scr_gemm<3>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kS64Sub, 3), s, (const __half*)S->a16, ldm, n,
                                (const __half*)(S->r16 + (size_t)k0 * ldm), (const float*)S->anorm, (const float*)(S->rn2p + k0), kS64Rhs,
                                (const float*)(S->tab + (size_t)k0 * kScrTab), (const uint32_t*)S->sublist, kS64Sub, (const float*)S->meta,
-                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew());
+                               ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, cnt, scr_skew(), 0u);
         k0 += cnt;
     }
     if (e3) (void)hipEventRecord(e3, s);
     hipLaunchKernelGGL(k_s64_finish, dim3((kS64Sub + 255) / 256), dim3(256), 0, s, (const uint32_t*)S->sublist, (const double*)S->xsub, n, ws.x,
                        ws.st, (const uint32_t*)S->ctl, T, c_inf, K);
+    return hipGetLastError();
+}
+
+// ---- fp64, resident tier (resident.hip) ---------------------------------------------------------------------------------------
+// The whole solve queued in one go: the first pass over the fp16 copy (or, first16 = false, the caller's fp64 sweep in ws.c0) ranks
+// the columns, the 256 best become the subset, Gs = A_S^T A_S and the exact c0 of its columns from the fp64 dictionary (MFMA),
+// k_res_solve<double> runs the path in ONE workgroup — this is what is reported —, k_res_residuals64 rounds the states' residuals
+// to fp16 and the screening pass certifies every state against all columns (four tiles of 32 states up to 128, five beyond: both
+// launches are queued, each looks at the log's length).  The verdict reaches the host through the epilogue launch
+// (DevState::need_sweep -> kStatusSubsetFail); a path that leaves the kernel's common path arrives as kStatusSubsetDecline.
+bool screen64_resident_usable(ss_hip_ctx* ctx)
+{
+    ScreenState* S = scr_of(ctx);
+    return S != nullptr && S->sub256 != nullptr && ctx->n >= 4u * (uint32_t)ResCfg<double>::S && res_solve_usable<double>();
+}
+
+hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp, hipEvent_t e0,
+                                    hipEvent_t e1, hipEvent_t e2, hipEvent_t e3)
+{
+    typedef ResCfg<double> RC;
+    ScreenState* S = scr_of(ctx);
+    if (S == nullptr || S->sub256 == nullptr) return hipErrorInvalidConfiguration;
+    hipStream_t s = ctx->stream;
+    const uint32_t ldm = ctx->ldm, n = (uint32_t)ctx->n, np = ctx->n_pad;
+    const double* y = ws.rhs;                                     // (r = y: the caller's reset put it there)
+    if (first16) {
+        if (e0) (void)hipEventRecord(e0, s);
+        const hipError_t ef = launch_scr_first<double>(ctx, S, y, S->cabs);
+        if (ef != hipSuccess) return ef;
+        if (e1) (void)hipEventRecord(e1, s);
+    } else {
+        hipLaunchKernelGGL(k_s64_cabs, dim3((np + 255) / 256), dim3(256), 0, s, (const double*)ws.c0, n, np, S->cabs);
+    }
+    (void)launch_select_top(ctx, S->cabs, n, np, (uint32_t)RC::S, S->sub256, S->sub256 + RC::S, reinterpret_cast<float*>(S->sub256 + RC::S + 1),
+                            first16 ? S->meta + 6 : nullptr);
+    { const hipError_t eg = launch_sgram64(ctx, S->sub256, y, S->gs64_part, S->gs64, ws.c0); if (eg != hipSuccess) return eg; }
+    const ResLog<double> log{ S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X };
+    { const hipError_t es = launch_res_solve<double>(ctx, 1, S->gs64, (uint32_t)RC::S, 0, ws.c0, 0, S->sub256, tol, max_iter, ws.dims.kcap, log, ws.x, 0, ws.gam,
+                                                     ws.touched, ws.st, ws.trace, ws.trace_cap, omp);
+      if (es != hipSuccess) return es; }
+    (void)launch_res_residuals64(ctx, y, log, tol, S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, first16, omp);
+    if (e2) (void)hipEventRecord(e2, s);
+    hipLaunchKernelGGL(k_scr_gemm<4>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds((uint32_t)RC::S, 4), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
+                       (const float*)S->anorm, (const float*)S->rn2p, kS64Rhs, (const float*)S->tab, (const uint32_t*)S->sub256, (uint32_t)RC::S, (const float*)S->meta,
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 1u);
+    hipLaunchKernelGGL(k_scr_gemm<5>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds((uint32_t)RC::S, 5), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
+                       (const float*)S->anorm, (const float*)S->rn2p, kS64Rhs, (const float*)S->tab, (const uint32_t*)S->sub256, (uint32_t)RC::S, (const float*)S->meta,
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 2u);
+    if (e3) (void)hipEventRecord(e3, s);
     return hipGetLastError();
 }
 

@@ -92,7 +92,8 @@ struct DevState {
     uint32_t ticket_gram; // arrival counter of k_gramupd
     uint32_t pad2_[31];
     double   dot;         // a_idx . a_idx of the column being inserted (k_gramupd hand-off)
-    uint32_t pad3_[30];
+    uint32_t sub_reason;  // subset / screened forms: why the signal was not reported (bit mask, resident.h: kReason*); single-writer or atomicOr
+    uint32_t pad3_[29];
     uint32_t bar_count;   // grid barrier of k_la_iter: arrivals so far in this solve (monotonic)
     uint32_t pad4_[31];
 };
@@ -254,6 +255,8 @@ struct ss_hip_ctx {
     // the subset form steps aside where it does not pay: after a chunk (or a run of single solves) of which it had to hand
     // back more than a third, the next 8 chunks (64 solves) go the other way at once, then it is tried again
     uint32_t sub_off_chunks = 0, sub_off_solves = 0, sub_seen = 0, sub_failed = 0;
+    uint32_t res_off_solves = 0, res_seen = 0, res_failed = 0;   // ... the same for the resident tier of the fp64 screened form
+    int screen_resident = 1;          // option: 1 = the screened forms run their path in the resident kernel (resident.hip), 0 = the forms before it
     hipEvent_t ev_sub_sel = nullptr;  // profiling: between the subset form's selection and its solves
     hipEvent_t ev_c0a = nullptr, ev_c0b = nullptr;   // profiling: around the batch GEMM c0 = A^T y of a chunk
     int batch_subset = 1;             // option: 1 = large Gram-form batches run in the subset form (one workgroup per signal + a check over all columns)
@@ -448,6 +451,10 @@ double* screen64_xsub(ss_hip_ctx* ctx);
 hipError_t screen64_gather(ss_hip_ctx* ctx, const double* c0, const double* y, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // (c0 = nullptr: the first pass over the fp16 copy, here; e0, e1 around it)
 hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double* y, uint32_t T, double tol, double c_inf, uint32_t K,
                             hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr, bool omp = false, bool first16 = false);
+// fp64, resident tier (resident.hip): the path on the 256 best-ranked columns in ONE workgroup, everything queued in one go
+bool screen64_resident_usable(ss_hip_ctx* ctx);
+hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp,
+                                    hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
 double screen_read_headroom(ss_hip_ctx* ctx);             // largest (|c~| + eps) / bound of the last screened solve (synchronises)
 hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr);      // signals one pass of the engine can carry (1 without the LDS-staged sweep)

@@ -31,6 +31,7 @@
 // Everything else follows the lock-step kernels (k_scansel's predicates, select_toggle's update, sign dead zone).
 #include "ss_hip_internal.h"
 #include "ss_hip_device.h"
+#include "resident.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -544,7 +545,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
     __syncthreads();
     int32_t mypos = -1;                       // position of my column while it is in the support
     uint32_t P = 0, K = 0;                    // positions given out, support size
-    uint32_t status = 0, iter = 0, nlog = 0;
+    uint32_t status = 0, iter = 0, nlog = 0, reason = 0;
     float c_inf = 0.f, lambda_prev = 0.f, gamma_prev = 0.f, lambda0 = 0.f;
     uint32_t just_removed = 0xffffffffu;
     bool tie_any = false;
@@ -576,7 +577,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
     };
 
     if (s_u[0] == 0xffffffffu) {
-        status = kStatusSubsetDecline;        // (cannot happen: the largest |c0| is in the subset)
+        status = kStatusSubsetDecline; reason |= kReasonNoCand;        // (cannot happen: the largest |c0| is in the subset)
     } else {
         // first pick (homotopy-cpu.cpp:217-229): inv = [1 / ||a||^2] through the norm, direction = inv * sign
         const uint32_t sp0 = s_u[0];
@@ -601,7 +602,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
         lambda0 = fabsf(c0[idx0]);
         lambda_prev = lambda0;                 // (k_init leaves c_inf = lambda0, gamma = 0: the first round's lambda is "where the last step left it")
         // (screened form: the tolerance guard of the Gram forms, k_la_init_pick's — the caller's usual engine decides what to do)
-        if (gsub && !((double)tol >= kGramGuard * (double)lambda0)) status = kStatusSubsetDecline;
+        if (gsub && !((double)tol >= kGramGuard * (double)lambda0)) { status = kStatusSubsetDecline; reason |= kReasonGuard; }
 
         for (uint32_t round = 1; status == 0u; ++round) {
             // (the round's hand-shake words — whose column was picked, a tie seen — are cleared here: the reductions' barriers lie
@@ -628,7 +629,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
             SUB_STAMP(1)
             // ---- loop control (homotopy-cpu.cpp:236, 272) ---------------------------------------------------------
             const bool stop = (round > 1 && !(c_inf > tol)) || round > max_iter;
-            if (nlog >= kSbLog) { status = kStatusSubsetDecline; break; }
+            if (nlog >= kSbLog) { status = kStatusSubsetDecline; reason |= kReasonLog; break; }
             if (j == 0) {
                 uint32_t* h = hdr + nlog * 8;
                 h[0] = P; h[1] = stop ? 0u : 1u; h[2] = 0xffffffffu; h[3] = 0u; h[4] = __float_as_uint(c_inf); h[5] = 0u;
@@ -667,8 +668,8 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
             block_reduce_pair_1b<float, false>(g, idx, sv2, si2);
             tie_any = s_u[3] != 0u || tie_any;
             SUB_STAMP(3)
-            if (tie_any && tie_exit) { status = kStatusTieRerun; iter = round - 1; ++nlog; break; }
-            if (!(g < Lim<float>::max())) { status = kStatusSubsetDecline; break; }     // (no positive candidate: the reference toggles column 0)
+            if (tie_any && tie_exit) { status = kStatusTieRerun; reason |= kReasonTie; iter = round - 1; ++nlog; break; }
+            if (!(g < Lim<float>::max())) { status = kStatusSubsetDecline; reason |= kReasonNoCand; break; }     // (no positive candidate: the reference toggles column 0)
             // whose column is it, and is it in the support?
             if (valid && mycol == idx) { s_u[1] = j; s_u[2] = mypos >= 0 ? 1u + (uint32_t)mypos : 0u; }
             __syncthreads();
@@ -685,7 +686,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
                 trace[round].idx = idx; trace[round].added = added ? 1u : 0u; trace[round].gamma = (double)g; trace[round].c_inf = (double)c_inf;
             }
             const uint32_t K_new = added ? K + 1u : K - 1u;
-            if (K_new == 0u || K_new > kcap || (added && P >= kSbRows)) { status = kStatusSubsetDecline; break; }
+            if (K_new == 0u || K_new > kcap || (added && P >= kSbRows)) { status = kStatusSubsetDecline; reason |= K_new == 0u ? kReasonRemoval : kReasonPositions; break; }
             // ---- x += gamma d over the old support (homotopy-cpu.cpp:252) -----------------------------------------------
             if (j < P && L.alive[j]) {
                 const float xn = L.xs[j] + g * L.ds[j];
@@ -701,7 +702,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
             if (!added) {
                 // the column leaves: in reference mode it keeps its rounding residue (and stays in c through it): not this form's path
                 const float res = L.xs[rpos];
-                if (res != 0.f && !zero_on_removal) { status = kStatusSubsetDecline; break; }
+                if (res != 0.f && !zero_on_removal) { status = kStatusSubsetDecline; reason |= kReasonRemoval; break; }
                 __syncthreads();
                 // deflate (online_inverse.h:275-290): u3 = -I[.][r] / I[r][r];  I' = I + (-I[r][r] u3) u3^T; row / column r zero
                 const float dd = L.I[rpos * kSbInvPitch + rpos];
@@ -811,6 +812,7 @@ void k_sub_solve(const float* __restrict__ G, uint32_t gpitch, const float* __re
         st->solo_nlog = nlog;                  // breakpoints logged (k_sub_verify)
         st->need_sweep = 0;                    // (k_sub_verify raises it when a breakpoint does not hold)
         st->done_round = iter + 1u;
+        st->sub_reason = reason;
     }
     if constexpr (STAMPS) {
         if (dbg != nullptr && slot == 0u && j == 0u)
@@ -960,7 +962,10 @@ void k_sub_verify(const float* __restrict__ G, uint32_t gpitch, const float* __r
         if (mine0) sub_check(cv0, qv0, j0, k, nlog, sH, tol, tie_guard, st, fail, tie);
         if (mine1) sub_check(cv1, qv1, j1, k, nlog, sH, tol, tie_guard, st, fail, tie);
     }
-    if (fail) __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by k_sub_finish)
+    if (fail) {
+        __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by k_sub_finish)
+        if (!(__hip_atomic_load(&st->sub_reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kReasonColumn)) atomicOr(&st->sub_reason, kReasonColumn);
+    }
     if (tie) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -98,6 +98,19 @@ class Stats(ctypes.Structure):
         ("first16_launches", ctypes.c_uint64),
         ("first16_ms", ctypes.c_double),
         ("first16_bytes", ctypes.c_uint64),
+        ("screen_resident", ctypes.c_uint64),
+        ("screen_tier2", ctypes.c_uint64),
+        ("why_removal", ctypes.c_uint64),
+        ("why_positions", ctypes.c_uint64),
+        ("why_breakpoints", ctypes.c_uint64),
+        ("why_guard", ctypes.c_uint64),
+        ("why_no_candidate", ctypes.c_uint64),
+        ("why_first_state", ctypes.c_uint64),
+        ("why_irregular", ctypes.c_uint64),
+        ("why_overflow", ctypes.c_uint64),
+        ("why_column", ctypes.c_uint64),
+        ("why_tie", ctypes.c_uint64),
+        ("screen_recheck", ctypes.c_uint64),
     ]
 
 

@@ -35,9 +35,10 @@ def small():
             same = np.array_equal(np.nonzero(x)[0], np.nonzero(xo)[0])
             rel = np.abs(x - xo).max() / np.abs(xo).max()
             reld = np.abs(xd - xo).max() / np.abs(xo).max()
-            print("m %5d n %6d k %3d first16 %d | screened %d redone %d headroom %.3f | iter %d / default %d / oracle %d | support %s | "
-                  "rel err %.2e (default %.2e)" % (m, n, k, first16, st["screen_signals"], st["screen_redone"], st["screen_headroom"], it, itd, ito,
-                                                   same, rel, reld), flush=True)
+            why = {k_: v for k_, v in st.items() if k_.startswith("why_") and v}
+            print("m %5d n %6d k %3d first16 %d | screened %d (resident %d, tier2 %d) redone %d headroom %.3f | iter %d / default %d / oracle %d | support %s | "
+                  "rel err %.2e (default %.2e) %s" % (m, n, k, first16, st["screen_signals"], st["screen_resident"], st["screen_tier2"], st["screen_redone"],
+                                                      st["screen_headroom"], it, itd, ito, same, rel, reld, why), flush=True)
             # (a path with removals leaves rounding residue on its columns in the default engine as well: compared with that)
             if it != ito or rel > max(1e-10, 3 * reld) or (not same and not np.array_equal(np.nonzero(x)[0], np.nonzero(xd)[0])):
                 bad += 1
@@ -83,8 +84,8 @@ def big():
         dt5 = (time.perf_counter() - t5) / len(sigs)
         st = h5.stats()
         print("configs[4] screen_single %d first16 %d: %.3f ms per solve (incl. the copy of x to the host), iterations %s, supports exact %d / %d, max rel coef err %.2e, "
-              "screened %d redone %d headroom %.3f" % (mode, first16, dt5 * 1e3, its, ok, len(sigs), cerr, st["screen_signals"], st["screen_redone"],
-                                                      st["screen_headroom"]), flush=True)
+              "screened %d (resident %d, tier2 %d) redone %d headroom %.3f" % (mode, first16, dt5 * 1e3, its, ok, len(sigs), cerr, st["screen_signals"],
+                                                                               st["screen_resident"], st["screen_tier2"], st["screen_redone"], st["screen_headroom"]), flush=True)
     d = max(np.abs(res[(1, i)] - res[(0, i)]).max() / np.abs(res[(0, i)]).max() for i in range(1, len(sigs) + 1))
     print("screened vs default engine: max |x - x'| / max |x| = %.2e" % d)
     # clean timing without host copies
