@@ -8,7 +8,7 @@ namespace sship {
 // shape of the resident kernel per element type: subset columns, threads (eight lanes per group of CT columns), positions
 // (support columns a path may take), states it may log
 template <typename T> struct ResCfg;
-template <> struct ResCfg<double> { static constexpr int S = 256, THREADS = 512, CT = 4, PCAP = 144, LOGCAP = 160; };
+template <> struct ResCfg<double> { static constexpr int S = 256, THREADS = 512, CT = 4, PCAP = 136, LOGCAP = 160; };
 template <> struct ResCfg<float>  { static constexpr int S = 448, THREADS = 448, CT = 8, PCAP = 72, LOGCAP = 80; };
 static_assert(ResCfg<float>::S == (int)kSbS && ResCfg<float>::PCAP == (int)kSbRows && ResCfg<float>::LOGCAP == (int)kSbLog,
               "the fp32 resident kernel writes the subset form's log (subbatch.hip, screen.hip read it)");

@@ -750,9 +750,11 @@ def test_batch_full_size(sship, c2_host_matrix):
 
 
 def test_fp64_full_size_vs_oracle(sship):
-    """configs[4] shape against the ORACLE with a bounded budget: A 16384 x 131072 fp64 (16 GiB), k = 128,
-    tol 1e-9, max_iter = 8 — the first breakpoints exact, coefficients within 1e-10; then the full solve
-    (support recovery, coefficients, iteration count) and OMP on the same context."""
+    """configs[4] shape against the ORACLE: A 16384 x 131072 fp64 (16 GiB), k = 128, tol 1e-9.  The default engine with a bounded
+    budget (max_iter = 8: the first breakpoints exact, coefficients within 1e-10), then the WHOLE 128-iteration path of the oracle
+    (about a minute of host time) against both the default engine and the shipped default — the fp64 screened form with its resident
+    tier (csrc/resident.hip): iteration count, every breakpoint (column, step length, lambda), support, coefficients within 1e-10;
+    and OMP on the same context."""
     import torch
     m, n, k = 16384, 131072, 128
     g = torch.Generator(device="cuda:0").manual_seed(4321)
@@ -769,6 +771,7 @@ def test_fp64_full_size_vs_oracle(sship):
     with sship.Homotopy(A) as h:
         del A
         torch.cuda.empty_cache()
+        h.set_option("screen_single", 0)
         h.set_option("trace", 1)
         xo, ito, eo, tro = oracle.homotopy(Ah, yh, 1e-9, 8, trace=True)
         xg, itg, eg = h.solve(y, 1e-9, 8)
@@ -780,28 +783,51 @@ def test_fp64_full_size_vs_oracle(sship):
         assert np.array_equal(np.nonzero(xg)[0], np.nonzero(xo)[0])
         assert np.abs(xg - xo).max() <= 1e-10 * np.abs(xo).max()
         assert abs(eg - eo) <= 1e-10 * abs(eo)
+        # the oracle's whole path
+        xf, itf, ef, trf = oracle.homotopy(Ah, yh, 1e-9, 512, trace=True)
         del Ah
-        h.set_option("trace", 0)
+        assert itf == k and np.array_equal(significant_support(xf, 1e-9), sup)
+
+        def same_path(tr):
+            # (the last toggle of a converged path is a rounding-level tie of all columns: DESIGN.md §4)
+            assert np.array_equal(tr["idx"][:-1], trf["idx"][:-1]) and np.array_equal(tr["added"][:-1], trf["added"][:-1])
+            assert np.allclose(tr["gamma"][:-1], trf["gamma"][:-1], rtol=1e-8, atol=0)
+            assert np.allclose(tr["c_inf"][1:], trf["c_inf"][:-1], rtol=1e-9, atol=0)        # (lambda at the start of iteration t = the oracle's after t - 1)
+
         x, it, err = h.solve(y, 1e-9, 512)
-        assert it == k and err <= 1e-9
-        assert np.array_equal(np.nonzero(x)[0], sup)
+        same_path(h.trace())
+        assert it == itf == k and err <= 1e-9
+        assert np.array_equal(significant_support(x, 1e-9), sup)
+        assert np.abs(x - xf).max() <= 1e-10 * np.abs(xf).max()
         assert np.abs(x[sup] - coef).max() <= 1e-10 * coef.max()
-        # the shipped default at this size: the fp64 screened form (csrc/screen.hip) — the path solved on the 2048 columns with
-        # the largest |c0|, every state certified against all 131 072 columns; against the default engine's result above
+        # the shipped default at this size: the fp64 screened form — the path in ONE workgroup on the 256 best-ranked columns
+        # (resident tier), every state certified against all 131 072 columns
         h.set_option("screen_single", 1)
         h.reset_stats()
         xs, its, errs = h.solve(y, 1e-9, 512)
         sts = h.stats()
-        h.set_option("screen_single", 0)
-        assert sts["screen_signals"] == 1 and sts["screen_redone"] == 0 and 0.0 < sts["screen_headroom"] < 0.7
-        assert its == it and errs <= 1e-9
-        assert np.array_equal(np.nonzero(xs)[0], sup)
+        same_path(h.trace())
+        note("test_fp64_full_size_vs_oracle", certified=sts["screen_signals"], resident=sts["screen_resident"], tier2=sts["screen_tier2"],
+             headroom=sts["screen_headroom"], max_rel_vs_oracle=float(np.abs(xs - xf).max() / np.abs(xf).max()))
+        assert sts["screen_signals"] == 1 and sts["screen_resident"] == 1 and sts["screen_redone"] == 0 and 0.0 < sts["screen_headroom"] < 0.7
+        assert its == itf and errs <= 1e-9
+        assert np.array_equal(significant_support(xs, 1e-9), sup)
+        assert np.abs(xs - xf).max() <= 1e-10 * np.abs(xf).max()
         assert np.abs(xs[sup] - coef).max() <= 1e-10 * coef.max()
-        assert np.abs(xs - x).max() <= 1e-12 * np.abs(x).max()
+        # ... and its second tier alone (the path on the 2048-column sub-dictionary by the launch-per-iteration engine)
+        h.set_option("trace", 0)
+        h.set_option("screen_resident", 0)
+        h.reset_stats()
+        x2, it2, err2 = h.solve(y, 1e-9, 512)
+        st2 = h.stats()
+        h.set_option("screen_resident", 1)
+        assert st2["screen_signals"] == 1 and st2["screen_resident"] == 0 and st2["screen_redone"] == 0
+        assert it2 == itf and np.abs(x2 - xf).max() <= 1e-10 * np.abs(xf).max()
         xq, itq, eq = h.solve_omp(y, 1e-9, 512)
         assert itq == k and eq <= 1e-9
         assert np.array_equal(np.nonzero(xq)[0], sup)
         assert np.abs(xq[sup] - coef).max() <= 1e-10 * coef.max()
+        h.set_option("screen_single", 0)
         r = rng.standard_normal(m)
         c, ms = h.gemv_t(r, 3)
         print("fp64 sweep: %.3f ms = %.0f GB/s" % (ms, (m * n * 8 + m * 8 + n * 8) / ms / 1e6))

@@ -1,9 +1,11 @@
 # kernel times of IRLS construction + solves under rocprofv3 (GPU box): bash tools/trace_irls.sh
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
+PY=$(python3 -c 'import sys,os;print(os.path.realpath(sys.executable))')
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 rm -rf gpurun_out/irt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/irt -o t -- python tools/probe_irls.py > gpurun_out/irt.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/irt -o t -- "$PY" tools/probe_irls.py > gpurun_out/irt.log 2>&1 || exit 1
 tail -4 gpurun_out/irt.log
-python - <<PY
+"$PY" - <<PY
 import csv,glob
 f=[x for x in glob.glob("gpurun_out/irt/**/*.csv",recursive=True) if "kernel_stats" in x]
 rows=sorted(csv.DictReader(open(f[0])), key=lambda r:-float(r["TotalDurationNs"]))
