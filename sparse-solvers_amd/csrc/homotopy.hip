@@ -1367,6 +1367,7 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
         }
         if ((scr1 || scr64) && hs.status == 0) ctx->stats.screen_signals += 1;
+        if (scr1 && hs.status == 0 && ctx->screen_resident && res_solve_usable<float>()) ctx->stats.screen_resident += 1;
         if (scr1 && ctx->sub_dbg != nullptr) {
             unsigned long long tp[9];
             HIPCHK(hipMemcpy(tp, ctx->sub_dbg, sizeof(tp), hipMemcpyDeviceToHost));

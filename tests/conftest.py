@@ -10,11 +10,9 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "sparse-solvers
         sys.path.insert(0, p)
 
 
-# The engine tests of test_gpu_parity.py examine the lookahead engine's forms one by one (early form, speculative launches,
-# resident kernel ...) on shapes where a context would by default take the screened form of csrc/screen.hip instead: the
-# initial value of option "screen_single" is 0 in this process; tests/test_gpu_screen.py and test_full_size_vs_oracle set
-# the option themselves.  (bench.py and __graft_entry__.smoke() run the shipped default.)
-os.environ.setdefault("SS_HIP_SCREEN_SINGLE", "0")
+# (No process-wide engine switch: every test runs the shipped defaults unless it sets an option itself.  The tests of
+# test_gpu_parity.py that examine ONE of the engines behind the screened form on a dictionary large enough for that form to
+# take the signal pin option "screen_single" = 0 through the fixture `engine_forms` there.)
 
 
 def note(test, **facts):

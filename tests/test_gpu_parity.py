@@ -28,9 +28,30 @@ def sship():
     return mod
 
 
-def hip_solve_factory(sship):
+# Tests that examine ONE engine behind the screened form (speculative launches, the early form's passes, the resident lookahead
+# kernel, full-G mode ...) on dictionaries large enough for the screened form to take the signal by default: for THESE tests the
+# initial value of option "screen_single" is 0 (the library reads SS_HIP_SCREEN_SINGLE when a context is created).  Every other
+# test runs the shipped default; the call surface is tested with and without the screened form in tests/test_gpu_screen.py.
+ENGINE_FORM_TESTS = ("test_speculative_form_matches_resident", "test_early_form_matches_plain_form", "test_first_sweep_64_columns",
+                     "test_early_form_wide_dictionary_keeps_speculating", "test_full_gram_single_signal", "test_sweep_linearity_full_size",
+                     "test_batch_full_size", "test_engines_agree", "test_resident_kernel_matches_launch_per_iteration",
+                     "test_speculative_form_failed_verification", "test_speculative_form_random_problems",
+                     "test_small_batches_take_the_subset_form_once_G_exists", "test_cache_budget_exhausted_falls_back")
+
+
+@pytest.fixture(autouse=True)
+def engine_forms(request, monkeypatch):
+    if request.node.originalname in ENGINE_FORM_TESTS:
+        monkeypatch.setenv("SS_HIP_SCREEN_SINGLE", "0")
+    else:
+        monkeypatch.delenv("SS_HIP_SCREEN_SINGLE", raising=False)
+
+
+def hip_solve_factory(sship, options=None):
     def solve(A, y, tol, max_iter):
         with sship.Homotopy(A) as h:
+            for key, val in (options or {}).items():
+                h.set_option(key, val)
             return h.solve(np.asarray(y, dtype=A.dtype), tol, max_iter)
     return solve
 
@@ -848,6 +869,20 @@ def test_ref_smoke_column_subset(sship, dtype):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_ref_noisy_signal(sship, dtype):
     ref_cases.noisy_signal(hip_solve_factory(sship), dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ref_cases_with_the_screened_form_forced(sship, dtype):
+    """the reference's own cases once more with option screen_single = 2 (the screened form on every shape it can run on; on shapes it
+    cannot — most of these are far below its 448 columns — the option must change nothing)"""
+    solve = hip_solve_factory(sship, {"screen_single": 2})
+    ref_cases.smoke(solve, dtype)
+    ref_cases.smoke_column_subset(solve, dtype)
+    ref_cases.noisy_signal(solve, dtype)
+    if dtype == np.float32:
+        ref_cases.noisy_patterns(solve, 100, 25)
+        ref_cases.noisy_patterns(solve, 25, 100)
+    ref_cases.permutations(solve, 10, 10, dtype, .1, .1, 10)
 
 
 @pytest.mark.parametrize("shape", [(100, 25), (25, 100)])

@@ -26,6 +26,7 @@ def sship():
 
 SHAPES = [(1024, 8192, 16), (1024, 8192, 40), (768, 2048, 20), (2048, 16384, 48), (4096, 8192, 64), (1536, 6000, 30),
           (1024, 1000, 12)]
+CERTIFIED_SHAPES = [(1024, 8192, 16), (4096, 8192, 64), (1536, 6000, 30)]
 
 
 @pytest.mark.parametrize("first16", [1, 0])
@@ -48,7 +49,12 @@ def test_screened_form_vs_oracle(sship, shape, mode, first16):
         st = h.stats()
     xo, ito, eo, tro = oracle.homotopy(A, y, 1e-3, 4 * k, flags=flags, trace=True)
     assert st["screen_signals"] + st["screen_redone"] == 1
-    note("test_screened_form_vs_oracle", shape=list(shape), mode=mode, certified=st["screen_signals"], headroom=st["screen_headroom"])
+    why = {k_: v for k_, v in st.items() if k_.startswith("why_") and v}
+    note("test_screened_form_vs_oracle", shape=list(shape), mode=mode, certified=st["screen_signals"], resident=st["screen_resident"],
+         headroom=st["screen_headroom"], why=why)
+    # well-posed shapes the form MUST certify (a form that always handed back would pass everything else here), by the resident kernel
+    if shape in CERTIFIED_SHAPES:
+        assert st["screen_signals"] == 1 and st["screen_resident"] == 1 and not why, (shape, st["screen_headroom"], why)
     assert_parity(xg, itg, eg, xo, ito, eo, np.float32)
     assert np.array_equal(significant_support(xg, 1e-4), sup)
     assert np.array_equal(trg["idx"][:-1], tro["idx"][:-1])
@@ -346,6 +352,8 @@ def test_screened_form_wide_dictionary(sship, n):
     assert st["screen_signals"] + st["screen_redone"] == 1
     assert_parity(xg, itg, eg, xo, ito, eo, np.float32)
     note("test_screened_form_wide_dictionary", n=n, certified=st["screen_signals"], headroom=st["screen_headroom"])
+    if n == 98304:
+        assert st["screen_signals"] == 1           # (a well-posed wide dictionary must be certified, not merely handed back correctly)
     # 3000 copies of one column whose |c0| sits between the support's and the noise's
     rng = np.random.default_rng(n)
     dup = np.sort(rng.choice(n, 3000, replace=False))
@@ -446,6 +454,95 @@ def test_screened_form_compact_records_and_strides(sship, B):
         assert np.array_equal(r["idx"][:r["K"]], nz) and np.array_equal(r["val"][:r["K"]], X[b][nz])
     assert np.array_equal(xbig[::3], X[0]) or np.abs(xbig[::3] - X[0]).max() <= 1e-5 * np.abs(X[0]).max()
     assert np.all(xbig[1::3] == -7.0) and np.all(xbig[2::3] == -7.0)
+
+
+@pytest.mark.parametrize("screen", [0, 2])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_api_surface_with_and_without_the_screened_form(sship, dtype, screen):
+    """What a drop-in user touches — strided host y / x, device-resident y / x, the breakpoint trace, compact records of a small
+    batch — gives the oracle's answer whether the context solves in the screened form (option screen_single = 2: forced on this
+    shape; fp64: its resident tier) or in the engine behind it (0); with 2 every signal must really have been certified."""
+    import torch
+    import sharding
+    m, n, k = 2048, 16384, 16          # (well-posed enough for the fp64 resident tier's 256 columns to hold every signal's support)
+    A, y, x0, sup = make_gaussian_problem(9300 + np.dtype(dtype).itemsize, m, n, k, dtype)
+    tol = 1e-3 if dtype == np.float32 else 1e-9
+    xo, ito, eo, tro = oracle.homotopy(A, y, tol, 4 * k, trace=True)
+    B = 5
+    rng = np.random.default_rng(9350)
+    Y = np.empty((B, m), dtype)
+    for b in range(B):
+        sb = np.sort(rng.choice(n, k, replace=False))
+        xb = np.zeros(n)
+        xb[sb] = 1.0 + np.abs(rng.standard_normal(k))
+        Y[b] = (A.astype(np.float64) @ xb).astype(dtype)
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", screen)
+        h.set_option("trace", 1)
+        h.reset_stats()
+        ybuf = np.zeros(3 * m, dtype)
+        ybuf[::3] = y
+        xbuf = np.full(2 * n, -7.0, dtype)
+        _, it1, e1 = h.solve(ybuf[::3], tol, 4 * k, out=xbuf[::2])
+        tr = h.trace()
+        yd = torch.from_numpy(y).to("cuda:0")
+        xd = torch.full((n,), -3.0, dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda:0")
+        _, it2, e2 = h.solve(yd, tol, 4 * k, out=xd)
+        st = h.stats()
+        h.set_option("trace", 0)
+        rec = h.solve_batch_compact(Y, tol, 4 * k, kmax=48)
+        stb = h.stats()
+        X, its, errs = h.solve_batch(Y, tol, 4 * k)
+    assert_parity(xbuf[::2], it1, e1, xo, ito, eo, dtype)
+    assert np.all(xbuf[1::2] == -7.0)
+    assert np.array_equal(tr["idx"][:-1], tro["idx"][:-1]) and np.array_equal(tr["added"][:-1], tro["added"][:-1])
+    assert np.allclose(tr["gamma"][:-1], tro["gamma"][:-1], rtol=1e-3 if dtype == np.float32 else 1e-8, atol=1e-6 if dtype == np.float32 else 0)
+    assert it2 == it1 and e2 == e1 and np.array_equal(xd.cpu().numpy(), xbuf[::2])
+    note("test_api_surface_with_and_without_the_screened_form", dtype=np.dtype(dtype).name, screen=screen, certified=st["screen_signals"],
+         resident=st["screen_resident"], batch_certified=stb["screen_signals"] - st["screen_signals"])
+    if screen == 2:
+        assert st["screen_signals"] == 2 and st["screen_redone"] == 0 and st["screen_resident"] == 2
+        assert stb["screen_signals"] - st["screen_signals"] == B and stb["screen_redone"] == 0, {k_: v for k_, v in stb.items() if k_.startswith(("why_", "screen_"))}
+    else:
+        assert stb["screen_signals"] == 0
+    recs = sharding.unpack_records(rec, 48, dtype)
+    for b in range(B):
+        r = recs[b]
+        nz = np.nonzero(X[b])[0]
+        assert r["K"] == len(nz) and r["iter"] == its[b] and r["err"] == errs[b]
+        assert np.array_equal(r["idx"][:r["K"]], nz) and np.array_equal(r["val"][:r["K"]], X[b][nz])
+        xb_o, itb_o, eb_o = oracle.homotopy(A, Y[b], tol, 4 * k)
+        assert_parity(X[b], its[b], errs[b], xb_o, itb_o, eb_o, dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_screened_form_tie_goes_to_the_arbiter(sship, dtype):
+    """An exact tie met by the subset solve: A = [I | Gaussian], y = e_0 + e_1 + e_5 / 2.  Column 0 enters (left-most arg-max), column 1
+    then ATTAINS lambda and the reference's strict t > 0 skips it for good (homotopy-cpu.cpp:143-153).  The screened form does not
+    decide such a signal — a tie is a tie of the subset's view —: it goes to the engine behind it, which meets the tie over all columns
+    and asks the reference-order engine; what comes back is the oracle's result, word for word."""
+    m, n = 1024, 16384
+    rng = np.random.default_rng(9360)
+    A = np.empty((m, n), dtype)
+    A[:, :m] = np.eye(m, dtype=dtype)
+    A[:, m:] = (rng.standard_normal((m, n - m)) / np.sqrt(m)).astype(dtype)
+    y = np.zeros(m, dtype)
+    y[0] = y[1] = 1.0
+    y[5] = 0.5
+    tol, max_iter = 1e-3, 12
+    xo, ito, eo, tro = oracle.homotopy(A, y, tol, max_iter, trace=True)
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.set_option("trace", 1)
+        h.reset_stats()
+        xg, itg, eg = h.solve(y, tol, max_iter)
+        trg = h.trace()
+        st = h.stats()
+    note("test_screened_form_tie_goes_to_the_arbiter", dtype=np.dtype(dtype).name, tie_reruns=st["tie_reruns"], why_tie=st["why_tie"],
+         certified=st["screen_signals"], redone=st["screen_redone"], tier2=st["screen_tier2"])
+    assert st["tie_reruns"] == 1 and st["why_tie"] >= 1 and st["screen_signals"] == 0
+    assert itg == ito and eg == eo and np.array_equal(xg, xo)
+    assert np.array_equal(trg["idx"], tro["idx"]) and np.array_equal(trg["added"], tro["added"]) and np.array_equal(trg["gamma"], tro["gamma"])
 
 
 def test_bench_measures_traffic_in_the_run():
