@@ -5,14 +5,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N = 1 — configs[1], the configuration the metric is quoted on: a step is ONE Homotopy solve of one signal
-(A 8192 x 65536 fp32, k = 64) with inputs resident in HBM; `value` = signals/s; `roofline` = the dominant HBM
-kernel — in the screened form (csrc/screen.hip, the default) the correlation GEMV of the metric itself, c~0 = A16^T y
-over the half-precision copy of A (k_scr_first; priced on the bytes of that copy, with SURVEY 8d's fp32 figure beside
-it) —, timed live with HIP events on the solver's stream, its `traffic` measured in the same run (two short child runs of
-tools/pmc_probe.py under `rocprofv3 --pmc`; profiles/traffic.json only as the labelled fallback); `screening_pass` = the second
-pass over the fp16 copy, which certifies the path; `fp32_first_pass` / `atr_gemv` = the same form with c0 = A^T y by the fp32 sweep (k_sweep);
-`without_screening` / `lookahead_sweep_32rhs` = the engine behind it (three fp32 passes over A); those outside the timed
-region.  Outside the timed region the same run also reports: configs[2] (a batch of 4096 signals
+(A 8192 x 65536 fp32, k = 64) with inputs resident in HBM; `value` = signals/s; `roofline` = the METRIC'S kernel, SURVEY 8d's
+fp32 correlation GEMV c = A^T y (k_sweep, 2 147 778 560 bytes per launch), timed with HIP events on the solver's stream and its
+`traffic` measured in the same run (child runs of tools/pmc_probe.py under `rocprofv3 --pmc`; profiles/traffic.json only as the
+labelled fallback) — `in_timed_solve: false`: a certified solve of the shipped default (the screened form, csrc/screen.hip +
+csrc/resident.hip) reads the half-precision copy of A in both of its passes and launches no fp32 sweep; those two passes are
+`screening_pass` (k_scr_gemm, the certificate) and `first_pass_fp16` (k_scr_first, the ranking), the longer one first in
+`fp16_passes_longest_first`; `solve_roofline` = the bytes of those two passes / the whole solve / the HBM peak;
+`dominant_by_time` = the kernel a solve spends most of its time in (the path kernel: one workgroup); `scale_value` = the batched
+workload's signals/s on this world size (the one axis a --gpus sweep has); `fp32_first_pass` / `atr_gemv` = the screened form
+with c0 = A^T y by the fp32 sweep; `without_screening` / `lookahead_sweep_32rhs` = the engine behind the form (three fp32
+passes over A); `extras.harder_workload` = signed coefficients + noise (certified fraction, time incl. hand-backs).  Outside the timed region the same run also reports: configs[2] (a batch of 4096 signals
 sharing A, with the MFMA roofline of the G = A^T A build and the HBM roofline of the Gram-form pass), a 64-signal
 batch without G (screened batch form), the drop-in surface timed with host arrays, OMP, configs[4] in fp64
 (Homotopy and OMP, fp64 screened form), IRLS, and the CPU baseline (the reference's
@@ -206,7 +209,7 @@ def measure_traffic_live(timeout_s=150.0):
             for r in csv.DictReader(open(files[0])):
                 if r.get("Counter_Name") != counter:
                     continue
-                for key, sub in (("first16", "k_scr_first"), ("screen", "k_scr_gemm")):
+                for key, sub in (("first16", "k_scr_first"), ("screen", "k_scr_gemm"), ("sweep1", "k_sweep<float, 1")):
                     if sub in r["Kernel_Name"]:
                         per.setdefault(key, []).append(float(r["Counter_Value"]))
             for key, vals in per.items():
@@ -272,9 +275,16 @@ def main():
     if workload == "auto":
         workload = "single" if world == 1 else "batched"
 
-    # the same seeded sensing matrix on every rank (replicated, 2 GiB of the 288 GB HBM)
-    A_host = survey_matrix()
-    A = torch.from_numpy(A_host).to(dev)
+    # the same seeded sensing matrix on every rank (replicated, 2 GiB of the 288 GB HBM): rank 0 draws it (SURVEY 8d's numpy recipe)
+    # and the other ranks receive it by ONE RCCL broadcast — not N x default_rng on the host cores the ranks share
+    A_host = None
+    if rank == 0 or not use_dist:
+        A_host = survey_matrix()
+        A = torch.from_numpy(A_host).to(dev)
+    else:
+        A = torch.empty((M, N), device=dev, dtype=torch.float32)
+    if use_dist:
+        dist.broadcast(A, src=0)
     if not (rank == 0 and world == 1 and workload == "single" and not args.no_cpu_baseline):
         A_host = None
     h = sship.Homotopy(A, device=local_rank)
@@ -396,6 +406,8 @@ def run_batched(args, h, A, dev, rank, world, use_dist, torch, dist, sharding):
                             "(whose `value` is the single-signal configs[1] rate)",
         },
         "roofline": roof,
+        # one axis for a --gpus sweep (the N = 1 line carries the same workload's single-GPU rate under this key)
+        "scale_value": world * B * args.steps / elapsed,
         "batch_rounds_per_step": st["batch_rounds"] / max(1, args.steps),
         "recovered": {"signals_checked": world * B, "support_exact": int(agg[0].item()),
                       "ran_to_max_iter": int(agg[1].item()), "max_rel_coef_err_rank0": cerr,
@@ -554,6 +566,53 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         del XO
         extras["omp"] = {"workload": "OMP (ss::omp<float>, parity unpinned: the reference has no OMP), the same A and signals, %d picks" % K_SPARSE,
                          "ms_per_solve": dto / args.steps * 1e3, "support_exact": oko, "signals": args.steps}
+
+    # extra (NOT `value`): a HARDER workload for the screened default — signed coefficients (half of them meet the reference's first-step
+    # sign quirk: a derailed path is not certified) and noisy signals, the tolerance above the noise floor
+    if extras is not None:
+        nh = 20
+        hard = []
+        for s_ in range(nh):
+            rngh = np.random.default_rng(880000 + s_)
+            suph = np.sort(rngh.choice(N, K_SPARSE, replace=False))
+            coefh = (1.0 + np.abs(rngh.standard_normal(K_SPARSE))) * rngh.choice([-1.0, 1.0], K_SPARSE)
+            yh = (A[:, torch.from_numpy(suph).to(dev)].double() @ torch.from_numpy(coefh).to(dev))
+            yh = yh + 1e-2 * float(yh.std().item()) * torch.from_numpy(rngh.standard_normal(M)).to(dev)
+            hard.append((yh.float().contiguous(), suph, coefh))
+        h.solve(hard[0][0], 2e-2, MAX_ITER, out=xw)
+        h.reset_stats()
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        okh = 0
+        for (yh, suph, coefh) in hard:
+            h.solve(yh, 2e-2, MAX_ITER, out=xw)
+            xs_ = xw.cpu().numpy()
+            big = np.nonzero(np.abs(xs_) > 0.3)[0]
+            okh += int(np.array_equal(big, suph) and bool(np.all(np.sign(xs_[suph]) == np.sign(coefh))))
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - th
+        sth = h.stats()
+        # ... the same signals through the engine behind the form only
+        h.set_option("screen_single", 0)
+        h.solve(hard[0][0], 2e-2, MAX_ITER, out=xw)
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for (yh, suph, coefh) in hard:
+            h.solve(yh, 2e-2, MAX_ITER, out=xw)
+        torch.cuda.synchronize()
+        dth0 = time.perf_counter() - th0
+        h.set_option("screen_single", 1)
+        extras["harder_workload"] = {
+            "workload": "configs[1] matrix; %d signals with SIGNED coefficients +-(1 + |N(0,1)|) on 64 columns and noise 1e-2 x std(y) per entry; "
+                        "tolerance 2e-2 (above the noise floor), max_iter 256; shipped defaults (reference behaviour: the first-step sign quirk "
+                        "derails the paths whose leading correlation is negative; such a path is not certified and goes to the default engine)" % nh,
+            "ms_per_solve_incl_hand_backs_and_host_copy_of_x": dth / nh * 1e3,
+            "ms_per_solve_default_engine_only": dth0 / nh * 1e3,
+            "signals": nh, "certified": int(sth["screen_signals"]), "handed_back": int(sth["screen_redone"]),
+            "certified_fraction": sth["screen_signals"] / float(nh),
+            "why_not_certified": {k_: int(v_) for k_, v_ in sth.items() if k_.startswith("why_") and v_},
+            "tie_reruns": int(sth["tie_reruns"]),
+            "planted_support_and_signs_recovered": okh}
 
     # extra (NOT `value`): the reference-order engine (engine 3: every reduction in the documented 8-partial order, one
     # fused pass over A per iteration; the arbiter of exact ties) on the same matrix and signals — its sweep and a whole solve
@@ -813,23 +872,36 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         f16_ms = st["first16_ms"] / max(1, st["first16_launches"])
         f16_bytes = st["first16_bytes"] / max(1, st["first16_launches"])
         f16_gbs = f16_bytes / (f16_ms * 1e-3) / 1e9 if f16_ms > 0 else 0.0
+        first_pass_roof = None
         if screened and first16:
-            # screened form with BOTH passes over the fp16 copy of A (csrc/screen.hip, the default): the dominant HBM-bound kernel is the
-            # correlation GEMV of the metric itself, c~0 = A16^T y (k_scr_first).  Priced on the bytes it is given to read — the
-            # half-precision copy; by SURVEY 8d's fp32 figure for a sweep (m n 4 + m 4 + n 4) the same launch would read as
-            # `by_survey_8d_fp32_bytes` (above the HBM peak: the pass answers the sweep's question from half the bytes)
+            # The metric's kernel is SURVEY 8d's fp32 correlation GEMV c = A^T y (k_sweep, one right-hand side, m n 4 + m 4 + n 4 bytes).
+            # The shipped default no longer launches it in a certified solve — both passes of the screened form read the fp16 copy of A —
+            # so it is timed (HIP events on the solver's stream, inside solves) in the run of the same signals with option
+            # screen_first16 = 0, where every solve starts with it; `in_timed_solve` says so.  The two passes that ARE in the timed
+            # solve follow as `screening_pass` and `first_pass_fp16` (the longer one first).
             s8d = float(M) * N * 4 + M * 4 + N * 4
-            roof = {"bound": "hbm", "kernel": "k_scr_first<4 columns per wave, 3 stages>: c~0 = A16^T y, the correlation GEMV of the metric over the "
-                                              "half-precision copy of A (16-byte column loads, y in LDS, fp32 sums) — the first of the two passes "
-                                              "over A16 of a solve in the screened form; no fp32 pass over A is left in a certified solve",
-                    "achieved": f16_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f16_gbs / HBM_PEAK_GBS,
-                    "traffic": live["first16"] if live else tj.get("first16_hbm_bytes_per_launch"), "bytes_per_launch": f16_bytes,
-                    "avg_launch_ms": f16_ms, "launches_timed": st["first16_launches"],
-                    "by_survey_8d_fp32_bytes": {"bytes_per_launch": s8d, "achieved": s8d / (f16_ms * 1e-3) / 1e9 if f16_ms > 0 else 0.0,
-                                                "frac": (s8d / (f16_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if f16_ms > 0 else 0.0},
-                    "traffic_source": live_src if live else
-                                      (("profiles/traffic.json (%s): HBM bytes per launch from separate rocprofv3 --pmc passes (recorded once, "
-                                        "replayed here; NOT measured in this run)" % tj.get("first16_source")) if tj.get("first16_hbm_bytes_per_launch") else None)}
+            roof = {"bound": "hbm", "kernel": "k_sweep<float, 1 rhs, 16 waves x 4 columns>: c = A^T y, the fp32 correlation GEMV of the metric "
+                                              "(SURVEY 8d: coalesced 16-byte column loads, y in LDS, per-lane partial sums + wave reduction)",
+                    "achieved": s1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s1_gbs / HBM_PEAK_GBS,
+                    "traffic": (live["sweep1"] if (live and "sweep1" in live) else tj.get("sweep1_hbm_bytes_per_launch")),
+                    "bytes_per_launch": s8d, "avg_launch_ms": s1_ms, "launches_timed": st_s1["sweep1_launches"],
+                    "in_timed_solve": False,
+                    "timed_in": "the run of the timed signals with option screen_first16 = 0 (the screened form with c0 = A^T y by this sweep), "
+                                "HIP events on the solver's stream around the launch inside the solves",
+                    "traffic_source": live_src if (live and "sweep1" in live) else
+                                      "profiles/traffic.json (HBM bytes per launch from separate rocprofv3 --pmc passes, replayed; NOT measured in this run)"}
+            first_pass_roof = {"bound": "hbm", "kernel": "k_scr_first<4 columns per wave, 3 stages>: c~0 = A16^T y over the half-precision copy of A (16-byte column "
+                                                         "loads, y in LDS, fp32 sums) — the first of the two passes over A16 of a solve in the screened form: the "
+                                                         "ranking of the columns; state 0 is certified from it like every other state",
+                               "achieved": f16_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f16_gbs / HBM_PEAK_GBS,
+                               "traffic": live["first16"] if live else tj.get("first16_hbm_bytes_per_launch"), "bytes_per_launch": f16_bytes,
+                               "avg_launch_ms": f16_ms, "launches_timed": st["first16_launches"], "in_timed_solve": True,
+                               "by_survey_8d_fp32_bytes": {"bytes_per_launch": s8d, "achieved": s8d / (f16_ms * 1e-3) / 1e9 if f16_ms > 0 else 0.0,
+                                                           "frac": (s8d / (f16_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if f16_ms > 0 else 0.0,
+                                                           "note": "the pass answers the sweep's question (the ranking) from half the bytes: not a bandwidth"},
+                               "traffic_source": live_src if live else
+                                                 (("profiles/traffic.json (%s): replayed; NOT measured in this run" % tj.get("first16_source"))
+                                                  if tj.get("first16_hbm_bytes_per_launch") else None)}
         elif screened:
             # screened form with the fp32 first pass (option screen_first16 = 0, or a row count the half-precision first pass does not
             # take): the passes over A are c = A^T y (fp32, k_sweep) and the screening pass over the fp16 copy of A
@@ -850,7 +922,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                         "traffic": live["screen"] if (live and "screen" in live) else tj.get("screen_hbm_bytes_per_launch"),
                         "traffic_source": live_src if (live and "screen" in live) else "profiles/traffic.json (replayed; NOT measured in this run)",
                         "bytes_per_launch": sc_bytes, "avg_launch_ms": sc_ms,
-                        "launches_timed": st["screen_launches"],
+                        "launches_timed": st["screen_launches"], "in_timed_solve": True,
                         "certificate_headroom": st["screen_headroom"],
                         "note": "bytes = the fp16 copy of A (ldm * n_pad * 2) + the residual block + the column norms; headroom = largest "
                                 "(|c~| + eps) / bound of the last solve (< 1: certified)"}
@@ -894,6 +966,30 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                 "sweep_variant": h.get_option("sweep_variant"), "engine": engine,
             },
             "roofline": roof,
+            # the two HBM passes a certified solve actually runs (over the fp16 copy of A), the longer one first
+            "fp16_passes_longest_first": (sorted([kk for kk, vv in (("screening_pass", scr_roof), ("first_pass_fp16", first_pass_roof)) if vv],
+                                                 key=lambda kk: -{"screening_pass": scr_roof, "first_pass_fp16": first_pass_roof}[kk]["avg_launch_ms"])
+                                          if screened else None),
+            "first_pass_fp16": first_pass_roof,
+            # what a solve's time buys against the HBM roof: the algorithmic bytes of its passes over A16 / the whole solve
+            "solve_roofline": ({"bound": "hbm", "algorithmic_bytes_per_solve": f16_bytes + scr_roof["bytes_per_launch"],
+                                "achieved": (f16_bytes + scr_roof["bytes_per_launch"]) / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": (f16_bytes + scr_roof["bytes_per_launch"]) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "bytes = the two passes over the fp16 copy of A (ranking + certificate); the reference moves 4 m n 4 bytes per ITERATION"}
+                               if (screened and first16) else None),
+            # the kernel a solve spends most of its time in
+            "dominant_by_time": ({"kernel": "k_res_solve<float> (csrc/resident.hip): all iterations of the path in ONE workgroup — the subset's Gram "
+                                            "values in registers, the inverse in LDS, four workgroup barriers per iteration; latency / issue-bound, "
+                                            "no bandwidth or MFMA roof to stand against",
+                                  "us": 1e3 * st["res_solve_ms"] / max(1, st["res_solve_launches"]), "compute_units_used": 1, "of_compute_units": 256,
+                                  "share_of_solve": (st["res_solve_ms"] / max(1, st["res_solve_launches"])) / ms_per_step,
+                                  "us_per_iteration": 1e3 * st["res_solve_ms"] / max(1, st["res_solve_launches"]) / max(1.0, st["iterations"] / max(1, st["solves"])),
+                                  "launches_timed": int(st["res_solve_launches"])}
+                                 if (screened and st.get("res_solve_launches", 0) > 0) else None),
+            # one axis for a --gpus sweep: the BATCHED workload's signals/s on this world size (configs[2] here, configs[3] on N > 1)
+            "scale_value": batched["signals_per_s"] if batched else None,
+            "scale_value_note": "signals/s of the batched workload (4096 signals per rank and step sharing A) on this world size: the N > 1 lines' "
+                                "`value` is this quantity, the N = 1 line's `value` is the single-signal rate of configs[1]",
             # the 32-column lookahead sweep (HBM-bound), when any of the timed solves needed one
             "lookahead_sweep_32rhs": hbm_roof if roof is not hbm_roof else None,
             # screened form: the (second) pass over the fp16 copy of A that certifies every state of the path against all columns
@@ -1042,12 +1138,16 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         extras["fp64_configs4"] = {
             "workload": "configs[4] shape: Homotopy fp64, A 16384x131072 (16 GiB, torch.randn seed 4321 / sqrt(m)), k=128, tol 1e-9, max_iter 512",
             "ms_per_solve": dt5 * 1e3, "iterations": int(it5), "support_exact": ok5, "max_rel_coef_err": err5,
-            "engine": ("fp64 screened form (csrc/screen.hip): the columns ranked by c~0 = A16^T y over the fp16 copy of A (option screen_first16; 0 = A^T y "
-                       "by the fp64 sweep), the path solved by the fp64 engine on a sub-dictionary of the 2048 best (a context of its own; lambda_0 and "
-                       "every value reported are its fp64 arithmetic), every state — state 0 included — certified against all columns by the "
-                       "pass over the fp16 copy"
+            "engine": ("fp64 screened form (csrc/screen.hip) with its RESIDENT tier (csrc/resident.hip): the columns ranked by c~0 = A16^T y over the fp16 copy "
+                       "of A (option screen_first16; 0 = A^T y by the fp64 sweep); the 256 best become the subset — their Gram matrix and exact fp64 c0 "
+                       "from the fp64 dictionary (v_mfma_f64_16x16x4_f64) —, the whole path runs in ONE workgroup in fp64 (Gram values in registers, "
+                       "the inverse in LDS: every value reported is that arithmetic), every state — state 0 included — is certified against all "
+                       "columns by the pass over the fp16 copy; everything queued in one go.  What this tier does not report goes to the "
+                       "sub-dictionary tier (2048 columns, launch-per-iteration engine), then to the default engine"
                        if st5["screen_signals"] > 0 else "lookahead engine, one launch per iteration"),
-            "screened_form": {"signals_certified": int(st5["screen_signals"]), "signals_redone_in_the_default_engine": int(st5["screen_redone"]),
+            "screened_form": {"signals_certified": int(st5["screen_signals"]), "by_the_resident_tier": int(st5["screen_resident"]),
+                              "handed_to_the_sub_dictionary_tier": int(st5["screen_tier2"]),
+                              "signals_redone_in_the_default_engine": int(st5["screen_redone"]),
                               "certificate_headroom": st5["screen_headroom"]},
             "without_screening": un5,
             "fp64_first_pass": f64first5,

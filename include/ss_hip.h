@@ -297,6 +297,9 @@ typedef struct ss_hip_stats {
     uint64_t why_column;           /* the screening pass (or the subset form's check) could not certify a (column, state)                  */
     uint64_t why_tie;              /* the subset's scan met an exact tie (its view: the default engine decides)                            */
     uint64_t screen_recheck;       /* screened signals whose uncertified (column, state) pairs were re-derived exactly in fp32 and passed   */
+    uint64_t res_solve_launches;   /* timed launches (profiling on) of the path kernel of a screened single signal — k_res_solve (or, option
+                                      screen_resident = 0, k_sub_solve): ONE workgroup, all iterations of the solve                        */
+    double   res_solve_ms;         /* sum of their HIP-event durations                                                                    */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------

@@ -52,6 +52,7 @@ struct Rccl {
     int (*GetUniqueId)(cs_unique_id*) = nullptr;
     int (*CommInitRank)(cs_comm_t*, int, cs_unique_id, int) = nullptr;
     int (*CommDestroy)(cs_comm_t) = nullptr;
+    int (*CommAbort)(cs_comm_t) = nullptr;             // (optional: a communicator with an outstanding collective is aborted, not destroyed)
     int (*AllReduce)(const void*, void*, size_t, int, int, cs_comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -73,6 +74,7 @@ static Rccl* rccl()
     r.GetUniqueId = reinterpret_cast<int (*)(cs_unique_id*)>(dlsym(r.lib, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<int (*)(cs_comm_t*, int, cs_unique_id, int)>(dlsym(r.lib, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<int (*)(cs_comm_t)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<int (*)(cs_comm_t)>(dlsym(r.lib, "ncclCommAbort"));
     r.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, cs_comm_t, hipStream_t)>(dlsym(r.lib, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(r.lib, "ncclGetErrorString"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) { r.lib = nullptr; return nullptr; }
@@ -101,6 +103,10 @@ struct ColShard {
     uint32_t xcount = 0;            // its length in floats
     // pinned staging for host collectives
     unsigned char* hstage = nullptr;
+    // the ranks' agreement on "everything this solve needs is allocated" (made at create: it must exist when an allocation fails)
+    uint64_t* agree_dev = nullptr;  // [1] device word of the RCCL all-reduce
+    uint64_t* agree_host = nullptr; // [1] pinned
+    bool dead = false;              // the communicator was aborted in the middle of a solve: the context refuses further solves
 };
 
 struct CsState {                     // device-resident, replicated scalars (one 128-byte line)
@@ -547,6 +553,8 @@ void colshard_destroy(ss_hip_ctx* ctx)
     if (!cs) return;
     if (cs->comm != nullptr) { Rccl* r = rccl(); if (r) (void)r->CommDestroy(cs->comm); }
     cs_free(cs);
+    if (cs->agree_dev) (void)hipFree(cs->agree_dev);
+    if (cs->agree_host) (void)hipHostFree(cs->agree_host);
     delete cs;
     ctx->colshard = nullptr;
 }
@@ -600,6 +608,13 @@ ss_hip_ctx* ss_hip_homotopy_colshard_create_f32(const float* A_local, size_t m, 
     ctx->colshard = cs;
     cs->col_lo = (uint32_t)col_lo; cs->n_total = (uint32_t)n_total; cs->rank = rank; cs->world = world;
     cs->n_local = (uint32_t)n_local;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&cs->agree_dev), 64) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&cs->agree_host), 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_err(err, errlen, "colshard_create: out of memory");
+        ss_hip_homotopy_destroy(ctx);
+        return nullptr;
+    }
     if (comm_id != nullptr) {
         Rccl* r = rccl();
         if (!r) { set_err(err, errlen, "colshard_create: librccl.so could not be loaded"); ss_hip_homotopy_destroy(ctx); return nullptr; }
@@ -631,26 +646,66 @@ int ss_hip_homotopy_colshard_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_
     if (max_iter == 0) { set_err(err, errlen, "colshard_solve: max_iterations must be > 0"); return SS_HIP_EINVAL; }
     if (!(tol >= std::numeric_limits<float>::epsilon() && tol < 1.f)) { set_err(err, errlen, "colshard_solve: tolerance must satisfy eps <= tolerance < 1"); return SS_HIP_EINVAL; }
     if (incy <= 0 || incx <= 0) { set_err(err, errlen, "colshard_solve: vector increments must be positive"); return SS_HIP_EINVAL; }
+    if (cs->dead) { set_err(err, errlen, "colshard_solve: the communicator of this context was aborted by an earlier failure"); return SS_HIP_ERUNTIME; }
+    // ---- everything this solve allocates, BEFORE the first collective; then the ranks AGREE on having it.  The protocol below is
+    // collective: a rank that left alone on a failed hipMalloc would leave the others blocked in their next all-reduce for good.
+    const uint32_t kcap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(cs->n_total, (uint64_t)max_iter + 1), kKcapLimit);
+    const uint32_t want_trace = ctx->tracing ? (uint32_t)std::min<uint64_t>((uint64_t)max_iter + 2, 1u << 20) : 0u;
+    int local = SS_HIP_OK;
+    std::string local_msg;
     try {
         CSHIP(hipSetDevice(ctx->device));
-        const uint32_t kcap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(cs->n_total, (uint64_t)max_iter + 1), kKcapLimit);
+        if (ctx->colshard_fail_prepare) throw CsFail{ "preparation failure requested (option colshard_fail_prepare)" };
         cs_ensure(ctx, cs, kcap);
-        const uint32_t K = cs->kcap;
         // the shard's own workspace: y, rhs (r, p), c, q, x, d, insup, sweep partials (homotopy.hip: Workspace<float>)
-        int rc0 = colshard_workspace(ctx, kcap);
-        if (rc0 != SS_HIP_OK) { set_err(err, errlen, "colshard_solve: workspace allocation failed"); return rc0; }
+        const int rc0 = colshard_workspace(ctx, kcap);
+        if (rc0 != SS_HIP_OK) throw CsFail{ "workspace allocation failed" };
+        Workspace<float>& ws0 = *static_cast<Workspace<float>*>(ctx->ws);
+        if (want_trace > ws0.trace_cap) {
+            if (ws0.trace) CSHIP(hipFree(ws0.trace));
+            ws0.trace = nullptr; ws0.trace_cap = 0;
+            CSHIP(hipMalloc(&ws0.trace, (size_t)want_trace * sizeof(TraceEntry)));
+            ws0.trace_cap = want_trace;
+        }
+    } catch (const CsFail& f) {
+        (void)hipGetLastError();
+        local = SS_HIP_ENOMEM;
+        local_msg = f.msg;
+    } catch (const std::bad_alloc&) {
+        local = SS_HIP_ENOMEM;
+        local_msg = "out of host memory";
+    }
+    {
+        // max over the ranks of the local status (0 = ready): one 8-byte all-reduce per solve
+        uint64_t agreed = (uint64_t)local;
+        bool transport_failed = false;
+        if (cs->comm != nullptr) {
+            Rccl* r = rccl();
+            *cs->agree_host = agreed;
+            if (hipMemcpyAsync(cs->agree_dev, cs->agree_host, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                r->AllReduce(cs->agree_dev, cs->agree_dev, 1, kNcclUint64, kNcclMax, cs->comm, ctx->stream) != 0 ||
+                hipMemcpyAsync(cs->agree_host, cs->agree_dev, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); transport_failed = true; }
+            else agreed = *cs->agree_host;
+        } else if (cs->have_host) {
+            if (cs->host.allreduce_max_u64(cs->host.user, &agreed, 1) != 0) transport_failed = true;
+        }
+        if (transport_failed) { set_err(err, errlen, "colshard_solve: the ranks could not agree on their preparation (collective failed)"); return SS_HIP_ERUNTIME; }
+        if (agreed != 0) {
+            set_err(err, errlen, local != SS_HIP_OK ? "colshard_solve: preparation failed on this rank: " + local_msg
+                                                    : std::string("colshard_solve: preparation failed on another rank; every rank leaves the solve"));
+            return (int)agreed;
+        }
+    }
+    bool in_collectives = false;
+    try {
+        const uint32_t K = cs->kcap;
         Workspace<float>& ws = *static_cast<Workspace<float>*>(ctx->ws);
         hipStream_t st = ctx->stream;
         const uint32_t ldm = ctx->ldm, m = (uint32_t)ctx->m, nl = cs->n_local, np = ctx->n_pad;
         const float* At = static_cast<const float*>(ctx->At);
         CsState* dst = reinterpret_cast<CsState*>(ws.st);                  // (DevState is 640 bytes: room for the 128 of CsState)
-        const uint32_t want_trace = ctx->tracing ? (uint32_t)std::min<uint64_t>((uint64_t)max_iter + 2, 1u << 20) : 0u;
-        if (want_trace > ws.trace_cap) {
-            if (ws.trace) CSHIP(hipFree(ws.trace));
-            ws.trace = nullptr; ws.trace_cap = 0;
-            CSHIP(hipMalloc(&ws.trace, (size_t)want_trace * sizeof(TraceEntry)));
-            ws.trace_cap = want_trace;
-        }
+        in_collectives = true;
         TraceEntry* trace = ctx->tracing ? ws.trace : nullptr;
         ctx->host_flags[0] = 0; ctx->host_flags[1] = 0;
         // y, zero padded; x, d, membership flags of the shard
@@ -731,6 +786,16 @@ int ss_hip_homotopy_colshard_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_
         ctx->stats.solves += 1;
         ctx->stats.iterations += hs.iter;
     } catch (const CsFail& f) {
+        // A failure in the middle of the protocol (a launch error, a collective that returned an error): this rank's communicator may
+        // have a collective outstanding — it is ABORTED (ncclCommAbort), not destroyed later, and the context refuses further solves.
+        // (The other ranks learn of it from their transport: RCCL reports the aborted peer, a host table returns non-zero.)
+        (void)hipGetLastError();
+        if (in_collectives && cs->comm != nullptr) {
+            Rccl* r = rccl();
+            if (r && r->CommAbort) (void)r->CommAbort(cs->comm);
+            cs->comm = nullptr;
+            cs->dead = true;
+        }
         set_err(err, errlen, f.msg);
         return SS_HIP_ERUNTIME;
     } catch (const std::bad_alloc&) {

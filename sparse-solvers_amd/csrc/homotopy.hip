@@ -825,7 +825,7 @@ inline hipError_t sub_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t) 
 
 // one signal in the screened form (screen.hip): no G — the subset's own Gram matrix from A, then one pass over the fp16 copy of A
 inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, hipEvent_t e0, hipEvent_t e1,
-                             hipEvent_t e2, hipEvent_t e3)
+                             hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5)
 {
     const size_t need = sub_buffer_bytes(1);
     if (ctx->sub_buf_bytes < need) {
@@ -840,9 +840,9 @@ inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, u
         HIPCHK(hipMemsetAsync(ctx->sub_dbg, 0, 16 * sizeof(unsigned long long), ctx->stream));
     }
     // (with the state mirrored to mapped host memory the epilogue launch applies the certificate's verdict: no k_sub_finish)
-    return launch_screen_form(ctx, ws, tol, max_iter, first16, ctx->hs_mapped == nullptr, e0, e1, e2, e3);
+    return launch_screen_form(ctx, ws, tol, max_iter, first16, ctx->hs_mapped == nullptr, e0, e1, e2, e3, e4, e5);
 }
-inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
 // (typed shims of the fp64 screened form: never reached for float)
 inline hipError_t scr64_gather(ss_hip_ctx* ctx, const double* c0, const double* y, hipEvent_t e0, hipEvent_t e1) { return screen64_gather(ctx, c0, y, e0, e1); }
 inline hipError_t scr64_gather(ss_hip_ctx*, const float*, const float*, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
@@ -854,11 +854,11 @@ inline hipError_t scr64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const do
 inline hipError_t scr64_certify(ss_hip_ctx*, Workspace<float>&, const float*, uint32_t, float, double, uint32_t, hipEvent_t, hipEvent_t, bool, bool) { return hipErrorInvalidConfiguration; }
 
 inline hipError_t scr64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp, hipEvent_t e0, hipEvent_t e1,
-                                 hipEvent_t e2, hipEvent_t e3)
+                                 hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5)
 {
-    return launch_screen64_resident(ctx, ws, tol, max_iter, first16, omp, e0, e1, e2, e3);
+    return launch_screen64_resident(ctx, ws, tol, max_iter, first16, omp, e0, e1, e2, e3, e4, e5);
 }
-inline hipError_t scr64_resident(ss_hip_ctx*, Workspace<float>&, float, uint32_t, bool, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr64_resident(ss_hip_ctx*, Workspace<float>&, float, uint32_t, bool, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
 
 // why a subset / screened solve was not reported: DevState::sub_reason's bits into the statistics
 inline void count_reasons(ss_hip_ctx* ctx, uint32_t r, bool tie)
@@ -1040,11 +1040,11 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c0, nullptr, ws.pmax_val, ws.pmax_idx, &nb1, ws.st));
                 if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
             }
-            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
             if (prof && first16) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(7); ++nprof; }
-            if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); }
-            HIPCHK(scr64_resident(ctx, ws, tol, max_iter, first16, omp, e0, e1, e2, e3));
-            if (prof) { ctx->prof_kind.push_back(6); ++nprof; }
+            if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); e4 = prof_event(ctx, 2 * nprof + 2); e5 = prof_event(ctx, 2 * nprof + 3); }
+            HIPCHK(scr64_resident(ctx, ws, tol, max_iter, first16, omp, e0, e1, e2, e3, e4, e5));
+            if (prof) { ctx->prof_kind.push_back(6); ctx->prof_kind.push_back(8); nprof += 2; }      // (6 = the screening pass, 8 = the path kernel)
         } else if (scr64) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             if (!omp) HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y (OMP: done above)
@@ -1121,11 +1121,11 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 HIPCHK(sub_single(ctx, ws, tol, max_iter));
             } else {
                 // (6 = the screening pass over the fp16 copy of A, 7 = the first pass when it runs there too)
-                hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+                hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
                 if (prof && first16) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(7); ++nprof; }
-                if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); }
-                HIPCHK(scr_single(ctx, ws, tol, max_iter, first16, e0, e1, e2, e3));
-                if (prof) { ctx->prof_kind.push_back(6); ++nprof; }
+                if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); e4 = prof_event(ctx, 2 * nprof + 2); e5 = prof_event(ctx, 2 * nprof + 3); }
+                HIPCHK(scr_single(ctx, ws, tol, max_iter, first16, e0, e1, e2, e3, e4, e5));
+                if (prof) { ctx->prof_kind.push_back(6); ctx->prof_kind.push_back(8); nprof += 2; }      // (6 = the screening pass, 8 = the path kernel)
             }
         } else if (la) {
             Lookahead<T>::ensure(ctx, ws, kcap);
@@ -1480,6 +1480,9 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                     ctx->stats.screen_launches += scr_launches;
                     ctx->stats.screen_ms += ms;
                     ctx->stats.screen_bytes += (uint64_t)scr_launches * ((uint64_t)ctx->ldm * ctx->n_pad * 2ull + 96ull * ctx->ldm * 2ull + (uint64_t)ctx->n_pad * 4ull);
+                } else if (ctx->prof_kind[i] == 8) {
+                    ctx->stats.res_solve_launches += 1;
+                    ctx->stats.res_solve_ms += ms;
                 } else if (ctx->prof_kind[i] == 7) {
                     ctx->stats.first16_launches += 1;
                     ctx->stats.first16_ms += ms;
@@ -2676,6 +2679,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "screen_first16")) { ctx->screen_first16 = value != 0 ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_screen"))  { ctx->batch_screen = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_resident")) { ctx->screen_resident = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "colshard_fail_prepare")) { ctx->colshard_fail_prepare = value ? 1 : 0; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 
@@ -2752,6 +2756,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "screen_first16")) { *value = ctx->screen_first16; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_screen"))  { *value = ctx->batch_screen; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_resident")) { *value = ctx->screen_resident; return SS_HIP_OK; }
+    if (!std::strcmp(key, "colshard_fail_prepare")) { *value = ctx->colshard_fail_prepare; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
 

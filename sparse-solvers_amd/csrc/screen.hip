@@ -1211,7 +1211,7 @@ static hipError_t launch_scr_first(ss_hip_ctx* ctx, ScreenState* S, const TY* y,
 }
 
 hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, bool finish, hipEvent_t e0,
-                              hipEvent_t e1, hipEvent_t e2, hipEvent_t e3)
+                              hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5)
 {
     ScreenState* S = scr_of(ctx);
     if (S == nullptr || ctx->sub_buf == nullptr) return hipErrorInvalidConfiguration;
@@ -1232,13 +1232,15 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256 + (first16 ? kSbS : 0u)), dim3(256), 0, s, (const float*)S->gs_part, nsplit, S->gs,
                        At, ldm, (const float*)ws.rhs, (const uint32_t*)B.sub, n, ws.c0);
     // the path on the subset: the resident kernel (resident.hip: Gram values in registers, four barriers per iteration) or, option
-    // screen_resident = 0, k_sub_solve (subbatch.hip) — the same log either way
+    // screen_resident = 0, k_sub_solve (subbatch.hip) — the same log either way (e4, e5: profiling events around it)
+    if (e4) (void)hipEventRecord(e4, s);
     if (ctx->screen_resident && res_solve_usable<float>()) {
         const ResLog<float> log{ B.hdr, nullptr, B.pcol, B.LX };
         (void)launch_res_solve<float>(ctx, 1, (const float*)S->gs, kSbS, 0, (const float*)ws.c0, 0, (const uint32_t*)B.sub, tol, max_iter, ws.dims.kcap, log, ws.x, 0,
                                       ws.gam, ws.touched, ws.st, ws.trace, ws.trace_cap, false);
     } else
         (void)launch_sub_solve(ctx, ws, B, 1, (const float*)S->gs, kSbS, first16 ? 2 : 1, ws.c0, tol, max_iter);
+    if (e5) (void)hipEventRecord(e5, s);
     hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs,
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
                        (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, first16 ? 1 : 0);
@@ -1493,7 +1495,7 @@ bool screen64_resident_usable(ss_hip_ctx* ctx)
 }
 
 hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp, hipEvent_t e0,
-                                    hipEvent_t e1, hipEvent_t e2, hipEvent_t e3)
+                                    hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5)
 {
     typedef ResCfg<double> RC;
     ScreenState* S = scr_of(ctx);
@@ -1513,9 +1515,11 @@ hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, doub
                             first16 ? S->meta + 6 : nullptr);
     { const hipError_t eg = launch_sgram64(ctx, S->sub256, y, S->gs64_part, S->gs64, ws.c0); if (eg != hipSuccess) return eg; }
     const ResLog<double> log{ S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X };
+    if (e4) (void)hipEventRecord(e4, s);
     { const hipError_t es = launch_res_solve<double>(ctx, 1, S->gs64, (uint32_t)RC::S, 0, ws.c0, 0, S->sub256, tol, max_iter, ws.dims.kcap, log, ws.x, 0, ws.gam,
                                                      ws.touched, ws.st, ws.trace, ws.trace_cap, omp);
       if (es != hipSuccess) return es; }
+    if (e5) (void)hipEventRecord(e5, s);
     (void)launch_res_residuals64(ctx, y, log, tol, S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, first16, omp);
     if (e2) (void)hipEventRecord(e2, s);
     hipLaunchKernelGGL(k_scr_gemm<4>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds((uint32_t)RC::S, 4), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,

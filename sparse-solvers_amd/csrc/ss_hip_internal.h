@@ -311,6 +311,7 @@ struct ss_hip_ctx {
     int gram_single = 1;         // option: 1 = single-signal solves use G as their Gram-column cache once it exists, 0 = never
     int gram_symmetric = 1;      // option: 1 = G is formed from the tiles on and above the diagonal + mirrored store, 0 = full product
     uint64_t single_solves = 0;  // single-signal solves since create (the trigger of gram_full_after; not a statistic)
+    int colshard_fail_prepare = 0;   // test option: this rank's column-sharded solves fail in their preparation (the ranks must all leave)
     void* colshard = nullptr;    // sship::ColShard* of a column-sharded context (colshard.hip): shard description, communicator, replicated active set
     int kind = 0;            // 0 = Homotopy / OMP context, 1 = IRLS context
     void* irls = nullptr;    // sship::IrlsState<T>* of an IRLS context
@@ -437,7 +438,7 @@ hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32
 bool screen_form_usable(ss_hip_ctx* ctx);                 // shape / option test + one-time preparation (fp16 copy of A, column norms)
 bool screen_first16_usable(const ss_hip_ctx* ctx);        // ... with the FIRST pass (A^T y) over the half-precision copy too
 hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, bool finish, hipEvent_t e0 = nullptr,
-                              hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
+                              hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr, hipEvent_t e4 = nullptr, hipEvent_t e5 = nullptr);
 // a batch chunk of nslots <= screen_batch_cap() signals in the screened form: c0 = A^T y of every slot in c0_all ([nslots][n_pad]), the
 // signals in ws.y; the slots' verdicts in their states (k_sub_finish) like the subset form's
 uint32_t screen_batch_cap();
@@ -454,7 +455,8 @@ hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double
 // fp64, resident tier (resident.hip): the path on the 256 best-ranked columns in ONE workgroup, everything queued in one go
 bool screen64_resident_usable(ss_hip_ctx* ctx);
 hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp,
-                                    hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
+                                    hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr,
+                                    hipEvent_t e4 = nullptr, hipEvent_t e5 = nullptr);
 double screen_read_headroom(ss_hip_ctx* ctx);             // largest (|c~| + eps) / bound of the last screened solve (synchronises)
 hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr);      // signals one pass of the engine can carry (1 without the LDS-staged sweep)

@@ -111,6 +111,8 @@ class Stats(ctypes.Structure):
         ("why_column", ctypes.c_uint64),
         ("why_tie", ctypes.c_uint64),
         ("screen_recheck", ctypes.c_uint64),
+        ("res_solve_launches", ctypes.c_uint64),
+        ("res_solve_ms", ctypes.c_double),
     ]
 
 

@@ -308,6 +308,60 @@ def test_native_column_sharded_host_collectives(tmp_path, cfg):
     assert np.abs(x0 - x1).max() <= (1e-5 if which != 1 else 2e-3) * np.abs(xo).max()
 
 
+def _native_failing_rank(rank, world, port, tmpdir, bad_rank):
+    """one rank of a column-sharded solve in which rank `bad_rank` fails in its preparation (option colshard_fail_prepare):
+    EVERY rank must come back with an error — nobody may be left waiting in a collective"""
+    import torch
+    import torch.distributed as dist
+    import sship
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, y, tol, mi = _native_problem(0)
+    lo, hi = _bounds(A.shape[1], world, 0)[rank]
+
+    def allreduce(buf, op):
+        t = torch.from_numpy(buf.view(np.int64) if buf.dtype == np.uint64 else buf)
+        dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
+
+    shard = torch.from_numpy(np.ascontiguousarray(A[:, lo:hi])).to("cuda:0")
+    outcome = {}
+    with sship.ColumnSharded(shard, lo, A.shape[1], rank=rank, world=world, allreduce=allreduce) as h:
+        if rank == bad_rank:
+            h.set_option("colshard_fail_prepare", 1)
+        try:
+            h.solve(torch.from_numpy(y).to("cuda:0"), tol, mi)
+            outcome["first"] = "ok"
+        except sship.SsHipError as ex:
+            outcome["first"] = "error %d: %s" % (ex.code, str(ex)[:120])
+        # the same context, the failure gone: the ranks solve together again
+        h.set_option("colshard_fail_prepare", 0)
+        x, it, err = h.solve(torch.from_numpy(y).to("cuda:0"), tol, mi)
+        outcome["second_iter"] = int(it)
+    import json
+    with open(os.path.join(tmpdir, "fail_rank%d.json" % rank), "w") as f:
+        json.dump(outcome, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad_rank", [0, 1])
+def test_native_column_sharded_one_rank_fails_everyone_leaves(tmp_path, bad_rank):
+    """The column-sharded protocol is collective: a rank that fails while it prepares a solve (an allocation that does not fit) must
+    not leave alone.  Everything a solve allocates is allocated before its first collective and the ranks agree on the outcome with
+    one 8-byte all-reduce: here one of two ranks is made to fail — both return an error (the failing one says so, the other one
+    says a peer failed), nobody hangs, and the next solve on the same contexts works."""
+    import json
+    import torch.multiprocessing as mp
+    port = 36100 + (os.getpid() % 1000) + bad_rank
+    mp.spawn(_native_failing_rank, args=(2, port, str(tmp_path), bad_rank), nprocs=2, join=True)
+    outs = [json.load(open(tmp_path / ("fail_rank%d.json" % r))) for r in range(2)]
+    assert all(o["first"].startswith("error") for o in outs), outs
+    assert "this rank" in outs[bad_rank]["first"] and "another rank" in outs[1 - bad_rank]["first"], outs
+    assert outs[0]["second_iter"] == outs[1]["second_iter"] > 0
+
+
 def _native_rccl_rank(rank, world, port, tmpdir):
     import sship
     A, y, tol, mi = _native_problem(0)

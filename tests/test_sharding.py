@@ -193,3 +193,30 @@ def test_product_sharded_batch_two_ranks_one_gpu(tmp_path, B):
         xo, ito, eo = oracle.homotopy(A, Y[b], 1e-3, 64)
         assert r["iter"] == ito and np.array_equal(r["idx"], np.nonzero(xo)[0])
         assert np.abs(r["val"] - xo[r["idx"]]).max() <= 1e-5 * np.abs(xo).max()
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_launch_rehearsed_on_one_gpu():
+    """configs[3]'s launch line, rehearsed on the one GPU a test box has: `python -m torch.distributed.run --nproc-per-node 1 bench.py
+    --workload batched ...` with SS_BENCH_DIST=1 walks everything an N > 1 launch executes — RCCL init, the broadcast of A from rank 0,
+    the barriers, the per-step all_gather of the records, the all_reduce of the timing — and prints the one JSON line the driver
+    parses: its metric / unit / scaling, `value` = `scale_value` (the batched workload's signals/s: the one axis of a --gpus sweep), the
+    roofline block, every planted support exact.  (No scaling curve comes out of one GPU: that stays unmeasured.)"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SS_BENCH_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "batched", "--batch", "1536",
+           "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["unit"] == "signals/s" and out["scaling"] == "weak" and out["n_gpus"] == 1 and out["steps"] == 2
+    assert out["value"] > 0 and out["scale_value"] == out["value"]
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["bound"] in ("hbm", "mfma")
+    assert out["recovered"]["support_exact"] == out["recovered"]["signals_checked"] == 1536
+    assert "configs[3]" in out["config"]["workload"]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A few configs[1] solves in the screened form — the child process of bench.py's live HBM-traffic measurement:
+"""A few configs[1] solves in the screened form and four launches of the fp32 sweep c = A^T y — the child process of bench.py's live HBM-traffic measurement:
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir> -- python3 tools/pmc_probe.py
 
@@ -28,5 +28,7 @@ with sship.Homotopy(A, device=0) as h:
         y = (A[:, torch.from_numpy(sup).to(dev)].double() @ torch.from_numpy(coef).to(dev)).float().contiguous()
         h.solve(y, 1e-3, 256, out=x)
     st = h.stats()
+    # ... and the fp32 correlation GEMV of the metric itself, c = A^T y (k_sweep, one right-hand side): SURVEY 8d's kernel
+    h.gemv_t(y, 4)
 torch.cuda.synchronize()
 print("pmc_probe: %d solves, %d certified" % (st["solves"], st["screen_signals"]))

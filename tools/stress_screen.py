@@ -20,6 +20,8 @@ count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(20261004)
 cert = redone = bad = 0
 worst = 0.0
+why_total = {}
+by_kind = {}
 for case in range(count):
     f64 = case % 3 == 2
     dt = np.float64 if f64 else np.float32
@@ -56,6 +58,12 @@ for case in range(count):
     rel = np.abs(x.astype(np.float64) - xo).max() / scale
     reld = np.abs(xd.astype(np.float64) - xo).max() / scale
     certified = st["screen_signals"] == 1
+    for k_, v_ in st.items():
+        if k_.startswith("why_") and v_:
+            why_total[k_] = why_total.get(k_, 0) + int(v_)
+    kind = ("f64" if f64 else "f32", "signed" if signed else "positive", "noise %g" % noise)
+    by_kind.setdefault(kind, [0, 0])
+    by_kind[kind][0 if certified else 1] += 1
     cert += certified
     redone += st["screen_redone"]
     ok = True
@@ -72,4 +80,7 @@ for case in range(count):
           % (case, "f64" if f64 else "f32", m, n, k, signed, noise, fixes, "certified " if certified else "handed back", st["screen_headroom"], it, itd, ito,
              rel, reld, "" if ok else "  <-- BAD"), flush=True)
 print("certified %d, handed back %d, bad %d of %d; largest headroom among the certified %.3f" % (cert, redone, bad, count, worst))
+print("why not certified (a signal may count in several; fp64 signals count per tier):", dict(sorted(why_total.items())))
+for kind in sorted(by_kind):
+    print("   %-32s certified %3d  handed back %3d" % (" ".join(kind), by_kind[kind][0], by_kind[kind][1]))
 sys.exit(1 if bad else 0)
