@@ -1361,13 +1361,16 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         if ((scr1 || scr64) && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie)) {
             ctx->stats.screen_redone += 1;
             count_reasons(ctx, hs.sub_reason, scr_tie);
-            if (std::getenv("SS_HIP_SUB_DEBUG"))
-                std::fprintf(stderr, "[screened form] status %u after %u iterations, %u states logged, K = %u, lambda %g, lambda0 %g\n",
-                             hs.status, hs.iter, hs.solo_nlog, hs.K, hs.c_inf, (double)hs.lambda0);
+            if (std::getenv("SS_HIP_SUB_DEBUG")) {
+                std::fprintf(stderr, "[screened form] status %u reason 0x%x after %u iterations, %u states logged, K = %u, lambda %g, lambda0 %g\n",
+                             hs.status, hs.sub_reason, hs.iter, hs.solo_nlog, hs.K, hs.c_inf, (double)hs.lambda0);
+                if (scr1) screen_debug_recheck(ctx);
+            }
             return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
         }
         if ((scr1 || scr64) && hs.status == 0) ctx->stats.screen_signals += 1;
         if (scr1 && hs.status == 0 && ctx->screen_resident && res_solve_usable<float>()) ctx->stats.screen_resident += 1;
+        if ((scr1 || scr64r) && hs.status == 0 && (hs.sub_reason & kReasonRechecked)) ctx->stats.screen_recheck += 1;
         if (scr1 && ctx->sub_dbg != nullptr) {
             unsigned long long tp[9];
             HIPCHK(hipMemcpy(tp, ctx->sub_dbg, sizeof(tp), hipMemcpyDeviceToHost));
@@ -2679,6 +2682,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "screen_first16")) { ctx->screen_first16 = value != 0 ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_screen"))  { ctx->batch_screen = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_resident")) { ctx->screen_resident = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_recheck")) { ctx->screen_recheck = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "colshard_fail_prepare")) { ctx->colshard_fail_prepare = value ? 1 : 0; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
@@ -2756,6 +2760,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "screen_first16")) { *value = ctx->screen_first16; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_screen"))  { *value = ctx->batch_screen; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_resident")) { *value = ctx->screen_resident; return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_recheck")) { *value = ctx->screen_recheck; return SS_HIP_OK; }
     if (!std::strcmp(key, "colshard_fail_prepare")) { *value = ctx->colshard_fail_prepare; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }

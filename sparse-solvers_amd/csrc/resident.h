@@ -27,11 +27,12 @@ enum : uint32_t {
     kReasonOverflow = 1u << 7,      // a residual overflowed the half-precision range
     kReasonColumn = 1u << 8,        // the screening pass could not certify a (column, state)
     kReasonTie = 1u << 9,           // the subset's scan met an exact tie
+    kReasonRechecked = 1u << 10,    // (not a failure) the exact re-check of flagged columns ran for this signal
 };
 
 // the log of a resident solve (device pointers; per slot: hdr [LOGCAP][8] u32, H [LOGCAP][2] = {lambda, gamma} in T (may be null),
-// pcol [PCAP] u32, X [LOGCAP][PCAP] = x by position of every state)
-template <typename T> struct ResLog { uint32_t* hdr; T* H; uint32_t* pcol; T* X; };
+// pcol [PCAP] u32, X [LOGCAP][PCAP] = x by position of every state, D (may be null) = the direction by position likewise)
+template <typename T> struct ResLog { uint32_t* hdr; T* H; uint32_t* pcol; T* X; T* D; };
 
 template <typename T> bool res_solve_usable();
 template <typename T>

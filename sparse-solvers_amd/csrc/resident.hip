@@ -153,7 +153,7 @@ template <typename T, bool OMP, bool STAMPS = false>
 __global__ __launch_bounds__(ResCfg<T>::THREADS)
 void k_res_solve(const T* __restrict__ Gs_all, uint32_t gpitch, size_t g_slot_stride, const T* __restrict__ c0_all, uint32_t c0_stride,
                  const uint32_t* __restrict__ sub_all, uint32_t n, T tol, uint32_t max_iter, int strict_sign, int tie_guard, int tie_exit,
-                 uint32_t kcap, uint32_t* __restrict__ log_hdr, T* __restrict__ log_H, uint32_t* __restrict__ log_pcol, T* __restrict__ log_X,
+                 uint32_t kcap, uint32_t* __restrict__ log_hdr, T* __restrict__ log_H, uint32_t* __restrict__ log_pcol, T* __restrict__ log_X, T* __restrict__ log_D,
                  T* __restrict__ x_all, uint32_t x_stride, uint32_t* __restrict__ gam2_all, uint32_t* __restrict__ touched2_all,
                  DevState* __restrict__ st_all, TraceEntry* trace, uint32_t trace_cap, unsigned long long* dbg = nullptr)
 {
@@ -198,6 +198,7 @@ void k_res_solve(const T* __restrict__ Gs_all, uint32_t gpitch, size_t g_slot_st
     uint32_t* hdr = log_hdr + (size_t)slot * LOGCAP * 8;
     T* LH = log_H != nullptr ? log_H + (size_t)slot * LOGCAP * 2 : nullptr;
     T* LX = log_X + (size_t)slot * LOGCAP * PCAP;
+    T* LD = log_D != nullptr ? log_D + (size_t)slot * LOGCAP * PCAP : nullptr;
     if (slot != 0) trace = nullptr;
 
     // ---- the subset; my owned column ---------------------------------------------------------------------------------
@@ -572,7 +573,10 @@ void k_res_solve(const T* __restrict__ Gs_all, uint32_t gpitch, size_t g_slot_st
                     if (LH != nullptr) { LH[nlog * 2] = c_inf; LH[nlog * 2 + 1] = ok ? gmm : T(0); }
                     if (ok && trace != nullptr && round < trace_cap) { trace[round].idx = idx; trace[round].added = 1u; trace[round].gamma = (double)gmm; trace[round].c_inf = (double)c_inf; }
                 }
-                if (t < PCAP) LX[(size_t)nlog * PCAP + t] = t < P ? L.xvec[t] : T(0);
+                if (t < PCAP) {
+                    LX[(size_t)nlog * PCAP + t] = t < P ? L.xvec[t] : T(0);
+                    if (LD != nullptr) LD[(size_t)nlog * PCAP + t] = t < P ? L.dvec[t] : T(0);
+                }
                 if (stop || tied || ok) ++nlog;                    // (a declined round's state is not part of the path)
             }
             // (the entering column's Gram values of my columns: the round's only trip to memory, under the x and c updates)
@@ -972,7 +976,7 @@ hipError_t launch_res_solve(ss_hip_ctx* ctx, uint32_t nslots, const T* Gs, uint3
         if (ok) {
             hipLaunchKernelGGL((k_res_solve<T, false, true>), dim3(nslots), dim3(ResCfg<T>::THREADS), res_lds_bytes<T>(), ctx->stream, Gs, gpitch, g_slot_stride, c0, c0_stride,
                                sub, (uint32_t)ctx->n, tol, max_iter, ctx->strict_sign, ctx->tie_guard, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0, kcap,
-                               log.hdr, log.H, log.pcol, log.X, x, x_stride, gam2, touched2, st, trace, trace_cap, dbg);
+                               log.hdr, log.H, log.pcol, log.X, log.D, x, x_stride, gam2, touched2, st, trace, trace_cap, dbg);
             unsigned long long tp[6];
             if (hipMemcpyAsync(tp, dbg, sizeof(tp), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess) {
                 const double r = tp[5] ? (double)tp[5] : 1.0;
@@ -985,11 +989,11 @@ hipError_t launch_res_solve(ss_hip_ctx* ctx, uint32_t nslots, const T* Gs, uint3
     if (omp)
         hipLaunchKernelGGL((k_res_solve<T, true>), dim3(nslots), dim3(ResCfg<T>::THREADS), res_lds_bytes<T>(), ctx->stream, Gs, gpitch, g_slot_stride, c0, c0_stride,
                            sub, (uint32_t)ctx->n, tol, max_iter, ctx->strict_sign, ctx->tie_guard, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0, kcap,
-                           log.hdr, log.H, log.pcol, log.X, x, x_stride, gam2, touched2, st, trace, trace_cap);
+                           log.hdr, log.H, log.pcol, log.X, log.D, x, x_stride, gam2, touched2, st, trace, trace_cap);
     else
         hipLaunchKernelGGL((k_res_solve<T, false>), dim3(nslots), dim3(ResCfg<T>::THREADS), res_lds_bytes<T>(), ctx->stream, Gs, gpitch, g_slot_stride, c0, c0_stride,
                            sub, (uint32_t)ctx->n, tol, max_iter, ctx->strict_sign, ctx->tie_guard, (ctx->tie_rerun && !ctx->tie_guard) ? 1 : 0, kcap,
-                           log.hdr, log.H, log.pcol, log.X, x, x_stride, gam2, touched2, st, trace, trace_cap);
+                           log.hdr, log.H, log.pcol, log.X, log.D, x, x_stride, gam2, touched2, st, trace, trace_cap);
     return hipGetLastError();
 }
 template hipError_t launch_res_solve<float>(ss_hip_ctx*, uint32_t, const float*, uint32_t, size_t, const float*, uint32_t, const uint32_t*, float, uint32_t,

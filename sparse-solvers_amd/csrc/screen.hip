@@ -47,11 +47,13 @@
 #include "ss_hip_internal.h"
 #include "ss_hip_device.h"
 #include "resident.h"
+#include "subcheck.h"
 
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 
@@ -74,6 +76,9 @@ constexpr uint32_t kSgT = 64;                    // its tile: 64 x 64 outputs pe
 constexpr uint32_t kSgStep = 64;                 // rows staged per step
 constexpr uint32_t kSgPitchF = kSgStep + 4;      // floats per LDS row
 constexpr uint32_t kScrBatch = 64;               // slots of a batch chunk in the screened form
+constexpr uint32_t kScrFlCap = 1024;             // columns the half-precision certificate may leave to the exact re-check (per signal)
+constexpr uint32_t kScrFlWords = kScrFlCap + 12; // (+ 8 words: the first (column, state) the re-check failed, for SS_HIP_SUB_DEBUG)  // the list: [0] count, [1 .. cap] columns, [cap + 1] state 0 needs the re-check, [cap + 2] bits(bound_0), [cap + 3] bits(eps_0)
+constexpr uint32_t kScrRecheckWgs = 240;         // workgroups of the re-check launch
 constexpr uint32_t kS64Sub = 2048;               // fp64 form: columns of the sub-dictionary the path is solved on
 constexpr uint32_t kS64Rhs = 192;                // ... states it can certify (two launches of the screening pass)
 constexpr uint32_t kS64LogCap = 200, kS64LogK = 200;   // ... state log of the sub-context: states, coefficients per state
@@ -91,6 +96,7 @@ struct ScreenState {
     float* gs_part = nullptr;    // [kSgSplit][kSbS][kSbS]
     float* gs = nullptr;         // [kSbS][kSbS]
     float* wmax = nullptr;       // [kScrWmax] k_scr_first: largest |c~0| per wave of its launch (the selection's floor)
+    uint32_t* fl = nullptr;      // [kScrFlWords] the columns the certificate could not vouch for: re-checked exactly (k_scr_recheck)
     int gemm_attr = -1;
     // a batch chunk in the screened form (kScrBatch slots): every slot its own residual block, subset Gram matrix, table
     __half* b_r16 = nullptr;     // [kScrBatch][kScrRhs][ldm]
@@ -410,8 +416,10 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
                      const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pcol,
                      const float* __restrict__ LX, float tol, const float* __restrict__ meta, __half* __restrict__ r16,
                      float* __restrict__ rn2p, float* __restrict__ tab, uint32_t* __restrict__ headroom, DevState* __restrict__ st,
-                     int first16)
+                     int first16, uint32_t* __restrict__ fl)
 {
+    // fl (one signal, may be null): the list of columns left to the exact re-check (k_scr_recheck) — cleared here; a state 0 the
+    // half-precision first pass cannot certify by its threshold alone is left to that list too (its columns are found by k_scr_gemm)
     __shared__ __attribute__((aligned(16))) float sAc[kSbRows][64];
     __shared__ __attribute__((aligned(16))) float sXt[kSbRows][kSbLog];
     __shared__ float sS[kSbLog];
@@ -429,6 +437,7 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
     if (st->status != 0u) return;
     const uint32_t tid = threadIdx.x;
     float ratio0 = 0.f;
+    if (fl != nullptr && blockIdx.x == 0u && blockIdx.y == 0u && tid == 0u) { fl[0] = 0u; fl[kScrFlCap + 1u] = 0u; fl[kScrFlCap + 4u] = 0u; }
     if (first16 && blockIdx.x == 0u && tid == 0u) {
         // state 0 after a first pass in half precision (k_scr_first): every column left out of the subset has |c~0| < T, so
         // |c0| < T + eps_0 — certified against lambda_0 (the subset's exact max |c0|) with the margin of every other state
@@ -437,7 +446,10 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
         const float eps0 = 0.0019726562f * yn * meta[4] + 6.103515625e-05f * sqrtf((float)ldm) * yn * meta[1];
         const float bound0 = lam0 * 0.875f - 1e-5f * lam0;
         const float v0 = meta[6] + eps0;
-        if (!(v0 <= bound0)) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonFirstState); }
+        if (!(v0 <= bound0)) {
+            if (fl != nullptr && bound0 > 0.f) { fl[kScrFlCap + 1u] = 1u; fl[kScrFlCap + 2u] = __float_as_uint(bound0); fl[kScrFlCap + 3u] = __float_as_uint(eps0); }
+            else { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonFirstState); }
+        }
         ratio0 = bound0 > 0.f && v0 == v0 ? v0 / bound0 : 3.0e38f;
     }
     const uint32_t nlog = st->solo_nlog;
@@ -528,7 +540,11 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
             // only REGULAR paths are certified: every step inserts a column and lambda goes down.  On a path with removals, or one
             // the first-step sign quirk has derailed, steps of rounding size decide what is toggled next, and the subset's Gram
             // matrix is the default engine's only to rounding (see k_s64_dense): those go back to that engine
-            if (hp[3] == 0u || lam > __uint_as_float(hp[4]) * 1.00001f) { bound = -1.f; atomicOr(&st->sub_reason, kReasonIrregular); }
+            if (hp[3] == 0u || lam > __uint_as_float(hp[4]) * 1.00001f) {
+                bound = -1.f;
+                atomicOr(&st->sub_reason, kReasonIrregular);
+                __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (the screening pass does not run for it)
+            }
             const float inv_sk = 1.f / sS[tid];
             tab[tid * kScrTab + 0] = meta[1] * inv_sk;
             tab[tid * kScrTab + 1] = bound;
@@ -548,8 +564,12 @@ __global__ __launch_bounds__(256, 2)
 void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const __half* __restrict__ r16,
                 const float* __restrict__ anorm, const float* __restrict__ rn2p, uint32_t rn_pitch, const float* __restrict__ tab,
                 const uint32_t* __restrict__ sub, uint32_t nsub, const float* __restrict__ meta, DevState* __restrict__ st,
-                uint32_t* __restrict__ headroom, uint32_t nst_fixed, uint32_t skew, uint32_t gate)
+                uint32_t* __restrict__ headroom, uint32_t nst_fixed, uint32_t skew, uint32_t gate, uint32_t* __restrict__ fl = nullptr,
+                const float* __restrict__ c0h = nullptr)
 {
+    // fl (one fp32 signal, may be null): a column this pass cannot certify is APPENDED to the list of the exact re-check
+    // (k_scr_recheck) instead of failing the signal; c0h: the half-precision first pass's c~0 — when state 0 was left to the list
+    // (fl[cap + 1]) every column with |c~0| + eps_0 above the bound joins it
     // gate (states from the slot's log only): 1 = this launch only if the log holds <= 128 states, 2 = only if more (the fp64
     // resident form queues a four-tile and a five-tile launch without the host knowing the path's length)
     // grid = (slots, column tiles): the workgroups of one tile of A16 — one per slot of a batch — are neighbours in the launch
@@ -572,6 +592,7 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     uint32_t nst = nst_fixed;
     if (nst_fixed == 0u || nst_fixed == 0xffffffffu) {
         if (st->status != 0u) return;
+        if (fl != nullptr && st->need_sweep != 0u) return;        // (already failed — an irregular path, an overflow: no pass for it)
         const uint32_t nlog = st->solo_nlog;
         if (nlog < 2u) return;
         nst = nlog - 1u;
@@ -702,9 +723,18 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
             }
         }
     }
+    if (fl != nullptr && c0h != nullptr && fl[kScrFlCap + 1u] != 0u && mine) {
+        const float v0 = fabsf(c0h[col]) + __uint_as_float(fl[kScrFlCap + 3u]);
+        if (!(v0 <= __uint_as_float(fl[kScrFlCap + 2u]))) flag = true;
+    }
     if (mine && flag) {
-        __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by k_sub_finish)
-        if (!(__hip_atomic_load(&st->sub_reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kReasonColumn)) atomicOr(&st->sub_reason, kReasonColumn);
+        if (fl != nullptr) {
+            const uint32_t at = atomicAdd(&fl[0], 1u);
+            if (at < kScrFlCap) fl[1u + at] = col;
+        } else {
+            __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by k_sub_finish)
+            if (!(__hip_atomic_load(&st->sub_reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kReasonColumn)) atomicOr(&st->sub_reason, kReasonColumn);
+        }
     }
     if (!mine) worst = 0.f;
     worst = fmaxf(worst, __shfl_xor(worst, 1)); worst = fmaxf(worst, __shfl_xor(worst, 2)); worst = fmaxf(worst, __shfl_xor(worst, 4));
@@ -713,6 +743,82 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
 }
 
 
+
+// ---- the exact re-check of the columns the half-precision certificate could not vouch for ---------------------------------------
+// The certificate asks "is |c_i(k)| safely below the bound" with a margin (1/8 lambda_k) and an error term: a column it flags is
+// usually NOT a column that changes the path — on noisy signals the columns of the noise floor come close to lambda at the late
+// states.  Instead of handing the signal back, the few flagged columns (tens; the list holds 1024) are decided EXACTLY here, the way
+// the subset form checks all columns on G (subbatch.hip: k_sub_verify): for column i the Gram values g_p = a_i . a_{col_p} with the
+// path's positions and c0_i = a_i . y are formed in fp32 from A, c_i(k) and q_i(k) of every logged state follow by the solve's own
+// chain — c = fma(-x_p, g_p, c), q = fma(d_p, g_p, q) over the logged coefficients — and the reference's predicates decide
+// (sub_check: |c| <= lambda, no candidate beats the logged step or ties it from the left; the state a path ends in: a larger |c|
+// that leaves the tolerance test as it was is merged into the reported ||c||_inf).  Nothing approximate is left in the verdict of a
+// re-checked column.  One workgroup per flagged column (a fixed grid walks the list); a wave forms the dot products of every
+// fourth position.
+__global__ __launch_bounds__(256)
+void k_scr_recheck(const float* __restrict__ At, uint32_t ldm, uint32_t n, const float* __restrict__ y, const uint32_t* __restrict__ hdr,
+                   const uint32_t* __restrict__ pcol, const float* __restrict__ LX, const float* __restrict__ LD, uint32_t* __restrict__ fl,
+                   float tol, int tie_guard, DevState* __restrict__ st)
+{
+    __shared__ uint32_t sH[kSbLog * 8];
+    __shared__ float sG[kSbRows + 1];                            // g_p of the column in hand; [kSbRows] = its c0
+    if (st->status != 0u || st->need_sweep != 0u) return;
+    const uint32_t nfl = fl[0];
+    if (nfl == 0u) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (nfl > kScrFlCap) {
+        if (blockIdx.x == 0u && tid == 0u) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonColumn); }
+        return;
+    }
+    if (blockIdx.x == 0u && tid == 0u) atomicOr(&st->sub_reason, kReasonRechecked);
+    const uint32_t nlog = st->solo_nlog;
+    if (nlog == 0u) return;
+    for (uint32_t e = tid; e < nlog * 8u; e += 256u) sH[e] = hdr[e];
+    __syncthreads();
+    const uint32_t Pfin = sH[(nlog - 1u) * 8u];
+    bool fail = false, tie = false;
+    for (uint32_t f = blockIdx.x; f < nfl; f += gridDim.x) {
+        const uint32_t col = fl[1u + f];
+        const float* ai = At + (size_t)(col < n ? col : 0u) * ldm;
+        // wave w: the positions p = w, w + 4, ... (and, wave 0, c0 = a_i . y last): a lane's four rows of every 256, ascending, then the wave's sum
+        for (uint32_t p = wave; p <= Pfin; p += 4u) {
+            const bool isy = p == Pfin;
+            if (isy && wave != (Pfin & 3u)) continue;
+            const float* ap = isy ? y : At + (size_t)pcol[p] * ldm;
+            float acc = 0.f;
+            for (uint32_t r = 4u * lane; r < ldm; r += 256u) {
+                const scr_v4f a = *reinterpret_cast<const scr_v4f*>(ai + r), b = *reinterpret_cast<const scr_v4f*>(ap + r);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(a[q], b[q], acc);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0u) sG[isy ? kSbRows : p] = acc;
+        }
+        __syncthreads();
+        if (tid < nlog && col < n) {
+            const uint32_t Pk = sH[tid * 8u];
+            const float* xk = LX + (size_t)tid * kSbRows;
+            const float* dk = LD + (size_t)tid * kSbRows;
+            float cv = sG[kSbRows], qv = 0.f;
+            for (uint32_t p = 0; p < Pk; ++p) {
+                const float g = sG[p];
+                cv = __builtin_fmaf(-xk[p], g, cv);
+                qv = __builtin_fmaf(dk[p], g, qv);
+            }
+            const bool before = fail;
+            sub_check(cv, qv, col, tid, nlog, sH, tol, tie_guard, st, fail, tie);
+            if (fail && !before && atomicCAS(&fl[kScrFlCap + 4u], 0u, 1u) == 0u) {        // (developer aid: the first failure)
+                fl[kScrFlCap + 5u] = col; fl[kScrFlCap + 6u] = tid; fl[kScrFlCap + 7u] = __float_as_uint(cv); fl[kScrFlCap + 8u] = __float_as_uint(qv);
+            }
+        }
+        __syncthreads();
+    }
+    if (fail) {
+        __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(__hip_atomic_load(&st->sub_reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kReasonColumn)) atomicOr(&st->sub_reason, kReasonColumn);
+    }
+    if (tie) __hip_atomic_store(&st->tie_stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- the screening pass of a batch chunk: FOUR slots per workgroup ----------------------------------------------------
 // k_scr_gemm with a slot per workgroup re-stages every tile of A16 once per slot: 64 slots = 64 x 0.17 ms, whatever L2 holds
@@ -1098,7 +1204,7 @@ void screen_free(ss_hip_ctx* ctx)
     ScreenState* S = scr_of(ctx);
     if (!S) return;
     void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->wmax, S->cabs, S->sublist, S->xsub, S->xd, S->ctl,
-                     S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs, S->sub256, S->gs64, S->gs64_part, S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X };
+                     S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs, S->fl, S->sub256, S->gs64, S->gs64_part, S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (S->sub) {
@@ -1153,6 +1259,7 @@ bool screen_form_usable(ss_hip_ctx* ctx)
     alloc(reinterpret_cast<void**>(&S->gs_part), (size_t)kSgSplit * kSbS * kSbS * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->gs), (size_t)kSbS * kSbS * sizeof(float));
     alloc(reinterpret_cast<void**>(&S->wmax), (size_t)kScrWmax * sizeof(float));
+    alloc(reinterpret_cast<void**>(&S->fl), (size_t)kScrFlWords * sizeof(uint32_t));
     if (ok) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)scr_gemm_lds(kS64Sub));
@@ -1235,7 +1342,7 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     // screen_resident = 0, k_sub_solve (subbatch.hip) — the same log either way (e4, e5: profiling events around it)
     if (e4) (void)hipEventRecord(e4, s);
     if (ctx->screen_resident && res_solve_usable<float>()) {
-        const ResLog<float> log{ B.hdr, nullptr, B.pcol, B.LX };
+        const ResLog<float> log{ B.hdr, nullptr, B.pcol, B.LX, B.LD };
         (void)launch_res_solve<float>(ctx, 1, (const float*)S->gs, kSbS, 0, (const float*)ws.c0, 0, (const uint32_t*)B.sub, tol, max_iter, ws.dims.kcap, log, ws.x, 0,
                                       ws.gam, ws.touched, ws.st, ws.trace, ws.trace_cap, false);
     } else
@@ -1243,12 +1350,18 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     if (e5) (void)hipEventRecord(e5, s);
     hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs,
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
-                       (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, first16 ? 1 : 0);
+                       (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, first16 ? 1 : 0,
+                       ctx->screen_recheck ? S->fl : (uint32_t*)nullptr);
     if (e2) (void)hipEventRecord(e2, s);
     hipLaunchKernelGGL(k_scr_gemm<3>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
                        (const float*)S->anorm, (const float*)S->rn2p, kScrRhs, (const float*)S->tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
-                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 0u);
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 0u, ctx->screen_recheck ? S->fl : (uint32_t*)nullptr,
+                       first16 ? (const float*)ws.c0 : (const float*)nullptr);
     if (e3) (void)hipEventRecord(e3, s);
+    // the columns that pass left undecided, exactly (an empty list: the launch returns at once)
+    if (ctx->screen_recheck)
+        hipLaunchKernelGGL(k_scr_recheck, dim3(kScrRecheckWgs), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs, (const uint32_t*)B.hdr, (const uint32_t*)B.pcol,
+                           (const float*)B.LX, (const float*)B.LD, S->fl, tol, ctx->tie_guard, ws.st);
     // (finish = false: the caller's epilogue launch turns "a column was not certified" into the status the host reads)
     if (finish) (void)launch_sub_finish(ctx, ws, 1);
     return hipGetLastError();
@@ -1299,14 +1412,14 @@ hipError_t launch_screen_batch(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t n
     hipLaunchKernelGGL(k_sgram_part, dim3(NT * (NT + 1) / 2, nsplit, nslots), dim3(256), 0, s, At, ldm, n, (const uint32_t*)B.sub, ldm / nsplit, S->b_gs_part);
     hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256, nslots), dim3(256), 0, s, (const float*)S->b_gs_part, nsplit, S->b_gs, (const float*)nullptr, 0u, (const float*)nullptr, (const uint32_t*)nullptr, 0u, (float*)nullptr);
     if (ctx->screen_resident && res_solve_usable<float>()) {
-        const ResLog<float> log{ B.hdr, nullptr, B.pcol, B.LX };
+        const ResLog<float> log{ B.hdr, nullptr, B.pcol, B.LX, B.LD };
         (void)launch_res_solve<float>(ctx, nslots, (const float*)S->b_gs, kSbS, (size_t)kSbS * kSbS, c0_all, np, (const uint32_t*)B.sub, tol, max_iter, ws.dims.kcap, log,
                                       ws.x, np, ws.gam, ws.touched, ws.st, ws.trace, ws.trace_cap, false);
     } else
         (void)launch_sub_solve(ctx, ws, B, nslots, (const float*)S->b_gs, kSbS, 1, c0_all, tol, max_iter, kSbS * kSbS);
     hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u, nslots), dim3(256), 0, s, At, ldm, n, (const float*)ws.y,
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
-                       (const float*)S->meta, S->b_r16, S->b_rn2p, S->b_tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, 0);
+                       (const float*)S->meta, S->b_r16, S->b_rn2p, S->b_tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, 0, (uint32_t*)nullptr);
     static const bool b_attr = [] {
         const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scr_gemm_b_lds()) == hipSuccess;
         if (!ok) (void)hipGetLastError();
@@ -1514,7 +1627,7 @@ hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, doub
     (void)launch_select_top(ctx, S->cabs, n, np, (uint32_t)RC::S, S->sub256, S->sub256 + RC::S, reinterpret_cast<float*>(S->sub256 + RC::S + 1),
                             first16 ? S->meta + 6 : nullptr);
     { const hipError_t eg = launch_sgram64(ctx, S->sub256, y, S->gs64_part, S->gs64, ws.c0); if (eg != hipSuccess) return eg; }
-    const ResLog<double> log{ S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X };
+    const ResLog<double> log{ S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X, nullptr };
     if (e4) (void)hipEventRecord(e4, s);
     { const hipError_t es = launch_res_solve<double>(ctx, 1, S->gs64, (uint32_t)RC::S, 0, ws.c0, 0, S->sub256, tol, max_iter, ws.dims.kcap, log, ws.x, 0, ws.gam,
                                                      ws.touched, ws.st, ws.trace, ws.trace_cap, omp);
@@ -1530,6 +1643,28 @@ hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, doub
                        ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 2u);
     if (e3) (void)hipEventRecord(e3, s);
     return hipGetLastError();
+}
+
+// developer aid (SS_HIP_SUB_DEBUG): the first (column, state) the exact re-check of the last screened solve failed, with the log around it
+void screen_debug_recheck(ss_hip_ctx* ctx)
+{
+    ScreenState* S = scr_of(ctx);
+    if (S == nullptr || S->fl == nullptr || ctx->sub_buf == nullptr) return;
+    uint32_t w[kScrFlWords];
+    if (hipMemcpy(w, S->fl, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::fprintf(stderr, "[screened form] columns left to the exact re-check: %u (state 0 among the questions: %u)\n", w[0], w[kScrFlCap + 1]);
+    if (w[kScrFlCap + 4] == 0u) return;
+    const SubBufs B = sub_bufs(ctx, 1);
+    uint32_t hdr[kSbLog * 8];
+    if (hipMemcpy(hdr, B.hdr, sizeof(hdr), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+    const uint32_t k = w[kScrFlCap + 6];
+    float cv, qv, lam, gam, lam1 = 0.f;
+    std::memcpy(&cv, &w[kScrFlCap + 7], 4); std::memcpy(&qv, &w[kScrFlCap + 8], 4);
+    std::memcpy(&lam, &hdr[k * 8 + 4], 4); std::memcpy(&gam, &hdr[k * 8 + 5], 4);
+    if (k + 1 < kSbLog) std::memcpy(&lam1, &hdr[(k + 1) * 8 + 4], 4);
+    std::fprintf(stderr, "    first failure: column %u at state %u (P = %u, flags %u, pick %u): c = %.9g, q = %.9g, lambda = %.9g, step = %.9g, next lambda = %.9g (next flags %u); "
+                 "candidates (lambda - c) / (1 - q) = %.9g, (lambda + c) / (1 + q) = %.9g\n", w[kScrFlCap + 5], k, hdr[k * 8], hdr[k * 8 + 1], hdr[k * 8 + 2], cv, qv, lam, gam,
+                 lam1, k + 1 < kSbLog ? hdr[(k + 1) * 8 + 1] : 0u, (lam - cv) / (1.f - qv), (lam + cv) / (1.f + qv));
 }
 
 double screen_read_headroom(ss_hip_ctx* ctx)

@@ -256,6 +256,8 @@ struct ss_hip_ctx {
     // back more than a third, the next 8 chunks (64 solves) go the other way at once, then it is tried again
     uint32_t sub_off_chunks = 0, sub_off_solves = 0, sub_seen = 0, sub_failed = 0;
     uint32_t res_off_solves = 0, res_seen = 0, res_failed = 0;   // ... the same for the resident tier of the fp64 screened form
+    int screen_recheck = 1;           // option: 1 = columns the screened form's half-precision certificate cannot vouch for are re-checked exactly in fp32
+                                      // (screen.hip: k_scr_recheck) instead of failing the signal
     int screen_resident = 1;          // option: 1 = the screened forms run their path in the resident kernel (resident.hip), 0 = the forms before it
     hipEvent_t ev_sub_sel = nullptr;  // profiling: between the subset form's selection and its solves
     hipEvent_t ev_c0a = nullptr, ev_c0b = nullptr;   // profiling: around the batch GEMM c0 = A^T y of a chunk
@@ -457,6 +459,7 @@ bool screen64_resident_usable(ss_hip_ctx* ctx);
 hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp,
                                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr,
                                     hipEvent_t e4 = nullptr, hipEvent_t e5 = nullptr);
+void screen_debug_recheck(ss_hip_ctx* ctx);               // developer aid (SS_HIP_SUB_DEBUG)
 double screen_read_headroom(ss_hip_ctx* ctx);             // largest (|c~| + eps) / bound of the last screened solve (synchronises)
 hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr);      // signals one pass of the engine can carry (1 without the LDS-staged sweep)

@@ -32,6 +32,7 @@
 #include "ss_hip_internal.h"
 #include "ss_hip_device.h"
 #include "resident.h"
+#include "subcheck.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -834,60 +835,7 @@ constexpr uint32_t kVsCols = 2 * kVsThreads;     // columns a workgroup checks
 constexpr uint32_t kVsPitch = kSbRows;           // floats per breakpoint row in LDS
 __host__ __device__ inline size_t sub_verify_lds_bytes() { return (2 * (size_t)kSbLog * kVsPitch + (size_t)kSbLog * 8 + kSbRows) * 4; }
 
-// the reference's predicates for one (column, breakpoint): cv, qv by the chain; h = the breakpoint's header
-__device__ __forceinline__ void sub_check(float cv, float qv, uint32_t j, uint32_t k, uint32_t nlog, const uint32_t* sH, float tol,
-                                          int tie_guard, DevState* st, bool& fail, bool& tie)
-{
-    const uint32_t* h = sH + k * 8;
-    const float lam = __uint_as_float(h[4]);
-    const float ac = fabsf(cv);
-    if (!(h[1] & 1u)) {
-        // the round the path ended in: ||c||_inf is REPORTED (homotopy_report::solution_error) and, unless the budget ran
-        // out, was compared with the tolerance — a larger |c| out here must leave that comparison as it was, and counts
-        if (!(ac <= lam)) {
-            if (!(lam > tol) && !(ac <= tol)) fail = true;
-            else if (ac == ac) atomicMax(reinterpret_cast<unsigned long long*>(&st->c_inf), (unsigned long long)__double_as_longlong((double)ac));
-            else fail = true;
-        }
-        return;
-    }
-    if (!(ac <= lam)) fail = true;                             // the true max |c| is larger (or NaN): every candidate changes
-    const float gam = __uint_as_float(h[5]);
-    const float dl = 1.f - qv, dr = 1.f + qv;
-    const float nl = lam - cv, nr = lam + cv;
-    // safe: the candidate is certainly larger than the step taken (1e-4 covers every rounding in between)
-    const float bound = gam * 1.0001f;
-    const bool safe_l = dl > 0.f && nl > dl * bound;
-    const bool safe_r = dr > 0.f && nr > dr * bound;
-    if (safe_l && safe_r) return;
-    const uint32_t pick = h[2];
-    const bool in_band = h[7] != 0u;
-    const uint32_t jr = h[6];
-    float m = Lim<float>::max();
-    if (dl != 0.f) {
-        float t = nl / dl;
-        if (tie_guard && t == 0.f && dl > 0.f) t = Lim<float>::tiny();
-        if (t == 0.f && j != jr && in_band) tie = true;
-        if (t > 0.f && t < m) m = t;
-    }
-    if (dr != 0.f) {
-        float t = nr / dr;
-        if (tie_guard && t == 0.f && dr > 0.f) t = Lim<float>::tiny();
-        if (t == 0.f && j != jr && in_band) tie = true;
-        if (t > 0.f && t < m) m = t;
-    }
-    if (better_min(m, j, gam, pick)) {
-        // it would have been picked instead.  One exception: the LAST step of a path that ends by tolerance — there
-        // lambda - gamma ~ 0 and every column's candidate ties with the step within rounding; whichever is
-        // inserted enters with x = 0 and the next round ends the path with the same coefficients.  A candidate
-        // within 1e-5 of the step taken is such a tie, a smaller one a real entrant.
-        // (and taking the shorter step must still end the path: lambda after it is the logged one plus the difference)
-        const float lam_end = __uint_as_float(sH[(k + 1u) * 8 + 4]);
-        const bool last_step = k + 2u == nlog && !(sH[(k + 1u) * 8 + 1] & 1u) && !(lam_end > tol);
-        if (!(last_step && m >= gam * 0.99999f && lam_end + (gam - m) <= tol)) fail = true;
-    }
-}
-
+// (sub_check — the reference's predicates for one (column, breakpoint) — lives in subcheck.h: screen.hip's exact re-check uses it too)
 __global__ __launch_bounds__(kVsThreads, 2)
 void k_sub_verify(const float* __restrict__ G, uint32_t gpitch, const float* __restrict__ c0_all, uint32_t n, uint32_t n_pad,
                   const uint32_t* __restrict__ sub_all, const uint32_t* __restrict__ log_hdr, const uint32_t* __restrict__ log_pcol,
