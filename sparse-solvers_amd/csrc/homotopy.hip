@@ -221,8 +221,11 @@ void k_epilogue(const uint32_t* __restrict__ st_words, uint32_t* __restrict__ hs
     // status_word != 0xffffffff (the screened form of one signal): the verdict of its certificate — "a column was not certified"
     // (the word at flag_word, raised by the screening pass) makes a clean status kStatusSubsetFail — is applied to the copy the host
     // reads, instead of a launch of its own (k_sub_finish) before this one
+    // (the caller's x receives the coefficients only of a path that was certified: an uncertified one is solved again by the engine
+    // behind the form, and if THAT fails the caller must not be left holding uncertified numbers beside an error code)
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-    if (x_dst != nullptr)
+    const bool withheld = status_word != 0xffffffffu && (st_words[status_word] != 0u || st_words[flag_word] != 0u);
+    if (x_dst != nullptr && !withheld)
         for (uint32_t i = gtid; i < n; i += gsz) x_dst[(long long)i * incx] = x_src[i];
     if (blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < st_nwords; i += blockDim.x) {

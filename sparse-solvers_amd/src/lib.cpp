@@ -116,6 +116,9 @@ namespace ss
     template <typename T>
     void homotopy_state<T>::init(const ndspan<T, 2> A, int device)
     {
+        /* a state built without a mode of its own is BOUND to the process-wide request in force now: what is uploaded (or not) here
+           and what solve() later asks for cannot drift apart when set_requested_mode() is called in between */
+        if (_mode == kernelpp::compute_mode::AUTO) _mode = effective(_mode);
         if (!wants_device(_mode)) {
             /* a mode that is not built: nothing is uploaded; solve() reports COMPUTE_MODE_DISABLED */
             _error = std::string("compute mode ") + kernelpp::to_string(effective(_mode)) + " is not built into this library";
@@ -181,6 +184,7 @@ namespace ss
     template <typename T>
     void irls_device_state<T>::init(const ndspan<T, 2> A, int device)
     {
+        if (_mode == kernelpp::compute_mode::AUTO) _mode = effective(_mode);      /* (bound to the request in force now: homotopy_state::init) */
         if (!wants_device(_mode)) {
             _error = std::string("compute mode ") + kernelpp::to_string(effective(_mode)) + " is not built into this library";
             return;

@@ -25,6 +25,14 @@ namespace ss
             homotopy_state<T>& state, const ndspan<T> y, T tolerance, std::uint32_t max_iterations, ndspan<T> x);
     };
 
+    /* the specialisations homotopy-hip.cpp defines, DECLARED before any use that would instantiate the primary template
+       ([temp.expl.spec]/6: without these the program is ill-formed, no diagnostic required — it only linked because the
+       primary has no definition) */
+    template <> kernelpp::maybe<homotopy_report> solve_homotopy::op<compute_mode::HIP, float>(
+        homotopy_state<float>&, const ndspan<float>, float, std::uint32_t, ndspan<float>);
+    template <> kernelpp::maybe<homotopy_report> solve_homotopy::op<compute_mode::HIP, double>(
+        homotopy_state<double>&, const ndspan<double>, double, std::uint32_t, ndspan<double>);
+
     /* orthogonal matching pursuit: not in the reference (include/ss/ss.h:60-64) */
     KERNEL_DECL(solve_omp, compute_mode::HIP)
     {
@@ -33,6 +41,11 @@ namespace ss
             homotopy_state<T>& state, const ndspan<T> y, T tolerance, std::uint32_t max_iterations, ndspan<T> x);
     };
 
+    template <> kernelpp::maybe<omp_report> solve_omp::op<compute_mode::HIP, float>(
+        homotopy_state<float>&, const ndspan<float>, float, std::uint32_t, ndspan<float>);
+    template <> kernelpp::maybe<omp_report> solve_omp::op<compute_mode::HIP, double>(
+        homotopy_state<double>&, const ndspan<double>, double, std::uint32_t, ndspan<double>);
+
     /* reference: src/solvers/irls.h:27-38 */
     KERNEL_DECL(solve_irls, compute_mode::HIP)
     {
@@ -40,4 +53,9 @@ namespace ss
         static kernelpp::maybe<irls_report> op(
             irls_device_state<T>& state, const ndspan<T> y, T tolerance, std::uint32_t max_iterations, ndspan<T> x);
     };
+
+    template <> kernelpp::maybe<irls_report> solve_irls::op<compute_mode::HIP, float>(
+        irls_device_state<float>&, const ndspan<float>, float, std::uint32_t, ndspan<float>);
+    template <> kernelpp::maybe<irls_report> solve_irls::op<compute_mode::HIP, double>(
+        irls_device_state<double>&, const ndspan<double>, double, std::uint32_t, ndspan<double>);
 }

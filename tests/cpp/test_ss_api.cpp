@@ -217,6 +217,15 @@ void compute_mode_seam(bool have_device)
         if (have_device) { CHECK(rh.is<ss::homotopy_report>()); CHECK(x == y); }
         else { CHECK(rh.is<kernelpp::error>() && rh.get<kernelpp::error>().code() != error_code::COMPUTE_MODE_DISABLED); }
     }
+    // a solver built without a mode of its own is BOUND to the request in force at its construction: one built while the request
+    // was CPU (nothing uploaded) still answers COMPUTE_MODE_DISABLED after the request has moved on to HIP — not a half-made state
+    {
+        ss::homotopy<float> made_under_cpu(Av);
+        kernelpp::set_requested_mode(compute_mode::HIP);
+        auto r = made_under_cpu.solve(ss::as_span(y), 0.001f, 2, ss::as_span(x));
+        CHECK(r.is<kernelpp::error>() && r.get<kernelpp::error>().code() == error_code::COMPUTE_MODE_DISABLED);
+        kernelpp::set_requested_mode(compute_mode::CPU);
+    }
     kernelpp::set_requested_mode(compute_mode::HIP);
     {
         ss::homotopy<float> s(Av);
