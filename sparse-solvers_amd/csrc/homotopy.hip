@@ -423,6 +423,7 @@ ss_hip_ctx* create_impl(const T* A, size_t m, size_t n, ptrdiff_t rs, ptrdiff_t 
 
 // ---- lookahead engine (fp32): Gram-column cache management and round launches -------------
 bool ensure_full_gram(ss_hip_ctx* ctx);     // G = A^T A of the context (defined with the batched paths)
+void gram_reserve_start(ss_hip_ctx* ctx, size_t B);
 
 // the 32-RHS lookahead sweep of either precision, and the resident iteration kernel (fp32 only)
 inline hipError_t launch_gemm32(const ss_hip_ctx* ctx, const uint32_t* rcols, const uint32_t* drows, float* D, uint32_t ldd, const DevState* st)
@@ -1531,6 +1532,27 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
 // terminated turns its kernels into no-ops; the solve ends when every slot is done.
 // the full Gram matrix G = A^T A for the batched Gram form: one GEMM of 2 m n^2 flops on the MFMA units
 // (0.55 s at C2), kept in the context for later batches; false if it does not fit the budget
+// G's memory ahead of time, on a helper thread (ss_hip_ctx::gram_reserve_thread): started by the first batch of >= 4 signals a
+// context receives, where G would fit the budget and is at most an eighth of the device's memory
+void gram_reserve_start(ss_hip_ctx* ctx, size_t B)
+{
+    if (!ctx->gram_reserve || ctx->gram_full || ctx->gram_reserve_thread || B < 4 || ctx->engine < 1 || ctx->batch_gram_min <= 0) return;
+    const size_t np = ctx->n_pad;
+    const size_t bytes = np * ((np + 1023) / 1024 * 1024) * sizeof(float);
+    if (ctx->gram_full_gib <= 0 || bytes > ((size_t)ctx->gram_full_gib << 30)) return;
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (bytes > total_b / 8 || bytes + ((size_t)16 << 30) > free_b) return;
+    const int device = ctx->device;
+    float** slot = &ctx->gram_reserved;
+    std::thread* th = new (std::nothrow) std::thread([device, bytes, slot]() {
+        float* p = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+        *slot = p;
+    });
+    ctx->gram_reserve_thread = th;
+}
+
 bool ensure_full_gram(ss_hip_ctx* ctx)
 {
     if (ctx->gram_full) return true;
@@ -1538,14 +1560,25 @@ bool ensure_full_gram(ss_hip_ctx* ctx)
     const uint32_t pitch = (uint32_t)((np + 1023) / 1024 * 1024);
     const size_t bytes = np * (size_t)pitch * sizeof(float);
     if (ctx->gram_full_gib <= 0 || bytes > ((size_t)ctx->gram_full_gib << 30)) return false;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)8 << 30) > free_b) {
-        (void)hipGetLastError();
-        return false;
-    }
     float* G = nullptr;
     const auto t_alloc = std::chrono::steady_clock::now();
-    if (hipMalloc(&G, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (ctx->gram_reserve_thread != nullptr) {
+        // (reserved ahead on a helper thread: what is left of that allocation is all this batch waits for)
+        std::thread* th = static_cast<std::thread*>(ctx->gram_reserve_thread);
+        th->join();
+        delete th;
+        ctx->gram_reserve_thread = nullptr;
+        G = ctx->gram_reserved;
+        ctx->gram_reserved = nullptr;
+    }
+    if (G == nullptr) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)8 << 30) > free_b) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (hipMalloc(&G, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
     ctx->stats.gram_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count();
     hipEvent_t g0 = nullptr, g1 = nullptr;
     if (hipEventCreate(&g0) != hipSuccess || hipEventCreate(&g1) != hipSuccess) { (void)hipGetLastError(); g0 = g1 = nullptr; }
@@ -2103,6 +2136,7 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
     // lock-step MFMA path once enough signals share the matrix (batch_min option, default 192) — or, with G = A^T A already
     // in HBM, from four signals on: the subset form then runs every signal on a workgroup of its own (subbatch.hip)
     const bool have_g = ctx->gram_full != nullptr && ctx->batch_subset && ctx->engine >= 1 && ctx->batch_gram_min > 0;
+    gram_reserve_start(ctx, B);
     // (from four: the batch GEMM that forms c0 works on 128 rows at a time — 1.1 ms at 8192 x 65536, three single sweeps)
     const bool lockstep = B >= (size_t)std::max(2, ctx->batch_min) || (have_g && B >= 4);
     int form = 0;
@@ -2158,6 +2192,74 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
     return solve_batch_seq<float>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
 }
 
+// fp64 batch, resident tier, in chunks of screen64_batch_cap() signals
+int solve_batch_res64(ss_hip_ctx* ctx, const double* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, double tol, uint32_t max_iter, double* X,
+                      ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen, void* rec_out, uint32_t kmax)
+{
+    if (max_iter == 0) { set_err(err, errlen, "solve_batch: max_iterations must be > 0"); return SS_HIP_EINVAL; }
+    if (!(tol >= std::numeric_limits<double>::epsilon() && tol < 1.0)) { set_err(err, errlen, "solve_batch: tolerance must satisfy eps <= tolerance < 1"); return SS_HIP_EINVAL; }
+    if (incy <= 0 || incx <= 0) { set_err(err, errlen, "solve_batch: vector increments must be positive"); return SS_HIP_EINVAL; }
+    const size_t rb = record_bytes(kmax, sizeof(double));
+    const uint32_t cap = screen64_batch_cap();
+    std::vector<size_t> redo;
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        const size_t m = ctx->m, n = ctx->n;
+        const uint32_t kcap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n, (uint64_t)max_iter + 1), kKcapLimit);
+        std::vector<DevState> hst(cap);
+        for (size_t b0 = 0; b0 < B; b0 += cap) {
+            const uint32_t nb = (uint32_t)std::min<size_t>(cap, B - b0);
+            ensure_workspace<double>(ctx, cap, kcap);
+            Workspace<double>& ws = *ws_of<double>(ctx);
+            hipStream_t st = ctx->stream;
+            HIPCHK(hipMemsetAsync(ws.y, 0, (size_t)cap * ctx->ldm * sizeof(double), st));
+            for (uint32_t b = 0; b < nb; ++b) copy_in<double>(ctx, ws.y + (size_t)b * ctx->ldm, Y + (ptrdiff_t)(b0 + b) * y_stride, incy, m);
+            HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)nb * ctx->n_pad * sizeof(double), st));
+            HIPCHK(hipMemsetAsync(ws.st, 0, (size_t)nb * sizeof(DevState), st));
+            HIPCHK(launch_screen64_batch(ctx, ws, nb, tol, max_iter));
+            const unsigned char* stage = rec_out ? pack_records<double>(ctx, ws, nb, kmax) : nullptr;
+            HIPCHK(hipMemcpyAsync(hst.data(), ws.st, (size_t)nb * sizeof(DevState), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (uint32_t b = 0; b < nb; ++b) {
+                const DevState& hs = hst[b];
+                const bool good = hs.done && hs.status == 0 && hs.tie_stall == 0;
+                if (!good) {
+                    redo.push_back(b0 + b);
+                    ctx->stats.screen_tier2 += 1;
+                    count_reasons(ctx, hs.sub_reason, hs.tie_stall != 0 || hs.status == kStatusTieRerun);
+                    continue;
+                }
+                if (X) copy_out<double>(ctx, X + (ptrdiff_t)(b0 + b) * x_stride, incx, ws.x + (size_t)b * ctx->n_pad, n);
+                if (rec_out) HIPCHK(hipMemcpyAsync(static_cast<unsigned char*>(rec_out) + (b0 + b) * rb, stage + (size_t)b * rb, rb, hipMemcpyDefault, st));
+                if (iter_out) iter_out[b0 + b] = hs.iter;
+                if (err_out) err_out[b0 + b] = hs.c_inf;
+                ctx->stats.solves += 1;
+                ctx->stats.iterations += hs.iter;
+                ctx->stats.screen_signals += 1;
+                ctx->stats.screen_resident += 1;
+            }
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    } catch (const HipFail& f) {
+        set_err(err, errlen, hip_msg(f));
+        return SS_HIP_ERUNTIME;
+    } catch (const std::bad_alloc&) {
+        set_err(err, errlen, "solve_batch: out of host memory");
+        return SS_HIP_ENOMEM;
+    }
+    // what the chunks did not report: alone, through the sub-dictionary tier and the engine behind it
+    for (size_t b : redo) {
+        uint32_t it = 0;
+        double e = 0.0;
+        const int rc = solve_impl<double>(ctx, Y + (ptrdiff_t)b * y_stride, incy, tol, max_iter, X ? X + (ptrdiff_t)b * x_stride : nullptr, incx, &it, &e, err, errlen,
+                                          false, false, false, rec_out ? static_cast<unsigned char*>(rec_out) + b * rb : nullptr, kmax, false, false, true);
+        if (rc != SS_HIP_OK) return rc;
+        if (iter_out) iter_out[b] = it;
+        if (err_out) err_out[b] = e;
+    }
+    return SS_HIP_OK;
+}
+
 int solve_batch_dispatch(ss_hip_ctx* ctx, const double* Y, size_t B, ptrdiff_t y_stride, ptrdiff_t incy, double tol,
                          uint32_t max_iter, double* X, ptrdiff_t x_stride, ptrdiff_t incx, uint32_t* iter_out,
                          double* err_out, char* err, size_t errlen, void* rec_out = nullptr, uint32_t kmax = 0)
@@ -2165,7 +2267,16 @@ int solve_batch_dispatch(ss_hip_ctx* ctx, const double* Y, size_t B, ptrdiff_t y
     // reference-order engine: in lock-step, up to 4 signals per pass over A
     if (ctx->engine == 3)
         return solve_batch_ro<double>(ctx, Y, nullptr, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
-    // fp64: one signal at a time (memory-bound sweep path)
+    // fp64 batches of four signals or more on dictionaries the fp64 screened form takes: the resident tier with the signals of a chunk
+    // side by side (screen.hip: launch_screen64_batch) — one pass over the fp16 copy ranks every signal's columns, the paths run in as
+    // many workgroups at once, every signal's states are certified by a screening pass of its own; what a slot's certificate does not
+    // cover is solved again alone, through the remaining tiers
+    if (B >= 4 && !ctx->tracing && ctx->engine >= 1 && ctx->la_fused >= 1 && ctx->screen_resident && ctx->sub_off_solves == 0 && ctx->res_off_solves == 0) {
+        bool usable = false;
+        try { HIPCHK(hipSetDevice(ctx->device)); usable = screen64_batch_usable(ctx); } catch (const HipFail&) { usable = false; }
+        if (usable) return solve_batch_res64(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
+    }
+    // otherwise one signal at a time
     return solve_batch_seq<double>(ctx, Y, B, y_stride, incy, tol, max_iter, X, x_stride, incx, iter_out, err_out, err, errlen, rec_out, kmax);
 }
 
@@ -2460,6 +2571,13 @@ void ss_hip_homotopy_destroy(ss_hip_ctx* ctx)
     }
     sship::irls_free(ctx);
     sship::colshard_destroy(ctx);
+    if (ctx->gram_reserve_thread != nullptr) {
+        std::thread* th = static_cast<std::thread*>(ctx->gram_reserve_thread);
+        th->join();
+        delete th;
+        ctx->gram_reserve_thread = nullptr;
+    }
+    if (ctx->gram_reserved) (void)hipFree(ctx->gram_reserved);
     if (ctx->gram_full) (void)hipFree(ctx->gram_full);
     if (ctx->c0_batch) (void)hipFree(ctx->c0_batch);
     if (ctx->sub_buf) (void)hipFree(ctx->sub_buf);
@@ -2686,6 +2804,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "batch_screen"))  { ctx->batch_screen = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_resident")) { ctx->screen_resident = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_recheck")) { ctx->screen_recheck = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "gram_reserve")) { ctx->gram_reserve = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "colshard_fail_prepare")) { ctx->colshard_fail_prepare = value ? 1 : 0; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }
@@ -2764,6 +2883,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "batch_screen"))  { *value = ctx->batch_screen; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_resident")) { *value = ctx->screen_resident; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_recheck")) { *value = ctx->screen_recheck; return SS_HIP_OK; }
+    if (!std::strcmp(key, "gram_reserve")) { *value = ctx->gram_reserve; return SS_HIP_OK; }
     if (!std::strcmp(key, "colshard_fail_prepare")) { *value = ctx->colshard_fail_prepare; return SS_HIP_OK; }
     return SS_HIP_EINVAL;
 }

@@ -40,9 +40,10 @@ hipError_t launch_res_solve(ss_hip_ctx* ctx, uint32_t nslots, const T* Gs, uint3
                             const uint32_t* sub, T tol, uint32_t max_iter, uint32_t kcap, const ResLog<T>& log, T* x, uint32_t x_stride,
                             uint32_t* gam2, uint32_t* touched2, DevState* st, TraceEntry* trace, uint32_t trace_cap, bool omp);
 // fp64: Gs = A_S^T A_S of the 256 subset columns (part: [kSg64MaxSplit][256][256] scratch) and their exact c0 = a_j . y into the dense c0
-hipError_t launch_sgram64(ss_hip_ctx* ctx, const uint32_t* sub, const double* y, double* part, double* gs, double* c0);
+// (nslots > 1: a batch — sub, y, gs, c0 and the partials carry a slot dimension: S, ldm, S * S, c0_stride, nsplit * S * S elements per slot)
+hipError_t launch_sgram64(ss_hip_ctx* ctx, const uint32_t* sub, const double* y, double* part, double* gs, double* c0, uint32_t nslots = 1, uint32_t c0_stride = 0);
 // fp64: residuals of the logged states in half precision, the screening pass's table, the certificate of state 0
 hipError_t launch_res_residuals64(ss_hip_ctx* ctx, const double* y, const ResLog<double>& log, double tol, const float* meta, void* r16, float* rn2p,
-                                  float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp);
+                                  float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp, uint32_t nslots = 1, const float* slotmeta = nullptr);
 
 }  // namespace sship

@@ -682,6 +682,8 @@ void k_sgram64_part(const double* __restrict__ At, uint32_t ldm, uint32_t n, con
     constexpr uint32_t S = ResCfg<double>::S;
     __shared__ double sI[kG64T][kG64Pitch];
     __shared__ double sJ[kG64T][kG64Pitch];
+    sub += (size_t)blockIdx.z * S;                                // (blockIdx.z = slot of a batch: its subset, its partials)
+    part += (size_t)blockIdx.z * gridDim.y * S * S;
     const uint32_t b = blockIdx.x;
     uint32_t tt = (uint32_t)((__fsqrt_rn(8.f * (float)b + 1.f) - 1.f) * 0.5f);
     while (tt * (tt + 1u) / 2u > b) --tt;
@@ -747,10 +749,14 @@ void k_sgram64_part(const double* __restrict__ At, uint32_t ldm, uint32_t n, con
 // (fixed order: a thread's strided terms ascending, then block_sum), written into the dense c0 at the column
 __global__ __launch_bounds__(256)
 void k_sgram64_sum(const double* __restrict__ part, uint32_t nsplit, double* __restrict__ gs, const double* __restrict__ At, uint32_t ldm,
-                   const double* __restrict__ y, const uint32_t* __restrict__ sub, uint32_t n, double* __restrict__ c0)
+                   const double* __restrict__ y, const uint32_t* __restrict__ sub, uint32_t n, double* __restrict__ c0, uint32_t c0_stride)
 {
     constexpr uint32_t S = ResCfg<double>::S;
     constexpr uint32_t NB = S * S / 256u;
+    {   // (blockIdx.y = slot of a batch)
+        const size_t slot = blockIdx.y;
+        part += slot * nsplit * S * S; gs += slot * S * S; y += slot * ldm; sub += slot * S; c0 += slot * c0_stride;
+    }
     if (blockIdx.x >= NB) {
         __shared__ double sv[16];
         const uint32_t col = sub[blockIdx.x - NB];
@@ -794,10 +800,19 @@ __global__ __launch_bounds__(256)
 void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, const double* __restrict__ y, const uint32_t* __restrict__ hdr,
                        const double* __restrict__ LH, const uint32_t* __restrict__ pcol, const double* __restrict__ LX, double tol,
                        const float* __restrict__ meta, __half* __restrict__ r16, float* __restrict__ rn2p, float* __restrict__ tab,
-                       uint32_t* __restrict__ headroom, DevState* __restrict__ st, int first16, int omp)
+                       uint32_t* __restrict__ headroom, DevState* __restrict__ st, int first16, int omp, const float* __restrict__ slotmeta)
 {
+    // slotmeta (a batch, may be null): per slot {||y||^2, what the columns left out of the subset stay below, 1 / s_y} of a first pass
+    // that rounded the signals to fp16 as well (k_scr_gemm in its writing mode) — one signal: meta[5], meta[6]
     constexpr uint32_t PCAP = ResCfg<double>::PCAP;
+    constexpr uint32_t LOGCAP = ResCfg<double>::LOGCAP;
     constexpr uint32_t XP = kR64Rhs + 8u;
+    {
+        const size_t slot = blockIdx.y;
+        y += slot * ldm; hdr += slot * LOGCAP * 8; LH += slot * LOGCAP * 2; pcol += slot * PCAP; LX += slot * LOGCAP * PCAP;
+        r16 += slot * kR64Rhs * ldm; rn2p += slot * (ldm / 64u) * kR64Rhs; tab += slot * kR64Rhs * 4u; st += slot;
+        if (slotmeta != nullptr) slotmeta += slot * 4u;
+    }
     __shared__ __attribute__((aligned(16))) double sAc[16][64];
     __shared__ __attribute__((aligned(16))) double sXt[16][XP];
     __shared__ float sS[kR64Rhs];
@@ -809,10 +824,11 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
         // state 0 after a first pass in half precision (k_scr_first): every column left out of the subset has |c~0| < T, so
         // |c0| < T + eps_0 — certified against lambda_0 (the subset's exact max |c0|) with the margin of every other state
         const float lam0 = (float)LH[0] * 0.9999999f;
-        const float yn = sqrtf(meta[5]) * 1.001f;
-        const float eps0 = 0.0019726562f * yn * meta[4] + 6.103515625e-05f * sqrtf((float)ldm) * yn * meta[1];
+        const float yn = sqrtf(slotmeta != nullptr ? slotmeta[0] : meta[5]) * 1.001f;
+        float eps0 = 0.0019726562f * yn * meta[4] + 6.103515625e-05f * sqrtf((float)ldm) * yn * meta[1];
+        if (slotmeta != nullptr) eps0 += 6.103515625e-05f * sqrtf((float)ldm) * meta[4] * slotmeta[2];     // (the signal was rounded too: its flush term)
         const float bound0 = lam0 * 0.875f - 1e-12f * lam0;
-        const float v0 = meta[6] + eps0;
+        const float v0 = (slotmeta != nullptr ? slotmeta[1] : meta[6]) + eps0;
         if (!(v0 <= bound0)) {
             __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atomicOr(&st->sub_reason, kReasonFirstState);
@@ -820,7 +836,7 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
         ratio0 = bound0 > 0.f && v0 == v0 ? v0 / bound0 : 3.0e38f;
     }
     if (nlog < 2u) {
-        if (blockIdx.x == 0u && tid == 0u) *headroom = __float_as_uint(ratio0);
+        if (blockIdx.x == 0u && tid == 0u && blockIdx.y == 0u) *headroom = __float_as_uint(ratio0);
         return;
     }
     const uint32_t nst = nlog - 1u;                                // states 1 .. nst
@@ -909,7 +925,7 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
     }
     if (ovf) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonOverflow); }
     if (blockIdx.x == 0u) {
-        if (tid == 0u) *headroom = __float_as_uint(ratio0);
+        if (tid == 0u && blockIdx.y == 0u) *headroom = __float_as_uint(ratio0);
         if (tid < nst) {
             const uint32_t* hh = hdr + (size_t)(tid + 1u) * 8u;
             const uint32_t* hp = hdr + (size_t)tid * 8u;
@@ -1001,7 +1017,7 @@ template hipError_t launch_res_solve<float>(ss_hip_ctx*, uint32_t, const float*,
 template hipError_t launch_res_solve<double>(ss_hip_ctx*, uint32_t, const double*, uint32_t, size_t, const double*, uint32_t, const uint32_t*, double, uint32_t,
                                              uint32_t, const ResLog<double>&, double*, uint32_t, uint32_t*, uint32_t*, DevState*, TraceEntry*, uint32_t, bool);
 
-hipError_t launch_sgram64(ss_hip_ctx* ctx, const uint32_t* sub, const double* y, double* part, double* gs, double* c0)
+hipError_t launch_sgram64(ss_hip_ctx* ctx, const uint32_t* sub, const double* y, double* part, double* gs, double* c0, uint32_t nslots, uint32_t c0_stride)
 {
     constexpr uint32_t S = ResCfg<double>::S, NT = S / kG64T;
     const uint32_t ldm = ctx->ldm;
@@ -1010,17 +1026,19 @@ hipError_t launch_sgram64(ss_hip_ctx* ctx, const uint32_t* sub, const double* y,
     if (nsplit > kSg64MaxSplit) nsplit = kSg64MaxSplit;
     while (nsplit > 1u && ldm % (nsplit * kG64Step) != 0u) --nsplit;
     const double* At = static_cast<const double*>(ctx->At);
-    hipLaunchKernelGGL(k_sgram64_part, dim3(NT * (NT + 1) / 2, nsplit), dim3(256), 0, ctx->stream, At, ldm, (uint32_t)ctx->n, sub, ldm / nsplit, part);
-    hipLaunchKernelGGL(k_sgram64_sum, dim3(S * S / 256u + S), dim3(256), 0, ctx->stream, (const double*)part, nsplit, gs, At, ldm, y, sub, (uint32_t)ctx->n, c0);
+    // (a slot's partials take nsplit * S * S doubles: the caller's `part` holds kSg64MaxSplit * S * S per slot — slots are packed by nsplit)
+    hipLaunchKernelGGL(k_sgram64_part, dim3(NT * (NT + 1) / 2, nsplit, nslots), dim3(256), 0, ctx->stream, At, ldm, (uint32_t)ctx->n, sub, ldm / nsplit, part);
+    hipLaunchKernelGGL(k_sgram64_sum, dim3(S * S / 256u + S, nslots), dim3(256), 0, ctx->stream, (const double*)part, nsplit, gs, At, ldm, y, sub, (uint32_t)ctx->n, c0,
+                       c0_stride);
     return hipGetLastError();
 }
 
 hipError_t launch_res_residuals64(ss_hip_ctx* ctx, const double* y, const ResLog<double>& log, double tol, const float* meta, void* r16, float* rn2p,
-                                  float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp)
+                                  float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp, uint32_t nslots, const float* slotmeta)
 {
-    hipLaunchKernelGGL(k_res_residuals64, dim3(ctx->ldm / 64u), dim3(256), 0, ctx->stream, static_cast<const double*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, y,
+    hipLaunchKernelGGL(k_res_residuals64, dim3(ctx->ldm / 64u, nslots), dim3(256), 0, ctx->stream, static_cast<const double*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, y,
                        (const uint32_t*)log.hdr, (const double*)log.H, (const uint32_t*)log.pcol, (const double*)log.X, tol, meta,
-                       static_cast<__half*>(r16), rn2p, tab, headroom, st, first16 ? 1 : 0, omp ? 1 : 0);
+                       static_cast<__half*>(r16), rn2p, tab, headroom, st, first16 ? 1 : 0, omp ? 1 : 0, slotmeta);
     return hipGetLastError();
 }
 

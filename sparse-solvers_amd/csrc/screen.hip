@@ -119,8 +119,26 @@ struct ScreenState {
     double* rl_H = nullptr;      // ... {lambda, gamma} [160][2]
     uint32_t* rl_pcol = nullptr; // ... the positions' columns [144]
     double* rl_X = nullptr;      // ... x by position of every state [160][144]
+    void* b64 = nullptr;         // Screen64Batch*: the buffers of an fp64 batch chunk in the resident tier (made by the first such batch)
 };
 static_assert(kS64Rhs == 192, "the residual block of the fp64 forms (resident.hip: kR64Rhs)");
+// buffers of an fp64 batch chunk in the resident tier (launch_screen64_batch)
+constexpr uint32_t kS64Batch = 32;               // slots of a chunk
+struct Screen64Batch {
+    __half* y16 = nullptr;       // [128][ldm] the chunk's signals in fp16 (rows beyond the chunk: zeros)
+    float* ytab = nullptr;       // [128][kScrTab] 1 / (sA s_y) per signal (the writing mode's scale)
+    float* ymeta = nullptr;      // [kS64Batch][4] {||y||^2, threshold of the selection, 1 / s_y, spare}
+    float* cabs = nullptr;       // [kS64Batch][n_pad] |c~0|
+    uint32_t* sub = nullptr;     // [kS64Batch][S] the subsets (+ 2 words of scratch behind the last)
+    double* gs = nullptr;        // [kS64Batch][S][S]
+    double* gs_part = nullptr;   // [kS64Batch][kSg64MaxSplit][S][S]
+    uint32_t* hdr = nullptr; double* H = nullptr; uint32_t* pcol = nullptr; double* X = nullptr;     // the slots' logs
+    __half* r16 = nullptr;       // [kS64Batch][kS64Rhs][ldm]
+    float* rn2p = nullptr;       // [kS64Batch][ldm / 64][kS64Rhs]
+    float* tab = nullptr;        // [kS64Batch][kS64Rhs][kScrTab]
+    float* zero = nullptr;       // [ldm / 64][128] zeros (the writing mode reads no residual norms)
+    double* c0 = nullptr;        // [kS64Batch][n_pad] dense c0 of every slot: exact at its subset's columns
+};
 
 // ---- one-time preparation ---------------------------------------------------------------------------------------
 template <typename T>
@@ -565,8 +583,10 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
                 const float* __restrict__ anorm, const float* __restrict__ rn2p, uint32_t rn_pitch, const float* __restrict__ tab,
                 const uint32_t* __restrict__ sub, uint32_t nsub, const float* __restrict__ meta, DevState* __restrict__ st,
                 uint32_t* __restrict__ headroom, uint32_t nst_fixed, uint32_t skew, uint32_t gate, uint32_t* __restrict__ fl = nullptr,
-                const float* __restrict__ c0h = nullptr)
+                const float* __restrict__ c0h = nullptr, float* __restrict__ out_abs = nullptr, uint32_t out_pitch = 0)
 {
+    // out_abs (the first pass of an fp64 BATCH, nst_fixed right-hand sides = signals rounded to fp16): no certificate — the launch writes
+    // |c~| = |A16^T y16| / (sA s_y) of every (signal, column) to out_abs[signal * out_pitch + column]: the ranking of each signal's columns
     // fl (one fp32 signal, may be null): a column this pass cannot certify is APPENDED to the list of the exact re-check
     // (k_scr_recheck) instead of failing the signal; c0h: the half-precision first pass's c~0 — when state 0 was left to the list
     // (fl[cap + 1]) every column with |c~0| + eps_0 above the bound joins it
@@ -670,6 +690,18 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
 #undef SCR_LOAD
     // ---- epilogue: the per-state table and the subset's columns into LDS, then every (column, state) of this wave ------
     __syncthreads();
+    if (out_abs != nullptr) {
+        const uint32_t colw = col0 + 32u * w + r;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t kk = 32u * (uint32_t)t + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * h;
+                if (kk < nst) out_abs[(size_t)kk * out_pitch + colw] = colw < n ? fabsf(acc[t][e]) * tab[kk * kScrTab] : 0.f;
+            }
+        }
+        return;
+    }
     constexpr uint32_t PB = NT <= 3 ? 128u : 64u;               // workgroups' partials staged at a time
     float* sT = reinterpret_cast<float*>(smem);                 // [32 NT][4]: 1/(sA s_k), bound, eps factor 1 (x ||a||), eps term 2
     uint32_t* sSub = reinterpret_cast<uint32_t*>(smem) + (uint32_t)RH * 4u;   // [nsub] the subset's columns, ascending (0xffffffff: none)
@@ -1207,6 +1239,13 @@ void screen_free(ss_hip_ctx* ctx)
                      S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs, S->fl, S->sub256, S->gs64, S->gs64_part, S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (S->b64) {
+        Screen64Batch* Bq = static_cast<Screen64Batch*>(S->b64);
+        void* bp[] = { Bq->y16, Bq->ytab, Bq->ymeta, Bq->cabs, Bq->sub, Bq->gs, Bq->gs_part, Bq->hdr, Bq->H, Bq->pcol, Bq->X, Bq->r16, Bq->rn2p, Bq->tab, Bq->zero, Bq->c0 };
+        for (void* p : bp) if (p) (void)hipFree(p);
+        delete Bq;
+        S->b64 = nullptr;
+    }
     if (S->sub) {
         if (S->sub->slog) (void)hipFree(S->sub->slog);
         S->sub->slog = nullptr;
@@ -1642,6 +1681,137 @@ hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, doub
                        (const float*)S->anorm, (const float*)S->rn2p, kS64Rhs, (const float*)S->tab, (const uint32_t*)S->sub256, (uint32_t)RC::S, (const float*)S->meta,
                        ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 2u);
     if (e3) (void)hipEventRecord(e3, s);
+    return hipGetLastError();
+}
+
+// ---- fp64 BATCHES in the resident tier -----------------------------------------------------------------------------------------
+// Signals that share the dictionary share its passes and run their paths side by side:
+//   k_y16_prep      every signal rounded to fp16 (scaled by a power of two), its norm, its table entry
+//   k_scr_gemm<4>   ONE pass over the fp16 copy of A for up to 128 signals: |c~0| of every (signal, column) — the rankings (writing mode)
+//   k_sub_select1w  the 256 best columns of each signal and what the columns left out stay below
+//   k_sgram64_*     the subsets' Gram matrices and exact fp64 c0, one launch for the chunk
+//   k_res_solve     the chunk's paths in as many workgroups, side by side (one signal alone leaves 255 compute units idle for 1 ms)
+//   k_res_residuals64, then per signal the screening pass (its 128 states fill a launch: 0.96 ms each — what a batch costs per signal)
+// What a slot's certificate does not cover is solved again, alone, through every tier (homotopy.hip: solve_batch_res64).
+
+__global__ __launch_bounds__(256)
+void k_y16_prep(const double* __restrict__ Y, uint32_t ldm, uint32_t nslots, const float* __restrict__ meta, __half* __restrict__ y16,
+                float* __restrict__ ytab, float* __restrict__ ymeta)
+{
+    __shared__ float sv[16];
+    __shared__ float s_sc;
+    const uint32_t slot = blockIdx.x, tid = threadIdx.x;
+    __half* out = y16 + (size_t)slot * ldm;
+    if (slot >= nslots) {                                         // (rows of the 128-row block beyond the chunk)
+        for (uint32_t i = tid; i < ldm; i += 256u) out[i] = __float2half_rn(0.f);
+        if (tid == 0u) ytab[slot * kScrTab] = 0.f;
+        return;
+    }
+    const double* y = Y + (size_t)slot * ldm;
+    float ss = 0.f, mx = 0.f;
+    for (uint32_t i = tid; i < ldm; i += 256u) { const float v = (float)y[i]; ss = __builtin_fmaf(v, v, ss); mx = fmaxf(mx, fabsf(v)); }
+    ss = block_sum(ss, sv);
+    __syncthreads();
+    mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+    mx = fmaxf(mx, __shfl_xor(mx, 8)); mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if ((tid & 63u) == 0u) sv[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0u) {
+        mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) e = (int)floorf(log2f(4096.f / mx));      // (max |y| -> 2^11 .. 2^12: far from the fp16 ceiling)
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        const float sc = ldexpf(1.f, e);
+        s_sc = sc;
+        ytab[slot * kScrTab + 0] = meta[1] * ldexpf(1.f, -e);
+        ytab[slot * kScrTab + 1] = 0.f; ytab[slot * kScrTab + 2] = ldexpf(1.f, -e); ytab[slot * kScrTab + 3] = 0.f;
+        ymeta[slot * 4u + 0] = ss * 1.0001f;                         // (the casts of y to float: inside)
+        ymeta[slot * 4u + 2] = ldexpf(1.f, -e);
+    }
+    __syncthreads();
+    const float sc = s_sc;
+    for (uint32_t i = tid; i < ldm; i += 256u) out[i] = __float2half_rn((float)y[i] * sc);
+}
+
+static Screen64Batch* s64b_of(ScreenState* S) { return static_cast<Screen64Batch*>(S->b64); }
+
+bool screen64_batch_usable(ss_hip_ctx* ctx)
+{
+    return ctx->is_f64 && screen64_usable(ctx) && screen64_resident_usable(ctx) && screen_first16_usable(ctx);
+}
+uint32_t screen64_batch_cap() { return kS64Batch; }
+
+// the chunk's signals are in ws.y ([nslots][ldm], zero padded), x / states / lists of the slots in ws; returns with everything queued
+hipError_t launch_screen64_batch(ss_hip_ctx* ctx, Workspace<double>& ws, uint32_t nslots, double tol, uint32_t max_iter)
+{
+    typedef ResCfg<double> RC;
+    ScreenState* S = scr_of(ctx);
+    if (S == nullptr || nslots == 0 || nslots > kS64Batch) return hipErrorInvalidConfiguration;
+    const uint32_t ldm = ctx->ldm, n = (uint32_t)ctx->n, np = ctx->n_pad;
+    Screen64Batch* Bq = s64b_of(S);
+    if (Bq == nullptr) {
+        Bq = new (std::nothrow) Screen64Batch();
+        if (Bq == nullptr) return hipErrorOutOfMemory;
+        bool ok = true;
+        auto alloc = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; } };
+        alloc(reinterpret_cast<void**>(&Bq->y16), (size_t)128 * ldm * sizeof(__half));
+        alloc(reinterpret_cast<void**>(&Bq->ytab), (size_t)128 * kScrTab * sizeof(float));
+        alloc(reinterpret_cast<void**>(&Bq->ymeta), (size_t)kS64Batch * 4 * sizeof(float));
+        alloc(reinterpret_cast<void**>(&Bq->cabs), (size_t)kS64Batch * np * sizeof(float));
+        alloc(reinterpret_cast<void**>(&Bq->sub), ((size_t)kS64Batch * RC::S + 2) * sizeof(uint32_t));
+        alloc(reinterpret_cast<void**>(&Bq->gs), (size_t)kS64Batch * RC::S * RC::S * sizeof(double));
+        alloc(reinterpret_cast<void**>(&Bq->gs_part), (size_t)kS64Batch * kSg64MaxSplit * RC::S * RC::S * sizeof(double));
+        alloc(reinterpret_cast<void**>(&Bq->hdr), (size_t)kS64Batch * RC::LOGCAP * 8 * sizeof(uint32_t));
+        alloc(reinterpret_cast<void**>(&Bq->H), (size_t)kS64Batch * RC::LOGCAP * 2 * sizeof(double));
+        alloc(reinterpret_cast<void**>(&Bq->pcol), (size_t)kS64Batch * RC::PCAP * sizeof(uint32_t));
+        alloc(reinterpret_cast<void**>(&Bq->X), (size_t)kS64Batch * RC::LOGCAP * RC::PCAP * sizeof(double));
+        alloc(reinterpret_cast<void**>(&Bq->r16), (size_t)kS64Batch * kS64Rhs * ldm * sizeof(__half));
+        alloc(reinterpret_cast<void**>(&Bq->rn2p), (size_t)kS64Batch * (ldm / 64u) * kS64Rhs * sizeof(float));
+        alloc(reinterpret_cast<void**>(&Bq->tab), (size_t)kS64Batch * kS64Rhs * kScrTab * sizeof(float));
+        alloc(reinterpret_cast<void**>(&Bq->zero), (size_t)(ldm / 64u) * 128 * sizeof(float));
+        alloc(reinterpret_cast<void**>(&Bq->c0), (size_t)kS64Batch * np * sizeof(double));
+        if (ok && (hipMemsetAsync(Bq->r16, 0, (size_t)kS64Batch * kS64Rhs * ldm * sizeof(__half), ctx->stream) != hipSuccess ||
+                   hipMemsetAsync(Bq->zero, 0, (size_t)(ldm / 64u) * 128 * sizeof(float), ctx->stream) != hipSuccess)) ok = false;
+        if (!ok) {
+            void* ptrs[] = { Bq->y16, Bq->ytab, Bq->ymeta, Bq->cabs, Bq->sub, Bq->gs, Bq->gs_part, Bq->hdr, Bq->H, Bq->pcol, Bq->X, Bq->r16, Bq->rn2p, Bq->tab, Bq->zero, Bq->c0 };
+            for (void* p : ptrs) if (p) (void)hipFree(p);
+            delete Bq;
+            (void)hipGetLastError();
+            return hipErrorOutOfMemory;
+        }
+        S->b64 = Bq;
+    }
+    hipStream_t s = ctx->stream;
+    const double* Y = ws.y;
+    // the signals in fp16, ONE pass over the fp16 copy for the whole chunk: |c~0| of every (signal, column)
+    hipLaunchKernelGGL(k_y16_prep, dim3(128), dim3(256), 0, s, Y, ldm, nslots, (const float*)S->meta, Bq->y16, Bq->ytab, Bq->ymeta);
+    hipLaunchKernelGGL(k_scr_gemm<4>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds((uint32_t)RC::S, 4), s, (const __half*)S->a16, ldm, n, (const __half*)Bq->y16,
+                       (const float*)S->anorm, (const float*)Bq->zero, 128u, (const float*)Bq->ytab, (const uint32_t*)Bq->sub, 0u, (const float*)S->meta,
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, nslots, scr_skew(), 0u, (uint32_t*)nullptr, (const float*)nullptr, Bq->cabs, np);
+    // each signal's 256 best columns and what the columns it left out stay below
+    for (uint32_t b = 0; b < nslots; ++b)
+        (void)launch_select_top(ctx, Bq->cabs + (size_t)b * np, n, np, (uint32_t)RC::S, Bq->sub + (size_t)b * RC::S, S->sublist + kS64Sub,
+                                reinterpret_cast<float*>(S->sublist + kS64Sub + 1), Bq->ymeta + (size_t)b * 4 + 1);
+    { const hipError_t eg = launch_sgram64(ctx, Bq->sub, Y, Bq->gs_part, Bq->gs, Bq->c0, nslots, np); if (eg != hipSuccess) return eg; }
+    const ResLog<double> log{ Bq->hdr, Bq->H, Bq->pcol, Bq->X, nullptr };
+    { const hipError_t es = launch_res_solve<double>(ctx, nslots, Bq->gs, (uint32_t)RC::S, (size_t)RC::S * RC::S, Bq->c0, np, Bq->sub, tol, max_iter, ws.dims.kcap, log,
+                                                     ws.x, np, ws.gam, ws.touched, ws.st, (TraceEntry*)nullptr, 0u, false);
+      if (es != hipSuccess) return es; }
+    (void)launch_res_residuals64(ctx, Y, log, tol, S->meta, Bq->r16, Bq->rn2p, Bq->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, true, false, nslots,
+                                 Bq->ymeta);
+    for (uint32_t b = 0; b < nslots; ++b) {
+        const __half* r16 = Bq->r16 + (size_t)b * kS64Rhs * ldm;
+        const float* rn = Bq->rn2p + (size_t)b * (ldm / 64u) * kS64Rhs;
+        const float* tb = Bq->tab + (size_t)b * kS64Rhs * kScrTab;
+        const uint32_t* sb = Bq->sub + (size_t)b * RC::S;
+        hipLaunchKernelGGL(k_scr_gemm<4>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds((uint32_t)RC::S, 4), s, (const __half*)S->a16, ldm, n, r16,
+                           (const float*)S->anorm, rn, kS64Rhs, tb, sb, (uint32_t)RC::S, (const float*)S->meta, ws.st + b,
+                           reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 1u);
+        hipLaunchKernelGGL(k_scr_gemm<5>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds((uint32_t)RC::S, 5), s, (const __half*)S->a16, ldm, n, r16,
+                           (const float*)S->anorm, rn, kS64Rhs, tb, sb, (uint32_t)RC::S, (const float*)S->meta, ws.st + b,
+                           reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 2u);
+    }
+    (void)launch_sub_finish_st(ctx, ws.st, nslots);
     return hipGetLastError();
 }
 

@@ -248,6 +248,12 @@ struct ss_hip_ctx {
     // the per-signal c0 = A^T y rows of the current chunk
     float* gram_full = nullptr;
     uint32_t gram_pitch = 0;
+    // G's memory reserved ahead of its first use: a context that has received a batch of >= 4 signals will likely receive the large
+    // one that forms G — the allocation (the driver clears fresh VRAM: ~0.5 s for 17 GiB) then runs on a helper thread beside the
+    // batches before it instead of in front of the first large one (option gram_reserve; only where G is a small share of the HBM)
+    void* gram_reserve_thread = nullptr;     // std::thread*
+    float* gram_reserved = nullptr;          // what that thread obtained (read after join)
+    int gram_reserve = 1;
     float* c0_batch = nullptr;
     void* sub_buf = nullptr;          // subset form (subbatch.hip): subsets, first picks, breakpoint logs of a chunk
     size_t sub_buf_bytes = 0;
@@ -433,6 +439,7 @@ hipError_t launch_sub_select(ss_hip_ctx* ctx, const SubBufs& B, uint32_t nslots,
 hipError_t launch_sub_solve(ss_hip_ctx* ctx, Workspace<float>& ws, const SubBufs& B, uint32_t nslots, const float* G, uint32_t gpitch, int gsub,
                             const float* c0, float tol, uint32_t max_iter, uint32_t g_slot_stride = 0);
 hipError_t launch_sub_finish(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots);
+hipError_t launch_sub_finish_st(ss_hip_ctx* ctx, DevState* st, uint32_t nslots);
 hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32_t n_pad, uint32_t nsel, uint32_t* sub, uint32_t* fpick, float* fval,
                              float* thr_out = nullptr, const float* wmax = nullptr, uint32_t nwmax = 0);
 // screened form of ONE signal (screen.hip): the subset form on the subset's own Gram matrix (formed from A), every state of
@@ -459,6 +466,11 @@ bool screen64_resident_usable(ss_hip_ctx* ctx);
 hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp,
                                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr,
                                     hipEvent_t e4 = nullptr, hipEvent_t e5 = nullptr);
+// fp64 batches in the resident tier: a chunk of nslots <= screen64_batch_cap() signals (in ws.y) — one pass over the fp16 copy ranks every signal's
+// columns, the chunk's paths run side by side, each signal's states are certified by a screening pass of its own; verdicts in the slots' states
+bool screen64_batch_usable(ss_hip_ctx* ctx);
+uint32_t screen64_batch_cap();
+hipError_t launch_screen64_batch(ss_hip_ctx* ctx, Workspace<double>& ws, uint32_t nslots, double tol, uint32_t max_iter);
 void screen_debug_recheck(ss_hip_ctx* ctx);               // developer aid (SS_HIP_SUB_DEBUG)
 double screen_read_headroom(ss_hip_ctx* ctx);             // largest (|c~| + eps) / bound of the last screened solve (synchronises)
 hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,

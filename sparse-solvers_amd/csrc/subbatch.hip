@@ -1011,6 +1011,12 @@ hipError_t launch_sub_finish(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nsl
     return hipGetLastError();
 }
 
+hipError_t launch_sub_finish_st(ss_hip_ctx* ctx, DevState* st, uint32_t nslots)
+{
+    hipLaunchKernelGGL(k_sub_finish, dim3((nslots + 255) / 256), dim3(256), 0, ctx->stream, st, nslots);
+    return hipGetLastError();
+}
+
 hipError_t launch_sub_form(ss_hip_ctx* ctx, Workspace<float>& ws, uint32_t nslots, const float* c0, float tol, uint32_t max_iter,
                            hipEvent_t e0, hipEvent_t e1, hipEvent_t e2)
 {

@@ -582,6 +582,46 @@ def test_exact_recheck_of_the_columns_the_certificate_leaves_open(sship):
     assert went >= 1, "no signal went through the exact re-check: the test does not reach what it is for"
 
 
+@pytest.mark.parametrize("B", [4, 9, 37])
+def test_fp64_batch_in_the_resident_tier(sship, B):
+    """fp64 batches of four signals or more: the signals of a chunk (32) share ONE ranking pass over the fp16 copy of A, run their
+    paths side by side in as many workgroups (csrc/resident.hip) and are certified one screening pass each; against the oracle
+    signal by signal (iterations, support, coefficients within 1e-10), dense output and compact records, one signal made
+    uncertifiable on purpose (its support beyond the 144 positions a path may take: it must come back from the tiers behind, still the
+    oracle's)."""
+    import sharding
+    m, n, k = 2048, 16384, 16
+    rng = np.random.default_rng(9900 + B)
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    Y = np.empty((B, m))
+    ks = []
+    for b in range(B):
+        kb = 150 if b == 2 else k                       # (slot 2: more columns than the resident kernel holds positions)
+        sb = np.sort(rng.choice(n, kb, replace=False))
+        xb = np.zeros(n)
+        xb[sb] = 1.0 + np.abs(rng.standard_normal(kb))
+        Y[b] = A @ xb
+        ks.append(kb)
+    budget = 4 * 150
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.reset_stats()
+        X, its, errs = h.solve_batch(Y, 1e-9, budget)
+        st = h.stats()
+        rec = h.solve_batch_compact(Y, 1e-9, budget, kmax=200)
+    note("test_fp64_batch_in_the_resident_tier", B=B, certified=st["screen_signals"], resident=st["screen_resident"], tier2=st["screen_tier2"],
+         redone=st["screen_redone"], why={k_: v for k_, v in st.items() if k_.startswith("why_") and v})
+    assert st["screen_resident"] >= B - 1 and st["screen_tier2"] >= 1 and st["why_positions"] >= 1
+    recs = sharding.unpack_records(rec, 200, np.float64)
+    for b in range(B):
+        xo, ito, eo = oracle.homotopy(A, Y[b], 1e-9, budget)
+        assert_parity(X[b], its[b], errs[b], xo, ito, eo, np.float64)
+        r = recs[b]
+        nz = np.nonzero(X[b])[0]
+        assert r["K"] == len(nz) and r["iter"] == its[b]
+        assert np.array_equal(r["idx"][:r["K"]], nz) and np.abs(r["val"][:r["K"]] - X[b][nz]).max() <= 1e-12 * np.abs(X[b]).max()
+
+
 def test_bench_measures_traffic_in_the_run():
     """bench.py's roofline.traffic: two child runs of tools/pmc_probe.py under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE). Where the
     profiler is at hand the figure must be the passes' algorithmic bytes to within 2 % (1.0004 x and 1.0071 x on an MI355X); where

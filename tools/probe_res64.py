@@ -53,6 +53,31 @@ def main():
                   "headroom %.3f %s" % (which, name, dt * 1e3, bool(np.array_equal(np.nonzero(xh)[0], sup5)),
                                         float(np.abs(xh[sup5] - coef5).max() / coef5.max()), st["screen_signals"], st["screen_resident"],
                                         st["screen_tier2"], st["screen_redone"], st["screen_headroom"], why), flush=True)
+    if "--batch" in sys.argv:
+        nbt = int(sys.argv[sys.argv.index("--batch") + 1])
+        Yb = torch.stack([sigs[i % len(sigs)][0] for i in range(nbt)]).contiguous()
+        Xb = torch.zeros((nbt, n5), device=dev, dtype=torch.float64)
+        h5.set_option("screen_resident", 1)
+        h5.solve_batch(Yb, 1e-9, 512, out=Xb)
+        h5.reset_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h5.solve_batch(Yb, 1e-9, 512, out=Xb)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        st = h5.stats()
+        okb = 0
+        Xh = Xb.cpu().numpy()
+        for i in range(nbt):
+            okb += int(np.array_equal(np.nonzero(Xh[i])[0], sigs[i % len(sigs)][1]))
+        t0 = time.perf_counter()
+        for i in range(nbt):
+            h5.solve(Yb[i], 1e-9, 512, out=x5)
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t0
+        print("configs[4] batch of %d fp64 signals: %.2f ms = %.3f ms per signal (one solve per signal: %.3f ms each — %.2f x); supports exact %d / %d; "
+              "certified in the batch %d, handed to the tiers behind %d" % (nbt, dtb * 1e3, dtb * 1e3 / nbt, dt1 * 1e3 / nbt, dt1 / dtb, okb, nbt,
+                                                                           st["screen_resident"], st["screen_tier2"]), flush=True)
     h5.close()
 
 
