@@ -778,6 +778,23 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                 "achieved": cq_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cq_gbs / HBM_PEAK_GBS, "traffic": None,
                 "bytes_total": stb["cq_bytes"], "ms_total": stb["cq_ms"], "launches_timed": stb["cq_launches"]},
         }
+        # a COLD context whose very first call is the large batch: nothing reserved ahead — allocation of G (the driver clears 17 GiB of
+        # fresh VRAM), its formation, the batch.  (In the runs above the context had seen small batches before: G's memory was reserved
+        # on a helper thread beside them — option gram_reserve — and the first large batch waited only for what was left of that.)
+        try:
+            hc = sship.Homotopy(A, device=local_rank)
+            torch.cuda.synchronize()
+            tcold = time.perf_counter()
+            hc.solve_batch_compact(Yb, TOL, MAX_ITER, kmax=KMAX_RECORD, out=rec)
+            torch.cuda.synchronize()
+            dcold = time.perf_counter() - tcold
+            stc = hc.stats()
+            hc.close()
+            batched["cold_context_first_batch"] = {"seconds": dcold, "signals_per_s": Bx / dcold, "gram_alloc_ms": stc["gram_alloc_ms"],
+                                                   "gram_build_ms": stc["gram_build_ms"]}
+        except Exception as ex:
+            batched["cold_context_first_batch"] = {"error": repr(ex)}
+        batched["gram_memory_reserved_ahead"] = bool(h.get_option("gram_reserve"))
         del rec, Yb
 
     # extra (NOT `value`): with G = A^T A in HBM (the batch above formed it) a single-signal solve needs no pass
@@ -1144,6 +1161,58 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         omp5 = {"ms_per_solve": dto5 * 1e3, "picks": int(ito5), "support_exact": bool(np.array_equal(np.nonzero(xo5h)[0], sup5)),
                 "max_rel_coef_err": float(np.abs(xo5h[sup5] - coef5).max() / coef5.max())}
         del xo5
+        # a BATCH of 64 fp64 signals sharing the dictionary: one ranking pass over the fp16 copy for a chunk of 32, the paths side by side,
+        # one screening pass per signal — against one solve per signal (and the sub-dictionary tier alone: what round 3 ran)
+        b64 = None
+        try:
+            nb5 = 64
+            sig5 = []
+            for s_ in range(nb5):
+                rb5 = np.random.default_rng(4400 + s_)
+                sb5 = np.sort(rb5.choice(n5, k5, replace=False))
+                cb5 = 1.0 + np.abs(rb5.standard_normal(k5))
+                sig5.append((sb5, cb5))
+            Yb5 = torch.zeros((nb5, m5), device=dev, dtype=torch.float64)
+            # (the dictionary lives in the context only: the signals are formed from its device copy through the library's own product)
+            for s_ in range(nb5):
+                xs5 = np.zeros(n5)
+                xs5[sig5[s_][0]] = sig5[s_][1]
+                Yb5[s_] = torch.from_numpy(h5.reconstruct(xs5)).to(dev)
+            Xb5 = torch.zeros((nb5, n5), device=dev, dtype=torch.float64)
+            h5.solve_batch(Yb5, 1e-9, 512, out=Xb5)
+            h5.reset_stats()
+            torch.cuda.synchronize()
+            tb5 = time.perf_counter()
+            h5.solve_batch(Yb5, 1e-9, 512, out=Xb5)
+            torch.cuda.synchronize()
+            dtb5 = time.perf_counter() - tb5
+            stb5 = h5.stats()
+            Xb5h = Xb5.cpu().numpy()
+            okb5 = sum(int(np.array_equal(np.nonzero(Xb5h[s_])[0], sig5[s_][0])) for s_ in range(nb5))
+            errb5 = max(float(np.abs(Xb5h[s_][sig5[s_][0]] - sig5[s_][1]).max() / sig5[s_][1].max()) for s_ in range(nb5))
+            tq5 = time.perf_counter()
+            for s_ in range(8):
+                h5.solve(Yb5[s_], 1e-9, 512, out=x5)
+            torch.cuda.synchronize()
+            dt1_5 = (time.perf_counter() - tq5) / 8
+            h5.set_option("screen_resident", 0)
+            h5.solve(Yb5[0], 1e-9, 512, out=x5)
+            torch.cuda.synchronize()
+            tq5 = time.perf_counter()
+            for s_ in range(4):
+                h5.solve(Yb5[s_], 1e-9, 512, out=x5)
+            torch.cuda.synchronize()
+            dt2_5 = (time.perf_counter() - tq5) / 4
+            h5.set_option("screen_resident", 1)
+            b64 = {"workload": "64 fp64 signals (k = 128 each) sharing the configs[4] dictionary, ss_hip_homotopy_solve_batch_f64, dense output",
+                   "ms": dtb5 * 1e3, "ms_per_signal": dtb5 * 1e3 / nb5, "signals_per_s": nb5 / dtb5,
+                   "one_solve_per_signal_ms": dt1_5 * 1e3, "speedup_vs_one_solve_per_signal": dt1_5 * nb5 / dtb5,
+                   "sub_dictionary_tier_alone_ms_per_solve": dt2_5 * 1e3, "speedup_vs_the_sub_dictionary_tier_one_by_one": dt2_5 * nb5 / dtb5,
+                   "support_exact": okb5, "max_rel_coef_err": errb5, "certified_in_the_batch": int(stb5["screen_resident"]),
+                   "handed_to_the_tiers_behind": int(stb5["screen_tier2"])}
+            del Yb5, Xb5
+        except Exception as ex:
+            b64 = {"error": repr(ex)}
         _, ms32 = h5.gram_cols(np.arange(0, 32000, 1000, dtype=np.uint32), 5)
         _, ms1 = h5.gemv_t(y5, 3)
         b32 = m5 * n5 * 8 + 32 * m5 * 8 + 32 * n5 * 8
@@ -1165,6 +1234,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             "without_screening": un5,
             "fp64_first_pass": f64first5,
             "omp_fp64_same_signal": omp5,
+            "batch_of_64": b64,
             "lookahead_sweeps_per_solve": st5["lookahead_sweeps"] / max(1, st5["solves"]),
             "lookahead_sweep_f64": {"ms": ms32, "GB/s": b32 / ms32 / 1e6, "frac_of_8TBs": b32 / ms32 / 1e6 / HBM_PEAK_GBS},
             "atr_gemv_f64": {"ms": ms1, "GB/s": b1 / ms1 / 1e6, "frac_of_8TBs": b1 / ms1 / 1e6 / HBM_PEAK_GBS}}

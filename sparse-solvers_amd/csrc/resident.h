@@ -28,6 +28,7 @@ enum : uint32_t {
     kReasonColumn = 1u << 8,        // the screening pass could not certify a (column, state)
     kReasonTie = 1u << 9,           // the subset's scan met an exact tie
     kReasonRechecked = 1u << 10,    // (not a failure) the exact re-check of flagged columns ran for this signal
+    kReasonRepaired = 1u << 11,     // (not a failure) ... and the last step was taken again with a column outside the subset stopping it
 };
 
 // the log of a resident solve (device pointers; per slot: hdr [LOGCAP][8] u32, H [LOGCAP][2] = {lambda, gamma} in T (may be null),

@@ -331,7 +331,8 @@ def test_screened_form_random_problems(sship):
         assert it == ito, tag
         assert np.array_equal(significant_support(x, 100 * lim), significant_support(xo, 100 * lim)), tag
         assert np.abs(x.astype(np.float64) - xo).max() <= max(lim, 3 * reld) * np.abs(xo).max(), tag
-        assert 0.0 < st["screen_headroom"] < 1.0, tag
+        # (headroom >= 1: the half-precision certificate left columns open and the exact re-check decided them)
+        assert 0.0 < st["screen_headroom"] < 1.0 or st["screen_recheck"] == 1, tag
     note("test_screened_form_random_problems", certified=cert, handed_back=redone)
     assert cert >= 8 and redone >= 8
 
