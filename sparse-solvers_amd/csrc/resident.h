@@ -13,6 +13,7 @@ template <> struct ResCfg<float>  { static constexpr int S = 448, THREADS = 448,
 static_assert(ResCfg<float>::S == (int)kSbS && ResCfg<float>::PCAP == (int)kSbRows && ResCfg<float>::LOGCAP == (int)kSbLog,
               "the fp32 resident kernel writes the subset form's log (subbatch.hip, screen.hip read it)");
 
+constexpr uint32_t kScrFlCap = 1024;              // columns the screened forms' half-precision certificate may leave to the exact re-check (screen.hip)
 constexpr uint32_t kSg64MaxSplit = 64;            // row chunks of the fp64 subset Gram matrix at most
 
 // why a subset solve was not reported (DevState::sub_reason, a bit mask; ss_hip_stats counts them)
@@ -45,6 +46,7 @@ hipError_t launch_res_solve(ss_hip_ctx* ctx, uint32_t nslots, const T* Gs, uint3
 hipError_t launch_sgram64(ss_hip_ctx* ctx, const uint32_t* sub, const double* y, double* part, double* gs, double* c0, uint32_t nslots = 1, uint32_t c0_stride = 0);
 // fp64: residuals of the logged states in half precision, the screening pass's table, the certificate of state 0
 hipError_t launch_res_residuals64(ss_hip_ctx* ctx, const double* y, const ResLog<double>& log, double tol, const float* meta, void* r16, float* rn2p,
-                                  float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp, uint32_t nslots = 1, const float* slotmeta = nullptr);
+                                  float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp, uint32_t nslots = 1, const float* slotmeta = nullptr,
+                                  uint32_t* fl = nullptr);
 
 }  // namespace sship

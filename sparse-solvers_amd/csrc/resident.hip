@@ -800,8 +800,12 @@ __global__ __launch_bounds__(256)
 void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, const double* __restrict__ y, const uint32_t* __restrict__ hdr,
                        const double* __restrict__ LH, const uint32_t* __restrict__ pcol, const double* __restrict__ LX, double tol,
                        const float* __restrict__ meta, __half* __restrict__ r16, float* __restrict__ rn2p, float* __restrict__ tab,
-                       uint32_t* __restrict__ headroom, DevState* __restrict__ st, int first16, int omp, const float* __restrict__ slotmeta)
+                       uint32_t* __restrict__ headroom, DevState* __restrict__ st, int first16, int omp, const float* __restrict__ slotmeta,
+                       uint32_t* __restrict__ fl)
 {
+    // fl (one signal, may be null): the list of the exact re-check (screen.hip: k_scr_recheck), cleared here; a state 0 the first pass's
+    // threshold cannot certify is left to it ([1024 + 1 .. + 3]: flag, bits(bound_0), bits(eps_0))
+    constexpr uint32_t kFlCap = kScrFlCap;
     // slotmeta (a batch, may be null): per slot {||y||^2, what the columns left out of the subset stay below, 1 / s_y} of a first pass
     // that rounded the signals to fp16 as well (k_scr_gemm in its writing mode) — one signal: meta[5], meta[6]
     constexpr uint32_t PCAP = ResCfg<double>::PCAP;
@@ -820,6 +824,9 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
     const uint32_t tid = threadIdx.x, r0 = blockIdx.x * 64u;
     const uint32_t nlog = st->solo_nlog;
     float ratio0 = 0.f;
+    if (fl != nullptr && blockIdx.x == 0u && blockIdx.y == 0u && tid == 0u) {
+        fl[0] = 0u; fl[kFlCap + 1u] = 0u; fl[kFlCap + 4u] = 0u; fl[kFlCap + 12u] = 0u;
+    }
     if (first16 && blockIdx.x == 0u && tid == 0u && nlog >= 1u) {
         // state 0 after a first pass in half precision (k_scr_first): every column left out of the subset has |c~0| < T, so
         // |c0| < T + eps_0 — certified against lambda_0 (the subset's exact max |c0|) with the margin of every other state
@@ -830,8 +837,8 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
         const float bound0 = lam0 * 0.875f - 1e-12f * lam0;
         const float v0 = (slotmeta != nullptr ? slotmeta[1] : meta[6]) + eps0;
         if (!(v0 <= bound0)) {
-            __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicOr(&st->sub_reason, kReasonFirstState);
+            if (fl != nullptr && bound0 > 0.f) { fl[kFlCap + 1u] = 1u; fl[kFlCap + 2u] = __float_as_uint(bound0); fl[kFlCap + 3u] = __float_as_uint(eps0); }
+            else { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonFirstState); }
         }
         ratio0 = bound0 > 0.f && v0 == v0 ? v0 / bound0 : 3.0e38f;
     }
@@ -947,7 +954,11 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
                 if (ls_jump) bound = (float)tol * 0.9375f - slack;
                 else bound = fminf(lam, (float)lam_exp) * 0.875f - slack;
                 // only REGULAR paths are certified: every step inserts a column, lambda goes down
-                if (hp[3] == 0u || lam_d > lam_pd * (1.0 + 1e-12)) { bound = -1.f; atomicOr(&st->sub_reason, kReasonIrregular); }
+                if (hp[3] == 0u || lam_d > lam_pd * (1.0 + 1e-12)) {
+                    bound = -1.f;
+                    atomicOr(&st->sub_reason, kReasonIrregular);
+                    __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (no screening pass for it)
+                }
             }
             const float inv_sk = 1.f / sS[tid];
             tab[tid * 4u + 0] = meta[1] * inv_sk;
@@ -1034,11 +1045,11 @@ hipError_t launch_sgram64(ss_hip_ctx* ctx, const uint32_t* sub, const double* y,
 }
 
 hipError_t launch_res_residuals64(ss_hip_ctx* ctx, const double* y, const ResLog<double>& log, double tol, const float* meta, void* r16, float* rn2p,
-                                  float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp, uint32_t nslots, const float* slotmeta)
+                                  float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp, uint32_t nslots, const float* slotmeta, uint32_t* fl)
 {
     hipLaunchKernelGGL(k_res_residuals64, dim3(ctx->ldm / 64u, nslots), dim3(256), 0, ctx->stream, static_cast<const double*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, y,
                        (const uint32_t*)log.hdr, (const double*)log.H, (const uint32_t*)log.pcol, (const double*)log.X, tol, meta,
-                       static_cast<__half*>(r16), rn2p, tab, headroom, st, first16 ? 1 : 0, omp ? 1 : 0, slotmeta);
+                       static_cast<__half*>(r16), rn2p, tab, headroom, st, first16 ? 1 : 0, omp ? 1 : 0, slotmeta, fl);
     return hipGetLastError();
 }
 

@@ -76,8 +76,9 @@ constexpr uint32_t kSgT = 64;                    // its tile: 64 x 64 outputs pe
 constexpr uint32_t kSgStep = 64;                 // rows staged per step
 constexpr uint32_t kSgPitchF = kSgStep + 4;      // floats per LDS row
 constexpr uint32_t kScrBatch = 64;               // slots of a batch chunk in the screened form
-constexpr uint32_t kScrFlCap = 1024;             // columns the half-precision certificate may leave to the exact re-check (per signal)
-constexpr uint32_t kScrFlWords = kScrFlCap + 12; // (+ 8 words: the first (column, state) the re-check failed, for SS_HIP_SUB_DEBUG)  // the list: [0] count, [1 .. cap] columns, [cap + 1] state 0 needs the re-check, [cap + 2] bits(bound_0), [cap + 3] bits(eps_0)
+// (kScrFlCap — columns the half-precision certificate may leave to the exact re-check, per signal — is resident.h's: k_res_residuals64 clears the list)
+constexpr uint32_t kScrRepCap = 64;              // columns that may be ahead of the subset's last step (candidates of the repair)
+constexpr uint32_t kScrFlWords = kScrFlCap + 16 + 4 * kScrRepCap; // (+ the first failure for SS_HIP_SUB_DEBUG at [cap + 4 ..], the repair's count at [cap + 12], its {column, -, step as a double} entries from [cap + 16])  // the list: [0] count, [1 .. cap] columns, [cap + 1] state 0 needs the re-check, [cap + 2] bits(bound_0), [cap + 3] bits(eps_0)
 constexpr uint32_t kScrRecheckWgs = 240;         // workgroups of the re-check launch
 constexpr uint32_t kS64Sub = 2048;               // fp64 form: columns of the sub-dictionary the path is solved on
 constexpr uint32_t kS64Rhs = 192;                // ... states it can certify (two launches of the screening pass)
@@ -118,7 +119,8 @@ struct ScreenState {
     uint32_t* rl_hdr = nullptr;  // the resident solve's log: headers [160][8]
     double* rl_H = nullptr;      // ... {lambda, gamma} [160][2]
     uint32_t* rl_pcol = nullptr; // ... the positions' columns [144]
-    double* rl_X = nullptr;      // ... x by position of every state [160][144]
+    double* rl_X = nullptr;      // ... x by position of every state [160][136]
+    double* rl_D = nullptr;      // ... the direction by position likewise (the exact re-check's chain)
     void* b64 = nullptr;         // Screen64Batch*: the buffers of an fp64 batch chunk in the resident tier (made by the first such batch)
 };
 static_assert(kS64Rhs == 192, "the residual block of the fp64 forms (resident.hip: kR64Rhs)");
@@ -457,7 +459,7 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
     float ratio0 = 0.f;
     if (fl != nullptr && blockIdx.x == 0u && blockIdx.y == 0u && tid == 0u) {
         fl[0] = 0u; fl[kScrFlCap + 1u] = 0u; fl[kScrFlCap + 4u] = 0u;
-        fl[kScrFlCap + 10u] = 0xffffffffu; fl[kScrFlCap + 11u] = 0xffffffffu;      // (the last step's repair: no candidate yet)
+        fl[kScrFlCap + 12u] = 0u;                                                   // (the last step's repair: no candidate yet)
     }
     if (first16 && blockIdx.x == 0u && tid == 0u) {
         // state 0 after a first pass in half precision (k_scr_first): every column left out of the subset has |c~0| < T, so
@@ -784,19 +786,35 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
 // usually NOT a column that changes the path — on noisy signals the columns of the noise floor come close to lambda at the late
 // states.  Instead of handing the signal back, the few flagged columns (tens; the list holds 1024) are decided EXACTLY here, the way
 // the subset form checks all columns on G (subbatch.hip: k_sub_verify): for column i the Gram values g_p = a_i . a_{col_p} with the
-// path's positions and c0_i = a_i . y are formed in fp32 from A, c_i(k) and q_i(k) of every logged state follow by the solve's own
-// chain — c = fma(-x_p, g_p, c), q = fma(d_p, g_p, q) over the logged coefficients — and the reference's predicates decide
-// (sub_check: |c| <= lambda, no candidate beats the logged step or ties it from the left; the state a path ends in: a larger |c|
-// that leaves the tolerance test as it was is merged into the reported ||c||_inf).  Nothing approximate is left in the verdict of a
-// re-checked column.  One workgroup per flagged column (a fixed grid walks the list); a wave forms the dot products of every
-// fourth position.
+// path's positions and c0_i = a_i . y are formed from A in the solve's own precision, c_i(k) and q_i(k) of every logged state follow
+// by the solve's own chain — c = fma(-x_p, g_p, c), q = fma(d_p, g_p, q) over the logged coefficients — and the reference's
+// predicates decide (sub_check_v: |c| <= lambda, no candidate beats the logged step or ties it from the left; the state a path ends
+// in: a larger |c| that leaves the tolerance test as it was is merged into the reported ||c||_inf).  Nothing approximate is left in
+// the verdict of a re-checked column.  One workgroup per flagged column (a fixed grid walks the list); a wave forms the dot products
+// of every fourth position.  fp32 (one signal of the screened form) and fp64 (the resident tier of the fp64 form).
+//
+// The LAST step of a path that ends by tolerance gets a treatment of its own.  On a noisy signal that step runs from the last planted
+// column down to the noise floor, and the column that stops it — the first of the floor to reach lambda — has a small |c0|: it is not
+// in the subset.  The subset's step is then too long, the coefficients overshoot, and the check rightly says so.  But such a column
+// only SHORTENS the last step: the reference takes the smallest candidate m over all columns, x = x + m d, and stops (lambda - m <=
+// tolerance); which column it was does not reach x (it enters with x = 0).  Every column whose candidate can be below the subset's
+// step ends above the subset's final lambda and is therefore on this list.  So a column that beats the last step does not fail the
+// signal: it POSTS its candidate (atomic min on the ordered bits, left-most on a tie) and k_scr_repair takes the step again with the
+// smallest one.
+template <typename T> struct ScrOrd;
+template <> struct ScrOrd<float>  { static __device__ __forceinline__ unsigned long long pack(float m, uint32_t col) { return ((unsigned long long)__float_as_uint(m) << 32) | col; } };
+template <typename T>
 __global__ __launch_bounds__(256)
-void k_scr_recheck(const float* __restrict__ At, uint32_t ldm, uint32_t n, const float* __restrict__ y, const uint32_t* __restrict__ hdr,
-                   const uint32_t* __restrict__ pcol, const float* __restrict__ LX, const float* __restrict__ LD, uint32_t* __restrict__ fl,
-                   float tol, int tie_guard, DevState* __restrict__ st)
+void k_scr_recheck(const T* __restrict__ At, uint32_t ldm, uint32_t n, const T* __restrict__ y, const uint32_t* __restrict__ hdr, const T* __restrict__ LH,
+                   const uint32_t* __restrict__ pcol, const T* __restrict__ LX, const T* __restrict__ LD, uint32_t* __restrict__ fl,
+                   T tol, int tie_guard, DevState* __restrict__ st)
 {
-    __shared__ uint32_t sH[kSbLog * 8];
-    __shared__ float sG[kSbRows + 1];                            // g_p of the column in hand; [kSbRows] = its c0
+    constexpr uint32_t PCAP = ResCfg<T>::PCAP, LOGCAP = ResCfg<T>::LOGCAP;
+    constexpr uint32_t VE = 16u / sizeof(T);                          // elements per 16-byte load
+    typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    __shared__ uint32_t sH[LOGCAP * 8];
+    __shared__ T sL[LOGCAP * 2];                                   // lambda, step of every state
+    __shared__ T sG[PCAP + 1];                                     // g_p of the column in hand; [PCAP] = its c0
     if (st->status != 0u || st->need_sweep != 0u) return;
     const uint32_t nfl = fl[0];
     if (nfl == 0u) return;
@@ -807,76 +825,89 @@ void k_scr_recheck(const float* __restrict__ At, uint32_t ldm, uint32_t n, const
     }
     if (blockIdx.x == 0u && tid == 0u) atomicOr(&st->sub_reason, kReasonRechecked);
     const uint32_t nlog = st->solo_nlog;
-    if (nlog == 0u) return;
+    if (nlog == 0u || nlog > LOGCAP) return;
     for (uint32_t e = tid; e < nlog * 8u; e += 256u) sH[e] = hdr[e];
+    for (uint32_t e = tid; e < nlog; e += 256u) {
+        if (LH != nullptr) { sL[2 * e] = LH[2 * e]; sL[2 * e + 1] = LH[2 * e + 1]; }
+        else { sL[2 * e] = (T)__uint_as_float(hdr[e * 8u + 4u]); sL[2 * e + 1] = (T)__uint_as_float(hdr[e * 8u + 5u]); }
+    }
     __syncthreads();
     const uint32_t Pfin = sH[(nlog - 1u) * 8u];
+    const bool tol_stop = nlog >= 2u && !(sH[(nlog - 1u) * 8u + 1u] & 1u) && !(sL[2u * (nlog - 1u)] > tol);
     bool fail = false, tie = false;
     for (uint32_t f = blockIdx.x; f < nfl; f += gridDim.x) {
         const uint32_t col = fl[1u + f];
-        const float* ai = At + (size_t)(col < n ? col : 0u) * ldm;
-        // wave w: the positions p = w, w + 4, ... (and, wave 0, c0 = a_i . y last): a lane's four rows of every 256, ascending, then the wave's sum
+        const T* ai = At + (size_t)(col < n ? col : 0u) * ldm;
+        // wave w: the positions p = w, w + 4, ... (and c0 = a_i . y behind the last): a lane's 16-byte pieces of every 64, ascending, then the wave's sum
         for (uint32_t p = wave; p <= Pfin; p += 4u) {
             const bool isy = p == Pfin;
-            if (isy && wave != (Pfin & 3u)) continue;
-            const float* ap = isy ? y : At + (size_t)pcol[p] * ldm;
-            float acc = 0.f;
-            for (uint32_t r = 4u * lane; r < ldm; r += 256u) {
-                const scr_v4f a = *reinterpret_cast<const scr_v4f*>(ai + r), b = *reinterpret_cast<const scr_v4f*>(ap + r);
+            const T* ap = isy ? y : At + (size_t)pcol[p] * ldm;
+            T acc = T(0);
+            for (uint32_t r = VE * lane; r < ldm; r += 64u * VE) {
+                const vec_t a = *reinterpret_cast<const vec_t*>(ai + r), b = *reinterpret_cast<const vec_t*>(ap + r);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(a[q], b[q], acc);
+                for (uint32_t q = 0; q < VE; ++q) acc = sizeof(T) == 8 ? (T)__builtin_fma((double)a[q], (double)b[q], (double)acc) : (T)__builtin_fmaf((float)a[q], (float)b[q], (float)acc);
             }
             acc = wave_sum(acc);
-            if (lane == 0u) sG[isy ? kSbRows : p] = acc;
+            if (lane == 0u) sG[isy ? PCAP : p] = acc;
         }
         __syncthreads();
         if (tid < nlog && col < n) {
-            const uint32_t Pk = sH[tid * 8u];
-            const float* xk = LX + (size_t)tid * kSbRows;
-            const float* dk = LD + (size_t)tid * kSbRows;
-            float cv = sG[kSbRows], qv = 0.f;
-            for (uint32_t p = 0; p < Pk; ++p) {
-                const float g = sG[p];
-                cv = __builtin_fmaf(-xk[p], g, cv);
-                qv = __builtin_fmaf(dk[p], g, qv);
-            }
+            auto chain = [&](uint32_t k, T& cv, T& qv) {
+                const uint32_t Pk = sH[k * 8u];
+                const T* xk = LX + (size_t)k * PCAP;
+                const T* dk = LD + (size_t)k * PCAP;
+                cv = sG[PCAP]; qv = T(0);
+                for (uint32_t p = 0; p < Pk; ++p) {
+                    const T g = sG[p];
+                    if (sizeof(T) == 8) { cv = (T)__builtin_fma(-(double)xk[p], (double)g, (double)cv); qv = (T)__builtin_fma((double)dk[p], (double)g, (double)qv); }
+                    else { cv = (T)__builtin_fmaf(-(float)xk[p], (float)g, (float)cv); qv = (T)__builtin_fmaf((float)dk[p], (float)g, (float)qv); }
+                }
+            };
+            auto check = [&](uint32_t k, T cv, T qv) {
+                const uint32_t* h = sH + k * 8u;
+                const bool has_scan = (h[1] & 1u) != 0u;
+                const T lam_end = k + 1u < nlog ? sL[2u * (k + 1u)] : T(0);
+                const bool end_is_final = k + 1u < nlog && !(sH[(k + 1u) * 8u + 1u] & 1u);
+                sub_check_v<T>(cv, qv, col, has_scan, sL[2u * k], sL[2u * k + 1u], h[2], h[7] != 0u, h[6], k + 2u == nlog, lam_end, end_is_final, tol,
+                               tie_guard, st, fail, tie);
+            };
+            T cv, qv;
+            chain(tid, cv, qv);
             const bool before = fail;
-            // The LAST step of a path that ends by tolerance gets a treatment of its own.  On a noisy signal that step runs from the
-            // last planted column down to the noise floor, and the column that stops it — the first of the floor to reach lambda — has
-            // a small |c0|: it is not in the subset.  The subset's step is then too long, the coefficients overshoot, and the check
-            // rightly says so.  But such a column only SHORTENS the last step: the reference takes the smallest candidate m over
-            // all columns, x = x + m d, and stops (lambda - m <= tolerance); which column it was does not reach x (it enters with
-            // x = 0).  Every column whose candidate can be below the subset's step ends above the subset's final lambda and is
-            // therefore on this list.  So a column that beats the last step does not fail the signal: it POSTS its candidate
-            // (atomic min, left-most on a tie) and k_scr_repair takes the step again with the smallest one.
-            const bool tol_stop = nlog >= 2u && !(sH[(nlog - 1u) * 8u + 1u] & 1u) && !(__uint_as_float(sH[(nlog - 1u) * 8u + 4u]) > tol);
             if (tol_stop && tid + 2u == nlog) {
                 const uint32_t* h = sH + tid * 8u;
-                const float lam = __uint_as_float(h[4]), gam = __uint_as_float(h[5]);
+                const T lam = sL[2u * tid], gam = sL[2u * tid + 1u];
                 const uint32_t pick = h[2];
-                if (!(fabsf(cv) <= lam)) fail = true;
-                const float dl = 1.f - qv, dr = 1.f + qv;
-                float m = Lim<float>::max();
-                if (dl != 0.f) { float t_ = (lam - cv) / dl; if (tie_guard && t_ == 0.f && dl > 0.f) t_ = Lim<float>::tiny(); if (t_ == 0.f && h[7] != 0u) tie = true; if (t_ > 0.f && t_ < m) m = t_; }
-                if (dr != 0.f) { float t_ = (lam + cv) / dr; if (tie_guard && t_ == 0.f && dr > 0.f) t_ = Lim<float>::tiny(); if (t_ == 0.f && h[7] != 0u) tie = true; if (t_ > 0.f && t_ < m) m = t_; }
-                if (better_min(m, col, gam, pick) && !(m >= gam * 0.99999f)) {
-                    if (lam - m <= tol) atomicMin(reinterpret_cast<unsigned long long*>(fl + kScrFlCap + 10u), ((unsigned long long)__float_as_uint(m) << 32) | col);
-                    else fail = true;                                   // (the shorter step would not end the path: not this form's path)
+                const T ac = cv < T(0) ? -cv : cv;
+                if (!(ac <= lam)) fail = true;
+                const T dl = T(1) - qv, dr = T(1) + qv;
+                T m = Lim<T>::max();
+                if (dl != T(0)) { T t_ = (lam - cv) / dl; if (tie_guard && t_ == T(0) && dl > T(0)) t_ = Lim<T>::tiny(); if (t_ == T(0) && h[7] != 0u) tie = true; if (t_ > T(0) && t_ < m) m = t_; }
+                if (dr != T(0)) { T t_ = (lam + cv) / dr; if (tie_guard && t_ == T(0) && dr > T(0)) t_ = Lim<T>::tiny(); if (t_ == T(0) && h[7] != 0u) tie = true; if (t_ > T(0) && t_ < m) m = t_; }
+                if (better_min(m, col, gam, pick) && !(m >= gam * (sizeof(T) == 8 ? T(1) - T(1e-12) : T(0.99999)))) {
+                    // (ahead of the subset's last step: a candidate for the repair — appended with its step; k_scr_repair takes the smallest)
+                    if (lam - m <= tol) {
+                        const uint32_t at = atomicAdd(&fl[kScrFlCap + 12u], 1u);
+                        if (at < kScrRepCap) {
+                            uint32_t* ent = fl + kScrFlCap + 16u + 4u * at;
+                            ent[0] = col;
+                            *reinterpret_cast<double*>(ent + 2) = (double)m;
+                        } else fail = true;
+                    } else fail = true;                                 // (the shorter step would not end the path: not this form's path)
                 } else {
                     // (not ahead of the subset's step — or level with it within rounding, the tie of all columns at a least-squares jump:
                     // the usual predicates, and the state the path ends in)
-                    sub_check(cv, qv, col, tid, nlog, sH, tol, tie_guard, st, fail, tie);
-                    const uint32_t Pf = sH[(nlog - 1u) * 8u];
-                    const float* xf = LX + (size_t)(nlog - 1u) * kSbRows;
-                    float cf = sG[kSbRows];
-                    for (uint32_t p = 0; p < Pf; ++p) cf = __builtin_fmaf(-xf[p], sG[p], cf);
-                    sub_check(cf, 0.f, col, nlog - 1u, nlog, sH, tol, tie_guard, st, fail, tie);
+                    check(tid, cv, qv);
+                    T cf, qf;
+                    chain(nlog - 1u, cf, qf);
+                    check(nlog - 1u, cf, T(0));
                 }
             } else if (!(tol_stop && tid + 1u == nlog)) {
-                sub_check(cv, qv, col, tid, nlog, sH, tol, tie_guard, st, fail, tie);
+                check(tid, cv, qv);
             }
             if (fail && !before && atomicCAS(&fl[kScrFlCap + 4u], 0u, 1u) == 0u) {        // (developer aid: the first failure)
-                fl[kScrFlCap + 5u] = col; fl[kScrFlCap + 6u] = tid; fl[kScrFlCap + 7u] = __float_as_uint(cv); fl[kScrFlCap + 8u] = __float_as_uint(qv);
+                fl[kScrFlCap + 5u] = col; fl[kScrFlCap + 6u] = tid; fl[kScrFlCap + 7u] = __float_as_uint((float)cv); fl[kScrFlCap + 8u] = __float_as_uint((float)qv);
             }
         }
         __syncthreads();
@@ -891,34 +922,77 @@ void k_scr_recheck(const float* __restrict__ At, uint32_t ldm, uint32_t n, const
 // ---- the last step again, with the smallest candidate the re-check found (see k_scr_recheck) -----------------------------------
 // x = x_{K-1} + m d_{K-1} over the positions of the last scan state (homotopy-cpu.cpp:252), lambda = lambda_{K-1} - m, the column that
 // stops the step in the lists and the trace instead of the subset's pick (either enters with x = 0: the coefficients do not see it).
+// The winner's step is formed again here from its exact c and q (one workgroup: its Gram values with the positions, the chain).
+template <typename T>
 __global__ __launch_bounds__(256)
-void k_scr_repair(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pcol, const float* __restrict__ LX, const float* __restrict__ LD,
-                  const uint32_t* __restrict__ fl, float* __restrict__ x, uint32_t* __restrict__ gam, uint32_t* __restrict__ tch, DevState* __restrict__ st,
-                  TraceEntry* trace, uint32_t trace_cap)
+void k_scr_repair(const T* __restrict__ At, uint32_t ldm, uint32_t n, const T* __restrict__ y, const uint32_t* __restrict__ hdr, const T* __restrict__ LH,
+                  const uint32_t* __restrict__ pcol, const T* __restrict__ LX, const T* __restrict__ LD, const uint32_t* __restrict__ fl, T* __restrict__ x,
+                  uint32_t* __restrict__ gam, uint32_t* __restrict__ tch, DevState* __restrict__ st, TraceEntry* trace, uint32_t trace_cap)
 {
+    constexpr uint32_t PCAP = ResCfg<T>::PCAP;
+    constexpr uint32_t VE = 16u / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    __shared__ T sG[PCAP + 1];
+    __shared__ T s_m;
     if (st->status != 0u || st->need_sweep != 0u) return;
-    const unsigned long long best = *reinterpret_cast<const unsigned long long*>(fl + kScrFlCap + 10u);
-    if (best == ~0ull) return;
+    const uint32_t ncand = fl[kScrFlCap + 12u];
+    if (ncand == 0u) return;
     const uint32_t nlog = st->solo_nlog;
-    if (nlog < 2u) return;
-    const uint32_t ks = nlog - 2u, tid = threadIdx.x;
-    const float m = __uint_as_float((uint32_t)(best >> 32));
-    const uint32_t col = (uint32_t)best;
+    if (nlog < 2u || ncand > kScrRepCap) return;                     // (an overflowing list failed the signal in k_scr_recheck)
+    const uint32_t ks = nlog - 2u, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t col = 0xffffffffu;
+    {
+        double bm = 1.0e300;
+        for (uint32_t i = 0; i < ncand; ++i) {                        // (uniform: every thread walks the short list)
+            const uint32_t* ent = fl + kScrFlCap + 16u + 4u * i;
+            const double mi = *reinterpret_cast<const double*>(ent + 2);
+            if (mi < bm || (mi == bm && ent[0] < col)) { bm = mi; col = ent[0]; }
+        }
+    }
     const uint32_t Pk = hdr[ks * 8u], old_pick = hdr[ks * 8u + 2u];
-    if (tid < Pk) x[pcol[tid]] = LX[(size_t)ks * kSbRows + tid] + m * LD[(size_t)ks * kSbRows + tid];
+    const T lam_k = LH != nullptr ? LH[2u * ks] : (T)__uint_as_float(hdr[ks * 8u + 4u]);
+    // the winner's candidate in the solve's precision
+    const T* ai = At + (size_t)(col < n ? col : 0u) * ldm;
+    for (uint32_t p = wave; p <= Pk; p += 4u) {
+        const bool isy = p == Pk;
+        const T* ap = isy ? y : At + (size_t)pcol[p] * ldm;
+        T acc = T(0);
+        for (uint32_t r = VE * lane; r < ldm; r += 64u * VE) {
+            const vec_t a = *reinterpret_cast<const vec_t*>(ai + r), b = *reinterpret_cast<const vec_t*>(ap + r);
+#pragma unroll
+            for (uint32_t q = 0; q < VE; ++q) acc = sizeof(T) == 8 ? (T)__builtin_fma((double)a[q], (double)b[q], (double)acc) : (T)__builtin_fmaf((float)a[q], (float)b[q], (float)acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0u) sG[isy ? PCAP : p] = acc;
+    }
+    __syncthreads();
     if (tid == 0u) {
-        const float lam = __uint_as_float(hdr[ks * 8u + 4u]) - m;
-        st->c_inf = (double)lam;
+        T cv = sG[PCAP], qv = T(0);
+        for (uint32_t p = 0; p < Pk; ++p) {
+            cv = cv - LX[(size_t)ks * PCAP + p] * sG[p];
+            qv = qv + LD[(size_t)ks * PCAP + p] * sG[p];
+        }
+        const T dl = T(1) - qv, dr = T(1) + qv;
+        T m = Lim<T>::max();
+        if (dl != T(0)) { const T t_ = (lam_k - cv) / dl; if (t_ > T(0) && t_ < m) m = t_; }
+        if (dr != T(0)) { const T t_ = (lam_k + cv) / dr; if (t_ > T(0) && t_ < m) m = t_; }
+        s_m = m;
+    }
+    __syncthreads();
+    const T m = s_m;
+    if (tid < Pk) x[pcol[tid]] = LX[(size_t)ks * PCAP + tid] + m * LD[(size_t)ks * PCAP + tid];
+    if (tid == 0u) {
+        st->c_inf = (double)(lam_k - m);
         st->gamma = (double)m;
         st->idx = col;
         atomicOr(&st->sub_reason, kReasonRepaired);
         const uint32_t round = nlog - 1u;
         if (trace != nullptr && round < trace_cap) { trace[round].idx = col; trace[round].gamma = (double)m; }
         // the sorted lists: the subset's last pick out, the column that really stops the step in
-        const uint32_t K = st->K;
         for (int which = 0; which < 2; ++which) {
             uint32_t* L = which == 0 ? gam : tch;
-            uint32_t cnt = which == 0 ? K : st->ntouched, w = 0;
+            const uint32_t cnt = which == 0 ? st->K : st->ntouched;
+            uint32_t w = 0;
             for (uint32_t i = 0; i < cnt; ++i) if (L[i] != old_pick) L[w++] = L[i];
             uint32_t pos = w;
             while (pos > 0u && L[pos - 1u] > col) { L[pos] = L[pos - 1u]; --pos; }
@@ -1311,7 +1385,7 @@ void screen_free(ss_hip_ctx* ctx)
     ScreenState* S = scr_of(ctx);
     if (!S) return;
     void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->wmax, S->cabs, S->sublist, S->xsub, S->xd, S->ctl,
-                     S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs, S->fl, S->sub256, S->gs64, S->gs64_part, S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X };
+                     S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs, S->fl, S->sub256, S->gs64, S->gs64_part, S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X, S->rl_D };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (S->b64) {
@@ -1474,11 +1548,12 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     if (e3) (void)hipEventRecord(e3, s);
     // the columns that pass left undecided, exactly (an empty list: the launch returns at once)
     if (ctx->screen_recheck)
-        hipLaunchKernelGGL(k_scr_recheck, dim3(kScrRecheckWgs), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs, (const uint32_t*)B.hdr, (const uint32_t*)B.pcol,
-                           (const float*)B.LX, (const float*)B.LD, S->fl, tol, ctx->tie_guard, ws.st);
+        hipLaunchKernelGGL((k_scr_recheck<float>), dim3(kScrRecheckWgs), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs, (const uint32_t*)B.hdr, (const float*)nullptr,
+                           (const uint32_t*)B.pcol, (const float*)B.LX, (const float*)B.LD, S->fl, tol, ctx->tie_guard, ws.st);
     if (ctx->screen_recheck)
-        hipLaunchKernelGGL(k_scr_repair, dim3(1), dim3(256), 0, s, (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, (const float*)B.LD,
-                           (const uint32_t*)S->fl, ws.x, ws.gam, ws.touched, ws.st, ws.trace, ws.trace_cap);
+        hipLaunchKernelGGL((k_scr_repair<float>), dim3(1), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs, (const uint32_t*)B.hdr, (const float*)nullptr,
+                           (const uint32_t*)B.pcol, (const float*)B.LX, (const float*)B.LD, (const uint32_t*)S->fl, ws.x, ws.gam, ws.touched, ws.st, ws.trace,
+                           ws.trace_cap);
     // (finish = false: the caller's epilogue launch turns "a column was not certified" into the status the host reads)
     if (finish) (void)launch_sub_finish(ctx, ws, 1);
     return hipGetLastError();
@@ -1600,6 +1675,8 @@ bool screen64_usable(ss_hip_ctx* ctx)
         alloc(reinterpret_cast<void**>(&S->rl_H), (size_t)RC::LOGCAP * 2 * sizeof(double));
         alloc(reinterpret_cast<void**>(&S->rl_pcol), (size_t)RC::PCAP * sizeof(uint32_t));
         alloc(reinterpret_cast<void**>(&S->rl_X), (size_t)RC::LOGCAP * RC::PCAP * sizeof(double));
+        alloc(reinterpret_cast<void**>(&S->rl_D), (size_t)RC::LOGCAP * RC::PCAP * sizeof(double));
+        alloc(reinterpret_cast<void**>(&S->fl), (size_t)kScrFlWords * sizeof(uint32_t));
     }
     if (ok) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1744,21 +1821,31 @@ hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, doub
     (void)launch_select_top(ctx, S->cabs, n, np, (uint32_t)RC::S, S->sub256, S->sub256 + RC::S, reinterpret_cast<float*>(S->sub256 + RC::S + 1),
                             first16 ? S->meta + 6 : nullptr);
     { const hipError_t eg = launch_sgram64(ctx, S->sub256, y, S->gs64_part, S->gs64, ws.c0); if (eg != hipSuccess) return eg; }
-    const ResLog<double> log{ S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X, nullptr };
+    const ResLog<double> log{ S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X, S->rl_D };
     if (e4) (void)hipEventRecord(e4, s);
     { const hipError_t es = launch_res_solve<double>(ctx, 1, S->gs64, (uint32_t)RC::S, 0, ws.c0, 0, S->sub256, tol, max_iter, ws.dims.kcap, log, ws.x, 0, ws.gam,
                                                      ws.touched, ws.st, ws.trace, ws.trace_cap, omp);
       if (es != hipSuccess) return es; }
     if (e5) (void)hipEventRecord(e5, s);
-    (void)launch_res_residuals64(ctx, y, log, tol, S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, first16, omp);
+    uint32_t* fl = (ctx->screen_recheck && !omp) ? S->fl : nullptr;      // (the exact re-check decides Homotopy's predicates: not OMP's)
+    (void)launch_res_residuals64(ctx, y, log, tol, S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, first16, omp, 1, nullptr, fl);
     if (e2) (void)hipEventRecord(e2, s);
     hipLaunchKernelGGL(k_scr_gemm<4>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds((uint32_t)RC::S, 4), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
                        (const float*)S->anorm, (const float*)S->rn2p, kS64Rhs, (const float*)S->tab, (const uint32_t*)S->sub256, (uint32_t)RC::S, (const float*)S->meta,
-                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 1u);
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 1u, fl, first16 ? (const float*)S->cabs : (const float*)nullptr);
     hipLaunchKernelGGL(k_scr_gemm<5>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds((uint32_t)RC::S, 5), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
                        (const float*)S->anorm, (const float*)S->rn2p, kS64Rhs, (const float*)S->tab, (const uint32_t*)S->sub256, (uint32_t)RC::S, (const float*)S->meta,
-                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 2u);
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 2u, fl, first16 ? (const float*)S->cabs : (const float*)nullptr);
     if (e3) (void)hipEventRecord(e3, s);
+    if (fl != nullptr) {
+        // the columns those passes left undecided, exactly, in fp64 (an empty list: the launches return at once)
+        const double* At = static_cast<const double*>(ctx->At);
+        hipLaunchKernelGGL((k_scr_recheck<double>), dim3(kScrRecheckWgs), dim3(256), 0, s, At, ldm, n, y, (const uint32_t*)S->rl_hdr, (const double*)S->rl_H,
+                           (const uint32_t*)S->rl_pcol, (const double*)S->rl_X, (const double*)S->rl_D, fl, tol, ctx->tie_guard, ws.st);
+        hipLaunchKernelGGL((k_scr_repair<double>), dim3(1), dim3(256), 0, s, At, ldm, n, y, (const uint32_t*)S->rl_hdr, (const double*)S->rl_H,
+                           (const uint32_t*)S->rl_pcol, (const double*)S->rl_X, (const double*)S->rl_D, (const uint32_t*)fl, ws.x, ws.gam, ws.touched, ws.st,
+                           ws.trace, ws.trace_cap);
+    }
     return hipGetLastError();
 }
 

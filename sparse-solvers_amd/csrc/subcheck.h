@@ -62,4 +62,47 @@ __device__ __forceinline__ void sub_check(float cv, float qv, uint32_t j, uint32
     }
 }
 
+// The same predicates with the state's figures handed over as values (fp64 logs keep lambda and the step in doubles beside the
+// header): lam / gam = lambda and the step of state k, lam_end / end_is_final = lambda of state k + 1 and whether the path ends there.
+template <typename T>
+__device__ __forceinline__ void sub_check_v(T cv, T qv, uint32_t j, bool has_scan, T lam, T gam, uint32_t pick, bool in_band, uint32_t jr,
+                                            bool is_last_scan, T lam_end, bool end_is_final, T tol, int tie_guard, DevState* st, bool& fail, bool& tie)
+{
+    const T ac = cv < T(0) ? -cv : cv;
+    if (!has_scan) {
+        if (!(ac <= lam)) {
+            if (!(lam > tol) && !(ac <= tol)) fail = true;
+            else if (ac == ac) atomicMax(reinterpret_cast<unsigned long long*>(&st->c_inf), (unsigned long long)__double_as_longlong((double)ac));
+            else fail = true;
+        }
+        return;
+    }
+    if (!(ac <= lam)) fail = true;
+    const T dl = T(1) - qv, dr = T(1) + qv;
+    const T nl = lam - cv, nr = lam + cv;
+    const T bound = gam * T(1.0001);                              // (only a shortcut: what it cannot rule out is evaluated exactly below)
+    const bool safe_l = dl > T(0) && nl > dl * bound;
+    const bool safe_r = dr > T(0) && nr > dr * bound;
+    if (safe_l && safe_r) return;
+    T m = Lim<T>::max();
+    if (dl != T(0)) {
+        T t = nl / dl;
+        if (tie_guard && t == T(0) && dl > T(0)) t = Lim<T>::tiny();
+        if (t == T(0) && j != jr && in_band) tie = true;
+        if (t > T(0) && t < m) m = t;
+    }
+    if (dr != T(0)) {
+        T t = nr / dr;
+        if (tie_guard && t == T(0) && dr > T(0)) t = Lim<T>::tiny();
+        if (t == T(0) && j != jr && in_band) tie = true;
+        if (t > T(0) && t < m) m = t;
+    }
+    if (better_min(m, j, gam, pick)) {
+        const bool last_step = is_last_scan && end_is_final && !(lam_end > tol);
+        // (the window of "a tie of all columns within rounding" scales with the precision: 1e-5 in fp32, 1e-12 in fp64)
+        const T window = sizeof(T) == 8 ? T(1) - T(1e-12) : T(0.99999);
+        if (!(last_step && m >= gam * window && lam_end + (gam - m) <= tol)) fail = true;
+    }
+}
+
 }  // namespace sship
