@@ -358,6 +358,25 @@ ss_hip_ctx* ss_hip_homotopy_colshard_create_f32(const float* A_local, size_t m, 
 int ss_hip_homotopy_colshard_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_t incy, float tol, uint32_t max_iter,
                                        float* x_local, ptrdiff_t incx, uint32_t* iter_out, double* err_out,
                                        char* err, size_t errlen);
+/* The same in fp64 (round 4).  A double and its column index do not share one 64-bit word, so the two (value, index)
+ * reductions of an iteration travel as a [world][2] table of 64-bit words — every rank fills its own pair, zeros elsewhere —
+ * gathered by ONE exact MAX all-reduce each and reduced by every rank in the same order (largest value, then smallest global
+ * index): still three collectives per iteration (2 x 16 * world bytes, (m + kcap) * 8 bytes), at most 64 ranks.  The host
+ * table therefore needs two entries only.  Sharded and unsharded runs agree bit for bit, like in fp32. */
+typedef struct ss_hip_collectives_f64 {
+    void* user;
+    int (*allreduce_max_u64)(void* user, uint64_t* buf, size_t count);   /* 0 on success */
+    int (*allreduce_sum_f64)(void* user, double* buf, size_t count);
+} ss_hip_collectives_f64;
+ss_hip_ctx* ss_hip_homotopy_colshard_create_f64(const double* A_local, size_t m, size_t n_local,
+                                                ptrdiff_t stride_row, ptrdiff_t stride_col,
+                                                size_t col_lo, size_t n_total, int device,
+                                                const unsigned char* comm_id, int rank, int world,
+                                                const ss_hip_collectives_f64* host_collectives,
+                                                char* err, size_t errlen);
+int ss_hip_homotopy_colshard_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy, double tol, uint32_t max_iter,
+                                       double* x_local, ptrdiff_t incx, uint32_t* iter_out, double* err_out,
+                                       char* err, size_t errlen);
 
 /* profiling != 0: bracket every sweep launch with HIP events on the context's stream. */
 int ss_hip_set_profiling(ss_hip_ctx* ctx, int profiling);

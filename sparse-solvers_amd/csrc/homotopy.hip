@@ -326,7 +326,8 @@ namespace sship {
 int colshard_workspace(ss_hip_ctx* ctx, uint32_t kcap)
 {
     try {
-        ensure_workspace<float>(ctx, 1, kcap);
+        if (ctx->is_f64) ensure_workspace<double>(ctx, 1, kcap);
+        else ensure_workspace<float>(ctx, 1, kcap);
     } catch (const HipFail&) {
         (void)hipGetLastError();
         return SS_HIP_ENOMEM;

@@ -34,18 +34,25 @@ SYMBOLS = [
     "ss_hip_irls_create_f32", "ss_hip_irls_create_f64", "ss_hip_irls_solve_f32", "ss_hip_irls_solve_f64",
     "ss_hip_irls_destroy",
     "ss_hip_comm_unique_id", "ss_hip_homotopy_colshard_create_f32", "ss_hip_homotopy_colshard_solve_f32",
+    "ss_hip_homotopy_colshard_create_f64", "ss_hip_homotopy_colshard_solve_f64",
 ]
 
 
 COMM_ID_BYTES = 128
 _CB_U64 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t)
 _CB_F32 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t)
+_CB_F64 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t)
 
 
 class Collectives(ctypes.Structure):
     """struct ss_hip_collectives (include/ss_hip.h): host-side in-place all-reduces"""
     _fields_ = [("user", ctypes.c_void_p), ("allreduce_max_u64", _CB_U64), ("allreduce_min_u64", _CB_U64),
                 ("allreduce_sum_f32", _CB_F32)]
+
+
+class Collectives64(ctypes.Structure):
+    """struct ss_hip_collectives_f64: fp64 contexts gather their (value, index) reductions by MAX and sum doubles"""
+    _fields_ = [("user", ctypes.c_void_p), ("allreduce_max_u64", _CB_U64), ("allreduce_sum_f64", _CB_F64)]
 
 
 class Stats(ctypes.Structure):
@@ -195,6 +202,12 @@ def lib():
                                                       ctypes.POINTER(Collectives), cp, sz]
     L.ss_hip_homotopy_colshard_solve_f32.restype = ctypes.c_int
     L.ss_hip_homotopy_colshard_solve_f32.argtypes = [vp, vp, pd, ctypes.c_float, u32, vp, pd, ctypes.POINTER(u32),
+                                                     ctypes.POINTER(ctypes.c_double), cp, sz]
+    L.ss_hip_homotopy_colshard_create_f64.restype = vp
+    L.ss_hip_homotopy_colshard_create_f64.argtypes = [vp, sz, sz, pd, pd, sz, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.POINTER(Collectives64), cp, sz]
+    L.ss_hip_homotopy_colshard_solve_f64.restype = ctypes.c_int
+    L.ss_hip_homotopy_colshard_solve_f64.argtypes = [vp, vp, pd, ctypes.c_double, u32, vp, pd, ctypes.POINTER(u32),
                                                      ctypes.POINTER(ctypes.c_double), cp, sz]
     _lib = L
     return L
@@ -497,7 +510,7 @@ def comm_unique_id():
 
 
 class ColumnSharded(Homotopy):
-    """ONE signal over a column-sharded dictionary (ss_hip_homotopy_colshard_*_f32): this rank owns the columns
+    """ONE signal over a column-sharded dictionary (ss_hip_homotopy_colshard_*_f32 / _f64): this rank owns the columns
     [col_lo, col_lo + A_local.shape[1]) of the m x n_total matrix.  Transport: `comm_id` (128 bytes from
     comm_unique_id(), the same on every rank: RCCL) or `allreduce` = a callable (numpy array, op) -> None that
     all-reduces the array IN PLACE over the ranks, op in {"max", "min", "sum"} (host collectives: tests, other
@@ -505,8 +518,8 @@ class ColumnSharded(Homotopy):
 
     def __init__(self, A_local, col_lo, n_total, rank=0, world=1, comm_id=None, allreduce=None, device=0):
         ptr, shape, strides, dt, keep = _describe(A_local)
-        if len(shape) != 2 or dt != np.float32:
-            raise ValueError("A_local must be a 2-D float32 matrix")
+        if len(shape) != 2 or dt not in (np.float32, np.float64):
+            raise ValueError("A_local must be a 2-D float32 or float64 matrix")
         _sync_producers(A_local)
         self.suffix, self.ctype = _suffix(dt)
         self.dtype = dt
@@ -525,8 +538,12 @@ class ColumnSharded(Homotopy):
                         traceback.print_exc()
                         return 1
                 return cb
-            self._cbs = (_CB_U64(wrap("max", np.uint64)), _CB_U64(wrap("min", np.uint64)), _CB_F32(wrap("sum", np.float32)))
-            self._coll = Collectives(None, *self._cbs)
+            if dt == np.float64:
+                self._cbs = (_CB_U64(wrap("max", np.uint64)), _CB_F64(wrap("sum", np.float64)))
+                self._coll = Collectives64(None, *self._cbs)
+            else:
+                self._cbs = (_CB_U64(wrap("max", np.uint64)), _CB_U64(wrap("min", np.uint64)), _CB_F32(wrap("sum", np.float32)))
+                self._coll = Collectives(None, *self._cbs)
             coll_p = ctypes.byref(self._coll)
         idbuf = None
         if comm_id is not None:
@@ -535,7 +552,7 @@ class ColumnSharded(Homotopy):
             idbuf = ctypes.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
         err = ctypes.create_string_buffer(512)
         # (an empty shard has no data pointer worth passing)
-        self._h = lib().ss_hip_homotopy_colshard_create_f32(
+        self._h = getattr(lib(), "ss_hip_homotopy_colshard_create_" + self.suffix)(
             ptr if self.n else None, self.m, self.n, strides[0], strides[1], self.col_lo, self.n_total, device,
             ctypes.cast(idbuf, ctypes.c_void_p) if idbuf is not None else None, int(rank), int(world), coll_p, err, len(err))
         if not self._h:
@@ -545,19 +562,19 @@ class ColumnSharded(Homotopy):
         """-> (x_local, iter, solution_error): the shard's coefficients"""
         yp, yshape, ystr, ydt, keep = _describe(y)
         if ydt != self.dtype or len(yshape) != 1 or yshape[0] != self.m:
-            raise ValueError("y must be a float32 vector of length m = %d" % self.m)
+            raise ValueError("y must be a %s vector of length m = %d" % (np.dtype(self.dtype).name, self.m))
         if tolerance is None:
             tolerance = float(np.finfo(self.dtype).eps) * 10
         if out is None:
             out = np.empty(self.n, dtype=self.dtype)
         xp, xshape, xstr, xdt, keepx = _describe(out)
         if xdt != self.dtype or len(xshape) != 1 or xshape[0] != self.n:
-            raise ValueError("out must be a float32 vector of the shard's width")
+            raise ValueError("out must be a %s vector of the shard's width" % np.dtype(self.dtype).name)
         it = ctypes.c_uint32(0)
         e = ctypes.c_double(0.0)
         err = ctypes.create_string_buffer(512)
         _sync_producers(y, out)
-        rc = lib().ss_hip_homotopy_colshard_solve_f32(self._h, yp, ystr[0], ctypes.c_float(tolerance), int(max_iterations),
+        rc = getattr(lib(), "ss_hip_homotopy_colshard_solve_" + self.suffix)(self._h, yp, ystr[0], self.ctype(tolerance), int(max_iterations),
                                                       xp if self.n else None, xstr[0] if self.n else 1, ctypes.byref(it), ctypes.byref(e),
                                                       err, len(err))
         self._check(rc, err)

@@ -225,7 +225,7 @@ def test_column_sharded_over_rccl_one_rank(tmp_path):
 
 # ---------------------------------------------------------------- the NATIVE column-sharded path (csrc/colshard.hip)
 
-def _native_problem(which):
+def _native_problem(which, dtype=np.float32):
     rng = np.random.default_rng(900 + which)
     if which == 0:
         m, n, k, noise = 256, 4096, 10, 0.0
@@ -233,15 +233,15 @@ def _native_problem(which):
         m, n, k, noise = 64, 700, 12, 0.02              # short, noisy: columns leave the support again
     else:
         m, n, k, noise = 300, 1501, 20, 0.0              # widths off every padding
-    A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(np.float32)
+    A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(dtype)
     x0 = np.zeros(n)
     x0[rng.choice(n, k, replace=False)] = 1 + np.abs(rng.standard_normal(k))
-    y = (A.astype(np.float64) @ x0 + noise * rng.standard_normal(m)).astype(np.float32)
+    y = (A.astype(np.float64) @ x0 + noise * rng.standard_normal(m)).astype(dtype)
     return A, y, 1e-3, 4 * k + 20
 
 
-def _native_rank(rank, world, port, tmpdir, which, empty_last):
-    """one rank: its shard through ss_hip_homotopy_colshard_*_f32 with HOST collectives over gloo (two RCCL ranks cannot
+def _native_rank(rank, world, port, tmpdir, which, empty_last, dtype=np.float32):
+    """one rank: its shard through ss_hip_homotopy_colshard_*_f32 / _f64 with HOST collectives over gloo (two RCCL ranks cannot
     share one GPU; the device-side RCCL form is the one-rank test below) — same kernels, same host loop"""
     import torch
     import torch.distributed as dist
@@ -249,15 +249,15 @@ def _native_rank(rank, world, port, tmpdir, which, empty_last):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    A, y, tol, mi = _native_problem(which)
+    A, y, tol, mi = _native_problem(which, dtype)
     lo, hi = _bounds(A.shape[1], world, 3 if empty_last else 0)[rank]
 
     def allreduce(buf, op):
-        # (the packed words keep their top bit clear: int64 orders them like uint64)
+        # (the packed words — fp64: the gathered value bits and index keys — keep their top bit clear: int64 orders them like uint64)
         t = torch.from_numpy(buf.view(np.int64) if buf.dtype == np.uint64 else buf)
         dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
 
-    shard = torch.from_numpy(np.ascontiguousarray(A[:, lo:hi])).to("cuda:0") if hi > lo else np.zeros((A.shape[0], 0), np.float32)
+    shard = torch.from_numpy(np.ascontiguousarray(A[:, lo:hi])).to("cuda:0") if hi > lo else np.zeros((A.shape[0], 0), dtype)
     with sship.ColumnSharded(shard, lo, A.shape[1], rank=rank, world=world, allreduce=allreduce) as h:
         h.set_option("trace", 1)
         x, it, err = h.solve(torch.from_numpy(y).to("cuda:0"), tol, mi)
@@ -268,9 +268,11 @@ def _native_rank(rank, world, port, tmpdir, which, empty_last):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("cfg", [(2, 0, False), (3, 1, False), (3, 2, True)])
-def test_native_column_sharded_host_collectives(tmp_path, cfg):
-    """ss_hip_homotopy_colshard_{create,solve}_f32 with the dictionary's columns split over 2 / 3 ranks that share the
+def test_native_column_sharded_host_collectives(tmp_path, cfg, dtype):
+    """ss_hip_homotopy_colshard_{create,solve}_f32 / _f64 (fp64: the two (value, index) reductions of an iteration travel as
+    gathered [world][2] tables, not packed words) with the dictionary's columns split over 2 / 3 ranks that share the
     one MI355X (collectives: the host table, over gloo): every rank must report the same path, the assembled solution
     must equal — bit for bit — what ONE rank computes on the whole dictionary through the same entry point, and both
     must be the oracle's path (column, insert / remove at every breakpoint) and coefficients to fp32 tolerance"""
@@ -278,14 +280,14 @@ def test_native_column_sharded_host_collectives(tmp_path, cfg):
     import sship
     import torch.multiprocessing as mp
     world, which, empty_last = cfg
-    port = 34100 + (os.getpid() % 1000) + 10 * which + world
-    mp.spawn(_native_rank, args=(world, port, str(tmp_path), which, empty_last), nprocs=world, join=True)
-    A, y, tol, mi = _native_problem(which)
+    port = 34100 + (os.getpid() % 1000) + 10 * which + world + (40 if dtype == np.float64 else 0)
+    mp.spawn(_native_rank, args=(world, port, str(tmp_path), which, empty_last, dtype), nprocs=world, join=True)
+    A, y, tol, mi = _native_problem(which, dtype)
     with sship.ColumnSharded(A, 0, A.shape[1]) as h:            # world = 1: no transport needed
         h.set_option("trace", 1)
         x1, it1, e1 = h.solve(y, tol, mi)
         t1 = h.trace()
-    x = np.zeros(A.shape[1], np.float32)
+    x = np.zeros(A.shape[1], dtype)
     for r in range(world):
         p = np.load(tmp_path / ("rank%d.npz" % r))
         x[int(p["lo"]):int(p["hi"])] = p["x"]
@@ -297,7 +299,8 @@ def test_native_column_sharded_host_collectives(tmp_path, cfg):
     assert it1 == ito
     assert np.array_equal(t1["idx"][:-1], tro["idx"][:-1]) and np.array_equal(t1["added"][:-1], tro["added"][:-1])
     assert np.array_equal(np.abs(x1) > 1e-4, np.abs(xo) > 1e-4)
-    assert np.abs(x1 - xo).max() <= (1e-5 if which != 1 else 2e-3) * np.abs(xo).max()
+    rel = (1e-5 if which != 1 else 2e-3) if dtype == np.float32 else 1e-10
+    assert np.abs(x1 - xo).max() <= rel * np.abs(xo).max()
     # and the single-GPU residual form (engine 0) walks the same path
     with sship.Homotopy(A) as h0:
         h0.set_option("engine", 0)
@@ -362,9 +365,9 @@ def test_native_column_sharded_one_rank_fails_everyone_leaves(tmp_path, bad_rank
     assert outs[0]["second_iter"] == outs[1]["second_iter"] > 0
 
 
-def _native_rccl_rank(rank, world, port, tmpdir):
+def _native_rccl_rank(rank, world, port, tmpdir, dtype=np.float32):
     import sship
-    A, y, tol, mi = _native_problem(0)
+    A, y, tol, mi = _native_problem(0, dtype)
     cid = sship.comm_unique_id()                               # ncclGetUniqueId through the library
     with sship.ColumnSharded(A, 0, A.shape[1], rank=0, world=1, comm_id=cid) as h:   # ncclCommInitRank inside
         h.set_option("trace", 1)
@@ -374,7 +377,8 @@ def _native_rccl_rank(rank, world, port, tmpdir):
 
 
 @pytest.mark.gpu
-def test_native_column_sharded_over_rccl_one_rank(tmp_path):
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_native_column_sharded_over_rccl_one_rank(tmp_path, dtype):
     """the device-side transport: an RCCL communicator built from a ncclUniqueId inside libss_hip.so (librccl opened at
     run time), the three all-reduces of every iteration enqueued on the context's stream.  One rank — a box with one
     GPU cannot host two — so this walks the RCCL code path, not an exchange (that is the host-collective test above);
@@ -382,8 +386,8 @@ def test_native_column_sharded_over_rccl_one_rank(tmp_path):
     import sship
     import torch.multiprocessing as mp
     port = 35100 + (os.getpid() % 1000)
-    mp.spawn(_native_rccl_rank, args=(1, port, str(tmp_path)), nprocs=1, join=True)
-    A, y, tol, mi = _native_problem(0)
+    mp.spawn(_native_rccl_rank, args=(1, port, str(tmp_path), dtype), nprocs=1, join=True)
+    A, y, tol, mi = _native_problem(0, dtype)
     with sship.ColumnSharded(A, 0, A.shape[1]) as h:
         h.set_option("trace", 1)
         x1, it1, e1 = h.solve(y, tol, mi)
