@@ -1256,18 +1256,27 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                 yid = torch.from_numpy(yi).to(dev)
                 hi_ = sship.Irls(Aid, device=local_rank)                      # (first construction: allocations)
                 hi_.close()
-                torch.cuda.synchronize()
-                tq = time.perf_counter()
-                hi_ = sship.Irls(Aid, device=local_rank)
-                torch.cuda.synchronize()
-                dq = time.perf_counter() - tq
+                # (best of three: a single construction / solve now and then meets a slow hipMalloc or a clock ramp on a fresh box —
+                # 75 ms and 63 ms were seen once each where every other run gave 31 and 7.5)
+                dq = float("inf")
+                hi_ = None
+                for _rep in range(3):
+                    if hi_ is not None:
+                        hi_.close()
+                    torch.cuda.synchronize()
+                    tq = time.perf_counter()
+                    hi_ = sship.Irls(Aid, device=local_rank)
+                    torch.cuda.synchronize()
+                    dq = min(dq, time.perf_counter() - tq)
                 xo_ = torch.zeros(ni, device=dev, dtype=torch.float32)
                 hi_.solve(yid, 1e-3, 8, out=xo_)
-                torch.cuda.synchronize()
-                ts_ = time.perf_counter()
-                _, iti, epsi, spdi = hi_.solve(yid, 1e-3, 8, out=xo_)
-                torch.cuda.synchronize()
-                ds_ = time.perf_counter() - ts_
+                ds_ = float("inf")
+                for _rep in range(3):
+                    torch.cuda.synchronize()
+                    ts_ = time.perf_counter()
+                    _, iti, epsi, spdi = hi_.solve(yid, 1e-3, 8, out=xo_)
+                    torch.cuda.synchronize()
+                    ds_ = min(ds_, time.perf_counter() - ts_)
                 hi_.close()
                 r = {"workload": "IRLS fp32, A %d x %d Gaussian / sqrt(m), 8 non-zeros, tolerance 1e-3, max_iterations 8" % (mi, ni),
                      "construct_ms_householder_qr": dq * 1e3, "solve_ms": ds_ * 1e3, "iterations": int(iti),

@@ -174,12 +174,15 @@ void k_pack_records(const T* __restrict__ x, const uint32_t* __restrict__ gam2, 
     const size_t s = blockIdx.x;
     x += s * L.n_pad;
     st += s;
-    const uint32_t cur = st->cur;
+    const uint32_t cur = st->cur & 1u;
     const uint32_t* list = (use_touched ? touched2 : gam2) + s * 2 * (size_t)L.kcap + (size_t)cur * L.kcap;
     // (a solve that ended on an emptied support keeps the one column in its list: its x is handed back)
     uint32_t cnt = use_touched ? st->ntouched : st->K;
     if (cnt == 0u) cnt = 1u;
     if (cnt > L.kcap) cnt = L.kcap;
+    // A slot that did not report (a form declined it: the one-workgroup kernels then leave K set and the lists unwritten) packs an
+    // EMPTY record — whoever solves it again overwrites the record; its lists must not be walked (stale words as column indices)
+    if (st->status != 0u) cnt = 0u;
     unsigned char* r = rec + s * rec_bytes;
     uint32_t* idx = reinterpret_cast<uint32_t*>(r + 16);
     T* val = reinterpret_cast<T*>(r + 16 + (size_t)kmax * 4);
@@ -190,7 +193,7 @@ void k_pack_records(const T* __restrict__ x, const uint32_t* __restrict__ gam2, 
         const uint32_t j = j0 + tid;
         uint32_t col = 0;
         T v = T(0);
-        if (j < cnt) { col = list[j]; v = x[col]; }
+        if (j < cnt) { col = list[j]; v = col < L.n_pad ? x[col] : T(0); }
         const bool nz = j < cnt && v != T(0);
         const uint64_t bal = __ballot(nz);
         __syncthreads();
@@ -318,6 +321,11 @@ void ensure_workspace(ss_hip_ctx* ctx, uint32_t nslots, uint32_t kcap)
     HIPCHK(hipMemsetAsync(w->cq, 0, 2 * (size_t)b_pad * np * s, ctx->stream));
     HIPCHK(hipMemsetAsync(w->st, 0, B * sizeof(DevState), ctx->stream));
     HIPCHK(hipMemsetAsync(w->ndone, 0, 64, ctx->stream));
+    // the support / touched lists start as "no column" (0xffffffff), not as whatever the allocation held: a reader that walks a list
+    // nobody wrote (a slot a form declined) then meets an index every consumer bounds-checks — the same on every run, not a stale
+    // word that happens to be a valid column in one process and an unmapped address in the next
+    HIPCHK(hipMemsetAsync(w->gam, 0xff, B * 2 * K * sizeof(uint32_t), ctx->stream));
+    HIPCHK(hipMemsetAsync(w->touched, 0xff, B * 2 * K * sizeof(uint32_t), ctx->stream));
 }
 
 }  // namespace
@@ -881,29 +889,438 @@ inline void count_reasons(ss_hip_ctx* ctx, uint32_t r, bool tie)
     if (tie || (r & kReasonTie)) S.why_tie += 1;
 }
 
+// ---- the host side of a solve in the launch-chain engines ---------------------------------------------------------------------
+// The device decides termination (k_scansel / k_la_iter raise DevState::done and mirror it, with the round reached, into pinned host
+// memory).  The host keeps at most `lookahead` launches queued beyond the device's position and stops enqueueing as soon as it
+// sees `done`; launches already queued behind it are no-ops.
+struct PumpState {
+    bool solo = false;            // speculative launches still in use (the device may hand over to the resident form)
+    bool solo_started = false;
+    bool early = false;           // early form: a solo group (and the resident launch behind it) is queued already
+    uint32_t early_lds_cols = 0;
+    size_t nprof = 0;             // profiling events used so far
+    bool enqueued = false;        // the pump queued work behind a speculative epilogue
+};
+
+// Fused lookahead engine: every launch of k_la_iter performs the next iteration, or nothing while the device waits for a Gram
+// column (host_flags[2] counts those waits).  Returns false if the loop made no progress (internal error).
+template <typename T>
+bool pump_fused(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter, bool la, bool la_omp, bool prof, PumpState& ps)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
+    volatile uint32_t* hf = ctx->host_flags;
+    bool& solo = ps.solo;
+    const bool solo_started = ps.solo_started, early = ps.early;
+    const uint32_t early_lds_cols = ps.early_lds_cols;
+    size_t& nprof = ps.nprof;
+    bool& pump_enqueued = ps.enqueued;
+    // Fused lookahead engine: every launch of k_la_iter performs the next iteration, or
+    // nothing while the device waits for a Gram column (hf[2] counts those waits).  The
+    // host keeps L launches queued ahead and answers each wait with one fetch.
+    uint64_t enq = early ? (early_lds_cols != 0 ? 2u : 1u) : 0u;   // (early form: a solo group and the resident launch behind it are queued)
+    uint32_t handled = 0, timed_fetches = 0;
+    // resident kernel: LDS tier (support columns it can hold); 0 = one launch per iteration
+    uint32_t lds_cols = 0;
+    const uint32_t kcap_ws = ws.dims.kcap;       // what the device checks K against (>= this solve's kcap)
+    if (la && ctx->la_fused >= 2 && sizeof(T) == 4) {
+        lds_cols = std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsSmall);
+        if (!la_persist_usable(ctx, lds_cols)) lds_cols = 0;
+    }
+    const uint64_t max_launch = 4 * ((uint64_t)max_iter + 2) + 64;
+    bool stuck = false;
+    for (;;) {
+        uint32_t spins = 0;
+        // (a solo group runs until the host has to act — fetch, hand-over, end — so one group in
+        // flight is enough: every further one is three launches that find nothing to do; after
+        // the hand-over, near the end of the path, two resident launches)
+        const uint32_t depth = solo ? 1u : (solo_started ? std::min<uint32_t>(L, 2u) : L);
+        while (hf[1] == 0 && hf[2] == handled && enq >= (uint64_t)hf[0] + depth) {
+            if ((++spins & 0x3ffu) == 0) {
+                const hipError_t qs = hipStreamQuery(st);
+                if (qs == hipSuccess) break;
+                if (qs != hipErrorNotReady) throw HipFail{ qs, "hipStreamQuery(solve loop)" };
+            }
+            std::this_thread::yield();
+        }
+        if (hf[1] != 0) break;
+        pump_enqueued = true;
+        if (hf[2] != handled) {
+            const bool timed_la = prof && (timed_fetches++ % (uint32_t)std::max(1, ctx->profile_every) == 0);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (timed_la) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
+            if (la_omp) Lookahead<T>::fetch_omp(ctx, ws, tol, e0, e1);
+            else Lookahead<T>::fetch(ctx, ws, tol, e0, e1, solo, handled);
+            if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
+            ++handled;
+        }
+        if (lds_cols != 0 && hf[3] > lds_cols) {
+            // the support outgrew the tier: take the large one, or go on one launch per iteration
+            const uint32_t big = std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsLarge);
+            lds_cols = (hf[3] <= big && big > lds_cols && la_persist_usable(ctx, big)) ? big : 0u;
+        }
+        if (enq >= max_launch) { stuck = true; break; }
+        if (solo && hf[4] != 0) solo = false;   // the device handed over to the resident / launch-per-iteration form
+        if (la_omp) HIPCHK(launch_la_omp<T>(ctx, ws, tol, max_iter));
+        else Lookahead<T>::iterate(ctx, ws, tol, max_iter, lds_cols, solo);
+        ++enq;
+        if (solo && lds_cols != 0) {
+            // the resident form queued right behind the speculative group: a no-op unless that group hands
+            // over (the last step of a path), which then costs no trip through the host
+            HIPCHK(launch_persist(ctx, ws, tol, max_iter, lds_cols, true));
+            ++enq;
+        }
+    }
+    if (stuck) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (hf[1] == 0) return false;
+    }
+    return true;
+}
+
+// One launch chain per round (engine 0: the fused sweep + tail; the lookahead engine without in-kernel grid synchronisation; the
+// reference-order engine; OMP in residual form).
+template <typename T>
+void pump_rounds(ss_hip_ctx* ctx, Workspace<T>& ws, T tol, uint32_t max_iter, bool la, bool ro, bool omp, uint32_t ro_parts,
+                 size_t rhs_stride, bool prof, PumpState& ps)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
+    volatile uint32_t* hf = ctx->host_flags;
+    const uint64_t last_round = (uint64_t)max_iter + 1;
+    size_t& nprof = ps.nprof;
+    for (uint64_t round = 1; round <= last_round; ++round) {
+        if (round > L) {
+            const uint32_t need = (uint32_t)(round - L);
+            uint32_t spins = 0;
+            while (hf[1] == 0 && hf[0] < need) {
+                if ((++spins & 0x3ffu) == 0) {
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q == hipSuccess) break;               // queue drained
+                    if (q != hipErrorNotReady) throw HipFail{ q, "hipStreamQuery(solve loop)" };
+                }
+                std::this_thread::yield();
+            }
+            if (hf[1] != 0) break;
+        }
+        if (la) {
+            // the launch is a no-op unless a column without cached Gram column enters: time
+            // every `profile_every`-th launch and keep the ones that did work (see below)
+            const bool timed_la = prof && (round % (uint64_t)std::max(1, ctx->profile_every) == 0);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (timed_la) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
+            Lookahead<T>::round(ctx, ws, (uint32_t)round, tol, max_iter, e0, e1);
+            if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
+            continue;
+        }
+        if (ro) {
+            // homotopy-cpu.cpp:236-272 with ONE pass over A per iteration: r = y - A x and p = A d (the direction built
+            // from the signs of c - gamma q), the fused sweep [c, q] = A^T [r, p], lambda + the while-test + the check of
+            // those signs against the re-computed c (a mismatch rebuilds the direction; p and q are then formed again),
+            // the scan + toggle + x update, the inverse update and the next direction
+            HIPCHK(launch_ro_round<T>(ctx, ws, 1u, (uint32_t)round, ro_parts, tol, max_iter));
+            continue;
+        }
+        if (omp) {
+            // orthogonal matching pursuit round: c = A^T r (one right-hand side), pick,
+            // bordered inverse + least squares on the support, new residual
+            uint32_t nbo = 0;
+            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nbo, ws.st));
+            HIPCHK(launch_omp_tail<T>(ctx, ws, 1, (uint32_t)round, nbo, tol, max_iter));
+            continue;
+        }
+        uint32_t nb = 0;
+        // HIP events cost tens of microseconds of stream time each: time every
+        // `profile_every`-th fused sweep only (option), still inside the solve
+        const bool timed = prof && (round % (uint64_t)std::max(1, ctx->profile_every) == 0);
+        if (timed) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
+        HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 2, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, &nb, ws.st));
+        if (timed) {
+            HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st));
+            ctx->prof_kind.push_back((int)round + 16);     // >= 16: fused sweep of round (kind-16)
+            ++nprof;
+        }
+        HIPCHK(launch_iteration_tail<T>(ctx, ws, 1, (uint32_t)round, nb, tol, max_iter));
+    }
+}
+
+// The HIP events of a profiled solve into the context's statistics (prof_kind says what each pair bracketed)
+template <typename T>
+void account_profile(ss_hip_ctx* ctx, size_t nprof, uint32_t scr_launches, const DevState& hs)
+{
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
+    ctx->stats.solve_ms += ms;
+    // only sweeps that did real work: the initial one and rounds 1..done_round
+    for (size_t i = 0; i < nprof; ++i) {
+        HIPCHK(hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
+        if (ctx->prof_kind[i] == 1) {
+            ctx->stats.sweep1_launches += 1;
+            ctx->stats.sweep1_ms += ms;
+        } else if (ctx->prof_kind[i] == 6) {
+            // the screening pass: fp16 copy of A + the residual block (re-read from L2 by every workgroup: not counted) + norms
+            ctx->stats.screen_launches += scr_launches;
+            ctx->stats.screen_ms += ms;
+            ctx->stats.screen_bytes += (uint64_t)scr_launches * ((uint64_t)ctx->ldm * ctx->n_pad * 2ull + 96ull * ctx->ldm * 2ull + (uint64_t)ctx->n_pad * 4ull);
+        } else if (ctx->prof_kind[i] == 8) {
+            ctx->stats.res_solve_launches += 1;
+            ctx->stats.res_solve_ms += ms;
+        } else if (ctx->prof_kind[i] == 7) {
+            ctx->stats.first16_launches += 1;
+            ctx->stats.first16_ms += ms;
+            ctx->stats.first16_bytes += (uint64_t)ctx->ldm * ctx->n_pad * 2ull + (uint64_t)ctx->ldm * sizeof(T) + (uint64_t)ctx->n_pad * 4ull;
+        } else if (ctx->prof_kind[i] == 4) {
+            if (ms > 0.02f) {                          // (a launch of a solve that ended at the first pick is a no-op)
+                ctx->stats.sweep64_launches += 1;
+                ctx->stats.sweep64_ms += ms;
+            }
+        } else if (ctx->prof_kind[i] == 3 || ctx->prof_kind[i] == 5) {
+            // lookahead sweep: a launch that found nothing to do returns in microseconds.  Bytes per EVENT: a
+            // plain pass (3) covers all n columns, the early form's main launch (5) its share of them
+            const uint64_t sz = sizeof(T);
+            const uint64_t cols = ctx->prof_kind[i] == 5 ? ctx->stats.sweep32_timed_cols : (uint64_t)ctx->n;
+            const uint64_t bytes = (uint64_t)ctx->m * cols * sz + 32ull * ctx->m * sz + 32ull * cols * sz;
+            if ((double)bytes / (ms * 1e-3) < 50e12) {   // < 50 TB/s: it streamed A
+                ctx->stats.sweep32_launches += 1;
+                ctx->stats.sweep32_ms += ms;
+                ctx->stats.sweep32_bytes_timed += bytes;
+            }
+        } else if ((uint32_t)(ctx->prof_kind[i] - 16) <= hs.done_round) {
+            ctx->stats.sweep_launches += 1;
+            ctx->stats.sweep_ms += ms;
+        }
+    }
+}
+
+// developer aid (SS_HIP_SOLO_DEBUG = a path): the log and the verification partials of the last speculative launch
+template <typename T>
+void dump_solo_debug(Workspace<T>& ws, const DevState& hs, const char* path)
+{
+    // developer aid: the log and the verification partials of the last solo launch
+    const size_t lw = (size_t)kSoloHeaderWords + (size_t)kSoloLogCap * kSoloEntryWords;
+    std::vector<uint32_t> lg(lw), vm((size_t)kSoloLogCap * ws.nvwg);
+    std::vector<uint64_t> vn((size_t)kSoloLogCap * ws.nvwg);
+    HIPCHK(hipMemcpy(lg.data(), ws.solo_log, lw * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vm.data(), ws.v_max, vm.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vn.data(), ws.v_min, vn.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (FILE* fp = std::fopen(path, "wb")) {
+        const uint32_t hdr[4] = { hs.solo_nlog, ws.nvwg, kSoloEntryWords, kSoloHeaderWords };
+        std::fwrite(hdr, 4, 4, fp);
+        std::fwrite(lg.data(), 4, lg.size(), fp);
+        std::fwrite(vm.data(), 4, vm.size(), fp);
+        std::fwrite(vn.data(), 8, vn.size(), fp);
+        std::fclose(fp);
+    }
+}
+
+// ---- which way a single-signal solve goes ---------------------------------------------------------------------------------
+// A solve is ONE attempt in one form (solve_once); what the attempt reports decides whether another form takes the signal
+// (the ladder in solve_once's verdict section).  A Route is everything a later attempt is told about the earlier ones.
+struct Route {
+    bool omp = false;              // orthogonal matching pursuit (ss_hip_omp_solve_*)
+    bool force_residual = false;   // the Gram form's tolerance guard tripped: residual form (engine 0) for this signal
+    bool no_solo = false;          // no speculative launches (callers that run many contexts side by side)
+    bool force_ro = false;         // a step-length scan met an exact tie: the reference-order engine (reforder.hip) arbitrates
+    bool no_sub = false;           // the subset / screened forms declined the signal: the default engine
+    bool no_res = false;           // fp64: the resident tier declined it: the sub-dictionary tier
+    bool plain = false;            // the early form asked for the plain speculative form (sticky for the rest of this solve)
+    Route after() const { Route r; r.plain = plain; return r; }     // a fresh route that keeps what is sticky
+};
+
+// The forms an attempt can take (at most one of sub1 / scr1 / scr64 / scr64r; la / la_omp / ro say which engine stands behind)
+struct Forms {
+    bool y_direct = false;   // the lookahead engine reads the signal from the caller's device buffer (no copy command)
+    bool ro = false;         // reference-order engine (option engine = 3, and the arbiter of tie stalls)
+    bool la = false;         // lookahead (Gram-form) engine: the default
+    bool la_omp = false;     // OMP in Gram form (k_la_omp)
+    bool sub1 = false;       // G = A^T A at hand: the subset form of the batches for ONE signal (subbatch.hip)
+    bool scr1 = false;       // fp32 screened form (screen.hip + resident.hip): the default on large dictionaries
+    bool scr64 = false;      // fp64 screened form, sub-dictionary tier (2048 columns, a context of its own)
+    bool scr64r = false;     // fp64 screened form, resident tier (256 columns, one workgroup)
+};
+
+// What a context's options, its size and the route so far allow.  (No side effects: the step-aside counters are applied by the
+// caller, so that asking twice gives the same answer.)
+template <typename T>
+Forms choose_forms(ss_hip_ctx* ctx, const Route& route, const T* y, void* rec_out)
+{
+    Forms f;
+    const bool omp = route.omp;
+    f.y_direct = !omp && !route.force_ro && ctx->engine != 3 && Lookahead<T>::supported && ctx->engine >= 1 && !route.force_residual &&
+                 is_device_pointer(y);
+    f.ro = !omp && (route.force_ro || ctx->engine == 3);
+    f.la = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !route.force_residual && !f.ro;
+    f.la_omp = omp && Lookahead<T>::supported && ctx->engine >= 1 && !route.force_residual && ctx->la_fused >= 1;
+    // With G = A^T A at hand (a large batch has run on the context, or option gram_full_after) a single signal takes the
+    // subset form of the batches (subbatch.hip): A^T y, one workgroup on 448 columns, the check over all columns — no
+    // pass over A beyond A^T y.  What the form does not vouch for is solved again the usual way (no_sub).
+    // (where the screened form below applies it is the faster of the two since its first pass reads the fp16 copy — 0.71 ms against
+    // 1.0 at configs[1] — and takes the signal; option screen_single = 0 leaves it to this form)
+    f.sub1 = f.la && sizeof(T) == 4 && !route.no_sub && ctx->batch_subset && ctx->gram_single && ctx->gram_full != nullptr && sub_form_usable(ctx);
+    // Without G: the screened form (screen.hip) — the same subset solve on the subset's own Gram matrix (formed from A), every
+    // state of its path then screened against all columns by ONE pass over a half-precision copy of A with a rigorous error
+    // bound, instead of the default engine's two fp32 passes.  It stands in for the default speculative engine only
+    // (la_fused = 3 with the early form: contexts whose options ask for another engine get that engine).
+    f.scr1 = f.la && sizeof(T) == 4 && !route.no_sub && ctx->la_fused >= 3 && ctx->early_solo && !ctx->early_probe &&
+             ctx->solo_subset == 256 && (!f.sub1 || screen_first16_usable(ctx)) && screen_form_usable(ctx);
+    if (f.scr1) f.sub1 = false;
+    // fp64: the same certificate around the fp64 engine — the path is solved by a context of its own on the 2048 columns with
+    // the largest |c0| (passes and iterations on 1.6 % of the dictionary), its logged states are screened against all columns
+    // (not with a trace or compact records asked for: the sub-context's lists are over ITS columns)
+    // (OMP too: the sub-context runs k_la_omp, the certificate is the same — nothing outside the sub-dictionary reaches the pick's |c|)
+    f.scr64 = (f.la || f.la_omp) && sizeof(T) == 8 && !route.no_sub && !ctx->tracing && rec_out == nullptr && ctx->la_fused >= 1 && screen64_usable(ctx);
+    // ... and before that tier, the RESIDENT tier (resident.hip): the path on the 256 best-ranked columns in ONE workgroup with the
+    // Gram values in registers — no sub-context, no host round trip, everything queued in one go; its lists are over the
+    // dictionary's own columns, so a trace and compact records work too.  What it does not report goes to the tier above.
+    f.scr64r = (f.la || f.la_omp) && sizeof(T) == 8 && !route.no_sub && !route.no_res && ctx->screen_resident && ctx->la_fused >= 1 &&
+               !(omp && ctx->tracing) && screen64_usable(ctx) && screen64_resident_usable(ctx);
+    return f;
+}
+
+// ---- what an attempt reported: the ladder ---------------------------------------------------------------------------------------
+// Reads the device state of a finished attempt and decides: report it (*report), fail (the returned status), or hand the signal to
+// another form (*again, *next).  Rungs, in the order they are tried:
+//   exact tie in a step-length scan            -> reference-order engine (the arbiter; option tie_rerun)
+//   fp64 resident tier declined                -> sub-dictionary tier                      (no_res)
+//   screened form (fp32 / fp64 tier 2) declined -> default engine                           (no_sub)
+//   subset form on G declined                  -> default engine                           (no_sub)
+//   early form used too many unfetched columns -> plain speculative form                   (plain)
+//   Gram-form tolerance guard                  -> residual form                            (force_residual)
+//   a resident grid's wait expired             -> launch per iteration, then no in-kernel grid synchronisation (context options)
+// Every rung also keeps the statistics (ss_hip_stats) and the step-aside counters of its form.
+template <typename T>
+int attempt_verdict(ss_hip_ctx* ctx, const Route& route, const Forms& f, const DevState& hs, Route* next, bool* again, bool* report,
+                    char* err, size_t errlen)
+{
+    const bool omp = route.omp, force_residual = route.force_residual, no_solo = route.no_solo;
+    const bool ro = f.ro, la = f.la, la_omp = f.la_omp, sub1 = f.sub1, scr1 = f.scr1, scr64 = f.scr64, scr64r = f.scr64r;
+    auto retry = [&](const Route& r) { *next = r; *again = true; return SS_HIP_OK; };
+
+    if (!hs.done) {
+        set_err(err, errlen, "solve: internal error, device loop did not terminate");
+        return SS_HIP_ERUNTIME;
+    }
+    // (a tie met by the screened form's subset solve is a tie of the SUBSET's view — on a subset that cannot be certified it may not
+    // exist over all columns: such a signal goes to the default engine below, which meets the tie itself if it is real)
+    const bool scr_tie = (scr1 || scr64r) && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun);
+    if (!ro && !omp && !scr_tie && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun)) {
+        // a step-length scan met an exact tie (DevState::tie_stall): whether the strict t > 0 of the reference then
+        // derails the path is decided by rounding — the reference-order engine is the arbiter
+        ctx->stats.tie_reruns += 1;
+        Route r = route.after(); r.no_solo = no_solo; r.force_ro = true;
+        return retry(r);
+    }
+    if (sub1 || scr1 || scr64) {
+        // (a context whose signals the form hands back more often than not stops trying for a while)
+        ctx->sub_seen += 1;
+        if (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie) ctx->sub_failed += 1;
+        if (ctx->sub_seen >= 8) {
+            if (2 * ctx->sub_failed > ctx->sub_seen) ctx->sub_off_solves = 64;
+            ctx->sub_seen = 0;
+            ctx->sub_failed = 0;
+        }
+    }
+    if (scr64r) {
+        const bool back = hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie;
+        ctx->res_seen += 1;
+        if (back) ctx->res_failed += 1;
+        if (ctx->res_seen >= 8) {
+            if (2 * ctx->res_failed > ctx->res_seen) ctx->res_off_solves = 64;
+            ctx->res_seen = 0;
+            ctx->res_failed = 0;
+        }
+        if (back) {
+            // the resident tier does not report this signal: the sub-dictionary tier (2048 columns) takes it next
+            ctx->stats.screen_tier2 += 1;
+            count_reasons(ctx, hs.sub_reason, scr_tie);
+            if (std::getenv("SS_HIP_SUB_DEBUG"))
+                std::fprintf(stderr, "[screened form, fp64 resident tier] status %u reason 0x%x after %u iterations, %u states logged, K = %u, lambda %g\n",
+                             hs.status, hs.sub_reason, hs.iter, hs.solo_nlog, hs.K, hs.c_inf);
+            Route r = route; r.no_res = true;
+            return retry(r);
+        }
+        if (hs.status == 0) { ctx->stats.screen_signals += 1; ctx->stats.screen_resident += 1; }
+    }
+    if ((scr1 || scr64) && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie)) {
+        ctx->stats.screen_redone += 1;
+        count_reasons(ctx, hs.sub_reason, scr_tie);
+        if (std::getenv("SS_HIP_SUB_DEBUG")) {
+            std::fprintf(stderr, "[screened form] status %u reason 0x%x after %u iterations, %u states logged, K = %u, lambda %g, lambda0 %g\n",
+                         hs.status, hs.sub_reason, hs.iter, hs.solo_nlog, hs.K, hs.c_inf, (double)hs.lambda0);
+            if (scr1) screen_debug_recheck(ctx);
+        }
+        Route r = route; r.no_sub = true;
+        return retry(r);
+    }
+    if ((scr1 || scr64) && hs.status == 0) ctx->stats.screen_signals += 1;
+    if (scr1 && hs.status == 0 && ctx->screen_resident && res_solve_usable<float>()) ctx->stats.screen_resident += 1;
+    if ((scr1 || scr64r) && hs.status == 0 && (hs.sub_reason & kReasonRechecked)) ctx->stats.screen_recheck += 1;
+    if (scr1 && ctx->sub_dbg != nullptr) {
+        unsigned long long tp[9];
+        HIPCHK(hipMemcpy(tp, ctx->sub_dbg, sizeof(tp), hipMemcpyDeviceToHost));
+        const double r = tp[8] ? (double)tp[8] : 1.0;
+        std::fprintf(stderr, "[k_sub_solve, cycles per round over %llu rounds] chain %.0f  max|c| %.0f  log+scan %.0f  arg-min %.0f  hand-shake+x %.0f  u1/u2 %.0f  "
+                             "inverse+signs %.0f  direction %.0f\n", tp[8], tp[0] / r, tp[1] / r, tp[2] / r, tp[3] / r, tp[4] / r, tp[5] / r, tp[6] / r, tp[7] / r);
+    }
+    if (sub1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
+        ctx->stats.subset_redone += 1;
+        count_reasons(ctx, hs.sub_reason, false);
+        Route r = route; r.no_sub = true;
+        return retry(r);
+    }
+    if (sub1 && hs.status == 0) ctx->stats.subset_signals += 1;
+    if (la && hs.status == kStatusRetryPlain) {
+        // the early form's first launch used too many columns beyond the prefetched ones: plain form for this solve
+        // (solve_impl switches option early_solo off until this solve has returned)
+        Route r = route.after(); r.omp = omp; r.force_residual = force_residual; r.no_solo = no_solo; r.plain = true;
+        return retry(r);
+    }
+    if ((la || la_omp) && hs.status == kStatusRetryResidual) {
+        // tolerance too tight for Gram-form correlations (see k_la_init_pick): residual form
+        ctx->stats.gram_fallbacks += 1;
+        Route r = route.after(); r.omp = omp; r.force_residual = true; r.no_solo = no_solo;
+        return retry(r);
+    }
+    if (la && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 2 && (ctx->persist_workers[0] != 0 || ctx->persist_workers[1] != 0)) {
+        // the resident kernel gave up on a wait (its grid was not fully resident): this context
+        // goes on with one launch per iteration
+        ctx->persist_workers[0] = 0;
+        ctx->persist_workers[1] = 0;
+        ctx->stats.persist_fallbacks += 1;
+        Route r = route.after(); r.omp = omp; r.force_residual = force_residual; r.no_solo = no_solo;
+        return retry(r);
+    }
+    if ((la || la_omp) && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 1) {
+        // k_la_iter's grid barrier expired as well (the GPU is shared with another resident grid):
+        // from here on this context uses the form without in-kernel grid synchronisation
+        ctx->la_fused = 0;
+        ctx->stats.persist_fallbacks += 1;
+        Route r = route.after(); r.omp = omp; r.force_residual = force_residual; r.no_solo = no_solo;
+        return retry(r);
+    }
+    if (hs.status != 0) {
+        set_err(err, errlen, hs.status == SS_HIP_ECAPACITY
+                                 ? "solve: active set outgrew the workspace capacity (4096 columns)"
+                                 : "solve: internal error, a device-side wait expired");
+        return (int)hs.status;
+    }
+    *report = true;
+    return SS_HIP_OK;
+}
+
 template <typename T>
 int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
                ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
-               bool omp = false, bool force_residual = false, bool no_solo = false,
-               void* rec_out = nullptr, uint32_t kmax = 0, bool force_ro = false, bool no_sub = false, bool no_res = false)
+               Route route = Route(), void* rec_out = nullptr, uint32_t kmax = 0);
+
+// One attempt.  Returns the status of the solve, or — with *again set — the route of the next attempt in *next.
+template <typename T>
+int solve_once(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
+               ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
+               const Route& route, void* rec_out, uint32_t kmax, Route* next, bool* again)
 {
-    if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
-    if (ctx->kind != 0) { set_err(err, errlen, "solve: this context was created for IRLS"); return SS_HIP_EINVAL; }
-    if (ctx->is_f64 != (sizeof(T) == 8)) {
-        set_err(err, errlen, "solve: element type of the call does not match the context");
-        return SS_HIP_ETYPE;
-    }
-    if (!y || (!x && !rec_out)) { set_err(err, errlen, "solve: y and x must not be null"); return SS_HIP_EINVAL; }
-    // preconditions the reference asserts (homotopy-cpu.cpp:193-199)
-    if (max_iter == 0) { set_err(err, errlen, "solve: max_iterations must be > 0"); return SS_HIP_EINVAL; }
-    if (!(tol >= std::numeric_limits<T>::epsilon() && tol < T(1))) {
-        set_err(err, errlen, "solve: tolerance must satisfy eps <= tolerance < 1");
-        return SS_HIP_EINVAL;
-    }
-    if (incy <= 0 || incx <= 0) {
-        set_err(err, errlen, "solve: vector increments must be positive");
-        return SS_HIP_EINVAL;
-    }
+    const bool omp = route.omp, force_residual = route.force_residual, no_solo = route.no_solo;
+    auto retry = [&](const Route& r) { *next = r; *again = true; return SS_HIP_OK; };
     try {
         HIPCHK(hipSetDevice(ctx->device));
         const size_t m = ctx->m, n = ctx->n;
@@ -935,14 +1352,14 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         ctx->host_flags[3] = 0;
         ctx->host_flags[4] = 0;
         if (prof) HIPCHK(hipEventRecord(ctx->ev_solve0, st));
+        Forms forms = choose_forms<T>(ctx, route, y, rec_out);
         // (lookahead engine with the signal on the device: k_la_reset reads it from the caller's buffer — no copy command)
-        const bool y_direct = !omp && !force_ro && ctx->engine != 3 && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual &&
-                              is_device_pointer(y);
+        const bool y_direct = forms.y_direct;
         if (!y_direct) copy_in<T>(ctx, ws.y, y, incy, m);
         // reference-order engine (reforder.hip; option engine = 3, and the arbiter of tie stalls): the reference's
         // iteration with every reduction in the documented 8-partial order, two passes over A per iteration
-        const bool ro = !omp && (force_ro || ctx->engine == 3);
-        const bool la_path = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && !ro;
+        const bool ro = forms.ro;
+        const bool la_path = forms.la;
         if (!la_path) {
             HIPCHK(hipMemsetAsync(ws.x, 0, (size_t)ctx->n_pad * sizeof(T), st));
             HIPCHK(hipMemsetAsync(ws.d, 0, (size_t)ctx->n_pad * sizeof(T), st));
@@ -953,35 +1370,13 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         if (!la_path) HIPCHK(hipMemcpyAsync(ws.rhs, ws.y, (size_t)ctx->ldm * sizeof(T), hipMemcpyDeviceToDevice, st));
         const size_t rhs_stride = (size_t)ws.dims.b_pad * ctx->ldm;   // r-block -> p-block
 
-        const bool la = !omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && !ro;
+        const bool la = forms.la;
         // orthogonal matching pursuit in Gram form (k_la_omp): same cache, same sweeps
-        const bool la_omp = omp && Lookahead<T>::supported && ctx->engine >= 1 && !force_residual && ctx->la_fused >= 1;
+        const bool la_omp = forms.la_omp;
         bool solo = false, solo_started = false, early = false;
         uint32_t early_lds_cols = 0, ro_parts = 0;
-        // With G = A^T A at hand (a large batch has run on the context, or option gram_full_after) a single signal takes the
-        // subset form of the batches (subbatch.hip): A^T y, one workgroup on 448 columns, the check over all columns — no
-        // pass over A beyond A^T y.  What the form does not vouch for is solved again the usual way (no_sub).
-        // (where the screened form below applies it is the faster of the two since its first pass reads the fp16 copy — 0.82 ms against
-        // 1.16 at configs[1] — and takes the signal; option screen_single = 0 leaves it to this form)
-        bool sub1 = la && sizeof(T) == 4 && !no_sub && ctx->batch_subset && ctx->gram_single && ctx->gram_full != nullptr &&
-                    sub_form_usable(ctx);
-        // Without G: the screened form (screen.hip) — the same subset solve on the subset's own Gram matrix (formed from A), every
-        // state of its path then screened against all columns by ONE pass over a half-precision copy of A with a rigorous error
-        // bound, instead of the default engine's two fp32 passes.  It stands in for the default speculative engine only
-        // (la_fused = 3 with the early form: contexts whose options ask for another engine get that engine).
-        bool scr1 = la && sizeof(T) == 4 && !no_sub && ctx->la_fused >= 3 && ctx->early_solo && !ctx->early_probe &&
-                    ctx->solo_subset == 256 && (!sub1 || screen_first16_usable(ctx)) && screen_form_usable(ctx);
-        if (scr1) sub1 = false;
-        // fp64: the same certificate around the fp64 engine — the path is solved by a context of its own on the 2048 columns with
-        // the largest |c0| (passes and iterations on 1.6 % of the dictionary), its logged states are screened against all columns
-        // (not with a trace or compact records asked for: the sub-context's lists are over ITS columns)
-        // (OMP too: the sub-context runs k_la_omp, the certificate is the same — nothing outside the sub-dictionary reaches the pick's |c|)
-        bool scr64 = (la || la_omp) && sizeof(T) == 8 && !no_sub && !ctx->tracing && rec_out == nullptr && ctx->la_fused >= 1 && screen64_usable(ctx);
-        // ... and before that tier, the RESIDENT tier (resident.hip): the path on the 256 best-ranked columns in ONE workgroup with the
-        // Gram values in registers — no sub-context, no host round trip, everything queued in one go; its lists are over the
-        // dictionary's own columns, so a trace and compact records work too.  What it does not report goes to the tier above.
-        bool scr64r = (la || la_omp) && sizeof(T) == 8 && !no_sub && !no_res && ctx->screen_resident && ctx->la_fused >= 1 && !(omp && ctx->tracing) &&
-                      screen64_usable(ctx) && screen64_resident_usable(ctx);
+        bool sub1 = forms.sub1, scr1 = forms.scr1, scr64 = forms.scr64, scr64r = forms.scr64r;
+        // (a context whose signals a form hands back more often than not steps that form aside for a while: the counters below)
         if ((sub1 || scr1 || scr64 || scr64r) && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; scr1 = false; scr64 = false; scr64r = false; }
         if (scr64r && ctx->res_off_solves > 0) { ctx->res_off_solves -= 1; scr64r = false; }
         if (scr64r) scr64 = false;
@@ -1076,8 +1471,8 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 const uint64_t ties0 = sub->stats.tie_reruns, gf0 = sub->stats.gram_fallbacks, pf0 = sub->stats.persist_fallbacks;
                 uint32_t it_s = 0;
                 double e_s = 0.0;
-                const int rc_s = solve_impl<T>(sub, ws.rhs, 1, tol, max_iter, screen64_xsub(ctx), 1, &it_s, &e_s, err, errlen, omp, false, false,
-                                               nullptr, 0, false, true);
+                Route rs; rs.omp = omp; rs.no_sub = true;
+                const int rc_s = solve_impl<T>(sub, ws.rhs, 1, tol, max_iter, screen64_xsub(ctx), 1, &it_s, &e_s, err, errlen, rs, nullptr, 0);
                 HIPCHK(hipSetDevice(ctx->device));
                 const bool clean = rc_s == SS_HIP_OK && sub->stats.tie_reruns == ties0 && sub->stats.gram_fallbacks == gf0 &&
                                    sub->stats.persist_fallbacks == pf0 && it_s >= 1u && it_s <= 192u;
@@ -1101,7 +1496,8 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             if (handed_back) {
                 // the sub-context's solve left its common path (a tie re-run, a residual-form retry, too many states): the usual engine
                 ctx->stats.screen_redone += 1;
-                return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
+                Route r = route; r.no_sub = true;
+                return retry(r);
             }
         } else if (la_omp) {
             Lookahead<T>::ensure(ctx, ws, kcap);
@@ -1188,240 +1584,29 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             HIPCHK(launch_rp<T>(ctx, ws, 1));
         }
 
-        // The device decides termination (k_scansel raises DevState::done and mirrors it,
-        // with the round it has reached, into pinned host memory).  The host keeps at most
-        // `lookahead` rounds queued beyond the device's position and stops enqueueing as
-        // soon as it sees `done`; rounds already queued behind it are no-ops.
-        const uint32_t L = (uint32_t)std::max(1, std::min(ctx->lookahead, 64));
-        volatile uint32_t* hf = ctx->host_flags;
-        const uint64_t last_round = (uint64_t)max_iter + 1;
+        PumpState ps;
+        ps.solo = solo; ps.solo_started = solo_started; ps.early = early; ps.early_lds_cols = early_lds_cols; ps.nprof = nprof;
         if (sub1 || scr1 || scr64 || scr64r) {
             // (everything is queued: selection, the solve, the check)
         } else if ((la && ctx->la_fused) || la_omp) {
-            // Fused lookahead engine: every launch of k_la_iter performs the next iteration, or
-            // nothing while the device waits for a Gram column (hf[2] counts those waits).  The
-            // host keeps L launches queued ahead and answers each wait with one fetch.
-            uint64_t enq = early ? (early_lds_cols != 0 ? 2u : 1u) : 0u;   // (early form: a solo group and the resident launch behind it are queued)
-            uint32_t handled = 0, timed_fetches = 0;
-            // resident kernel: LDS tier (support columns it can hold); 0 = one launch per iteration
-            uint32_t lds_cols = 0;
-            const uint32_t kcap_ws = ws.dims.kcap;       // what the device checks K against (>= this solve's kcap)
-            if (la && ctx->la_fused >= 2 && sizeof(T) == 4) {
-                lds_cols = std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsSmall);
-                if (!la_persist_usable(ctx, lds_cols)) lds_cols = 0;
+            if (!pump_fused<T>(ctx, ws, tol, max_iter, la, la_omp, prof, ps)) {
+                set_err(err, errlen, "solve: internal error, lookahead loop made no progress");
+                return SS_HIP_ERUNTIME;
             }
-            const uint64_t max_launch = 4 * ((uint64_t)max_iter + 2) + 64;
-            bool stuck = false;
-            for (;;) {
-                uint32_t spins = 0;
-                // (a solo group runs until the host has to act — fetch, hand-over, end — so one group in
-                // flight is enough: every further one is three launches that find nothing to do; after
-                // the hand-over, near the end of the path, two resident launches)
-                const uint32_t depth = solo ? 1u : (solo_started ? std::min<uint32_t>(L, 2u) : L);
-                while (hf[1] == 0 && hf[2] == handled && enq >= (uint64_t)hf[0] + depth) {
-                    if ((++spins & 0x3ffu) == 0) {
-                        const hipError_t qs = hipStreamQuery(st);
-                        if (qs == hipSuccess) break;
-                        if (qs != hipErrorNotReady) throw HipFail{ qs, "hipStreamQuery(solve loop)" };
-                    }
-                    std::this_thread::yield();
-                }
-                if (hf[1] != 0) break;
-                pump_enqueued = true;
-                if (hf[2] != handled) {
-                    const bool timed_la = prof && (timed_fetches++ % (uint32_t)std::max(1, ctx->profile_every) == 0);
-                    hipEvent_t e0 = nullptr, e1 = nullptr;
-                    if (timed_la) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
-                    if (la_omp) Lookahead<T>::fetch_omp(ctx, ws, tol, e0, e1);
-                    else Lookahead<T>::fetch(ctx, ws, tol, e0, e1, solo, handled);
-                    if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
-                    ++handled;
-                }
-                if (lds_cols != 0 && hf[3] > lds_cols) {
-                    // the support outgrew the tier: take the large one, or go on one launch per iteration
-                    const uint32_t big = std::min<uint32_t>((kcap_ws + 15u) & ~15u, kLaLdsLarge);
-                    lds_cols = (hf[3] <= big && big > lds_cols && la_persist_usable(ctx, big)) ? big : 0u;
-                }
-                if (enq >= max_launch) { stuck = true; break; }
-                if (solo && hf[4] != 0) solo = false;   // the device handed over to the resident / launch-per-iteration form
-                if (la_omp) HIPCHK(launch_la_omp<T>(ctx, ws, tol, max_iter));
-                else Lookahead<T>::iterate(ctx, ws, tol, max_iter, lds_cols, solo);
-                ++enq;
-                if (solo && lds_cols != 0) {
-                    // the resident form queued right behind the speculative group: a no-op unless that group hands
-                    // over (the last step of a path), which then costs no trip through the host
-                    HIPCHK(launch_persist(ctx, ws, tol, max_iter, lds_cols, true));
-                    ++enq;
-                }
-            }
-            if (stuck) {
-                HIPCHK(hipStreamSynchronize(st));
-                if (hf[1] == 0) {
-                    set_err(err, errlen, "solve: internal error, lookahead loop made no progress");
-                    return SS_HIP_ERUNTIME;
-                }
-            }
-        } else
-        for (uint64_t round = 1; round <= last_round; ++round) {
-            if (round > L) {
-                const uint32_t need = (uint32_t)(round - L);
-                uint32_t spins = 0;
-                while (hf[1] == 0 && hf[0] < need) {
-                    if ((++spins & 0x3ffu) == 0) {
-                        const hipError_t q = hipStreamQuery(st);
-                        if (q == hipSuccess) break;               // queue drained
-                        if (q != hipErrorNotReady) throw HipFail{ q, "hipStreamQuery(solve loop)" };
-                    }
-                    std::this_thread::yield();
-                }
-                if (hf[1] != 0) break;
-            }
-            if (la) {
-                // the launch is a no-op unless a column without cached Gram column enters: time
-                // every `profile_every`-th launch and keep the ones that did work (see below)
-                const bool timed_la = prof && (round % (uint64_t)std::max(1, ctx->profile_every) == 0);
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (timed_la) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); }
-                Lookahead<T>::round(ctx, ws, (uint32_t)round, tol, max_iter, e0, e1);
-                if (timed_la) { ctx->prof_kind.push_back(3); ++nprof; }
-                continue;
-            }
-            if (ro) {
-                // homotopy-cpu.cpp:236-272 with ONE pass over A per iteration: r = y - A x and p = A d (the direction built
-                // from the signs of c - gamma q), the fused sweep [c, q] = A^T [r, p], lambda + the while-test + the check of
-                // those signs against the re-computed c (a mismatch rebuilds the direction; p and q are then formed again),
-                // the scan + toggle + x update, the inverse update and the next direction
-                HIPCHK(launch_ro_round<T>(ctx, ws, 1u, (uint32_t)round, ro_parts, tol, max_iter));
-                continue;
-            }
-            if (omp) {
-                // orthogonal matching pursuit round: c = A^T r (one right-hand side), pick,
-                // bordered inverse + least squares on the support, new residual
-                uint32_t nbo = 0;
-                HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 1, ws.c, nullptr, ws.pmax_val, ws.pmax_idx, &nbo, ws.st));
-                HIPCHK(launch_omp_tail<T>(ctx, ws, 1, (uint32_t)round, nbo, tol, max_iter));
-                continue;
-            }
-            uint32_t nb = 0;
-            // HIP events cost tens of microseconds of stream time each: time every
-            // `profile_every`-th fused sweep only (option), still inside the solve
-            const bool timed = prof && (round % (uint64_t)std::max(1, ctx->profile_every) == 0);
-            if (timed) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof), st)); }
-            HIPCHK(launch_sweep<T>(ctx, ws.rhs, rhs_stride, 2, ws.c, ws.q, ws.pmax_val, ws.pmax_idx, &nb, ws.st));
-            if (timed) {
-                HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st));
-                ctx->prof_kind.push_back((int)round + 16);     // >= 16: fused sweep of round (kind-16)
-                ++nprof;
-            }
-            HIPCHK(launch_iteration_tail<T>(ctx, ws, 1, (uint32_t)round, nb, tol, max_iter));
+        } else {
+            pump_rounds<T>(ctx, ws, tol, max_iter, la, ro, omp, ro_parts, rhs_stride, prof, ps);
         }
+        solo = ps.solo; nprof = ps.nprof; pump_enqueued = ps.enqueued;
 
         if (!(spec_epilogue && !pump_enqueued)) enqueue_epilogue();
         HIPCHK(hipStreamSynchronize(st));
         const DevState hs = *static_cast<const DevState*>(ctx->hs_pinned);
-
-        if (!hs.done) {
-            set_err(err, errlen, "solve: internal error, device loop did not terminate");
-            return SS_HIP_ERUNTIME;
-        }
-        // (a tie met by the screened form's subset solve is a tie of the SUBSET's view — on a subset that cannot be certified it may not
-        // exist over all columns: such a signal goes to the default engine below, which meets the tie itself if it is real)
-        const bool scr_tie = (scr1 || scr64r) && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun);
-        if (!ro && !omp && !scr_tie && ctx->tie_rerun && !ctx->tie_guard && (hs.tie_stall != 0 || hs.status == kStatusTieRerun)) {
-            // a step-length scan met an exact tie (DevState::tie_stall): whether the strict t > 0 of the reference then
-            // derails the path is decided by rounding — the reference-order engine is the arbiter
-            ctx->stats.tie_reruns += 1;
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, false, false, no_solo, rec_out, kmax, true);
-        }
-        if (sub1 || scr1 || scr64) {
-            // (a context whose signals the form hands back more often than not stops trying for a while)
-            ctx->sub_seen += 1;
-            if (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie) ctx->sub_failed += 1;
-            if (ctx->sub_seen >= 8) {
-                if (2 * ctx->sub_failed > ctx->sub_seen) ctx->sub_off_solves = 64;
-                ctx->sub_seen = 0;
-                ctx->sub_failed = 0;
-            }
-        }
-        if (scr64r) {
-            const bool back = hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie;
-            ctx->res_seen += 1;
-            if (back) ctx->res_failed += 1;
-            if (ctx->res_seen >= 8) {
-                if (2 * ctx->res_failed > ctx->res_seen) ctx->res_off_solves = 64;
-                ctx->res_seen = 0;
-                ctx->res_failed = 0;
-            }
-            if (back) {
-                // the resident tier does not report this signal: the sub-dictionary tier (2048 columns) takes it next
-                ctx->stats.screen_tier2 += 1;
-                count_reasons(ctx, hs.sub_reason, scr_tie);
-                if (std::getenv("SS_HIP_SUB_DEBUG"))
-                    std::fprintf(stderr, "[screened form, fp64 resident tier] status %u reason 0x%x after %u iterations, %u states logged, K = %u, lambda %g\n",
-                                 hs.status, hs.sub_reason, hs.iter, hs.solo_nlog, hs.K, hs.c_inf);
-                return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, false, true);
-            }
-            if (hs.status == 0) { ctx->stats.screen_signals += 1; ctx->stats.screen_resident += 1; }
-        }
-        if ((scr1 || scr64) && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie)) {
-            ctx->stats.screen_redone += 1;
-            count_reasons(ctx, hs.sub_reason, scr_tie);
-            if (std::getenv("SS_HIP_SUB_DEBUG")) {
-                std::fprintf(stderr, "[screened form] status %u reason 0x%x after %u iterations, %u states logged, K = %u, lambda %g, lambda0 %g\n",
-                             hs.status, hs.sub_reason, hs.iter, hs.solo_nlog, hs.K, hs.c_inf, (double)hs.lambda0);
-                if (scr1) screen_debug_recheck(ctx);
-            }
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
-        }
-        if ((scr1 || scr64) && hs.status == 0) ctx->stats.screen_signals += 1;
-        if (scr1 && hs.status == 0 && ctx->screen_resident && res_solve_usable<float>()) ctx->stats.screen_resident += 1;
-        if ((scr1 || scr64r) && hs.status == 0 && (hs.sub_reason & kReasonRechecked)) ctx->stats.screen_recheck += 1;
-        if (scr1 && ctx->sub_dbg != nullptr) {
-            unsigned long long tp[9];
-            HIPCHK(hipMemcpy(tp, ctx->sub_dbg, sizeof(tp), hipMemcpyDeviceToHost));
-            const double r = tp[8] ? (double)tp[8] : 1.0;
-            std::fprintf(stderr, "[k_sub_solve, cycles per round over %llu rounds] chain %.0f  max|c| %.0f  log+scan %.0f  arg-min %.0f  hand-shake+x %.0f  u1/u2 %.0f  "
-                                 "inverse+signs %.0f  direction %.0f\n", tp[8], tp[0] / r, tp[1] / r, tp[2] / r, tp[3] / r, tp[4] / r, tp[5] / r, tp[6] / r, tp[7] / r);
-        }
-        if (sub1 && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail)) {
-            ctx->stats.subset_redone += 1;
-            count_reasons(ctx, hs.sub_reason, false);
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax, false, true);
-        }
-        if (sub1 && hs.status == 0) ctx->stats.subset_signals += 1;
-        if (la && hs.status == kStatusRetryPlain) {
-            // the early form's first launch used too many columns beyond the prefetched ones: plain form for this solve
-            const int keep = ctx->early_solo;
-            ctx->early_solo = 0;
-            const int rc2 = solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax);
-            ctx->early_solo = keep;
-            return rc2;
-        }
-        if ((la || la_omp) && hs.status == kStatusRetryResidual) {
-            // tolerance too tight for Gram-form correlations (see k_la_init_pick): residual form
-            ctx->stats.gram_fallbacks += 1;
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, true, no_solo, rec_out, kmax);
-        }
-        if (la && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 2 && (ctx->persist_workers[0] != 0 || ctx->persist_workers[1] != 0)) {
-            // the resident kernel gave up on a wait (its grid was not fully resident): this context
-            // goes on with one launch per iteration
-            ctx->persist_workers[0] = 0;
-            ctx->persist_workers[1] = 0;
-            ctx->stats.persist_fallbacks += 1;
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax);
-        }
-        if ((la || la_omp) && hs.status == SS_HIP_ERUNTIME && ctx->la_fused >= 1) {
-            // k_la_iter's grid barrier expired as well (the GPU is shared with another resident grid):
-            // from here on this context uses the form without in-kernel grid synchronisation
-            ctx->la_fused = 0;
-            ctx->stats.persist_fallbacks += 1;
-            return solve_impl<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, omp, force_residual, no_solo, rec_out, kmax);
-        }
-        if (hs.status != 0) {
-            set_err(err, errlen, hs.status == SS_HIP_ECAPACITY
-                                     ? "solve: active set outgrew the workspace capacity (4096 columns)"
-                                     : "solve: internal error, a device-side wait expired");
-            return (int)hs.status;
+        Forms eff = forms;
+        eff.sub1 = sub1; eff.scr1 = scr1; eff.scr64 = scr64; eff.scr64r = scr64r;      // (after the step-aside counters)
+        {
+            bool report = false;
+            const int vrc = attempt_verdict<T>(ctx, route, eff, hs, next, again, &report, err, errlen);
+            if (!report) return vrc;
         }
         if (iter_out) *iter_out = hs.iter;
         if (err_out) *err_out = hs.c_inf;
@@ -1452,71 +1637,12 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             ctx->solo_failed += hs.solo_fails;
             if (ctx->solo_seen >= 8 && 2 * ctx->solo_failed > ctx->solo_seen) ctx->solo_off_solves = 64;
             const char* path = hs.solo_fails ? std::getenv("SS_HIP_SOLO_DEBUG") : nullptr;
-            if (path != nullptr) {
-                // developer aid: the log and the verification partials of the last solo launch
-                const size_t lw = (size_t)kSoloHeaderWords + (size_t)kSoloLogCap * kSoloEntryWords;
-                std::vector<uint32_t> lg(lw), vm((size_t)kSoloLogCap * ws.nvwg);
-                std::vector<uint64_t> vn((size_t)kSoloLogCap * ws.nvwg);
-                HIPCHK(hipMemcpy(lg.data(), ws.solo_log, lw * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(vm.data(), ws.v_max, vm.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(vn.data(), ws.v_min, vn.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-                if (FILE* fp = std::fopen(path, "wb")) {
-                    const uint32_t hdr[4] = { hs.solo_nlog, ws.nvwg, kSoloEntryWords, kSoloHeaderWords };
-                    std::fwrite(hdr, 4, 4, fp);
-                    std::fwrite(lg.data(), 4, lg.size(), fp);
-                    std::fwrite(vm.data(), 4, vm.size(), fp);
-                    std::fwrite(vn.data(), 8, vn.size(), fp);
-                    std::fclose(fp);
-                }
-            }
+            if (path != nullptr) dump_solo_debug<T>(ws, hs, path);
         }
         ctx->stats.iterations += hs.iter;
         if (la || la_omp) ctx->stats.lookahead_sweeps += hs.nsweeps;
         if (ro) ctx->stats.ro_resweeps += hs.nsweeps;
-        if (prof) {
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
-            ctx->stats.solve_ms += ms;
-            // only sweeps that did real work: the initial one and rounds 1..done_round
-            for (size_t i = 0; i < nprof; ++i) {
-                HIPCHK(hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
-                if (ctx->prof_kind[i] == 1) {
-                    ctx->stats.sweep1_launches += 1;
-                    ctx->stats.sweep1_ms += ms;
-                } else if (ctx->prof_kind[i] == 6) {
-                    // the screening pass: fp16 copy of A + the residual block (re-read from L2 by every workgroup: not counted) + norms
-                    ctx->stats.screen_launches += scr_launches;
-                    ctx->stats.screen_ms += ms;
-                    ctx->stats.screen_bytes += (uint64_t)scr_launches * ((uint64_t)ctx->ldm * ctx->n_pad * 2ull + 96ull * ctx->ldm * 2ull + (uint64_t)ctx->n_pad * 4ull);
-                } else if (ctx->prof_kind[i] == 8) {
-                    ctx->stats.res_solve_launches += 1;
-                    ctx->stats.res_solve_ms += ms;
-                } else if (ctx->prof_kind[i] == 7) {
-                    ctx->stats.first16_launches += 1;
-                    ctx->stats.first16_ms += ms;
-                    ctx->stats.first16_bytes += (uint64_t)ctx->ldm * ctx->n_pad * 2ull + (uint64_t)ctx->ldm * sizeof(T) + (uint64_t)ctx->n_pad * 4ull;
-                } else if (ctx->prof_kind[i] == 4) {
-                    if (ms > 0.02f) {                          // (a launch of a solve that ended at the first pick is a no-op)
-                        ctx->stats.sweep64_launches += 1;
-                        ctx->stats.sweep64_ms += ms;
-                    }
-                } else if (ctx->prof_kind[i] == 3 || ctx->prof_kind[i] == 5) {
-                    // lookahead sweep: a launch that found nothing to do returns in microseconds.  Bytes per EVENT: a
-                    // plain pass (3) covers all n columns, the early form's main launch (5) its share of them
-                    const uint64_t sz = sizeof(T);
-                    const uint64_t cols = ctx->prof_kind[i] == 5 ? ctx->stats.sweep32_timed_cols : (uint64_t)ctx->n;
-                    const uint64_t bytes = (uint64_t)ctx->m * cols * sz + 32ull * ctx->m * sz + 32ull * cols * sz;
-                    if ((double)bytes / (ms * 1e-3) < 50e12) {   // < 50 TB/s: it streamed A
-                        ctx->stats.sweep32_launches += 1;
-                        ctx->stats.sweep32_ms += ms;
-                        ctx->stats.sweep32_bytes_timed += bytes;
-                    }
-                } else if ((uint32_t)(ctx->prof_kind[i] - 16) <= hs.done_round) {
-                    ctx->stats.sweep_launches += 1;
-                    ctx->stats.sweep_ms += ms;
-                }
-            }
-        }
+        if (prof) account_profile<T>(ctx, nprof, scr_launches, hs);
     } catch (const HipFail& f) {
         set_err(err, errlen, hip_msg(f));
         return SS_HIP_ERUNTIME;
@@ -1525,6 +1651,44 @@ int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         return SS_HIP_ENOMEM;
     }
     return SS_HIP_OK;
+}
+
+// The solve: validate once, then attempts until one of them reports (at most one per rung of the ladder: every retry sets a
+// flag of the route or changes the context so that the same rung cannot be taken twice).
+template <typename T>
+int solve_impl(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_iter, T* x,
+               ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen,
+               Route route, void* rec_out, uint32_t kmax)
+{
+    if (!ctx) { set_err(err, errlen, "solve: null context"); return SS_HIP_EINVAL; }
+    if (ctx->kind != 0) { set_err(err, errlen, "solve: this context was created for IRLS"); return SS_HIP_EINVAL; }
+    if (ctx->is_f64 != (sizeof(T) == 8)) {
+        set_err(err, errlen, "solve: element type of the call does not match the context");
+        return SS_HIP_ETYPE;
+    }
+    if (!y || (!x && !rec_out)) { set_err(err, errlen, "solve: y and x must not be null"); return SS_HIP_EINVAL; }
+    // preconditions the reference asserts (homotopy-cpu.cpp:193-199)
+    if (max_iter == 0) { set_err(err, errlen, "solve: max_iterations must be > 0"); return SS_HIP_EINVAL; }
+    if (!(tol >= std::numeric_limits<T>::epsilon() && tol < T(1))) {
+        set_err(err, errlen, "solve: tolerance must satisfy eps <= tolerance < 1");
+        return SS_HIP_EINVAL;
+    }
+    if (incy <= 0 || incx <= 0) {
+        set_err(err, errlen, "solve: vector increments must be positive");
+        return SS_HIP_EINVAL;
+    }
+    // (a retry in the plain speculative form runs — with everything it may fall back to in turn — with option early_solo off)
+    struct EarlyKeep { ss_hip_ctx* c; int keep; bool on = false; ~EarlyKeep() { if (on) c->early_solo = keep; } } early_keep{ ctx, ctx->early_solo };
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        Route next;
+        bool again = false;
+        if (route.plain && !early_keep.on) { early_keep.on = true; ctx->early_solo = 0; }
+        const int rc = solve_once<T>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, route, rec_out, kmax, &next, &again);
+        if (!again) return rc;
+        route = next;
+    }
+    set_err(err, errlen, "solve: internal error, the forms kept handing the signal on");
+    return SS_HIP_ERUNTIME;
 }
 
 // ---- batched solve: B signals share the sensing matrix and advance in lock-step ---------
@@ -2059,8 +2223,9 @@ int solve_batch_gemm_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_
             for (size_t g : redo) {
                 uint32_t it = 0;
                 double e = 0.0;
+                Route r; r.no_sub = true;                  // (the batch's screened form has declined it: the default engine)
                 const int rc = solve_impl<T>(ctx, Y + (ptrdiff_t)g * y_stride, incy, tol, max_iter, X ? X + (ptrdiff_t)g * x_stride : nullptr, incx, &it, &e,
-                                             err, errlen, false, false, false, rec_out ? static_cast<unsigned char*>(rec_out) + g * rb : nullptr, kmax, false, true);
+                                             err, errlen, r, rec_out ? static_cast<unsigned char*>(rec_out) + g * rb : nullptr, kmax);
                 if (rc != SS_HIP_OK) return rc;
                 if (iter_out) iter_out[g] = it;
                 if (err_out) err_out[g] = e;
@@ -2118,7 +2283,7 @@ int solve_batch_seq(ss_hip_ctx* ctx, const T* Y, size_t B, ptrdiff_t y_stride, p
         uint32_t it = 0;
         double e = 0.0;
         const int rc = solve_impl<T>(ctx, Y + (ptrdiff_t)b * y_stride, incy, tol, max_iter,
-                                     X ? X + (ptrdiff_t)b * x_stride : nullptr, incx, &it, &e, err, errlen, false, false, false,
+                                     X ? X + (ptrdiff_t)b * x_stride : nullptr, incx, &it, &e, err, errlen, Route(),
                                      rec_out ? static_cast<unsigned char*>(rec_out) + b * rb : nullptr, kmax);
         if (rc != SS_HIP_OK) return rc;
         if (iter_out) iter_out[b] = it;
@@ -2252,8 +2417,9 @@ int solve_batch_res64(ss_hip_ctx* ctx, const double* Y, size_t B, ptrdiff_t y_st
     for (size_t b : redo) {
         uint32_t it = 0;
         double e = 0.0;
+        Route r; r.no_res = true;                          // (the batch's resident tier has declined it: the tiers behind)
         const int rc = solve_impl<double>(ctx, Y + (ptrdiff_t)b * y_stride, incy, tol, max_iter, X ? X + (ptrdiff_t)b * x_stride : nullptr, incx, &it, &e, err, errlen,
-                                          false, false, false, rec_out ? static_cast<unsigned char*>(rec_out) + b * rb : nullptr, kmax, false, false, true);
+                                          r, rec_out ? static_cast<unsigned char*>(rec_out) + b * rb : nullptr, kmax);
         if (rc != SS_HIP_OK) return rc;
         if (iter_out) iter_out[b] = it;
         if (err_out) err_out[b] = e;
@@ -2628,13 +2794,15 @@ int ss_hip_homotopy_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy, 
 int ss_hip_omp_solve_f32(ss_hip_ctx* ctx, const float* y, ptrdiff_t incy, float tol, uint32_t max_iter,
                          float* x, ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen)
 {
-    return solve_impl<float>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, true);
+    Route r; r.omp = true;
+    return solve_impl<float>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, r);
 }
 
 int ss_hip_omp_solve_f64(ss_hip_ctx* ctx, const double* y, ptrdiff_t incy, double tol, uint32_t max_iter,
                          double* x, ptrdiff_t incx, uint32_t* iter_out, double* err_out, char* err, size_t errlen)
 {
-    return solve_impl<double>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, true);
+    Route r; r.omp = true;
+    return solve_impl<double>(ctx, y, incy, tol, max_iter, x, incx, iter_out, err_out, err, errlen, r);
 }
 
 int ss_hip_homotopy_solve_batch_f32(ss_hip_ctx* ctx, const float* Y, size_t B, ptrdiff_t y_stride,
