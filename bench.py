@@ -1292,7 +1292,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                     r["same_iterations_as_cpu"] = bool(itc_ == iti)
                     r["max_abs_diff_vs_cpu"] = float(np.abs(xo_.cpu().numpy() - xc_).max())
                 return r
-            irls = {"note": "construction: Householder QR by panels of 32 columns — a panel factored in one launch (its columns' workgroups hand the reflectors on through flags), its reflectors applied to the trailing columns in one launch, Q formed in one launch (latency-bound: 32 dependent links per panel); Newton loop: a chain of launches from n = 96 on (blocked Cholesky, blocked triangular solves, products with Q on all CUs); off the "
+            irls = {"note": "construction: Householder QR by panels of 32 columns — a panel factored in one launch (its columns' workgroups hand the reflectors on through flags), its reflectors applied to the trailing columns in one launch, Q formed in one launch, every workgroup holding its column(s) in registers (latency-bound: 32 dependent links per panel); Newton loop: a chain of launches from n = 96 on (blocked Cholesky, blocked triangular solves, products with Q on all CUs); off the "
                             "benchmark's metric; the CPU restatement (scalar loops, as the reference's QR) is timed at the small "
                             "shape only (4096 x 1024 takes it two minutes)",
                     "large": irls_case(4096, 1024, False)}

@@ -265,6 +265,280 @@ void k_qr_formq_all(const T* __restrict__ Vt, T* __restrict__ Qt, uint32_t ldm, 
     }
 }
 
+// ==== register-resident forms of the factorisation kernels (round 4) ==========================================================
+// The kernels above walk a column in global memory for every reflector (read for the dot product, read + write for the update:
+// three passes of m elements per reflector, through L2).  ldm is a multiple of 256, so a workgroup of 256 threads can HOLD a column:
+// thread t keeps the rows t + 256 e, e < RPT = ldm / 256, in registers from the first reflector to the last; a reflector then costs
+// its own read (shared by the NC columns a workgroup carries), RPT fmas per column, ONE barrier (the partial sums go through
+// alternating LDS slots) and RPT fmas again.  The statements are the reference's (qr_decomposition.h:111-172); the rows of a partial
+// sum are the same residue class mod 256 as before, the classes are combined in another order (parity by tolerance, as for every
+// sum of this file).  Reflector rows above the diagonal and beyond m are stored as zeros in Vt, so no row range is tested: those
+// products are exact zeros.  Used for ldm <= 8192 (RPT <= 32); taller matrices keep the kernels above.
+
+// sum of NC values over the workgroup (256 threads), every thread receives them; pp alternates the LDS slot: one barrier per call
+template <typename T, int NC>
+__device__ __forceinline__ void block_sum_pp(T (&v)[NC], T (*sv)[NC][4], int& pp)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const T w = wave_sum(v[c]);
+        if (lane == 0) sv[pp][c][wave] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = ((sv[pp][c][0] + sv[pp][c][1]) + sv[pp][c][2]) + sv[pp][c][3];
+    pp ^= 1;
+}
+
+// (RPT is the next of 4, 8, 16, 32 at or above ldm / 256: the slots past ldm hold zeros and are never stored)
+template <typename T, int RPT>
+__device__ __forceinline__ void col_load(T (&a)[RPT], const T* __restrict__ col, uint32_t ldm)
+{
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) { const uint32_t i = threadIdx.x + 256u * (uint32_t)e; a[e] = i < ldm ? col[i] : T(0); }
+}
+template <typename T, int RPT>
+__device__ __forceinline__ void col_store(const T (&a)[RPT], T* __restrict__ col, uint32_t ldm)
+{
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) { const uint32_t i = threadIdx.x + 256u * (uint32_t)e; if (i < ldm) col[i] = a[e]; }
+}
+
+// the reflectors k0 .. k0 + nb - 1 applied, in order, to NC trailing columns per workgroup (k_qr_apply_panel's statements)
+template <typename T, int RPT, int NC>
+__global__ __launch_bounds__(kQrThreads)
+void k_qr_apply_panel_reg(T* __restrict__ At, const T* __restrict__ Vt, uint32_t ldm, uint32_t n, uint32_t k0, uint32_t nb)
+{
+    __shared__ T sv[2][NC][4];
+    T a[NC][RPT], v[RPT], vn[RPT];
+    const uint32_t c0 = k0 + nb + NC * blockIdx.x;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const uint32_t col = c0 + (uint32_t)c < n ? c0 + (uint32_t)c : n - 1u;      // (a column past the end: a copy, never stored)
+        col_load<T, RPT>(a[c], At + (size_t)col * ldm, ldm);
+    }
+    col_load<T, RPT>(v, Vt + (size_t)k0 * ldm, ldm);
+    int pp = 0;
+    for (uint32_t k = k0; k < k0 + nb; ++k) {
+        const T vk = Vt[(size_t)k * ldm + k];
+        if (k + 1u < k0 + nb) col_load<T, RPT>(vn, Vt + (size_t)(k + 1u) * ldm, ldm);
+        if (vk != T(0)) {                                       // (a zero pivot column: the others are left alone)
+            T part[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                part[c] = T(0);
+#pragma unroll
+                for (int e = 0; e < RPT; ++e) part[c] += v[e] * a[c][e];
+            }
+            block_sum_pp<T, NC>(part, sv, pp);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const T sc = part[c] / -vk;
+#pragma unroll
+                for (int e = 0; e < RPT; ++e) a[c][e] += v[e] * sc;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) v[e] = vn[e];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (c0 + (uint32_t)c < n) col_store<T, RPT>(a[c], At + (size_t)(c0 + (uint32_t)c) * ldm, ldm);
+}
+
+// a panel of nb <= 32 columns factored in one launch (k_qr_panel's protocol and statements), the workgroup's column in registers
+template <typename T, int RPT>
+__global__ __launch_bounds__(kQrThreads)
+void k_qr_panel_reg(T* __restrict__ At, T* __restrict__ Vt, T* __restrict__ rdiag, uint32_t ldm, uint32_t m, uint32_t k0,
+                    uint32_t* __restrict__ ready)
+{
+    __shared__ T sv[2][1][4];
+    __shared__ T sm[16];
+    __shared__ T s_piv;
+    __shared__ uint32_t s_gave_up;
+    const uint32_t kown = k0 + blockIdx.x, tid = threadIdx.x;
+    T a[RPT], v[RPT];
+    col_load<T, RPT>(a, At + (size_t)kown * ldm, ldm);
+    if (tid == 0) s_gave_up = 0u;
+    __syncthreads();
+    int pp = 0;
+    for (uint32_t k = k0; k < kown; ++k) {
+        if (tid == 0) {
+            // (bounded, like k_qr_panel: a producer that never shows up must not hang the device)
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&ready[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && spins < (1u << 26)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+            if (spins >= (1u << 26)) s_gave_up = 1u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (s_gave_up != 0u) break;
+        const T* vr = Vt + (size_t)k * ldm;
+        const T vk = vr[k];
+        if (vk == T(0)) continue;
+        col_load<T, RPT>(v, vr, ldm);
+        T part[1] = { T(0) };
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) part[0] += v[e] * a[e];
+        block_sum_pp<T, 1>(part, sv, pp);
+        const T sc = part[0] / -vk;
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) a[e] += v[e] * sc;
+    }
+    // the column as the panel's reflectors have left it (its rows above the diagonal are R's)
+    col_store<T, RPT>(a, At + (size_t)kown * ldm, ldm);
+    const uint32_t k = kown;
+    T* vout = Vt + (size_t)k * ldm;
+    if (s_gave_up != 0u) {
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) if (tid + 256u * (uint32_t)e < ldm) vout[tid + 256u * (uint32_t)e] = T(0);
+        if (tid == 0) rdiag[k] = T(0) / T(0);
+    } else {
+        // my column is the pivot of step kown (k_qr_step's statements): 2-norm of rows k .. m - 1 without overflow
+        T amax = T(0), mine = T(0);
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) {
+            const uint32_t i = tid + 256u * (uint32_t)e;
+            if (i >= k && i < m) amax = max(amax, t_abs(a[e]));
+            if (i == k) mine = a[e];
+        }
+        if (tid == (k & 255u)) s_piv = mine;
+        amax = block_max(amax, sm);                              // (its barriers publish s_piv too)
+        const T pivk = s_piv;
+        T nrm2 = T(0);
+        if (amax > T(0)) {
+            T part[1] = { T(0) };
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) {
+                const uint32_t i = tid + 256u * (uint32_t)e;
+                if (i >= k && i < m) { const T z = a[e] / amax; part[0] += z * z; }
+            }
+            block_sum_pp<T, 1>(part, sv, pp);
+            nrm2 = amax * sqrt(part[0]);
+        }
+        if (nrm2 == T(0)) {
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) if (tid + 256u * (uint32_t)e < ldm) vout[tid + 256u * (uint32_t)e] = T(0);
+            if (tid == 0) rdiag[k] = -nrm2;
+        } else {
+            if (pivk < T(0)) nrm2 = -nrm2;
+            const T vk = pivk / nrm2 + T(1);
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) {
+                const uint32_t i = tid + 256u * (uint32_t)e;
+                if (i < ldm) vout[i] = (i < k || i >= m) ? T(0) : (i == k ? vk : a[e] / nrm2);
+            }
+            if (tid == 0) rdiag[k] = -nrm2;
+        }
+    }
+    // publish: every wave's stores drained, then the leader releases and raises the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&ready[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// back-accumulation of the thin Q, NC neighbouring columns per workgroup: column j starts as e_j and receives the reflectors j,
+// j - 1, ... 0 (k_qr_formq_all's statements).  A reflector kk > j meets e_j with v_kk[j] = 0: an exact no-op, so the NC columns share
+// one walk from the last of them down.
+template <typename T, int RPT, int NC>
+__global__ __launch_bounds__(kQrThreads)
+void k_qr_formq_reg(const T* __restrict__ Vt, T* __restrict__ Qt, uint32_t ldm, uint32_t n)
+{
+    __shared__ T sv[2][NC][4];
+    T q[NC][RPT], v[RPT], vn[RPT];
+    const uint32_t j0 = NC * blockIdx.x;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) q[c][e] = (threadIdx.x + 256u * (uint32_t)e == j0 + (uint32_t)c) ? T(1) : T(0);
+    const uint32_t top = (j0 + NC - 1u < n ? j0 + NC - 1u : n - 1u);
+    col_load<T, RPT>(v, Vt + (size_t)top * ldm, ldm);
+    int pp = 0;
+    for (uint32_t kk = top + 1u; kk-- > 0;) {
+        const T vk = Vt[(size_t)kk * ldm + kk];
+        if (kk > 0u) col_load<T, RPT>(vn, Vt + (size_t)(kk - 1u) * ldm, ldm);
+        if (vk != T(0)) {
+            T part[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                part[c] = T(0);
+#pragma unroll
+                for (int e = 0; e < RPT; ++e) part[c] += v[e] * q[c][e];
+            }
+            block_sum_pp<T, NC>(part, sv, pp);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const T sc = -part[c] / vk;
+#pragma unroll
+                for (int e = 0; e < RPT; ++e) q[c][e] += sc * v[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) v[e] = vn[e];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (j0 + (uint32_t)c < n) col_store<T, RPT>(q[c], Qt + (size_t)(j0 + (uint32_t)c) * ldm, ldm);
+}
+
+// R (qr_decomposition.h:174-190); workgroup i does row i
+template <typename T>
+__global__ __launch_bounds__(kQrThreads)
+void k_irls_setup_r(const T* __restrict__ At, const T* __restrict__ rdiag, T* __restrict__ R, uint32_t ldm, uint32_t n)
+{
+    const uint32_t i = blockIdx.x;
+    for (uint32_t j = threadIdx.x; j < n; j += kQrThreads)
+        R[(size_t)i * n + j] = j > i ? At[(size_t)j * ldm + i] : (j == i ? rdiag[i] : T(0));
+}
+
+// the lower triangle of Q^T Q by 32 x 32 tiles: workgroup b = tile (bi >= bj); 64 rows of the two blocks of columns staged in LDS
+// per step, a 2 x 2 patch of the tile per thread (k_irls_setup walks a whole column of Q per entry: n^2 / 2 columns through L2)
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_irls_gram_tiled(const T* __restrict__ Qt, T* __restrict__ G0, uint32_t ldm, uint32_t m, uint32_t n)
+{
+    constexpr uint32_t TB = 32, RC = 64;
+    __shared__ T sI[TB][RC + 1];
+    __shared__ T sJ[TB][RC + 1];
+    const uint32_t b = blockIdx.x;
+    uint32_t bi = (uint32_t)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
+    while (bi * (bi + 1u) / 2u > b) --bi;
+    while ((bi + 1u) * (bi + 2u) / 2u <= b) ++bi;
+    const uint32_t bj = b - bi * (bi + 1u) / 2u;                 // bj <= bi
+    const uint32_t tid = threadIdx.x, ti = tid >> 4, tj = tid & 15u;
+    T acc[2][2] = { { T(0), T(0) }, { T(0), T(0) } };
+    const uint32_t lc = tid >> 3, lr = (tid & 7u) * 8u;           // staging: column lc of the block, rows lr .. lr + 7 of the step
+    const uint32_t ci = bi * TB + lc, cj = bj * TB + lc;
+    for (uint32_t r0 = 0; r0 < m; r0 += RC) {
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) {
+            const uint32_t r = r0 + lr + q;
+            sI[lc][lr + q] = (ci < n && r < m) ? Qt[(size_t)ci * ldm + r] : T(0);
+            sJ[lc][lr + q] = (cj < n && r < m) ? Qt[(size_t)cj * ldm + r] : T(0);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (uint32_t r = 0; r < RC; ++r) {
+            const T a0 = sI[2u * ti][r], a1 = sI[2u * ti + 1u][r], b0 = sJ[2u * tj][r], b1 = sJ[2u * tj + 1u][r];
+            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const uint32_t i = bi * TB + 2u * ti + (uint32_t)x, j = bj * TB + 2u * tj + (uint32_t)y;
+            if (i < n && j < n) {
+                if (j <= i) G0[(size_t)i * n + j] = acc[x][y];
+                else if (bi == bj) G0[(size_t)i * n + j] = T(0);          // (above the diagonal inside a diagonal tile)
+            }
+        }
+}
+
 // R (qr_decomposition.h:174-190) and the lower triangle of Q^T Q; workgroup i does row i
 template <typename T>
 __global__ __launch_bounds__(kQrThreads)
@@ -847,6 +1121,7 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
     IRLS_TRY(hipMalloc(&S->ctl, sizeof(IrlsCtl<T>)));
     IRLS_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->done_host), 64, hipHostMallocDefault));
     IRLS_TRY(hipMemsetAsync(S->Qt, 0, (size_t)n * ldm * sizeof(T), ctx->stream));
+    IRLS_TRY(hipMemsetAsync(S->G0, 0, (size_t)n * n * sizeof(T), ctx->stream));
     IRLS_TRY(hipMemsetAsync(S->vec, 0, vec_bytes + (size_t)n * sizeof(uint32_t), ctx->stream));
     T* At = static_cast<T*>(ctx->At);
     uint32_t* qr_ready = nullptr;                                 // (flags of the one-launch panel kernel: behind S->vec, zeroed above)
@@ -860,6 +1135,32 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
             hipLaunchKernelGGL((k_qr_formq<T>), dim3(n - kk), dim3(kQrThreads), 0, ctx->stream, (const T*)S->Vt, S->Qt, ldm, m, kk);
             IRLS_TRY(hipGetLastError());
         }
+    } else if (ldm <= 8192u && !std::getenv("SS_HIP_IRLS_QR_GLOBAL")) {
+        // register-resident form (round 4): a workgroup holds its column(s) for a whole panel / the whole back-accumulation
+        // (SS_HIP_IRLS_QR_GLOBAL keeps the kernels that walk global memory: A/B aid)
+        constexpr uint32_t NBQ = 32;
+        uint32_t* const ready = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(S->vec) + vec_bytes);
+        qr_ready = ready;
+        const uint32_t rpt = ldm / 256u;
+#define IRLS_QR_REG(RPT, NCA, NCQ)                                                                                                         \
+        for (uint32_t k0 = 0; k0 < n; k0 += NBQ) {                                                                                         \
+            const uint32_t nb = std::min<uint32_t>(NBQ, n - k0);                                                                           \
+            hipLaunchKernelGGL((k_qr_panel_reg<T, RPT>), dim3(nb), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k0, ready); \
+            IRLS_TRY(hipGetLastError());                                                                                                   \
+            if (k0 + nb < n) {                                                                                                             \
+                const uint32_t nt = n - (k0 + nb);                                                                                         \
+                hipLaunchKernelGGL((k_qr_apply_panel_reg<T, RPT, NCA>), dim3((nt + NCA - 1) / NCA), dim3(kQrThreads), 0, ctx->stream, At,     \
+                                   (const T*)S->Vt, ldm, n, k0, nb);                                                                       \
+                IRLS_TRY(hipGetLastError());                                                                                               \
+            }                                                                                                                              \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL((k_qr_formq_reg<T, RPT, NCQ>), dim3((n + NCQ - 1) / NCQ), dim3(kQrThreads), 0, ctx->stream, (const T*)S->Vt, S->Qt, ldm, n); \
+        IRLS_TRY(hipGetLastError());
+        if (rpt <= 4u) { IRLS_QR_REG(4, 2, 4) }
+        else if (rpt <= 8u) { IRLS_QR_REG(8, 2, 4) }
+        else if (rpt <= 16u) { IRLS_QR_REG(16, 2, 4) }
+        else { IRLS_QR_REG(32, 1, 2) }
+#undef IRLS_QR_REG
     } else {
         // By panels of 32 columns: the panel's own columns step by step (launches of <= 32 workgroups), then its 32 reflectors
         // applied to every trailing column in ONE launch; Q's columns are independent of each other: one launch for all of them.
@@ -888,8 +1189,15 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
         hipLaunchKernelGGL((k_qr_formq_all<T>), dim3(n), dim3(kQrThreads), 0, ctx->stream, (const T*)S->Vt, S->Qt, ldm, m);
         IRLS_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL((k_irls_setup<T>), dim3(n), dim3(kQrThreads), 0, ctx->stream, (const T*)At, (const T*)S->Qt,
-                       (const T*)S->rdiag, S->R, S->G0, ldm, m, n);
+    if (std::getenv("SS_HIP_IRLS_FUSED") || std::getenv("SS_HIP_IRLS_QR_GLOBAL")) {
+        hipLaunchKernelGGL((k_irls_setup<T>), dim3(n), dim3(kQrThreads), 0, ctx->stream, (const T*)At, (const T*)S->Qt,
+                           (const T*)S->rdiag, S->R, S->G0, ldm, m, n);
+    } else {
+        // R row by row; Q^T Q by 32 x 32 tiles on and below the diagonal (G0 was zeroed above: the tiles above it stay zero)
+        hipLaunchKernelGGL((k_irls_setup_r<T>), dim3(n), dim3(kQrThreads), 0, ctx->stream, (const T*)At, (const T*)S->rdiag, S->R, ldm, n);
+        const uint32_t tb = (n + 31u) / 32u;
+        hipLaunchKernelGGL((k_irls_gram_tiled<T>), dim3(tb * (tb + 1u) / 2u), dim3(256), 0, ctx->stream, (const T*)S->Qt, S->G0, ldm, m, n);
+    }
     IRLS_TRY(hipGetLastError());
     IRLS_TRY(hipStreamSynchronize(ctx->stream));
     return hipSuccess;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """configs[4] (A 16384 x 131072 fp64, k = 128) in the shipped default — the fp64 screened form with its resident tier (csrc/resident.hip) —
 timed, Homotopy and OMP; with --tier2 also the sub-dictionary tier alone (option screen_resident = 0).
-    python tools/probe_res64.py [--tier2] [--solves N]          (under rocprofv3: tools/trace_screen_kernels.sh tools/probe_res64.py)"""
+    python tools/probe_res64.py [--tier2] [--solves N] [--k K]          (under rocprofv3: tools/trace_screen_kernels.sh tools/probe_res64.py)"""
 import os
 import sys
 import time
@@ -17,7 +17,7 @@ def main():
     import torch
     dev = torch.device("cuda", 0)
     nsolve = int(sys.argv[sys.argv.index("--solves") + 1]) if "--solves" in sys.argv else 6
-    m5, n5, k5 = 16384, 131072, 128
+    m5, n5, k5 = 16384, 131072, (int(sys.argv[sys.argv.index("--k") + 1]) if "--k" in sys.argv else 128)
     g5 = torch.Generator(device=dev).manual_seed(4321)
     A5 = torch.randn((m5, n5), generator=g5, device=dev, dtype=torch.float64)
     A5 /= np.sqrt(m5)
