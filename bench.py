@@ -571,8 +571,10 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
     # positive and (b) with SIGNED coefficients (half of those meet the reference's first-step sign quirk: the path derails — removals,
     # lambda going up — and is not certified; the reference itself then wanders for hundreds of iterations)
     if extras is not None:
-        def harder(signed, nh=20):
+        def harder(signed, nh=20, strict=False):
             hard = []
+            if strict:
+                h.set_option("strict_sign", 1)       # (setting screen_single below also clears the step-aside counters the derailed paths left)
             for s_ in range(nh):
                 rngh = np.random.default_rng(880000 + s_)
                 suph = np.sort(rngh.choice(N, K_SPARSE, replace=False))
@@ -610,6 +612,8 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             torch.cuda.synchronize()
             dth0 = time.perf_counter() - th0
             h.set_option("screen_single", 1)
+            if strict:
+                h.set_option("strict_sign", 0)
             del Xh_
             return {"signals": nh, "ms_per_solve_incl_hand_backs": dth / nh * 1e3, "ms_per_solve_default_engine_only": dth0 / nh * 1e3,
                     "certified": int(sth["screen_signals"]), "certified_by_the_exact_recheck": int(sth["screen_recheck"]),
@@ -623,6 +627,9 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                         "noise floor), max_iter 256, shipped defaults (the reference's behaviour, first-step sign quirk included)",
             "positive_coefficients": harder(False),
             "signed_coefficients": harder(True),
+            "signed_coefficients_with_strict_sign": harder(True, strict=True),
+            "note_strict_sign": "the same signed signals with option strict_sign = 1 (the first direction takes the sign of the leading correlation: the "
+                                "fix of the reference's quirk, opt-in, restated in the oracle): the paths are regular again and the screened form certifies them",
             "note": "signed: where the leading correlation is negative the reference's first direction has the wrong sign (homotopy-cpu.cpp:223-227): "
                     "the path derails (removals, lambda going up), the screened form declines it and the engine behind it follows the reference "
                     "through its long way round — that time is the reference's algorithm, not the screen's"}
@@ -902,6 +909,9 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
         f16_ms = st["first16_ms"] / max(1, st["first16_launches"])
         f16_bytes = st["first16_bytes"] / max(1, st["first16_launches"])
         f16_gbs = f16_bytes / (f16_ms * 1e-3) / 1e9 if f16_ms > 0 else 0.0
+        # (the ranking pass reads the fp8 copy of A where the row count allows — option screen_first8 — else the fp16 copy)
+        first_fp8 = first16 and f16_bytes < 1.5 * float(M) * N
+        fp_key = "first_pass_fp8" if first_fp8 else "first_pass_fp16"
         first_pass_roof = None
         if screened and first16:
             # The metric's kernel is SURVEY 8d's fp32 correlation GEMV c = A^T y (k_sweep, one right-hand side, m n 4 + m 4 + n 4 bytes).
@@ -920,15 +930,20 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
                                 "HIP events on the solver's stream around the launch inside the solves",
                     "traffic_source": live_src if (live and "sweep1" in live) else
                                       "profiles/traffic.json (HBM bytes per launch from separate rocprofv3 --pmc passes, replayed; NOT measured in this run)"}
-            first_pass_roof = {"bound": "hbm", "kernel": "k_scr_first<4 columns per wave, 3 stages>: c~0 = A16^T y over the half-precision copy of A (16-byte column "
-                                                         "loads, y in LDS, fp32 sums) — the first of the two passes over A16 of a solve in the screened form: the "
-                                                         "ranking of the columns; state 0 is certified from it like every other state",
+            first_pass_roof = {"bound": "hbm", "kernel": ("k_scr_first8<4 columns per wave, 3 stages>: c~0 = A8^T y over the FP8 (e4m3) copy of A (16-byte column "
+                                                          "loads = 16 rows per lane, y in LDS, fp32 sums) — the ranking pass of a solve in the screened form: it "
+                                                          "only chooses the 448 columns and bounds what was left out (eps_0 = 2^-4 ||a|| ||y||); nothing it computes is reported"
+                                                          if first_fp8 else
+                                                          "k_scr_first<4 columns per wave, 3 stages>: c~0 = A16^T y over the half-precision copy of A (16-byte column "
+                                                          "loads, y in LDS, fp32 sums) — the first of the two passes over A16 of a solve in the screened form: the "
+                                                          "ranking of the columns; state 0 is certified from it like every other state"),
+                               "precision_of_the_copy_read": "fp8 e4m3" if first_fp8 else "fp16",
                                "achieved": f16_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f16_gbs / HBM_PEAK_GBS,
                                "traffic": live["first16"] if live else tj.get("first16_hbm_bytes_per_launch"), "bytes_per_launch": f16_bytes,
                                "avg_launch_ms": f16_ms, "launches_timed": st["first16_launches"], "in_timed_solve": True,
                                "by_survey_8d_fp32_bytes": {"bytes_per_launch": s8d, "achieved": s8d / (f16_ms * 1e-3) / 1e9 if f16_ms > 0 else 0.0,
                                                            "frac": (s8d / (f16_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if f16_ms > 0 else 0.0,
-                                                           "note": "the pass answers the sweep's question (the ranking) from half the bytes: not a bandwidth"},
+                                                           "note": "the pass answers the sweep's question (the ranking) from a %s of the bytes: not a bandwidth" % ("quarter" if first_fp8 else "half")},
                                "traffic_source": live_src if live else
                                                  (("profiles/traffic.json (%s): replayed; NOT measured in this run" % tj.get("first16_source"))
                                                   if tj.get("first16_hbm_bytes_per_launch") else None)}
@@ -997,15 +1012,15 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             },
             "roofline": roof,
             # the two HBM passes a certified solve actually runs (over the fp16 copy of A), the longer one first
-            "fp16_passes_longest_first": (sorted([kk for kk, vv in (("screening_pass", scr_roof), ("first_pass_fp16", first_pass_roof)) if vv],
-                                                 key=lambda kk: -{"screening_pass": scr_roof, "first_pass_fp16": first_pass_roof}[kk]["avg_launch_ms"])
+            "fp16_passes_longest_first": (sorted([kk for kk, vv in (("screening_pass", scr_roof), (fp_key, first_pass_roof)) if vv],
+                                                 key=lambda kk: -{"screening_pass": scr_roof, fp_key: first_pass_roof}[kk]["avg_launch_ms"])
                                           if screened else None),
-            "first_pass_fp16": first_pass_roof,
+            fp_key: first_pass_roof,
             # what a solve's time buys against the HBM roof: the algorithmic bytes of its passes over A16 / the whole solve
             "solve_roofline": ({"bound": "hbm", "algorithmic_bytes_per_solve": f16_bytes + scr_roof["bytes_per_launch"],
                                 "achieved": (f16_bytes + scr_roof["bytes_per_launch"]) / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": (f16_bytes + scr_roof["bytes_per_launch"]) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "note": "bytes = the two passes over the fp16 copy of A (ranking + certificate); the reference moves 4 m n 4 bytes per ITERATION"}
+                                "note": "bytes = the ranking pass (over the %s copy of A) + the certificate pass (over the fp16 copy); the reference moves 4 m n 4 bytes per ITERATION" % ("fp8" if first_fp8 else "fp16")}
                                if (screened and first16) else None),
             # the kernel a solve spends most of its time in
             "dominant_by_time": ({"kernel": "k_res_solve<float> (csrc/resident.hip): all iterations of the path in ONE workgroup — the subset's Gram "
@@ -1036,12 +1051,12 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             "sweeps_per_solve": {"lookahead_64rhs_first": 1.0 if st["sweep64_launches"] else 0.0,
                                  "lookahead_32rhs": max(0.0, n32) if engine >= 1 else 0.0,
                                  "atr_1rhs_fp32": 0 if (screened and first16) else 1,
-                                 "first_pass_fp16": 1 if (screened and first16) else 0,
+                                 fp_key: 1 if (screened and first16) else 0,
                                  "screening_fp16": st["screen_signals"] / max(1, st["solves"]),
                                  "reference_gemv_per_iteration": 4},
             "screened_form": {"signals_certified": int(st["screen_signals"]), "signals_redone_in_the_default_engine": int(st["screen_redone"])},
             # where a solve's time goes (event-timed passes; the rest is selection, the subset Gram matrix and the iteration kernel: latency-bound)
-            "ms_per_solve": (({"total": ms_per_step, "first_pass_fp16": f16_ms, "screening_pass": scr_roof["avg_launch_ms"],
+            "ms_per_solve": (({"total": ms_per_step, fp_key: f16_ms, "screening_pass": scr_roof["avg_launch_ms"],
                                "selection_subset_gram_iterations_and_rest": ms_per_step - f16_ms - scr_roof["avg_launch_ms"],
                                "us_per_iteration": 1e3 * (ms_per_step - f16_ms - scr_roof["avg_launch_ms"]) / max(1.0, st["iterations"] / max(1, st["solves"]))}
                               if first16 else
@@ -1057,7 +1072,12 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             "batched": batched,
             "single_signal_with_gram_matrix": with_gram,
             "iterations_mean": float(iters.mean()),
-            "engine": (("screened form (csrc/screen.hip), both passes over the fp16 copy of A: c~0 = A16^T y ranks the columns, the exact fp32 c0 and "
+            "engine": (("screened form (csrc/screen.hip + resident.hip): c~0 = A8^T y over an FP8 copy of A (0.5 GB) ranks the columns, the exact fp32 c0 and "
+                        "Gram matrix of the 448 chosen ones are formed from A (fp32 MFMA), the whole path is solved by one workgroup on those in "
+                        "fp32, every state of the path — state 0 included — is certified against all columns with a rigorous error bound (state 0 by the "
+                        "ranking pass's own bound, the others by a pass over the fp16 copy of A); columns the certificate cannot clear are re-checked exactly; "
+                        "an uncertified signal is solved again by the default engine") if (first16 and first_fp8) else
+                       ("screened form (csrc/screen.hip), both passes over the fp16 copy of A: c~0 = A16^T y ranks the columns, the exact fp32 c0 and "
                         "Gram matrix of the 448 chosen ones are formed from A (fp32 MFMA), the whole path is solved by one workgroup on those in "
                         "fp32, every state of the path — state 0 included — is certified against all columns with a rigorous error bound by the "
                         "second pass over A16; an uncertified signal is solved again by the default engine") if first16 else
@@ -1135,7 +1155,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             torch.cuda.synchronize()
             f64first5 = {"ms_per_solve": (time.perf_counter() - tf5) / 3 * 1e3}
             h5.set_option("screen_first16", 1)
-            # (the first pass over the fp16 copy, timed: k_scr_first<double y>, 4.3 GB)
+            # (the ranking pass, timed: k_scr_first8<double y> over the fp8 copy, 2.15 GB; k_scr_first over the fp16 copy, 4.3 GB, where fp8 is off)
             h5.set_profiling(True)
             h5.reset_stats()
             for _ in range(3):
@@ -1145,7 +1165,9 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             if stf5["first16_launches"] > 0:
                 f_ms = stf5["first16_ms"] / stf5["first16_launches"]
                 f_b = stf5["first16_bytes"] / stf5["first16_launches"]
-                f64first5["first_pass_fp16"] = {"kernel": "k_scr_first: c~0 = A16^T y (the ranking of the columns)", "ms": f_ms, "bytes_per_launch": f_b,
+                fp8_5 = f_b < 1.5 * float(m5) * n5
+                f64first5["first_pass_fp8" if fp8_5 else "first_pass_fp16"] = {"kernel": ("k_scr_first8: c~0 = A8^T y over the fp8 copy (the ranking of the columns)" if fp8_5
+                                                                                           else "k_scr_first: c~0 = A16^T y (the ranking of the columns)"), "ms": f_ms, "bytes_per_launch": f_b,
                                                 "GB/s": f_b / f_ms / 1e6, "frac_of_8TBs": f_b / f_ms / 1e6 / HBM_PEAK_GBS}
         # configs[4] names OMP: the same signal through ss::omp<double> (parity unpinned: the reference has no OMP); it takes the fp64
         # screened form as well (the sub-context runs k_la_omp)

@@ -1068,7 +1068,7 @@ void account_profile(ss_hip_ctx* ctx, size_t nprof, uint32_t scr_launches, const
         } else if (ctx->prof_kind[i] == 7) {
             ctx->stats.first16_launches += 1;
             ctx->stats.first16_ms += ms;
-            ctx->stats.first16_bytes += (uint64_t)ctx->ldm * ctx->n_pad * 2ull + (uint64_t)ctx->ldm * sizeof(T) + (uint64_t)ctx->n_pad * 4ull;
+            ctx->stats.first16_bytes += (uint64_t)ctx->ldm * ctx->n_pad * (uint64_t)ctx->first_pass_elem_bytes + (uint64_t)ctx->ldm * sizeof(T) + (uint64_t)ctx->n_pad * 4ull;
         } else if (ctx->prof_kind[i] == 4) {
             if (ms > 0.02f) {                          // (a launch of a solve that ended at the first pick is a no-op)
                 ctx->stats.sweep64_launches += 1;
@@ -2925,6 +2925,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "lookahead"))     { ctx->lookahead = (int)value; return SS_HIP_OK; }
     if (!std::strcmp(key, "temporal_cols")) { ctx->temporal_cols = std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "strict_sign"))   { ctx->strict_sign = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_first8")) { ctx->screen_first8 = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "trace"))         { ctx->tracing = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { ctx->zero_on_removal = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
@@ -2968,7 +2969,12 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "gram_single"))   { ctx->gram_single = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "gram_symmetric")) { ctx->gram_symmetric = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_chunk"))   { ctx->batch_chunk = (int)std::max<long>(4, value); return SS_HIP_OK; }
-    if (!std::strcmp(key, "screen_single")) { ctx->screen_single = (int)std::max<long>(0, std::min<long>(2, value)); return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_single")) {
+        // (setting the option also forgets what the context has learnt about its signals: the step-aside counters start again)
+        ctx->screen_single = (int)std::max<long>(0, std::min<long>(2, value));
+        ctx->sub_off_solves = 0; ctx->sub_seen = 0; ctx->sub_failed = 0; ctx->res_off_solves = 0; ctx->res_seen = 0; ctx->res_failed = 0;
+        return SS_HIP_OK;
+    }
     if (!std::strcmp(key, "screen_first16")) { ctx->screen_first16 = value != 0 ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "batch_screen"))  { ctx->batch_screen = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_resident")) { ctx->screen_resident = value ? 1 : 0; return SS_HIP_OK; }
@@ -3000,6 +3006,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "lookahead"))     { *value = ctx->lookahead; return SS_HIP_OK; }
     if (!std::strcmp(key, "temporal_cols")) { *value = ctx->temporal_cols; return SS_HIP_OK; }
     if (!std::strcmp(key, "strict_sign"))   { *value = ctx->strict_sign; return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_first8")) { *value = ctx->screen_first8; return SS_HIP_OK; }
     if (!std::strcmp(key, "trace"))         { *value = ctx->tracing; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { *value = ctx->zero_on_removal; return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_guard"))     { *value = ctx->tie_guard; return SS_HIP_OK; }

@@ -832,7 +832,9 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
         // |c0| < T + eps_0 — certified against lambda_0 (the subset's exact max |c0|) with the margin of every other state
         const float lam0 = (float)LH[0] * 0.9999999f;
         const float yn = sqrtf(slotmeta != nullptr ? slotmeta[0] : meta[5]) * 1.001f;
-        float eps0 = 0.0019726562f * yn * meta[4] + 6.103515625e-05f * sqrtf((float)ldm) * yn * meta[1];
+        // (one signal: the error model of the first pass that ran — k_scr_first / k_scr_first8; a batch: its ranking GEMM over the fp16 copy)
+        float eps0 = slotmeta != nullptr ? 0.0019726562f * yn * meta[4] + 6.103515625e-05f * sqrtf((float)ldm) * yn * meta[1]
+                                         : meta[8] * yn * meta[4] + meta[9] * sqrtf((float)ldm) * yn;
         if (slotmeta != nullptr) eps0 += 6.103515625e-05f * sqrtf((float)ldm) * meta[4] * slotmeta[2];     // (the signal was rounded too: its flush term)
         const float bound0 = lam0 * 0.875f - 1e-12f * lam0;
         const float v0 = (slotmeta != nullptr ? slotmeta[1] : meta[6]) + eps0;

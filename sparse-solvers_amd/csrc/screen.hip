@@ -63,13 +63,14 @@ typedef _Float16 scr_h8 __attribute__((ext_vector_type(8)));
 typedef float scr_v16f __attribute__((ext_vector_type(16)));
 typedef float scr_v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t scr_u4 __attribute__((ext_vector_type(4)));
+typedef float scr_v2f __attribute__((ext_vector_type(2)));
 
 constexpr uint32_t kScrRhs = 96;                 // right-hand sides of the screening pass: states 1 .. nlog - 1 (<= kSbLog - 1 = 79)
 constexpr uint32_t kScrCols = 128;               // dictionary columns per workgroup of the pass
 constexpr uint32_t kScrKc = 128;                 // rows per stage
 constexpr uint32_t kScrPitchB = kScrKc * 2 + 16; // bytes per LDS row: 272 (16-byte reads of 8 consecutive rows: conflict-free)
 constexpr uint32_t kScrWmax = 8192;              // floats of ScreenState::wmax (2 workgroups per CU x 8 waves)
-constexpr uint32_t kScrMeta = 8;                 // floats of ScreenState::meta
+constexpr uint32_t kScrMeta = 16;                // floats of ScreenState::meta ([8], [9]: the error model of the first pass that ran; [10], [11]: the fp8 copy's scale and its inverse)
 constexpr uint32_t kScrTab = 4;                  // floats per state in the table: 1 / (sA s_k), bound_k, 1 / s_k, spare
 constexpr uint32_t kSgSplit = 8;                 // row chunks of the subset Gram matrix (partials summed in order)
 constexpr uint32_t kSgT = 64;                    // its tile: 64 x 64 outputs per workgroup, a 32 x 32 quadrant per wave
@@ -88,6 +89,8 @@ static_assert(kSbLog - 1 <= kScrRhs, "screening pass: right-hand sides");
 
 struct ScreenState {
     __half* a16 = nullptr;       // [n_pad][ldm] fl16(sA * A), column-contiguous like A
+    uint8_t* a8 = nullptr;       // [n_pad][ldm] fl8(sA8 * A) in OCP e4m3: the RANKING pass only (k_scr_first8; made on first use)
+    bool a8_failed = false;      // its allocation did not fit: the half-precision first pass goes on
     float* anorm = nullptr;      // [n_pad] ||a_i||_2, rounded up
     float* meta = nullptr;       // [0] sA  [1] 1 / sA  [2] bits(max |A|)  [3] headroom of the last solve (bits, as uint)
                                  // [4] max ||a_i||  [5] ||y||^2 (k_scr_first)  [6] what the columns left out of the subset stay below (selection)
@@ -193,6 +196,38 @@ void k_a16_convert(const T* __restrict__ At, size_t total8, const float* __restr
     }
 }
 
+// the fp8 (OCP e4m3: 3 mantissa bits, normal range 2^-6 .. 448, subnormal spacing 2^-9) copy for the ranking pass: the largest |a| lands in
+// (112, 224] — far from the format's 448, so nothing saturates — and an entry's rounding error is 2^-4 relative, or 2^-10 absolute (scaled
+// units) below the normal range
+__global__ void k_a8_scale(float* __restrict__ meta)
+{
+    const float amax = __uint_as_float(reinterpret_cast<const uint32_t*>(meta)[2]);
+    int e = 0;
+    if (amax > 0.f && amax < 3.0e38f) e = (int)floorf(log2f(224.f / amax));
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    meta[10] = ldexpf(1.f, e);
+    meta[11] = ldexpf(1.f, -e);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_a8_convert(const T* __restrict__ At, size_t total16, const float* __restrict__ meta, uint8_t* __restrict__ a8)
+{
+    const T s8 = (T)meta[10];
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < total16; i += (size_t)gridDim.x * 256u) {
+        scr_u4 w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T* a = At + 16u * i + 4u * (size_t)q;
+            int p = 0;
+            p = __builtin_amdgcn_cvt_pk_fp8_f32((float)(a[0] * s8), (float)(a[1] * s8), p, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32((float)(a[2] * s8), (float)(a[3] * s8), p, true);
+            w[q] = (uint32_t)p;
+        }
+        *reinterpret_cast<scr_u4*>(a8 + 16u * i) = w;
+    }
+}
+
 // ---- the FIRST pass in half precision: c~0 = A16^T y --------------------------------------------------------------
 // What the subset form needs from A^T y over ALL columns is a ranking (which 448 columns are worth solving on) and the same
 // question as every later state: does anything left out reach lambda_0?  Both are answered from the half-precision copy,
@@ -228,7 +263,8 @@ void k_scr_first(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, uint3
     }
     if (blockIdx.x == 0u) {
         ss = block_sum(ss, sv);
-        if (tid == 0u) meta[5] = ss;
+        // ([8], [9]: this pass's error model for the certificate of state 0 — |c~0 - c0| <= [8] ||a|| ||y|| + [9] sqrt(ldm) ||y||)
+        if (tid == 0u) { meta[5] = ss; meta[8] = 0.0019726562f; meta[9] = 6.103515625e-05f * meta[1]; }
     }
     __syncthreads();
     const float inv_sA = meta[1];
@@ -286,6 +322,108 @@ void k_scr_first(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, uint3
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
             const float v = wave_sum(acc[c]) * inv_sA;
+            const uint32_t col = col0 + (uint32_t)c;
+            if (lane == 0u) c0h[col] = col < n ? v : 0.f;
+            if (col < n) wmx = fmaxf(wmx, fabsf(v));
+        }
+    }
+    if (wmax != nullptr && lane == 0u) wmax[blockIdx.x * 8u + wave] = wmx;
+}
+
+// ---- the first pass over the FP8 copy: c~0 = A8^T y — half the bytes again ---------------------------------------------------------
+// What the first pass is for is a RANKING (which columns are worth solving on) and a bound T + eps_0 on what was left out; nothing it
+// computes is reported.  e4m3 keeps three mantissa bits: |c~0 - c0| <= (2^-4 + ldm 2^-24) sum |a||y| <= 2^-4 x 1.02 ||a|| ||y|| (ldm <=
+// 16384), plus 2^-10 per entry (scaled units) below the normal range — sixteen times the half-precision pass's eps_0, and still a
+// fraction of lambda_0 on the signals this form is for (||y|| ~ 4 lambda_0: eps_0 ~ 0.25 lambda_0); where T + eps_0 does not stay below
+// the bound, state 0 is left to the exact re-check's list like any column the certificate cannot clear, or the signal goes back.
+// Layout as k_scr_first, 16 rows per lane and load: 1024 rows per step; y in LDS so that the four 16-byte reads of a lane are
+// conflict-free: row 1024 s + 16 l + 4 q + e at 1024 s + 256 q + 4 l + e.
+template <typename TY, int CPW, int DEPTH>
+__global__ __launch_bounds__(512, 2)
+void k_scr_first8(const uint8_t* __restrict__ a8, uint32_t ldm, uint32_t n, uint32_t ngroups, const TY* __restrict__ y,
+                  float* __restrict__ meta, float* __restrict__ c0h, uint32_t skew, float* __restrict__ wmax)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* ly = reinterpret_cast<float*>(smem);                  // [ldm]
+    float* sv = ly + ldm;                                        // [16] reduction scratch
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float ss = 0.f;
+    for (uint32_t i = tid * 4u; i < ldm; i += 2048u) {
+        scr_v4f v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)y[i + (uint32_t)e];
+        const uint32_t wq = i & 1023u;                           // = 16 l + 4 q
+        *reinterpret_cast<scr_v4f*>(&ly[(i & ~1023u) + (((wq >> 2) & 3u) << 8) + ((wq >> 4) << 2)]) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss = __builtin_fmaf(v[e], v[e], ss);
+    }
+    if (blockIdx.x == 0u) {
+        ss = block_sum(ss, sv);
+        if (tid == 0u) { meta[5] = ss; meta[8] = 0.06375f; meta[9] = 9.765625e-04f * meta[11]; }
+    }
+    __syncthreads();
+    const float inv_s8 = meta[11];
+    const uint32_t nsteps = ldm >> 10;
+    float wmx = 0.f;
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint32_t col0 = g * (8u * CPW) + wave * CPW;
+        const uint8_t* cb[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) cb[c] = a8 + (size_t)(col0 + c) * ldm + lane * 16u;
+        float acc[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) acc[c] = 0.f;
+        const uint32_t ts0 = (g * skew + wave) % nsteps;
+        scr_u4 a[DEPTH][CPW];
+#define F8_ROW(T) ((ts0 + (T)) >= nsteps ? (ts0 + (T)) - nsteps : (ts0 + (T)))
+#define F8_LOAD(STAGE, T)                                                                           \
+        {                                                                                           \
+            const uint32_t rr_ = F8_ROW(T);                                                         \
+            _Pragma("unroll") for (int c = 0; c < CPW; ++c)                                         \
+                a[STAGE][c] = __builtin_nontemporal_load(reinterpret_cast<const scr_u4*>(cb[c] + (size_t)rr_ * 1024u)); \
+        }
+#define F8_COMPUTE(STAGE, T)                                                                        \
+        {                                                                                           \
+            const uint32_t rr_ = F8_ROW(T);                                                         \
+            scr_v4f yq_[4];                                                                         \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                           \
+                yq_[q] = *reinterpret_cast<const scr_v4f*>(&ly[(rr_ << 10) + 256u * (uint32_t)q + 4u * lane]); \
+            _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                                       \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
+                    const scr_v2f lo_ = __builtin_amdgcn_cvt_pk_f32_fp8((int)a[STAGE][c][q], false); \
+                    const scr_v2f hi_ = __builtin_amdgcn_cvt_pk_f32_fp8((int)a[STAGE][c][q], true);  \
+                    acc[c] = __builtin_fmaf(lo_[0], yq_[q][0], acc[c]);                             \
+                    acc[c] = __builtin_fmaf(lo_[1], yq_[q][1], acc[c]);                             \
+                    acc[c] = __builtin_fmaf(hi_[0], yq_[q][2], acc[c]);                             \
+                    acc[c] = __builtin_fmaf(hi_[1], yq_[q][3], acc[c]);                             \
+                }                                                                                   \
+            }                                                                                       \
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < DEPTH - 1; ++sidx)
+            if ((uint32_t)sidx < nsteps) F8_LOAD(sidx, (uint32_t)sidx)
+        uint32_t t = 0;
+        for (; t + (2 * DEPTH - 1) <= nsteps; t += DEPTH) {
+#pragma unroll
+            for (int sidx = 0; sidx < DEPTH; ++sidx) {
+                F8_LOAD((sidx + DEPTH - 1) % DEPTH, t + (uint32_t)(sidx + DEPTH - 1))
+                F8_COMPUTE(sidx, t + (uint32_t)sidx)
+            }
+        }
+        for (; t < nsteps; t += DEPTH) {
+#pragma unroll
+            for (int sidx = 0; sidx < DEPTH; ++sidx) {
+                if (t + (uint32_t)(sidx + DEPTH - 1) < nsteps) F8_LOAD((sidx + DEPTH - 1) % DEPTH, t + (uint32_t)(sidx + DEPTH - 1))
+                if (t + (uint32_t)sidx < nsteps) F8_COMPUTE(sidx, t + (uint32_t)sidx)
+            }
+        }
+#undef F8_COMPUTE
+#undef F8_LOAD
+#undef F8_ROW
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const float v = wave_sum(acc[c]) * inv_s8;
             const uint32_t col = col0 + (uint32_t)c;
             if (lane == 0u) c0h[col] = col < n ? v : 0.f;
             if (col < n) wmx = fmaxf(wmx, fabsf(v));
@@ -466,7 +604,7 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
         // |c0| < T + eps_0 — certified against lambda_0 (the subset's exact max |c0|) with the margin of every other state
         const float lam0 = st->lambda0;
         const float yn = sqrtf(meta[5]) * 1.001f;
-        const float eps0 = 0.0019726562f * yn * meta[4] + 6.103515625e-05f * sqrtf((float)ldm) * yn * meta[1];
+        const float eps0 = meta[8] * yn * meta[4] + meta[9] * sqrtf((float)ldm) * yn;          // (the first pass's own error model)
         const float bound0 = lam0 * 0.875f - 1e-5f * lam0;
         const float v0 = meta[6] + eps0;
         if (!(v0 <= bound0)) {
@@ -1335,7 +1473,7 @@ void k_s64_residuals(const double* __restrict__ Asub, uint32_t ldm, const double
                 // sub-dictionary has |c~0| < T — certified against the sub-context's exact lambda_0
                 const float lam0 = (float)l_lam[0] * 0.9999999f;
                 const float yn = sqrtf(meta[5]) * 1.001f;
-                const float eps0 = 0.0019726562f * yn * meta[4] + 6.103515625e-05f * sqrtf((float)ldm) * yn * meta[1];
+                const float eps0 = meta[8] * yn * meta[4] + meta[9] * sqrtf((float)ldm) * yn;
                 const float bound0 = lam0 * 0.875f - 1e-12f * lam0;
                 const float v0 = meta[6] + eps0;
                 if (!(v0 <= bound0)) ctl[0] = 1u;
@@ -1387,7 +1525,7 @@ void screen_free(ss_hip_ctx* ctx)
 {
     ScreenState* S = scr_of(ctx);
     if (!S) return;
-    void* ptrs[] = { S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->wmax, S->cabs, S->sublist, S->xsub, S->xd, S->ctl,
+    void* ptrs[] = { S->a8, S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->wmax, S->cabs, S->sublist, S->xsub, S->xd, S->ctl,
                      S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs, S->fl, S->sub256, S->gs64, S->gs64_part, S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X, S->rl_D };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1497,7 +1635,41 @@ bool screen_first16_usable(const ss_hip_ctx* ctx)
     return ctx->is_f64 ? scr_first_attr<double>() : scr_first_attr<float>();
 }
 
-// c~0 = A16^T y / sA into c0h ([n_pad] floats), ||y||^2 into meta[5]
+// The fp8 copy for the ranking pass (option screen_first8, default 1): made the first time a first pass is launched on a context whose
+// rows allow it (ldm a multiple of 1024); a failed allocation leaves the half-precision pass in place.
+template <typename TA>
+static bool screen_first8_ready(ss_hip_ctx* ctx, ScreenState* S)
+{
+    if (ctx->screen_first8 == 0 || ctx->ldm % 1024u != 0u || S->a8_failed) return false;
+    if (S->a8 != nullptr) return true;
+    const uint32_t ldm = ctx->ldm, np = ctx->n_pad;
+    size_t free_b = 0, total_b = 0;
+    const size_t bytes = (size_t)np * ldm;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)2 << 30) > free_b || hipMalloc(reinterpret_cast<void**>(&S->a8), bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        S->a8 = nullptr;
+        S->a8_failed = true;
+        return false;
+    }
+    hipStream_t s = ctx->stream;
+    const size_t total16 = bytes / 16u;
+    hipLaunchKernelGGL(k_a8_scale, dim3(1), dim3(1), 0, s, S->meta);
+    hipLaunchKernelGGL((k_a8_convert<TA>), dim3((unsigned)std::min<size_t>((total16 + 255) / 256, 65536)), dim3(256), 0, s, static_cast<const TA*>(ctx->At), total16,
+                       (const float*)S->meta, S->a8);
+    if (hipGetLastError() != hipSuccess) { (void)hipFree(S->a8); S->a8 = nullptr; S->a8_failed = true; return false; }
+    return true;
+}
+template <typename TY> static bool scr_first8_attr()
+{
+    static const bool ok = [] {
+        const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_first8<TY, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64) == hipSuccess;
+        if (!a) (void)hipGetLastError();
+        return a;
+    }();
+    return ok;
+}
+
+// c~0 = A16^T y / sA (or A8^T y / sA8) into c0h ([n_pad] floats), ||y||^2 into meta[5], the pass's error model into meta[8], meta[9]
 template <typename TY>
 static hipError_t launch_scr_first(ss_hip_ctx* ctx, ScreenState* S, const TY* y, float* c0h, float* wmax = nullptr, uint32_t* nwmax = nullptr)
 {
@@ -1506,6 +1678,14 @@ static hipError_t launch_scr_first(ss_hip_ctx* ctx, ScreenState* S, const TY* y,
     if (lds > 65536u && !scr_first_attr<TY>()) return hipErrorInvalidConfiguration;
     const uint32_t grid = std::min<uint32_t>(np / 32u, (uint32_t)ctx->num_cus * 2u);
     if (grid * 8u > kScrWmax) wmax = nullptr;
+    if (screen_first8_ready<TY>(ctx, S) && (lds <= 65536u || scr_first8_attr<TY>())) {
+        hipLaunchKernelGGL((k_scr_first8<TY, 4, 3>), dim3(grid), dim3(512), lds, ctx->stream, (const uint8_t*)S->a8, ldm, (uint32_t)ctx->n, np / 32u, y,
+                           S->meta, c0h, scr_skew() == 0u ? 0u : 5u, wmax);
+        if (nwmax != nullptr) *nwmax = wmax != nullptr ? grid * 8u : 0u;
+        ctx->first_pass_elem_bytes = 1;
+        return hipGetLastError();
+    }
+    ctx->first_pass_elem_bytes = 2;
     hipLaunchKernelGGL((k_scr_first<TY, 4, 3>), dim3(grid), dim3(512), lds, ctx->stream, (const __half*)S->a16, ldm, (uint32_t)ctx->n, np / 32u, y,
                        S->meta, c0h, scr_skew() == 0u ? 0u : 5u, wmax);
     if (nwmax != nullptr) *nwmax = wmax != nullptr ? grid * 8u : 0u;

@@ -251,6 +251,8 @@ struct ss_hip_ctx {
     // G's memory reserved ahead of its first use: a context that has received a batch of >= 4 signals will likely receive the large
     // one that forms G — the allocation (the driver clears fresh VRAM: ~0.5 s for 17 GiB) then runs on a helper thread beside the
     // batches before it instead of in front of the first large one (option gram_reserve; only where G is a small share of the HBM)
+    int screen_first8 = 1;                   // the screened form's ranking pass over an fp8 copy of A (screen.hip: k_scr_first8); 0 = over the fp16 copy
+    int first_pass_elem_bytes = 2;           // what the last reduced-precision first pass read per entry of A (statistics)
     void* gram_reserve_thread = nullptr;     // std::thread*
     float* gram_reserved = nullptr;          // what that thread obtained (read after join)
     int gram_reserve = 1;

@@ -29,19 +29,21 @@ SHAPES = [(1024, 8192, 16), (1024, 8192, 40), (768, 2048, 20), (2048, 16384, 48)
 CERTIFIED_SHAPES = [(1024, 8192, 16), (4096, 8192, 64), (1536, 6000, 30)]
 
 
-@pytest.mark.parametrize("first16", [1, 0])
+@pytest.mark.parametrize("first16", [2, 1, 0])
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("shape", SHAPES)
 def test_screened_form_vs_oracle(sship, shape, mode, first16):
     """option screen_single = 2 (any shape the form can run on): well-posed Gaussian problems are certified and equal the
-    oracle — iterations, support, coefficients, breakpoints — in both modes, with the first pass (A^T y) over the
-    half-precision copy (option screen_first16, the default where the row count allows) and over the fp32 dictionary."""
+    oracle — iterations, support, coefficients, breakpoints — in both modes, with the first pass (A^T y) over the fp8 copy
+    (2: option screen_first8, the default where the padded row count is a multiple of 1024), over the half-precision copy
+    (1: option screen_first16, multiples of 512) and over the fp32 dictionary (0)."""
     m, n, k = shape
     A, y, x0, sup = make_gaussian_problem(9100 + m + k, m, n, k, np.float32)
     with sship.Homotopy(A) as h:
         flags = set_mode(h, mode)
         h.set_option("screen_single", 2)
-        h.set_option("screen_first16", first16)
+        h.set_option("screen_first16", 1 if first16 else 0)
+        h.set_option("screen_first8", 1 if first16 == 2 else 0)
         h.set_option("trace", 1)
         h.reset_stats()
         xg, itg, eg = h.solve(y, 1e-3, 4 * k)
@@ -192,7 +194,7 @@ def test_screen_certificate_is_a_bound(sship):
     assert worst <= st["screen_headroom"] + 1e-3         # the device's figure (|c~| + eps) / bound dominates |c| / (0.875 lambda)... loosely
 
 
-@pytest.mark.parametrize("first16", [1, 0])
+@pytest.mark.parametrize("first16", [2, 1, 0])
 @pytest.mark.parametrize("shape", [(1024, 16384, 24), (1536, 9000, 40), (2048, 16384, 60), (1024, 12000, 16), (4096, 16384, 104)])
 def test_screened_form_fp64_vs_oracle(sship, shape, first16):
     """fp64: the path is solved by the fp64 engine on a sub-dictionary (the 2048 columns with the largest |c0| — ranked by the
@@ -204,7 +206,8 @@ def test_screened_form_fp64_vs_oracle(sship, shape, first16):
     A, y, x0, sup = make_gaussian_problem(9400 + m + k, m, n, k, np.float64)
     with sship.Homotopy(A) as h:
         h.set_option("screen_single", 2)
-        h.set_option("screen_first16", first16)
+        h.set_option("screen_first16", 1 if first16 else 0)      # (2: the ranking pass over the fp8 copy, 1: over the fp16 copy, 0: the fp64 sweep)
+        h.set_option("screen_first8", 1 if first16 == 2 else 0)
         h.reset_stats()
         xg, itg, eg = h.solve(y, 1e-9, 4 * k)
         st = h.stats()
@@ -638,7 +641,39 @@ def test_bench_measures_traffic_in_the_run():
     note("test_bench_measures_traffic_in_the_run", got=got)
     if got is None:
         pytest.skip("no rocprofv3 --pmc run possible here")
-    alg_first = 8192 * 65536 * 2 + 8192 * 4 + 65536 * 4
+    alg_first = 8192 * 65536 * 1 + 8192 * 4 + 65536 * 4          # (the ranking pass reads the fp8 copy: k_scr_first8)
     alg_screen = 8192 * 65536 * 2 + 96 * 8192 * 2 + 65536 * 4
     assert 0.99 * alg_first <= got["first16"] <= 1.02 * alg_first
     assert 0.99 * alg_screen <= got["screen"] <= 1.02 * alg_screen
+
+
+def test_fp8_ranking_pass_stays_inside_its_error_model(sship):
+    """The ranking pass over the fp8 (e4m3) copy of A reports nothing, but state 0 is certified from ITS bound: every column it left
+    out has |c0| <= T + eps_0 with eps_0 = 2^-4 x 1.02 ||a|| ||y|| + the flush term.  Here the bound is checked from outside: on
+    dictionaries with entries over many binades (so that the subnormal range of the format is used too) every signal the form certifies
+    with the fp8 pass must be the oracle's — and the same signals with the fp16 pass and the fp32 sweep give the same answer."""
+    import torch
+    rng = np.random.default_rng(9900)
+    m, n, k = 2048, 16384, 24
+    scale = np.exp2(rng.integers(-14, 1, size=(m, n))).astype(np.float32)          # entries over fifteen binades
+    A = (rng.standard_normal((m, n)).astype(np.float32) * scale)
+    A /= np.linalg.norm(A, axis=0, keepdims=True)
+    outs = {}
+    sup = np.sort(rng.choice(n, k, replace=False))
+    x0 = np.zeros(n, np.float32)
+    x0[sup] = 1.0 + np.abs(rng.standard_normal(k)).astype(np.float32)
+    y = (A.astype(np.float64) @ x0).astype(np.float32)
+    for first in (2, 1, 0):
+        with sship.Homotopy(A) as h:
+            h.set_option("screen_single", 2)
+            h.set_option("screen_first16", 1 if first else 0)
+            h.set_option("screen_first8", 1 if first == 2 else 0)
+            h.reset_stats()
+            outs[first] = h.solve(y, 1e-3, 4 * k) + (h.stats(),)
+    xo, ito, eo = oracle.homotopy(A, y, 1e-3, 4 * k)
+    note("test_fp8_ranking_pass", certified={f: o[3]["screen_signals"] for f, o in outs.items()}, headroom={f: o[3]["screen_headroom"] for f, o in outs.items()})
+    for first, (x, it, e, st) in outs.items():
+        assert_parity(x, it, e, xo, ito, eo, np.float32)
+    assert outs[2][3]["screen_signals"] == 1 and outs[1][3]["screen_signals"] == 1
+    # (certified by either pass, the path is the subset solve's: the same bits)
+    assert np.array_equal(outs[2][0], outs[1][0]) and outs[2][1] == outs[1][1]

@@ -94,7 +94,10 @@ def main():
         targets = [("gemm32" if "gemm32" in KERNEL_KEY else "sweep2", KERNEL_KEY, None)]
     else:
         # the screened form of a single signal (csrc/screen.hip): its two passes over the fp16 copy of A, the fp32 GEMV c = A^T y (untimed run)
-        targets = [("first16", "k_scr_first", 8192 * 65536 * 2 + 8192 * 4 + 65536 * 4),
+        # (the ranking pass: over the fp8 copy, k_scr_first8 — or over the fp16 copy, k_scr_first, where option screen_first8 is off;
+        # whichever did not run has no rows in the counter files and is skipped)
+        targets = [("first16", "k_scr_first8<", 8192 * 65536 * 1 + 8192 * 4 + 65536 * 4),
+                   ("first16", "k_scr_first<", 8192 * 65536 * 2 + 8192 * 4 + 65536 * 4),
                    ("sweep1", "k_sweep<float, 1", 8192 * 65536 * 4 + 8192 * 4 + 65536 * 4),
                    ("screen", "k_scr_gemm", 8192 * 65536 * 2 + 96 * 8192 * 2 + 65536 * 4),
                    ("gemm32", "k_gemm32_tn_f32<128, 256, 3", 57344 * 8192 * 4 + 32 * 8192 * 4 + 32 * 57344 * 4)]
