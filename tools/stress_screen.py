@@ -17,6 +17,7 @@ import oracle  # noqa: E402
 import sship  # noqa: E402
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+ONLY = set(int(v) for v in os.environ.get("STRESS_ONLY", "").split(",") if v.strip())
 rng = np.random.default_rng(20261004)
 cert = redone = bad = 0
 worst = 0.0
@@ -43,6 +44,8 @@ for case in range(count):
     y = y.astype(dt)
     tol = 1e-9 if f64 else 1e-3
     budget = 3 * k + 8
+    if ONLY and case not in ONLY:                     # (STRESS_ONLY="7,85": those cases only — the generator still walks every case)
+        continue
     flags = oracle.SPARSE_NOTRANS | ((oracle.ZERO_ON_REMOVAL | oracle.TIE_GUARD) if fixes else 0)
     with sship.Homotopy(A, device=0) as h:
         if fixes:
@@ -78,7 +81,7 @@ for case in range(count):
         bad += 1
     print("%3d %s m %4d n %5d k %3d signed %d noise %-6g fixes %d | %s headroom %.3f | iter %d / default %d / oracle %d | rel %.2e (default %.2e) %s"
           % (case, "f64" if f64 else "f32", m, n, k, signed, noise, fixes, "certified " if certified else "handed back", st["screen_headroom"], it, itd, ito,
-             rel, reld, "" if ok else "  <-- BAD"), flush=True)
+             rel, reld, "" if ok else "  <-- BAD"), " ".join("%s" % k_[4:] for k_, v_ in st.items() if k_.startswith("why_") and v_), flush=True)
 print("certified %d, handed back %d, bad %d of %d; largest headroom among the certified %.3f" % (cert, redone, bad, count, worst))
 print("why not certified (a signal may count in several; fp64 signals count per tier):", dict(sorted(why_total.items())))
 for kind in sorted(by_kind):
