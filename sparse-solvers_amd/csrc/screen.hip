@@ -1602,6 +1602,7 @@ bool screen_form_usable(ss_hip_ctx* ctx)
     hipStream_t s = ctx->stream;
     const float* At = static_cast<const float*>(ctx->At);
     (void)hipMemsetAsync(S->meta, 0, kScrMeta * sizeof(float), s);
+    (void)hipMemsetAsync(S->fl, 0, (size_t)kScrFlWords * sizeof(uint32_t), s);
     (void)hipMemsetAsync(S->r16, 0, (size_t)kScrRhs * ldm * sizeof(__half), s);
     hipLaunchKernelGGL((k_a16_stats<float>), dim3(np), dim3(256), 0, s, At, ldm, S->anorm, S->meta);
     hipLaunchKernelGGL(k_a16_scale, dim3(1), dim3(1), 0, s, S->meta);
@@ -1864,6 +1865,7 @@ bool screen64_usable(ss_hip_ctx* ctx)
         alloc(reinterpret_cast<void**>(&S->rl_X), (size_t)RC::LOGCAP * RC::PCAP * sizeof(double));
         alloc(reinterpret_cast<void**>(&S->rl_D), (size_t)RC::LOGCAP * RC::PCAP * sizeof(double));
         alloc(reinterpret_cast<void**>(&S->fl), (size_t)kScrFlWords * sizeof(uint32_t));
+        if (ok) (void)hipMemsetAsync(S->fl, 0, (size_t)kScrFlWords * sizeof(uint32_t), ctx->stream);
     }
     if (ok) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scr_gemm<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2180,6 +2182,7 @@ void screen_debug_recheck(ss_hip_ctx* ctx)
     uint32_t hdr[kSbLog * 8];
     if (hipMemcpy(hdr, B.hdr, sizeof(hdr), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
     const uint32_t k = w[kScrFlCap + 6];
+    if (k >= kSbLog) return;                                     // (the list was not written in this attempt: the solve declined before its residuals)
     float cv, qv, lam, gam, lam1 = 0.f;
     std::memcpy(&cv, &w[kScrFlCap + 7], 4); std::memcpy(&qv, &w[kScrFlCap + 8], 4);
     std::memcpy(&lam, &hdr[k * 8 + 4], 4); std::memcpy(&gam, &hdr[k * 8 + 5], 4);
