@@ -838,7 +838,7 @@ inline hipError_t sub_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t) 
 
 // one signal in the screened form (screen.hip): no G — the subset's own Gram matrix from A, then one pass over the fp16 copy of A
 inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, hipEvent_t e0, hipEvent_t e1,
-                             hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5)
+                             hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5, bool omp)
 {
     const size_t need = sub_buffer_bytes(1);
     if (ctx->sub_buf_bytes < need) {
@@ -853,9 +853,9 @@ inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, u
         HIPCHK(hipMemsetAsync(ctx->sub_dbg, 0, 16 * sizeof(unsigned long long), ctx->stream));
     }
     // (with the state mirrored to mapped host memory the epilogue launch applies the certificate's verdict: no k_sub_finish)
-    return launch_screen_form(ctx, ws, tol, max_iter, first16, ctx->hs_mapped == nullptr, e0, e1, e2, e3, e4, e5);
+    return launch_screen_form(ctx, ws, tol, max_iter, first16, ctx->hs_mapped == nullptr, e0, e1, e2, e3, e4, e5, omp);
 }
-inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, bool) { return hipErrorInvalidConfiguration; }
 // (typed shims of the fp64 screened form: never reached for float)
 inline hipError_t scr64_gather(ss_hip_ctx* ctx, const double* c0, const double* y, hipEvent_t e0, hipEvent_t e1) { return screen64_gather(ctx, c0, y, e0, e1); }
 inline hipError_t scr64_gather(ss_hip_ctx*, const float*, const float*, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
@@ -1161,8 +1161,9 @@ Forms choose_forms(ss_hip_ctx* ctx, const Route& route, const T* y, void* rec_ou
     // state of its path then screened against all columns by ONE pass over a half-precision copy of A with a rigorous error
     // bound, instead of the default engine's two fp32 passes.  It stands in for the default speculative engine only
     // (la_fused = 3 with the early form: contexts whose options ask for another engine get that engine).
-    f.scr1 = f.la && sizeof(T) == 4 && !route.no_sub && ctx->la_fused >= 3 && ctx->early_solo && !ctx->early_probe &&
-             ctx->solo_subset == 256 && (!f.sub1 || screen_first16_usable(ctx)) && screen_form_usable(ctx);
+    // (OMP — ss::omp<float> — takes it too: the resident kernel's OMP statement on the same subset, the same certificate; not with a trace)
+    f.scr1 = (f.la || (f.la_omp && ctx->screen_resident && !ctx->tracing)) && sizeof(T) == 4 && !route.no_sub && ctx->la_fused >= 3 && ctx->early_solo &&
+             !ctx->early_probe && ctx->solo_subset == 256 && (!f.sub1 || screen_first16_usable(ctx)) && screen_form_usable(ctx);
     if (f.scr1) f.sub1 = false;
     // fp64: the same certificate around the fp64 engine — the path is solved by a context of its own on the 2048 columns with
     // the largest |c0| (passes and iterations on 1.6 % of the dictionary), its logged states are screened against all columns
@@ -1499,7 +1500,7 @@ int solve_once(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 Route r = route; r.no_sub = true;
                 return retry(r);
             }
-        } else if (la_omp) {
+        } else if (la_omp && !scr1) {
             Lookahead<T>::ensure(ctx, ws, kcap);
             enter_full_gram();
             uint32_t nb1 = 0;
@@ -1509,7 +1510,7 @@ int solve_once(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             if (!ws.gram_is_full) HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // nothing cached yet
         } else if (sub1 || scr1) {
             Lookahead<T>::ensure(ctx, ws, kcap);
-            HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y
+            if (!omp) HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y (OMP: done above)
             // (the screened form's first pass — A^T y over all columns — reads the half-precision copy too: screen.hip, k_scr_first)
             const bool first16 = scr1 && screen_first16_usable(ctx);
             uint32_t nb1 = 0;
@@ -1525,7 +1526,7 @@ int solve_once(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
                 if (prof && first16) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(7); ++nprof; }
                 if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); e4 = prof_event(ctx, 2 * nprof + 2); e5 = prof_event(ctx, 2 * nprof + 3); }
-                HIPCHK(scr_single(ctx, ws, tol, max_iter, first16, e0, e1, e2, e3, e4, e5));
+                HIPCHK(scr_single(ctx, ws, tol, max_iter, first16, e0, e1, e2, e3, e4, e5, omp));
                 if (prof) { ctx->prof_kind.push_back(6); ctx->prof_kind.push_back(8); nprof += 2; }      // (6 = the screening pass, 8 = the path kernel)
             }
         } else if (la) {

@@ -574,7 +574,7 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
                      const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pcol,
                      const float* __restrict__ LX, float tol, const float* __restrict__ meta, __half* __restrict__ r16,
                      float* __restrict__ rn2p, float* __restrict__ tab, uint32_t* __restrict__ headroom, DevState* __restrict__ st,
-                     int first16, uint32_t* __restrict__ fl)
+                     int first16, uint32_t* __restrict__ fl, int omp = 0)
 {
     // fl (one signal, may be null): the list of columns left to the exact re-check (k_scr_recheck) — cleared here; a state 0 the
     // half-precision first pass cannot certify by its threshold alone is left to that list too (its columns are found by k_scr_gemm)
@@ -696,12 +696,13 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
             // Otherwise (noise: the path crosses the tolerance on a regular step) that step is certified like any other.
             const bool ls_jump = final_state && !(lam > tol) && !(lam_exp > 2e-6f * lam0);
             float bound;
-            if (ls_jump) bound = tol * 0.9375f - slack;
+            if (omp) bound = (final_state && !(lam > tol) ? tol * 0.9375f : lam * 0.875f) - slack;      // (OMP: the pick is the largest |c| — nothing outside may reach it; the state it ends in: the tolerance)
+            else if (ls_jump) bound = tol * 0.9375f - slack;
             else bound = fminf(lam, lam_exp) * 0.875f - slack;
             // only REGULAR paths are certified: every step inserts a column and lambda goes down.  On a path with removals, or one
             // the first-step sign quirk has derailed, steps of rounding size decide what is toggled next, and the subset's Gram
             // matrix is the default engine's only to rounding (see k_s64_dense): those go back to that engine
-            if (hp[3] == 0u || lam > __uint_as_float(hp[4]) * 1.00001f) {
+            if (!omp && (hp[3] == 0u || lam > __uint_as_float(hp[4]) * 1.00001f)) {
                 bound = -1.f;
                 atomicOr(&st->sub_reason, kReasonIrregular);
                 __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (the screening pass does not run for it)
@@ -1694,8 +1695,12 @@ static hipError_t launch_scr_first(ss_hip_ctx* ctx, ScreenState* S, const TY* y,
 }
 
 hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, bool finish, hipEvent_t e0,
-                              hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5)
+                              hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5, bool omp)
 {
+    // (omp: orthogonal matching pursuit on the same subset — k_res_solve<float, OMP> logs its states the same way, the certificate reads
+    // "nothing outside the subset reaches the pick's |c|"; the exact re-check decides Homotopy's predicates and stays out)
+    if (omp && !(ctx->screen_resident && res_solve_usable<float>())) return hipErrorInvalidConfiguration;
+    uint32_t* const fl = (ctx->screen_recheck && !omp) ? scr_of(ctx)->fl : nullptr;
     ScreenState* S = scr_of(ctx);
     if (S == nullptr || ctx->sub_buf == nullptr) return hipErrorInvalidConfiguration;
     const SubBufs B = sub_bufs(ctx, 1);
@@ -1720,25 +1725,25 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     if (ctx->screen_resident && res_solve_usable<float>()) {
         const ResLog<float> log{ B.hdr, nullptr, B.pcol, B.LX, B.LD };
         (void)launch_res_solve<float>(ctx, 1, (const float*)S->gs, kSbS, 0, (const float*)ws.c0, 0, (const uint32_t*)B.sub, tol, max_iter, ws.dims.kcap, log, ws.x, 0,
-                                      ws.gam, ws.touched, ws.st, ws.trace, ws.trace_cap, false);
+                                      ws.gam, ws.touched, ws.st, ws.trace, ws.trace_cap, omp);
     } else
         (void)launch_sub_solve(ctx, ws, B, 1, (const float*)S->gs, kSbS, first16 ? 2 : 1, ws.c0, tol, max_iter);
     if (e5) (void)hipEventRecord(e5, s);
     hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs,
                        (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
                        (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, first16 ? 1 : 0,
-                       ctx->screen_recheck ? S->fl : (uint32_t*)nullptr);
+                       fl, omp ? 1 : 0);
     if (e2) (void)hipEventRecord(e2, s);
     hipLaunchKernelGGL(k_scr_gemm<3>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
                        (const float*)S->anorm, (const float*)S->rn2p, kScrRhs, (const float*)S->tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
-                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 0u, ctx->screen_recheck ? S->fl : (uint32_t*)nullptr,
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 0u, fl,
                        first16 ? (const float*)ws.c0 : (const float*)nullptr);
     if (e3) (void)hipEventRecord(e3, s);
     // the columns that pass left undecided, exactly (an empty list: the launch returns at once)
-    if (ctx->screen_recheck)
+    if (fl != nullptr)
         hipLaunchKernelGGL((k_scr_recheck<float>), dim3(kScrRecheckWgs), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs, (const uint32_t*)B.hdr, (const float*)nullptr,
                            (const uint32_t*)B.pcol, (const float*)B.LX, (const float*)B.LD, S->fl, tol, ctx->tie_guard, ws.st);
-    if (ctx->screen_recheck)
+    if (fl != nullptr)
         hipLaunchKernelGGL((k_scr_repair<float>), dim3(1), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs, (const uint32_t*)B.hdr, (const float*)nullptr,
                            (const uint32_t*)B.pcol, (const float*)B.LX, (const float*)B.LD, (const uint32_t*)S->fl, ws.x, ws.gam, ws.touched, ws.st, ws.trace,
                            ws.trace_cap);

@@ -449,7 +449,8 @@ hipError_t launch_select_top(ss_hip_ctx* ctx, const float* v, uint32_t n, uint32
 bool screen_form_usable(ss_hip_ctx* ctx);                 // shape / option test + one-time preparation (fp16 copy of A, column norms)
 bool screen_first16_usable(const ss_hip_ctx* ctx);        // ... with the FIRST pass (A^T y) over the half-precision copy too
 hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, bool finish, hipEvent_t e0 = nullptr,
-                              hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr, hipEvent_t e4 = nullptr, hipEvent_t e5 = nullptr);
+                              hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr, hipEvent_t e4 = nullptr, hipEvent_t e5 = nullptr,
+                              bool omp = false);
 // a batch chunk of nslots <= screen_batch_cap() signals in the screened form: c0 = A^T y of every slot in c0_all ([nslots][n_pad]), the
 // signals in ws.y; the slots' verdicts in their states (k_sub_finish) like the subset form's
 uint32_t screen_batch_cap();

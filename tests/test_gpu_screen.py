@@ -282,6 +282,37 @@ def test_screened_form_fp64_omp(sship, shape, first16):
     assert np.abs(xg[sup] - ls).max() <= 1e-10 * np.abs(ls).max()
 
 
+@pytest.mark.parametrize("first16", [2, 0])
+@pytest.mark.parametrize("shape", [(1024, 8192, 16), (2048, 16384, 48), (1536, 6000, 30)])
+def test_screened_form_fp32_omp(sship, shape, first16):
+    """OMP in fp32 (ss::omp<float>; no reference implementation: pinned against this library's default OMP engine and numpy's least
+    squares on the planted support) through the screened form: k_res_solve<float, OMP> on the 448 best-ranked columns, the certificate
+    is that no column outside the subset reaches the pick's |c| at any state."""
+    m, n, k = shape
+    rng = np.random.default_rng(5100 + k)
+    A = (rng.standard_normal((m, n)) / np.sqrt(m)).astype(np.float32)
+    sup = np.sort(rng.choice(n, k, replace=False))
+    x0 = np.zeros(n, np.float32)
+    x0[sup] = (1.0 + np.abs(rng.standard_normal(k))).astype(np.float32)
+    y = (A.astype(np.float64) @ x0).astype(np.float32)
+    with sship.Homotopy(A) as h:
+        h.set_option("screen_single", 2)
+        h.set_option("screen_first16", 1 if first16 else 0)
+        h.reset_stats()
+        xg, itg, eg = h.solve_omp(y, 1e-3, 4 * k)
+        st = h.stats()
+        h.set_option("screen_single", 0)
+        xd, itd, ed = h.solve_omp(y, 1e-3, 4 * k)
+    note("test_screened_form_fp32_omp", shape=list(shape), first=first16, certified=st["screen_signals"], redone=st["screen_redone"],
+         headroom=st["screen_headroom"], why={k_: v for k_, v in st.items() if k_.startswith("why_") and v})
+    assert st["screen_signals"] + st["screen_redone"] == 1
+    assert st["screen_signals"] == 1 and st["screen_resident"] == 1, "a well-posed OMP problem must be certified"
+    assert itg == itd == k and np.array_equal(np.nonzero(xg)[0], sup)
+    assert np.abs(xg - xd).max() <= 2e-5 * np.abs(xd).max()
+    ls = np.linalg.lstsq(A[:, sup].astype(np.float64), y.astype(np.float64), rcond=None)[0]
+    assert np.abs(xg[sup] - ls).max() <= 2e-5 * np.abs(ls).max()
+
+
 def test_screened_form_random_problems(sship):
     """tools/stress_screen.py in small: random shapes, fp32 and fp64, signed coefficients (the reference's first-step sign quirk
     derails those paths), noise, both modes.  Whatever the form certifies must be the oracle's; whatever it hands back must be the
