@@ -433,6 +433,19 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    certified like every other state: T + eps_0 <= 7/8 lambda_0 with T above every |c~0| left out and
  *                    eps_0 = 2^-9 max ||a_i|| ||y|| + the flush term.  No fp32 pass over A is left in a certified solve
  *                    (ss_hip_stats::first16_*); 0 = c0 = A^T y by the fp32 sweep
+ *   "screen_first8"  1 (default) = where the padded row count is a multiple of 1024 that first pass reads an FP8 (OCP e4m3) copy of A instead of the
+ *                    fp16 copy (a quarter of A's bytes again, made on the first such solve): the pass only RANKS the columns and bounds what it
+ *                    left out — eps_0 = 2^-4 x 1.02 max ||a_i|| ||y|| + its flush term, sixteen times the fp16 pass's, written by the pass
+ *                    itself for the state-0 certificate; nothing it computes is reported.  fp32 and fp64 contexts; 0 = the fp16 copy
+ *                    (no fp8 copy is made); an allocation that does not fit does the same by itself
+ *   "screen_resident" 1 (default) = the path of the screened form runs in the one-workgroup resident kernel (csrc/resident.hip; fp32: 448 columns,
+ *                    72 positions; fp64: 256 columns, 136 positions — the fp64 resident tier); 0 = fp32: k_sub_solve, fp64: the sub-dictionary
+ *                    tier only.  OMP takes the screened form only with 1
+ *   "screen_recheck" 1 (default) = columns the half-precision certificate cannot clear are decided exactly from A in the solve's precision
+ *                    (k_scr_recheck) and a last step an outside column stops early is repaired (k_scr_repair); 0 = such signals go back
+ *   "gram_reserve"   1 (default) = the memory of G = A^T A is reserved on a helper thread when the first batch of >= 4 signals arrives, so that
+ *                    the batch that forms G does not wait for the allocation; 0 = allocated on first use
+ *   "colshard_fail_prepare" test aid: 1 = the next column-sharded solve fails on this rank while it prepares (the ranks must all leave)
  *   "ro_slots"       1..8 (default 8; fp64 contexts use at most 4): signals the reference-order engine runs in lock-step per pass over A (batches in
  *                    engine 3, a batch's tie re-runs); every signal's words are those of its own solve
  *   "ro_staged"      1 (default) = its sweep stages the dictionary through LDS (coalesced loads); 0 = direct 16-byte
