@@ -815,10 +815,7 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     // around — the sum's order is free here — so that the 512 workgroups do not walk the same 256-byte phase of their
     // 16-KiB-strided columns together (the HBM channels are selected by those address bits)
     const uint32_t nstage = ldm / kScrKc;
-    // (skew: multiplier in the low half, a WINDOW in the high half — offsets drawn from the first `window` stages only, so that the
-    // workgroups in flight walk nearly the same rows of the right-hand sides at a time: their block then stays in L2)
-    const uint32_t swin = skew >> 16;
-    const uint32_t sbase = (blockIdx.y * (skew & 0xffffu)) % ((swin != 0u && swin < nstage) ? swin : nstage);
+    const uint32_t sbase = (blockIdx.y * skew) % nstage;
 #define SCR_ROW(S) ((sbase + (S) >= nstage ? sbase + (S) - nstage : sbase + (S)) * kScrKc)
     SCR_LOAD(pa0, pr0, SCR_ROW(0u))
     if constexpr (TWO) {
@@ -1225,7 +1222,7 @@ void k_scr_gemm_b(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, cons
         }                                                                                                         \
     }
     const uint32_t nstage = ldm / kScrKc;
-    const uint32_t sbase = (blockIdx.y * (skew & 0xffffu)) % nstage;
+    const uint32_t sbase = (blockIdx.y * skew) % nstage;
 #define SCB_ROW(S) ((sbase + (S) >= nstage ? sbase + (S) - nstage : sbase + (S)) * kScrKc)
     SCB_LOAD(pa0, pr0, SCB_ROW(0u))
     SCB_LOAD(pa1, pr1, SCB_ROW(1u))
@@ -1553,11 +1550,7 @@ void screen_free(ss_hip_ctx* ctx)
 // row offset of workgroup b = (b * skew) mod stages (developer aid: SS_HIP_SCR_SKEW overrides the multiplier)
 static uint32_t scr_skew()
 {
-    static const uint32_t v = [] {
-        const char* e = std::getenv("SS_HIP_SCR_SKEW");
-        const char* w = std::getenv("SS_HIP_SCR_SKEW_WIN");
-        return ((e ? (uint32_t)std::atoi(e) : 29u) & 0xffffu) | ((w ? (uint32_t)std::atoi(w) : 0u) << 16);
-    }();
+    static const uint32_t v = [] { const char* e = std::getenv("SS_HIP_SCR_SKEW"); return e ? (uint32_t)std::atoi(e) : 29u; }();
     return v;
 }
 
