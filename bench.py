@@ -629,6 +629,7 @@ def run_single(args, h, A, A_host, dev, rank, local_rank, world, use_dist, torch
             del Xh_
             return {"signals": nh, "ms_per_solve_incl_hand_backs": dth / nh * 1e3, "ms_per_solve_default_engine_only": dth0 / nh * 1e3,
                     "certified": int(sth["screen_signals"]), "certified_by_the_exact_recheck": int(sth["screen_recheck"]),
+                    "certified_by_the_rescue": int(sth["screen_rescued"]), "rescues_tried": int(sth["screen_rescue_tried"]),
                     "handed_back": int(sth["screen_redone"]), "not_tried_form_stepped_aside": nh - int(sth["screen_signals"]) - int(sth["screen_redone"]),
                     "certified_fraction": sth["screen_signals"] / float(nh),
                     "why_not_certified": {k_: int(v_) for k_, v_ in sth.items() if k_.startswith("why_") and v_},

@@ -300,6 +300,9 @@ typedef struct ss_hip_stats {
     uint64_t res_solve_launches;   /* timed launches (profiling on) of the path kernel of a screened single signal — k_res_solve (or, option
                                       screen_resident = 0, k_sub_solve): ONE workgroup, all iterations of the solve                        */
     double   res_solve_ms;         /* sum of their HIP-event durations                                                                    */
+    uint64_t screen_rescued;       /* screened signals (fp32) certified by the RESCUE: the first attempt declined — a planted column was ranked out
+                                      of the subset — its log named the missing columns, the second attempt held them (option "screen_rescue")  */
+    uint64_t screen_rescue_tried;  /* rescues attempted                                                                                  */
 } ss_hip_stats;
 
 /* ---- IRLS: the reference's second solver (src/solvers/irls-cpu.cpp:63-124) ----------------------
@@ -441,6 +444,9 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *   "screen_resident" 1 (default) = the path of the screened form runs in the one-workgroup resident kernel (csrc/resident.hip; fp32: 448 columns,
  *                    72 positions; fp64: 256 columns, 136 positions — the fp64 resident tier); 0 = fp32: k_sub_solve, fp64: the sub-dictionary
  *                    tier only.  OMP takes the screened form only with 1
+ *   "screen_rescue"  1 (default) = a single fp32 signal the screened form declined because its path ran out of positions or an outside column beat
+ *                    a state is scanned for the columns the ranking missed (the certificate pass over the declined solve's early states) and
+ *                    solved once more in the same form with those columns in the subset (ss_hip_stats::screen_rescued); 0 = it goes back
  *   "screen_recheck" 1 (default) = columns the half-precision certificate cannot clear are decided exactly from A in the solve's precision
  *                    (k_scr_recheck) and a last step an outside column stops early is repaired (k_scr_repair); 0 = such signals go back
  *   "gram_reserve"   1 (default) = the memory of G = A^T A is reserved on a helper thread when the first batch of >= 4 signals arrives, so that

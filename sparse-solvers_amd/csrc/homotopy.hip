@@ -838,7 +838,7 @@ inline hipError_t sub_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t) 
 
 // one signal in the screened form (screen.hip): no G — the subset's own Gram matrix from A, then one pass over the fp16 copy of A
 inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, hipEvent_t e0, hipEvent_t e1,
-                             hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5, bool omp)
+                             hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5, bool omp, bool rescue)
 {
     const size_t need = sub_buffer_bytes(1);
     if (ctx->sub_buf_bytes < need) {
@@ -853,9 +853,11 @@ inline hipError_t scr_single(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, u
         HIPCHK(hipMemsetAsync(ctx->sub_dbg, 0, 16 * sizeof(unsigned long long), ctx->stream));
     }
     // (with the state mirrored to mapped host memory the epilogue launch applies the certificate's verdict: no k_sub_finish)
-    return launch_screen_form(ctx, ws, tol, max_iter, first16, ctx->hs_mapped == nullptr, e0, e1, e2, e3, e4, e5, omp);
+    return launch_screen_form(ctx, ws, tol, max_iter, first16, ctx->hs_mapped == nullptr, e0, e1, e2, e3, e4, e5, omp, rescue);
 }
-inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, bool) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr_rescue_scan(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, bool from_recheck, uint32_t* found) { return launch_screen_rescue_scan(ctx, ws, tol, from_recheck, found); }
+inline hipError_t scr_rescue_scan(ss_hip_ctx*, Workspace<double>&, double, bool, uint32_t*) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr_single(ss_hip_ctx*, Workspace<double>&, double, uint32_t, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, bool, bool) { return hipErrorInvalidConfiguration; }
 // (typed shims of the fp64 screened form: never reached for float)
 inline hipError_t scr64_gather(ss_hip_ctx* ctx, const double* c0, const double* y, hipEvent_t e0, hipEvent_t e1) { return screen64_gather(ctx, c0, y, e0, e1); }
 inline hipError_t scr64_gather(ss_hip_ctx*, const float*, const float*, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
@@ -1124,6 +1126,8 @@ struct Route {
     bool no_sub = false;           // the subset / screened forms declined the signal: the default engine
     bool no_res = false;           // fp64: the resident tier declined it: the sub-dictionary tier
     bool plain = false;            // the early form asked for the plain speculative form (sticky for the rest of this solve)
+    bool rescue = false;           // the screened form declined the signal for a column its ranking missed: once more, with the columns its log names
+    uint32_t rescue_why = 0;       // ... the declined attempt's reason bits (kReason*)
     Route after() const { Route r; r.plain = plain; return r; }     // a fresh route that keeps what is sticky
 };
 
@@ -1183,6 +1187,7 @@ Forms choose_forms(ss_hip_ctx* ctx, const Route& route, const T* y, void* rec_ou
 // another form (*again, *next).  Rungs, in the order they are tried:
 //   exact tie in a step-length scan            -> reference-order engine (the arbiter; option tie_rerun)
 //   fp64 resident tier declined                -> sub-dictionary tier                      (no_res)
+//   fp32 screened form declined, a missed column -> the same form once more with it        (rescue)
 //   screened form (fp32 / fp64 tier 2) declined -> default engine                           (no_sub)
 //   subset form on G declined                  -> default engine                           (no_sub)
 //   early form used too many unfetched columns -> plain speculative form                   (plain)
@@ -1243,16 +1248,25 @@ int attempt_verdict(ss_hip_ctx* ctx, const Route& route, const Forms& f, const D
         if (hs.status == 0) { ctx->stats.screen_signals += 1; ctx->stats.screen_resident += 1; }
     }
     if ((scr1 || scr64) && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie)) {
-        ctx->stats.screen_redone += 1;
-        count_reasons(ctx, hs.sub_reason, scr_tie);
+        const uint32_t rs = hs.sub_reason;
+        if (!route.rescue) count_reasons(ctx, rs, scr_tie);            // (why the FIRST attempt declined)
         if (std::getenv("SS_HIP_SUB_DEBUG")) {
-            std::fprintf(stderr, "[screened form] status %u reason 0x%x after %u iterations, %u states logged, K = %u, lambda %g, lambda0 %g\n",
-                         hs.status, hs.sub_reason, hs.iter, hs.solo_nlog, hs.K, hs.c_inf, (double)hs.lambda0);
+            std::fprintf(stderr, "[screened form%s] status %u reason 0x%x after %u iterations, %u states logged, K = %u, lambda %g, lambda0 %g\n",
+                         route.rescue ? ", rescue" : "", hs.status, hs.sub_reason, hs.iter, hs.solo_nlog, hs.K, hs.c_inf, (double)hs.lambda0);
             if (scr1) screen_debug_recheck(ctx);
         }
-        Route r = route; r.no_sub = true;
+        // The rescue (fp32 Homotopy, option screen_rescue): the path ran out of positions / states, or an outside column beat a state, and
+        // nothing else was wrong with it — typically a planted column the ranking left out of the subset.  The next attempt scans this
+        // attempt's log for such columns (screen.hip: launch_screen_rescue_scan) and repeats the form with them; once.
+        const bool rescuable = scr1 && !omp && !route.rescue && !scr_tie && ctx->screen_rescue && ctx->screen_resident && !ctx->tracing &&
+                               screen_first16_usable(ctx) && (rs & (kReasonPositions | kReasonLog | kReasonColumn)) != 0u &&
+                               (rs & (kReasonRemoval | kReasonIrregular | kReasonTie | kReasonGuard | kReasonNoCand | kReasonFirstState | kReasonOverflow)) == 0u;
+        if (rescuable) { Route r = route; r.rescue = true; r.rescue_why = rs; return retry(r); }
+        ctx->stats.screen_redone += 1;
+        Route r = route; r.rescue = false; r.no_sub = true;
         return retry(r);
     }
+    if (scr1 && hs.status == 0 && route.rescue) ctx->stats.screen_rescued += 1;
     if ((scr1 || scr64) && hs.status == 0) ctx->stats.screen_signals += 1;
     if (scr1 && hs.status == 0 && ctx->screen_resident && res_solve_usable<float>()) ctx->stats.screen_resident += 1;
     if ((scr1 || scr64r) && hs.status == 0 && (hs.sub_reason & kReasonRechecked)) ctx->stats.screen_recheck += 1;
@@ -1380,6 +1394,7 @@ int solve_once(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         // (a context whose signals a form hands back more often than not steps that form aside for a while: the counters below)
         if ((sub1 || scr1 || scr64 || scr64r) && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; scr1 = false; scr64 = false; scr64r = false; }
         if (scr64r && ctx->res_off_solves > 0) { ctx->res_off_solves -= 1; scr64r = false; }
+        if (route.rescue && !scr1) ctx->stats.screen_redone += 1;      // (the form has stepped aside meanwhile: the signal is the default engine's after all)
         if (scr64r) scr64 = false;
         uint32_t scr_launches = 1;
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
@@ -1510,6 +1525,18 @@ int solve_once(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             if (!ws.gram_is_full) HIPCHK(hipMemsetAsync(ws.slot_of, 0xff, (size_t)ctx->n_pad * sizeof(int32_t), st));   // nothing cached yet
         } else if (sub1 || scr1) {
             Lookahead<T>::ensure(ctx, ws, kcap);
+            bool rescue = false;
+            if (route.rescue) {
+                // the scan of the declined attempt's log — its state, logs and c~0 are still in place: nothing has been reset yet
+                uint32_t found = 0;
+                // (a decline by the exact re-check alone left the list of the columns that failed it: no scan)
+                const bool from_recheck = (route.rescue_why & kReasonRechecked) != 0u && (route.rescue_why & (kReasonPositions | kReasonLog)) == 0u;
+                if (scr1) HIPCHK(scr_rescue_scan(ctx, ws, tol, from_recheck, &found));
+                rescue = scr1 && found >= 1u && found <= screen_rescue_cap();
+                if (std::getenv("SS_HIP_SUB_DEBUG")) std::fprintf(stderr, "[screened form, rescue] the scan lists %u columns the ranking missed\n", found);
+                if (!rescue) { ctx->stats.screen_redone += 1; Route r = route; r.rescue = false; r.no_sub = true; return retry(r); }
+                ctx->stats.screen_rescue_tried += 1;
+            }
             if (!omp) HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y (OMP: done above)
             // (the screened form's first pass — A^T y over all columns — reads the half-precision copy too: screen.hip, k_scr_first)
             const bool first16 = scr1 && screen_first16_usable(ctx);
@@ -1524,9 +1551,9 @@ int solve_once(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
             } else {
                 // (6 = the screening pass over the fp16 copy of A, 7 = the first pass when it runs there too)
                 hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
-                if (prof && first16) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(7); ++nprof; }
+                if (prof && first16 && !rescue) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(7); ++nprof; }
                 if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); e4 = prof_event(ctx, 2 * nprof + 2); e5 = prof_event(ctx, 2 * nprof + 3); }
-                HIPCHK(scr_single(ctx, ws, tol, max_iter, first16, e0, e1, e2, e3, e4, e5, omp));
+                HIPCHK(scr_single(ctx, ws, tol, max_iter, first16, e0, e1, e2, e3, e4, e5, omp, rescue));
                 if (prof) { ctx->prof_kind.push_back(6); ctx->prof_kind.push_back(8); nprof += 2; }      // (6 = the screening pass, 8 = the path kernel)
             }
         } else if (la) {
@@ -2927,6 +2954,7 @@ int ss_hip_set_option(ss_hip_ctx* ctx, const char* key, long value)
     if (!std::strcmp(key, "temporal_cols")) { ctx->temporal_cols = std::max<long>(0, value); return SS_HIP_OK; }
     if (!std::strcmp(key, "strict_sign"))   { ctx->strict_sign = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_first8")) { ctx->screen_first8 = value ? 1 : 0; return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_rescue")) { ctx->screen_rescue = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "trace"))         { ctx->tracing = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { ctx->zero_on_removal = value ? 1 : 0; return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_guard"))     { ctx->tie_guard = value ? 1 : 0; return SS_HIP_OK; }
@@ -3008,6 +3036,7 @@ int ss_hip_get_option(ss_hip_ctx* ctx, const char* key, long* value)
     if (!std::strcmp(key, "temporal_cols")) { *value = ctx->temporal_cols; return SS_HIP_OK; }
     if (!std::strcmp(key, "strict_sign"))   { *value = ctx->strict_sign; return SS_HIP_OK; }
     if (!std::strcmp(key, "screen_first8")) { *value = ctx->screen_first8; return SS_HIP_OK; }
+    if (!std::strcmp(key, "screen_rescue")) { *value = ctx->screen_rescue; return SS_HIP_OK; }
     if (!std::strcmp(key, "trace"))         { *value = ctx->tracing; return SS_HIP_OK; }
     if (!std::strcmp(key, "zero_on_removal")) { *value = ctx->zero_on_removal; return SS_HIP_OK; }
     if (!std::strcmp(key, "tie_guard"))     { *value = ctx->tie_guard; return SS_HIP_OK; }

@@ -825,7 +825,7 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
     const uint32_t nlog = st->solo_nlog;
     float ratio0 = 0.f;
     if (fl != nullptr && blockIdx.x == 0u && blockIdx.y == 0u && tid == 0u) {
-        fl[0] = 0u; fl[kFlCap + 1u] = 0u; fl[kFlCap + 4u] = 0u; fl[kFlCap + 12u] = 0u;
+        fl[0] = 0u; fl[kFlCap + 1u] = 0u; fl[kFlCap + 4u] = 0u; fl[kFlCap + 12u] = 0u; fl[kFlCap + 14u] = 0u;
     }
     if (first16 && blockIdx.x == 0u && tid == 0u && nlog >= 1u) {
         // state 0 after a first pass in half precision (k_scr_first): every column left out of the subset has |c~0| < T, so

@@ -79,7 +79,9 @@ constexpr uint32_t kSgPitchF = kSgStep + 4;      // floats per LDS row
 constexpr uint32_t kScrBatch = 64;               // slots of a batch chunk in the screened form
 // (kScrFlCap — columns the half-precision certificate may leave to the exact re-check, per signal — is resident.h's: k_res_residuals64 clears the list)
 constexpr uint32_t kScrRepCap = 64;              // columns that may be ahead of the subset's last step (candidates of the repair)
-constexpr uint32_t kScrFlWords = kScrFlCap + 16 + 4 * kScrRepCap; // (+ the first failure for SS_HIP_SUB_DEBUG at [cap + 4 ..], the repair's count at [cap + 12], its {column, -, step as a double} entries from [cap + 16])  // the list: [0] count, [1 .. cap] columns, [cap + 1] state 0 needs the re-check, [cap + 2] bits(bound_0), [cap + 3] bits(eps_0)
+constexpr uint32_t kScrRescueCap = 64;             // columns a rescue may add to the subset (more: the signal goes back)
+constexpr uint32_t kScrFlFail = kScrFlCap + 16 + 4 * kScrRepCap;    // the columns that FAILED the exact re-check (count at [cap + 14]): what a rescue adds to the subset
+constexpr uint32_t kScrFlWords = kScrFlFail + kScrRescueCap; // (+ the first failure for SS_HIP_SUB_DEBUG at [cap + 4 ..], the repair's count at [cap + 12], its {column, -, step as a double} entries from [cap + 16])  // the list: [0] count, [1 .. cap] columns, [cap + 1] state 0 needs the re-check, [cap + 2] bits(bound_0), [cap + 3] bits(eps_0)
 constexpr uint32_t kScrRecheckWgs = 240;         // workgroups of the re-check launch
 constexpr uint32_t kS64Sub = 2048;               // fp64 form: columns of the sub-dictionary the path is solved on
 constexpr uint32_t kS64Rhs = 192;                // ... states it can certify (two launches of the screening pass)
@@ -89,6 +91,8 @@ static_assert(kSbLog - 1 <= kScrRhs, "screening pass: right-hand sides");
 
 struct ScreenState {
     __half* a16 = nullptr;       // [n_pad][ldm] fl16(sA * A), column-contiguous like A
+    float* rank = nullptr;       // [n_pad] the rescue's ranking vector (made on first use)
+    uint32_t rescue_first = 1, rescue_count = 0, rescue_first2 = 1, rescue_count2 = 0;   // which pieces of the list the rescue takes: first word, length
     uint8_t* a8 = nullptr;       // [n_pad][ldm] fl8(sA8 * A) in OCP e4m3: the RANKING pass only (k_scr_first8; made on first use)
     bool a8_failed = false;      // its allocation did not fit: the half-precision first pass goes on
     float* anorm = nullptr;      // [n_pad] ||a_i||_2, rounded up
@@ -574,8 +578,11 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
                      const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ pcol,
                      const float* __restrict__ LX, float tol, const float* __restrict__ meta, __half* __restrict__ r16,
                      float* __restrict__ rn2p, float* __restrict__ tab, uint32_t* __restrict__ headroom, DevState* __restrict__ st,
-                     int first16, uint32_t* __restrict__ fl, int omp = 0)
+                     int first16, uint32_t* __restrict__ fl, int omp = 0, int scan = 0)
 {
+    // scan (the RESCUE of a declined solve, launch_screen_rescue_scan): the log of a solve that was declined — it ran out of positions, or
+    // a column outside the subset beat a state — is examined once more: the residuals of its states are formed as usual (irregular states
+    // are switched off), nothing is written to the slot's state; k_scr_gemm (gate 3) then lists the columns the ranking missed.
     // fl (one signal, may be null): the list of columns left to the exact re-check (k_scr_recheck) — cleared here; a state 0 the
     // half-precision first pass cannot certify by its threshold alone is left to that list too (its columns are found by k_scr_gemm)
     __shared__ __attribute__((aligned(16))) float sAc[kSbRows][64];
@@ -592,14 +599,16 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
         tab += (size_t)slot * kScrRhs * kScrTab;
         st += slot;
     }
-    if (st->status != 0u) return;
+    if (st->status != 0u && !scan) return;
     const uint32_t tid = threadIdx.x;
     float ratio0 = 0.f;
     if (fl != nullptr && blockIdx.x == 0u && blockIdx.y == 0u && tid == 0u) {
         fl[0] = 0u; fl[kScrFlCap + 1u] = 0u; fl[kScrFlCap + 4u] = 0u;
         fl[kScrFlCap + 12u] = 0u;                                                   // (the last step's repair: no candidate yet)
+        fl[kScrFlCap + 13u] = 0u;                                                   // (the rescue scan's second list)
+        if (!scan) fl[kScrFlCap + 14u] = 0u;                                        // (the re-check's list of failed columns: a scan leaves the first attempt's alone)
     }
-    if (first16 && blockIdx.x == 0u && tid == 0u) {
+    if (first16 && !scan && blockIdx.x == 0u && tid == 0u) {
         // state 0 after a first pass in half precision (k_scr_first): every column left out of the subset has |c~0| < T, so
         // |c0| < T + eps_0 — certified against lambda_0 (the subset's exact max |c0|) with the margin of every other state
         const float lam0 = st->lambda0;
@@ -676,7 +685,7 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
             }
         }
     }
-    if (ovf) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonOverflow); }
+    if (ovf && !scan) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonOverflow); }
     if (blockIdx.x == 0u) {
         const float lam0 = st->lambda0;
         if (tid == 0u && blockIdx.y == 0u) *headroom = __float_as_uint(ratio0);
@@ -702,11 +711,13 @@ void k_scr_residuals(const float* __restrict__ At, uint32_t ldm, uint32_t n, con
             // only REGULAR paths are certified: every step inserts a column and lambda goes down.  On a path with removals, or one
             // the first-step sign quirk has derailed, steps of rounding size decide what is toggled next, and the subset's Gram
             // matrix is the default engine's only to rounding (see k_s64_dense): those go back to that engine
-            if (!omp && (hp[3] == 0u || lam > __uint_as_float(hp[4]) * 1.00001f)) {
+            const bool irregular = !omp && (hp[3] == 0u || lam > __uint_as_float(hp[4]) * 1.00001f);
+            if (irregular && !scan) {
                 bound = -1.f;
                 atomicOr(&st->sub_reason, kReasonIrregular);
                 __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (the screening pass does not run for it)
             }
+            if (scan && (irregular || final_state)) bound = 3.0e38f;
             const float inv_sk = 1.f / sS[tid];
             tab[tid * kScrTab + 0] = meta[1] * inv_sk;
             tab[tid * kScrTab + 1] = bound;
@@ -755,13 +766,15 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t nst = nst_fixed;
     if (nst_fixed == 0u || nst_fixed == 0xffffffffu) {
-        if (st->status != 0u) return;
-        if (fl != nullptr && st->need_sweep != 0u) return;        // (already failed — an irregular path, an overflow: no pass for it)
+        // (gate = 3: the rescue's scan of a DECLINED solve's log — launch_screen_rescue_scan; nothing of the slot's state is read as a verdict or written)
+        if (st->status != 0u && gate != 3u) return;
+        if (fl != nullptr && st->need_sweep != 0u && gate != 3u) return;        // (already failed — an irregular path, an overflow: no pass for it)
         const uint32_t nlog = st->solo_nlog;
         if (nlog < 2u) return;
         nst = nlog - 1u;
         if (nst_fixed == 0xffffffffu && nst <= 64u) return;     // (batch chunk: k_scr_gemm_b carries the slots of up to 64 states)
         if ((gate == 1u && nst > 128u) || (gate == 2u && nst <= 128u)) return;
+        if (nst > 32u * (uint32_t)NT && gate == 3u) nst = 32u * (uint32_t)NT;
         if (nst > 32u * (uint32_t)NT) {                           // (more states than this launch carries: nothing is certified)
             if (threadIdx.x == 0 && blockIdx.y == 0) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonLog); }
             return;
@@ -884,7 +897,7 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     const bool mine = col < n && !(lo < nsub && sSub[lo] == col);
     const float an = anorm[col < n ? col : 0u];
     bool flag = false;
-    float worst = 0.f;
+    float worst = 0.f, big = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -893,11 +906,23 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
             if (kk < nst) {
                 const scr_v4f T4 = *reinterpret_cast<const scr_v4f*>(&sT[kk * 4u]);
                 const float v = fabsf(acc[t][e]) * T4[0] + (an * T4[2] + T4[3]);
+                big = fmaxf(big, fabsf(acc[t][e]) * T4[0]);
                 if (!(v <= T4[1])) flag = true;
                 const float ratio = T4[1] > 0.f ? v / T4[1] : 3.0e38f;
                 worst = fmaxf(worst, ratio == ratio ? ratio : 3.0e38f);
             }
         }
+    }
+    // (the rescue's scan: a column the ranking MISSED beats a state's bound and, somewhere on the path, stands above everything that was
+    // ranked out at state 0 — meta[6], the selection's threshold; a noise column that only beats the small bounds of the late states does not)
+    if (gate == 3u) {
+        // two lists: [1 .. cap / 2] the columns of that kind, [cap / 2 + 1 .. cap] every other column that beats a state (count at [cap + 13]): on a
+        // noisy signal the columns of the noise floor that enter the reference's path near its end are of the second kind, and few
+        if (mine && flag) {
+            if (big >= meta[6]) { const uint32_t at = atomicAdd(&fl[0], 1u); if (at < kScrFlCap / 2u) fl[1u + at] = col; }
+            else { const uint32_t at = atomicAdd(&fl[kScrFlCap + 13u], 1u); if (at < kScrFlCap / 2u) fl[1u + kScrFlCap / 2u + at] = col; }
+        }
+        return;
     }
     if (fl != nullptr && c0h != nullptr && fl[kScrFlCap + 1u] != 0u && mine) {
         const float v0 = fabsf(c0h[col]) + __uint_as_float(fl[kScrFlCap + 3u]);
@@ -915,7 +940,26 @@ void k_scr_gemm(const __half* __restrict__ a16, uint32_t ldm, uint32_t n, const 
     if (!mine) worst = 0.f;
     worst = fmaxf(worst, __shfl_xor(worst, 1)); worst = fmaxf(worst, __shfl_xor(worst, 2)); worst = fmaxf(worst, __shfl_xor(worst, 4));
     worst = fmaxf(worst, __shfl_xor(worst, 8)); worst = fmaxf(worst, __shfl_xor(worst, 16)); worst = fmaxf(worst, __shfl_xor(worst, 32));
-    if (lane == 0u && worst > 0.f) atomicMax(headroom, __float_as_uint(worst));
+    if (lane == 0u && worst > 0.f && gate != 3u) atomicMax(headroom, __float_as_uint(worst));
+}
+
+// ---- the rescue's ranking: |c~0| of every column, the columns the scan listed on top ---------------------------------------------
+__global__ __launch_bounds__(256)
+void k_scr_rescue_rank(const float* __restrict__ c0h, const uint32_t* __restrict__ fl, uint32_t first, uint32_t cnt1, uint32_t first2, uint32_t cnt2,
+                       uint32_t n, uint32_t n_pad, float* __restrict__ rank)
+{
+    // (two pieces of the list: [first, first + cnt1) and [first2, first2 + cnt2), together at most kScrRescueCap columns)
+    __shared__ uint32_t sL[kScrRescueCap];
+    cnt1 = cnt1 < kScrRescueCap ? cnt1 : kScrRescueCap;
+    cnt2 = cnt1 + cnt2 <= kScrRescueCap ? cnt2 : kScrRescueCap - cnt1;
+    const uint32_t cnt = cnt1 + cnt2;
+    for (uint32_t e = threadIdx.x; e < cnt; e += 256u) sL[e] = e < cnt1 ? fl[first + e] : fl[first2 + (e - cnt1)];
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_pad; i += gridDim.x * 256u) {
+        float v = i < n ? fabsf(c0h[i]) : 0.f;
+        for (uint32_t e = 0; e < cnt; ++e) if (sL[e] == i) v = 3.0e38f;
+        rank[i] = v;
+    }
 }
 
 
@@ -973,8 +1017,11 @@ void k_scr_recheck(const T* __restrict__ At, uint32_t ldm, uint32_t n, const T* 
     __syncthreads();
     const uint32_t Pfin = sH[(nlog - 1u) * 8u];
     const bool tol_stop = nlog >= 2u && !(sH[(nlog - 1u) * 8u + 1u] & 1u) && !(sL[2u * (nlog - 1u)] > tol);
-    bool fail = false, tie = false;
+    __shared__ uint32_t s_colfail;
+    if (tid == 0u) s_colfail = 0u;
+    bool fail_any = false, tie = false;
     for (uint32_t f = blockIdx.x; f < nfl; f += gridDim.x) {
+        bool fail = false;                                            // (of THIS column)
         const uint32_t col = fl[1u + f];
         const T* ai = At + (size_t)(col < n ? col : 0u) * ldm;
         // wave w: the positions p = w, w + 4, ... (and c0 = a_i . y behind the last): a lane's 16-byte pieces of every 64, ascending, then the wave's sum
@@ -1048,9 +1095,17 @@ void k_scr_recheck(const T* __restrict__ At, uint32_t ldm, uint32_t n, const T* 
             if (fail && !before && atomicCAS(&fl[kScrFlCap + 4u], 0u, 1u) == 0u) {        // (developer aid: the first failure)
                 fl[kScrFlCap + 5u] = col; fl[kScrFlCap + 6u] = tid; fl[kScrFlCap + 7u] = __float_as_uint((float)cv); fl[kScrFlCap + 8u] = __float_as_uint((float)qv);
             }
+            if (fail) { fail_any = true; s_colfail = 1u; }
         }
         __syncthreads();
+        // (a column that beats a state of the path: listed for the rescue — the form once more with it in the subset, homotopy.hip)
+        if (tid == 0u && s_colfail != 0u) {
+            s_colfail = 0u;
+            const uint32_t at = atomicAdd(&fl[kScrFlCap + 14u], 1u);
+            if (at < kScrRescueCap) fl[kScrFlFail + at] = col;
+        }
     }
+    const bool fail = fail_any;
     if (fail) {
         __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!(__hip_atomic_load(&st->sub_reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kReasonColumn)) atomicOr(&st->sub_reason, kReasonColumn);
@@ -1523,7 +1578,7 @@ void screen_free(ss_hip_ctx* ctx)
 {
     ScreenState* S = scr_of(ctx);
     if (!S) return;
-    void* ptrs[] = { S->a8, S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->wmax, S->cabs, S->sublist, S->xsub, S->xd, S->ctl,
+    void* ptrs[] = { S->rank, S->a8, S->a16, S->anorm, S->meta, S->r16, S->rn2p, S->tab, S->gs_part, S->gs, S->wmax, S->cabs, S->sublist, S->xsub, S->xd, S->ctl,
                      S->b_r16, S->b_rn2p, S->b_tab, S->b_gs_part, S->b_gs, S->fl, S->sub256, S->gs64, S->gs64_part, S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X, S->rl_D };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1688,8 +1743,10 @@ static hipError_t launch_scr_first(ss_hip_ctx* ctx, ScreenState* S, const TY* y,
 }
 
 hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, bool finish, hipEvent_t e0,
-                              hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5, bool omp)
+                              hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5, bool omp, bool rescue)
 {
+    // (rescue: the second attempt on a signal the first one declined — no first pass; the selection ranks S->rank, where the columns the
+    // scan of the first attempt's log found missing sit on top: launch_screen_rescue_scan)
     // (omp: orthogonal matching pursuit on the same subset — k_res_solve<float, OMP> logs its states the same way, the certificate reads
     // "nothing outside the subset reaches the pick's |c|"; the exact re-check decides Homotopy's predicates and stays out)
     if (omp && !(ctx->screen_resident && res_solve_usable<float>())) return hipErrorInvalidConfiguration;
@@ -1703,12 +1760,18 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
     const uint32_t nsplit = (ldm % (kSgSplit * kSgStep) == 0) ? kSgSplit : 4u;        // (ldm is a multiple of 256)
     constexpr uint32_t NT = kSbS / kSgT;
     uint32_t nwmax = 0;
-    if (first16) {
+    if (first16 && !rescue) {
         if (e0) (void)hipEventRecord(e0, s);
         { const hipError_t ef = launch_scr_first<float>(ctx, S, (const float*)ws.rhs, ws.c0, S->wmax, &nwmax); if (ef != hipSuccess) return ef; }
         if (e1) (void)hipEventRecord(e1, s);
     }
-    (void)launch_sub_select(ctx, B, 1, ws.c0, first16 ? S->meta + 6 : nullptr, nwmax != 0u ? (const float*)S->wmax : nullptr, nwmax);
+    if (rescue) {
+        if (S->rank == nullptr || !first16) return hipErrorInvalidConfiguration;
+        hipLaunchKernelGGL(k_scr_rescue_rank, dim3(std::min<uint32_t>((np + 255u) / 256u, 1024u)), dim3(256), 0, s, (const float*)ws.c0, (const uint32_t*)S->fl,
+                           S->rescue_first, S->rescue_count, S->rescue_first2, S->rescue_count2, n, np, S->rank);
+    }
+    (void)launch_sub_select(ctx, B, 1, rescue ? (const float*)S->rank : (const float*)ws.c0, first16 ? S->meta + 6 : nullptr,
+                            nwmax != 0u ? (const float*)S->wmax : nullptr, nwmax);
     hipLaunchKernelGGL(k_sgram_part, dim3(NT * (NT + 1) / 2, nsplit), dim3(256), 0, s, At, ldm, n, (const uint32_t*)B.sub, ldm / nsplit, S->gs_part);
     hipLaunchKernelGGL(k_sgram_sum, dim3((kSbS * kSbS + 255) / 256 + (first16 ? kSbS : 0u)), dim3(256), 0, s, (const float*)S->gs_part, nsplit, S->gs,
                        At, ldm, (const float*)ws.rhs, (const uint32_t*)B.sub, n, ws.c0);
@@ -1746,6 +1809,52 @@ hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, 
 }
 
 
+
+// The rescue of a declined solve (one fp32 signal, Homotopy; option screen_rescue).  A planted column whose |c0| drowns in the noise of the
+// other planted columns is not among the 448 best-ranked: the subset's path then goes wrong where that column should have entered — it runs
+// out of positions, or the certificate finds the column far above a state's bound.  Its log still says WHICH column: at the early states
+// (k_scr_residuals, scan) no column that was ranked out for a good reason can reach 7/8 lambda_k, so whatever the certificate pass lists
+// there is a column the ranking missed.  This queues that scan over the declined solve's log and reads the list's length back (one
+// synchronisation, on the rare path); the caller then repeats the screened form with those columns forced into the subset.
+// -> the number of columns found (0: nothing to rescue; > kScrRescueCap: too many)
+hipError_t launch_screen_rescue_scan(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, bool from_recheck, uint32_t* count_out)
+{
+    ScreenState* S = scr_of(ctx);
+    *count_out = 0;
+    if (S == nullptr || ctx->sub_buf == nullptr || S->fl == nullptr) return hipErrorInvalidConfiguration;
+    const SubBufs B = sub_bufs(ctx, 1);
+    hipStream_t s = ctx->stream;
+    const uint32_t ldm = ctx->ldm, n = (uint32_t)ctx->n, np = ctx->n_pad;
+    if (S->rank == nullptr && hipMalloc(reinterpret_cast<void**>(&S->rank), (size_t)np * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); S->rank = nullptr; return hipErrorOutOfMemory; }
+    const float* At = static_cast<const float*>(ctx->At);
+    hipLaunchKernelGGL(k_scr_residuals, dim3(ldm / 64u), dim3(256), 0, s, At, ldm, n, (const float*)ws.rhs,
+                       (const uint32_t*)B.hdr, (const uint32_t*)B.pcol, (const float*)B.LX, tol,
+                       (const float*)S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, 1, S->fl, 0, 1);
+    hipLaunchKernelGGL(k_scr_gemm<3>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds(kSbS), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
+                       (const float*)S->anorm, (const float*)S->rn2p, kScrRhs, (const float*)S->tab, (const uint32_t*)B.sub, kSbS, (const float*)S->meta,
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 3u, S->fl, (const float*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    uint32_t cnt = 0, tail[3] = { 0u, 0u, 0u };                  // [cap + 12 .. + 14]: repair's count, the scan's second list, the re-check's failures
+    e = hipMemcpyAsync(&cnt, S->fl, sizeof(cnt), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(tail, S->fl + kScrFlCap + 12u, sizeof(tail), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    const uint32_t cnt2 = tail[1], cntf = from_recheck ? tail[2] : 0u;
+    // the columns that stand above everything ranked out at state 0 (planted columns the ranking missed); if there is none, the columns the declined
+    // attempt's exact re-check found beating a state; if there is neither: whatever else beats a state, where that is a handful
+    // (in that order: on a path that went astray early the re-check's failures and the other violators are mostly the noise columns of its late
+    // states — hundreds; the first kind names what went wrong)
+    S->rescue_first2 = 1u; S->rescue_count2 = 0u;
+    if (cnt != 0u) { S->rescue_first = 1u; S->rescue_count = cnt; }
+    else if (cntf != 0u) { S->rescue_first = kScrFlFail; S->rescue_count = cntf; }
+    else { S->rescue_first = 1u + kScrFlCap / 2u; S->rescue_count = cnt2; }
+    *count_out = S->rescue_count + S->rescue_count2;
+    return hipSuccess;
+}
+uint32_t screen_rescue_cap() { return kScrRescueCap; }
 
 static size_t scr_gemm_b_lds()
 {

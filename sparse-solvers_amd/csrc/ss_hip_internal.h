@@ -251,6 +251,8 @@ struct ss_hip_ctx {
     // G's memory reserved ahead of its first use: a context that has received a batch of >= 4 signals will likely receive the large
     // one that forms G — the allocation (the driver clears fresh VRAM: ~0.5 s for 17 GiB) then runs on a helper thread beside the
     // batches before it instead of in front of the first large one (option gram_reserve; only where G is a small share of the HBM)
+    int screen_rescue = 1;                   // a declined screened solve (positions ran out / an outside column beat a state) is scanned for the columns the
+                                             // ranking missed and repeated once with those in the subset (screen.hip: launch_screen_rescue_scan)
     int screen_first8 = 1;                   // the screened form's ranking pass over an fp8 copy of A (screen.hip: k_scr_first8); 0 = over the fp16 copy
     int first_pass_elem_bytes = 2;           // what the last reduced-precision first pass read per entry of A (statistics)
     void* gram_reserve_thread = nullptr;     // std::thread*
@@ -450,7 +452,10 @@ bool screen_form_usable(ss_hip_ctx* ctx);                 // shape / option test
 bool screen_first16_usable(const ss_hip_ctx* ctx);        // ... with the FIRST pass (A^T y) over the half-precision copy too
 hipError_t launch_screen_form(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, uint32_t max_iter, bool first16, bool finish, hipEvent_t e0 = nullptr,
                               hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr, hipEvent_t e4 = nullptr, hipEvent_t e5 = nullptr,
-                              bool omp = false);
+                              bool omp = false, bool rescue = false);
+// the rescue of a declined solve: the scan of its log for the columns the ranking missed (-> their number), see screen.hip
+hipError_t launch_screen_rescue_scan(ss_hip_ctx* ctx, Workspace<float>& ws, float tol, bool from_recheck, uint32_t* count_out);
+uint32_t screen_rescue_cap();
 // a batch chunk of nslots <= screen_batch_cap() signals in the screened form: c0 = A^T y of every slot in c0_all ([nslots][n_pad]), the
 // signals in ws.y; the slots' verdicts in their states (k_sub_finish) like the subset form's
 uint32_t screen_batch_cap();

@@ -120,6 +120,8 @@ class Stats(ctypes.Structure):
         ("screen_recheck", ctypes.c_uint64),
         ("res_solve_launches", ctypes.c_uint64),
         ("res_solve_ms", ctypes.c_double),
+        ("screen_rescued", ctypes.c_uint64),
+        ("screen_rescue_tried", ctypes.c_uint64),
     ]
 
 

@@ -708,3 +708,38 @@ def test_fp8_ranking_pass_stays_inside_its_error_model(sship):
     assert outs[2][3]["screen_signals"] == 1 and outs[1][3]["screen_signals"] == 1
     # (certified by either pass, the path is the subset solve's: the same bits)
     assert np.array_equal(outs[2][0], outs[1][0]) and outs[2][1] == outs[1][1]
+
+
+def test_rescue_of_a_signal_whose_planted_column_the_ranking_missed(sship):
+    """Crowded supports (k / m = 4 %): a planted column with a small coefficient has |c0| below the 448th noise column and is ranked out
+    of the subset — the subset's path then runs out of positions, or the certificate finds the column far above a state.  Option
+    screen_rescue (default): the declined solve's log is scanned for such columns (the certificate pass over its early states) and the
+    form runs once more with them in the subset.  Every answer must be the oracle's, rescued or not; with the option off the same
+    signals go back to the default engine."""
+    rescued = declined_without = 0
+    for seed in range(6):
+        m, n, k = 1024, 8192, 39
+        A, y, x0, sup = make_gaussian_problem(9700 + seed, m, n, k, np.float32)
+        xo, ito, eo = oracle.homotopy(A, y, 1e-3, 3 * k + 8)
+        with sship.Homotopy(A) as h:
+            h.set_option("screen_single", 2)
+            h.reset_stats()
+            x1, it1, e1 = h.solve(y, 1e-3, 3 * k + 8)
+            st = h.stats()
+            h.set_option("screen_rescue", 0)
+            h.reset_stats()
+            x2, it2, e2 = h.solve(y, 1e-3, 3 * k + 8)
+            st2 = h.stats()
+        note("test_rescue", seed=seed, certified=st["screen_signals"], rescued=st["screen_rescued"], tried=st["screen_rescue_tried"], redone=st["screen_redone"],
+             why={k_: v for k_, v in st.items() if k_.startswith("why_") and v}, without=dict(certified=st2["screen_signals"], redone=st2["screen_redone"]))
+        assert_parity(x1, it1, e1, xo, ito, eo, np.float32)
+        assert_parity(x2, it2, e2, xo, ito, eo, np.float32)
+        assert st["screen_signals"] + st["screen_redone"] == 1 and st2["screen_signals"] + st2["screen_redone"] == 1
+        assert st2["screen_rescued"] == 0 and st2["screen_rescue_tried"] == 0
+        assert st["screen_rescued"] <= st["screen_rescue_tried"] <= 1
+        rescued += st["screen_rescued"]
+        declined_without += st2["screen_redone"]
+        if st["screen_rescued"]:
+            assert st2["screen_redone"] == 1, "a rescue happened on a signal the form certifies without it"
+    assert declined_without >= 2, "the test's signals are not crowded enough to be declined"
+    assert rescued >= 1, "no declined signal was rescued"
