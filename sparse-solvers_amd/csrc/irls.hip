@@ -1,7 +1,7 @@
 // irls.hip — the reference's second solver, IRLS (iteratively reweighted least squares), on the device.
 //
 // Reference (paths under /root/reference):
-//   qr_decomposition<T>        src/linalg/qr_decomposition.h:93-190   -> k_qr_step, k_qr_formq, k_irls_setup
+//   qr_decomposition<T>        src/linalg/qr_decomposition.h:93-190   -> k_qr_panel / k_qr_panel_reg, k_qr_apply_panel(_reg), k_qr_formq_all / k_qr_formq_reg, k_irls_setup(_r), k_irls_gram_tiled
 //   cholesky_decomposition<T>  src/linalg/cholesky_decomposition.h:56-100 -> k_irls_solve (in place)
 //   irls_newton / run_solver   src/solvers/irls-cpu.cpp:39-124        -> k_irls_solve
 //
@@ -67,80 +67,8 @@ __device__ __forceinline__ T block_max(T v, T* sv)
     return r;
 }
 
-// One Householder step (qr_decomposition.h:111-134).  Workgroup j handles column k + j; the pivot
-// column k is read-only in this launch (its reflector is written to Vt), so every workgroup forms the
-// reflector for itself.
-template <typename T>
-__global__ __launch_bounds__(kQrThreads)
-void k_qr_step(T* __restrict__ At, T* __restrict__ Vt, T* __restrict__ rdiag, uint32_t ldm, uint32_t m, uint32_t k)
-{
-    __shared__ T sv[16];
-    const T* piv = At + (size_t)k * ldm;
-    // 2-norm of piv[k..m) without overflow: scale by the largest magnitude
-    T amax = T(0);
-    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) amax = max(amax, t_abs(piv[i]));
-    amax = block_max(amax, sv);
-    T nrm2 = T(0);
-    if (amax > T(0)) {
-        T part = T(0);
-        for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) { const T z = piv[i] / amax; part += z * z; }
-        nrm2 = amax * sqrt(block_sum(part, sv));
-        __syncthreads();
-    }
-    const uint32_t col = k + blockIdx.x;
-    if (nrm2 == T(0)) {
-        if (blockIdx.x == 0) {
-            for (uint32_t i = threadIdx.x; i < ldm; i += kQrThreads) Vt[(size_t)k * ldm + i] = T(0);
-            if (threadIdx.x == 0) rdiag[k] = -nrm2;
-        }
-        return;
-    }
-    if (piv[k] < T(0)) nrm2 = -nrm2;
-    const T vk = piv[k] / nrm2 + T(1);
-    if (blockIdx.x == 0) {
-        for (uint32_t i = threadIdx.x; i < ldm; i += kQrThreads)
-            Vt[(size_t)k * ldm + i] = (i < k || i >= m) ? T(0) : (i == k ? vk : piv[i] / nrm2);
-        if (threadIdx.x == 0) rdiag[k] = -nrm2;
-        return;
-    }
-    // apply the reflector to column `col`: s = v . a / (-v_k); a += v s
-    T* a = At + (size_t)col * ldm;
-    T part = T(0);
-    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) {
-        const T v = (i == k) ? vk : piv[i] / nrm2;
-        part += v * a[i];
-    }
-    const T s = block_sum(part, sv) / -vk;
-    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) {
-        const T v = (i == k) ? vk : piv[i] / nrm2;
-        a[i] += v * s;
-    }
-}
-
-// Back-accumulation of the thin Q (qr_decomposition.h:141-172), step k (run for k = N-1 .. 0):
-// workgroup j handles column k + j of Q (row k + j of Qt).
-template <typename T>
-__global__ __launch_bounds__(kQrThreads)
-void k_qr_formq(const T* __restrict__ Vt, T* __restrict__ Qt, uint32_t ldm, uint32_t m, uint32_t k)
-{
-    __shared__ T sv[16];
-    const T* v = Vt + (size_t)k * ldm;
-    T* qc = Qt + (size_t)(k + blockIdx.x) * ldm;
-    if (blockIdx.x == 0) {
-        for (uint32_t i = threadIdx.x; i < ldm; i += kQrThreads) qc[i] = (i == k) ? T(1) : T(0);
-        __syncthreads();
-    }
-    const T vk = v[k];
-    if (vk == T(0)) return;
-    T part = T(0);
-    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) part += v[i] * qc[i];
-    const T s = -block_sum(part, sv) / vk;
-    for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) qc[i] += s * v[i];
-}
-
-
 // The reflectors k0 .. k0 + nb - 1 of a factored panel applied, in order, to one trailing column per workgroup: the same
-// statements as k_qr_step's (the reflector read from Vt, where k_qr_step's workgroup 0 left exactly the values the other
+// statements as the reference's Householder step (qr_decomposition.h:111-134; the reflector read from Vt, where the pivot's workgroup left exactly the values the other
 // workgroups form for themselves), so a column receives the same arithmetic in the same order — one launch per panel
 // instead of one per reflector.
 template <typename T>
@@ -152,7 +80,7 @@ void k_qr_apply_panel(T* __restrict__ At, const T* __restrict__ Vt, uint32_t ldm
     for (uint32_t k = k0; k < k0 + nb; ++k) {
         const T* v = Vt + (size_t)k * ldm;
         const T vk = v[k];
-        if (vk == T(0)) continue;                               // (a zero pivot column: k_qr_step leaves the others alone)
+        if (vk == T(0)) continue;                               // (a zero pivot column: the others are left alone)
         T part = T(0);
         for (uint32_t i = k + threadIdx.x; i < m; i += kQrThreads) part += v[i] * a[i];
         const T s = block_sum(part, sv) / -vk;
@@ -163,7 +91,7 @@ void k_qr_apply_panel(T* __restrict__ At, const T* __restrict__ Vt, uint32_t ldm
 
 // A whole panel of nb <= 32 columns factored in ONE launch: workgroup j owns column k0 + j.  It applies the reflectors
 // k0 .. k0 + j - 1 to its column as each becomes available (k_qr_apply_panel's statements), then forms its own reflector
-// (k_qr_step's statements, its column being the pivot) and publishes it: Vt row, rdiag, then a flag — release / acquire at
+// (the Householder step's statements, qr_decomposition.h:111-134, its column being the pivot) and publishes it: Vt row, rdiag, then a flag — release / acquire at
 // agent scope, the pattern of arrive_last (ss_hip_device.h): the reader's leader spins on the flag, acquires, and the
 // workgroup reads the row with vector loads behind a barrier.  A workgroup only ever waits for lower-numbered ones, all
 // nb <= 32 workgroups are resident: no deadlock.  Same arithmetic per column in the same order as one launch per
@@ -243,7 +171,7 @@ void k_qr_panel(T* __restrict__ At, T* __restrict__ Vt, T* __restrict__ rdiag, u
 }
 
 // Back-accumulation of the thin Q, all steps of one column in one workgroup: column j of Q starts as e_j at step j and then
-// receives the reflectors j, j - 1, ... 0 — independent of every other column (k_qr_formq's statements, its order).
+// receives the reflectors j, j - 1, ... 0 — independent of every other column (the reference's back-accumulation, qr_decomposition.h:141-172, in its order).
 template <typename T>
 __global__ __launch_bounds__(kQrThreads)
 void k_qr_formq_all(const T* __restrict__ Vt, T* __restrict__ Qt, uint32_t ldm, uint32_t m)
@@ -394,7 +322,7 @@ void k_qr_panel_reg(T* __restrict__ At, T* __restrict__ Vt, T* __restrict__ rdia
         for (int e = 0; e < RPT; ++e) if (tid + 256u * (uint32_t)e < ldm) vout[tid + 256u * (uint32_t)e] = T(0);
         if (tid == 0) rdiag[k] = T(0) / T(0);
     } else {
-        // my column is the pivot of step kown (k_qr_step's statements): 2-norm of rows k .. m - 1 without overflow
+        // my column is the pivot of step kown (qr_decomposition.h:111-134): 2-norm of rows k .. m - 1 without overflow
         T amax = T(0), mine = T(0);
 #pragma unroll
         for (int e = 0; e < RPT; ++e) {
@@ -1125,17 +1053,7 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
     IRLS_TRY(hipMemsetAsync(S->vec, 0, vec_bytes + (size_t)n * sizeof(uint32_t), ctx->stream));
     T* At = static_cast<T*>(ctx->At);
     uint32_t* qr_ready = nullptr;                                 // (flags of the one-launch panel kernel: behind S->vec, zeroed above)
-    if (std::getenv("SS_HIP_IRLS_FUSED")) {
-        // (A/B aid: the round-2 form — every reflector a launch over all trailing columns)
-        for (uint32_t k = 0; k < n; ++k) {
-            hipLaunchKernelGGL((k_qr_step<T>), dim3(n - k), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k);
-            IRLS_TRY(hipGetLastError());
-        }
-        for (uint32_t kk = n; kk-- > 0;) {
-            hipLaunchKernelGGL((k_qr_formq<T>), dim3(n - kk), dim3(kQrThreads), 0, ctx->stream, (const T*)S->Vt, S->Qt, ldm, m, kk);
-            IRLS_TRY(hipGetLastError());
-        }
-    } else if (ldm <= 8192u && !std::getenv("SS_HIP_IRLS_QR_GLOBAL")) {
+    if (ldm <= 8192u && !std::getenv("SS_HIP_IRLS_QR_GLOBAL")) {
         // register-resident form (round 4): a workgroup holds its column(s) for a whole panel / the whole back-accumulation
         // (SS_HIP_IRLS_QR_GLOBAL keeps the kernels that walk global memory: A/B aid)
         constexpr uint32_t NBQ = 32;
@@ -1166,21 +1084,13 @@ hipError_t irls_factor(ss_hip_ctx* ctx)
         // applied to every trailing column in ONE launch; Q's columns are independent of each other: one launch for all of them.
         // Same arithmetic per column, in the same order: the same bits as the round-2 form.
         constexpr uint32_t NBQ = 32;
-        // (one flag per column for the one-launch panel kernel; SS_HIP_IRLS_QR_STEPS keeps a launch per reflector: A/B aid)
-        if (!std::getenv("SS_HIP_IRLS_QR_STEPS"))
-            qr_ready = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(S->vec) + vec_bytes);
+        // (one flag per column for the one-launch panel kernel)
+        qr_ready = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(S->vec) + vec_bytes);
         uint32_t* const ready = qr_ready;
         for (uint32_t k0 = 0; k0 < n; k0 += NBQ) {
             const uint32_t nb = std::min<uint32_t>(NBQ, n - k0);
-            if (ready != nullptr) {
-                hipLaunchKernelGGL((k_qr_panel<T>), dim3(nb), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k0, ready);
-                IRLS_TRY(hipGetLastError());
-            } else {
-                for (uint32_t k = k0; k < k0 + nb; ++k) {
-                    hipLaunchKernelGGL((k_qr_step<T>), dim3(k0 + nb - k), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k);
-                    IRLS_TRY(hipGetLastError());
-                }
-            }
+            hipLaunchKernelGGL((k_qr_panel<T>), dim3(nb), dim3(kQrThreads), 0, ctx->stream, At, S->Vt, S->rdiag, ldm, m, k0, ready);
+            IRLS_TRY(hipGetLastError());
             if (k0 + nb < n) {
                 hipLaunchKernelGGL((k_qr_apply_panel<T>), dim3(n - (k0 + nb)), dim3(kQrThreads), 0, ctx->stream, At, (const T*)S->Vt, ldm, m, k0, nb);
                 IRLS_TRY(hipGetLastError());

@@ -1602,11 +1602,10 @@ void screen_free(ss_hip_ctx* ctx)
 }
 
 // (the main loop's two tiles; the epilogue's tables — 96 x 4 + 448 + 128 x 96 floats — fit inside)
-// row offset of workgroup b = (b * skew) mod stages (developer aid: SS_HIP_SCR_SKEW overrides the multiplier)
+// row offset of workgroup b = (b * skew) mod stages (29: any odd multiplier not near a divisor of the stage count does; 0 = no offsets was 0.61 of the HBM peak)
 static uint32_t scr_skew()
 {
-    static const uint32_t v = [] { const char* e = std::getenv("SS_HIP_SCR_SKEW"); return e ? (uint32_t)std::atoi(e) : 29u; }();
-    return v;
+    return 29u;
 }
 
 static size_t scr_gemm_lds(uint32_t nsub, uint32_t nt = 3)
