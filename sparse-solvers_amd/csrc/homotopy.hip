@@ -869,11 +869,13 @@ inline hipError_t scr64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const do
 inline hipError_t scr64_certify(ss_hip_ctx*, Workspace<float>&, const float*, uint32_t, float, double, uint32_t, hipEvent_t, hipEvent_t, bool, bool) { return hipErrorInvalidConfiguration; }
 
 inline hipError_t scr64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp, hipEvent_t e0, hipEvent_t e1,
-                                 hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5)
+                                 hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5, bool rescue)
 {
-    return launch_screen64_resident(ctx, ws, tol, max_iter, first16, omp, e0, e1, e2, e3, e4, e5);
+    return launch_screen64_resident(ctx, ws, tol, max_iter, first16, omp, e0, e1, e2, e3, e4, e5, rescue);
 }
-inline hipError_t scr64_resident(ss_hip_ctx*, Workspace<float>&, float, uint32_t, bool, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr64_resident(ss_hip_ctx*, Workspace<float>&, float, uint32_t, bool, bool, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t, bool) { return hipErrorInvalidConfiguration; }
+inline hipError_t scr64_rescue_scan(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, bool from_recheck, uint32_t* found) { return launch_screen64_rescue_scan(ctx, ws, tol, from_recheck, found); }
+inline hipError_t scr64_rescue_scan(ss_hip_ctx*, Workspace<float>&, float, bool, uint32_t*) { return hipErrorInvalidConfiguration; }
 
 // why a subset / screened solve was not reported: DevState::sub_reason's bits into the statistics
 inline void count_reasons(ss_hip_ctx* ctx, uint32_t r, bool tie)
@@ -1236,15 +1238,22 @@ int attempt_verdict(ss_hip_ctx* ctx, const Route& route, const Forms& f, const D
             ctx->res_failed = 0;
         }
         if (back) {
+            const uint32_t rs = hs.sub_reason;
+            if (!route.rescue) count_reasons(ctx, rs, scr_tie);
+            if (std::getenv("SS_HIP_SUB_DEBUG"))
+                std::fprintf(stderr, "[screened form, fp64 resident tier%s] status %u reason 0x%x after %u iterations, %u states logged, K = %u, lambda %g\n",
+                             route.rescue ? ", rescue" : "", hs.status, hs.sub_reason, hs.iter, hs.solo_nlog, hs.K, hs.c_inf);
+            // (the rescue, as in fp32: a column the ranking left out of the 256 — the tier once more with the columns its log names)
+            const bool rescuable = !omp && !route.rescue && !scr_tie && ctx->screen_rescue && !ctx->tracing && screen_first16_usable(ctx) &&
+                                   (rs & (kReasonPositions | kReasonLog | kReasonColumn)) != 0u &&
+                                   (rs & (kReasonRemoval | kReasonIrregular | kReasonTie | kReasonGuard | kReasonNoCand | kReasonFirstState | kReasonOverflow)) == 0u;
+            if (rescuable) { Route r = route; r.rescue = true; r.rescue_why = rs; return retry(r); }
             // the resident tier does not report this signal: the sub-dictionary tier (2048 columns) takes it next
             ctx->stats.screen_tier2 += 1;
-            count_reasons(ctx, hs.sub_reason, scr_tie);
-            if (std::getenv("SS_HIP_SUB_DEBUG"))
-                std::fprintf(stderr, "[screened form, fp64 resident tier] status %u reason 0x%x after %u iterations, %u states logged, K = %u, lambda %g\n",
-                             hs.status, hs.sub_reason, hs.iter, hs.solo_nlog, hs.K, hs.c_inf);
-            Route r = route; r.no_res = true;
+            Route r = route; r.rescue = false; r.no_res = true;
             return retry(r);
         }
+        if (hs.status == 0 && route.rescue) ctx->stats.screen_rescued += 1;
         if (hs.status == 0) { ctx->stats.screen_signals += 1; ctx->stats.screen_resident += 1; }
     }
     if ((scr1 || scr64) && (hs.status == kStatusSubsetDecline || hs.status == kStatusSubsetFail || scr_tie)) {
@@ -1394,7 +1403,7 @@ int solve_once(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         // (a context whose signals a form hands back more often than not steps that form aside for a while: the counters below)
         if ((sub1 || scr1 || scr64 || scr64r) && ctx->sub_off_solves > 0) { ctx->sub_off_solves -= 1; sub1 = false; scr1 = false; scr64 = false; scr64r = false; }
         if (scr64r && ctx->res_off_solves > 0) { ctx->res_off_solves -= 1; scr64r = false; }
-        if (route.rescue && !scr1) ctx->stats.screen_redone += 1;      // (the form has stepped aside meanwhile: the signal is the default engine's after all)
+        if (route.rescue && !scr1 && !scr64r) ctx->stats.screen_redone += 1;      // (the form has stepped aside meanwhile: the signal is the default engine's after all)
         if (scr64r) scr64 = false;
         uint32_t scr_launches = 1;
         // end of a solve: the device state to pinned memory, x (and the compact record) to the caller
@@ -1448,6 +1457,16 @@ int solve_once(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
         };
         if (scr64r) {
             Lookahead<T>::ensure(ctx, ws, kcap);
+            bool rescue = false;
+            if (route.rescue) {
+                uint32_t found = 0;
+                const bool from_recheck = (route.rescue_why & kReasonRechecked) != 0u && (route.rescue_why & (kReasonPositions | kReasonLog)) == 0u;
+                HIPCHK(scr64_rescue_scan(ctx, ws, tol, from_recheck, &found));
+                rescue = found >= 1u && found <= screen_rescue_cap();
+                if (std::getenv("SS_HIP_SUB_DEBUG")) std::fprintf(stderr, "[screened form, fp64 resident tier, rescue] the scan lists %u columns the ranking missed\n", found);
+                if (!rescue) { ctx->stats.screen_tier2 += 1; Route r = route; r.rescue = false; r.no_res = true; return retry(r); }
+                ctx->stats.screen_rescue_tried += 1;
+            }
             if (!omp) HIPCHK(launch_la_reset<T>(ctx, ws, false, y_direct ? y : (const T*)nullptr, incy));     // x, d, flags, DevState, r = y (OMP: done above)
             const bool first16 = screen_first16_usable(ctx);
             uint32_t nb1 = 0;
@@ -1457,9 +1476,9 @@ int solve_once(ss_hip_ctx* ctx, const T* y, ptrdiff_t incy, T tol, uint32_t max_
                 if (prof) { HIPCHK(hipEventRecord(prof_event(ctx, 2 * nprof + 1), st)); ctx->prof_kind.push_back(1); ++nprof; }
             }
             hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
-            if (prof && first16) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(7); ++nprof; }
+            if (prof && first16 && !rescue) { e0 = prof_event(ctx, 2 * nprof); e1 = prof_event(ctx, 2 * nprof + 1); ctx->prof_kind.push_back(7); ++nprof; }
             if (prof) { e2 = prof_event(ctx, 2 * nprof); e3 = prof_event(ctx, 2 * nprof + 1); e4 = prof_event(ctx, 2 * nprof + 2); e5 = prof_event(ctx, 2 * nprof + 3); }
-            HIPCHK(scr64_resident(ctx, ws, tol, max_iter, first16, omp, e0, e1, e2, e3, e4, e5));
+            HIPCHK(scr64_resident(ctx, ws, tol, max_iter, first16, omp, e0, e1, e2, e3, e4, e5, rescue));
             if (prof) { ctx->prof_kind.push_back(6); ctx->prof_kind.push_back(8); nprof += 2; }      // (6 = the screening pass, 8 = the path kernel)
         } else if (scr64) {
             Lookahead<T>::ensure(ctx, ws, kcap);

@@ -47,6 +47,6 @@ hipError_t launch_sgram64(ss_hip_ctx* ctx, const uint32_t* sub, const double* y,
 // fp64: residuals of the logged states in half precision, the screening pass's table, the certificate of state 0
 hipError_t launch_res_residuals64(ss_hip_ctx* ctx, const double* y, const ResLog<double>& log, double tol, const float* meta, void* r16, float* rn2p,
                                   float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp, uint32_t nslots = 1, const float* slotmeta = nullptr,
-                                  uint32_t* fl = nullptr);
+                                  uint32_t* fl = nullptr, bool scan = false);
 
 }  // namespace sship

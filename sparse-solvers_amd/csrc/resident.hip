@@ -801,8 +801,10 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
                        const double* __restrict__ LH, const uint32_t* __restrict__ pcol, const double* __restrict__ LX, double tol,
                        const float* __restrict__ meta, __half* __restrict__ r16, float* __restrict__ rn2p, float* __restrict__ tab,
                        uint32_t* __restrict__ headroom, DevState* __restrict__ st, int first16, int omp, const float* __restrict__ slotmeta,
-                       uint32_t* __restrict__ fl)
+                       uint32_t* __restrict__ fl, int scan)
 {
+    // scan: the rescue's look at a DECLINED solve's log (screen.hip: launch_screen64_rescue_scan; see k_scr_residuals) — the residuals of its
+    // states as usual, irregular states and the one the path ended in switched off, nothing of the slot's state written
     // fl (one signal, may be null): the list of the exact re-check (screen.hip: k_scr_recheck), cleared here; a state 0 the first pass's
     // threshold cannot certify is left to it ([1024 + 1 .. + 3]: flag, bits(bound_0), bits(eps_0))
     constexpr uint32_t kFlCap = kScrFlCap;
@@ -820,14 +822,15 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
     __shared__ __attribute__((aligned(16))) double sAc[16][64];
     __shared__ __attribute__((aligned(16))) double sXt[16][XP];
     __shared__ float sS[kR64Rhs];
-    if (st->status != 0u) return;
+    if (st->status != 0u && !scan) return;
     const uint32_t tid = threadIdx.x, r0 = blockIdx.x * 64u;
     const uint32_t nlog = st->solo_nlog;
     float ratio0 = 0.f;
     if (fl != nullptr && blockIdx.x == 0u && blockIdx.y == 0u && tid == 0u) {
-        fl[0] = 0u; fl[kFlCap + 1u] = 0u; fl[kFlCap + 4u] = 0u; fl[kFlCap + 12u] = 0u; fl[kFlCap + 14u] = 0u;
+        fl[0] = 0u; fl[kFlCap + 1u] = 0u; fl[kFlCap + 4u] = 0u; fl[kFlCap + 12u] = 0u; fl[kFlCap + 13u] = 0u;
+        if (!scan) fl[kFlCap + 14u] = 0u;                            // (the re-check's list of failed columns: a scan leaves the first attempt's alone)
     }
-    if (first16 && blockIdx.x == 0u && tid == 0u && nlog >= 1u) {
+    if (first16 && !scan && blockIdx.x == 0u && tid == 0u && nlog >= 1u) {
         // state 0 after a first pass in half precision (k_scr_first): every column left out of the subset has |c~0| < T, so
         // |c0| < T + eps_0 — certified against lambda_0 (the subset's exact max |c0|) with the margin of every other state
         const float lam0 = (float)LH[0] * 0.9999999f;
@@ -850,7 +853,7 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
     }
     const uint32_t nst = nlog - 1u;                                // states 1 .. nst
     if (nst > kR64Rhs) {
-        if (blockIdx.x == 0u && tid == 0u) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonLog); }
+        if (blockIdx.x == 0u && tid == 0u && !scan) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonLog); }
         return;
     }
     const uint32_t Pfin = hdr[(size_t)(nlog - 1u) * 8u];
@@ -932,7 +935,7 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
             }
         }
     }
-    if (ovf) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonOverflow); }
+    if (ovf && !scan) { __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(&st->sub_reason, kReasonOverflow); }
     if (blockIdx.x == 0u) {
         if (tid == 0u && blockIdx.y == 0u) *headroom = __float_as_uint(ratio0);
         if (tid < nst) {
@@ -956,11 +959,13 @@ void k_res_residuals64(const double* __restrict__ At, uint32_t ldm, uint32_t n, 
                 if (ls_jump) bound = (float)tol * 0.9375f - slack;
                 else bound = fminf(lam, (float)lam_exp) * 0.875f - slack;
                 // only REGULAR paths are certified: every step inserts a column, lambda goes down
-                if (hp[3] == 0u || lam_d > lam_pd * (1.0 + 1e-12)) {
+                const bool irregular = hp[3] == 0u || lam_d > lam_pd * (1.0 + 1e-12);
+                if (irregular && !scan) {
                     bound = -1.f;
                     atomicOr(&st->sub_reason, kReasonIrregular);
                     __hip_atomic_store(&st->need_sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (no screening pass for it)
                 }
+                if (scan && (irregular || final_state)) bound = 3.0e38f;
             }
             const float inv_sk = 1.f / sS[tid];
             tab[tid * 4u + 0] = meta[1] * inv_sk;
@@ -1047,11 +1052,11 @@ hipError_t launch_sgram64(ss_hip_ctx* ctx, const uint32_t* sub, const double* y,
 }
 
 hipError_t launch_res_residuals64(ss_hip_ctx* ctx, const double* y, const ResLog<double>& log, double tol, const float* meta, void* r16, float* rn2p,
-                                  float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp, uint32_t nslots, const float* slotmeta, uint32_t* fl)
+                                  float* tab, uint32_t* headroom, DevState* st, bool first16, bool omp, uint32_t nslots, const float* slotmeta, uint32_t* fl, bool scan)
 {
     hipLaunchKernelGGL(k_res_residuals64, dim3(ctx->ldm / 64u, nslots), dim3(256), 0, ctx->stream, static_cast<const double*>(ctx->At), ctx->ldm, (uint32_t)ctx->n, y,
                        (const uint32_t*)log.hdr, (const double*)log.H, (const uint32_t*)log.pcol, (const double*)log.X, tol, meta,
-                       static_cast<__half*>(r16), rn2p, tab, headroom, st, first16 ? 1 : 0, omp ? 1 : 0, slotmeta, fl);
+                       static_cast<__half*>(r16), rn2p, tab, headroom, st, first16 ? 1 : 0, omp ? 1 : 0, slotmeta, fl, scan ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -2096,8 +2096,43 @@ bool screen64_resident_usable(ss_hip_ctx* ctx)
     return S != nullptr && S->sub256 != nullptr && ctx->n >= 4u * (uint32_t)ResCfg<double>::S && res_solve_usable<double>();
 }
 
+// The rescue in the fp64 resident tier (see launch_screen_rescue_scan): the declined solve's log scanned by the five-tile certificate pass
+// (up to 160 states in one launch), the same three lists, the same order of preference.
+hipError_t launch_screen64_rescue_scan(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, bool from_recheck, uint32_t* count_out)
+{
+    typedef ResCfg<double> RC;
+    ScreenState* S = scr_of(ctx);
+    *count_out = 0;
+    if (S == nullptr || S->sub256 == nullptr || S->fl == nullptr) return hipErrorInvalidConfiguration;
+    hipStream_t s = ctx->stream;
+    const uint32_t ldm = ctx->ldm, n = (uint32_t)ctx->n, np = ctx->n_pad;
+    if (S->rank == nullptr && hipMalloc(reinterpret_cast<void**>(&S->rank), (size_t)np * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); S->rank = nullptr; return hipErrorOutOfMemory; }
+    const ResLog<double> log{ S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X, S->rl_D };
+    (void)launch_res_residuals64(ctx, (const double*)ws.rhs, log, tol, S->meta, S->r16, S->rn2p, S->tab, reinterpret_cast<uint32_t*>(S->meta) + 3, ws.st, true, false, 1,
+                                 nullptr, S->fl, true);
+    hipLaunchKernelGGL(k_scr_gemm<5>, dim3(1, np / kScrCols), dim3(256), scr_gemm_lds((uint32_t)RC::S, 5), s, (const __half*)S->a16, ldm, n, (const __half*)S->r16,
+                       (const float*)S->anorm, (const float*)S->rn2p, kS64Rhs, (const float*)S->tab, (const uint32_t*)S->sub256, (uint32_t)RC::S, (const float*)S->meta,
+                       ws.st, reinterpret_cast<uint32_t*>(S->meta) + 3, 0u, scr_skew(), 3u, S->fl, (const float*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    uint32_t cnt = 0, tail[3] = { 0u, 0u, 0u };
+    e = hipMemcpyAsync(&cnt, S->fl, sizeof(cnt), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(tail, S->fl + kScrFlCap + 12u, sizeof(tail), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    const uint32_t cnt2 = tail[1], cntf = from_recheck ? tail[2] : 0u;
+    S->rescue_first2 = 1u; S->rescue_count2 = 0u;
+    if (cnt != 0u) { S->rescue_first = 1u; S->rescue_count = cnt; }
+    else if (cntf != 0u) { S->rescue_first = kScrFlFail; S->rescue_count = cntf; }
+    else { S->rescue_first = 1u + kScrFlCap / 2u; S->rescue_count = cnt2; }
+    *count_out = S->rescue_count;
+    return hipSuccess;
+}
+
 hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp, hipEvent_t e0,
-                                    hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5)
+                                    hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t e4, hipEvent_t e5, bool rescue)
 {
     typedef ResCfg<double> RC;
     ScreenState* S = scr_of(ctx);
@@ -2105,7 +2140,12 @@ hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, doub
     hipStream_t s = ctx->stream;
     const uint32_t ldm = ctx->ldm, n = (uint32_t)ctx->n, np = ctx->n_pad;
     const double* y = ws.rhs;                                     // (r = y: the caller's reset put it there)
-    if (first16) {
+    if (rescue) {
+        // (the second attempt on a signal the tier declined: no first pass — S->cabs still holds |c~0| —, the columns the scan named on top of the ranking)
+        if (S->rank == nullptr || !first16) return hipErrorInvalidConfiguration;
+        hipLaunchKernelGGL(k_scr_rescue_rank, dim3(std::min<uint32_t>((np + 255u) / 256u, 1024u)), dim3(256), 0, s, (const float*)S->cabs, (const uint32_t*)S->fl,
+                           S->rescue_first, S->rescue_count, S->rescue_first2, S->rescue_count2, n, np, S->rank);
+    } else if (first16) {
         if (e0) (void)hipEventRecord(e0, s);
         const hipError_t ef = launch_scr_first<double>(ctx, S, y, S->cabs);
         if (ef != hipSuccess) return ef;
@@ -2113,8 +2153,8 @@ hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, doub
     } else {
         hipLaunchKernelGGL(k_s64_cabs, dim3((np + 255) / 256), dim3(256), 0, s, (const double*)ws.c0, n, np, S->cabs);
     }
-    (void)launch_select_top(ctx, S->cabs, n, np, (uint32_t)RC::S, S->sub256, S->sub256 + RC::S, reinterpret_cast<float*>(S->sub256 + RC::S + 1),
-                            first16 ? S->meta + 6 : nullptr);
+    (void)launch_select_top(ctx, rescue ? (const float*)S->rank : (const float*)S->cabs, n, np, (uint32_t)RC::S, S->sub256, S->sub256 + RC::S,
+                            reinterpret_cast<float*>(S->sub256 + RC::S + 1), first16 ? S->meta + 6 : nullptr);
     { const hipError_t eg = launch_sgram64(ctx, S->sub256, y, S->gs64_part, S->gs64, ws.c0); if (eg != hipSuccess) return eg; }
     const ResLog<double> log{ S->rl_hdr, S->rl_H, S->rl_pcol, S->rl_X, S->rl_D };
     if (e4) (void)hipEventRecord(e4, s);

@@ -473,7 +473,8 @@ hipError_t screen64_certify(ss_hip_ctx* ctx, Workspace<double>& ws, const double
 bool screen64_resident_usable(ss_hip_ctx* ctx);
 hipError_t launch_screen64_resident(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, uint32_t max_iter, bool first16, bool omp,
                                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr,
-                                    hipEvent_t e4 = nullptr, hipEvent_t e5 = nullptr);
+                                    hipEvent_t e4 = nullptr, hipEvent_t e5 = nullptr, bool rescue = false);
+hipError_t launch_screen64_rescue_scan(ss_hip_ctx* ctx, Workspace<double>& ws, double tol, bool from_recheck, uint32_t* count_out);
 // fp64 batches in the resident tier: a chunk of nslots <= screen64_batch_cap() signals (in ws.y) — one pass over the fp16 copy ranks every signal's
 // columns, the chunk's paths run side by side, each signal's states are certified by a screening pass of its own; verdicts in the slots' states
 bool screen64_batch_usable(ss_hip_ctx* ctx);

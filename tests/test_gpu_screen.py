@@ -237,16 +237,24 @@ def test_screened_form_fp64_hands_back(sship):
     y = A @ x0
     with sship.Homotopy(A) as h:
         h.set_option("screen_single", 2)
+        h.set_option("screen_rescue", 0)                  # (the rescue would find the column and certify: test_rescue_in_the_fp64_resident_tier)
         h.reset_stats()
         xg, itg, eg = h.solve(y, 1e-9, 4 * k)
         st = h.stats()
+        h.set_option("screen_rescue", 1)
+        h.reset_stats()
+        xr, itr, er = h.solve(y, 1e-9, 4 * k)
+        str_ = h.stats()
         h.set_option("screen_single", 0)
         xd, itd, ed = h.solve(y, 1e-9, 4 * k)
     xo, ito, eo = oracle.homotopy(A, y, 1e-9, 4 * k)
-    note("test_screened_form_fp64_hands_back", certified=st["screen_signals"], redone=st["screen_redone"])
+    note("test_screened_form_fp64_hands_back", certified=st["screen_signals"], redone=st["screen_redone"], with_rescue=dict(certified=str_["screen_signals"],
+         rescued=str_["screen_rescued"], redone=str_["screen_redone"]))
     assert st["screen_signals"] + st["screen_redone"] == 1
     assert itg == itd and eg == ed and np.array_equal(xg, xd)
     assert_parity(xg, itg, eg, xo, ito, eo, np.float64)
+    assert str_["screen_signals"] + str_["screen_redone"] == 1
+    assert_parity(xr, itr, er, xo, ito, eo, np.float64)
 
 
 @pytest.mark.parametrize("first16", [1, 0])
@@ -742,4 +750,35 @@ def test_rescue_of_a_signal_whose_planted_column_the_ranking_missed(sship):
         if st["screen_rescued"]:
             assert st2["screen_redone"] == 1, "a rescue happened on a signal the form certifies without it"
     assert declined_without >= 2, "the test's signals are not crowded enough to be declined"
+    assert rescued >= 1, "no declined signal was rescued"
+
+
+def test_rescue_in_the_fp64_resident_tier(sship):
+    """The same in fp64: the resident tier's subset is 256 columns; a crowded support leaves planted columns out of it, the tier's path goes
+    astray, its log names them, the tier runs once more with them (ss_hip_stats::screen_rescued) instead of handing the signal to the
+    sub-dictionary tier.  Every answer is the oracle's to 1e-10."""
+    rescued = 0
+    for seed in range(4):
+        m, n, k = 1024, 12000, 40
+        A, y, x0, sup = make_gaussian_problem(9800 + seed, m, n, k, np.float64)
+        xo, ito, eo = oracle.homotopy(A, y, 1e-9, 3 * k + 8)
+        with sship.Homotopy(A) as h:
+            h.set_option("screen_single", 2)
+            h.reset_stats()
+            x1, it1, e1 = h.solve(y, 1e-9, 3 * k + 8)
+            st = h.stats()
+            h.set_option("screen_rescue", 0)
+            h.reset_stats()
+            x2, it2, e2 = h.solve(y, 1e-9, 3 * k + 8)
+            st2 = h.stats()
+        note("test_rescue_fp64", seed=seed, certified=st["screen_signals"], resident=st["screen_resident"], rescued=st["screen_rescued"], tried=st["screen_rescue_tried"],
+             tier2=st["screen_tier2"], why={k_: v for k_, v in st.items() if k_.startswith("why_") and v},
+             without=dict(certified=st2["screen_signals"], resident=st2["screen_resident"], tier2=st2["screen_tier2"]))
+        assert_parity(x1, it1, e1, xo, ito, eo, np.float64)
+        assert_parity(x2, it2, e2, xo, ito, eo, np.float64)
+        assert st2["screen_rescued"] == 0 and st2["screen_rescue_tried"] == 0
+        assert st["screen_rescued"] <= st["screen_rescue_tried"] <= 1
+        if st["screen_rescued"]:
+            assert st["screen_resident"] == 1 and st2["screen_tier2"] >= 1, "a rescue happened on a signal the tier certifies without it"
+        rescued += st["screen_rescued"]
     assert rescued >= 1, "no declined signal was rescued"
