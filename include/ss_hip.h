@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_HIP_ABI_VERSION 4
+#define SS_HIP_ABI_VERSION 6     /* (5: the per-reason counters of round 4; 6: screen_rescued / screen_rescue_tried, the colshard _f64 entry points) */
 
 typedef struct ss_hip_ctx ss_hip_ctx;
 
@@ -300,7 +300,8 @@ typedef struct ss_hip_stats {
     uint64_t res_solve_launches;   /* timed launches (profiling on) of the path kernel of a screened single signal — k_res_solve (or, option
                                       screen_resident = 0, k_sub_solve): ONE workgroup, all iterations of the solve                        */
     double   res_solve_ms;         /* sum of their HIP-event durations                                                                    */
-    uint64_t screen_rescued;       /* screened signals (fp32) certified by the RESCUE: the first attempt declined — a planted column was ranked out
+    /* ABI version 6 */
+    uint64_t screen_rescued;       /* screened signals (fp32 and fp64 resident tier) certified by the RESCUE: the first attempt declined — a planted column was ranked out
                                       of the subset — its log named the missing columns, the second attempt held them (option "screen_rescue")  */
     uint64_t screen_rescue_tried;  /* rescues attempted                                                                                  */
 } ss_hip_stats;
