@@ -452,6 +452,11 @@ int ss_hip_reset_stats(ss_hip_ctx* ctx);
  *                    (k_scr_recheck) and a last step an outside column stops early is repaired (k_scr_repair); 0 = such signals go back
  *   "gram_reserve"   1 (default) = the memory of G = A^T A is reserved on a helper thread when the first batch of >= 4 signals arrives, so that
  *                    the batch that forms G does not wait for the allocation; 0 = allocated on first use
+ *   "temporal_cols"  leading dictionary columns the sweeps read with cache-allocating loads (the rest: non-temporal); 0 (default) = none
+ *   "sweep_f64_variant" tiling of the 32-column fp64 pass: 0 (default) = 256 columns / 512 threads, one workgroup per CU; 1, 2 = 128 / 256, two or three
+ *   "solo_full_gram" tests: 1 = the speculative form may run with G = A^T A as its cache too (default 0: it does not — gathers of scattered entries)
+ *   "early_probe"    developer aid: 1 = the early form without overlap (the passes first, then the speculative launch)
+ *   "pass_dbg_ptr"   developer aid: a device buffer (1 + 4 x 4096 u64) that receives a per-workgroup trace of the early form's passes (tools/probe_pass_trace.py)
  *   "colshard_fail_prepare" test aid: 1 = the next column-sharded solve fails on this rank while it prepares (the ranks must all leave)
  *   "ro_slots"       1..8 (default 8; fp64 contexts use at most 4): signals the reference-order engine runs in lock-step per pass over A (batches in
  *                    engine 3, a batch's tie re-runs); every signal's words are those of its own solve

@@ -114,3 +114,17 @@ def test_no_null_stream_memset_in_the_device_sources():
         for m in re.finditer(r"\bhipMemset(2D|3D)?\s*\(", text):
             bad.append("%s:%d" % (name, text.count("\n", 0, m.start()) + 1))
     assert not bad, "blocking hipMemset on the null stream: %s" % ", ".join(bad)
+
+
+def test_every_option_key_is_documented_in_the_header():
+    """ss_hip_set_option accepts a key iff include/ss_hip.h says what it does: the keys of the dispatcher in csrc/homotopy.hip
+    (strcmp(key, "...")) must all appear, quoted, in the header's option list."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "sparse-solvers_amd", "csrc", "homotopy.hip")).read()
+    body = src[src.index("int ss_hip_set_option"):src.index("int ss_hip_get_option")]
+    keys = sorted(set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', body)))
+    hdr = open(os.path.join(root, "include", "ss_hip.h")).read()
+    assert len(keys) >= 40
+    missing = [k for k in keys if ('"%s"' % k) not in hdr]
+    assert not missing, "options without a line in include/ss_hip.h: %s" % missing
