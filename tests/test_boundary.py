@@ -128,3 +128,22 @@ def test_every_option_key_is_documented_in_the_header():
     assert len(keys) >= 40
     missing = [k for k in keys if ('"%s"' % k) not in hdr]
     assert not missing, "options without a line in include/ss_hip.h: %s" % missing
+
+
+def test_python_mirror_of_the_statistics_struct_matches_the_header():
+    """sship.Stats (ctypes) mirrors struct ss_hip_stats field by field, in order and in type: a field added to the header only would make
+    ss_hip_get_stats write past the Python object."""
+    import ctypes
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "sparse-solvers_amd", "python"))
+    import sship
+    hdr = open(os.path.join(root, "include", "ss_hip.h")).read()
+    body = hdr[hdr.index("typedef struct ss_hip_stats"):hdr.index("} ss_hip_stats;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(uint64_t|double|uint32_t|float)\s+([a-z0-9_]+)\s*;", body)
+    ctype = {"uint64_t": ctypes.c_uint64, "double": ctypes.c_double, "uint32_t": ctypes.c_uint32, "float": ctypes.c_float}
+    assert len(fields) >= 40
+    mirror = [(n, t) for n, t in sship.Stats._fields_]
+    assert [n for _, n in fields] == [n for n, _ in mirror]
+    assert [ctype[t] for t, _ in fields] == [t for _, t in mirror]
